@@ -1,0 +1,113 @@
+"""Synthetic KITTI-shaped optical-flow features (SURVEY.md §8d generator spec).
+
+The reference ships no feature dumps (only image path lists with absolute paths,
+/root/reference/dataset/kitti_image_00.txt), so every measured configuration runs on
+synthetic frames that have the shape the reference's drivers hand to
+``ScaleEstimator.scale_calculation``: ``feature3d`` (N,3) float64 camera-frame points up
+to scale and ``feature2d`` (N,2) float64 pixel coordinates, produced the way
+/root/reference/src/main.py:102-106 produces them (pinhole re-projection with one focal
+length for both axes).  Camera constants are KITTI-00's, /root/reference/src/param.py:30-36.
+
+Everything is seeded per frame (``default_rng(base_seed + frame_idx)``) so that a fixture
+can store outputs only and regenerate the inputs (a checksum of the inputs travels with
+the fixture to detect RNG drift).
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+
+# KITTI-00 intrinsics, /root/reference/src/param.py:30-35
+IMG_W = 1241.0
+IMG_H = 376.0
+FX = 718.856
+CX = 607.1928
+CY = 185.2157
+
+
+def synth_frame(frame_idx: int, n_features: int = 2000, base_seed: int = 1234,
+                sigma: float | None = None, h_cam: float | None = None,
+                v_min: float = 186.0, upper_fraction: float = 0.0):
+    """One frame of KITTI-shaped features.
+
+    Returns ``(feature3d (N,3) f64, feature2d (N,2) f64)``.
+
+    * ``u ~ U(0, IMG_W)``, ``v ~ U(v_min, IMG_H)``; with ``v_min=186`` every feature passes
+      the reference's ``v > vanish(185)`` filter (/root/reference/src/scale_calculator.py:252)
+      so N features give ~2N triangles.  ``upper_fraction`` > 0 places that share of the
+      features above the vanishing row (they must be dropped by the filter).
+    * features inside the road trapezoid ``|u-cx| < 250 + 2 (v-cy)`` lie on the ground plane
+      at camera height ``h_cam`` (VO units): ``z = h fx / max(v-cy, 1)``; the others are
+      obstacles above the ground: ``z = min(U(5,60), z_ground)``.
+    * multiplicative depth noise ``z *= 1 + sigma N(0,1)``.
+    """
+    rng = np.random.default_rng(base_seed + frame_idx)
+    if h_cam is None:
+        h_cam = 0.6 + 0.4 * ((frame_idx * 0.6180339887498949) % 1.0)
+    if sigma is None:
+        sigma = 0.01 + 0.01 * ((frame_idx * 0.7548776662466927) % 1.0)
+    u = rng.uniform(0.0, IMG_W, n_features)
+    v = rng.uniform(v_min, IMG_H, n_features)
+    if upper_fraction > 0.0:
+        up = rng.uniform(0.0, 1.0, n_features) < upper_fraction
+        v = np.where(up, rng.uniform(0.0, 185.0, n_features), v)
+    dv = np.maximum(v - CY, 1.0)
+    z_ground = h_cam * FX / dv
+    on_road = np.abs(u - CX) < 250.0 + 2.0 * (v - CY)
+    z_obst = np.minimum(rng.uniform(5.0, 60.0, n_features), z_ground)
+    z = np.where(on_road & (v > CY), z_ground, z_obst)
+    z = z * (1.0 + sigma * rng.standard_normal(n_features))
+    z = np.maximum(z, 0.2)
+    x = (u - CX) * z / FX
+    y = (v - CY) * z / FX
+    feature3d = np.stack([x, y, z], axis=1).astype(np.float64)
+    feature2d = np.stack([u, v], axis=1).astype(np.float64)
+    return feature3d, feature2d
+
+
+def synth_sequence_dict(n_frames: int, base_seed: int = 77, n_lo: int = 300, n_hi: int = 1500,
+                        p_not_moving: float = 0.01, p_too_few: float = 0.01,
+                        fixed_n: int | None = None):
+    """A dict with the schema /root/reference/src/main.py:149-154 saves and
+    /root/reference/src/main_offline.py:52-55 replays: ``motions`` (12-vectors),
+    ``move_flags``, ``feature2ds``, ``feature3ds`` (``[]`` for non-moving frames,
+    /root/reference/src/main.py:94-95).  A few frames are non-moving and a few carry
+    <= 100 features so both caller gates (/root/reference/src/main_offline.py:64,73)
+    are exercised.
+    """
+    rng = np.random.default_rng(base_seed)
+    motions, move_flags, f2, f3 = [], [], [], []
+    for i in range(n_frames):
+        r = rng.uniform()
+        if i > 1 and r < p_not_moving:
+            motions.append(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float64))
+            move_flags.append(False)
+            f2.append([])
+            f3.append([])
+            continue
+        if r > 1.0 - p_too_few:
+            n = int(rng.integers(20, 101))
+        elif fixed_n is not None:
+            n = fixed_n
+        else:
+            n = int(rng.integers(n_lo, n_hi + 1))
+        a3, a2 = synth_frame(i, n, base_seed=base_seed * 1000003, upper_fraction=0.15)
+        t = rng.normal(0.0, 0.02, 3)
+        t[2] = 1.0
+        t /= np.linalg.norm(t)
+        m = np.eye(3, 4)
+        m[:, 3] = t
+        motions.append(m.reshape(-1))
+        move_flags.append(True)
+        f2.append(a2)
+        f3.append(a3)
+    return {"motions": motions, "move_flags": move_flags, "feature2ds": f2, "feature3ds": f3}
+
+
+def checksum(*arrays) -> int:
+    """CRC32 over the raw bytes of the arrays (detects RNG drift in regenerated inputs)."""
+    c = 0
+    for a in arrays:
+        c = zlib.crc32(np.ascontiguousarray(a).tobytes(), c)
+    return c

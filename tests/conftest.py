@@ -1,0 +1,50 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+def load_json(name):
+    with open(os.path.join(GOLDEN, name)) as fh:
+        return json.load(fh)
+
+
+def load_npz(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    meta = json.loads(str(z["meta"])) if "meta" in z.files else {}
+    return z, meta
+
+
+@pytest.fixture(scope="session")
+def stages():
+    """Per-stage goldens of the reference (tests/golden/make_golden.py: make_stages): a list of
+    dicts, one per frame, inputs regenerated from the seeds and checked against the stored CRC."""
+    from mvoscalerecovery_amd import synth
+    z, meta = load_npz("stages.npz")
+    frames = []
+    for k, fr in enumerate(meta["frames"]):
+        f3, f2 = synth.synth_frame(fr["frame_idx"], fr["n"], base_seed=fr["seed"],
+                                   upper_fraction=fr["upper_fraction"])
+        assert synth.checksum(f3, f2) == fr["crc"], "synthetic generator drifted from the fixture"
+        d = {"f3": f3, "f2": f2, "per_triangle": fr["per_triangle"], "abs_ref": meta["abs_ref"]}
+        pre = "f%d_" % k
+        for name in z.files:
+            if name.startswith(pre):
+                d[name[len(pre):]] = z[name]
+        d["tri1"] = d["tri1"].astype(np.int32)
+        d["tri2"] = d["tri2"].astype(np.int32)
+        frames.append(d)
+    return frames
