@@ -1,0 +1,213 @@
+/*
+ * mvosr.h — C ABI of libmvosr.so: MI355X (gfx950) kernels for the per-frame scale-recovery hot
+ * path of TimingSpace/MVOScaleRecovery.
+ *
+ * The reference is pure Python and has no FFI/plugin registry: the drop-in boundary is the
+ * Python class `ScaleEstimator` chosen by an import line (/root/reference/src/main.py:18-20,
+ * /root/reference/src/main_offline.py:18-20).  mvoscalerecovery_amd/scale_calculator.py keeps
+ * that class surface and binds the entry points below with ctypes (see INTEGRATION.md for the
+ * stub).  Each entry point cites the reference routine whose per-frame work it replaces; all of
+ * them process a BATCH of independent frames, one workgroup (or one wavefront for small
+ * frames) per frame.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer inside mvosr_batch / mvosr_outputs is a DEVICE
+ *     pointer (hipMalloc'ed by mvosr_malloc, or e.g. torch.Tensor.data_ptr()); the structs
+ *     themselves live in host memory and are read during the call;
+ *   - every function returns 0 on success, a negative mvosr_err on failure, never throws;
+ *     mvosr_last_error() returns a thread-local message;
+ *   - launches are asynchronous on the context's HIP stream; call mvosr_ctx_sync() (or
+ *     synchronise the adopted stream yourself) before reading outputs;
+ *   - all floating-point data is IEEE binary64 (the reference computes in NumPy float64 and
+ *     its result is a quantised histogram mode, so threshold decisions must match bit-for-bit:
+ *     SURVEY.md fact 5); triangle vertex ids are int32 exactly as scipy.spatial.Delaunay
+ *     emits `simplices` (row-major (T,3); the order of vertices inside a row matters,
+ *     /root/reference/src/scale_calculator.py:113-115).
+ */
+#ifndef MVOSR_H
+#define MVOSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVOSR_ABI_VERSION 1
+
+/* error codes (function return values) */
+enum mvosr_err {
+    MVOSR_OK = 0,
+    MVOSR_ERR_HIP = -1,          /* a HIP runtime call failed (message has hipGetErrorString) */
+    MVOSR_ERR_ARG = -2,          /* bad argument (null pointer, negative size, ...) */
+    MVOSR_ERR_TOO_LARGE = -3,    /* a frame does not fit the requested kernel variant */
+    MVOSR_ERR_NO_DEVICE = -4     /* no gfx950 device visible */
+};
+
+/* per-frame status codes written to mvosr_outputs.status.  0-3 are the reference's normal
+ * return branches, 4 its "no enough flat feature" fallback, 5-7 the places where the reference
+ * raises; the Python shim maps them back to return-or-raise. */
+enum mvosr_status {
+    MVOSR_ST_MODE = 0,          /* height = mode/10               scale_calculator.py:354     */
+    MVOSR_ST_RIGHT = 1,         /* skew > 0.3: right minimum edge scale_calculator.py:348-352 */
+    MVOSR_ST_MEDIAN = 2,        /* no modes: median(y)            scale_calculator.py:331-333 */
+    MVOSR_ST_LEVEL = 3,         /* no modes, no points: height_level          :334-335        */
+    MVOSR_ST_NO_FLAT = 4,       /* selection empty: scale = ref/height_level  :277-279,:420-422 */
+    MVOSR_ST_ERR_LEFT = 5,      /* IndexError at scale_calculator.py:343 */
+    MVOSR_ST_ERR_RIGHT = 6,     /* IndexError at scale_calculator.py:344 */
+    MVOSR_ST_ERR_SINGULAR = 7,  /* LinAlgError at scale_calculator.py:229 */
+    MVOSR_ST_ERR_MASK = 8,      /* tri2 inconsistent with the vote computed on the GPU, or a
+                                   vertex id out of range (build-side check, no reference analogue) */
+    MVOSR_ST_ERR_EMPTY = 9      /* frame without features/triangles (build-side check) */
+};
+
+/* number of int32 per frame in mvosr_outputs.counts */
+#define MVOSR_N_COUNTS 8
+enum mvosr_count_slot {
+    MVOSR_CNT_VALID = 0,        /* features with vote counter >= 0            (:164-166) */
+    MVOSR_CNT_TRI_PITCH = 1,    /* triangles with pitch_deg < -80             (:235)     */
+    MVOSR_CNT_TRI_VALID = 2,    /* ... and mean height > height_level         (:243-244) */
+    MVOSR_CNT_SELECTED = 3,     /* unique vertices of those triangles         (:247)     */
+    MVOSR_CNT_KEPT = 4,         /* selected points left after remove_single   (:284-293) */
+    MVOSR_CNT_MODES = 5,        /* number of mode clusters                    (:468-481) */
+    MVOSR_CNT_MODE_LEFT = 6,    /* mode_left  (:339), -1 if none */
+    MVOSR_CNT_MODE_RIGHT = 7    /* mode_right (:338), -1 if none */
+};
+
+#define MVOSR_HIST_BINS 169     /* np.histogram(y, bins=arange(170)*0.1)      (:326) */
+
+typedef struct mvosr_ctx mvosr_ctx;
+
+/* Scalars of the path.  cos/sin are passed (not the angle) so that the kernels use the very
+ * doubles NumPy produced on the host (scale_calculator.py:391-392). */
+typedef struct mvosr_params {
+    double cos_pitch;            /* np.cos(camera_pitch), camera_pitch = -0.5*pi/180 (:24) */
+    double sin_pitch;            /* np.sin(camera_pitch) */
+    double absolute_reference;   /* real camera height, param.camera_h (main.py:55) */
+    double pitch_threshold_deg;  /* -80 (:235,:239) */
+    double skew_threshold;       /* 0.3 (:348) */
+    double mode_rel;             /* 0.33 (:461) */
+    int32_t mode_min;            /* 2 (:451,:462) */
+    int32_t reserved;
+} mvosr_params;
+
+/* A packed batch of F frames, resident in HBM.  Features are those that passed the
+ * vanishing-row filter (:252-254), stored as planes (structure of arrays) with the frames'
+ * segments back to back; segment starts are even (16-byte aligned doubles).  x/y/z are the
+ * caller's raw feature3d columns — feature_remap (:390-394) is applied by the kernels at load. */
+typedef struct mvosr_batch {
+    int64_t n_frames;
+    const int64_t *feat_off;     /* [F]   start of frame f in x/y/z/v (multiple of 2)          */
+    const int32_t *feat_cnt;     /* [F]   number of features of frame f                        */
+    const double *x, *y, *z;     /* feature3d[:,0..2] before the remap                         */
+    const double *v;             /* feature2d[:,1]  (pixel row; u is never read by the path)   */
+    const int64_t *tri1_off;     /* [F+1] triangle offsets of the first triangulation          */
+    const int32_t *tri1;         /* [tri1_off[F]*3] Delaunay(feature2d).simplices  (:257-258)  */
+    const int64_t *tri2_off;     /* [F+1] triangle offsets of the second triangulation         */
+    const int32_t *tri2;         /* [tri2_off[F]*3] Delaunay(feature2d[valid]).simplices (:266-267);
+                                    ids index the features that survive the vote, in order     */
+    const int32_t *n2_expected;  /* [F] or NULL: number of points tri2 was built on; a frame whose
+                                    vote keeps a different number gets MVOSR_ST_ERR_MASK        */
+    int32_t max_feat;            /* max(feat_cnt) — sizes the LDS request                      */
+    int32_t reserved;
+} mvosr_batch;
+
+/* Outputs (device pointers; any optional pointer may be NULL). */
+typedef struct mvosr_outputs {
+    double *raw_scale;           /* [F] absolute_reference/height, before the window median (:419,:421) */
+    double *height;              /* [F] camera height over the road in VO units (:418)          */
+    double *height_level;        /* [F] mean height of the non-flat triangles (:239-241)        */
+    int32_t *status;             /* [F] enum mvosr_status                                      */
+    int32_t *counts;             /* [F*MVOSR_N_COUNTS] or NULL                                 */
+    /* stage-level outputs for parity tests / the per-frame drop-in call; all optional */
+    int32_t *vote_counters;      /* [sum feat_cnt, laid out like x] per-feature counters (:153-163) */
+    uint8_t *selected;           /* [like x] 1 where the k-th SURVIVING feature of the frame is selected (:247) */
+    double *tri_normals;         /* [tri2_off[F]*3] n = A^-1 . 1  (:229-230)                   */
+    double *tri_pitch_deg;       /* [tri2_off[F]]   asin(-n_y/|n|)*180/pi (:233)               */
+    double *tri_heights;         /* [tri2_off[F]]   mean y of the 3 vertices (:238)            */
+    int32_t *hist;               /* [F*2*MVOSR_HIST_BINS] histogram before / after zeroing single bins (:326,:328) */
+    double *stats;               /* [F*4] mean, std, skew, median-or-nan of the kept points (:346,:496) */
+} mvosr_outputs;
+
+/* ---- library / context ------------------------------------------------------------------ */
+int mvosr_abi_version(void);
+const char *mvosr_last_error(void);
+int mvosr_device_count(void);
+
+/* One context = one device + one HIP stream + a small workspace. */
+int mvosr_ctx_create(int device, mvosr_ctx **out);
+int mvosr_ctx_destroy(mvosr_ctx *ctx);
+/* Adopt an external stream (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the
+ * context's own stream. */
+int mvosr_ctx_set_stream(mvosr_ctx *ctx, void *hip_stream);
+void *mvosr_ctx_stream(mvosr_ctx *ctx);
+int mvosr_ctx_sync(mvosr_ctx *ctx);
+/* Device facts for the host (name, CU count, LDS per workgroup). */
+int mvosr_ctx_device_info(mvosr_ctx *ctx, char *name, int name_len, int *n_cu, int *lds_per_block);
+
+/* ---- device memory / events (so that a ctypes-only host needs no other GPU library) ------ */
+int mvosr_malloc(mvosr_ctx *ctx, size_t bytes, void **dptr);
+int mvosr_free(mvosr_ctx *ctx, void *dptr);
+int mvosr_memcpy_h2d(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);   /* stream-ordered, returns after the copy */
+int mvosr_memcpy_d2h(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);   /* stream-ordered, returns after the copy */
+int mvosr_memset(mvosr_ctx *ctx, void *dst, int value, size_t bytes);
+int mvosr_event_create(mvosr_ctx *ctx, void **event);
+int mvosr_event_record(mvosr_ctx *ctx, void *event);          /* on the context's current stream */
+int mvosr_event_elapsed_ms(mvosr_ctx *ctx, void *start, void *stop, float *ms);  /* synchronises on `stop` */
+int mvosr_event_destroy(mvosr_ctx *ctx, void *event);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+void mvosr_default_params(mvosr_params *p, double absolute_reference);
+
+/*
+ * Fused per-frame scale recovery: replaces, for every frame of the batch, the body of
+ * ScaleEstimator.scale_calculation (scale_calculator.py:411-422) between the two host
+ * Delaunay calls and the window median:
+ *   feature_remap (:390-394) -> find_outliers/check_triangle on tri1 (:151-167,:105-119)
+ *   -> compaction of the survivors (:264-265) -> feature_selection_by_tri on tri2 (:225-248)
+ *   -> road_model_calculation_static (:324-354) -> raw scale (:419/:421).
+ * `waves_per_frame` selects the variant: 0 = choose from max_feat, 1 = one wavefront per
+ * frame, 4/8/16 = one workgroup of that many wavefronts per frame.
+ * `first_frame`/`n_launch` restrict the launch to a sub-range of the batch (n_launch <= 0: all).
+ */
+int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b,
+                      const mvosr_outputs *o, int waves_per_frame,
+                      int64_t first_frame, int64_t n_launch);
+
+/*
+ * Stage K1 alone: find_outliers (scale_calculator.py:151-167) for every frame; writes
+ * o->vote_counters (required) and counts[MVOSR_CNT_VALID] (optional).  Used by the per-frame
+ * drop-in call and by the batch path when the second triangulation still has to be built on
+ * the host from the surviving features.  Only b->feat_*, y, z, v, tri1* are read.
+ */
+int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b,
+                             const mvosr_outputs *o, int waves_per_frame);
+
+/*
+ * Stage K3 alone: road_model_calculation_static (scale_calculator.py:324-354) on packed
+ * lists of already-remapped y values (feat_off/feat_cnt/y of `b`; nothing else is read);
+ * `height_level_in` [F] supplies the fallback level (:335).  Writes height, status and the
+ * optional counts/hist/stats; raw_scale = absolute_reference/height.
+ */
+int mvosr_road_model_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b,
+                           const double *height_level_in, const mvosr_outputs *o,
+                           int waves_per_frame);
+
+/*
+ * K4: scale_filtering (scale_calculator.py:396-400) over a whole sequence: out[i] = median of
+ * the last `window` pushed raw scales, the deque pre-loaded with `queue_in[0..n_queue)`.
+ * raw/out are device pointers of n doubles; queue_in is a HOST pointer (n_queue <= window).
+ */
+int mvosr_window_median(mvosr_ctx *ctx, const double *raw, int64_t n, int window,
+                        const double *queue_in, int n_queue, double *out);
+
+/* LDS bytes the fused kernel requests for a frame of n features (host-side planning). */
+size_t mvosr_lds_bytes(int n_features);
+/* Largest frame the LDS-resident variant accepts on this build. */
+int mvosr_max_lds_features(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVOSR_H */

@@ -1,0 +1,204 @@
+"""ctypes binding of libmvosr.so (C ABI: include/mvosr.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded every product entry
+point raises :class:`MvosrLibraryError`.  The library is built in-tree by
+``__graft_entry__.build()`` / ``make -C mvoscalerecovery_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")
+ABI_VERSION = 1
+N_COUNTS = 8
+HIST_BINS = 169
+
+
+class MvosrLibraryError(RuntimeError):
+    """libmvosr.so is missing / not loadable / a call into it failed."""
+
+
+class Params(C.Structure):
+    _fields_ = [("cos_pitch", C.c_double), ("sin_pitch", C.c_double), ("absolute_reference", C.c_double),
+                ("pitch_threshold_deg", C.c_double), ("skew_threshold", C.c_double), ("mode_rel", C.c_double),
+                ("mode_min", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_frames", C.c_int64), ("feat_off", C.c_void_p), ("feat_cnt", C.c_void_p),
+                ("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("v", C.c_void_p),
+                ("tri1_off", C.c_void_p), ("tri1", C.c_void_p), ("tri2_off", C.c_void_p), ("tri2", C.c_void_p),
+                ("n2_expected", C.c_void_p), ("max_feat", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("raw_scale", C.c_void_p), ("height", C.c_void_p), ("height_level", C.c_void_p),
+                ("status", C.c_void_p), ("counts", C.c_void_p), ("vote_counters", C.c_void_p),
+                ("selected", C.c_void_p), ("tri_normals", C.c_void_p), ("tri_pitch_deg", C.c_void_p),
+                ("tri_heights", C.c_void_p), ("hist", C.c_void_p), ("stats", C.c_void_p)]
+
+
+# every symbol include/mvosr.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "mvosr_abi_version": (C.c_int, []),
+    "mvosr_last_error": (C.c_char_p, []),
+    "mvosr_device_count": (C.c_int, []),
+    "mvosr_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "mvosr_ctx_destroy": (C.c_int, [_P]),
+    "mvosr_ctx_set_stream": (C.c_int, [_P, _P]),
+    "mvosr_ctx_stream": (_P, [_P]),
+    "mvosr_ctx_sync": (C.c_int, [_P]),
+    "mvosr_ctx_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mvosr_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "mvosr_free": (C.c_int, [_P, _P]),
+    "mvosr_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "mvosr_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "mvosr_memset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),
+    "mvosr_event_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "mvosr_event_record": (C.c_int, [_P, _P]),
+    "mvosr_event_elapsed_ms": (C.c_int, [_P, _P, _P, C.POINTER(C.c_float)]),
+    "mvosr_event_destroy": (C.c_int, [_P, _P]),
+    "mvosr_default_params": (None, [C.POINTER(Params), C.c_double]),
+    "mvosr_scale_batch": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Batch), C.POINTER(Outputs), C.c_int,
+                                    C.c_int64, C.c_int64]),
+    "mvosr_outlier_vote_batch": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Batch), C.POINTER(Outputs), C.c_int]),
+    "mvosr_road_model_batch": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Batch), _P, C.POINTER(Outputs), C.c_int]),
+    "mvosr_window_median": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, _P]),
+    "mvosr_lds_bytes": (C.c_size_t, [C.c_int]),
+    "mvosr_max_lds_features": (C.c_int, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmvosr.so once and set prototypes.  Raises if it is not there — loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise MvosrLibraryError(
+            "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C mvoscalerecovery_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise MvosrLibraryError("cannot load %s: %s" % (LIB_PATH, exc)) from exc
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise MvosrLibraryError("libmvosr.so lacks symbol %s" % name) from exc
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mvosr_abi_version() != ABI_VERSION:
+        raise MvosrLibraryError("libmvosr.so ABI %d != binding ABI %d" % (lib.mvosr_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mvosr_last_error()
+        raise MvosrLibraryError("%s failed (%d): %s" % (what or "libmvosr call", rc, (msg or b"").decode()))
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed array with NumPy dtype/shape metadata."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(ctx.lib.mvosr_malloc(ctx.handle, max(self.nbytes, 16), C.byref(p)), "mvosr_malloc")
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert arr.nbytes == self.nbytes, (arr.shape, self.shape)
+        check(self.ctx.lib.mvosr_memcpy_h2d(self.ctx.handle, self.ptr, arr.ctypes.data, self.nbytes), "h2d")
+        return self
+
+    def download(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(self.ctx.lib.mvosr_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes), "d2h")
+        return out
+
+    def fill(self, byte=0):
+        check(self.ctx.lib.mvosr_memset(self.ctx.handle, self.ptr, byte, self.nbytes), "memset")
+        return self
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.mvosr_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One device + one HIP stream (mvosr_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        check(self.lib.mvosr_ctx_create(int(device), C.byref(h)), "mvosr_ctx_create")
+        self.handle = h
+        self.device = int(device)
+        name = C.create_string_buffer(128)
+        ncu, lds = C.c_int(), C.c_int()
+        check(self.lib.mvosr_ctx_device_info(self.handle, name, 128, C.byref(ncu), C.byref(lds)))
+        self.name, self.n_cu, self.lds_per_block = name.value.decode(), ncu.value, lds.value
+
+    def to_device(self, arr, dtype=None):
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        return DeviceBuffer(self, arr.shape, arr.dtype).upload(arr)
+
+    def empty(self, shape, dtype):
+        return DeviceBuffer(self, shape, dtype)
+
+    def zeros(self, shape, dtype):
+        return DeviceBuffer(self, shape, dtype).fill(0)
+
+    def sync(self):
+        check(self.lib.mvosr_ctx_sync(self.handle), "mvosr_ctx_sync")
+
+    def set_stream(self, stream_ptr):
+        check(self.lib.mvosr_ctx_set_stream(self.handle, C.c_void_p(stream_ptr)), "mvosr_ctx_set_stream")
+
+    def event(self):
+        ev = C.c_void_p()
+        check(self.lib.mvosr_event_create(self.handle, C.byref(ev)), "event_create")
+        return ev
+
+    def record(self, ev):
+        check(self.lib.mvosr_event_record(self.handle, ev), "event_record")
+
+    def elapsed_ms(self, start, stop):
+        ms = C.c_float()
+        check(self.lib.mvosr_event_elapsed_ms(self.handle, start, stop, C.byref(ms)), "event_elapsed")
+        return float(ms.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mvosr_ctx_destroy(self.handle)
+            self.handle = None
+
+
+_contexts = {}
+
+
+def default_context(device=0):
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]

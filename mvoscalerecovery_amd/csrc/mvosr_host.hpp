@@ -1,0 +1,27 @@
+// mvosr_host.hpp — host-side plumbing shared by the C-ABI translation units: context object,
+// thread-local error message, HIP error mapping.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/mvosr.h"
+
+struct mvosr_ctx {
+    int device;
+    hipStream_t own_stream;
+    hipStream_t stream;        // own_stream, or an adopted external stream
+    int n_cu;
+    int max_lds_per_block;
+    char name[128];
+};
+
+namespace mvosr {
+
+int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int set_hip_error(const char *what, hipError_t e);
+int check_launch(const char *kernel);
+int ctx_activate(mvosr_ctx *ctx);                 // hipSetDevice(ctx->device)
+inline hipStream_t ctx_stream(mvosr_ctx *ctx) { return ctx->stream; }
+void set_max_dynamic_lds(int bytes);
+
+}  // namespace mvosr

@@ -1,0 +1,796 @@
+// mvosr_kernels.hip — HIP kernels (CDNA4 / gfx950) for the per-frame scale-recovery hot path and
+// the C-ABI launchers declared in include/mvosr.h.
+//
+// One frame = one workgroup of WAVES wavefronts (WAVES = 1 for small frames: one frame per
+// wavefront).  A frame's features are staged once from HBM into LDS as fp64 planes and every
+// per-triangle gather of the three stages is served from LDS:
+//
+//   phase A  load v, remapped y', z'            (feature_remap, scale_calculator.py:390-394)
+//            vote over tri1 with LDS atomics    (find_outliers/check_triangle, :151-167,:105-119)
+//            ballot prefix-sum compaction map   (feature2d[valid], :264-265)
+//   phase B  load x over v; per-triangle plane normal, pitch test, mean height over tri2;
+//            block reduction -> height_level; second sweep marks the selected vertices in an
+//            LDS bit-set                         (feature_selection_by_tri, :225-248)
+//   phase C  169-bin LDS histogram of the selected y', remove_single, mode / local-minimum
+//            logic on 64-bit ballots, mean/std/skew, median fallback
+//                                                (road_model_calculation_static, :324-354)
+//
+// LDS per frame: 26 B per feature (x|v, y', z' as fp64 + a 16-bit word that is the vote counter
+// in phase A and the compaction map afterwards) + ~1.5 KB -> 53.5 KB at N=2000, three
+// workgroups per CU.  HBM traffic per frame = the inputs once (x,y,z,v + tri1 + tri2) and
+// 28 B of results.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/mvosr.h"
+#include "mvosr_device.hpp"
+#include "mvosr_host.hpp"
+
+namespace mvosr {
+
+// ---------------------------------------------------------------------------------------------
+// LDS carve-up (byte offsets, all multiples of 16)
+// ---------------------------------------------------------------------------------------------
+struct LdsPlan {
+    uint32_t x, y, z, cm, sel, hist, red, misc, total;
+};
+__host__ __device__ inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+__host__ __device__ inline LdsPlan lds_plan(int n) {
+    LdsPlan p;
+    const uint32_t npad = (uint32_t)((n + 1) & ~1);
+    p.x = 0;
+    p.y = p.x + 8u * npad;
+    p.z = p.y + 8u * npad;
+    p.cm = p.z + 8u * npad;                       // 16-bit counter / map per feature
+    p.sel = align16(p.cm + 2u * npad);            // selected bit-set, one bit per surviving feature
+    p.hist = align16(p.sel + 4u * ((uint32_t)(n + 31) / 32u));
+    p.red = p.hist + 4u * 192u;                   // 169 bins (+pad)
+    p.misc = p.red + 8u * 64u;                    // reduction scratch: 64 doubles
+    p.total = p.misc + 4u * 32u;                  // 32 ints of per-frame scalars
+    return p;
+}
+
+struct Smem {
+    double *X, *Y, *Z;
+    uint16_t *cm;
+    uint32_t *cm32;
+    uint32_t *sel;
+    int *hist;
+    double *red;
+    int *misc;
+};
+__device__ __forceinline__ Smem carve(char *base, int n) {
+    const LdsPlan p = lds_plan(n);
+    Smem s;
+    s.X = reinterpret_cast<double *>(base + p.x);
+    s.Y = reinterpret_cast<double *>(base + p.y);
+    s.Z = reinterpret_cast<double *>(base + p.z);
+    s.cm = reinterpret_cast<uint16_t *>(base + p.cm);
+    s.cm32 = reinterpret_cast<uint32_t *>(base + p.cm);
+    s.sel = reinterpret_cast<uint32_t *>(base + p.sel);
+    s.hist = reinterpret_cast<int *>(base + p.hist);
+    s.red = reinterpret_cast<double *>(base + p.red);
+    s.misc = reinterpret_cast<int *>(base + p.misc);
+    return s;
+}
+
+// misc[] slots
+enum { M_WCNT = 0 /* [0..15] per-wave survivor counts */, M_LIST = 16, M_MEDLO = 18, M_MEDHI = 20 /* doubles at 18..21 */ };
+
+struct TriIds { int a, b, c; };
+__device__ __forceinline__ TriIds load_tri(const int32_t *tri, int64_t t) {
+    const int32_t *p = tri + 3 * t;
+    TriIds r;
+    r.a = p[0]; r.b = p[1]; r.c = p[2];
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase A: stage v, y', z' and run the depth-order vote over the first triangulation.
+// On return (after the trailing barrier) cm[j] = index of the j-th surviving feature and the
+// return value is the number of survivors.  `bad` is set when a vertex id is out of range.
+// ---------------------------------------------------------------------------------------------
+template <int WAVES>
+__device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gy, const double *gz, const double *gv,
+                                          const int32_t *tri1, int64_t t1_begin, int t1_count, double cp, double sp,
+                                          int32_t *g_counters, int &bad) {
+    constexpr int B = WAVES * kWave;
+    const int tid = threadIdx.x;
+    const int npad2 = (n + 1) >> 1;
+    // planes are 16-byte aligned per frame: two features per lane and load
+    const double2 *gy2 = reinterpret_cast<const double2 *>(gy);
+    const double2 *gz2 = reinterpret_cast<const double2 *>(gz);
+    const double2 *gv2 = reinterpret_cast<const double2 *>(gv);
+    double2 *sY2 = reinterpret_cast<double2 *>(s.Y);
+    double2 *sZ2 = reinterpret_cast<double2 *>(s.Z);
+    double2 *sX2 = reinterpret_cast<double2 *>(s.X);
+    for (int i = tid; i < npad2; i += B) {
+        const double2 yy = gy2[i], zz = gz2[i], vv = gv2[i];
+        double2 yr, zr;
+        yr.x = yy.x * cp - zz.x * sp;  yr.y = yy.y * cp - zz.y * sp;      // :391
+        zr.x = yy.x * sp + zz.x * cp;  zr.y = yy.y * sp + zz.y * cp;      // :392
+        sY2[i] = yr; sZ2[i] = zr; sX2[i] = vv;
+        s.cm32[i] = ((uint32_t)(kCounterBias + 1) << 16) | (uint32_t)(kCounterBias + 1);   // np.ones, :153
+    }
+    __syncthreads();
+
+    // the vote: +1 on a vertex the triangle does not flag, -1 on one it flags (:160-163)
+    for (int t = tid; t < t1_count; t += B) {
+        const TriIds q = load_tri(tri1, t1_begin + t);
+        if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
+        const double v0 = s.X[q.a], v1 = s.X[q.b], v2 = s.X[q.c];
+        const double d0 = s.Z[q.a], d1 = s.Z[q.b], d2 = s.Z[q.c];
+        const bool pa = (v0 - v1) * (d0 - d1) > 0.0;       // :107,:110
+        const bool pb = (v0 - v2) * (d0 - d2) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
+        const bool pc = (v1 - v2) * (d1 - d2) > 0.0;       // :109,:116
+        const bool f0 = pa | pb, f1 = pa | pb | pc, f2 = pc;
+        const uint32_t u0 = 1u << ((q.a & 1) * 16), u1 = 1u << ((q.b & 1) * 16), u2 = 1u << ((q.c & 1) * 16);
+        if (f0) atomicSub(&s.cm32[q.a >> 1], u0); else atomicAdd(&s.cm32[q.a >> 1], u0);
+        if (f1) atomicSub(&s.cm32[q.b >> 1], u1); else atomicAdd(&s.cm32[q.b >> 1], u1);
+        if (f2) atomicSub(&s.cm32[q.c >> 1], u2); else atomicAdd(&s.cm32[q.c >> 1], u2);
+    }
+    __syncthreads();
+
+    // compaction: every wave owns a contiguous slice of the features; survivors keep their order
+    const int w = wave_id(), lane = lane_id();
+    const int per = ((n + WAVES * kWave - 1) / (WAVES * kWave)) * kWave;     // slice length, multiple of 64
+    const int begin = w * per;
+    const int end = min(n, begin + per);
+    unsigned long long mine = 0ull;              // bit k: my feature of sub-chunk k survives
+    int cnt = 0;
+    for (int k = 0, i0 = begin; i0 < end; i0 += kWave, ++k) {
+        const int i = i0 + lane;
+        bool keep = false;
+        if (i < end) {
+            const int c = (int)s.cm[i] - kCounterBias;
+            keep = c >= 0;                                                    // :166
+            if (g_counters) g_counters[i] = c;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) mine |= 1ull << k;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) s.misc[M_WCNT + w] = cnt;
+    __syncthreads();                             // all counters consumed: cm may now hold the map
+    int base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) { const int c = s.misc[M_WCNT + i]; if (i < w) base += c; total += c; }
+    for (int k = 0, i0 = begin; i0 < end; i0 += kWave, ++k) {
+        const bool keep = (mine >> k) & 1ull;
+        const unsigned long long m = __ballot(keep);
+        if (keep) s.cm[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(i0 + lane);
+        base += __popcll(m);
+    }
+    __syncthreads();
+    return total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase B: plane normals / pitch / height over the second triangulation, height_level, and the
+// bit-set of selected (surviving-feature) indices.
+// ---------------------------------------------------------------------------------------------
+struct SelectResult {
+    double height_level;
+    int n_pitch, n_tri_valid;
+    int singular, bad;
+};
+
+struct PitchTest {
+    double thr_deg;      // -80
+    double s2_hi, s2_lo; // sin^2(|thr|) * (1 +- 1e-9): outside this band the decision needs no asin
+};
+
+template <int WAVES, bool FULL>
+__device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid, const int32_t *tri2, int64_t t2_begin,
+                                                     int t2_count, PitchTest pt, double *g_normals, double *g_pitch,
+                                                     double *g_heights) {
+    constexpr int B = WAVES * kWave;
+    const int tid = threadIdx.x;
+    unsigned long long flat = 0ull;          // bit k: my k-th triangle has pitch_deg < thr
+    double hsum = 0.0, hcnt = 0.0;
+    int npitch = 0, singular = 0, bad = 0;
+    for (int k = 0, t = tid; t < t2_count; t += B, ++k) {
+        const TriIds q = load_tri(tri2, t2_begin + t);
+        if ((unsigned)q.a >= (unsigned)n_valid || (unsigned)q.b >= (unsigned)n_valid || (unsigned)q.c >= (unsigned)n_valid) { bad = 1; continue; }
+        const int i0 = s.cm[q.a], i1 = s.cm[q.b], i2 = s.cm[q.c];
+        const double x0 = s.X[i0], y0 = s.Y[i0], z0 = s.Z[i0];
+        const double x1 = s.X[i1], y1 = s.Y[i1], z1 = s.Z[i1];
+        const double x2 = s.X[i2], y2 = s.Y[i2], z2 = s.Z[i2];
+        double nx, ny, nz;
+        if (!plane_normal(x0, y0, z0, x1, y1, z1, x2, y2, z2, nx, ny, nz)) singular = 1;      // :229-230
+        const double len2 = (nx * nx + ny * ny) + nz * nz;                                   // :231
+        const double h = div3((y0 + y1) + y2);                                               // :238
+        bool is_flat, is_steep;
+        bool decided = false;
+        if constexpr (!FULL) {
+            // pitch_deg < thr  <=>  n_y/|n| > sin(|thr|); only inside a 1e-9 band around the
+            // threshold does the outcome depend on how asin rounds, and there the full
+            // expression below is evaluated.
+            const double q2 = ny * ny;
+            if (ny > 0.0 && q2 > pt.s2_hi * len2) { is_flat = true; is_steep = false; decided = true; }
+            else if (ny <= 0.0 || q2 < pt.s2_lo * len2) { is_flat = false; is_steep = true; decided = true; }
+        }
+        if (!decided) {
+            const double len = sqrt(len2);
+            const double uy = ny / len;                                                      // :232
+            const double pitch = asin(-uy) * 180.0 / 3.141592653589793;                      // :233
+            is_flat = pitch < pt.thr_deg;                                                    // :235
+            is_steep = pitch >= pt.thr_deg;                                                  // :239  (NaN: neither)
+            if constexpr (FULL) {
+                if (g_normals) { double *o = g_normals + 3 * (t2_begin + t); o[0] = nx; o[1] = ny; o[2] = nz; }
+                if (g_pitch) g_pitch[t2_begin + t] = pitch;
+                if (g_heights) g_heights[t2_begin + t] = h;
+            }
+        }
+        if (is_steep) { hsum += h; hcnt += 1.0; }                                            // :240
+        if (is_flat) { flat |= 1ull << k; ++npitch; }
+    }
+    block_sum2<WAVES>(hsum, hcnt, s.red);
+    SelectResult r;
+    r.height_level = hsum / hcnt;                 // np.mean of an empty set -> 0/0 = NaN, like :240
+    const double hl = r.height_level;
+    int ntv = 0;
+    for (int k = 0, t = tid; t < t2_count; t += B, ++k) {
+        if (!((flat >> k) & 1ull)) continue;
+        const TriIds q = load_tri(tri2, t2_begin + t);
+        const double y0 = s.Y[s.cm[q.a]], y1 = s.Y[s.cm[q.b]], y2 = s.Y[s.cm[q.c]];
+        const double h = div3((y0 + y1) + y2);
+        if (h > hl) {                                                                        // :243-244
+            ++ntv;
+            atomicOr(&s.sel[q.a >> 5], 1u << (q.a & 31));                                    // :247
+            atomicOr(&s.sel[q.b >> 5], 1u << (q.b & 31));
+            atomicOr(&s.sel[q.c >> 5], 1u << (q.c & 31));
+        }
+    }
+    block_sum4i<WAVES>(npitch, ntv, singular, bad, reinterpret_cast<int *>(s.red));   // also orders the atomicOr's
+    r.n_pitch = npitch; r.n_tri_valid = ntv; r.singular = singular; r.bad = bad;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase C: road model on the y' of the selected points.
+// `fetch(j, y)` yields the j-th candidate value (returns false if candidate j is not selected).
+// ---------------------------------------------------------------------------------------------
+struct RoadResult {
+    double height;
+    int status;
+    int n_sel, n_kept, n_modes, mode_left, mode_right;
+    double mean, std, skew, median;
+};
+
+// is y inside the interval remove_single deletes for a single-count bin? (:284-293)
+__device__ __forceinline__ bool dropped_by_single(double y, const int *hist, int first_single) {
+    if (first_single < 0 || !(y > -1.0 && y < 18.0)) return false;
+    int kb = (int)(y * 10.0);
+    kb = max(0, min(kBins - 1, kb));
+    for (int k = max(0, kb - 1); k <= min(kBins - 1, kb + 1); ++k) {
+        if (hist[k] != 1) continue;
+        const double r = bin_edge(k + 1);
+        const double lo = r - 0.1;                          // bin_single-0.1, not the bin's own left edge
+        const bool in = (k == first_single) ? (y >= lo && y <= r) : (y > lo && y <= r);
+        if (in) return true;
+    }
+    return false;
+}
+
+template <int WAVES, typename Fetch>
+__device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetch fetch, double height_level,
+                                                 const mvosr_params &P, double *list /* >= n_cand doubles of LDS, free */,
+                                                 int32_t *g_hist) {
+    constexpr int B = WAVES * kWave;
+    const int tid = threadIdx.x, lane = lane_id();
+    RoadResult R;
+    R.height = nan(""); R.status = MVOSR_ST_MODE; R.n_modes = 0; R.mode_left = -1; R.mode_right = -1;
+    R.mean = R.std = R.skew = R.median = nan("");
+
+    // histogram (np.histogram, :326); hist[] was zeroed by the caller before a barrier
+    int nsel = 0;
+    for (int j = tid; j < n_cand; j += B) {
+        double y;
+        if (!fetch(j, y)) continue;
+        ++nsel;
+        const int k = bin_of(y);
+        if (k >= 0) atomicAdd(&s.hist[k], 1);
+    }
+    int d0 = 0, d1 = 0, d2 = 0;
+    block_sum4i<WAVES>(nsel, d0, d1, d2, reinterpret_cast<int *>(s.red));    // barrier: histogram complete
+    R.n_sel = nsel;
+    if (nsel == 0) { R.status = MVOSR_ST_NO_FLAT; R.n_kept = 0; return R; }
+
+    // every wave evaluates the 169-bin logic redundantly on ballots (no serial section):
+    // lane l looks at bins l, l+64, l+128
+    int hraw[3], hz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int b = lane + 64 * c;
+        hraw[c] = (b < kBins) ? s.hist[b] : 0;
+        hz[c] = (hraw[c] == 1) ? 0 : hraw[c];                                  // dis[dis==1]=0, :328
+    }
+    if (g_hist && tid < kWave) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int b = lane + 64 * c;
+            if (b < kBins) { g_hist[b] = hraw[c]; g_hist[kBins + b] = hz[c]; }
+        }
+    }
+    Bits192 single, modes, mins;
+    int mx = 0, mn = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int b = lane + 64 * c;
+        single.w[c] = __ballot(b < kBins && hraw[c] == 1);
+        if (b < kBins) { mx = max(mx, hz[c]); mn = min(mn, hz[c]); }
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    const int first_single = single.lowest_from(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int b = lane + 64 * c;
+        bool is_mode = false, is_min = false;
+        if (b < kBins) {
+            const int h = hz[c];
+            if (b == 0 || b == kBins - 1) {
+                is_mode = (h == mx);                                            // :454-458
+                is_min = (h == mn);                                             // :433-437
+            } else {
+                const int lraw = s.hist[b - 1], rraw = s.hist[b + 1];
+                const int hl_ = (lraw == 1) ? 0 : lraw, hr_ = (rraw == 1) ? 0 : rraw;
+                is_mode = (h >= hl_) && (h >= hr_) && ((double)h >= P.mode_rel * (double)mx) && (h >= P.mode_min);   // :459-463
+                is_min = (h <= hl_) && (h <= hr_) && !((h == hr_) && (h == hl_));                                   // :438-442
+            }
+        }
+        modes.w[c] = __ballot(is_mode);
+        mins.w[c] = __ballot(is_min);
+    }
+    const bool have_modes = (mx > P.mode_min) && modes.any();                   // :451-452
+    R.n_modes = have_modes ? modes.runs() : 0;                                  // :468-481 (edges 0.1 apart cluster, gap < 0.11)
+
+    // pass over the selected points again: drop those inside a single bin's interval, accumulate the mean
+    double sum = 0.0, cntd = 0.0;
+    if (!have_modes && tid == 0) s.misc[M_LIST] = 0;
+    if (!have_modes) __syncthreads();
+    for (int j = tid; j < n_cand; j += B) {
+        double y;
+        if (!fetch(j, y)) continue;
+        if (dropped_by_single(y, s.hist, first_single)) continue;
+        sum += y; cntd += 1.0;
+        if (!have_modes) list[atomicAdd(&s.misc[M_LIST], 1)] = y;              // only the median needs the values
+    }
+    block_sum2<WAVES>(sum, cntd, s.red);
+    const int nkept = (int)cntd;
+    R.n_kept = nkept;
+
+    if (!have_modes) {
+        if (nkept == 0) { R.height = height_level; R.status = MVOSR_ST_LEVEL; return R; }   // :334-335
+        // np.median (:333) by rank counting: the two middle order statistics
+        const int klo = (nkept - 1) >> 1, khi = nkept >> 1;
+        double *med = reinterpret_cast<double *>(&s.misc[M_MEDLO]);
+        for (int i = tid; i < nkept; i += B) {
+            const double yi = list[i];
+            int rank = 0;
+            for (int j = 0; j < nkept; ++j) {
+                const double yj = list[j];
+                rank += (yj < yi) || (yj == yi && j < i);
+            }
+            if (rank == klo) med[0] = yi;
+            if (rank == khi) med[1] = yi;
+        }
+        __syncthreads();
+        R.median = (klo == khi) ? med[0] : (med[0] + med[1]) / 2.0;
+        R.height = R.median; R.status = MVOSR_ST_MEDIAN;
+        return R;
+    }
+
+    // last cluster = last run of consecutive mode bins (:338-340); int(edge*10) == bin+1
+    const int i_last = modes.highest_below(kBins);
+    int i_first = i_last;
+    while (i_first > 0 && modes.test(i_first - 1)) --i_first;
+    const int ml = i_first + 1, mr = i_last + 1;
+    R.mode_left = ml; R.mode_right = mr;
+    const double mode = (double)(ml + mr) / 2.0;                                // :340
+    const int il = mins.highest_below(ml);                                      // :341,:343  bins 0..ml-1
+    if (il < 0) { R.status = MVOSR_ST_ERR_LEFT; return R; }
+    const int ir = mins.lowest_from(mr);                                        // :342,:344  bins mr..168
+    if (ir < 0) { R.status = MVOSR_ST_ERR_RIGHT; return R; }
+    const double right = bin_edge(ir + 1);
+
+    const double mean = sum / cntd;                                             // np.mean, :496
+    double ss = 0.0, dummy = 0.0;
+    for (int j = tid; j < n_cand; j += B) {
+        double y;
+        if (!fetch(j, y)) continue;
+        if (dropped_by_single(y, s.hist, first_single)) continue;
+        const double d = y - mean;
+        ss += d * d;
+    }
+    block_sum2<WAVES>(ss, dummy, s.red);
+    const double sd = sqrt(ss / cntd);                                          // np.std
+    const double skew = (mean - mode / 10.0) / sd;                              // :496
+    R.mean = mean; R.std = sd; R.skew = skew;
+    if (skew > P.skew_threshold) { R.height = right; R.status = MVOSR_ST_RIGHT; }   // :348-352
+    else { R.height = mode / 10.0; R.status = MVOSR_ST_MODE; }                      // :354
+    return R;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+struct KArgs {
+    mvosr_params P;
+    mvosr_batch b;
+    mvosr_outputs o;
+    PitchTest pt;
+    int64_t first_frame;
+    const double *height_level_in;
+};
+
+__device__ __forceinline__ void write_counts(const KArgs &a, int64_t f, int nvalid, int npitch, int ntv, const RoadResult &R) {
+    if (!a.o.counts) return;
+    int32_t *c = a.o.counts + f * MVOSR_N_COUNTS;
+    c[MVOSR_CNT_VALID] = nvalid; c[MVOSR_CNT_TRI_PITCH] = npitch; c[MVOSR_CNT_TRI_VALID] = ntv;
+    c[MVOSR_CNT_SELECTED] = R.n_sel; c[MVOSR_CNT_KEPT] = R.n_kept; c[MVOSR_CNT_MODES] = R.n_modes;
+    c[MVOSR_CNT_MODE_LEFT] = R.mode_left; c[MVOSR_CNT_MODE_RIGHT] = R.mode_right;
+}
+
+template <int WAVES, bool FULL>
+__global__ __launch_bounds__(WAVES *kWave) void scale_frames_kernel(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int B = WAVES * kWave;
+    const int tid = threadIdx.x;
+    const int64_t f = a.first_frame + blockIdx.x;
+    const int n = a.b.feat_cnt[f];
+    const int64_t off = a.b.feat_off[f];
+    const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
+    const int t1n = (int)(a.b.tri1_off[f + 1] - t1b), t2n = (int)(a.b.tri2_off[f + 1] - t2b);
+    const Smem s = carve(smem, n);
+
+    RoadResult R;
+    R.height = nan(""); R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
+    R.mean = R.std = R.skew = R.median = nan("");
+    if (n <= 0 || t2n <= 0) {
+        if (tid == 0) {
+            a.o.raw_scale[f] = nan(""); a.o.height[f] = nan(""); a.o.height_level[f] = nan("");
+            a.o.status[f] = MVOSR_ST_ERR_EMPTY;
+            write_counts(a, f, 0, 0, 0, R);
+        }
+        return;
+    }
+    for (int i = tid; i < (n + 31) / 32; i += B) s.sel[i] = 0u;
+    for (int i = tid; i < 192; i += B) s.hist[i] = 0;
+
+    int bad = 0;
+    const int nvalid = phase_vote<WAVES>(s, n, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
+                                         a.P.cos_pitch, a.P.sin_pitch,
+                                         a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad);
+    const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
+
+    // x replaces v in LDS
+    {
+        const double2 *gx2 = reinterpret_cast<const double2 *>(a.b.x + off);
+        double2 *sX2 = reinterpret_cast<double2 *>(s.X);
+        for (int i = tid; i < ((n + 1) >> 1); i += B) sX2[i] = gx2[i];
+    }
+    __syncthreads();
+
+    SelectResult S;
+    S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 0;
+    if (!mask_mismatch)
+        S = phase_select<WAVES, FULL>(s, nvalid, a.b.tri2, t2b, t2n, a.pt, a.o.tri_normals, a.o.tri_pitch_deg, a.o.tri_heights);
+    {
+        int b0 = bad, b1 = 0, b2 = 0, b3 = 0;
+        block_sum4i<WAVES>(b0, b1, b2, b3, reinterpret_cast<int *>(s.red));
+        bad = b0 | S.bad;
+    }
+    int status;
+    double height = nan(""), raw = nan("");
+    if (mask_mismatch || bad) {
+        status = MVOSR_ST_ERR_MASK;
+    } else if (S.singular) {
+        status = MVOSR_ST_ERR_SINGULAR;
+    } else {
+        auto fetch = [&](int j, double &y) -> bool {
+            if (!((s.sel[j >> 5] >> (j & 31)) & 1u)) return false;
+            y = s.Y[s.cm[j]];
+            return true;
+        };
+        if (a.o.selected) {
+            for (int j = tid; j < nvalid; j += B) a.o.selected[off + j] = (uint8_t)((s.sel[j >> 5] >> (j & 31)) & 1u);
+        }
+        R = phase_road<WAVES>(s, nvalid, fetch, S.height_level, a.P, s.X, a.o.hist ? a.o.hist + f * 2 * kBins : nullptr);
+        status = R.status;
+        if (status == MVOSR_ST_NO_FLAT) raw = a.P.absolute_reference / S.height_level;        // :421
+        else if (status <= MVOSR_ST_LEVEL) { height = R.height; raw = a.P.absolute_reference / height; }   // :419
+    }
+    if (tid == 0) {
+        a.o.raw_scale[f] = raw;
+        a.o.height[f] = height;
+        a.o.height_level[f] = S.height_level;
+        a.o.status[f] = status;
+        write_counts(a, f, nvalid, S.n_pitch, S.n_tri_valid, R);
+        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = R.mean; st[1] = R.std; st[2] = R.skew; st[3] = R.median; }
+    }
+}
+
+// K1 alone
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *kWave) void outlier_vote_kernel(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t f = a.first_frame + blockIdx.x;
+    const int n = a.b.feat_cnt[f];
+    if (n <= 0) { if (threadIdx.x == 0 && a.o.counts) a.o.counts[f * MVOSR_N_COUNTS + MVOSR_CNT_VALID] = 0; return; }
+    const int64_t off = a.b.feat_off[f];
+    const int64_t t1b = a.b.tri1_off[f];
+    const int t1n = (int)(a.b.tri1_off[f + 1] - t1b);
+    const Smem s = carve(smem, n);
+    int bad = 0;
+    const int nvalid = phase_vote<WAVES>(s, n, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
+                                         a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters + off, bad);
+    int b0 = bad, b1 = 0, b2 = 0, b3 = 0;
+    block_sum4i<WAVES>(b0, b1, b2, b3, reinterpret_cast<int *>(s.red));
+    if (threadIdx.x == 0) {
+        if (a.o.counts) a.o.counts[f * MVOSR_N_COUNTS + MVOSR_CNT_VALID] = nvalid;
+        if (a.o.status) a.o.status[f] = b0 ? MVOSR_ST_ERR_MASK : MVOSR_ST_MODE;
+    }
+}
+
+// K3 alone: y lists straight from HBM (already remapped), staged into the Y plane
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *kWave) void road_model_kernel(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int B = WAVES * kWave;
+    const int tid = threadIdx.x;
+    const int64_t f = a.first_frame + blockIdx.x;
+    const int n = a.b.feat_cnt[f];
+    const int64_t off = a.b.feat_off[f];
+    const Smem s = carve(smem, max(n, 1));
+    for (int i = tid; i < 192; i += B) s.hist[i] = 0;
+    for (int i = tid; i < n; i += B) s.Y[i] = a.b.y[off + i];
+    __syncthreads();
+    const double hl = a.height_level_in ? a.height_level_in[f] : nan("");
+    auto fetch = [&](int j, double &y) -> bool { y = s.Y[j]; return true; };
+    RoadResult R = phase_road<WAVES>(s, n, fetch, hl, a.P, s.X, a.o.hist ? a.o.hist + f * 2 * kBins : nullptr);
+    if (tid == 0) {
+        double height = nan(""), raw = nan("");
+        if (R.status == MVOSR_ST_NO_FLAT) raw = a.P.absolute_reference / hl;
+        else if (R.status <= MVOSR_ST_LEVEL) { height = R.height; raw = a.P.absolute_reference / height; }
+        a.o.raw_scale[f] = raw; a.o.height[f] = height; a.o.status[f] = R.status;
+        if (a.o.height_level) a.o.height_level[f] = hl;
+        write_counts(a, f, n, 0, 0, R);
+        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = R.mean; st[1] = R.std; st[2] = R.skew; st[3] = R.median; }
+    }
+}
+
+// K4: sliding-window median of the raw scale sequence (scale_filtering, :396-400)
+constexpr int kMaxWindow = 64;
+struct MedianArgs {
+    const double *raw; double *out; int64_t n; int window; int n_queue;
+    double queue[kMaxWindow];
+};
+__global__ __launch_bounds__(256) void window_median_kernel(const MedianArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    // position in the concatenated push sequence [queue..., raw...]
+    const int64_t last = a.n_queue + i;
+    int64_t first = last - a.window + 1;
+    if (first < 0) first = 0;
+    const int m = (int)(last - first + 1);
+    double w[kMaxWindow];
+    bool has_nan = false;
+    for (int k = 0; k < m; ++k) {
+        const int64_t p = first + k;
+        const double x = (p < a.n_queue) ? a.queue[p] : a.raw[p - a.n_queue];
+        has_nan |= (x != x);
+        int j = k;                                   // insertion sort
+        while (j > 0 && w[j - 1] > x) { w[j] = w[j - 1]; --j; }
+        w[j] = x;
+    }
+    double r;
+    if (has_nan) r = nan("");                        // np.median propagates NaN
+    else if (m & 1) r = w[m >> 1];
+    else r = (w[(m >> 1) - 1] + w[m >> 1]) / 2.0;     // np.mean of the two middle values
+    a.out[i] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static int g_max_dyn_lds = 160 * 1024 - 0;   // refined from the device in ctx_create
+
+template <typename K>
+static int prepare_kernel(K kernel, size_t lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_hip_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
+    return MVOSR_OK;
+}
+
+static PitchTest make_pitch_test(double thr_deg) {
+    PitchTest pt;
+    pt.thr_deg = thr_deg;
+    if (thr_deg < -1.0 && thr_deg > -89.9) {
+        const double sn = sin(-thr_deg * 3.141592653589793 / 180.0);
+        pt.s2_hi = sn * sn * (1.0 + 1e-9);
+        pt.s2_lo = sn * sn * (1.0 - 1e-9);
+    } else {                                   // no safe band: always evaluate asin
+        pt.s2_hi = INFINITY;
+        pt.s2_lo = -INFINITY;
+    }
+    return pt;
+}
+
+static int pick_waves(int requested, int max_feat) {
+    if (requested == 1 || requested == 4 || requested == 8 || requested == 16) return requested;
+    if (max_feat <= 320) return 1;
+    if (max_feat <= 1024) return 4;
+    return 8;
+}
+
+static int check_common(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const mvosr_outputs *o) {
+    if (!ctx || !p || !b || !o) return set_error(MVOSR_ERR_ARG, "null argument");
+    if (b->n_frames < 0 || !b->feat_off || !b->feat_cnt) return set_error(MVOSR_ERR_ARG, "batch without frames/offsets");
+    if (b->max_feat < 0) return set_error(MVOSR_ERR_ARG, "max_feat < 0");
+    return MVOSR_OK;
+}
+
+template <int WAVES>
+static int check_fit(const mvosr_batch *b, size_t lds, int64_t max_tri) {
+    if ((int64_t)lds > (int64_t)g_max_dyn_lds)
+        return set_error(MVOSR_ERR_TOO_LARGE, "frame of %d features needs %zu B of LDS (> %d)", b->max_feat, lds, g_max_dyn_lds);
+    if (b->max_feat > 65535) return set_error(MVOSR_ERR_TOO_LARGE, "more than 65535 features per frame");
+    if ((int64_t)b->max_feat > (int64_t)64 * 64 * WAVES)
+        return set_error(MVOSR_ERR_TOO_LARGE, "%d features need more wavefronts per frame than %d", b->max_feat, WAVES);
+    (void)max_tri;
+    return MVOSR_OK;
+}
+
+template <int WAVES>
+static int launch_scale(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool full) {
+    const size_t lds = lds_plan(ka.b.max_feat).total;
+    int rc = check_fit<WAVES>(&ka.b, lds, 0);
+    if (rc) return rc;
+    // a triangle sweep keeps one flag bit per iteration in a 64-bit register: T2 <= 64 * block
+    // (2N triangles for N features, so this only binds for the one-wave variant)
+    if ((int64_t)2 * ka.b.max_feat > (int64_t)64 * 64 * WAVES)
+        return set_error(MVOSR_ERR_TOO_LARGE, "%d features give more triangles than %d wavefronts sweep", ka.b.max_feat, WAVES);
+    if (full) {
+        if ((rc = prepare_kernel(scale_frames_kernel<WAVES, true>, lds))) return rc;
+        hipLaunchKernelGGL((scale_frames_kernel<WAVES, true>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
+    } else {
+        if ((rc = prepare_kernel(scale_frames_kernel<WAVES, false>, lds))) return rc;
+        hipLaunchKernelGGL((scale_frames_kernel<WAVES, false>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
+    }
+    return check_launch("scale_frames_kernel");
+}
+
+template <int WAVES>
+static int launch_vote(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
+    const size_t lds = lds_plan(ka.b.max_feat).total;
+    int rc = check_fit<WAVES>(&ka.b, lds, 0);
+    if (rc) return rc;
+    if ((rc = prepare_kernel(outlier_vote_kernel<WAVES>, lds))) return rc;
+    hipLaunchKernelGGL((outlier_vote_kernel<WAVES>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
+    return check_launch("outlier_vote_kernel");
+}
+
+template <int WAVES>
+static int launch_road(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
+    const size_t lds = lds_plan(ka.b.max_feat > 0 ? ka.b.max_feat : 1).total;
+    int rc = check_fit<WAVES>(&ka.b, lds, 0);
+    if (rc) return rc;
+    if ((rc = prepare_kernel(road_model_kernel<WAVES>, lds))) return rc;
+    hipLaunchKernelGGL((road_model_kernel<WAVES>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
+    return check_launch("road_model_kernel");
+}
+
+void set_max_dynamic_lds(int bytes) { g_max_dyn_lds = bytes; }
+
+}  // namespace mvosr
+
+using namespace mvosr;
+
+extern "C" {
+
+void mvosr_default_params(mvosr_params *p, double absolute_reference) {
+    if (!p) return;
+    const double pitch = -0.5 * 3.141592653589793 / 180.0;   // scale_calculator.py:24 (the Python shim overwrites cos/sin with NumPy's)
+    p->cos_pitch = cos(pitch);
+    p->sin_pitch = sin(pitch);
+    p->absolute_reference = absolute_reference;
+    p->pitch_threshold_deg = -80.0;
+    p->skew_threshold = 0.3;
+    p->mode_rel = 0.33;
+    p->mode_min = 2;
+    p->reserved = 0;
+}
+
+size_t mvosr_lds_bytes(int n_features) { return lds_plan(n_features < 1 ? 1 : n_features).total; }
+
+int mvosr_max_lds_features(void) {
+    int lo = 1, hi = 65535;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if ((int64_t)lds_plan(mid).total <= (int64_t)g_max_dyn_lds) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const mvosr_outputs *o,
+                      int waves_per_frame, int64_t first_frame, int64_t n_launch) {
+    int rc = check_common(ctx, p, b, o);
+    if (rc) return rc;
+    if (!b->x || !b->y || !b->z || !b->v || !b->tri1_off || !b->tri2_off || !b->tri2 || (!b->tri1 && false))
+        return set_error(MVOSR_ERR_ARG, "scale_batch: missing input plane / triangulation");
+    if (!o->raw_scale || !o->height || !o->height_level || !o->status)
+        return set_error(MVOSR_ERR_ARG, "scale_batch: raw_scale/height/height_level/status are required outputs");
+    if (n_launch <= 0) { first_frame = 0; n_launch = b->n_frames; }
+    if (first_frame < 0 || first_frame + n_launch > b->n_frames) return set_error(MVOSR_ERR_ARG, "frame range outside the batch");
+    if (n_launch == 0) return MVOSR_OK;
+    if ((rc = ctx_activate(ctx))) return rc;
+    KArgs ka;
+    ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
+    ka.first_frame = first_frame; ka.height_level_in = nullptr;
+    const bool full = o->tri_normals || o->tri_pitch_deg || o->tri_heights;
+    switch (pick_waves(waves_per_frame, b->max_feat)) {
+        case 1: return launch_scale<1>(ctx, ka, n_launch, full);
+        case 4: return launch_scale<4>(ctx, ka, n_launch, full);
+        case 16: return launch_scale<16>(ctx, ka, n_launch, full);
+        default: return launch_scale<8>(ctx, ka, n_launch, full);
+    }
+}
+
+int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const mvosr_outputs *o,
+                             int waves_per_frame) {
+    int rc = check_common(ctx, p, b, o);
+    if (rc) return rc;
+    if (!b->y || !b->z || !b->v || !b->tri1_off || !b->tri1) return set_error(MVOSR_ERR_ARG, "outlier_vote: missing y/z/v/tri1");
+    if (!o->vote_counters) return set_error(MVOSR_ERR_ARG, "outlier_vote: vote_counters output required");
+    if (b->n_frames == 0) return MVOSR_OK;
+    if ((rc = ctx_activate(ctx))) return rc;
+    KArgs ka;
+    ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
+    ka.first_frame = 0; ka.height_level_in = nullptr;
+    switch (pick_waves(waves_per_frame, b->max_feat)) {
+        case 1: return launch_vote<1>(ctx, ka, b->n_frames);
+        case 4: return launch_vote<4>(ctx, ka, b->n_frames);
+        case 16: return launch_vote<16>(ctx, ka, b->n_frames);
+        default: return launch_vote<8>(ctx, ka, b->n_frames);
+    }
+}
+
+int mvosr_road_model_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const double *height_level_in,
+                           const mvosr_outputs *o, int waves_per_frame) {
+    int rc = check_common(ctx, p, b, o);
+    if (rc) return rc;
+    if (!b->y) return set_error(MVOSR_ERR_ARG, "road_model: y plane required");
+    if (!o->raw_scale || !o->height || !o->status) return set_error(MVOSR_ERR_ARG, "road_model: raw_scale/height/status required");
+    if (b->n_frames == 0) return MVOSR_OK;
+    if ((rc = ctx_activate(ctx))) return rc;
+    KArgs ka;
+    ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
+    ka.first_frame = 0; ka.height_level_in = height_level_in;
+    switch (pick_waves(waves_per_frame, b->max_feat)) {
+        case 1: return launch_road<1>(ctx, ka, b->n_frames);
+        case 4: return launch_road<4>(ctx, ka, b->n_frames);
+        case 16: return launch_road<16>(ctx, ka, b->n_frames);
+        default: return launch_road<8>(ctx, ka, b->n_frames);
+    }
+}
+
+int mvosr_window_median(mvosr_ctx *ctx, const double *raw, int64_t n, int window, const double *queue_in, int n_queue,
+                        double *out) {
+    if (!ctx || (n > 0 && (!raw || !out))) return set_error(MVOSR_ERR_ARG, "window_median: null argument");
+    if (window < 1 || window > kMaxWindow) return set_error(MVOSR_ERR_ARG, "window_median: window must be in 1..%d", kMaxWindow);
+    if (n_queue < 0 || n_queue > window || (n_queue > 0 && !queue_in)) return set_error(MVOSR_ERR_ARG, "window_median: bad carried-in queue");
+    if (n <= 0) return MVOSR_OK;
+    int rc = ctx_activate(ctx);
+    if (rc) return rc;
+    MedianArgs ma;
+    ma.raw = raw; ma.out = out; ma.n = n; ma.window = window; ma.n_queue = n_queue;
+    for (int i = 0; i < kMaxWindow; ++i) ma.queue[i] = (i < n_queue) ? queue_in[i] : 0.0;
+    hipLaunchKernelGGL(window_median_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx_stream(ctx), ma);
+    return check_launch("window_median_kernel");
+}
+
+}  // extern "C"

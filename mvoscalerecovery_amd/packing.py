@@ -1,0 +1,185 @@
+"""Host-side packing of frames into the HBM layout the kernels read (include/mvosr.h, mvosr_batch).
+
+Per frame the path consumes: the features that pass the vanishing-row filter
+(/root/reference/src/scale_calculator.py:252-254), as raw ``x, y, z`` (before feature_remap,
+which the kernels fuse into their load) and the pixel row ``v``; the first triangulation
+``Delaunay(feature2d).simplices`` (:257-258) and the second one over the features that survive
+the depth-order vote (:266-267).  Both triangulations are *inputs* of the GPU path: Qhull runs on
+the host (SciPy), exactly where the reference calls it, and its ``simplices`` are carried
+verbatim (int32, vertex order inside a row untouched — SURVEY.md fact 4).
+
+Layout: structure of arrays.  ``x|y|z|v`` are float64 planes holding all frames back to back,
+each frame's segment starting at an even element (16-byte aligned); ``tri1``/``tri2`` are
+(T,3) int32 row-major with per-frame offsets in triangles.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+VANISH = 185        # /root/reference/src/scale_calculator.py:22
+
+
+def delaunay_simplices(points2d):
+    """scipy.spatial.Delaunay(points).simplices — the reference's call (:257-258,:266-267)."""
+    from scipy.spatial import Delaunay
+    return np.ascontiguousarray(Delaunay(points2d).simplices, dtype=np.int32)
+
+
+def _delaunay_job(points2d):
+    try:
+        return delaunay_simplices(points2d)
+    except Exception as exc:  # QhullError etc.: re-raised in frame order by the caller
+        return exc
+
+
+def delaunay_many(point_sets, workers=0):
+    """Triangulate many point sets, optionally on a process pool (Qhull is ~8 ms per 2000
+    points; this is the host stage that bounds end-to-end throughput — SURVEY.md §7 hard part 1)."""
+    if workers and workers > 1 and len(point_sets) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            return pool.map(_delaunay_job, point_sets, chunksize=max(1, len(point_sets) // (workers * 8)))
+    return [_delaunay_job(p) for p in point_sets]
+
+
+@dataclass
+class PackedFrames:
+    """NumPy-side image of an ``mvosr_batch``."""
+    n_frames: int
+    feat_off: np.ndarray            # int64 [F]
+    feat_cnt: np.ndarray            # int32 [F]
+    x: np.ndarray                   # float64 [total padded]
+    y: np.ndarray
+    z: np.ndarray
+    v: np.ndarray
+    u: np.ndarray                   # host only (Delaunay input); never uploaded
+    lower_index: list               # per frame: indices of the kept features in the caller's arrays
+    tri1_off: np.ndarray = None     # int64 [F+1]
+    tri1: np.ndarray = None         # int32 [T1,3]
+    tri2_off: np.ndarray = None
+    tri2: np.ndarray = None
+    n2_expected: np.ndarray = None  # int32 [F]
+    max_feat: int = 0
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def total_padded(self):
+        return int(self.x.shape[0])
+
+    def frame_slice(self, f):
+        o = int(self.feat_off[f])
+        return slice(o, o + int(self.feat_cnt[f]))
+
+    def algorithmic_bytes(self):
+        """B = 8*(3N+N) + 12*(T1+T2) + 12 per frame, summed over the batch."""
+        n = int(self.feat_cnt.sum())
+        t1 = int(self.tri1_off[-1]) if self.tri1_off is not None else 0
+        t2 = int(self.tri2_off[-1]) if self.tri2_off is not None else 0
+        return 8 * 4 * n + 12 * (t1 + t2) + 12 * self.n_frames
+
+
+def pack_features(feature3ds, feature2ds, vanish=VANISH):
+    """Apply the vanishing-row filter and lay the survivors out as planes."""
+    F = len(feature3ds)
+    cnt = np.zeros(F, dtype=np.int32)
+    lower_index = []
+    for f in range(F):
+        f2 = np.asarray(feature2ds[f], dtype=np.float64)
+        idx = np.nonzero(f2[:, 1] > vanish)[0] if f2.size else np.zeros(0, dtype=np.int64)   # :252
+        lower_index.append(idx)
+        cnt[f] = idx.shape[0]
+    padded = (cnt.astype(np.int64) + 1) & ~np.int64(1)
+    off = np.zeros(F, dtype=np.int64)
+    if F:
+        off[1:] = np.cumsum(padded)[:-1]
+    total = int(padded.sum()) if F else 0
+    x = np.zeros(max(total, 2), dtype=np.float64)
+    y = np.zeros_like(x)
+    z = np.zeros_like(x)
+    v = np.zeros_like(x)
+    u = np.zeros_like(x)
+    for f in range(F):
+        n = int(cnt[f])
+        if n == 0:
+            continue
+        idx = lower_index[f]
+        f3 = np.asarray(feature3ds[f], dtype=np.float64)
+        f2 = np.asarray(feature2ds[f], dtype=np.float64)
+        o = int(off[f])
+        x[o:o + n] = f3[idx, 0]
+        y[o:o + n] = f3[idx, 1]
+        z[o:o + n] = f3[idx, 2]
+        u[o:o + n] = f2[idx, 0]
+        v[o:o + n] = f2[idx, 1]
+    return PackedFrames(F, off, cnt, x, y, z, v, u, lower_index, max_feat=int(cnt.max()) if F else 0)
+
+
+def _pack_tris(tris):
+    F = len(tris)
+    off = np.zeros(F + 1, dtype=np.int64)
+    for f, t in enumerate(tris):
+        off[f + 1] = off[f] + (0 if t is None else int(t.shape[0]))
+    flat = np.zeros((max(int(off[-1]), 1), 3), dtype=np.int32)
+    for f, t in enumerate(tris):
+        if t is not None and t.shape[0]:
+            flat[off[f]:off[f + 1]] = t
+    return off, flat
+
+
+def attach_tri1(pf: PackedFrames, tri1s=None, workers=0):
+    """First triangulation per frame (given, or SciPy on the packed (u,v))."""
+    if tri1s is None:
+        pts = []
+        for f in range(pf.n_frames):
+            s = pf.frame_slice(f)
+            pts.append(np.stack([pf.u[s], pf.v[s]], axis=1))
+        tri1s = delaunay_many(pts, workers)
+    pf.extra["tri1_errors"] = {f: t for f, t in enumerate(tri1s) if isinstance(t, Exception)}
+    tri1s = [None if isinstance(t, Exception) else np.ascontiguousarray(t, dtype=np.int32) for t in tri1s]
+    pf.tri1_off, pf.tri1 = _pack_tris(tri1s)
+    return pf
+
+
+def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0):
+    """Second triangulation per frame: given, or SciPy over the features with ``valid_masks[f]``
+    (the vote result that came back from the GPU)."""
+    if tri2s is None:
+        assert valid_masks is not None
+        pts = []
+        for f in range(pf.n_frames):
+            s = pf.frame_slice(f)
+            m = valid_masks[f]
+            pts.append(np.stack([pf.u[s][m], pf.v[s][m]], axis=1))
+        tri2s = delaunay_many(pts, workers)
+    pf.extra["tri2_errors"] = {f: t for f, t in enumerate(tri2s) if isinstance(t, Exception)}
+    tri2s = [None if isinstance(t, Exception) else np.ascontiguousarray(t, dtype=np.int32) for t in tri2s]
+    pf.tri2_off, pf.tri2 = _pack_tris(tri2s)
+    if valid_masks is not None:
+        pf.n2_expected = np.array([int(np.count_nonzero(m)) for m in valid_masks], dtype=np.int32)
+    return pf
+
+
+def tile_frames(pf: PackedFrames, repeats: int) -> PackedFrames:
+    """Replicate a pool of packed frames ``repeats`` times (bench datasets: a pool of P unique
+    frames tiled to the requested size)."""
+    F = pf.n_frames
+    padded_total = pf.total_padded
+    feat_off = np.concatenate([pf.feat_off + r * padded_total for r in range(repeats)])
+    out = PackedFrames(F * repeats, feat_off, np.tile(pf.feat_cnt, repeats),
+                       np.tile(pf.x, repeats), np.tile(pf.y, repeats), np.tile(pf.z, repeats),
+                       np.tile(pf.v, repeats), np.tile(pf.u, repeats), pf.lower_index * repeats,
+                       max_feat=pf.max_feat)
+    for name in ("tri1", "tri2"):
+        off = getattr(pf, name + "_off")
+        arr = getattr(pf, name)
+        if off is None:
+            continue
+        t = int(off[-1])
+        new_off = np.concatenate([off[:-1] + r * t for r in range(repeats)] + [np.array([repeats * t], dtype=np.int64)])
+        setattr(out, name + "_off", new_off)
+        setattr(out, name, np.tile(arr[:max(t, 1)], (repeats, 1)))
+    if pf.n2_expected is not None:
+        out.n2_expected = np.tile(pf.n2_expected, repeats)
+    return out

@@ -1,0 +1,215 @@
+"""Drop-in ``ScaleEstimator`` backed by the MI355X kernels.
+
+Mirrors the call surface of /root/reference/src/scale_calculator.py:21-46,396-423 (the
+deterministic estimator; ``rescale.ScaleEstimator`` has the same ctor/methods,
+/root/reference/src/rescale.py:22-38,191-193), so that the only edit in the reference's drivers
+is the import line (/root/reference/src/main.py:18-20, main_offline.py:18-20):
+
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+
+Per frame the work is split exactly where the reference calls Qhull:
+
+    host   vanishing-row filter (:252-254), Delaunay #1 (:257)            [SciPy, as in the reference]
+    GPU    feature_remap + find_outliers (:390-394,:151-167)               [mvosr_outlier_vote_batch]
+    host   Delaunay #2 over the survivors (:266)                           [SciPy]
+    GPU    feature_selection_by_tri + road model + raw scale (:225-248,:324-354,:419)  [mvosr_scale_batch]
+    GPU    window median (:396-400)                                        [mvosr_window_median]
+
+``scale_calculation_batch`` does the same for a whole list of frames with one launch per GPU
+stage (and, when both triangulations are supplied, a single fused launch).  There is no CPU
+implementation behind this class: without libmvosr.so / a gfx950 device it raises.
+"""
+from __future__ import annotations
+
+from collections import deque
+
+import numpy as np
+
+from . import _lib
+from . import constants as K
+from . import packing
+from .engine import DeviceBatch, DeviceOutputs, ScaleEngine
+
+
+def raise_for_status(status, frame=None):
+    """Turn a kernel status into what the reference does at that point."""
+    where = "" if frame is None else " (frame %d of the batch)" % frame
+    if status == K.ST_ERR_LEFT:      # scale_calculator.py:343, empty selection indexed with [-1]
+        raise IndexError("index -1 is out of bounds for axis 0 with size 0" + where)
+    if status == K.ST_ERR_RIGHT:     # scale_calculator.py:344, empty selection indexed with [0]
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0" + where)
+    if status == K.ST_ERR_SINGULAR:  # scale_calculator.py:229
+        raise np.linalg.LinAlgError("Singular matrix" + where)
+    if status == K.ST_ERR_MASK:
+        raise _lib.MvosrLibraryError("second triangulation inconsistent with the vote computed on the GPU" + where)
+    if status == K.ST_ERR_EMPTY:
+        raise ValueError("frame without features below the vanishing row / without triangles" + where)
+
+
+class ScaleEstimator:
+    def __init__(self, absolute_reference, window_size=6, vanish=K.VANISH, focus=K.FOCUS, device=0,
+                 delaunay_workers=0, verbose=False, mutate_inputs=True):
+        # reference attributes (scale_calculator.py:23-40)
+        self.absolute_reference = absolute_reference
+        self.camera_pitch = K.CAMERA_PITCH
+        self.scale = None
+        self.inliers = None
+        self.scale_queue = deque()
+        self.motion_queue = deque()
+        self.window_size = window_size
+        self.vanish = vanish
+        self.focus = focus
+        self.b_matrix = np.ones((3, 1), float)
+        self.all_features = []
+        self.correct_distance_features = []
+        self.flat_features = []
+        self.all_feature = []
+        self.correct_distance_feature = []
+        self.flat_feature = []
+        self.flat_feature_2d = []
+        self.img = None
+        # build-side state
+        self.verbose = verbose
+        self.mutate_inputs = mutate_inputs          # the reference remaps the caller's feature3d in place (:414)
+        self.delaunay_workers = delaunay_workers
+        self.engine = ScaleEngine(absolute_reference, device=device, camera_pitch=self.camera_pitch)
+        self.last_status = None
+        self.last_counts = None
+        self.last_raw_scale = None
+
+    # ---- reference surface -----------------------------------------------------------------
+    def initial_estimation(self, motion_t):
+        """scale_calculator.py:41-46 (host only: one asin)."""
+        motion_t = np.asarray(motion_t)
+        pitch = np.arcsin(motion_t[1]) * 180 / np.pi
+        if self.verbose:
+            print('initial pitch', pitch)
+        self.motion_queue.append(motion_t.reshape(-1))
+        return pitch
+
+    def feature_remap(self, feature3d):
+        """scale_calculator.py:390-394, in place on the caller's array (host mirror; the kernels
+        apply the same rotation to the raw values at load)."""
+        y = feature3d[:, 1] * np.cos(self.camera_pitch) - feature3d[:, 2] * np.sin(self.camera_pitch)
+        z = feature3d[:, 1] * np.sin(self.camera_pitch) + feature3d[:, 2] * np.cos(self.camera_pitch)
+        feature3d[:, 1] = y
+        feature3d[:, 2] = z
+
+    def scale_filtering(self, scale):
+        """scale_calculator.py:396-400 for one pushed value (GPU window-median kernel)."""
+        out = self.engine.window_median_host(np.array([scale], dtype=np.float64), self.window_size,
+                                             list(self.scale_queue))
+        self.scale_queue.append(scale)
+        if len(self.scale_queue) > self.window_size:
+            self.scale_queue.popleft()
+        return out[0]
+
+    def scale_calculation(self, feature3d, feature2d, img=None):
+        """scale_calculator.py:411-423: returns (filtered scale, std)."""
+        scales, stds = self.scale_calculation_batch([feature3d], [feature2d], _single=True)
+        return scales[0], stds[0]
+
+    # dead-but-referenced methods of the reference (main.py:117-123 under ``if(False)``)
+    def check_full_distribution(self, *a, **k):
+        raise NotImplementedError("visualisation helper of the reference; not part of the hot path")
+
+    def plot_distribution(self, *a, **k):
+        raise NotImplementedError("visualisation helper of the reference; not part of the hot path")
+
+    # ---- batched surface ---------------------------------------------------------------------
+    def scale_calculation_batch(self, feature3ds, feature2ds, tri1s=None, tri2s=None, _single=False):
+        """Equivalent to calling ``scale_calculation`` once per frame, in order, on this
+        estimator: returns ``(scales[F], stds[F])`` (filtered scales).  ``tri1s``/``tri2s`` may
+        carry precomputed triangulations (lists of (T,3) int arrays, SciPy ``simplices`` verbatim).
+        If a frame hits one of the reference's raise sites, the frames before it are applied to
+        the window state and the same exception type is raised."""
+        F = len(feature3ds)
+        if F == 0:
+            return np.zeros(0), np.zeros(0)
+        eng, ctx = self.engine, self.engine.ctx
+        # raw values are packed BEFORE the (optional) in-place remap of the caller's arrays
+        pf = packing.pack_features(feature3ds, feature2ds, self.vanish)
+        if self.mutate_inputs:
+            for f3 in feature3ds:
+                if isinstance(f3, np.ndarray) and f3.size:
+                    self.feature_remap(f3)                                   # :414
+        packing.attach_tri1(pf, tri1s, self.delaunay_workers)
+        dbatch = DeviceBatch(ctx, pf, with_tri2=False)
+        stage = _single or tri2s is None
+        valid_masks = None
+        if tri2s is None:
+            vote_out = DeviceOutputs(ctx, dbatch, counts=True, stage=True)
+            eng.outlier_vote_batch(dbatch, vote_out)
+            ctx.sync()
+            counters = vote_out.get("vote_counters")
+            valid_masks = [counters[pf.frame_slice(f)] >= 0 for f in range(F)]                  # :166
+            if self.verbose:
+                for m in valid_masks:
+                    print('feature rejected ', int(np.sum(~m)))
+                    print('feature left     ', int(np.sum(m)))
+            vote_out.free()
+        packing.attach_tri2(pf, tri2s, valid_masks, self.delaunay_workers)
+        dbatch.set_tri2(pf)
+        out = DeviceOutputs(ctx, dbatch, counts=True, stage=stage)
+        eng.scale_batch(dbatch, out)
+        ctx.sync()
+        raw = out.get("raw_scale")
+        status = out.get("status")
+        level = out.get("height_level")
+        counts = out.get("counts")
+        self.last_status, self.last_counts, self.last_raw_scale = status, counts, raw
+
+        # first frame at which the reference would have raised
+        err_at = F
+        err = None
+        for f in range(F):
+            if f in pf.extra["tri1_errors"]:
+                err_at, err = f, pf.extra["tri1_errors"][f]
+                break
+            if f in pf.extra["tri2_errors"]:
+                err_at, err = f, pf.extra["tri2_errors"][f]                  # QhullError at :266
+                break
+            if status[f] >= K.ST_ERR_LEFT:
+                err_at = f
+                break
+        n_ok = err_at
+        stds = np.where(status[:n_ok] == K.ST_NO_FLAT, 100, 1).astype(np.float64)   # :413,:333-354
+        filtered = eng.window_median_host(raw[:n_ok], self.window_size, list(self.scale_queue))   # :396-400
+        for s in raw[:n_ok]:
+            self.scale_queue.append(s)
+            if len(self.scale_queue) > self.window_size:
+                self.scale_queue.popleft()
+        if n_ok:
+            last = n_ok - 1
+            self.height_level = level[last]                                   # :241
+            if stage:
+                self._store_flat_feature(pf, out, feature3ds, feature2ds, valid_masks, last, status[last])
+            if self.verbose:
+                print('height level', self.height_level)
+        out.free()
+        dbatch.free()
+        if err is not None:
+            raise err
+        if err_at < F:
+            raise_for_status(int(status[err_at]), None if _single else err_at)
+        return filtered, stds
+
+    def _store_flat_feature(self, pf, out, feature3ds, feature2ds, valid_masks, f, st):
+        """self.flat_feature / self.flat_feature_2d of the last processed frame (:275-276,:416)."""
+        if st == K.ST_NO_FLAT:
+            self.flat_feature = None                                          # :279,:416
+            return
+        if valid_masks is None:
+            return
+        sl = pf.frame_slice(f)
+        sel = out.get("selected")[sl]
+        valid = valid_masks[f]
+        nvalid = int(np.count_nonzero(valid))
+        picked = np.nonzero(sel[:nvalid])[0]                                   # np.unique order, :247
+        idx = pf.lower_index[f][np.nonzero(valid)[0][picked]]
+        f3 = np.asarray(feature3ds[f], dtype=np.float64)
+        if not self.mutate_inputs:
+            f3 = f3.copy()
+            self.feature_remap(f3)
+        self.flat_feature = f3[idx]                                            # :276
+        self.flat_feature_2d = np.asarray(feature2ds[f], dtype=np.float64)[idx]   # :275

@@ -1,0 +1,352 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
+vectors of the reference.  Needs a real MI355X:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+
+from conftest import load_json, load_npz
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from mvoscalerecovery_amd import _lib
+    ctx = _lib.default_context(0)     # raises loudly if libmvosr.so / the GPU is missing
+    assert "gfx950" in ctx.name
+    return ctx
+
+
+def _oracle():
+    from oracle import scale_oracle as so
+    return so
+
+
+def _pack(frames, tri1s=None, tri2s=None, masks=None):
+    from mvoscalerecovery_amd import packing
+    pf = packing.pack_features([f[0] for f in frames], [f[1] for f in frames])
+    packing.attach_tri1(pf, tri1s)
+    if tri2s is not None:
+        packing.attach_tri2(pf, tri2s, masks)
+    return pf
+
+
+def _oracle_frames(frames, abs_ref=1.75):
+    so = _oracle()
+    return [so.frame_raw_scale(f3, f2, abs_ref) for f3, f2 in frames]
+
+
+def _run_fused(gpu, frames, oracle_res, waves=0, abs_ref=1.75, stage=True, per_triangle=False, hist=True):
+    from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs, ScaleEngine
+    pf = _pack(frames, [r.tri1 for r in oracle_res], [r.tri2 for r in oracle_res], [r.valid for r in oracle_res])
+    eng = ScaleEngine(abs_ref, ctx=gpu)
+    db = DeviceBatch(gpu, pf)
+    out = DeviceOutputs(gpu, db, counts=True, stage=stage, per_triangle=per_triangle, hist=hist)
+    eng.scale_batch(db, out, waves=waves)
+    gpu.sync()
+    res = {k: out.get(k) for k in out.bufs}
+    out.free()
+    db.free()
+    return pf, res
+
+
+def _assert_frame_equal(so, r, res, pf, f, check_stage=True):
+    from mvoscalerecovery_amd import constants as K
+    sl = pf.frame_slice(f)
+    assert res["status"][f] == r.status, (f, res["status"][f], r.status)
+    if check_stage:
+        assert np.array_equal(res["vote_counters"][sl], r.counters), f
+        nv = int(r.valid.sum())
+        assert res["counts"][f, K.CNT_VALID] == nv
+        sel = np.nonzero(res["selected"][sl][:nv])[0]
+        if r.status != so.ST_ERR_SINGULAR:
+            assert np.array_equal(sel, r.sel.selected_ids), f
+            assert res["counts"][f, K.CNT_TRI_PITCH] == int(r.sel.valid_pitch.sum())
+            assert res["counts"][f, K.CNT_TRI_VALID] == int(r.sel.tri_valid.sum())
+    if np.isnan(r.height_level):
+        assert np.isnan(res["height_level"][f])
+    else:
+        # the only float that is not bit-pinned: a mean over ~2000 heights (summation order)
+        assert abs(res["height_level"][f] - r.height_level) <= 1e-13 * abs(r.height_level), f
+    for name, want in (("height", r.height), ("raw_scale", r.raw_scale)):
+        got = res[name][f]
+        assert (np.isnan(got) and np.isnan(want)) or got == want, (f, name, got, want)
+    if r.road is not None and "hist" in res:
+        assert np.array_equal(res["hist"][f, 0], r.road.hist_raw), f
+        assert np.array_equal(res["hist"][f, 1], r.road.hist), f
+        assert res["counts"][f, K.CNT_KEPT] == r.road.n_kept
+        assert res["counts"][f, K.CNT_MODES] == r.road.n_modes
+        assert res["counts"][f, K.CNT_MODE_LEFT] == r.road.mode_left
+        assert res["counts"][f, K.CNT_MODE_RIGHT] == r.road.mode_right
+        if not np.isnan(r.road.skew):
+            np.testing.assert_allclose(res["stats"][f, :3], [r.road.mean, r.road.std, r.road.skew], rtol=1e-12)
+
+
+# ---------------------------------------------------------------- library surface
+def test_library_loaded_and_device(gpu):
+    from mvoscalerecovery_amd import _lib
+    lib = _lib.load()
+    assert lib.mvosr_abi_version() == 1
+    assert lib.mvosr_device_count() >= 1
+    assert gpu.n_cu >= 200
+    assert lib.mvosr_max_lds_features() >= 6000
+    assert lib.mvosr_lds_bytes(2000) <= 160 * 1024 // 3      # three 2000-feature frames per CU
+
+
+def test_status_codes_match_oracle():
+    from mvoscalerecovery_amd import constants as K
+    so = _oracle()
+    for name in ("ST_MODE", "ST_RIGHT", "ST_MEDIAN", "ST_LEVEL", "ST_NO_FLAT", "ST_ERR_LEFT", "ST_ERR_RIGHT",
+                 "ST_ERR_SINGULAR", "ST_ERR_MASK", "ST_ERR_EMPTY"):
+        assert getattr(K, name) == getattr(so, name)
+
+
+# ---------------------------------------------------------------- golden vectors of the reference
+def test_stage_goldens_fused(gpu, stages):
+    """Every per-stage golden of the reference, through the fused kernel with stage outputs."""
+    so = _oracle()
+    frames = [(g["f3"], g["f2"]) for g in stages]
+    ores = [so.frame_raw_scale(g["f3"], g["f2"], g["abs_ref"], g["tri1"], g["tri2"]) for g in stages]
+    for waves in (0, 4, 8, 16):
+        pf, res = _run_fused(gpu, frames, ores, waves=waves, per_triangle=True)
+        for f, g in enumerate(stages):
+            sl = pf.frame_slice(f)
+            assert np.array_equal(res["vote_counters"][sl] >= 0, g["valid"])
+            nv = int(g["valid"].sum())
+            assert np.array_equal(np.nonzero(res["selected"][sl][:nv])[0], g["selected_ids"])
+            assert res["height"][f] == float(g["height"])
+            assert res["raw_scale"][f] == float(g["scale_first_call"])
+            assert np.array_equal(res["hist"][f, 0], g["hist_raw"])
+            assert res["counts"][f, 4] == int(g["n_kept"])
+            assert res["counts"][f, 5] == int(g["n_modes"])
+            assert abs(res["height_level"][f] - float(g["height_level"])) <= 1e-13 * abs(float(g["height_level"]))
+            if "skew" in g:
+                np.testing.assert_allclose(res["stats"][f, 2], float(g["skew"]), rtol=1e-12)
+            if g["per_triangle"]:
+                t = slice(int(pf.tri2_off[f]), int(pf.tri2_off[f + 1]))
+                # mean height of 3 vertices: same three additions and one division -> bit-exact
+                assert np.array_equal(res["tri_heights"][t], g["tri_heights"])
+                n = res["tri_normals"][t]
+                nlen = np.sqrt((n * n).sum(1))
+                # LU solve vs LAPACK inverse: agreement to rounding amplified by the triangle's
+                # conditioning (points ~10 m away, sides ~0.1 m)
+                np.testing.assert_allclose(nlen, g["normals_len"], rtol=1e-9)
+                pitch = g["pitch_rad"] * 180 / np.pi
+                np.testing.assert_allclose(res["tri_pitch_deg"][t], pitch, rtol=0, atol=1e-6)
+                assert np.array_equal(res["tri_pitch_deg"][t] < -80, pitch < -80)
+            _assert_frame_equal(so, ores[f], res, pf, f)
+
+
+def test_one_wave_per_frame_small_frames(gpu, stages):
+    """The one-frame-per-wavefront variant on the frames small enough for it."""
+    so = _oracle()
+    small = [g for g in stages if g["f3"].shape[0] <= 1000]
+    assert len(small) >= 8
+    frames = [(g["f3"], g["f2"]) for g in small]
+    ores = [so.frame_raw_scale(g["f3"], g["f2"], g["abs_ref"], g["tri1"], g["tri2"]) for g in small]
+    pf, res = _run_fused(gpu, frames, ores, waves=1)
+    for f, g in enumerate(small):
+        assert res["height"][f] == float(g["height"])
+        _assert_frame_equal(so, ores[f], res, pf, f)
+
+
+def test_dense_frame_too_large_for_lds_is_refused(gpu):
+    """N=20000 does not fit LDS: the LDS-resident variant must refuse, not corrupt."""
+    from mvoscalerecovery_amd import _lib, synth
+    f3, f2 = synth.synth_frame(7, 20000, base_seed=555)
+    so = _oracle()
+    z, meta = load_npz("dense.npz")
+    r = so.frame_raw_scale(f3, f2, 1.75, z["tri1"].astype(np.int32), z["tri2"].astype(np.int32))
+    with pytest.raises(_lib.MvosrLibraryError, match="LDS|features"):
+        _run_fused(gpu, [(f3, f2)], [r])
+
+
+def test_road_cases_kernel(gpu):
+    """K3 alone on the reference's road-model edge cases (tests/golden/road_cases.json)."""
+    from mvoscalerecovery_amd import packing
+    from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs, ScaleEngine
+    so = _oracle()
+    cases = load_json("road_cases.json")
+    names = sorted(cases)
+    F = len(names)
+    cnt = np.array([len(cases[n]["y"]) for n in names], dtype=np.int32)
+    padded = (cnt.astype(np.int64) + 1) & ~np.int64(1)
+    off = np.concatenate([[0], np.cumsum(padded)[:-1]]).astype(np.int64)
+    y = np.zeros(int(padded.sum()), dtype=np.float64)
+    for i, n in enumerate(names):
+        y[off[i]:off[i] + cnt[i]] = cases[n]["y"]
+    pf = packing.PackedFrames(F, off, cnt, y.copy(), y, y.copy(), y.copy(), y.copy(), [None] * F, max_feat=int(cnt.max()))
+    hl = np.array([cases[n]["height_level"] for n in names])
+    for waves in (1, 4, 8):
+        eng = ScaleEngine(1.75, ctx=gpu)
+        db = DeviceBatch(gpu, pf, with_tri2=False)
+        out = DeviceOutputs(gpu, db, counts=True, hist=True)
+        eng.road_model_batch(db, out, hl, waves=waves)
+        st, h = out.get("status"), out.get("height")
+        counts, hist = out.get("counts"), out.get("hist")
+        for i, n in enumerate(names):
+            rm = so.road_model(np.array(cases[n]["y"], dtype=np.float64), cases[n]["height_level"])
+            assert st[i] == rm.status, (n, st[i], rm.status)
+            assert np.array_equal(hist[i, 0], rm.hist_raw), n
+            assert counts[i, 4] == rm.n_kept, n
+            if cases[n]["raises"]:
+                assert st[i] in (so.ST_ERR_LEFT, so.ST_ERR_RIGHT)
+            else:
+                assert h[i] == cases[n]["height"], (n, h[i], cases[n]["height"])
+        out.free()
+        db.free()
+
+
+def test_window_median_kernel(gpu):
+    from mvoscalerecovery_amd.engine import ScaleEngine
+    so = _oracle()
+    eng = ScaleEngine(1.75, ctx=gpu)
+    kat = load_json("kat.json")["scale_filtering"]
+    for w, rec in kat.items():
+        assert eng.window_median_host(rec["in"], int(w)).tolist() == rec["out"]
+    rng = np.random.default_rng(3)
+    raw = rng.uniform(0.5, 3.0, 5000)
+    raw[100] = np.nan
+    for w in (1, 2, 5, 6, 11, 64):
+        q = list(rng.uniform(0.5, 3.0, min(w, 3)))
+        want, _ = so.window_median(raw, w, q)
+        got = eng.window_median_host(raw, w, q)
+        assert np.array_equal(got, want, equal_nan=True)
+
+
+# ---------------------------------------------------------------- seeded batches vs the oracle
+@pytest.mark.parametrize("n,count,waves", [(2000, 24, 8), (2000, 8, 16), (700, 24, 4), (250, 48, 1), (4000, 6, 8), (6000, 3, 16)])
+def test_seeded_batches(gpu, n, count, waves):
+    from mvoscalerecovery_amd import synth
+    so = _oracle()
+    frames = [synth.synth_frame(i, n, base_seed=7000 + n, upper_fraction=0.05 * (i % 3)) for i in range(count)]
+    ores = _oracle_frames(frames)
+    pf, res = _run_fused(gpu, frames, ores, waves=waves)
+    for f in range(count):
+        _assert_frame_equal(so, ores[f], res, pf, f)
+    # product path (no stage outputs, fast pitch test) gives the same results
+    pf2, res2 = _run_fused(gpu, frames, ores, waves=waves, stage=False, hist=False)
+    for k in ("raw_scale", "height", "height_level", "status"):
+        assert np.array_equal(res[k], res2[k], equal_nan=True)
+    assert np.array_equal(res["counts"], res2["counts"])
+
+
+def test_ragged_batch_and_determinism(gpu):
+    """Ragged frame sizes in one launch; two launches of the same batch are bit-identical."""
+    from mvoscalerecovery_amd import synth
+    so = _oracle()
+    rng = np.random.default_rng(11)
+    frames = [synth.synth_frame(i, int(rng.integers(101, 2300)), base_seed=31337, upper_fraction=0.1) for i in range(40)]
+    ores = _oracle_frames(frames)
+    pf, res = _run_fused(gpu, frames, ores)
+    for f in range(len(frames)):
+        _assert_frame_equal(so, ores[f], res, pf, f)
+    _, res_b = _run_fused(gpu, frames, ores)
+    for k in res:
+        assert np.array_equal(res[k], res_b[k], equal_nan=True), k
+
+
+def test_frame_edge_cases(gpu):
+    """Frame-level goldens of the reference: nothing selected (std 100), NaN height_level,
+    duplicate pixels, five points, mostly-upper frame."""
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    cases = load_json("frame_cases.json")
+    for name, c in cases.items():
+        f3, f2 = np.array(c["f3"]), np.array(c["f2"])
+        est = ScaleEstimator(1.75, window_size=5)
+        s, sd = est.scale_calculation(f3.copy(), f2.copy())
+        assert sd == c["std"], name
+        assert (np.isnan(s) and np.isnan(c["scale"])) or s == c["scale"], (name, s, c["scale"])
+        if np.isnan(c["height_level"]):
+            assert np.isnan(est.height_level)
+        else:
+            assert abs(est.height_level - c["height_level"]) <= 1e-13 * abs(c["height_level"])
+        if c["n_flat"] is None:
+            assert est.flat_feature is None
+        else:
+            assert len(est.flat_feature) == c["n_flat"]
+
+
+def test_mask_mismatch_and_bad_index_are_flagged(gpu):
+    from mvoscalerecovery_amd import constants as K, synth
+    frames = [synth.synth_frame(i, 500, base_seed=5) for i in range(3)]
+    ores = _oracle_frames(frames)
+    # frame 1: tri2 built on a different mask; frame 2: a vertex id out of range
+    bad_mask = ores[1].valid.copy()
+    bad_mask[np.nonzero(bad_mask)[0][0]] = False
+    ores[1].valid = bad_mask
+    ores[2].tri2 = ores[2].tri2.copy()
+    ores[2].tri2[5, 1] = 100000
+    pf, res = _run_fused(gpu, frames, ores, stage=False, hist=False)
+    assert res["status"][0] <= K.ST_LEVEL
+    assert res["status"][1] == K.ST_ERR_MASK
+    assert res["status"][2] == K.ST_ERR_MASK
+
+
+def test_singular_triangle_status(gpu):
+    """Two identical vertices in one triangle: LAPACK reports a zero pivot (LinAlgError, :229)."""
+    from mvoscalerecovery_amd import constants as K, synth
+    so = _oracle()
+    f3, f2 = synth.synth_frame(0, 300, base_seed=8)
+    r = so.frame_raw_scale(f3, f2, 1.75)
+    # make two surviving features 3-D identical (pixels stay distinct so Delaunay is unchanged)
+    low = np.nonzero(r.lower)[0][np.nonzero(r.valid)[0]]
+    a, b = low[r.tri2[0, 0]], low[r.tri2[0, 1]]
+    f3 = f3.copy()
+    f3[b] = f3[a]
+    r2 = so.frame_raw_scale(f3, f2, 1.75, r.tri1, r.tri2)
+    if r2.status == so.ST_ERR_SINGULAR and np.array_equal(r2.valid, r.valid):
+        pf, res = _run_fused(gpu, [(f3, f2)], [r2], stage=False, hist=False)
+        assert res["status"][0] == K.ST_ERR_SINGULAR
+
+
+# ---------------------------------------------------------------- the drop-in class
+def test_estimator_per_frame_matches_oracle_sequence(gpu):
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    est = ScaleEstimator(1.75, window_size=5)
+    ref = so.OracleScaleEstimator(1.75, window_size=5)
+    for i in range(12):
+        f3, f2 = synth.synth_frame(i, 900, base_seed=404, upper_fraction=0.1)
+        t = np.array([0.01, -0.02, 0.9997])
+        assert est.initial_estimation(t) == ref.initial_estimation(t)
+        a3 = f3.copy()
+        s, sd = est.scale_calculation(a3, f2)
+        rs, rsd = ref.scale_calculation(f3, f2)
+        assert (s, sd) == (rs, rsd), i
+        assert np.array_equal(a3, so.remap(f3))                 # in-place remap like the reference (:414)
+        assert np.array_equal(est.flat_feature, ref.flat_feature)
+        assert np.array_equal(est.flat_feature_2d, ref.flat_feature_2d)
+        assert list(est.scale_queue) == list(ref.scale_queue)
+
+
+def test_estimator_batch_equals_per_frame(gpu):
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    frames = [synth.synth_frame(i, 1200, base_seed=2718, upper_fraction=0.1) for i in range(20)]
+    est_a = ScaleEstimator(1.75, window_size=5, mutate_inputs=False)
+    est_b = ScaleEstimator(1.75, window_size=5, mutate_inputs=False)
+    seq = [est_a.scale_calculation(f3, f2) for f3, f2 in frames]
+    s1, d1 = est_b.scale_calculation_batch([f[0] for f in frames[:7]], [f[1] for f in frames[:7]])
+    s2, d2 = est_b.scale_calculation_batch([f[0] for f in frames[7:]], [f[1] for f in frames[7:]])
+    assert [x[0] for x in seq] == list(s1) + list(s2)
+    assert [x[1] for x in seq] == list(d1) + list(d2)
+    assert list(est_a.scale_queue) == list(est_b.scale_queue)
+
+
+def test_seq200_golden_through_driver(gpu):
+    """Config C1: the 200-frame golden of the reference through the main_offline-shaped driver,
+    per frame and batched."""
+    from mvoscalerecovery_amd import offline, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z, meta = load_npz("seq200.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    res = offline.run_sequence_batched(data, ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False,
+                                                            delaunay_workers=4))
+    assert np.array_equal(res["kinds"], z["kinds"])
+    np.testing.assert_array_equal(res["scales"], z["scales"])
+    np.testing.assert_array_equal(res["error"], z["error"])
+    np.testing.assert_array_equal(res["pitchs"], z["pitchs"])
+    head = {k: (v[:25] if k != "motions" else v[:25]) for k, v in data.items()}
+    res1 = offline.run_sequence(head, ScaleEstimator(meta["abs_ref"], window_size=meta["window"]))
+    np.testing.assert_array_equal(res1["scales"], z["scales"][:25])
