@@ -1,0 +1,95 @@
+"""Multi-GPU data parallelism over frames.
+
+The raw scale of a frame depends on that frame only (/root/reference/src/scale_calculator.py:411-422
+up to the filter), so a sequence shards into contiguous blocks of frames, one block per rank
+(one process per GPU).  The only cross-frame coupling — the window median of
+scale_calculator.py:396-400 — is a sliding-window function of the raw sequence, so it runs after
+ONE all-gather of the per-rank ``(raw_scale, status)`` arrays (RCCL over xGMI through
+``torch.distributed``'s ``nccl`` backend; ``gloo`` in CPU tests).  No halo, no all-reduce.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def partition(n_frames: int, world_size: int, rank: int):
+    """Contiguous block of rank ``rank``: the first ``n_frames % world_size`` ranks get one extra
+    frame.  Returns ``(start, stop)``."""
+    base, extra = divmod(n_frames, world_size)
+    start = rank * base + min(rank, extra)
+    stop = start + base + (1 if rank < extra else 0)
+    return start, stop
+
+
+def shard_sizes(n_frames: int, world_size: int):
+    return [partition(n_frames, world_size, r)[1] - partition(n_frames, world_size, r)[0] for r in range(world_size)]
+
+
+def all_gather_frames(local_raw, local_status, n_frames, group=None):
+    """All-gather the per-rank raw scales (float64) and statuses (int32) into the full-sequence
+    arrays, on whatever device the local tensors live on.  Shards are padded to the largest shard
+    so a single ``all_gather_into_tensor`` per array suffices; the padding is dropped afterwards.
+
+    ``local_raw`` / ``local_status`` are torch tensors of this rank's block (partition order).
+    Returns ``(raw[n_frames], status[n_frames])`` torch tensors.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(n_frames, world)
+    cap = max(sizes) if sizes else 0
+    dev = local_raw.device
+    # one 12-byte record per frame would need a struct dtype; two flat gathers are as cheap
+    pad_raw = torch.full((cap,), float("nan"), dtype=torch.float64, device=dev)
+    pad_st = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+    n_local = local_raw.shape[0]
+    pad_raw[:n_local] = local_raw
+    pad_st[:n_local] = local_status
+    all_raw = torch.empty((world * cap,), dtype=torch.float64, device=dev)
+    all_st = torch.empty((world * cap,), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(all_raw, pad_raw, group=group)
+    dist.all_gather_into_tensor(all_st, pad_st, group=group)
+    if all(s == cap for s in sizes):
+        return all_raw, all_st
+    keep = torch.cat([torch.arange(r * cap, r * cap + s, device=dev) for r, s in enumerate(sizes)])
+    return all_raw[keep], all_st[keep]
+
+
+def gather_and_filter(local_raw, local_status, n_frames, window, median_fn, queue=(), group=None):
+    """Gather the raw scales of all ranks and apply the window median to the whole sequence.
+
+    ``median_fn(raw_tensor, window, queue) -> filtered_tensor`` runs the K4 kernel (product) —
+    injected so that the CPU (gloo) tests can drive the same code with the oracle's filter."""
+    raw, status = all_gather_frames(local_raw, local_status, n_frames, group)
+    return median_fn(raw, window, queue), raw, status
+
+
+def make_gpu_median(engine):
+    """``median_fn`` backed by mvosr_window_median on torch CUDA tensors (zero-copy: the kernel
+    reads/writes the tensors' device memory on the stream the engine's context has adopted)."""
+    import torch
+
+    def fn(raw, window, queue=()):
+        out = torch.empty_like(raw)
+        engine.window_median(raw.data_ptr(), raw.numel(), window, queue, out.data_ptr())
+        return out
+    return fn
+
+
+def init_distributed(backend=None):
+    """Read RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment (torch.distributed.run)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world

@@ -69,7 +69,10 @@ def _assert_frame_equal(so, r, res, pf, f, check_stage=True):
         assert abs(res["height_level"][f] - r.height_level) <= 1e-13 * abs(r.height_level), f
     for name, want in (("height", r.height), ("raw_scale", r.raw_scale)):
         got = res[name][f]
-        assert (np.isnan(got) and np.isnan(want)) or got == want, (f, name, got, want)
+        if name == "raw_scale" and r.status == so.ST_NO_FLAT and not np.isnan(want):
+            assert abs(got - want) <= 1e-13 * abs(want), (f, got, want)      # ref/height_level, see above
+        else:
+            assert (np.isnan(got) and np.isnan(want)) or got == want, (f, name, got, want)
     if r.road is not None and "hist" in res:
         assert np.array_equal(res["hist"][f, 0], r.road.hist_raw), f
         assert np.array_equal(res["hist"][f, 1], r.road.hist), f
@@ -255,7 +258,12 @@ def test_frame_edge_cases(gpu):
         est = ScaleEstimator(1.75, window_size=5)
         s, sd = est.scale_calculation(f3.copy(), f2.copy())
         assert sd == c["std"], name
-        assert (np.isnan(s) and np.isnan(c["scale"])) or s == c["scale"], (name, s, c["scale"])
+        if c["n_flat"] is None and not np.isnan(c["scale"]):
+            # nothing selected: scale = ref/height_level (:421) — the one output that is not quantised;
+            # height_level is a mean over ~T heights whose summation order differs from NumPy's pairwise sum
+            assert abs(s - c["scale"]) <= 1e-13 * abs(c["scale"]), (name, s, c["scale"])
+        else:
+            assert (np.isnan(s) and np.isnan(c["scale"])) or s == c["scale"], (name, s, c["scale"])
         if np.isnan(c["height_level"]):
             assert np.isnan(est.height_level)
         else:

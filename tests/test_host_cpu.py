@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_lds_plan_three_frames_per_cu():
     from mvoscalerecovery_amd import _lib
     lib = _lib.load()
-    assert lib.mvosr_lds_bytes(2000) == 26 * 2000 + (2000 // 8 + 6) // 16 * 16 + 768 + 512 + 128 or lib.mvosr_lds_bytes(2000) < 54 * 1024
+    assert 26 * 2000 < lib.mvosr_lds_bytes(2000) < 54 * 1024        # 26 B per feature + ~1.5 KB
     assert 3 * lib.mvosr_lds_bytes(2000) <= 160 * 1024
     assert lib.mvosr_lds_bytes(300) < 10 * 1024
 
