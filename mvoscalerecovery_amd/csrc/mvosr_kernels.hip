@@ -126,10 +126,12 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gy
         const bool pb = (v0 - v2) * (d0 - d2) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
         const bool pc = (v1 - v2) * (d1 - d2) > 0.0;       // :109,:116
         const bool f0 = pa | pb, f1 = pa | pb | pc, f2 = pc;
+        // one wrap-around add per vertex: +-1 in the vertex's 16-bit half (the halves stay in
+        // [1, 0xFFFE], so a -1 never borrows across them)
         const uint32_t u0 = 1u << ((q.a & 1) * 16), u1 = 1u << ((q.b & 1) * 16), u2 = 1u << ((q.c & 1) * 16);
-        if (f0) atomicSub(&s.cm32[q.a >> 1], u0); else atomicAdd(&s.cm32[q.a >> 1], u0);
-        if (f1) atomicSub(&s.cm32[q.b >> 1], u1); else atomicAdd(&s.cm32[q.b >> 1], u1);
-        if (f2) atomicSub(&s.cm32[q.c >> 1], u2); else atomicAdd(&s.cm32[q.c >> 1], u2);
+        atomicAdd(&s.cm32[q.a >> 1], f0 ? 0u - u0 : u0);
+        atomicAdd(&s.cm32[q.b >> 1], f1 ? 0u - u1 : u1);
+        atomicAdd(&s.cm32[q.c >> 1], f2 ? 0u - u2 : u2);
     }
     __syncthreads();
 
@@ -171,6 +173,37 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gy
 // Phase B: plane normals / pitch / height over the second triangulation, height_level, and the
 // bit-set of selected (surviving-feature) indices.
 // ---------------------------------------------------------------------------------------------
+// The reference's own formulation of the per-triangle test (scale_calculator.py:229-239): LU solve
+// for the plane normal, normalise, asin, degrees, compare.  Bit 0: pitch < thr (flat), bit 1:
+// pitch >= thr, bit 2: exactly singular.  Not inlined in the product kernel, where it is the
+// cold path taken only inside the 1e-9 band around the threshold.
+template <bool INLINE>
+__device__ int pitch_reference_impl(double x0, double y0, double z0, double x1, double y1, double z1,
+                                    double x2, double y2, double z2, double thr_deg,
+                                    double &nx, double &ny, double &nz, double &pitch) {
+    int r = 0;
+    if (!plane_normal(x0, y0, z0, x1, y1, z1, x2, y2, z2, nx, ny, nz)) r |= 4;        // :229-230
+    const double len2 = (nx * nx + ny * ny) + nz * nz;                               // :231
+    const double len = sqrt(len2);
+    const double uy = ny / len;                                                      // :232
+    pitch = asin(-uy) * 180.0 / 3.141592653589793;                                   // :233
+    if (pitch < thr_deg) r |= 1;                                                     // :235
+    if (pitch >= thr_deg) r |= 2;                                                    // :239  (NaN: neither)
+    return r;
+}
+__device__ __attribute__((noinline)) int pitch_reference_cold(double x0, double y0, double z0, double x1, double y1, double z1,
+                                                              double x2, double y2, double z2, double thr_deg) {
+    double nx, ny, nz, pitch;
+    return pitch_reference_impl<false>(x0, y0, z0, x1, y1, z1, x2, y2, z2, thr_deg, nx, ny, nz, pitch);
+}
+template <bool FULL>
+__device__ __forceinline__ int pitch_reference(double x0, double y0, double z0, double x1, double y1, double z1,
+                                               double x2, double y2, double z2, double thr_deg,
+                                               double &nx, double &ny, double &nz, double &pitch) {
+    if constexpr (FULL) return pitch_reference_impl<true>(x0, y0, z0, x1, y1, z1, x2, y2, z2, thr_deg, nx, ny, nz, pitch);
+    else { nx = ny = nz = pitch = 0.0; return pitch_reference_cold(x0, y0, z0, x1, y1, z1, x2, y2, z2, thr_deg); }
+}
+
 struct SelectResult {
     double height_level;
     int n_pitch, n_tri_valid;
@@ -198,26 +231,39 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
         const double x0 = s.X[i0], y0 = s.Y[i0], z0 = s.Z[i0];
         const double x1 = s.X[i1], y1 = s.Y[i1], z1 = s.Z[i1];
         const double x2 = s.X[i2], y2 = s.Y[i2], z2 = s.Z[i2];
-        double nx, ny, nz;
-        if (!plane_normal(x0, y0, z0, x1, y1, z1, x2, y2, z2, nx, ny, nz)) singular = 1;      // :229-230
-        const double len2 = (nx * nx + ny * ny) + nz * nz;                                   // :231
         const double h = div3((y0 + y1) + y2);                                               // :238
-        bool is_flat, is_steep;
+        bool is_flat = false, is_steep = false;
         bool decided = false;
         if constexpr (!FULL) {
-            // pitch_deg < thr  <=>  n_y/|n| > sin(|thr|); only inside a 1e-9 band around the
-            // threshold does the outcome depend on how asin rounds, and there the full
-            // expression below is evaluated.
-            const double q2 = ny * ny;
-            if (ny > 0.0 && q2 > pt.s2_hi * len2) { is_flat = true; is_steep = false; decided = true; }
-            else if (ny <= 0.0 || q2 < pt.s2_lo * len2) { is_flat = false; is_steep = true; decided = true; }
+            // The plane n.p = 1 through the vertices has n = c / det with c = (p1-p0) x (p2-p0) and
+            // det = p0 . c, so  pitch_deg < thr  <=>  n_y/|n| > sin(|thr|)  <=>  c_y det > 0 and
+            // c_y^2 > sin^2(|thr|) |c|^2 : no division, square root or asin.  Only inside a 1e-9
+            // band around the threshold (where the outcome depends on how the LU solve and asin
+            // round), for needle triangles and when det is lost to cancellation (possible exact
+            // singularity) is the reference's own formulation evaluated below.
+            const double e1x = x1 - x0, e1y = y1 - y0, e1z = z1 - z0;
+            const double e2x = x2 - x0, e2y = y2 - y0, e2z = z2 - z0;
+            const double cx = __builtin_fma(e1y, e2z, -(e1z * e2y));
+            const double cy = __builtin_fma(e1z, e2x, -(e1x * e2z));
+            const double cz = __builtin_fma(e1x, e2y, -(e1y * e2x));
+            const double tx = x0 * cx, ty = y0 * cy, tz = z0 * cz;
+            const double det = (tx + ty) + tz;
+            const double mag = (fabs(tx) + fabs(ty)) + fabs(tz);
+            const double c2 = __builtin_fma(cz, cz, __builtin_fma(cy, cy, cx * cx));
+            const double l1 = __builtin_fma(e1z, e1z, __builtin_fma(e1y, e1y, e1x * e1x));
+            const double l2 = __builtin_fma(e2z, e2z, __builtin_fma(e2y, e2y, e2x * e2x));
+            const bool safe = (fabs(det) > 1e-9 * mag) && (c2 > 1e-14 * (l1 * l2));
+            const double q2 = cy * cy;
+            const double sy = cy * det;
+            if (safe && sy > 0.0 && q2 > pt.s2_hi * c2) { is_flat = true; decided = true; }
+            else if (safe && (sy <= 0.0 || q2 < pt.s2_lo * c2)) { is_steep = true; decided = true; }
         }
         if (!decided) {
-            const double len = sqrt(len2);
-            const double uy = ny / len;                                                      // :232
-            const double pitch = asin(-uy) * 180.0 / 3.141592653589793;                      // :233
-            is_flat = pitch < pt.thr_deg;                                                    // :235
-            is_steep = pitch >= pt.thr_deg;                                                  // :239  (NaN: neither)
+            double nx, ny, nz, pitch;
+            const int r = pitch_reference<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, pt.thr_deg, nx, ny, nz, pitch);
+            if (r & 4) singular = 1;
+            is_flat = r & 1;
+            is_steep = r & 2;
             if constexpr (FULL) {
                 if (g_normals) { double *o = g_normals + 3 * (t2_begin + t); o[0] = nx; o[1] = ny; o[2] = nz; }
                 if (g_pitch) g_pitch[t2_begin + t] = pitch;

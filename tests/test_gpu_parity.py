@@ -358,3 +358,25 @@ def test_seq200_golden_through_driver(gpu):
     head = {k: (v[:25] if k != "motions" else v[:25]) for k, v in data.items()}
     res1 = offline.run_sequence(head, ScaleEstimator(meta["abs_ref"], window_size=meta["window"]))
     np.testing.assert_array_equal(res1["scales"], z["scales"][:25])
+
+
+def test_seq4541_golden_batched(gpu):
+    """Config C3: KITTI-00-length (4541 frames) main_offline-shaped replay, ragged N (300-1500),
+    not-moving and too-few-feature frames; every filtered scale must equal the reference's
+    (north_star tolerance: 1e-4 relative; here exact, the outputs are quantised)."""
+    from mvoscalerecovery_amd import constants as K, offline, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z, meta = load_npz("seq4541.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, delaunay_workers=8)
+    res = offline.run_sequence_batched(data, est)
+    assert np.array_equal(res["kinds"], z["kinds"])
+    raw = est.last_raw_scale
+    nf = est.last_status == K.ST_NO_FLAT
+    assert np.array_equal(raw[~nf], z["raw_scales"][~nf])
+    np.testing.assert_allclose(raw[nf], z["raw_scales"][nf], rtol=1e-13)
+    rel = np.abs(res["scales"] - z["scales"]) / np.maximum(np.abs(z["scales"]), 1e-300)
+    assert np.nanmax(rel) <= 1e-4
+    assert np.count_nonzero(res["scales"] != z["scales"]) <= int(nf.sum()) * meta["window"]
+    np.testing.assert_array_equal(res["error"], z["error"])
+    np.testing.assert_array_equal(res["pitchs"], z["pitchs"])

@@ -202,3 +202,12 @@ def test_seq200_golden():
     np.testing.assert_array_equal(res["scales"], z["scales"])
     np.testing.assert_array_equal(res["error"], z["error"])
     np.testing.assert_array_equal(res["pitchs"], z["pitchs"])
+
+
+def test_seq4541_golden():
+    """Config C3 shape: 4541-frame main_offline replay (ragged N, not-moving and too-few frames)."""
+    z, res, raws = _run_oracle_sequence("seq4541.npz")
+    assert np.array_equal(res["kinds"], z["kinds"])
+    np.testing.assert_array_equal(raws, z["raw_scales"])
+    np.testing.assert_array_equal(res["scales"], z["scales"])
+    np.testing.assert_array_equal(res["error"], z["error"])
