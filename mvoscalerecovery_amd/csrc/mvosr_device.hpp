@@ -47,34 +47,34 @@ __device__ __forceinline__ int wave_or(int v) {
 }
 
 // ---- block reductions over WAVES wavefronts, fixed order => run-to-run bit-identical ---------
-// `red` points at >= 2*WAVES doubles of LDS scratch.  Two barriers per call when WAVES > 1.
+// Every call site owns its own scratch slot (2*WAVES doubles) and a workgroup handles exactly
+// one frame, so a slot is written once: ONE barrier per reduction, none to protect reuse.
 template <int WAVES>
-__device__ __forceinline__ void block_sum2(double &a, double &b, double *red) {
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *slot) {
     a = wave_sum(a);
     b = wave_sum(b);
     if constexpr (WAVES > 1) {
         const int w = wave_id();
-        if (lane_id() == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+        if (lane_id() == 0) { slot[2 * w] = a; slot[2 * w + 1] = b; }
         __syncthreads();
         double ta = 0.0, tb = 0.0;
 #pragma unroll
-        for (int i = 0; i < WAVES; ++i) { ta += red[2 * i]; tb += red[2 * i + 1]; }
-        __syncthreads();
+        for (int i = 0; i < WAVES; ++i) { ta += slot[2 * i]; tb += slot[2 * i + 1]; }
         a = ta; b = tb;
     }
 }
-// four int counters at once (`red` reinterpreted: >= 4*WAVES ints)
+// four int counters at once (`slot` reinterpreted: 4*WAVES ints = 2*WAVES doubles)
 template <int WAVES>
-__device__ __forceinline__ void block_sum4i(int &a, int &b, int &c, int &d, int *red) {
+__device__ __forceinline__ void block_sum4i(int &a, int &b, int &c, int &d, double *slot_d) {
+    int *slot = reinterpret_cast<int *>(slot_d);
     a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
     if constexpr (WAVES > 1) {
         const int w = wave_id();
-        if (lane_id() == 0) { red[4 * w] = a; red[4 * w + 1] = b; red[4 * w + 2] = c; red[4 * w + 3] = d; }
+        if (lane_id() == 0) { slot[4 * w] = a; slot[4 * w + 1] = b; slot[4 * w + 2] = c; slot[4 * w + 3] = d; }
         __syncthreads();
         int ta = 0, tb = 0, tc = 0, td = 0;
 #pragma unroll
-        for (int i = 0; i < WAVES; ++i) { ta += red[4 * i]; tb += red[4 * i + 1]; tc += red[4 * i + 2]; td += red[4 * i + 3]; }
-        __syncthreads();
+        for (int i = 0; i < WAVES; ++i) { ta += slot[4 * i]; tb += slot[4 * i + 1]; tc += slot[4 * i + 2]; td += slot[4 * i + 3]; }
         a = ta; b = tb; c = tc; d = td;
     }
 }
@@ -84,6 +84,11 @@ struct Bits192 {
     unsigned long long w[3];
     __device__ __forceinline__ bool any() const { return (w[0] | w[1] | w[2]) != 0ull; }
     __device__ __forceinline__ bool test(int i) const {
+        const unsigned long long x = i < 64 ? w[0] : (i < 128 ? w[1] : w[2]);
+        return (x >> (i & 63)) & 1ull;
+    }
+    // per-lane test of a lane-varying index in 0..191 (branch-free)
+    __device__ __forceinline__ bool test_lane(int i) const {
         const unsigned long long x = i < 64 ? w[0] : (i < 128 ? w[1] : w[2]);
         return (x >> (i & 63)) & 1ull;
     }
@@ -127,12 +132,14 @@ struct Bits192 {
 __device__ __forceinline__ double bin_edge(int k) { return (double)k * 0.1; }
 
 // np.histogram(y, bins=edges) bin of y: edges[k] <= y < edges[k+1], last bin closed, -1 outside.
+// floor(10 y) is off by at most one bin from the bin defined by the edges k*0.1 (one rounding in
+// 10*y, one in k*0.1), so one correction step each way settles it, branch-free.
 __device__ __forceinline__ int bin_of(double y) {
     if (!(y >= 0.0 && y <= bin_edge(kBins))) return -1;
     int k = (int)(y * 10.0);
-    if (k > kBins - 1) k = kBins - 1;
-    while (k < kBins - 1 && y >= bin_edge(k + 1)) ++k;
-    while (k > 0 && y < bin_edge(k)) --k;
+    k = min(k, kBins - 1);
+    k += (k < kBins - 1 && y >= bin_edge(k + 1)) ? 1 : 0;
+    k -= (k > 0 && y < bin_edge(k)) ? 1 : 0;
     return k;
 }
 

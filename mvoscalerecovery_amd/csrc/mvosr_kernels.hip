@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/mvosr.h"
@@ -30,6 +31,22 @@
 
 namespace mvosr {
 
+// Diagnostic build only (-DMVOSR_STAMPS): thread 0 of every workgroup records s_memtime at the
+// phase boundaries and dumps the stamps over the frame's `hist` debug output.  Never defined in
+// the shipped library.
+#ifdef MVOSR_STAMPS
+__device__ unsigned long long g_stamp_dummy;
+#define MVOSR_STAMP(i) do { if (threadIdx.x == 0 && stamps) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MVOSR_STAMP_DECL unsigned long long stamps[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define MVOSR_STAMP_ARG , unsigned long long *stamps = nullptr
+#define MVOSR_STAMP_PASS , stamps
+#else
+#define MVOSR_STAMP(i) do {} while (0)
+#define MVOSR_STAMP_DECL
+#define MVOSR_STAMP_ARG
+#define MVOSR_STAMP_PASS
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // LDS carve-up (byte offsets, all multiples of 16)
 // ---------------------------------------------------------------------------------------------
@@ -37,7 +54,9 @@ struct LdsPlan {
     uint32_t x, y, z, cm, sel, hist, red, misc, total;
 };
 __host__ __device__ inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
-__host__ __device__ inline LdsPlan lds_plan(int n) {
+constexpr int kRedSlots = 6;                       // one scratch slot per block reduction site
+enum { R_SEL_H = 0, R_SEL_CNT = 1, R_ROAD_N = 2, R_ROAD_SUM = 3, R_ROAD_SS = 4, R_MISC = 5 };
+__host__ __device__ inline LdsPlan lds_plan(int n, int waves) {
     LdsPlan p;
     const uint32_t npad = (uint32_t)((n + 1) & ~1);
     p.x = 0;
@@ -46,8 +65,8 @@ __host__ __device__ inline LdsPlan lds_plan(int n) {
     p.cm = p.z + 8u * npad;                       // 16-bit counter / map per feature
     p.sel = align16(p.cm + 2u * npad);            // selected bit-set, one bit per surviving feature
     p.hist = align16(p.sel + 4u * ((uint32_t)(n + 31) / 32u));
-    p.red = p.hist + 4u * 192u;                   // 169 bins (+pad)
-    p.misc = p.red + 8u * 64u;                    // reduction scratch: 64 doubles
+    p.red = p.hist + 4u * 176u;                   // 169 bins (+pad)
+    p.misc = p.red + 8u * (uint32_t)(kRedSlots * 2 * waves);   // reduction scratch: 2*waves doubles per site
     p.total = p.misc + 4u * 32u;                  // 32 ints of per-frame scalars
     return p;
 }
@@ -61,8 +80,8 @@ struct Smem {
     double *red;
     int *misc;
 };
-__device__ __forceinline__ Smem carve(char *base, int n) {
-    const LdsPlan p = lds_plan(n);
+__device__ __forceinline__ Smem carve(char *base, int n, int waves) {
+    const LdsPlan p = lds_plan(n, waves);
     Smem s;
     s.X = reinterpret_cast<double *>(base + p.x);
     s.Y = reinterpret_cast<double *>(base + p.y);
@@ -88,52 +107,117 @@ __device__ __forceinline__ TriIds load_tri(const int32_t *tri, int64_t t) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Phase A: stage v, y', z' and run the depth-order vote over the first triangulation.
-// On return (after the trailing barrier) cm[j] = index of the j-th surviving feature and the
-// return value is the number of survivors.  `bad` is set when a vertex id is out of range.
+// Triangle ids are streamed in chunks of kTC triangles per thread: all loads of a chunk are in
+// flight together (a wave then has 8 x 768 B outstanding instead of one 768-B load per loop trip),
+// which is what keeps HBM busy — the sweeps are latency-bound otherwise.
+// ---------------------------------------------------------------------------------------------
+#ifndef MVOSR_TC
+#define MVOSR_TC 2
+#endif
+constexpr int kTC = MVOSR_TC;   // triangles per thread per chunk (3 VGPRs each)
+constexpr int kXC = 2;      // double2 x values per thread prefetched during the vote
+
+template <int B>
+struct TriChunk {
+    TriIds q[kTC];
+    __device__ __forceinline__ void load(const int32_t *tri, int64_t begin, int count, int base, int tid) {
+#pragma unroll
+        for (int k = 0; k < kTC; ++k) {
+            const int t = base + k * B + tid;
+            if (t < count) q[k] = load_tri(tri, begin + t);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Phase A: stage v, y', z' and run the depth-order vote over the first triangulation; then x
+// replaces v in LDS.  On return (after the trailing barrier) cm[j] = index of the j-th surviving
+// feature and the return value is the number of survivors.  `bad` is set when a vertex id is out
+// of range.  When tri2 is given, its first chunk is put in flight before the compaction barriers
+// and handed back in `next`.
 // ---------------------------------------------------------------------------------------------
 template <int WAVES>
-__device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gy, const double *gz, const double *gv,
-                                          const int32_t *tri1, int64_t t1_begin, int t1_count, double cp, double sp,
-                                          int32_t *g_counters, int &bad) {
+__device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx, const double *gy, const double *gz,
+                                          const double *gv, const int32_t *tri1, int64_t t1_begin, int t1_count,
+                                          double cp, double sp, int32_t *g_counters, int &bad,
+                                          const int32_t *tri2, int64_t t2_begin, int t2_count, TriChunk<WAVES * kWave> &next, int dbg = 0 MVOSR_STAMP_ARG) {
     constexpr int B = WAVES * kWave;
     const int tid = threadIdx.x;
     const int npad2 = (n + 1) >> 1;
-    // planes are 16-byte aligned per frame: two features per lane and load
+    TriChunk<B> tc;
+    tc.load(tri1, t1_begin, t1_count, 0, tid);          // in flight while the features stream in
+    // planes are 16-byte aligned per frame: two features per lane and load, two loads per plane in flight
     const double2 *gy2 = reinterpret_cast<const double2 *>(gy);
     const double2 *gz2 = reinterpret_cast<const double2 *>(gz);
     const double2 *gv2 = reinterpret_cast<const double2 *>(gv);
+    const double2 *gx2 = reinterpret_cast<const double2 *>(gx);
     double2 *sY2 = reinterpret_cast<double2 *>(s.Y);
     double2 *sZ2 = reinterpret_cast<double2 *>(s.Z);
     double2 *sX2 = reinterpret_cast<double2 *>(s.X);
-    for (int i = tid; i < npad2; i += B) {
-        const double2 yy = gy2[i], zz = gz2[i], vv = gv2[i];
+    const uint32_t ones = ((uint32_t)(kCounterBias + 1) << 16) | (uint32_t)(kCounterBias + 1);     // np.ones, :153
+    for (int i0 = tid; i0 < npad2; i0 += 2 * B) {
+        const int i1 = i0 + B;
+        const bool two = i1 < npad2;
+        const double2 ya = gy2[i0], za = gz2[i0], va = gv2[i0];
+        double2 yb = ya, zb = za, vb = va;
+        if (two) { yb = gy2[i1]; zb = gz2[i1]; vb = gv2[i1]; }
         double2 yr, zr;
-        yr.x = yy.x * cp - zz.x * sp;  yr.y = yy.y * cp - zz.y * sp;      // :391
-        zr.x = yy.x * sp + zz.x * cp;  zr.y = yy.y * sp + zz.y * cp;      // :392
-        sY2[i] = yr; sZ2[i] = zr; sX2[i] = vv;
-        s.cm32[i] = ((uint32_t)(kCounterBias + 1) << 16) | (uint32_t)(kCounterBias + 1);   // np.ones, :153
+        yr.x = ya.x * cp - za.x * sp;  yr.y = ya.y * cp - za.y * sp;      // :391
+        zr.x = ya.x * sp + za.x * cp;  zr.y = ya.y * sp + za.y * cp;      // :392
+        sY2[i0] = yr; sZ2[i0] = zr; sX2[i0] = va; s.cm32[i0] = ones;
+        if (two) {
+            yr.x = yb.x * cp - zb.x * sp;  yr.y = yb.y * cp - zb.y * sp;
+            zr.x = yb.x * sp + zb.x * cp;  zr.y = yb.y * sp + zb.y * cp;
+            sY2[i1] = yr; sZ2[i1] = zr; sX2[i1] = vb; s.cm32[i1] = ones;
+        }
     }
     __syncthreads();
+    MVOSR_STAMP(1);
+
+    // x is needed only after the vote: fetch it now, park it in registers
+    double2 xr[kXC];
+#pragma unroll
+    for (int k = 0; k < kXC; ++k) {
+        const int i = k * B + tid;
+        if (gx && i < npad2) xr[k] = gx2[i];
+    }
 
     // the vote: +1 on a vertex the triangle does not flag, -1 on one it flags (:160-163)
-    for (int t = tid; t < t1_count; t += B) {
-        const TriIds q = load_tri(tri1, t1_begin + t);
-        if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
-        const double v0 = s.X[q.a], v1 = s.X[q.b], v2 = s.X[q.c];
-        const double d0 = s.Z[q.a], d1 = s.Z[q.b], d2 = s.Z[q.c];
-        const bool pa = (v0 - v1) * (d0 - d1) > 0.0;       // :107,:110
-        const bool pb = (v0 - v2) * (d0 - d2) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
-        const bool pc = (v1 - v2) * (d1 - d2) > 0.0;       // :109,:116
-        const bool f0 = pa | pb, f1 = pa | pb | pc, f2 = pc;
-        // one wrap-around add per vertex: +-1 in the vertex's 16-bit half (the halves stay in
-        // [1, 0xFFFE], so a -1 never borrows across them)
-        const uint32_t u0 = 1u << ((q.a & 1) * 16), u1 = 1u << ((q.b & 1) * 16), u2 = 1u << ((q.c & 1) * 16);
-        atomicAdd(&s.cm32[q.a >> 1], f0 ? 0u - u0 : u0);
-        atomicAdd(&s.cm32[q.b >> 1], f1 ? 0u - u1 : u1);
-        atomicAdd(&s.cm32[q.c >> 1], f2 ? 0u - u2 : u2);
+    for (int base = 0; base < ((dbg & 1) ? 0 : t1_count); base += kTC * B) {
+        if (base > 0) tc.load(tri1, t1_begin, t1_count, base, tid);
+#pragma unroll
+        for (int k = 0; k < kTC; ++k) {
+            const int t = base + k * B + tid;
+            if (t >= t1_count) continue;
+            const TriIds q = tc.q[k];
+            if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
+            const double v0 = s.X[q.a], v1 = s.X[q.b], v2 = s.X[q.c];
+            const double d0 = s.Z[q.a], d1 = s.Z[q.b], d2 = s.Z[q.c];
+            const bool pa = (v0 - v1) * (d0 - d1) > 0.0;       // :107,:110
+            const bool pb = (v0 - v2) * (d0 - d2) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
+            const bool pc = (v1 - v2) * (d1 - d2) > 0.0;       // :109,:116
+            const bool f0 = pa | pb, f1 = pa | pb | pc, f2 = pc;
+            // one wrap-around add per vertex: +-1 in the vertex's 16-bit half (the halves stay in
+            // [1, 0xFFFE], so a -1 never borrows across them)
+            const uint32_t u0 = 1u << ((q.a & 1) * 16), u1 = 1u << ((q.b & 1) * 16), u2 = 1u << ((q.c & 1) * 16);
+            atomicAdd(&s.cm32[q.a >> 1], f0 ? 0u - u0 : u0);
+            atomicAdd(&s.cm32[q.b >> 1], f1 ? 0u - u1 : u1);
+            atomicAdd(&s.cm32[q.c >> 1], f2 ? 0u - u2 : u2);
+        }
     }
+    if (tri2) next.load(tri2, t2_begin, t2_count, 0, tid);   // lands while the survivors are compacted
     __syncthreads();
+    MVOSR_STAMP(2);
+
+    // v is dead: x takes its plane
+    if (gx) {
+#pragma unroll
+        for (int k = 0; k < kXC; ++k) {
+            const int i = k * B + tid;
+            if (i < npad2) sX2[i] = xr[k];
+        }
+        for (int i = kXC * B + tid; i < npad2; i += B) sX2[i] = gx2[i];
+    }
 
     // compaction: every wave owns a contiguous slice of the features; survivors keep their order
     const int w = wave_id(), lane = lane_id();
@@ -166,6 +250,7 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gy
         base += __popcll(m);
     }
     __syncthreads();
+    MVOSR_STAMP(3);
     return total;
 }
 
@@ -217,80 +302,98 @@ struct PitchTest {
 
 template <int WAVES, bool FULL>
 __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid, const int32_t *tri2, int64_t t2_begin,
-                                                     int t2_count, PitchTest pt, double *g_normals, double *g_pitch,
-                                                     double *g_heights) {
+                                                     int t2_count, TriChunk<WAVES * kWave> &tc, PitchTest pt,
+                                                     double *g_normals, double *g_pitch, double *g_heights, int bad_in, int dbg = 0 MVOSR_STAMP_ARG) {
     constexpr int B = WAVES * kWave;
     const int tid = threadIdx.x;
-    unsigned long long flat = 0ull;          // bit k: my k-th triangle has pitch_deg < thr
+    unsigned long long flat = 0ull;          // bit kk: my kk-th triangle has pitch_deg < thr
     double hsum = 0.0, hcnt = 0.0;
     int npitch = 0, singular = 0, bad = 0;
-    for (int k = 0, t = tid; t < t2_count; t += B, ++k) {
-        const TriIds q = load_tri(tri2, t2_begin + t);
-        if ((unsigned)q.a >= (unsigned)n_valid || (unsigned)q.b >= (unsigned)n_valid || (unsigned)q.c >= (unsigned)n_valid) { bad = 1; continue; }
-        const int i0 = s.cm[q.a], i1 = s.cm[q.b], i2 = s.cm[q.c];
-        const double x0 = s.X[i0], y0 = s.Y[i0], z0 = s.Z[i0];
-        const double x1 = s.X[i1], y1 = s.Y[i1], z1 = s.Z[i1];
-        const double x2 = s.X[i2], y2 = s.Y[i2], z2 = s.Z[i2];
-        const double h = div3((y0 + y1) + y2);                                               // :238
-        bool is_flat = false, is_steep = false;
-        bool decided = false;
-        if constexpr (!FULL) {
-            // The plane n.p = 1 through the vertices has n = c / det with c = (p1-p0) x (p2-p0) and
-            // det = p0 . c, so  pitch_deg < thr  <=>  n_y/|n| > sin(|thr|)  <=>  c_y det > 0 and
-            // c_y^2 > sin^2(|thr|) |c|^2 : no division, square root or asin.  Only inside a 1e-9
-            // band around the threshold (where the outcome depends on how the LU solve and asin
-            // round), for needle triangles and when det is lost to cancellation (possible exact
-            // singularity) is the reference's own formulation evaluated below.
-            const double e1x = x1 - x0, e1y = y1 - y0, e1z = z1 - z0;
-            const double e2x = x2 - x0, e2y = y2 - y0, e2z = z2 - z0;
-            const double cx = __builtin_fma(e1y, e2z, -(e1z * e2y));
-            const double cy = __builtin_fma(e1z, e2x, -(e1x * e2z));
-            const double cz = __builtin_fma(e1x, e2y, -(e1y * e2x));
-            const double tx = x0 * cx, ty = y0 * cy, tz = z0 * cz;
-            const double det = (tx + ty) + tz;
-            const double mag = (fabs(tx) + fabs(ty)) + fabs(tz);
-            const double c2 = __builtin_fma(cz, cz, __builtin_fma(cy, cy, cx * cx));
-            const double l1 = __builtin_fma(e1z, e1z, __builtin_fma(e1y, e1y, e1x * e1x));
-            const double l2 = __builtin_fma(e2z, e2z, __builtin_fma(e2y, e2y, e2x * e2x));
-            const bool safe = (fabs(det) > 1e-9 * mag) && (c2 > 1e-14 * (l1 * l2));
-            const double q2 = cy * cy;
-            const double sy = cy * det;
-            if (safe && sy > 0.0 && q2 > pt.s2_hi * c2) { is_flat = true; decided = true; }
-            else if (safe && (sy <= 0.0 || q2 < pt.s2_lo * c2)) { is_steep = true; decided = true; }
-        }
-        if (!decided) {
-            double nx, ny, nz, pitch;
-            const int r = pitch_reference<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, pt.thr_deg, nx, ny, nz, pitch);
-            if (r & 4) singular = 1;
-            is_flat = r & 1;
-            is_steep = r & 2;
-            if constexpr (FULL) {
-                if (g_normals) { double *o = g_normals + 3 * (t2_begin + t); o[0] = nx; o[1] = ny; o[2] = nz; }
-                if (g_pitch) g_pitch[t2_begin + t] = pitch;
-                if (g_heights) g_heights[t2_begin + t] = h;
+    // `tc` arrives with the first chunk of tri2 already loaded (phase_vote)
+    for (int base = 0; base < ((dbg & 2) ? 0 : t2_count); base += kTC * B) {
+        if (base > 0) tc.load(tri2, t2_begin, t2_count, base, tid);
+#pragma unroll
+        for (int k = 0; k < kTC; ++k) {
+            const int t = base + k * B + tid;
+            if (t >= t2_count) continue;
+            const int kk = base / B + k;
+            const TriIds q = tc.q[k];
+            if ((unsigned)q.a >= (unsigned)n_valid || (unsigned)q.b >= (unsigned)n_valid || (unsigned)q.c >= (unsigned)n_valid) { bad = 1; continue; }
+            const int i0 = s.cm[q.a], i1 = s.cm[q.b], i2 = s.cm[q.c];
+            const double x0 = s.X[i0], y0 = s.Y[i0], z0 = s.Z[i0];
+            const double x1 = s.X[i1], y1 = s.Y[i1], z1 = s.Z[i1];
+            const double x2 = s.X[i2], y2 = s.Y[i2], z2 = s.Z[i2];
+            const double h = div3((y0 + y1) + y2);                                               // :238
+            bool is_flat = false, is_steep = false;
+            bool decided = false;
+            if constexpr (!FULL) {
+                // The plane n.p = 1 through the vertices has n = c / det with c = (p1-p0) x (p2-p0) and
+                // det = p0 . c, so  pitch_deg < thr  <=>  n_y/|n| > sin(|thr|)  <=>  c_y det > 0 and
+                // c_y^2 > sin^2(|thr|) |c|^2 : no division, square root or asin.  Only inside a 1e-9
+                // band around the threshold (where the outcome depends on how the LU solve and asin
+                // round), for needle triangles and when det is lost to cancellation (possible exact
+                // singularity) is the reference's own formulation evaluated below.
+                const double e1x = x1 - x0, e1y = y1 - y0, e1z = z1 - z0;
+                const double e2x = x2 - x0, e2y = y2 - y0, e2z = z2 - z0;
+                const double cx = __builtin_fma(e1y, e2z, -(e1z * e2y));
+                const double cy = __builtin_fma(e1z, e2x, -(e1x * e2z));
+                const double cz = __builtin_fma(e1x, e2y, -(e1y * e2x));
+                const double tx = x0 * cx, ty = y0 * cy, tz = z0 * cz;
+                const double det = (tx + ty) + tz;
+                const double mag = (fabs(tx) + fabs(ty)) + fabs(tz);
+                const double c2 = __builtin_fma(cz, cz, __builtin_fma(cy, cy, cx * cx));
+                const double l1 = __builtin_fma(e1z, e1z, __builtin_fma(e1y, e1y, e1x * e1x));
+                const double l2 = __builtin_fma(e2z, e2z, __builtin_fma(e2y, e2y, e2x * e2x));
+                const bool safe = (fabs(det) > 1e-9 * mag) && (c2 > 1e-14 * (l1 * l2));
+                const double q2 = cy * cy;
+                const double sy = cy * det;
+                if (safe && sy > 0.0 && q2 > pt.s2_hi * c2) { is_flat = true; decided = true; }
+                else if (safe && (sy <= 0.0 || q2 < pt.s2_lo * c2)) { is_steep = true; decided = true; }
             }
+            if (!decided) {
+                double nx, ny, nz, pitch;
+                const int r = pitch_reference<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, pt.thr_deg, nx, ny, nz, pitch);
+                if (r & 4) singular = 1;
+                is_flat = r & 1;
+                is_steep = r & 2;
+                if constexpr (FULL) {
+                    if (g_normals) { double *o = g_normals + 3 * (t2_begin + t); o[0] = nx; o[1] = ny; o[2] = nz; }
+                    if (g_pitch) g_pitch[t2_begin + t] = pitch;
+                    if (g_heights) g_heights[t2_begin + t] = h;
+                }
+            }
+            if (is_steep) { hsum += h; hcnt += 1.0; }                                            // :240
+            if (is_flat) { flat |= 1ull << kk; ++npitch; }
         }
-        if (is_steep) { hsum += h; hcnt += 1.0; }                                            // :240
-        if (is_flat) { flat |= 1ull << k; ++npitch; }
     }
-    block_sum2<WAVES>(hsum, hcnt, s.red);
+    block_sum2<WAVES>(hsum, hcnt, s.red + R_SEL_H * 2 * WAVES);
+    MVOSR_STAMP(4);
     SelectResult r;
     r.height_level = hsum / hcnt;                 // np.mean of an empty set -> 0/0 = NaN, like :240
     const double hl = r.height_level;
     int ntv = 0;
-    for (int k = 0, t = tid; t < t2_count; t += B, ++k) {
-        if (!((flat >> k) & 1ull)) continue;
-        const TriIds q = load_tri(tri2, t2_begin + t);
-        const double y0 = s.Y[s.cm[q.a]], y1 = s.Y[s.cm[q.b]], y2 = s.Y[s.cm[q.c]];
-        const double h = div3((y0 + y1) + y2);
-        if (h > hl) {                                                                        // :243-244
-            ++ntv;
-            atomicOr(&s.sel[q.a >> 5], 1u << (q.a & 31));                                    // :247
-            atomicOr(&s.sel[q.b >> 5], 1u << (q.b & 31));
-            atomicOr(&s.sel[q.c >> 5], 1u << (q.c & 31));
+    const bool in_regs = t2_count <= kTC * B;     // the usual case: the ids are still in registers
+    for (int base = 0; base < ((dbg & 4) ? 0 : t2_count); base += kTC * B) {
+        if (!in_regs) tc.load(tri2, t2_begin, t2_count, base, tid);
+#pragma unroll
+        for (int k = 0; k < kTC; ++k) {
+            const int t = base + k * B + tid;
+            const int kk = base / B + k;
+            if (t >= t2_count || !((flat >> kk) & 1ull)) continue;
+            const TriIds q = tc.q[k];
+            const double y0 = s.Y[s.cm[q.a]], y1 = s.Y[s.cm[q.b]], y2 = s.Y[s.cm[q.c]];
+            const double h = div3((y0 + y1) + y2);
+            if (h > hl) {                                                                        // :243-244
+                ++ntv;
+                atomicOr(&s.sel[q.a >> 5], 1u << (q.a & 31));                                    // :247
+                atomicOr(&s.sel[q.b >> 5], 1u << (q.b & 31));
+                atomicOr(&s.sel[q.c >> 5], 1u << (q.c & 31));
+            }
         }
     }
-    block_sum4i<WAVES>(npitch, ntv, singular, bad, reinterpret_cast<int *>(s.red));   // also orders the atomicOr's
+    bad |= bad_in;
+    block_sum4i<WAVES>(npitch, ntv, singular, bad, s.red + R_SEL_CNT * 2 * WAVES);   // also orders the atomicOr's
+    MVOSR_STAMP(5);
     r.n_pitch = npitch; r.n_tri_valid = ntv; r.singular = singular; r.bad = bad;
     return r;
 }
@@ -307,41 +410,63 @@ struct RoadResult {
 };
 
 // is y inside the interval remove_single deletes for a single-count bin? (:284-293)
-__device__ __forceinline__ bool dropped_by_single(double y, const int *hist, int first_single) {
+// `single` = the bins whose raw count is exactly 1 (wave-uniform bit-set).
+__device__ __forceinline__ bool dropped_by_single(double y, const Bits192 &single, int first_single) {
     if (first_single < 0 || !(y > -1.0 && y < 18.0)) return false;
     int kb = (int)(y * 10.0);
     kb = max(0, min(kBins - 1, kb));
-    for (int k = max(0, kb - 1); k <= min(kBins - 1, kb + 1); ++k) {
-        if (hist[k] != 1) continue;
+    bool d = false;
+#pragma unroll
+    for (int dk = -1; dk <= 1; ++dk) {
+        const int k = kb + dk;
+        const bool is_single = (k >= 0) && (k < kBins) && single.test_lane(max(k, 0));
         const double r = bin_edge(k + 1);
         const double lo = r - 0.1;                          // bin_single-0.1, not the bin's own left edge
         const bool in = (k == first_single) ? (y >= lo && y <= r) : (y > lo && y <= r);
-        if (in) return true;
+        d |= is_single && in;
     }
-    return false;
+    return d;
 }
+
+constexpr int kRC = 4;      // road-model candidates per thread kept in registers across the passes
 
 template <int WAVES, typename Fetch>
 __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetch fetch, double height_level,
                                                  const mvosr_params &P, double *list /* >= n_cand doubles of LDS, free */,
-                                                 int32_t *g_hist) {
+                                                 int32_t *g_hist MVOSR_STAMP_ARG) {
     constexpr int B = WAVES * kWave;
     const int tid = threadIdx.x, lane = lane_id();
     RoadResult R;
     R.height = nan(""); R.status = MVOSR_ST_MODE; R.n_modes = 0; R.mode_left = -1; R.mode_right = -1;
     R.mean = R.std = R.skew = R.median = nan("");
 
-    // histogram (np.histogram, :326); hist[] was zeroed by the caller before a barrier
+    // histogram (np.histogram, :326); hist[] was zeroed by the caller before a barrier.
+    // The first kRC candidates of every thread stay in registers for the later passes.
+    double yc[kRC];
+    unsigned have = 0u, kept = 0u;
     int nsel = 0;
-    for (int j = tid; j < n_cand; j += B) {
+#pragma unroll
+    for (int k = 0; k < kRC; ++k) {
+        const int j = k * B + tid;
+        double y = 0.0;
+        if (j < n_cand && fetch(j, y)) {
+            have |= 1u << k;
+            ++nsel;
+            const int bin = bin_of(y);
+            if (bin >= 0) atomicAdd(&s.hist[bin], 1);
+        }
+        yc[k] = y;
+    }
+    for (int j = kRC * B + tid; j < n_cand; j += B) {
         double y;
         if (!fetch(j, y)) continue;
         ++nsel;
-        const int k = bin_of(y);
-        if (k >= 0) atomicAdd(&s.hist[k], 1);
+        const int bin = bin_of(y);
+        if (bin >= 0) atomicAdd(&s.hist[bin], 1);
     }
     int d0 = 0, d1 = 0, d2 = 0;
-    block_sum4i<WAVES>(nsel, d0, d1, d2, reinterpret_cast<int *>(s.red));    // barrier: histogram complete
+    block_sum4i<WAVES>(nsel, d0, d1, d2, s.red + R_ROAD_N * 2 * WAVES);    // barrier: histogram complete
+    MVOSR_STAMP(6);
     R.n_sel = nsel;
     if (nsel == 0) { R.status = MVOSR_ST_NO_FLAT; R.n_kept = 0; return R; }
 
@@ -394,18 +519,28 @@ __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetc
     const bool have_modes = (mx > P.mode_min) && modes.any();                   // :451-452
     R.n_modes = have_modes ? modes.runs() : 0;                                  // :468-481 (edges 0.1 apart cluster, gap < 0.11)
 
-    // pass over the selected points again: drop those inside a single bin's interval, accumulate the mean
+    // second pass: drop the points inside a single bin's interval (:284-293), accumulate the mean
     double sum = 0.0, cntd = 0.0;
     if (!have_modes && tid == 0) s.misc[M_LIST] = 0;
     if (!have_modes) __syncthreads();
-    for (int j = tid; j < n_cand; j += B) {
-        double y;
-        if (!fetch(j, y)) continue;
-        if (dropped_by_single(y, s.hist, first_single)) continue;
+#pragma unroll
+    for (int k = 0; k < kRC; ++k) {
+        if (!((have >> k) & 1u)) continue;
+        const double y = yc[k];
+        if (dropped_by_single(y, single, first_single)) continue;
+        kept |= 1u << k;
         sum += y; cntd += 1.0;
         if (!have_modes) list[atomicAdd(&s.misc[M_LIST], 1)] = y;              // only the median needs the values
     }
-    block_sum2<WAVES>(sum, cntd, s.red);
+    for (int j = kRC * B + tid; j < n_cand; j += B) {
+        double y;
+        if (!fetch(j, y)) continue;
+        if (dropped_by_single(y, single, first_single)) continue;
+        sum += y; cntd += 1.0;
+        if (!have_modes) list[atomicAdd(&s.misc[M_LIST], 1)] = y;
+    }
+    block_sum2<WAVES>(sum, cntd, s.red + R_ROAD_SUM * 2 * WAVES);
+    MVOSR_STAMP(7);
     const int nkept = (int)cntd;
     R.n_kept = nkept;
 
@@ -445,14 +580,21 @@ __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetc
 
     const double mean = sum / cntd;                                             // np.mean, :496
     double ss = 0.0, dummy = 0.0;
-    for (int j = tid; j < n_cand; j += B) {
+#pragma unroll
+    for (int k = 0; k < kRC; ++k) {
+        if (!((kept >> k) & 1u)) continue;
+        const double d = yc[k] - mean;
+        ss += d * d;
+    }
+    for (int j = kRC * B + tid; j < n_cand; j += B) {
         double y;
         if (!fetch(j, y)) continue;
-        if (dropped_by_single(y, s.hist, first_single)) continue;
+        if (dropped_by_single(y, single, first_single)) continue;
         const double d = y - mean;
         ss += d * d;
     }
-    block_sum2<WAVES>(ss, dummy, s.red);
+    block_sum2<WAVES>(ss, dummy, s.red + R_ROAD_SS * 2 * WAVES);
+    MVOSR_STAMP(8);
     const double sd = sqrt(ss / cntd);                                          // np.std
     const double skew = (mean - mode / 10.0) / sd;                              // :496
     R.mean = mean; R.std = sd; R.skew = skew;
@@ -471,6 +613,7 @@ struct KArgs {
     PitchTest pt;
     int64_t first_frame;
     const double *height_level_in;
+    int debug_skip;          // ablation bits for profiling builds (env MVOSR_DEBUG_SKIP); 0 in production
 };
 
 __device__ __forceinline__ void write_counts(const KArgs &a, int64_t f, int nvalid, int npitch, int ntv, const RoadResult &R) {
@@ -481,8 +624,11 @@ __device__ __forceinline__ void write_counts(const KArgs &a, int64_t f, int nval
     c[MVOSR_CNT_MODE_LEFT] = R.mode_left; c[MVOSR_CNT_MODE_RIGHT] = R.mode_right;
 }
 
+#ifndef MVOSR_MINW
+#define MVOSR_MINW 1
+#endif
 template <int WAVES, bool FULL>
-__global__ __launch_bounds__(WAVES *kWave) void scale_frames_kernel(const KArgs a) {
+__global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int B = WAVES * kWave;
     const int tid = threadIdx.x;
@@ -491,7 +637,9 @@ __global__ __launch_bounds__(WAVES *kWave) void scale_frames_kernel(const KArgs 
     const int64_t off = a.b.feat_off[f];
     const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
     const int t1n = (int)(a.b.tri1_off[f + 1] - t1b), t2n = (int)(a.b.tri2_off[f + 1] - t2b);
-    const Smem s = carve(smem, n);
+    const Smem s = carve(smem, n, WAVES);
+    MVOSR_STAMP_DECL
+    MVOSR_STAMP(0);
 
     RoadResult R;
     R.height = nan(""); R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
@@ -505,34 +653,24 @@ __global__ __launch_bounds__(WAVES *kWave) void scale_frames_kernel(const KArgs 
         return;
     }
     for (int i = tid; i < (n + 31) / 32; i += B) s.sel[i] = 0u;
-    for (int i = tid; i < 192; i += B) s.hist[i] = 0;
+    for (int i = tid; i < 176; i += B) s.hist[i] = 0;
 
     int bad = 0;
-    const int nvalid = phase_vote<WAVES>(s, n, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
+    TriChunk<B> tc2;
+    const int nvalid = phase_vote<WAVES>(s, n, a.b.x + off, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
                                          a.P.cos_pitch, a.P.sin_pitch,
-                                         a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad);
+                                         a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad,
+                                         a.b.tri2, t2b, t2n, tc2, a.debug_skip MVOSR_STAMP_PASS);
     const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
-
-    // x replaces v in LDS
-    {
-        const double2 *gx2 = reinterpret_cast<const double2 *>(a.b.x + off);
-        double2 *sX2 = reinterpret_cast<double2 *>(s.X);
-        for (int i = tid; i < ((n + 1) >> 1); i += B) sX2[i] = gx2[i];
-    }
-    __syncthreads();
 
     SelectResult S;
     S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 0;
     if (!mask_mismatch)
-        S = phase_select<WAVES, FULL>(s, nvalid, a.b.tri2, t2b, t2n, a.pt, a.o.tri_normals, a.o.tri_pitch_deg, a.o.tri_heights);
-    {
-        int b0 = bad, b1 = 0, b2 = 0, b3 = 0;
-        block_sum4i<WAVES>(b0, b1, b2, b3, reinterpret_cast<int *>(s.red));
-        bad = b0 | S.bad;
-    }
+        S = phase_select<WAVES, FULL>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg, a.o.tri_heights, bad, a.debug_skip MVOSR_STAMP_PASS);
+    bad = S.bad;          // (vertex-id errors of both sweeps, summed over the block)
     int status;
     double height = nan(""), raw = nan("");
-    if (mask_mismatch || bad) {
+    if (mask_mismatch || bad || (a.debug_skip & 8)) {
         status = MVOSR_ST_ERR_MASK;
     } else if (S.singular) {
         status = MVOSR_ST_ERR_SINGULAR;
@@ -545,11 +683,15 @@ __global__ __launch_bounds__(WAVES *kWave) void scale_frames_kernel(const KArgs 
         if (a.o.selected) {
             for (int j = tid; j < nvalid; j += B) a.o.selected[off + j] = (uint8_t)((s.sel[j >> 5] >> (j & 31)) & 1u);
         }
-        R = phase_road<WAVES>(s, nvalid, fetch, S.height_level, a.P, s.X, a.o.hist ? a.o.hist + f * 2 * kBins : nullptr);
+        R = phase_road<WAVES>(s, nvalid, fetch, S.height_level, a.P, s.X, a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
         status = R.status;
         if (status == MVOSR_ST_NO_FLAT) raw = a.P.absolute_reference / S.height_level;        // :421
         else if (status <= MVOSR_ST_LEVEL) { height = R.height; raw = a.P.absolute_reference / height; }   // :419
     }
+    MVOSR_STAMP(9);
+#ifdef MVOSR_STAMPS
+    if (tid == 0 && a.o.hist) { unsigned long long *d = reinterpret_cast<unsigned long long *>(a.o.hist + f * 2 * kBins); for (int i = 0; i < 10; ++i) d[i] = stamps[i]; }
+#endif
     if (tid == 0) {
         a.o.raw_scale[f] = raw;
         a.o.height[f] = height;
@@ -570,12 +712,14 @@ __global__ __launch_bounds__(WAVES *kWave) void outlier_vote_kernel(const KArgs 
     const int64_t off = a.b.feat_off[f];
     const int64_t t1b = a.b.tri1_off[f];
     const int t1n = (int)(a.b.tri1_off[f + 1] - t1b);
-    const Smem s = carve(smem, n);
+    const Smem s = carve(smem, n, WAVES);
     int bad = 0;
-    const int nvalid = phase_vote<WAVES>(s, n, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
-                                         a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters + off, bad);
+    MVOSR_STAMP_DECL
+    TriChunk<WAVES * kWave> unused;
+    const int nvalid = phase_vote<WAVES>(s, n, nullptr, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
+                                         a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters + off, bad, nullptr, 0, 0, unused, 0 MVOSR_STAMP_PASS);
     int b0 = bad, b1 = 0, b2 = 0, b3 = 0;
-    block_sum4i<WAVES>(b0, b1, b2, b3, reinterpret_cast<int *>(s.red));
+    block_sum4i<WAVES>(b0, b1, b2, b3, s.red + R_MISC * 2 * WAVES);
     if (threadIdx.x == 0) {
         if (a.o.counts) a.o.counts[f * MVOSR_N_COUNTS + MVOSR_CNT_VALID] = nvalid;
         if (a.o.status) a.o.status[f] = b0 ? MVOSR_ST_ERR_MASK : MVOSR_ST_MODE;
@@ -591,13 +735,14 @@ __global__ __launch_bounds__(WAVES *kWave) void road_model_kernel(const KArgs a)
     const int64_t f = a.first_frame + blockIdx.x;
     const int n = a.b.feat_cnt[f];
     const int64_t off = a.b.feat_off[f];
-    const Smem s = carve(smem, max(n, 1));
-    for (int i = tid; i < 192; i += B) s.hist[i] = 0;
+    const Smem s = carve(smem, max(n, 1), WAVES);
+    for (int i = tid; i < 176; i += B) s.hist[i] = 0;
     for (int i = tid; i < n; i += B) s.Y[i] = a.b.y[off + i];
     __syncthreads();
     const double hl = a.height_level_in ? a.height_level_in[f] : nan("");
     auto fetch = [&](int j, double &y) -> bool { y = s.Y[j]; return true; };
-    RoadResult R = phase_road<WAVES>(s, n, fetch, hl, a.P, s.X, a.o.hist ? a.o.hist + f * 2 * kBins : nullptr);
+    MVOSR_STAMP_DECL
+    RoadResult R = phase_road<WAVES>(s, n, fetch, hl, a.P, s.X, a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
     if (tid == 0) {
         double height = nan(""), raw = nan("");
         if (R.status == MVOSR_ST_NO_FLAT) raw = a.P.absolute_reference / hl;
@@ -666,6 +811,12 @@ static PitchTest make_pitch_test(double thr_deg) {
     return pt;
 }
 
+static int debug_skip_env() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MVOSR_DEBUG_SKIP"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 static int pick_waves(int requested, int max_feat) {
     if (requested == 1 || requested == 4 || requested == 8 || requested == 16) return requested;
     if (max_feat <= 320) return 1;
@@ -693,7 +844,7 @@ static int check_fit(const mvosr_batch *b, size_t lds, int64_t max_tri) {
 
 template <int WAVES>
 static int launch_scale(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool full) {
-    const size_t lds = lds_plan(ka.b.max_feat).total;
+    const size_t lds = lds_plan(ka.b.max_feat, WAVES).total;
     int rc = check_fit<WAVES>(&ka.b, lds, 0);
     if (rc) return rc;
     // a triangle sweep keeps one flag bit per iteration in a 64-bit register: T2 <= 64 * block
@@ -712,7 +863,7 @@ static int launch_scale(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool full) 
 
 template <int WAVES>
 static int launch_vote(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
-    const size_t lds = lds_plan(ka.b.max_feat).total;
+    const size_t lds = lds_plan(ka.b.max_feat, WAVES).total;
     int rc = check_fit<WAVES>(&ka.b, lds, 0);
     if (rc) return rc;
     if ((rc = prepare_kernel(outlier_vote_kernel<WAVES>, lds))) return rc;
@@ -722,7 +873,7 @@ static int launch_vote(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
 
 template <int WAVES>
 static int launch_road(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
-    const size_t lds = lds_plan(ka.b.max_feat > 0 ? ka.b.max_feat : 1).total;
+    const size_t lds = lds_plan(ka.b.max_feat > 0 ? ka.b.max_feat : 1, WAVES).total;
     int rc = check_fit<WAVES>(&ka.b, lds, 0);
     if (rc) return rc;
     if ((rc = prepare_kernel(road_model_kernel<WAVES>, lds))) return rc;
@@ -751,13 +902,16 @@ void mvosr_default_params(mvosr_params *p, double absolute_reference) {
     p->reserved = 0;
 }
 
-size_t mvosr_lds_bytes(int n_features) { return lds_plan(n_features < 1 ? 1 : n_features).total; }
+size_t mvosr_lds_bytes(int n_features) {
+    const int n = n_features < 1 ? 1 : n_features;
+    return lds_plan(n, pick_waves(0, n)).total;
+}
 
 int mvosr_max_lds_features(void) {
     int lo = 1, hi = 65535;
     while (lo < hi) {
         const int mid = (lo + hi + 1) / 2;
-        if ((int64_t)lds_plan(mid).total <= (int64_t)g_max_dyn_lds) lo = mid; else hi = mid - 1;
+        if ((int64_t)lds_plan(mid, 16).total <= (int64_t)g_max_dyn_lds) lo = mid; else hi = mid - 1;
     }
     return lo;
 }
@@ -776,7 +930,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     if ((rc = ctx_activate(ctx))) return rc;
     KArgs ka;
     ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
-    ka.first_frame = first_frame; ka.height_level_in = nullptr;
+    ka.first_frame = first_frame; ka.height_level_in = nullptr; ka.debug_skip = debug_skip_env();
     const bool full = o->tri_normals || o->tri_pitch_deg || o->tri_heights;
     switch (pick_waves(waves_per_frame, b->max_feat)) {
         case 1: return launch_scale<1>(ctx, ka, n_launch, full);
@@ -796,7 +950,7 @@ int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_
     if ((rc = ctx_activate(ctx))) return rc;
     KArgs ka;
     ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
-    ka.first_frame = 0; ka.height_level_in = nullptr;
+    ka.first_frame = 0; ka.height_level_in = nullptr; ka.debug_skip = 0;
     switch (pick_waves(waves_per_frame, b->max_feat)) {
         case 1: return launch_vote<1>(ctx, ka, b->n_frames);
         case 4: return launch_vote<4>(ctx, ka, b->n_frames);
@@ -815,7 +969,7 @@ int mvosr_road_model_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_ba
     if ((rc = ctx_activate(ctx))) return rc;
     KArgs ka;
     ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
-    ka.first_frame = 0; ka.height_level_in = height_level_in;
+    ka.first_frame = 0; ka.height_level_in = height_level_in; ka.debug_skip = 0;
     switch (pick_waves(waves_per_frame, b->max_feat)) {
         case 1: return launch_road<1>(ctx, ka, b->n_frames);
         case 4: return launch_road<4>(ctx, ka, b->n_frames);
