@@ -1,6 +1,6 @@
 // mvosr_device.hpp — device-side building blocks shared by the scale-recovery kernels (gfx950).
 //
-// Wave-level helpers (64-lane shuffles / ballots), block-level fixed-order reductions, the
+// Wave-level helpers (64-lane DPP reductions / ballots), block-level fixed-order reductions, the
 // 169-bin bit-set helpers, and the per-triangle 3x3 solve.  All arithmetic is IEEE binary64 and
 // the file is compiled with -ffp-contract=off: a fused multiply-add appears only where it is
 // written explicitly (the LU elimination and the divide-by-3), so that e.g. the histogram edges
@@ -19,31 +19,53 @@ constexpr int kCounterBias = 0x8000;        // 16-bit vote counters are stored b
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
-// ---- wave reductions: xor butterfly, every lane ends with the same (bitwise) value ----------
+// ---- wave reductions on DPP (no LDS crossbar traffic) -----------------------------------------
+// Four DPP steps (quad xor 1, quad xor 2, row_half_mirror, row_mirror) leave every lane with the
+// sum of its row of 16; the four row sums are then read with v_readlane and added in a fixed
+// order, so every lane ends with the same (bitwise) total and results are run-to-run identical.
+constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;   // row_half_mirror
+constexpr int kDppMirror = 0x140;       // row_mirror
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    return __hiloint2double(dpp_mov<CTRL>(__double2hiint(v)), dpp_mov<CTRL>(__double2loint(v)));
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
+    v += dpp_mov<kDppXor1>(v);
+    v += dpp_mov<kDppXor2>(v);
+    v += dpp_mov<kDppHalfMirror>(v);
+    v += dpp_mov<kDppMirror>(v);
+    return ((readlane_d(v, 0) + readlane_d(v, 16)) + readlane_d(v, 32)) + readlane_d(v, 48);
 }
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
+    v += dpp_mov<kDppXor1>(v);
+    v += dpp_mov<kDppXor2>(v);
+    v += dpp_mov<kDppHalfMirror>(v);
+    v += dpp_mov<kDppMirror>(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 __device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, kWave));
-    return v;
+    v = max(v, dpp_mov<kDppXor1>(v));
+    v = max(v, dpp_mov<kDppXor2>(v));
+    v = max(v, dpp_mov<kDppHalfMirror>(v));
+    v = max(v, dpp_mov<kDppMirror>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, kWave));
-    return v;
-}
-__device__ __forceinline__ int wave_or(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, kWave);
-    return v;
+    v = min(v, dpp_mov<kDppXor1>(v));
+    v = min(v, dpp_mov<kDppXor2>(v));
+    v = min(v, dpp_mov<kDppHalfMirror>(v));
+    v = min(v, dpp_mov<kDppMirror>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 // ---- block reductions over WAVES wavefronts, fixed order => run-to-run bit-identical ---------

@@ -2,23 +2,23 @@
 // the C-ABI launchers declared in include/mvosr.h.
 //
 // One frame = one workgroup of WAVES wavefronts (WAVES = 1 for small frames: one frame per
-// wavefront).  A frame's features are staged once from HBM into LDS as fp64 planes and every
+// wavefront).  A frame's features are staged once from HBM into LDS in fp64 and every
 // per-triangle gather of the three stages is served from LDS:
 //
 //   phase A  load v, remapped y', z'            (feature_remap, scale_calculator.py:390-394)
 //            vote over tri1 with LDS atomics    (find_outliers/check_triangle, :151-167,:105-119)
-//            ballot prefix-sum compaction map   (feature2d[valid], :264-265)
-//   phase B  load x over v; per-triangle plane normal, pitch test, mean height over tri2;
-//            block reduction -> height_level; second sweep marks the selected vertices in an
-//            LDS bit-set                         (feature_selection_by_tri, :225-248)
+//            survivors are moved down in place  (feature2d[valid], :264-265), x replacing v
+//   phase B  per-triangle plane normal / pitch test / mean height over tri2; block reduction
+//            -> height_level; second sweep marks the selected vertices in an LDS bit-set
+//                                                (feature_selection_by_tri, :225-248)
 //   phase C  169-bin LDS histogram of the selected y', remove_single, mode / local-minimum
 //            logic on 64-bit ballots, mean/std/skew, median fallback
 //                                                (road_model_calculation_static, :324-354)
 //
-// LDS per frame: 26 B per feature (x|v, y', z' as fp64 + a 16-bit word that is the vote counter
-// in phase A and the compaction map afterwards) + ~1.5 KB -> 53.5 KB at N=2000, three
-// workgroups per CU.  HBM traffic per frame = the inputs once (x,y,z,v + tri1 + tri2) and
-// 28 B of results.
+// LDS per frame: 26 B per feature — P[i] = {v|x, z'} (16 B, one ds_read_b128 per vertex), Y[i] =
+// y' (8 B), a 16-bit vote counter (whose space later holds the selected bit-set) — plus ~1.3 KB:
+// 53.4 KB at N=2000, three workgroups per CU.  HBM traffic per frame = the inputs once
+// (x,y,z,v + tri1 + tri2) and 28 B of results.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -35,7 +35,6 @@ namespace mvosr {
 // phase boundaries and dumps the stamps over the frame's `hist` debug output.  Never defined in
 // the shipped library.
 #ifdef MVOSR_STAMPS
-__device__ unsigned long long g_stamp_dummy;
 #define MVOSR_STAMP(i) do { if (threadIdx.x == 0 && stamps) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define MVOSR_STAMP_DECL unsigned long long stamps[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
 #define MVOSR_STAMP_ARG , unsigned long long *stamps = nullptr
@@ -51,7 +50,7 @@ __device__ unsigned long long g_stamp_dummy;
 // LDS carve-up (byte offsets, all multiples of 16)
 // ---------------------------------------------------------------------------------------------
 struct LdsPlan {
-    uint32_t x, y, z, cm, sel, hist, red, misc, total;
+    uint32_t p, y, c, hist, red, misc, total;
 };
 __host__ __device__ inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 constexpr int kRedSlots = 6;                       // one scratch slot per block reduction site
@@ -59,12 +58,10 @@ enum { R_SEL_H = 0, R_SEL_CNT = 1, R_ROAD_N = 2, R_ROAD_SUM = 3, R_ROAD_SS = 4, 
 __host__ __device__ inline LdsPlan lds_plan(int n, int waves) {
     LdsPlan p;
     const uint32_t npad = (uint32_t)((n + 1) & ~1);
-    p.x = 0;
-    p.y = p.x + 8u * npad;
-    p.z = p.y + 8u * npad;
-    p.cm = p.z + 8u * npad;                       // 16-bit counter / map per feature
-    p.sel = align16(p.cm + 2u * npad);            // selected bit-set, one bit per surviving feature
-    p.hist = align16(p.sel + 4u * ((uint32_t)(n + 31) / 32u));
+    p.p = 0;                                      // double2 {v|x, z'} per feature
+    p.y = p.p + 16u * npad;                       // y' per feature
+    p.c = p.y + 8u * npad;                        // 16-bit vote counter per feature; later the selected bit-set
+    p.hist = align16(p.c + 2u * npad + 16u);
     p.red = p.hist + 4u * 176u;                   // 169 bins (+pad)
     p.misc = p.red + 8u * (uint32_t)(kRedSlots * 2 * waves);   // reduction scratch: 2*waves doubles per site
     p.total = p.misc + 4u * 32u;                  // 32 ints of per-frame scalars
@@ -72,10 +69,11 @@ __host__ __device__ inline LdsPlan lds_plan(int n, int waves) {
 }
 
 struct Smem {
-    double *X, *Y, *Z;
-    uint16_t *cm;
-    uint32_t *cm32;
-    uint32_t *sel;
+    double2 *P;
+    double *Y;
+    uint16_t *c16;
+    uint32_t *c32;
+    uint32_t *sel;        // aliases the counters once they are consumed
     int *hist;
     double *red;
     int *misc;
@@ -83,12 +81,11 @@ struct Smem {
 __device__ __forceinline__ Smem carve(char *base, int n, int waves) {
     const LdsPlan p = lds_plan(n, waves);
     Smem s;
-    s.X = reinterpret_cast<double *>(base + p.x);
+    s.P = reinterpret_cast<double2 *>(base + p.p);
     s.Y = reinterpret_cast<double *>(base + p.y);
-    s.Z = reinterpret_cast<double *>(base + p.z);
-    s.cm = reinterpret_cast<uint16_t *>(base + p.cm);
-    s.cm32 = reinterpret_cast<uint32_t *>(base + p.cm);
-    s.sel = reinterpret_cast<uint32_t *>(base + p.sel);
+    s.c16 = reinterpret_cast<uint16_t *>(base + p.c);
+    s.c32 = reinterpret_cast<uint32_t *>(base + p.c);
+    s.sel = reinterpret_cast<uint32_t *>(base + p.c);
     s.hist = reinterpret_cast<int *>(base + p.hist);
     s.red = reinterpret_cast<double *>(base + p.red);
     s.misc = reinterpret_cast<int *>(base + p.misc);
@@ -108,14 +105,13 @@ __device__ __forceinline__ TriIds load_tri(const int32_t *tri, int64_t t) {
 
 // ---------------------------------------------------------------------------------------------
 // Triangle ids are streamed in chunks of kTC triangles per thread: all loads of a chunk are in
-// flight together (a wave then has 8 x 768 B outstanding instead of one 768-B load per loop trip),
-// which is what keeps HBM busy — the sweeps are latency-bound otherwise.
+// flight together, and the first chunk of each sweep is issued a phase early (tri1 with the
+// feature loads, tri2 before the compaction barriers) so that its latency is off the sweep.
 // ---------------------------------------------------------------------------------------------
 #ifndef MVOSR_TC
 #define MVOSR_TC 2
 #endif
 constexpr int kTC = MVOSR_TC;   // triangles per thread per chunk (3 VGPRs each)
-constexpr int kXC = 2;      // double2 x values per thread prefetched during the vote
 
 template <int B>
 struct TriChunk {
@@ -130,17 +126,19 @@ struct TriChunk {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Phase A: stage v, y', z' and run the depth-order vote over the first triangulation; then x
-// replaces v in LDS.  On return (after the trailing barrier) cm[j] = index of the j-th surviving
-// feature and the return value is the number of survivors.  `bad` is set when a vertex id is out
-// of range.  When tri2 is given, its first chunk is put in flight before the compaction barriers
-// and handed back in `next`.
+// Phase A: stage {v, z'}, y' and run the depth-order vote over the first triangulation; then the
+// survivors are moved down in place (order kept) with x taking v's slot, so that the second
+// triangulation's vertex ids address LDS directly.  Every wave owns a contiguous slice of SC*64
+// features for the compaction.  Returns the number of survivors; `bad` is set when a vertex id
+// is out of range.  When tri2 is given, its first chunk is put in flight before the compaction
+// barriers and handed back in `next`.
 // ---------------------------------------------------------------------------------------------
-template <int WAVES>
+template <int WAVES, int SC>
 __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx, const double *gy, const double *gz,
                                           const double *gv, const int32_t *tri1, int64_t t1_begin, int t1_count,
                                           double cp, double sp, int32_t *g_counters, int &bad,
-                                          const int32_t *tri2, int64_t t2_begin, int t2_count, TriChunk<WAVES * kWave> &next, int dbg = 0 MVOSR_STAMP_ARG) {
+                                          const int32_t *tri2, int64_t t2_begin, int t2_count, TriChunk<WAVES * kWave> &next,
+                                          int dbg = 0 MVOSR_STAMP_ARG) {
     constexpr int B = WAVES * kWave;
     const int tid = threadIdx.x;
     const int npad2 = (n + 1) >> 1;
@@ -150,10 +148,7 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
     const double2 *gy2 = reinterpret_cast<const double2 *>(gy);
     const double2 *gz2 = reinterpret_cast<const double2 *>(gz);
     const double2 *gv2 = reinterpret_cast<const double2 *>(gv);
-    const double2 *gx2 = reinterpret_cast<const double2 *>(gx);
     double2 *sY2 = reinterpret_cast<double2 *>(s.Y);
-    double2 *sZ2 = reinterpret_cast<double2 *>(s.Z);
-    double2 *sX2 = reinterpret_cast<double2 *>(s.X);
     const uint32_t ones = ((uint32_t)(kCounterBias + 1) << 16) | (uint32_t)(kCounterBias + 1);     // np.ones, :153
     for (int i0 = tid; i0 < npad2; i0 += 2 * B) {
         const int i1 = i0 + B;
@@ -161,25 +156,29 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
         const double2 ya = gy2[i0], za = gz2[i0], va = gv2[i0];
         double2 yb = ya, zb = za, vb = va;
         if (two) { yb = gy2[i1]; zb = gz2[i1]; vb = gv2[i1]; }
-        double2 yr, zr;
+        double2 yr, p0, p1;
         yr.x = ya.x * cp - za.x * sp;  yr.y = ya.y * cp - za.y * sp;      // :391
-        zr.x = ya.x * sp + za.x * cp;  zr.y = ya.y * sp + za.y * cp;      // :392
-        sY2[i0] = yr; sZ2[i0] = zr; sX2[i0] = va; s.cm32[i0] = ones;
+        p0.x = va.x; p0.y = ya.x * sp + za.x * cp;                        // :392
+        p1.x = va.y; p1.y = ya.y * sp + za.y * cp;
+        sY2[i0] = yr; s.P[2 * i0] = p0; s.P[2 * i0 + 1] = p1; s.c32[i0] = ones;
         if (two) {
             yr.x = yb.x * cp - zb.x * sp;  yr.y = yb.y * cp - zb.y * sp;
-            zr.x = yb.x * sp + zb.x * cp;  zr.y = yb.y * sp + zb.y * cp;
-            sY2[i1] = yr; sZ2[i1] = zr; sX2[i1] = vb; s.cm32[i1] = ones;
+            p0.x = vb.x; p0.y = yb.x * sp + zb.x * cp;
+            p1.x = vb.y; p1.y = yb.y * sp + zb.y * cp;
+            sY2[i1] = yr; s.P[2 * i1] = p0; s.P[2 * i1 + 1] = p1; s.c32[i1] = ones;
         }
     }
     __syncthreads();
     MVOSR_STAMP(1);
 
-    // x is needed only after the vote: fetch it now, park it in registers
-    double2 xr[kXC];
+    // x is needed only after the vote: fetch it now in the compaction's slice layout, park it in registers
+    const int w = wave_id(), lane = lane_id();
+    const int begin = w * (SC * kWave);
+    double xs[SC];
 #pragma unroll
-    for (int k = 0; k < kXC; ++k) {
-        const int i = k * B + tid;
-        if (gx && i < npad2) xr[k] = gx2[i];
+    for (int k = 0; k < SC; ++k) {
+        const int i = begin + k * kWave + lane;
+        xs[k] = (gx && i < n) ? gx[i] : 0.0;
     }
 
     // the vote: +1 on a vertex the triangle does not flag, -1 on one it flags (:160-163)
@@ -191,64 +190,61 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
             if (t >= t1_count) continue;
             const TriIds q = tc.q[k];
             if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
-            const double v0 = s.X[q.a], v1 = s.X[q.b], v2 = s.X[q.c];
-            const double d0 = s.Z[q.a], d1 = s.Z[q.b], d2 = s.Z[q.c];
-            const bool pa = (v0 - v1) * (d0 - d1) > 0.0;       // :107,:110
-            const bool pb = (v0 - v2) * (d0 - d2) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
-            const bool pc = (v1 - v2) * (d1 - d2) > 0.0;       // :109,:116
+            const double2 p0 = s.P[q.a], p1 = s.P[q.b], p2 = s.P[q.c];      // {v, z'}
+            const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
+            const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
+            const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
             const bool f0 = pa | pb, f1 = pa | pb | pc, f2 = pc;
             // one wrap-around add per vertex: +-1 in the vertex's 16-bit half (the halves stay in
             // [1, 0xFFFE], so a -1 never borrows across them)
             const uint32_t u0 = 1u << ((q.a & 1) * 16), u1 = 1u << ((q.b & 1) * 16), u2 = 1u << ((q.c & 1) * 16);
-            atomicAdd(&s.cm32[q.a >> 1], f0 ? 0u - u0 : u0);
-            atomicAdd(&s.cm32[q.b >> 1], f1 ? 0u - u1 : u1);
-            atomicAdd(&s.cm32[q.c >> 1], f2 ? 0u - u2 : u2);
+            atomicAdd(&s.c32[q.a >> 1], f0 ? 0u - u0 : u0);
+            atomicAdd(&s.c32[q.b >> 1], f1 ? 0u - u1 : u1);
+            atomicAdd(&s.c32[q.c >> 1], f2 ? 0u - u2 : u2);
         }
     }
     if (tri2) next.load(tri2, t2_begin, t2_count, 0, tid);   // lands while the survivors are compacted
     __syncthreads();
     MVOSR_STAMP(2);
 
-    // v is dead: x takes its plane
-    if (gx) {
-#pragma unroll
-        for (int k = 0; k < kXC; ++k) {
-            const int i = k * B + tid;
-            if (i < npad2) sX2[i] = xr[k];
-        }
-        for (int i = kXC * B + tid; i < npad2; i += B) sX2[i] = gx2[i];
-    }
-
-    // compaction: every wave owns a contiguous slice of the features; survivors keep their order
-    const int w = wave_id(), lane = lane_id();
-    const int per = ((n + WAVES * kWave - 1) / (WAVES * kWave)) * kWave;     // slice length, multiple of 64
-    const int begin = w * per;
-    const int end = min(n, begin + per);
-    unsigned long long mine = 0ull;              // bit k: my feature of sub-chunk k survives
+    // compaction, step 1: every wave reads its slice (flags, y', z') into registers and counts
+    unsigned keepmask = 0u;                      // bit k: my feature of sub-chunk k survives
+    double yk[SC], zk[SC];
     int cnt = 0;
-    for (int k = 0, i0 = begin; i0 < end; i0 += kWave, ++k) {
-        const int i = i0 + lane;
+#pragma unroll
+    for (int k = 0; k < SC; ++k) {
+        const int i = begin + k * kWave + lane;
         bool keep = false;
-        if (i < end) {
-            const int c = (int)s.cm[i] - kCounterBias;
+        yk[k] = 0.0; zk[k] = 0.0;
+        if (i < n) {
+            const int c = (int)s.c16[i] - kCounterBias;
             keep = c >= 0;                                                    // :166
             if (g_counters) g_counters[i] = c;
+            yk[k] = s.Y[i];
+            zk[k] = s.P[i].y;
         }
-        const unsigned long long m = __ballot(keep);
-        if (keep) mine |= 1ull << k;
-        cnt += __popcll(m);
+        if (keep) keepmask |= 1u << k;
+        cnt += __popcll(__ballot(keep));
     }
     if (lane == 0) s.misc[M_WCNT + w] = cnt;
-    __syncthreads();                             // all counters consumed: cm may now hold the map
+    __syncthreads();                             // every slice is in registers: LDS may be overwritten
+    // step 2: survivors go to their compacted positions; the counters' space becomes the selected bit-set
     int base = 0, total = 0;
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) { const int c = s.misc[M_WCNT + i]; if (i < w) base += c; total += c; }
-    for (int k = 0, i0 = begin; i0 < end; i0 += kWave, ++k) {
-        const bool keep = (mine >> k) & 1ull;
+#pragma unroll
+    for (int k = 0; k < SC; ++k) {
+        const bool keep = (keepmask >> k) & 1u;
         const unsigned long long m = __ballot(keep);
-        if (keep) s.cm[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(i0 + lane);
+        if (keep) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            double2 pv; pv.x = xs[k]; pv.y = zk[k];
+            s.P[pos] = pv;
+            s.Y[pos] = yk[k];
+        }
         base += __popcll(m);
     }
+    for (int i = tid; i < (n + 31) / 32; i += B) s.sel[i] = 0u;
     __syncthreads();
     MVOSR_STAMP(3);
     return total;
@@ -303,7 +299,8 @@ struct PitchTest {
 template <int WAVES, bool FULL>
 __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid, const int32_t *tri2, int64_t t2_begin,
                                                      int t2_count, TriChunk<WAVES * kWave> &tc, PitchTest pt,
-                                                     double *g_normals, double *g_pitch, double *g_heights, int bad_in, int dbg = 0 MVOSR_STAMP_ARG) {
+                                                     double *g_normals, double *g_pitch, double *g_heights, int bad_in,
+                                                     int dbg = 0 MVOSR_STAMP_ARG) {
     constexpr int B = WAVES * kWave;
     const int tid = threadIdx.x;
     unsigned long long flat = 0ull;          // bit kk: my kk-th triangle has pitch_deg < thr
@@ -319,10 +316,9 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
             const int kk = base / B + k;
             const TriIds q = tc.q[k];
             if ((unsigned)q.a >= (unsigned)n_valid || (unsigned)q.b >= (unsigned)n_valid || (unsigned)q.c >= (unsigned)n_valid) { bad = 1; continue; }
-            const int i0 = s.cm[q.a], i1 = s.cm[q.b], i2 = s.cm[q.c];
-            const double x0 = s.X[i0], y0 = s.Y[i0], z0 = s.Z[i0];
-            const double x1 = s.X[i1], y1 = s.Y[i1], z1 = s.Z[i1];
-            const double x2 = s.X[i2], y2 = s.Y[i2], z2 = s.Z[i2];
+            const double2 p0 = s.P[q.a], p1 = s.P[q.b], p2 = s.P[q.c];      // {x, z'}
+            const double y0 = s.Y[q.a], y1 = s.Y[q.b], y2 = s.Y[q.c];
+            const double x0 = p0.x, z0 = p0.y, x1 = p1.x, z1 = p1.y, x2 = p2.x, z2 = p2.y;
             const double h = div3((y0 + y1) + y2);                                               // :238
             bool is_flat = false, is_steep = false;
             bool decided = false;
@@ -372,7 +368,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     r.height_level = hsum / hcnt;                 // np.mean of an empty set -> 0/0 = NaN, like :240
     const double hl = r.height_level;
     int ntv = 0;
-    const bool in_regs = t2_count <= kTC * B;     // the usual case: the ids are still in registers
+    const bool in_regs = t2_count <= kTC * B;     // then the ids are still in registers
     for (int base = 0; base < ((dbg & 4) ? 0 : t2_count); base += kTC * B) {
         if (!in_regs) tc.load(tri2, t2_begin, t2_count, base, tid);
 #pragma unroll
@@ -381,7 +377,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
             const int kk = base / B + k;
             if (t >= t2_count || !((flat >> kk) & 1ull)) continue;
             const TriIds q = tc.q[k];
-            const double y0 = s.Y[s.cm[q.a]], y1 = s.Y[s.cm[q.b]], y2 = s.Y[s.cm[q.c]];
+            const double y0 = s.Y[q.a], y1 = s.Y[q.b], y2 = s.Y[q.c];
             const double h = div3((y0 + y1) + y2);
             if (h > hl) {                                                                        // :243-244
                 ++ntv;
@@ -401,6 +397,9 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
 // ---------------------------------------------------------------------------------------------
 // Phase C: road model on the y' of the selected points.
 // `fetch(j, y)` yields the j-th candidate value (returns false if candidate j is not selected).
+// All waves take part in the three passes and their reductions; the 169-bin mode / minimum
+// logic that turns the histogram into the answer runs on wave 0 only (thread 0 writes the
+// frame's outputs), so the returned struct is meaningful on wave 0.
 // ---------------------------------------------------------------------------------------------
 struct RoadResult {
     double height;
@@ -470,54 +469,23 @@ __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetc
     R.n_sel = nsel;
     if (nsel == 0) { R.status = MVOSR_ST_NO_FLAT; R.n_kept = 0; return R; }
 
-    // every wave evaluates the 169-bin logic redundantly on ballots (no serial section):
+    // every wave needs the single-count bins (remove_single) and the maximum (are there modes?):
     // lane l looks at bins l, l+64, l+128
     int hraw[3], hz[3];
+    Bits192 single;
+    int mx = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int b = lane + 64 * c;
         hraw[c] = (b < kBins) ? s.hist[b] : 0;
         hz[c] = (hraw[c] == 1) ? 0 : hraw[c];                                  // dis[dis==1]=0, :328
-    }
-    if (g_hist && tid < kWave) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int b = lane + 64 * c;
-            if (b < kBins) { g_hist[b] = hraw[c]; g_hist[kBins + b] = hz[c]; }
-        }
-    }
-    Bits192 single, modes, mins;
-    int mx = 0, mn = 0x7fffffff;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int b = lane + 64 * c;
         single.w[c] = __ballot(b < kBins && hraw[c] == 1);
-        if (b < kBins) { mx = max(mx, hz[c]); mn = min(mn, hz[c]); }
+        mx = max(mx, hz[c]);
     }
     mx = wave_max(mx);
-    mn = wave_min(mn);
     const int first_single = single.lowest_from(0);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int b = lane + 64 * c;
-        bool is_mode = false, is_min = false;
-        if (b < kBins) {
-            const int h = hz[c];
-            if (b == 0 || b == kBins - 1) {
-                is_mode = (h == mx);                                            // :454-458
-                is_min = (h == mn);                                             // :433-437
-            } else {
-                const int lraw = s.hist[b - 1], rraw = s.hist[b + 1];
-                const int hl_ = (lraw == 1) ? 0 : lraw, hr_ = (rraw == 1) ? 0 : rraw;
-                is_mode = (h >= hl_) && (h >= hr_) && ((double)h >= P.mode_rel * (double)mx) && (h >= P.mode_min);   // :459-463
-                is_min = (h <= hl_) && (h <= hr_) && !((h == hr_) && (h == hl_));                                   // :438-442
-            }
-        }
-        modes.w[c] = __ballot(is_mode);
-        mins.w[c] = __ballot(is_min);
-    }
-    const bool have_modes = (mx > P.mode_min) && modes.any();                   // :451-452
-    R.n_modes = have_modes ? modes.runs() : 0;                                  // :468-481 (edges 0.1 apart cluster, gap < 0.11)
+    // check_mode returns no modes iff max <= 2 (:451-452); otherwise the maximum bin itself is one
+    const bool have_modes = mx > P.mode_min;
 
     // second pass: drop the points inside a single bin's interval (:284-293), accumulate the mean
     double sum = 0.0, cntd = 0.0;
@@ -545,6 +513,10 @@ __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetc
     R.n_kept = nkept;
 
     if (!have_modes) {
+        if (g_hist && tid < kWave) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const int b = lane + 64 * c; if (b < kBins) { g_hist[b] = hraw[c]; g_hist[kBins + b] = hz[c]; } }
+        }
         if (nkept == 0) { R.height = height_level; R.status = MVOSR_ST_LEVEL; return R; }   // :334-335
         // np.median (:333) by rank counting: the two middle order statistics
         const int klo = (nkept - 1) >> 1, khi = nkept >> 1;
@@ -565,20 +537,8 @@ __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetc
         return R;
     }
 
-    // last cluster = last run of consecutive mode bins (:338-340); int(edge*10) == bin+1
-    const int i_last = modes.highest_below(kBins);
-    int i_first = i_last;
-    while (i_first > 0 && modes.test(i_first - 1)) --i_first;
-    const int ml = i_first + 1, mr = i_last + 1;
-    R.mode_left = ml; R.mode_right = mr;
-    const double mode = (double)(ml + mr) / 2.0;                                // :340
-    const int il = mins.highest_below(ml);                                      // :341,:343  bins 0..ml-1
-    if (il < 0) { R.status = MVOSR_ST_ERR_LEFT; return R; }
-    const int ir = mins.lowest_from(mr);                                        // :342,:344  bins mr..168
-    if (ir < 0) { R.status = MVOSR_ST_ERR_RIGHT; return R; }
-    const double right = bin_edge(ir + 1);
-
-    const double mean = sum / cntd;                                             // np.mean, :496
+    // third pass: standard deviation around the mean (np.std, :496)
+    const double mean = sum / cntd;                                             // np.mean
     double ss = 0.0, dummy = 0.0;
 #pragma unroll
     for (int k = 0; k < kRC; ++k) {
@@ -595,6 +555,49 @@ __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetc
     }
     block_sum2<WAVES>(ss, dummy, s.red + R_ROAD_SS * 2 * WAVES);
     MVOSR_STAMP(8);
+    if (wave_id() != 0) return R;               // the rest is the frame's scalar answer: wave 0 only
+
+    if (g_hist) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const int b = lane + 64 * c; if (b < kBins) { g_hist[b] = hraw[c]; g_hist[kBins + b] = hz[c]; } }
+    }
+    Bits192 modes, mins;
+    int mn = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { if (lane + 64 * c < kBins) mn = min(mn, hz[c]); }
+    mn = wave_min(mn);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int b = lane + 64 * c;
+        bool is_mode = false, is_min = false;
+        if (b < kBins) {
+            const int h = hz[c];
+            if (b == 0 || b == kBins - 1) {
+                is_mode = (h == mx);                                            // :454-458
+                is_min = (h == mn);                                             // :433-437
+            } else {
+                const int lraw = s.hist[b - 1], rraw = s.hist[b + 1];
+                const int hl_ = (lraw == 1) ? 0 : lraw, hr_ = (rraw == 1) ? 0 : rraw;
+                is_mode = (h >= hl_) && (h >= hr_) && ((double)h >= P.mode_rel * (double)mx) && (h >= P.mode_min);   // :459-463
+                is_min = (h <= hl_) && (h <= hr_) && !((h == hr_) && (h == hl_));                                   // :438-442
+            }
+        }
+        modes.w[c] = __ballot(is_mode);
+        mins.w[c] = __ballot(is_min);
+    }
+    R.n_modes = modes.runs();                                                   // :468-481 (edges 0.1 apart cluster, gap < 0.11)
+    // last cluster = last run of consecutive mode bins (:338-340); int(edge*10) == bin+1
+    const int i_last = modes.highest_below(kBins);
+    int i_first = i_last;
+    while (i_first > 0 && modes.test(i_first - 1)) --i_first;
+    const int ml = i_first + 1, mr = i_last + 1;
+    R.mode_left = ml; R.mode_right = mr;
+    const double mode = (double)(ml + mr) / 2.0;                                // :340
+    const int il = mins.highest_below(ml);                                      // :341,:343  bins 0..ml-1
+    if (il < 0) { R.status = MVOSR_ST_ERR_LEFT; return R; }
+    const int ir = mins.lowest_from(mr);                                        // :342,:344  bins mr..168
+    if (ir < 0) { R.status = MVOSR_ST_ERR_RIGHT; return R; }
+    const double right = bin_edge(ir + 1);
     const double sd = sqrt(ss / cntd);                                          // np.std
     const double skew = (mean - mode / 10.0) / sd;                              // :496
     R.mean = mean; R.std = sd; R.skew = skew;
@@ -613,7 +616,7 @@ struct KArgs {
     PitchTest pt;
     int64_t first_frame;
     const double *height_level_in;
-    int debug_skip;          // ablation bits for profiling builds (env MVOSR_DEBUG_SKIP); 0 in production
+    int debug_skip;          // ablation bits for profiling runs (env MVOSR_DEBUG_SKIP); 0 in production
 };
 
 __device__ __forceinline__ void write_counts(const KArgs &a, int64_t f, int nvalid, int npitch, int ntv, const RoadResult &R) {
@@ -627,7 +630,7 @@ __device__ __forceinline__ void write_counts(const KArgs &a, int64_t f, int nval
 #ifndef MVOSR_MINW
 #define MVOSR_MINW 1
 #endif
-template <int WAVES, bool FULL>
+template <int WAVES, int SC, bool FULL>
 __global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int B = WAVES * kWave;
@@ -652,38 +655,39 @@ __global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(
         }
         return;
     }
-    for (int i = tid; i < (n + 31) / 32; i += B) s.sel[i] = 0u;
     for (int i = tid; i < 176; i += B) s.hist[i] = 0;
 
     int bad = 0;
     TriChunk<B> tc2;
-    const int nvalid = phase_vote<WAVES>(s, n, a.b.x + off, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
-                                         a.P.cos_pitch, a.P.sin_pitch,
-                                         a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad,
-                                         a.b.tri2, t2b, t2n, tc2, a.debug_skip MVOSR_STAMP_PASS);
+    const int nvalid = phase_vote<WAVES, SC>(s, n, a.b.x + off, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
+                                             a.P.cos_pitch, a.P.sin_pitch,
+                                             a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad,
+                                             a.b.tri2, t2b, t2n, tc2, a.debug_skip MVOSR_STAMP_PASS);
     const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
 
     SelectResult S;
-    S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 0;
+    S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 1;
     if (!mask_mismatch)
-        S = phase_select<WAVES, FULL>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg, a.o.tri_heights, bad, a.debug_skip MVOSR_STAMP_PASS);
-    bad = S.bad;          // (vertex-id errors of both sweeps, summed over the block)
+        S = phase_select<WAVES, FULL>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
+                                      a.o.tri_heights, bad, a.debug_skip MVOSR_STAMP_PASS);
     int status;
     double height = nan(""), raw = nan("");
-    if (mask_mismatch || bad || (a.debug_skip & 8)) {
+    if (mask_mismatch || S.bad || (a.debug_skip & 8)) {      // S.bad: vertex-id errors of both sweeps, summed over the block
         status = MVOSR_ST_ERR_MASK;
     } else if (S.singular) {
         status = MVOSR_ST_ERR_SINGULAR;
     } else {
         auto fetch = [&](int j, double &y) -> bool {
             if (!((s.sel[j >> 5] >> (j & 31)) & 1u)) return false;
-            y = s.Y[s.cm[j]];
+            y = s.Y[j];
             return true;
         };
         if (a.o.selected) {
             for (int j = tid; j < nvalid; j += B) a.o.selected[off + j] = (uint8_t)((s.sel[j >> 5] >> (j & 31)) & 1u);
         }
-        R = phase_road<WAVES>(s, nvalid, fetch, S.height_level, a.P, s.X, a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
+        // the P plane is dead after the sweeps: it serves as the median's value list
+        R = phase_road<WAVES>(s, nvalid, fetch, S.height_level, a.P, reinterpret_cast<double *>(s.P),
+                              a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
         status = R.status;
         if (status == MVOSR_ST_NO_FLAT) raw = a.P.absolute_reference / S.height_level;        // :421
         else if (status <= MVOSR_ST_LEVEL) { height = R.height; raw = a.P.absolute_reference / height; }   // :419
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(
 }
 
 // K1 alone
-template <int WAVES>
+template <int WAVES, int SC>
 __global__ __launch_bounds__(WAVES *kWave) void outlier_vote_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = a.first_frame + blockIdx.x;
@@ -716,8 +720,9 @@ __global__ __launch_bounds__(WAVES *kWave) void outlier_vote_kernel(const KArgs 
     int bad = 0;
     MVOSR_STAMP_DECL
     TriChunk<WAVES * kWave> unused;
-    const int nvalid = phase_vote<WAVES>(s, n, nullptr, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
-                                         a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters + off, bad, nullptr, 0, 0, unused, 0 MVOSR_STAMP_PASS);
+    const int nvalid = phase_vote<WAVES, SC>(s, n, nullptr, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
+                                             a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters + off, bad, nullptr, 0, 0, unused,
+                                             0 MVOSR_STAMP_PASS);
     int b0 = bad, b1 = 0, b2 = 0, b3 = 0;
     block_sum4i<WAVES>(b0, b1, b2, b3, s.red + R_MISC * 2 * WAVES);
     if (threadIdx.x == 0) {
@@ -742,7 +747,8 @@ __global__ __launch_bounds__(WAVES *kWave) void road_model_kernel(const KArgs a)
     const double hl = a.height_level_in ? a.height_level_in[f] : nan("");
     auto fetch = [&](int j, double &y) -> bool { y = s.Y[j]; return true; };
     MVOSR_STAMP_DECL
-    RoadResult R = phase_road<WAVES>(s, n, fetch, hl, a.P, s.X, a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
+    RoadResult R = phase_road<WAVES>(s, n, fetch, hl, a.P, reinterpret_cast<double *>(s.P),
+                                     a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
     if (tid == 0) {
         double height = nan(""), raw = nan("");
         if (R.status == MVOSR_ST_NO_FLAT) raw = a.P.absolute_reference / hl;
@@ -788,7 +794,7 @@ __global__ __launch_bounds__(256) void window_median_kernel(const MedianArgs a) 
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-static int g_max_dyn_lds = 160 * 1024 - 0;   // refined from the device in ctx_create
+static int g_max_dyn_lds = 160 * 1024;       // refined from the device in ctx_create
 
 template <typename K>
 static int prepare_kernel(K kernel, size_t lds) {
@@ -817,12 +823,17 @@ static int debug_skip_env() {
     return v;
 }
 
+// Variants: (wavefronts per frame, 64-feature sub-chunks each wave compacts).  Capacity of a variant
+// is WAVES*SC*64 features; 16-bit vote counters and the 64-bit per-thread triangle flags are wider
+// than any frame that fits LDS.
 static int pick_waves(int requested, int max_feat) {
     if (requested == 1 || requested == 4 || requested == 8 || requested == 16) return requested;
-    if (max_feat <= 320) return 1;
+    if (max_feat <= 384) return 1;
     if (max_feat <= 1024) return 4;
-    return 8;
+    if (max_feat <= 2048) return 8;
+    return 16;
 }
+static int variant_capacity(int waves, int sc) { return waves * sc * kWave; }
 
 static int check_common(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const mvosr_outputs *o) {
     if (!ctx || !p || !b || !o) return set_error(MVOSR_ERR_ARG, "null argument");
@@ -831,55 +842,68 @@ static int check_common(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch
     return MVOSR_OK;
 }
 
-template <int WAVES>
-static int check_fit(const mvosr_batch *b, size_t lds, int64_t max_tri) {
+static int check_fit(const mvosr_batch *b, int waves, int sc, size_t lds) {
     if ((int64_t)lds > (int64_t)g_max_dyn_lds)
         return set_error(MVOSR_ERR_TOO_LARGE, "frame of %d features needs %zu B of LDS (> %d)", b->max_feat, lds, g_max_dyn_lds);
-    if (b->max_feat > 65535) return set_error(MVOSR_ERR_TOO_LARGE, "more than 65535 features per frame");
-    if ((int64_t)b->max_feat > (int64_t)64 * 64 * WAVES)
-        return set_error(MVOSR_ERR_TOO_LARGE, "%d features need more wavefronts per frame than %d", b->max_feat, WAVES);
-    (void)max_tri;
+    if (b->max_feat > variant_capacity(waves, sc))
+        return set_error(MVOSR_ERR_TOO_LARGE, "%d features exceed what %d wavefronts per frame handle (%d)", b->max_feat, waves,
+                         variant_capacity(waves, sc));
+    // a triangle sweep keeps one flag bit per iteration in a 64-bit register: T2 <= 64 * block
+    if ((int64_t)2 * b->max_feat > (int64_t)64 * kWave * waves)
+        return set_error(MVOSR_ERR_TOO_LARGE, "%d features give more triangles than %d wavefronts sweep", b->max_feat, waves);
     return MVOSR_OK;
 }
 
-template <int WAVES>
+template <int WAVES, int SC>
 static int launch_scale(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool full) {
     const size_t lds = lds_plan(ka.b.max_feat, WAVES).total;
-    int rc = check_fit<WAVES>(&ka.b, lds, 0);
+    int rc = check_fit(&ka.b, WAVES, SC, lds);
     if (rc) return rc;
-    // a triangle sweep keeps one flag bit per iteration in a 64-bit register: T2 <= 64 * block
-    // (2N triangles for N features, so this only binds for the one-wave variant)
-    if ((int64_t)2 * ka.b.max_feat > (int64_t)64 * 64 * WAVES)
-        return set_error(MVOSR_ERR_TOO_LARGE, "%d features give more triangles than %d wavefronts sweep", ka.b.max_feat, WAVES);
     if (full) {
-        if ((rc = prepare_kernel(scale_frames_kernel<WAVES, true>, lds))) return rc;
-        hipLaunchKernelGGL((scale_frames_kernel<WAVES, true>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
+        if ((rc = prepare_kernel(scale_frames_kernel<WAVES, SC, true>, lds))) return rc;
+        hipLaunchKernelGGL((scale_frames_kernel<WAVES, SC, true>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
     } else {
-        if ((rc = prepare_kernel(scale_frames_kernel<WAVES, false>, lds))) return rc;
-        hipLaunchKernelGGL((scale_frames_kernel<WAVES, false>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
+        if ((rc = prepare_kernel(scale_frames_kernel<WAVES, SC, false>, lds))) return rc;
+        hipLaunchKernelGGL((scale_frames_kernel<WAVES, SC, false>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
     }
     return check_launch("scale_frames_kernel");
 }
 
-template <int WAVES>
+template <int WAVES, int SC>
 static int launch_vote(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
     const size_t lds = lds_plan(ka.b.max_feat, WAVES).total;
-    int rc = check_fit<WAVES>(&ka.b, lds, 0);
+    int rc = check_fit(&ka.b, WAVES, SC, lds);
     if (rc) return rc;
-    if ((rc = prepare_kernel(outlier_vote_kernel<WAVES>, lds))) return rc;
-    hipLaunchKernelGGL((outlier_vote_kernel<WAVES>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
+    if ((rc = prepare_kernel(outlier_vote_kernel<WAVES, SC>, lds))) return rc;
+    hipLaunchKernelGGL((outlier_vote_kernel<WAVES, SC>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
     return check_launch("outlier_vote_kernel");
 }
 
 template <int WAVES>
 static int launch_road(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
     const size_t lds = lds_plan(ka.b.max_feat > 0 ? ka.b.max_feat : 1, WAVES).total;
-    int rc = check_fit<WAVES>(&ka.b, lds, 0);
-    if (rc) return rc;
+    if ((int64_t)lds > (int64_t)g_max_dyn_lds)
+        return set_error(MVOSR_ERR_TOO_LARGE, "list of %d values needs %zu B of LDS (> %d)", ka.b.max_feat, lds, g_max_dyn_lds);
+    int rc;
     if ((rc = prepare_kernel(road_model_kernel<WAVES>, lds))) return rc;
     hipLaunchKernelGGL((road_model_kernel<WAVES>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
     return check_launch("road_model_kernel");
 }
+
+// dispatch on (waves, sub-chunks): the smaller SC keeps fewer registers live across the compaction
+#define MVOSR_DISPATCH(FN, ...)                                                             \
+    do {                                                                                    \
+        const int n_ = ka.b.max_feat;                                                       \
+        switch (waves) {                                                                    \
+            case 1: return FN<1, 8>(__VA_ARGS__);                                           \
+            case 4: return (n_ <= variant_capacity(4, 4)) ? FN<4, 4>(__VA_ARGS__) : FN<4, 8>(__VA_ARGS__);     \
+            case 16: return (n_ <= variant_capacity(16, 4)) ? FN<16, 4>(__VA_ARGS__) : FN<16, 8>(__VA_ARGS__); \
+            default: return (n_ <= variant_capacity(8, 4)) ? FN<8, 4>(__VA_ARGS__) : FN<8, 8>(__VA_ARGS__);    \
+        }                                                                                   \
+    } while (0)
+
+static int dispatch_scale(mvosr_ctx *ctx, const KArgs &ka, int waves, int64_t nl, bool full) { MVOSR_DISPATCH(launch_scale, ctx, ka, nl, full); }
+static int dispatch_vote(mvosr_ctx *ctx, const KArgs &ka, int waves, int64_t nl) { MVOSR_DISPATCH(launch_vote, ctx, ka, nl); }
 
 void set_max_dynamic_lds(int bytes) { g_max_dyn_lds = bytes; }
 
@@ -908,7 +932,7 @@ size_t mvosr_lds_bytes(int n_features) {
 }
 
 int mvosr_max_lds_features(void) {
-    int lo = 1, hi = 65535;
+    int lo = 1, hi = 8192;
     while (lo < hi) {
         const int mid = (lo + hi + 1) / 2;
         if ((int64_t)lds_plan(mid, 16).total <= (int64_t)g_max_dyn_lds) lo = mid; else hi = mid - 1;
@@ -920,7 +944,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
                       int waves_per_frame, int64_t first_frame, int64_t n_launch) {
     int rc = check_common(ctx, p, b, o);
     if (rc) return rc;
-    if (!b->x || !b->y || !b->z || !b->v || !b->tri1_off || !b->tri2_off || !b->tri2 || (!b->tri1 && false))
+    if (!b->x || !b->y || !b->z || !b->v || !b->tri1_off || !b->tri2_off || !b->tri2)
         return set_error(MVOSR_ERR_ARG, "scale_batch: missing input plane / triangulation");
     if (!o->raw_scale || !o->height || !o->height_level || !o->status)
         return set_error(MVOSR_ERR_ARG, "scale_batch: raw_scale/height/height_level/status are required outputs");
@@ -932,12 +956,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
     ka.first_frame = first_frame; ka.height_level_in = nullptr; ka.debug_skip = debug_skip_env();
     const bool full = o->tri_normals || o->tri_pitch_deg || o->tri_heights;
-    switch (pick_waves(waves_per_frame, b->max_feat)) {
-        case 1: return launch_scale<1>(ctx, ka, n_launch, full);
-        case 4: return launch_scale<4>(ctx, ka, n_launch, full);
-        case 16: return launch_scale<16>(ctx, ka, n_launch, full);
-        default: return launch_scale<8>(ctx, ka, n_launch, full);
-    }
+    return dispatch_scale(ctx, ka, pick_waves(waves_per_frame, b->max_feat), n_launch, full);
 }
 
 int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const mvosr_outputs *o,
@@ -951,12 +970,7 @@ int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_
     KArgs ka;
     ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
     ka.first_frame = 0; ka.height_level_in = nullptr; ka.debug_skip = 0;
-    switch (pick_waves(waves_per_frame, b->max_feat)) {
-        case 1: return launch_vote<1>(ctx, ka, b->n_frames);
-        case 4: return launch_vote<4>(ctx, ka, b->n_frames);
-        case 16: return launch_vote<16>(ctx, ka, b->n_frames);
-        default: return launch_vote<8>(ctx, ka, b->n_frames);
-    }
+    return dispatch_vote(ctx, ka, pick_waves(waves_per_frame, b->max_feat), b->n_frames);
 }
 
 int mvosr_road_model_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const double *height_level_in,
