@@ -397,9 +397,11 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
 // ---------------------------------------------------------------------------------------------
 // Phase C: road model on the y' of the selected points.
 // `fetch(j, y)` yields the j-th candidate value (returns false if candidate j is not selected).
-// All waves take part in the three passes and their reductions; the 169-bin mode / minimum
-// logic that turns the histogram into the answer runs on wave 0 only (thread 0 writes the
-// frame's outputs), so the returned struct is meaningful on wave 0.
+// Every wave first packs the selected values of its own slice of candidates into a dense
+// per-wave list (ballot prefix, wave-local LDS, no barrier) and keeps them in registers, so the
+// three passes run on full lanes.  All waves take part in the passes and their reductions; the
+// 169-bin mode / minimum logic that turns the histogram into the answer runs on wave 0 only
+// (thread 0 writes the frame's outputs), so the returned struct is meaningful on wave 0.
 // ---------------------------------------------------------------------------------------------
 struct RoadResult {
     double height;
@@ -408,62 +410,71 @@ struct RoadResult {
     double mean, std, skew, median;
 };
 
-// is y inside the interval remove_single deletes for a single-count bin? (:284-293)
-// `single` = the bins whose raw count is exactly 1 (wave-uniform bit-set).
-__device__ __forceinline__ bool dropped_by_single(double y, const Bits192 &single, int first_single) {
-    if (first_single < 0 || !(y > -1.0 && y < 18.0)) return false;
-    int kb = (int)(y * 10.0);
-    kb = max(0, min(kBins - 1, kb));
+// is y (histogram bin `bin`) inside the interval remove_single deletes for a single-count bin?
+// (:284-293)  `single` = bins whose raw count is exactly 1; an interval is built from the bin's
+// RIGHT edge r as [r-0.1, r] for the first single bin and (r-0.1, r] for the others — r-0.1 is
+// not always the bin's own left edge in floating point, so neighbours are checked too.
+__device__ __forceinline__ bool dropped_by_single(double y, int bin, const Bits192 &single, int first_single) {
     bool d = false;
 #pragma unroll
     for (int dk = -1; dk <= 1; ++dk) {
-        const int k = kb + dk;
+        const int k = bin + dk;
         const bool is_single = (k >= 0) && (k < kBins) && single.test_lane(max(k, 0));
         const double r = bin_edge(k + 1);
-        const double lo = r - 0.1;                          // bin_single-0.1, not the bin's own left edge
+        const double lo = r - 0.1;
         const bool in = (k == first_single) ? (y >= lo && y <= r) : (y > lo && y <= r);
         d |= is_single && in;
     }
     return d;
 }
 
-constexpr int kRC = 4;      // road-model candidates per thread kept in registers across the passes
+constexpr int kRC = 4;      // dense road-model values per lane kept in registers across the passes
 
 template <int WAVES, typename Fetch>
 __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetch fetch, double height_level,
-                                                 const mvosr_params &P, double *list /* >= n_cand doubles of LDS, free */,
-                                                 int32_t *g_hist MVOSR_STAMP_ARG) {
+                                                 const mvosr_params &P, double *list /* the candidates' own LDS array: packed in place */,
+                                                 double *medlist /* >= n_cand doubles of free LDS */, int32_t *g_hist MVOSR_STAMP_ARG) {
     constexpr int B = WAVES * kWave;
-    const int tid = threadIdx.x, lane = lane_id();
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     RoadResult R;
     R.height = nan(""); R.status = MVOSR_ST_MODE; R.n_modes = 0; R.mode_left = -1; R.mode_right = -1;
     R.mean = R.std = R.skew = R.median = nan("");
 
+    // pack this wave's selected values in place: slice = `per` sub-chunks of 64 candidates.  A value
+    // moves to an index <= its own inside the wave's slice and a sub-chunk is read (one
+    // instruction, all lanes) before anything of it is overwritten, so no barrier is needed.
+    const int per = (n_cand + B - 1) / B;
+    const int wbeg = w * per * kWave;
+    double *mine = list + wbeg;
+    int cnt = 0;
+    for (int k = 0; k < per; ++k) {
+        const int j = wbeg + k * kWave + lane;
+        double y = 0.0;
+        const bool sel = (j < n_cand) && fetch(j, y);
+        const unsigned long long m = __ballot(sel);
+        if (sel) mine[cnt + __popcll(m & ((1ull << lane) - 1ull))] = y;
+        cnt += __popcll(m);
+    }
     // histogram (np.histogram, :326); hist[] was zeroed by the caller before a barrier.
-    // The first kRC candidates of every thread stay in registers for the later passes.
+    // The first kRC values of every lane stay in registers (with their bins) for the later passes.
     double yc[kRC];
-    unsigned have = 0u, kept = 0u;
-    int nsel = 0;
+    int binc[kRC];
 #pragma unroll
     for (int k = 0; k < kRC; ++k) {
-        const int j = k * B + tid;
-        double y = 0.0;
-        if (j < n_cand && fetch(j, y)) {
-            have |= 1u << k;
-            ++nsel;
+        const int i = k * kWave + lane;
+        yc[k] = 0.0; binc[k] = -1;
+        if (i < cnt) {
+            const double y = mine[i];
             const int bin = bin_of(y);
             if (bin >= 0) atomicAdd(&s.hist[bin], 1);
+            yc[k] = y; binc[k] = bin;
         }
-        yc[k] = y;
     }
-    for (int j = kRC * B + tid; j < n_cand; j += B) {
-        double y;
-        if (!fetch(j, y)) continue;
-        ++nsel;
-        const int bin = bin_of(y);
+    for (int i = kRC * kWave + lane; i < cnt; i += kWave) {
+        const int bin = bin_of(mine[i]);
         if (bin >= 0) atomicAdd(&s.hist[bin], 1);
     }
-    int d0 = 0, d1 = 0, d2 = 0;
+    int nsel = (lane == 0) ? cnt : 0, d0 = 0, d1 = 0, d2 = 0;
     block_sum4i<WAVES>(nsel, d0, d1, d2, s.red + R_ROAD_N * 2 * WAVES);    // barrier: histogram complete
     MVOSR_STAMP(6);
     R.n_sel = nsel;
@@ -484,28 +495,36 @@ __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetc
     }
     mx = wave_max(mx);
     const int first_single = single.lowest_from(0);
+    // a value can only be dropped if its own bin or a neighbouring one has count 1
+    Bits192 near;
+    near.w[0] = single.w[0] | (single.w[0] << 1) | (single.w[0] >> 1) | (single.w[1] << 63);
+    near.w[1] = single.w[1] | (single.w[1] << 1) | (single.w[1] >> 1) | (single.w[0] >> 63) | (single.w[2] << 63);
+    near.w[2] = single.w[2] | (single.w[2] << 1) | (single.w[2] >> 1) | (single.w[1] >> 63);
     // check_mode returns no modes iff max <= 2 (:451-452); otherwise the maximum bin itself is one
     const bool have_modes = mx > P.mode_min;
 
     // second pass: drop the points inside a single bin's interval (:284-293), accumulate the mean
     double sum = 0.0, cntd = 0.0;
+    unsigned kept = 0u;
     if (!have_modes && tid == 0) s.misc[M_LIST] = 0;
     if (!have_modes) __syncthreads();
 #pragma unroll
     for (int k = 0; k < kRC; ++k) {
-        if (!((have >> k) & 1u)) continue;
+        const int i = k * kWave + lane;
+        if (i >= cnt) continue;
         const double y = yc[k];
-        if (dropped_by_single(y, single, first_single)) continue;
+        const int bin = binc[k];
+        if (bin >= 0 && first_single >= 0 && near.test_lane(bin) && dropped_by_single(y, bin, single, first_single)) continue;
         kept |= 1u << k;
         sum += y; cntd += 1.0;
-        if (!have_modes) list[atomicAdd(&s.misc[M_LIST], 1)] = y;              // only the median needs the values
+        if (!have_modes) medlist[atomicAdd(&s.misc[M_LIST], 1)] = y;           // only the median needs the values
     }
-    for (int j = kRC * B + tid; j < n_cand; j += B) {
-        double y;
-        if (!fetch(j, y)) continue;
-        if (dropped_by_single(y, single, first_single)) continue;
+    for (int i = kRC * kWave + lane; i < cnt; i += kWave) {
+        const double y = mine[i];
+        const int bin = bin_of(y);
+        if (bin >= 0 && first_single >= 0 && near.test_lane(bin) && dropped_by_single(y, bin, single, first_single)) continue;
         sum += y; cntd += 1.0;
-        if (!have_modes) list[atomicAdd(&s.misc[M_LIST], 1)] = y;
+        if (!have_modes) medlist[atomicAdd(&s.misc[M_LIST], 1)] = y;
     }
     block_sum2<WAVES>(sum, cntd, s.red + R_ROAD_SUM * 2 * WAVES);
     MVOSR_STAMP(7);
@@ -522,10 +541,10 @@ __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetc
         const int klo = (nkept - 1) >> 1, khi = nkept >> 1;
         double *med = reinterpret_cast<double *>(&s.misc[M_MEDLO]);
         for (int i = tid; i < nkept; i += B) {
-            const double yi = list[i];
+            const double yi = medlist[i];
             int rank = 0;
             for (int j = 0; j < nkept; ++j) {
-                const double yj = list[j];
+                const double yj = medlist[j];
                 rank += (yj < yi) || (yj == yi && j < i);
             }
             if (rank == klo) med[0] = yi;
@@ -546,16 +565,16 @@ __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetc
         const double d = yc[k] - mean;
         ss += d * d;
     }
-    for (int j = kRC * B + tid; j < n_cand; j += B) {
-        double y;
-        if (!fetch(j, y)) continue;
-        if (dropped_by_single(y, single, first_single)) continue;
+    for (int i = kRC * kWave + lane; i < cnt; i += kWave) {
+        const double y = mine[i];
+        const int bin = bin_of(y);
+        if (bin >= 0 && first_single >= 0 && near.test_lane(bin) && dropped_by_single(y, bin, single, first_single)) continue;
         const double d = y - mean;
         ss += d * d;
     }
     block_sum2<WAVES>(ss, dummy, s.red + R_ROAD_SS * 2 * WAVES);
     MVOSR_STAMP(8);
-    if (wave_id() != 0) return R;               // the rest is the frame's scalar answer: wave 0 only
+    if (w != 0) return R;                       // the rest is the frame's scalar answer: wave 0 only
 
     if (g_hist) {
 #pragma unroll
@@ -685,8 +704,8 @@ __global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(
         if (a.o.selected) {
             for (int j = tid; j < nvalid; j += B) a.o.selected[off + j] = (uint8_t)((s.sel[j >> 5] >> (j & 31)) & 1u);
         }
-        // the P plane is dead after the sweeps: it serves as the median's value list
-        R = phase_road<WAVES>(s, nvalid, fetch, S.height_level, a.P, reinterpret_cast<double *>(s.P),
+        // the P plane is dead after the sweeps (it serves as the median's value list); Y is packed in place
+        R = phase_road<WAVES>(s, nvalid, fetch, S.height_level, a.P, s.Y, reinterpret_cast<double *>(s.P),
                               a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
         status = R.status;
         if (status == MVOSR_ST_NO_FLAT) raw = a.P.absolute_reference / S.height_level;        // :421
@@ -747,7 +766,7 @@ __global__ __launch_bounds__(WAVES *kWave) void road_model_kernel(const KArgs a)
     const double hl = a.height_level_in ? a.height_level_in[f] : nan("");
     auto fetch = [&](int j, double &y) -> bool { y = s.Y[j]; return true; };
     MVOSR_STAMP_DECL
-    RoadResult R = phase_road<WAVES>(s, n, fetch, hl, a.P, reinterpret_cast<double *>(s.P),
+    RoadResult R = phase_road<WAVES>(s, n, fetch, hl, a.P, s.Y, reinterpret_cast<double *>(s.P),
                                      a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
     if (tid == 0) {
         double height = nan(""), raw = nan("");
