@@ -111,6 +111,8 @@ typedef struct mvosr_batch {
                                     vote keeps a different number gets MVOSR_ST_ERR_MASK        */
     int32_t max_feat;            /* max(feat_cnt) — sizes the LDS request                      */
     int32_t reserved;
+    int64_t total_feat;          /* length (elements) of the x/y/z/v planes: feat_off[F-1] + padded
+                                    count of the last frame; sizes the context's workspace      */
 } mvosr_batch;
 
 /* Outputs (device pointers; any optional pointer may be NULL). */
@@ -143,6 +145,10 @@ int mvosr_ctx_destroy(mvosr_ctx *ctx);
 int mvosr_ctx_set_stream(mvosr_ctx *ctx, void *hip_stream);
 void *mvosr_ctx_stream(mvosr_ctx *ctx);
 int mvosr_ctx_sync(mvosr_ctx *ctx);
+/* Pre-size the context's workspace (the dense lists of selected y' the scale kernel hands to the
+ * road-model kernel: total_feat doubles + n_frames int32).  mvosr_scale_batch grows it on demand
+ * with hipMalloc; call this first if the launches must not allocate (e.g. under graph capture). */
+int mvosr_ctx_reserve(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat);
 /* Device facts for the host (name, CU count, LDS per workgroup). */
 int mvosr_ctx_device_info(mvosr_ctx *ctx, char *name, int name_len, int *n_cu, int *lds_per_block);
 
@@ -167,8 +173,12 @@ void mvosr_default_params(mvosr_params *p, double absolute_reference);
  *   feature_remap (:390-394) -> find_outliers/check_triangle on tri1 (:151-167,:105-119)
  *   -> compaction of the survivors (:264-265) -> feature_selection_by_tri on tri2 (:225-248)
  *   -> road_model_calculation_static (:324-354) -> raw scale (:419/:421).
- * `waves_per_frame` selects the variant: 0 = choose from max_feat, 1 = one wavefront per
- * frame, 4/8/16 = one workgroup of that many wavefronts per frame.
+ * Two launches on the context's stream: the scale kernel (remap, vote, compaction, triangle
+ * sweeps; one workgroup per frame, its features resident in LDS) leaves every frame's selected
+ * y' as a dense list in the context's workspace, and the road-model kernel (one WAVEFRONT per
+ * frame, no LDS-resident frame, full occupancy) turns each list into height / scale / status.
+ * `waves_per_frame` selects the scale kernel's variant: 0 = choose from max_feat, 1 = one
+ * wavefront per frame (<= 512 features), 4/8/16 = one workgroup of that many wavefronts.
  * `first_frame`/`n_launch` restrict the launch to a sub-range of the batch (n_launch <= 0: all).
  */
 int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b,
@@ -188,7 +198,8 @@ int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_
  * Stage K3 alone: road_model_calculation_static (scale_calculator.py:324-354) on packed
  * lists of already-remapped y values (feat_off/feat_cnt/y of `b`; nothing else is read);
  * `height_level_in` [F] supplies the fallback level (:335).  Writes height, status and the
- * optional counts/hist/stats; raw_scale = absolute_reference/height.
+ * optional counts/hist/stats; raw_scale = absolute_reference/height.  Same kernel as the second
+ * launch of mvosr_scale_batch (one wavefront per list); `waves_per_frame` is ignored.
  */
 int mvosr_road_model_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b,
                            const double *height_level_in, const mvosr_outputs *o,

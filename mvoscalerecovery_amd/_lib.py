@@ -31,7 +31,8 @@ class Batch(C.Structure):
     _fields_ = [("n_frames", C.c_int64), ("feat_off", C.c_void_p), ("feat_cnt", C.c_void_p),
                 ("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("v", C.c_void_p),
                 ("tri1_off", C.c_void_p), ("tri1", C.c_void_p), ("tri2_off", C.c_void_p), ("tri2", C.c_void_p),
-                ("n2_expected", C.c_void_p), ("max_feat", C.c_int32), ("reserved", C.c_int32)]
+                ("n2_expected", C.c_void_p), ("max_feat", C.c_int32), ("reserved", C.c_int32),
+                ("total_feat", C.c_int64)]
 
 
 class Outputs(C.Structure):
@@ -52,6 +53,7 @@ SYMBOLS = {
     "mvosr_ctx_set_stream": (C.c_int, [_P, _P]),
     "mvosr_ctx_stream": (_P, [_P]),
     "mvosr_ctx_sync": (C.c_int, [_P]),
+    "mvosr_ctx_reserve": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "mvosr_ctx_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mvosr_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "mvosr_free": (C.c_int, [_P, _P]),

@@ -36,6 +36,24 @@ int ctx_activate(mvosr_ctx *ctx) {
     return MVOSR_OK;
 }
 
+int ctx_workspace(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat, double **ysel, int32_t **nsel) {
+    if ((size_t)total_feat > ctx->ws_ysel_len) {
+        if (ctx->ws_ysel) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->ws_ysel); ctx->ws_ysel = nullptr; ctx->ws_ysel_len = 0; }
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->ws_ysel), (size_t)total_feat * sizeof(double));
+        if (e != hipSuccess) return set_hip_error("hipMalloc(workspace: selected-y plane)", e);
+        ctx->ws_ysel_len = (size_t)total_feat;
+    }
+    if ((size_t)n_frames > ctx->ws_nsel_len) {
+        if (ctx->ws_nsel) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->ws_nsel); ctx->ws_nsel = nullptr; ctx->ws_nsel_len = 0; }
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->ws_nsel), (size_t)n_frames * sizeof(int32_t));
+        if (e != hipSuccess) return set_hip_error("hipMalloc(workspace: selected counts)", e);
+        ctx->ws_nsel_len = (size_t)n_frames;
+    }
+    *ysel = ctx->ws_ysel;
+    *nsel = ctx->ws_nsel;
+    return MVOSR_OK;
+}
+
 }  // namespace mvosr
 
 using namespace mvosr;
@@ -75,6 +93,7 @@ int mvosr_ctx_create(int device, mvosr_ctx **out) {
     e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return set_hip_error("hipStreamCreateWithFlags", e); }
     ctx->stream = ctx->own_stream;
+    ctx->ws_ysel = nullptr; ctx->ws_ysel_len = 0; ctx->ws_nsel = nullptr; ctx->ws_nsel_len = 0;
     ctx->n_cu = prop.multiProcessorCount;
     int optin = 0;
     if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || optin <= 0)
@@ -91,6 +110,8 @@ int mvosr_ctx_destroy(mvosr_ctx *ctx) {
     if (!ctx) return MVOSR_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws_ysel) (void)hipFree(ctx->ws_ysel);
+    if (ctx->ws_nsel) (void)hipFree(ctx->ws_nsel);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MVOSR_OK;
@@ -117,6 +138,14 @@ int mvosr_ctx_device_info(mvosr_ctx *ctx, char *name, int name_len, int *n_cu, i
     if (n_cu) *n_cu = ctx->n_cu;
     if (lds_per_block) *lds_per_block = ctx->max_lds_per_block;
     return MVOSR_OK;
+}
+
+int mvosr_ctx_reserve(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat) {
+    if (!ctx || n_frames < 0 || total_feat < 0) return set_error(MVOSR_ERR_ARG, "ctx_reserve: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double *a = nullptr;
+    int32_t *b = nullptr;
+    return ctx_workspace(ctx, n_frames, total_feat, &a, &b);
 }
 
 int mvosr_malloc(mvosr_ctx *ctx, size_t bytes, void **dptr) {

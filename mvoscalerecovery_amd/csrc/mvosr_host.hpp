@@ -13,6 +13,11 @@ struct mvosr_ctx {
     int n_cu;
     int max_lds_per_block;
     char name[128];
+    // grow-only workspace between the scale kernel and the road-model kernel
+    double *ws_ysel;
+    size_t ws_ysel_len;
+    int32_t *ws_nsel;
+    size_t ws_nsel_len;
 };
 
 namespace mvosr {
@@ -23,5 +28,7 @@ int check_launch(const char *kernel);
 int ctx_activate(mvosr_ctx *ctx);                 // hipSetDevice(ctx->device)
 inline hipStream_t ctx_stream(mvosr_ctx *ctx) { return ctx->stream; }
 void set_max_dynamic_lds(int bytes);
+// Make the context's workspace at least (n_frames, total_feat) large; hipMalloc only when it grows.
+int ctx_workspace(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat, double **ysel, int32_t **nsel);
 
 }  // namespace mvosr

@@ -395,13 +395,13 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Phase C: road model on the y' of the selected points.
-// `fetch(j, y)` yields the j-th candidate value (returns false if candidate j is not selected).
-// Every wave first packs the selected values of its own slice of candidates into a dense
-// per-wave list (ballot prefix, wave-local LDS, no barrier) and keeps them in registers, so the
-// three passes run on full lanes.  All waves take part in the passes and their reductions; the
-// 169-bin mode / minimum logic that turns the histogram into the answer runs on wave 0 only
-// (thread 0 writes the frame's outputs), so the returned struct is meaningful on wave 0.
+// Phase C (its own kernel, one frame per WAVEFRONT): road model on a dense list of y' values —
+// the selected points the scale kernel wrote to the workspace, or caller-supplied lists.
+// No barriers: a wave keeps up to 16 values per lane in registers, builds the 169-bin histogram
+// with wave-local LDS atomics, evaluates remove_single / modes / local minima on 64-bit ballots
+// and reduces mean / std with DPP.  Runs at full occupancy, so its latency chains are hidden by
+// other waves instead of holding a 53 KB LDS allocation idle.
+//                                                (road_model_calculation_static, :324-354)
 // ---------------------------------------------------------------------------------------------
 struct RoadResult {
     double height;
@@ -428,72 +428,69 @@ __device__ __forceinline__ bool dropped_by_single(double y, int bin, const Bits1
     return d;
 }
 
-constexpr int kRC = 4;      // dense road-model values per lane kept in registers across the passes
+constexpr int kRoadRC = 16;            // values per lane kept in registers (lists up to 1024 values)
+constexpr int kRoadWaves = 4;          // frames (wavefronts) per workgroup
+constexpr int kStPending = -1;         // scale kernel -> road kernel: "road model still to run"
 
-template <int WAVES, typename Fetch>
-__device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetch fetch, double height_level,
-                                                 const mvosr_params &P, double *list /* the candidates' own LDS array: packed in place */,
-                                                 double *medlist /* >= n_cand doubles of free LDS */, int32_t *g_hist MVOSR_STAMP_ARG) {
-    constexpr int B = WAVES * kWave;
-    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+struct RoadArgs {
+    mvosr_params P;
+    const int64_t *off;          // [F] start of frame f's list in `y`
+    const int32_t *cnt;          // [F] list length
+    const double *y;             // the values
+    double *scratch;             // same layout, writable: kept values for the median fallback (may alias y)
+    const double *height_level;  // [F] fallback level (:335), may be NULL
+    mvosr_outputs o;
+    int64_t first_frame, n_frames;
+    int pending_only;            // 1: fused path, only frames the scale kernel left pending
+};
+
+__device__ __forceinline__ RoadResult road_wave(int *hist, const double *yv, double *scratch, int M, double height_level,
+                                                const mvosr_params &P, int32_t *g_hist) {
+    const int lane = lane_id();
     RoadResult R;
-    R.height = nan(""); R.status = MVOSR_ST_MODE; R.n_modes = 0; R.mode_left = -1; R.mode_right = -1;
+    R.height = nan(""); R.status = MVOSR_ST_MODE; R.n_sel = M; R.n_kept = 0; R.n_modes = 0; R.mode_left = -1; R.mode_right = -1;
     R.mean = R.std = R.skew = R.median = nan("");
-
-    // pack this wave's selected values in place: slice = `per` sub-chunks of 64 candidates.  A value
-    // moves to an index <= its own inside the wave's slice and a sub-chunk is read (one
-    // instruction, all lanes) before anything of it is overwritten, so no barrier is needed.
-    const int per = (n_cand + B - 1) / B;
-    const int wbeg = w * per * kWave;
-    double *mine = list + wbeg;
-    int cnt = 0;
-    for (int k = 0; k < per; ++k) {
-        const int j = wbeg + k * kWave + lane;
-        double y = 0.0;
-        const bool sel = (j < n_cand) && fetch(j, y);
-        const unsigned long long m = __ballot(sel);
-        if (sel) mine[cnt + __popcll(m & ((1ull << lane) - 1ull))] = y;
-        cnt += __popcll(m);
-    }
-    // histogram (np.histogram, :326); hist[] was zeroed by the caller before a barrier.
-    // The first kRC values of every lane stay in registers (with their bins) for the later passes.
-    double yc[kRC];
-    int binc[kRC];
+    if (M == 0) { R.status = MVOSR_ST_NO_FLAT; return R; }
 #pragma unroll
-    for (int k = 0; k < kRC; ++k) {
+    for (int c = 0; c < 3; ++c) { const int b = lane + 64 * c; if (b < 176) hist[b] = 0; }
+
+    // histogram (np.histogram, :326); the first kRoadRC values of every lane stay in registers
+    double yc[kRoadRC];
+    int binc[kRoadRC];
+#pragma unroll
+    for (int k = 0; k < kRoadRC; ++k) {
         const int i = k * kWave + lane;
         yc[k] = 0.0; binc[k] = -1;
-        if (i < cnt) {
-            const double y = mine[i];
+        if (i < M) {
+            const double y = yv[i];
             const int bin = bin_of(y);
-            if (bin >= 0) atomicAdd(&s.hist[bin], 1);
+            if (bin >= 0) atomicAdd(&hist[bin], 1);
             yc[k] = y; binc[k] = bin;
         }
     }
-    for (int i = kRC * kWave + lane; i < cnt; i += kWave) {
-        const int bin = bin_of(mine[i]);
-        if (bin >= 0) atomicAdd(&s.hist[bin], 1);
+    for (int i = kRoadRC * kWave + lane; i < M; i += kWave) {
+        const int bin = bin_of(yv[i]);
+        if (bin >= 0) atomicAdd(&hist[bin], 1);
     }
-    int nsel = (lane == 0) ? cnt : 0, d0 = 0, d1 = 0, d2 = 0;
-    block_sum4i<WAVES>(nsel, d0, d1, d2, s.red + R_ROAD_N * 2 * WAVES);    // barrier: histogram complete
-    MVOSR_STAMP(6);
-    R.n_sel = nsel;
-    if (nsel == 0) { R.status = MVOSR_ST_NO_FLAT; R.n_kept = 0; return R; }
-
-    // every wave needs the single-count bins (remove_single) and the maximum (are there modes?):
-    // lane l looks at bins l, l+64, l+128
+    // (one wave: its LDS operations execute in order, the reads below see the atomics above)
     int hraw[3], hz[3];
-    Bits192 single;
-    int mx = 0;
+    Bits192 single, modes, mins;
+    int mx = 0, mn = 0x7fffffff;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int b = lane + 64 * c;
-        hraw[c] = (b < kBins) ? s.hist[b] : 0;
+        hraw[c] = (b < kBins) ? hist[b] : 0;
         hz[c] = (hraw[c] == 1) ? 0 : hraw[c];                                  // dis[dis==1]=0, :328
         single.w[c] = __ballot(b < kBins && hraw[c] == 1);
         mx = max(mx, hz[c]);
+        if (b < kBins) mn = min(mn, hz[c]);
     }
     mx = wave_max(mx);
+    mn = wave_min(mn);
+    if (g_hist) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const int b = lane + 64 * c; if (b < kBins) { g_hist[b] = hraw[c]; g_hist[kBins + b] = hz[c]; } }
+    }
     const int first_single = single.lowest_from(0);
     // a value can only be dropped if its own bin or a neighbouring one has count 1
     Bits192 near;
@@ -506,85 +503,87 @@ __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetc
     // second pass: drop the points inside a single bin's interval (:284-293), accumulate the mean
     double sum = 0.0, cntd = 0.0;
     unsigned kept = 0u;
-    if (!have_modes && tid == 0) s.misc[M_LIST] = 0;
-    if (!have_modes) __syncthreads();
+    int nlist = 0;                               // median fallback: kept values packed into `scratch`
 #pragma unroll
-    for (int k = 0; k < kRC; ++k) {
+    for (int k = 0; k < kRoadRC; ++k) {
         const int i = k * kWave + lane;
-        if (i >= cnt) continue;
-        const double y = yc[k];
-        const int bin = binc[k];
-        if (bin >= 0 && first_single >= 0 && near.test_lane(bin) && dropped_by_single(y, bin, single, first_single)) continue;
-        kept |= 1u << k;
-        sum += y; cntd += 1.0;
-        if (!have_modes) medlist[atomicAdd(&s.misc[M_LIST], 1)] = y;           // only the median needs the values
+        bool keep = false;
+        if (i < M) {
+            const int bin = binc[k];
+            keep = !(bin >= 0 && first_single >= 0 && near.test_lane(bin) && dropped_by_single(yc[k], bin, single, first_single));
+        }
+        if (keep) { kept |= 1u << k; sum += yc[k]; cntd += 1.0; }
+        if (!have_modes) {                       // wave-uniform
+            const unsigned long long m = __ballot(keep);
+            if (keep) scratch[nlist + __popcll(m & ((1ull << lane) - 1ull))] = yc[k];
+            nlist += __popcll(m);
+        }
     }
-    for (int i = kRC * kWave + lane; i < cnt; i += kWave) {
-        const double y = mine[i];
-        const int bin = bin_of(y);
-        if (bin >= 0 && first_single >= 0 && near.test_lane(bin) && dropped_by_single(y, bin, single, first_single)) continue;
-        sum += y; cntd += 1.0;
-        if (!have_modes) medlist[atomicAdd(&s.misc[M_LIST], 1)] = y;
+    for (int i0 = kRoadRC * kWave; i0 < M; i0 += kWave) {
+        const int i = i0 + lane;
+        bool keep = false;
+        double y = 0.0;
+        if (i < M) {
+            y = yv[i];
+            const int bin = bin_of(y);
+            keep = !(bin >= 0 && first_single >= 0 && near.test_lane(bin) && dropped_by_single(y, bin, single, first_single));
+        }
+        if (keep) { sum += y; cntd += 1.0; }
+        if (!have_modes) {
+            const unsigned long long m = __ballot(keep);
+            if (keep) scratch[nlist + __popcll(m & ((1ull << lane) - 1ull))] = y;     // index <= i: in-place safe when scratch == yv
+            nlist += __popcll(m);
+        }
     }
-    block_sum2<WAVES>(sum, cntd, s.red + R_ROAD_SUM * 2 * WAVES);
-    MVOSR_STAMP(7);
+    sum = wave_sum(sum);
+    cntd = wave_sum(cntd);
     const int nkept = (int)cntd;
     R.n_kept = nkept;
 
     if (!have_modes) {
-        if (g_hist && tid < kWave) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { const int b = lane + 64 * c; if (b < kBins) { g_hist[b] = hraw[c]; g_hist[kBins + b] = hz[c]; } }
-        }
         if (nkept == 0) { R.height = height_level; R.status = MVOSR_ST_LEVEL; return R; }   // :334-335
-        // np.median (:333) by rank counting: the two middle order statistics
+        // np.median (:333) by rank counting over the packed list: the two middle order statistics
+        __threadfence_block();                   // the wave's own stores, visible to all its lanes
         const int klo = (nkept - 1) >> 1, khi = nkept >> 1;
-        double *med = reinterpret_cast<double *>(&s.misc[M_MEDLO]);
-        for (int i = tid; i < nkept; i += B) {
-            const double yi = medlist[i];
+        double mlo = 0.0, mhi = 0.0;
+        int flo = 0, fhi = 0;
+        for (int i = lane; i < nkept; i += kWave) {
+            const double yi = scratch[i];
             int rank = 0;
             for (int j = 0; j < nkept; ++j) {
-                const double yj = medlist[j];
+                const double yj = scratch[j];
                 rank += (yj < yi) || (yj == yi && j < i);
             }
-            if (rank == klo) med[0] = yi;
-            if (rank == khi) med[1] = yi;
+            if (rank == klo) { mlo = yi; flo = 1; }
+            if (rank == khi) { mhi = yi; fhi = 1; }
         }
-        __syncthreads();
-        R.median = (klo == khi) ? med[0] : (med[0] + med[1]) / 2.0;
+        // exactly one lane holds each of them
+        const unsigned long long blo = __ballot(flo), bhi = __ballot(fhi);
+        mlo = readlane_d(mlo, (int)__ffsll((long long)blo) - 1);
+        mhi = readlane_d(mhi, (int)__ffsll((long long)bhi) - 1);
+        R.median = (klo == khi) ? mlo : (mlo + mhi) / 2.0;
         R.height = R.median; R.status = MVOSR_ST_MEDIAN;
         return R;
     }
 
     // third pass: standard deviation around the mean (np.std, :496)
     const double mean = sum / cntd;                                             // np.mean
-    double ss = 0.0, dummy = 0.0;
+    double ss = 0.0;
 #pragma unroll
-    for (int k = 0; k < kRC; ++k) {
+    for (int k = 0; k < kRoadRC; ++k) {
         if (!((kept >> k) & 1u)) continue;
         const double d = yc[k] - mean;
         ss += d * d;
     }
-    for (int i = kRC * kWave + lane; i < cnt; i += kWave) {
-        const double y = mine[i];
+    for (int i = kRoadRC * kWave + lane; i < M; i += kWave) {
+        const double y = yv[i];
         const int bin = bin_of(y);
         if (bin >= 0 && first_single >= 0 && near.test_lane(bin) && dropped_by_single(y, bin, single, first_single)) continue;
         const double d = y - mean;
         ss += d * d;
     }
-    block_sum2<WAVES>(ss, dummy, s.red + R_ROAD_SS * 2 * WAVES);
-    MVOSR_STAMP(8);
-    if (w != 0) return R;                       // the rest is the frame's scalar answer: wave 0 only
+    ss = wave_sum(ss);
 
-    if (g_hist) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { const int b = lane + 64 * c; if (b < kBins) { g_hist[b] = hraw[c]; g_hist[kBins + b] = hz[c]; } }
-    }
-    Bits192 modes, mins;
-    int mn = 0x7fffffff;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { if (lane + 64 * c < kBins) mn = min(mn, hz[c]); }
-    mn = wave_min(mn);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int b = lane + 64 * c;
@@ -595,7 +594,7 @@ __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetc
                 is_mode = (h == mx);                                            // :454-458
                 is_min = (h == mn);                                             // :433-437
             } else {
-                const int lraw = s.hist[b - 1], rraw = s.hist[b + 1];
+                const int lraw = hist[b - 1], rraw = hist[b + 1];
                 const int hl_ = (lraw == 1) ? 0 : lraw, hr_ = (rraw == 1) ? 0 : rraw;
                 is_mode = (h >= hl_) && (h >= hr_) && ((double)h >= P.mode_rel * (double)mx) && (h >= P.mode_min);   // :459-463
                 is_min = (h <= hl_) && (h <= hr_) && !((h == hr_) && (h == hl_));                                   // :438-442
@@ -625,6 +624,32 @@ __device__ __forceinline__ RoadResult phase_road(const Smem &s, int n_cand, Fetc
     return R;
 }
 
+__global__ __launch_bounds__(kRoadWaves *kWave) void road_model_kernel(const RoadArgs a) {
+    __shared__ int hist_all[kRoadWaves][176];
+    const int64_t f = a.first_frame + (int64_t)blockIdx.x * kRoadWaves + wave_id();
+    if (f >= a.first_frame + a.n_frames) return;
+    if (a.pending_only && a.o.status[f] != kStPending) return;
+    const int M = a.cnt[f];
+    const int64_t off = a.off[f];
+    const double hl = a.height_level ? a.height_level[f] : nan("");
+    const RoadResult R = road_wave(hist_all[wave_id()], a.y + off, a.scratch + off, M, hl, a.P,
+                                   a.o.hist ? a.o.hist + f * 2 * kBins : nullptr);
+    if (lane_id() == 0) {
+        double height = nan(""), raw = nan("");
+        if (R.status == MVOSR_ST_NO_FLAT) raw = a.P.absolute_reference / hl;                        // :421
+        else if (R.status <= MVOSR_ST_LEVEL) { height = R.height; raw = a.P.absolute_reference / height; }   // :419
+        a.o.raw_scale[f] = raw; a.o.height[f] = height; a.o.status[f] = R.status;
+        if (!a.pending_only && a.o.height_level) a.o.height_level[f] = hl;
+        if (a.o.counts) {
+            int32_t *c = a.o.counts + f * MVOSR_N_COUNTS;
+            if (!a.pending_only) { c[MVOSR_CNT_VALID] = M; c[MVOSR_CNT_TRI_PITCH] = 0; c[MVOSR_CNT_TRI_VALID] = 0; }
+            c[MVOSR_CNT_SELECTED] = R.n_sel; c[MVOSR_CNT_KEPT] = R.n_kept; c[MVOSR_CNT_MODES] = R.n_modes;
+            c[MVOSR_CNT_MODE_LEFT] = R.mode_left; c[MVOSR_CNT_MODE_RIGHT] = R.mode_right;
+        }
+        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = R.mean; st[1] = R.std; st[2] = R.skew; st[3] = R.median; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
@@ -636,6 +661,8 @@ struct KArgs {
     int64_t first_frame;
     const double *height_level_in;
     int debug_skip;          // ablation bits for profiling runs (env MVOSR_DEBUG_SKIP); 0 in production
+    double *ysel;            // workspace plane (laid out like x): the selected y' of every frame, dense
+    int32_t *nsel;           // workspace [F]: how many
 };
 
 __device__ __forceinline__ void write_counts(const KArgs &a, int64_t f, int nvalid, int npitch, int ntv, const RoadResult &R) {
@@ -670,12 +697,11 @@ __global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(
         if (tid == 0) {
             a.o.raw_scale[f] = nan(""); a.o.height[f] = nan(""); a.o.height_level[f] = nan("");
             a.o.status[f] = MVOSR_ST_ERR_EMPTY;
+            a.nsel[f] = 0;
             write_counts(a, f, 0, 0, 0, R);
         }
         return;
     }
-    for (int i = tid; i < 176; i += B) s.hist[i] = 0;
-
     int bad = 0;
     TriChunk<B> tc2;
     const int nvalid = phase_vote<WAVES, SC>(s, n, a.b.x + off, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
@@ -689,27 +715,43 @@ __global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(
     if (!mask_mismatch)
         S = phase_select<WAVES, FULL>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
                                       a.o.tri_heights, bad, a.debug_skip MVOSR_STAMP_PASS);
-    int status;
-    double height = nan(""), raw = nan("");
+    int status = kStPending;
+    double raw = nan("");
+    int nsel = 0;
     if (mask_mismatch || S.bad || (a.debug_skip & 8)) {      // S.bad: vertex-id errors of both sweeps, summed over the block
         status = MVOSR_ST_ERR_MASK;
     } else if (S.singular) {
         status = MVOSR_ST_ERR_SINGULAR;
     } else {
-        auto fetch = [&](int j, double &y) -> bool {
-            if (!((s.sel[j >> 5] >> (j & 31)) & 1u)) return false;
-            y = s.Y[j];
-            return true;
-        };
-        if (a.o.selected) {
-            for (int j = tid; j < nvalid; j += B) a.o.selected[off + j] = (uint8_t)((s.sel[j >> 5] >> (j & 31)) & 1u);
+        // Hand the selected y' to the road-model kernel as one dense list: every wave packs its slice
+        // of Y in place (ballot prefix; a value moves to an index <= its own and a sub-chunk is read
+        // by one instruction before any of it is overwritten), then stores it at the wave's offset.
+        const int w = wave_id(), lane = lane_id();
+        const int per = (nvalid + B - 1) / B;
+        const int wbeg = w * per * kWave;
+        double *mine = s.Y + wbeg;
+        int cnt = 0;
+        for (int k = 0; k < per; ++k) {
+            const int j = wbeg + k * kWave + lane;
+            bool sel = false;
+            double y = 0.0;
+            if (j < nvalid) {
+                sel = (s.sel[j >> 5] >> (j & 31)) & 1u;
+                y = s.Y[j];
+                if (a.o.selected) a.o.selected[off + j] = (uint8_t)sel;                          // :247
+            }
+            const unsigned long long m = __ballot(sel);
+            if (sel) mine[cnt + __popcll(m & ((1ull << lane) - 1ull))] = y;
+            cnt += __popcll(m);
         }
-        // the P plane is dead after the sweeps (it serves as the median's value list); Y is packed in place
-        R = phase_road<WAVES>(s, nvalid, fetch, S.height_level, a.P, s.Y, reinterpret_cast<double *>(s.P),
-                              a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
-        status = R.status;
-        if (status == MVOSR_ST_NO_FLAT) raw = a.P.absolute_reference / S.height_level;        // :421
-        else if (status <= MVOSR_ST_LEVEL) { height = R.height; raw = a.P.absolute_reference / height; }   // :419
+        if (lane == 0) s.misc[M_WCNT + w] = cnt;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) { const int c = s.misc[M_WCNT + i]; if (i < w) base += c; nsel += c; }
+        double *dst = a.ysel + off + base;
+        for (int i = lane; i < cnt; i += kWave) dst[i] = mine[i];
+        if (nsel == 0) { status = MVOSR_ST_NO_FLAT; raw = a.P.absolute_reference / S.height_level; }   // :277-279,:421
     }
     MVOSR_STAMP(9);
 #ifdef MVOSR_STAMPS
@@ -717,11 +759,13 @@ __global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(
 #endif
     if (tid == 0) {
         a.o.raw_scale[f] = raw;
-        a.o.height[f] = height;
+        a.o.height[f] = nan("");
         a.o.height_level[f] = S.height_level;
-        a.o.status[f] = status;
+        a.o.status[f] = status;                  // kStPending: the road-model kernel finishes the frame
+        a.nsel[f] = nsel;
+        R.n_sel = nsel;
         write_counts(a, f, nvalid, S.n_pitch, S.n_tri_valid, R);
-        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = R.mean; st[1] = R.std; st[2] = R.skew; st[3] = R.median; }
+        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = st[1] = st[2] = st[3] = nan(""); }
     }
 }
 
@@ -747,35 +791,6 @@ __global__ __launch_bounds__(WAVES *kWave) void outlier_vote_kernel(const KArgs 
     if (threadIdx.x == 0) {
         if (a.o.counts) a.o.counts[f * MVOSR_N_COUNTS + MVOSR_CNT_VALID] = nvalid;
         if (a.o.status) a.o.status[f] = b0 ? MVOSR_ST_ERR_MASK : MVOSR_ST_MODE;
-    }
-}
-
-// K3 alone: y lists straight from HBM (already remapped), staged into the Y plane
-template <int WAVES>
-__global__ __launch_bounds__(WAVES *kWave) void road_model_kernel(const KArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int B = WAVES * kWave;
-    const int tid = threadIdx.x;
-    const int64_t f = a.first_frame + blockIdx.x;
-    const int n = a.b.feat_cnt[f];
-    const int64_t off = a.b.feat_off[f];
-    const Smem s = carve(smem, max(n, 1), WAVES);
-    for (int i = tid; i < 176; i += B) s.hist[i] = 0;
-    for (int i = tid; i < n; i += B) s.Y[i] = a.b.y[off + i];
-    __syncthreads();
-    const double hl = a.height_level_in ? a.height_level_in[f] : nan("");
-    auto fetch = [&](int j, double &y) -> bool { y = s.Y[j]; return true; };
-    MVOSR_STAMP_DECL
-    RoadResult R = phase_road<WAVES>(s, n, fetch, hl, a.P, s.Y, reinterpret_cast<double *>(s.P),
-                                     a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
-    if (tid == 0) {
-        double height = nan(""), raw = nan("");
-        if (R.status == MVOSR_ST_NO_FLAT) raw = a.P.absolute_reference / hl;
-        else if (R.status <= MVOSR_ST_LEVEL) { height = R.height; raw = a.P.absolute_reference / height; }
-        a.o.raw_scale[f] = raw; a.o.height[f] = height; a.o.status[f] = R.status;
-        if (a.o.height_level) a.o.height_level[f] = hl;
-        write_counts(a, f, n, 0, 0, R);
-        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = R.mean; st[1] = R.std; st[2] = R.skew; st[3] = R.median; }
     }
 }
 
@@ -898,14 +913,11 @@ static int launch_vote(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
     return check_launch("outlier_vote_kernel");
 }
 
-template <int WAVES>
-static int launch_road(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
-    const size_t lds = lds_plan(ka.b.max_feat > 0 ? ka.b.max_feat : 1, WAVES).total;
-    if ((int64_t)lds > (int64_t)g_max_dyn_lds)
-        return set_error(MVOSR_ERR_TOO_LARGE, "list of %d values needs %zu B of LDS (> %d)", ka.b.max_feat, lds, g_max_dyn_lds);
-    int rc;
-    if ((rc = prepare_kernel(road_model_kernel<WAVES>, lds))) return rc;
-    hipLaunchKernelGGL((road_model_kernel<WAVES>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
+// one wavefront per frame, kRoadWaves frames per workgroup
+static int launch_road(mvosr_ctx *ctx, const RoadArgs &ra) {
+    if (ra.n_frames <= 0) return MVOSR_OK;
+    const unsigned blocks = (unsigned)((ra.n_frames + kRoadWaves - 1) / kRoadWaves);
+    hipLaunchKernelGGL(road_model_kernel, dim3(blocks), dim3(kRoadWaves * kWave), 0, ctx_stream(ctx), ra);
     return check_launch("road_model_kernel");
 }
 
@@ -974,8 +986,17 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     KArgs ka;
     ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
     ka.first_frame = first_frame; ka.height_level_in = nullptr; ka.debug_skip = debug_skip_env();
+    if (b->total_feat <= 0) return set_error(MVOSR_ERR_ARG, "scale_batch: batch.total_feat (length of the feature planes) not set");
+    if ((rc = ctx_workspace(ctx, b->n_frames, b->total_feat, &ka.ysel, &ka.nsel))) return rc;
     const bool full = o->tri_normals || o->tri_pitch_deg || o->tri_heights;
-    return dispatch_scale(ctx, ka, pick_waves(waves_per_frame, b->max_feat), n_launch, full);
+    if ((rc = dispatch_scale(ctx, ka, pick_waves(waves_per_frame, b->max_feat), n_launch, full))) return rc;
+    // second launch of the step: the road model, one wavefront per frame, on the lists the first left
+    RoadArgs ra;
+    ra.P = *p; ra.off = b->feat_off; ra.cnt = ka.nsel; ra.y = ka.ysel; ra.scratch = ka.ysel;
+    ra.height_level = o->height_level; ra.o = *o;
+    ra.first_frame = first_frame; ra.n_frames = n_launch; ra.pending_only = 1;
+    if (debug_skip_env() & 16) return MVOSR_OK;
+    return launch_road(ctx, ra);
 }
 
 int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const mvosr_outputs *o,
@@ -994,21 +1015,22 @@ int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_
 
 int mvosr_road_model_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const double *height_level_in,
                            const mvosr_outputs *o, int waves_per_frame) {
+    (void)waves_per_frame;                      // the road model always runs one wavefront per frame
     int rc = check_common(ctx, p, b, o);
     if (rc) return rc;
     if (!b->y) return set_error(MVOSR_ERR_ARG, "road_model: y plane required");
     if (!o->raw_scale || !o->height || !o->status) return set_error(MVOSR_ERR_ARG, "road_model: raw_scale/height/status required");
     if (b->n_frames == 0) return MVOSR_OK;
+    if (b->total_feat <= 0) return set_error(MVOSR_ERR_ARG, "road_model: batch.total_feat (length of the y plane) not set");
     if ((rc = ctx_activate(ctx))) return rc;
-    KArgs ka;
-    ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
-    ka.first_frame = 0; ka.height_level_in = height_level_in; ka.debug_skip = 0;
-    switch (pick_waves(waves_per_frame, b->max_feat)) {
-        case 1: return launch_road<1>(ctx, ka, b->n_frames);
-        case 4: return launch_road<4>(ctx, ka, b->n_frames);
-        case 16: return launch_road<16>(ctx, ka, b->n_frames);
-        default: return launch_road<8>(ctx, ka, b->n_frames);
-    }
+    RoadArgs ra;
+    double *scratch = nullptr;
+    int32_t *unused = nullptr;
+    if ((rc = ctx_workspace(ctx, b->n_frames, b->total_feat, &scratch, &unused))) return rc;
+    ra.P = *p; ra.off = b->feat_off; ra.cnt = b->feat_cnt; ra.y = b->y; ra.scratch = scratch;
+    ra.height_level = height_level_in; ra.o = *o;
+    ra.first_frame = 0; ra.n_frames = b->n_frames; ra.pending_only = 0;
+    return launch_road(ctx, ra);
 }
 
 int mvosr_window_median(mvosr_ctx *ctx, const double *raw, int64_t n, int window, const double *queue_in, int n_queue,

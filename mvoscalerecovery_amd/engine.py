@@ -60,7 +60,7 @@ class DeviceBatch:
             p = lambda k: (self.bufs[k].ptr if k in self.bufs else None)
             self._struct = _lib.Batch(self.n_frames, p("feat_off"), p("feat_cnt"), p("x"), p("y"), p("z"), p("v"),
                                       p("tri1_off"), p("tri1"), p("tri2_off"), p("tri2"), p("n2_expected"),
-                                      self.max_feat, 0)
+                                      self.max_feat, 0, self.total_padded)
         return self._struct
 
     def free(self):
