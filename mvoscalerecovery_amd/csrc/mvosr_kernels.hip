@@ -914,10 +914,10 @@ static int launch_vote(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
 }
 
 // one wavefront per frame, kRoadWaves frames per workgroup
-static int launch_road(mvosr_ctx *ctx, const RoadArgs &ra) {
+static int launch_road(mvosr_ctx *ctx, const RoadArgs &ra, hipStream_t stream) {
     if (ra.n_frames <= 0) return MVOSR_OK;
     const unsigned blocks = (unsigned)((ra.n_frames + kRoadWaves - 1) / kRoadWaves);
-    hipLaunchKernelGGL(road_model_kernel, dim3(blocks), dim3(kRoadWaves * kWave), 0, ctx_stream(ctx), ra);
+    hipLaunchKernelGGL(road_model_kernel, dim3(blocks), dim3(kRoadWaves * kWave), 0, stream, ra);
     return check_launch("road_model_kernel");
 }
 
@@ -989,14 +989,19 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     if (b->total_feat <= 0) return set_error(MVOSR_ERR_ARG, "scale_batch: batch.total_feat (length of the feature planes) not set");
     if ((rc = ctx_workspace(ctx, b->n_frames, b->total_feat, &ka.ysel, &ka.nsel))) return rc;
     const bool full = o->tri_normals || o->tri_pitch_deg || o->tri_heights;
-    if ((rc = dispatch_scale(ctx, ka, pick_waves(waves_per_frame, b->max_feat), n_launch, full))) return rc;
-    // second launch of the step: the road model, one wavefront per frame, on the lists the first left
+    const int waves = pick_waves(waves_per_frame, b->max_feat);
     RoadArgs ra;
     ra.P = *p; ra.off = b->feat_off; ra.cnt = ka.nsel; ra.y = ka.ysel; ra.scratch = ka.ysel;
-    ra.height_level = o->height_level; ra.o = *o;
-    ra.first_frame = first_frame; ra.n_frames = n_launch; ra.pending_only = 1;
+    ra.height_level = o->height_level; ra.o = *o; ra.pending_only = 1;
+    // The step is two launches on the context's stream: the scale kernel, then the road model (one
+    // wavefront per frame) on the dense lists it left in the workspace.  (Splitting the batch into
+    // chunks to run the road model of one chunk under the scale kernel of the next was measured
+    // and lost 10%: smaller grids pay more tail than the overlap returns.)
+    ka.first_frame = first_frame;
+    if ((rc = dispatch_scale(ctx, ka, waves, n_launch, full))) return rc;
+    ra.first_frame = first_frame; ra.n_frames = n_launch;
     if (debug_skip_env() & 16) return MVOSR_OK;
-    return launch_road(ctx, ra);
+    return launch_road(ctx, ra, ctx_stream(ctx));
 }
 
 int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const mvosr_outputs *o,
@@ -1030,7 +1035,7 @@ int mvosr_road_model_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_ba
     ra.P = *p; ra.off = b->feat_off; ra.cnt = b->feat_cnt; ra.y = b->y; ra.scratch = scratch;
     ra.height_level = height_level_in; ra.o = *o;
     ra.first_frame = 0; ra.n_frames = b->n_frames; ra.pending_only = 0;
-    return launch_road(ctx, ra);
+    return launch_road(ctx, ra, ctx_stream(ctx));
 }
 
 int mvosr_window_median(mvosr_ctx *ctx, const double *raw, int64_t n, int window, const double *queue_in, int n_queue,

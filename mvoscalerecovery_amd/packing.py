@@ -183,3 +183,4 @@ def tile_frames(pf: PackedFrames, repeats: int) -> PackedFrames:
     if pf.n2_expected is not None:
         out.n2_expected = np.tile(pf.n2_expected, repeats)
     return out
+

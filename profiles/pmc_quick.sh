@@ -12,11 +12,11 @@ for PMC in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/${TAG}_q$i -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/${TAG}_q$i.log 2>&1
 done
 python3 - <<PY
-import csv,glob,statistics
+import csv,glob,statistics,os
 c={}
 for f in glob.glob("$OUT/${TAG}_q*/bench_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "scale_frames" in r["Kernel_Name"]:
+        if os.environ.get("KSEL","scale_frames") in r["Kernel_Name"]:
             c.setdefault(r["Counter_Name"],[]).append(float(r["Counter_Value"]))
 F=16384
 for k in sorted(c): print("%-28s %14.6g per-frame %10.1f"%(k,statistics.median(c[k]),statistics.median(c[k])/F))

@@ -31,10 +31,12 @@ for _ in range(3):
     eng.scale_batch(db, out)
 ctx.sync()
 h = out.get("hist").reshape(pf.n_frames, -1).view(np.uint64)[:, :10].astype(np.float64)
-names = ["load y,z,v + barrier", "vote sweep (tri1) + barrier", "x store + compaction", "select sweep 1 + reduce",
-         "select sweep 2 + reduce", "road: histogram + reduce", "road: logic + kept pass + reduce", "road: std pass + reduce", "epilogue"]
+cols = [0, 1, 2, 3, 4, 5, 9]            # stamps the scale kernel sets (6-8 belonged to the old fused road phase)
+names = ["load y,z,v + barrier", "vote sweep (tri1) + barrier", "compaction (2 barriers)", "select sweep 1 + reduce",
+         "select sweep 2 + reduce", "pack selected + store list"]
+h = h[:, cols]
 d = np.diff(h, axis=1)
-tot = h[:, 9] - h[:, 0]
+tot = h[:, -1] - h[:, 0]
 print("workgroup life: mean %.0f ticks (s_memtime), median %.0f" % (tot.mean(), np.median(tot)))
 for i, n in enumerate(names):
     print("%-36s mean %9.0f  share %5.1f%%" % (n, d[:, i].mean(), 100 * d[:, i].mean() / tot.mean()))
