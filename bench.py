@@ -6,18 +6,20 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of F frames per GPU, resident in HBM:
-the fused HIP kernel (feature_remap -> depth-order vote on tri1 -> compaction -> per-triangle
-plane normal / pitch / height on tri2 -> height_level -> road-model histogram/mode/skew -> raw
-scale), then (N>1) one RCCL all-gather of the raw scales + statuses, then the window-median
-kernel over the gathered sequence.  Workload = BASELINE.json configs[1]: 2000 features /
+mvosr_scale_batch = the scale kernel (feature_remap -> depth-order vote on tri1 -> compaction ->
+per-triangle plane normal / pitch / height on tri2 -> height_level -> selected points; one
+workgroup per frame) + the road-model kernel (histogram / modes / skew -> height -> raw scale; one
+wavefront per frame), then (N>1) one RCCL all-gather of the raw scales + statuses, then the
+window-median kernel over the gathered sequence.  Workload = BASELINE.json configs[1]: 2000 features /
 ~4000 triangles per frame (T1~3981 + T2~3780), both Delaunay triangulations precomputed on the
 host (they are inputs of the GPU path, like the optical flow itself).  Weak scaling: every rank
 owns F frames.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     algorithmic bytes per launch (8*(3N+N)+12*(T1+T2)+12 per frame)
-               / average duration of the fused kernel measured with HIP events on its stream,
-               against the 8 TB/s HBM peak;
+               / average duration of the dominant kernel (scale_frames_kernel), measured with HIP
+               events recorded on its launch stream around that kernel (mvosr_ctx_profile),
+               against the 8 TB/s HBM peak; `step_*` gives the same for both kernels of the step;
   cpu_baseline the CPU oracle (NumPy port of the reference) timed on this box's host, one
                core, on a bounded sample of the same frames (N=1 only).
 """
@@ -159,6 +161,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    ctx.profile(True)                    # HIP events around each of the step's two kernels, on the launch stream
     events = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
     barrier()
     torch.cuda.synchronize()
@@ -172,8 +175,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = [ctx.elapsed_ms(a, b) for a, b in events]
-    kernel_ms_avg = float(np.mean(kernel_ms))
+    step_ms_avg = float(np.mean([ctx.elapsed_ms(a, b) for a, b in events]))       # both kernels of the step
+    prof = [ctx.profile_read(k) for k in range(min(args.steps, 64))]
+    kernel_ms_avg = float(np.mean([p[0] for p in prof]))                               # scale_frames_kernel
+    road_ms_avg = float(np.mean([p[1] for p in prof]))                                 # road_model_kernel
+    ctx.profile(False)
 
     gpu_raw = raw[:pool].cpu().numpy()
     gpu_status = status[:pool].cpu().numpy()
@@ -207,7 +213,10 @@ def main():
                          "kernel": "scale_frames_kernel", "kernel_ms_avg": kernel_ms_avg,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "algorithmic_bytes_per_frame": bytes_per_launch / F,
-                         "frames_per_s_kernel_only": F / (kernel_ms_avg * 1e-3)},
+                         "frames_per_s_kernel_only": F / (kernel_ms_avg * 1e-3),
+                         "road_model_kernel_ms_avg": road_ms_avg, "step_kernels_ms_avg": step_ms_avg,
+                         "step_achieved": bytes_per_launch / (step_ms_avg * 1e-3) / 1e9,
+                         "step_frac": bytes_per_launch / (step_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             "status_histogram": {str(k): int(v) for k, v in zip(*np.unique(st_all, return_counts=True))},
             "host_delaunay_ms_per_frame": delaunay_s * 1e3,
         }

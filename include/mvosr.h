@@ -149,6 +149,12 @@ int mvosr_ctx_sync(mvosr_ctx *ctx);
  * road-model kernel: total_feat doubles + n_frames int32).  mvosr_scale_batch grows it on demand
  * with hipMalloc; call this first if the launches must not allocate (e.g. under graph capture). */
 int mvosr_ctx_reserve(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat);
+/* Per-call kernel timing of mvosr_scale_batch with HIP events on the launch stream: after
+ * mvosr_ctx_profile(ctx, 1) every call (up to 64) records an event before the scale kernel, between
+ * the two kernels and after the road-model kernel; mvosr_ctx_profile_read returns the two
+ * durations of call `call_index` (0-based since the enable; synchronises on that call's end). */
+int mvosr_ctx_profile(mvosr_ctx *ctx, int enable);
+int mvosr_ctx_profile_read(mvosr_ctx *ctx, int call_index, float *scale_kernel_ms, float *road_kernel_ms);
 /* Device facts for the host (name, CU count, LDS per workgroup). */
 int mvosr_ctx_device_info(mvosr_ctx *ctx, char *name, int name_len, int *n_cu, int *lds_per_block);
 

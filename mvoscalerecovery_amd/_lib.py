@@ -54,6 +54,8 @@ SYMBOLS = {
     "mvosr_ctx_stream": (_P, [_P]),
     "mvosr_ctx_sync": (C.c_int, [_P]),
     "mvosr_ctx_reserve": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "mvosr_ctx_profile": (C.c_int, [_P, C.c_int]),
+    "mvosr_ctx_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mvosr_ctx_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mvosr_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "mvosr_free": (C.c_int, [_P, _P]),
@@ -190,6 +192,14 @@ class Context:
         ms = C.c_float()
         check(self.lib.mvosr_event_elapsed_ms(self.handle, start, stop, C.byref(ms)), "event_elapsed")
         return float(ms.value)
+
+    def profile(self, enable=True):
+        check(self.lib.mvosr_ctx_profile(self.handle, 1 if enable else 0), "mvosr_ctx_profile")
+
+    def profile_read(self, call_index):
+        a, b = C.c_float(), C.c_float()
+        check(self.lib.mvosr_ctx_profile_read(self.handle, int(call_index), C.byref(a), C.byref(b)), "mvosr_ctx_profile_read")
+        return float(a.value), float(b.value)
 
     def close(self):
         if getattr(self, "handle", None):

@@ -93,6 +93,8 @@ int mvosr_ctx_create(int device, mvosr_ctx **out) {
     e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return set_hip_error("hipStreamCreateWithFlags", e); }
     ctx->stream = ctx->own_stream;
+    ctx->prof_on = 0; ctx->prof_calls = 0;
+    for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) ctx->prof_ev[i][j] = nullptr;
     ctx->ws_ysel = nullptr; ctx->ws_ysel_len = 0; ctx->ws_nsel = nullptr; ctx->ws_nsel_len = 0;
     ctx->n_cu = prop.multiProcessorCount;
     int optin = 0;
@@ -110,6 +112,7 @@ int mvosr_ctx_destroy(mvosr_ctx *ctx) {
     if (!ctx) return MVOSR_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) if (ctx->prof_ev[i][j]) (void)hipEventDestroy(ctx->prof_ev[i][j]);
     if (ctx->ws_ysel) (void)hipFree(ctx->ws_ysel);
     if (ctx->ws_nsel) (void)hipFree(ctx->ws_nsel);
     (void)hipStreamDestroy(ctx->own_stream);
@@ -137,6 +140,32 @@ int mvosr_ctx_device_info(mvosr_ctx *ctx, char *name, int name_len, int *n_cu, i
     if (name && name_len > 0) { strncpy(name, ctx->name, (size_t)name_len - 1); name[name_len - 1] = 0; }
     if (n_cu) *n_cu = ctx->n_cu;
     if (lds_per_block) *lds_per_block = ctx->max_lds_per_block;
+    return MVOSR_OK;
+}
+
+int mvosr_ctx_profile(mvosr_ctx *ctx, int enable) {
+    if (!ctx) return set_error(MVOSR_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (enable) {
+        for (int i = 0; i < kProfRing; ++i)
+            for (int j = 0; j < 3; ++j)
+                if (!ctx->prof_ev[i][j]) HIP_TRY(hipEventCreate(&ctx->prof_ev[i][j]));
+    }
+    ctx->prof_on = enable ? 1 : 0;
+    ctx->prof_calls = 0;
+    return MVOSR_OK;
+}
+
+int mvosr_ctx_profile_read(mvosr_ctx *ctx, int call_index, float *scale_kernel_ms, float *road_kernel_ms) {
+    if (!ctx || !scale_kernel_ms || !road_kernel_ms) return set_error(MVOSR_ERR_ARG, "profile_read: null argument");
+    if (call_index < 0 || call_index >= ctx->prof_calls || call_index >= kProfRing || ctx->prof_calls - call_index > kProfRing)
+        return set_error(MVOSR_ERR_ARG, "profile_read: call %d not recorded (%d calls since mvosr_ctx_profile, ring of %d)",
+                         call_index, ctx->prof_calls, kProfRing);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipEvent_t *ev = ctx->prof_ev[call_index % kProfRing];
+    HIP_TRY(hipEventSynchronize(ev[2]));
+    HIP_TRY(hipEventElapsedTime(scale_kernel_ms, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(road_kernel_ms, ev[1], ev[2]));
     return MVOSR_OK;
 }
 

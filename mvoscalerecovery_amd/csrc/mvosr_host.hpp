@@ -18,7 +18,13 @@ struct mvosr_ctx {
     size_t ws_ysel_len;
     int32_t *ws_nsel;
     size_t ws_nsel_len;
+    // optional per-call kernel timing (mvosr_ctx_profile): start / between the two kernels / end
+    int prof_on;
+    int prof_calls;
+    hipEvent_t prof_ev[64][3];
 };
+
+constexpr int kProfRing = 64;
 
 namespace mvosr {
 

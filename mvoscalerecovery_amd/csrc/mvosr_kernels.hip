@@ -998,10 +998,14 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     // chunks to run the road model of one chunk under the scale kernel of the next was measured
     // and lost 10%: smaller grids pay more tail than the overlap returns.)
     ka.first_frame = first_frame;
+    hipEvent_t *pev = (ctx->prof_on && ctx->prof_calls < kProfRing) ? ctx->prof_ev[ctx->prof_calls] : nullptr;
+    if (pev) (void)hipEventRecord(pev[0], ctx_stream(ctx));
     if ((rc = dispatch_scale(ctx, ka, waves, n_launch, full))) return rc;
+    if (pev) (void)hipEventRecord(pev[1], ctx_stream(ctx));
     ra.first_frame = first_frame; ra.n_frames = n_launch;
-    if (debug_skip_env() & 16) return MVOSR_OK;
-    return launch_road(ctx, ra, ctx_stream(ctx));
+    if (!(debug_skip_env() & 16)) { if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc; }
+    if (pev) { (void)hipEventRecord(pev[2], ctx_stream(ctx)); ctx->prof_calls++; }
+    return MVOSR_OK;
 }
 
 int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const mvosr_outputs *o,

@@ -31,7 +31,7 @@ def main():
     rows = list(csv.DictReader(open(stats)))
     krow = [r for r in rows if a.kernel in r["Name"]][0]
     bench = json.loads(open(os.path.join(out, a.tag + "_bench_under_rocprof.json")).read().strip().splitlines()[-1])
-    counters = {}
+    counters, road = {}, {}
     for d in sorted(glob.glob(os.path.join(out, a.tag + "_pmc*"))):
         f = os.path.join(d, "bench_counter_collection.csv")
         if not os.path.isfile(f):
@@ -39,7 +39,10 @@ def main():
         for r in csv.DictReader(open(f)):
             if a.kernel in r["Kernel_Name"]:
                 counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            if "road_model_kernel" in r["Kernel_Name"]:
+                road.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     med = {k: statistics.median(v) for k, v in counters.items()}
+    road = {k: statistics.median(v) for k, v in road.items()}
     F = a.frames
     lines = ["# rocprofv3 summary %s — `python bench.py` (N=1, %d frames x %d features per launch)" % (a.tag, F, a.features), ""]
     lines += ["## kernel trace (`rocprofv3 --kernel-trace --stats`, 10 timed + 2 warm-up steps)", "",
@@ -76,6 +79,10 @@ def main():
         if exact > 0:
             traffic_exact = exact + med.get("WRITE_SIZE", 0) * 1024
             lines += ["Read bytes by request size + WRITE_SIZE = %.4g B per launch (%.0f B/frame)." % (traffic_exact, traffic_exact / F)]
+    if "FETCH_SIZE" in road and "WRITE_SIZE" in road:
+        rt = 2.0 * road["FETCH_SIZE"] * 1024.0 + road["WRITE_SIZE"] * 1024.0
+        lines += ["", "Second kernel of the step, `road_model_kernel` (reads the dense selected-y lists the scale kernel wrote): "
+                  "2 x FETCH_SIZE + WRITE_SIZE = %.4g B per launch (%.0f B/frame)." % (rt, rt / F)]
     if "SQ_WAVE_CYCLES" in med:
         wc = med["SQ_WAVE_CYCLES"]
         lines += ["", "Wave-cycle shares: ACTIVE_INST_ANY %.2f, WAIT_ANY %.2f, WAIT_INST_ANY %.2f; VALU %.2f, LDS %.2f of wave cycles."
