@@ -112,6 +112,10 @@ __device__ __forceinline__ TriIds load_tri(const int32_t *tri, int64_t t) {
 #define MVOSR_TC 2
 #endif
 constexpr int kTC = MVOSR_TC;   // triangles per thread per chunk (3 VGPRs each)
+#ifndef MVOSR_KEEP
+#define MVOSR_KEEP 1
+#endif
+constexpr int kKeep = MVOSR_KEEP;   // tri2 chunks whose ids stay in registers (16-bit packed) for the second sweep
 
 template <int B>
 struct TriChunk {
@@ -306,60 +310,86 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     unsigned long long flat = 0ull;          // bit kk: my kk-th triangle has pitch_deg < thr
     double hsum = 0.0, hcnt = 0.0;
     int npitch = 0, singular = 0, bad = 0;
-    // `tc` arrives with the first chunk of tri2 already loaded (phase_vote)
-    for (int base = 0; base < ((dbg & 2) ? 0 : t2_count); base += kTC * B) {
-        if (base > 0) tc.load(tri2, t2_begin, t2_count, base, tid);
+    // One triangle of the first sweep (:229-240).
+    auto test_triangle = [&](int t, int kk, const TriIds q) {
+    if ((unsigned)q.a >= (unsigned)n_valid || (unsigned)q.b >= (unsigned)n_valid || (unsigned)q.c >= (unsigned)n_valid) { bad = 1; return; }
+    const double2 p0 = s.P[q.a], p1 = s.P[q.b], p2 = s.P[q.c];      // {x, z'}
+    const double y0 = s.Y[q.a], y1 = s.Y[q.b], y2 = s.Y[q.c];
+    const double x0 = p0.x, z0 = p0.y, x1 = p1.x, z1 = p1.y, x2 = p2.x, z2 = p2.y;
+    const double h = div3((y0 + y1) + y2);                                               // :238
+    bool is_flat = false, is_steep = false;
+    bool decided = false;
+    if constexpr (!FULL) {
+        // The plane n.p = 1 through the vertices has n = c / det with c = (p1-p0) x (p2-p0) and
+        // det = p0 . c, so  pitch_deg < thr  <=>  n_y/|n| > sin(|thr|)  <=>  c_y det > 0 and
+        // c_y^2 > sin^2(|thr|) |c|^2 : no division, square root or asin.  Only inside a 1e-9
+        // band around the threshold (where the outcome depends on how the LU solve and asin
+        // round), for needle triangles and when det is lost to cancellation (possible exact
+        // singularity) is the reference's own formulation evaluated below.
+        const double e1x = x1 - x0, e1y = y1 - y0, e1z = z1 - z0;
+        const double e2x = x2 - x0, e2y = y2 - y0, e2z = z2 - z0;
+        const double cx = __builtin_fma(e1y, e2z, -(e1z * e2y));
+        const double cy = __builtin_fma(e1z, e2x, -(e1x * e2z));
+        const double cz = __builtin_fma(e1x, e2y, -(e1y * e2x));
+        const double tx = x0 * cx, ty = y0 * cy, tz = z0 * cz;
+        const double det = (tx + ty) + tz;
+        const double mag = (fabs(tx) + fabs(ty)) + fabs(tz);
+        const double c2 = __builtin_fma(cz, cz, __builtin_fma(cy, cy, cx * cx));
+        const double l1 = __builtin_fma(e1z, e1z, __builtin_fma(e1y, e1y, e1x * e1x));
+        const double l2 = __builtin_fma(e2z, e2z, __builtin_fma(e2y, e2y, e2x * e2x));
+        const bool safe = (fabs(det) > 1e-9 * mag) && (c2 > 1e-14 * (l1 * l2));
+        const double q2 = cy * cy;
+        const double sy = cy * det;
+        if (safe && sy > 0.0 && q2 > pt.s2_hi * c2) { is_flat = true; decided = true; }
+        else if (safe && (sy <= 0.0 || q2 < pt.s2_lo * c2)) { is_steep = true; decided = true; }
+    }
+    if (!decided) {
+        double nx, ny, nz, pitch;
+        const int r = pitch_reference<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, pt.thr_deg, nx, ny, nz, pitch);
+        if (r & 4) singular = 1;
+        is_flat = r & 1;
+        is_steep = r & 2;
+        if constexpr (FULL) {
+            if (g_normals) { double *o = g_normals + 3 * (t2_begin + t); o[0] = nx; o[1] = ny; o[2] = nz; }
+            if (g_pitch) g_pitch[t2_begin + t] = pitch;
+            if (g_heights) g_heights[t2_begin + t] = h;
+        }
+    }
+    if (is_steep) { hsum += h; hcnt += 1.0; }                                            // :240
+    if (is_flat) { flat |= 1ull << kk; ++npitch; }
+    };
+    // `tc` arrives with the first chunk of tri2 already loaded (phase_vote).  The ids of the first
+    // kKeep chunks stay in registers for the second sweep, packed to 16 bits (1.5 VGPRs per
+    // triangle): re-reading tri2 costs a second pass over its 45 KB through the fabric otherwise.
+    const int t2c = (dbg & 2) ? 0 : t2_count;
+    uint32_t pab[kKeep * kTC], pcc[(kKeep * kTC + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < (kKeep * kTC + 1) / 2; ++i) pcc[i] = 0u;
+#pragma unroll
+    for (int ch = 0; ch < kKeep; ++ch) {
+        const int base = ch * kTC * B;
+        if (base < t2c) {
+            if (ch > 0) tc.load(tri2, t2_begin, t2_count, base, tid);
+#pragma unroll
+            for (int k = 0; k < kTC; ++k) {
+                const int t = base + k * B + tid;
+                const int idx = ch * kTC + k;
+                pab[idx] = 0u;
+                if (t < t2c) {
+                    const TriIds q = tc.q[k];
+                    pab[idx] = ((uint32_t)q.a & 0xFFFFu) | ((uint32_t)q.b << 16);
+                    pcc[idx >> 1] |= ((uint32_t)q.c & 0xFFFFu) << (16 * (idx & 1));
+                    test_triangle(t, ch * kTC + k, q);
+                }
+            }
+        }
+    }
+    for (int base = kKeep * kTC * B; base < t2c; base += kTC * B) {       // frames with more than kKeep chunks
+        tc.load(tri2, t2_begin, t2_count, base, tid);
 #pragma unroll
         for (int k = 0; k < kTC; ++k) {
             const int t = base + k * B + tid;
-            if (t >= t2_count) continue;
-            const int kk = base / B + k;
-            const TriIds q = tc.q[k];
-            if ((unsigned)q.a >= (unsigned)n_valid || (unsigned)q.b >= (unsigned)n_valid || (unsigned)q.c >= (unsigned)n_valid) { bad = 1; continue; }
-            const double2 p0 = s.P[q.a], p1 = s.P[q.b], p2 = s.P[q.c];      // {x, z'}
-            const double y0 = s.Y[q.a], y1 = s.Y[q.b], y2 = s.Y[q.c];
-            const double x0 = p0.x, z0 = p0.y, x1 = p1.x, z1 = p1.y, x2 = p2.x, z2 = p2.y;
-            const double h = div3((y0 + y1) + y2);                                               // :238
-            bool is_flat = false, is_steep = false;
-            bool decided = false;
-            if constexpr (!FULL) {
-                // The plane n.p = 1 through the vertices has n = c / det with c = (p1-p0) x (p2-p0) and
-                // det = p0 . c, so  pitch_deg < thr  <=>  n_y/|n| > sin(|thr|)  <=>  c_y det > 0 and
-                // c_y^2 > sin^2(|thr|) |c|^2 : no division, square root or asin.  Only inside a 1e-9
-                // band around the threshold (where the outcome depends on how the LU solve and asin
-                // round), for needle triangles and when det is lost to cancellation (possible exact
-                // singularity) is the reference's own formulation evaluated below.
-                const double e1x = x1 - x0, e1y = y1 - y0, e1z = z1 - z0;
-                const double e2x = x2 - x0, e2y = y2 - y0, e2z = z2 - z0;
-                const double cx = __builtin_fma(e1y, e2z, -(e1z * e2y));
-                const double cy = __builtin_fma(e1z, e2x, -(e1x * e2z));
-                const double cz = __builtin_fma(e1x, e2y, -(e1y * e2x));
-                const double tx = x0 * cx, ty = y0 * cy, tz = z0 * cz;
-                const double det = (tx + ty) + tz;
-                const double mag = (fabs(tx) + fabs(ty)) + fabs(tz);
-                const double c2 = __builtin_fma(cz, cz, __builtin_fma(cy, cy, cx * cx));
-                const double l1 = __builtin_fma(e1z, e1z, __builtin_fma(e1y, e1y, e1x * e1x));
-                const double l2 = __builtin_fma(e2z, e2z, __builtin_fma(e2y, e2y, e2x * e2x));
-                const bool safe = (fabs(det) > 1e-9 * mag) && (c2 > 1e-14 * (l1 * l2));
-                const double q2 = cy * cy;
-                const double sy = cy * det;
-                if (safe && sy > 0.0 && q2 > pt.s2_hi * c2) { is_flat = true; decided = true; }
-                else if (safe && (sy <= 0.0 || q2 < pt.s2_lo * c2)) { is_steep = true; decided = true; }
-            }
-            if (!decided) {
-                double nx, ny, nz, pitch;
-                const int r = pitch_reference<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, pt.thr_deg, nx, ny, nz, pitch);
-                if (r & 4) singular = 1;
-                is_flat = r & 1;
-                is_steep = r & 2;
-                if constexpr (FULL) {
-                    if (g_normals) { double *o = g_normals + 3 * (t2_begin + t); o[0] = nx; o[1] = ny; o[2] = nz; }
-                    if (g_pitch) g_pitch[t2_begin + t] = pitch;
-                    if (g_heights) g_heights[t2_begin + t] = h;
-                }
-            }
-            if (is_steep) { hsum += h; hcnt += 1.0; }                                            // :240
-            if (is_flat) { flat |= 1ull << kk; ++npitch; }
+            if (t < t2c) test_triangle(t, base / B + k, tc.q[k]);
         }
     }
     block_sum2<WAVES>(hsum, hcnt, s.red + R_SEL_H * 2 * WAVES);
@@ -368,23 +398,35 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     r.height_level = hsum / hcnt;                 // np.mean of an empty set -> 0/0 = NaN, like :240
     const double hl = r.height_level;
     int ntv = 0;
-    const bool in_regs = t2_count <= kTC * B;     // then the ids are still in registers
-    for (int base = 0; base < ((dbg & 4) ? 0 : t2_count); base += kTC * B) {
-        if (!in_regs) tc.load(tri2, t2_begin, t2_count, base, tid);
+    auto mark_triangle = [&](int kk, int qa, int qb, int qc) {
+        if (!((flat >> kk) & 1ull)) return;
+        const double y0 = s.Y[qa], y1 = s.Y[qb], y2 = s.Y[qc];
+        const double h = div3((y0 + y1) + y2);
+        if (h > hl) {                                                                        // :243-244
+            ++ntv;
+            atomicOr(&s.sel[qa >> 5], 1u << (qa & 31));                                      // :247
+            atomicOr(&s.sel[qb >> 5], 1u << (qb & 31));
+            atomicOr(&s.sel[qc >> 5], 1u << (qc & 31));
+        }
+    };
+    const int t2d = (dbg & 4) ? 0 : t2_count;
+#pragma unroll
+    for (int ch = 0; ch < kKeep; ++ch) {
+        const int base = ch * kTC * B;
+        if (base < t2d) {
+#pragma unroll
+            for (int k = 0; k < kTC; ++k) {
+                const int idx = ch * kTC + k;
+                if (base + k * B + tid < t2d)
+                    mark_triangle(idx, (int)(pab[idx] & 0xFFFFu), (int)(pab[idx] >> 16), (int)((pcc[idx >> 1] >> (16 * (idx & 1))) & 0xFFFFu));
+            }
+        }
+    }
+    for (int base = kKeep * kTC * B; base < t2d; base += kTC * B) {
+        tc.load(tri2, t2_begin, t2_count, base, tid);
 #pragma unroll
         for (int k = 0; k < kTC; ++k) {
-            const int t = base + k * B + tid;
-            const int kk = base / B + k;
-            if (t >= t2_count || !((flat >> kk) & 1ull)) continue;
-            const TriIds q = tc.q[k];
-            const double y0 = s.Y[q.a], y1 = s.Y[q.b], y2 = s.Y[q.c];
-            const double h = div3((y0 + y1) + y2);
-            if (h > hl) {                                                                        // :243-244
-                ++ntv;
-                atomicOr(&s.sel[q.a >> 5], 1u << (q.a & 31));                                    // :247
-                atomicOr(&s.sel[q.b >> 5], 1u << (q.b & 31));
-                atomicOr(&s.sel[q.c >> 5], 1u << (q.c & 31));
-            }
+            if (base + k * B + tid < t2d) mark_triangle(base / B + k, tc.q[k].a, tc.q[k].b, tc.q[k].c);
         }
     }
     bad |= bad_in;
