@@ -39,7 +39,9 @@ namespace mvosr {
 #define MVOSR_STAMP_DECL unsigned long long stamps[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
 #define MVOSR_STAMP_ARG , unsigned long long *stamps = nullptr
 #define MVOSR_STAMP_PASS , stamps
+#define MVOSR_RSTAMP(i) do { if (stamps) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define MVOSR_RSTAMP(i) do {} while (0)
 #define MVOSR_STAMP(i) do {} while (0)
 #define MVOSR_STAMP_DECL
 #define MVOSR_STAMP_ARG
@@ -470,8 +472,12 @@ __device__ __forceinline__ bool dropped_by_single(double y, int bin, const Bits1
     return d;
 }
 
-constexpr int kRoadRC = 16;            // values per lane kept in registers (lists up to 1024 values)
+#ifndef MVOSR_ROAD_RC
+#define MVOSR_ROAD_RC 16
+#endif
+constexpr int kRoadRC = MVOSR_ROAD_RC;   // values per lane kept in registers (lists up to 64*RC values; longer ones re-read)
 constexpr int kRoadWaves = 4;          // frames (wavefronts) per workgroup
+constexpr int kTrash = 175;            // histogram slot for values that are not binned (bins are 0..168)
 constexpr int kStPending = -1;         // scale kernel -> road kernel: "road model still to run"
 
 struct RoadArgs {
@@ -486,8 +492,18 @@ struct RoadArgs {
     int pending_only;            // 1: fused path, only frames the scale kernel left pending
 };
 
-__device__ __forceinline__ RoadResult road_wave(int *hist, const double *yv, double *scratch, int M, double height_level,
-                                                const mvosr_params &P, int32_t *g_hist) {
+// bin of y against the workgroup's table edges[k] = {edge k, edge k+1} (same doubles as bin_edge)
+__device__ __forceinline__ int bin_of_table(double y, const double2 *edges) {
+    if (!(y >= 0.0 && y <= bin_edge(kBins))) return -1;
+    int k = min((int)(y * 10.0), kBins - 1);
+    const double2 e = edges[k];
+    k += (k < kBins - 1 && y >= e.y) ? 1 : 0;
+    k -= (y < e.x) ? 1 : 0;
+    return k;
+}
+
+__device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, const double2 *edges, const double *yv, double *scratch,
+                                                int M, double height_level, const mvosr_params &P, int32_t *g_hist MVOSR_STAMP_ARG) {
     const int lane = lane_id();
     RoadResult R;
     R.height = nan(""); R.status = MVOSR_ST_MODE; R.n_sel = M; R.n_kept = 0; R.n_modes = 0; R.mode_left = -1; R.mode_right = -1;
@@ -499,21 +515,33 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, const double *yv, dou
     // histogram (np.histogram, :326); the first kRoadRC values of every lane stay in registers
     double yc[kRoadRC];
     int binc[kRoadRC];
+    // Branch-free on purpose: with no control flow between them the 16 loads, table reads and
+    // atomics of a lane are scheduled in batches instead of one dependent round trip per value.
+    // Values that take no part (beyond the list, or outside [0,16.9]) go to the trash bin kTrash.
+    const int nfull = M / kWave;
+    const unsigned valid = (nfull >= kRoadRC) ? ((1u << kRoadRC) - 1u)                  // bit k: value k*64+lane exists
+                                              : (((1u << nfull) - 1u) | ((lane < M - nfull * kWave ? 1u : 0u) << nfull));
 #pragma unroll
     for (int k = 0; k < kRoadRC; ++k) {
-        const int i = k * kWave + lane;
-        yc[k] = 0.0; binc[k] = -1;
-        if (i < M) {
-            const double y = yv[i];
-            const int bin = bin_of(y);
-            if (bin >= 0) atomicAdd(&hist[bin], 1);
-            yc[k] = y; binc[k] = bin;
-        }
+        const int i = min(k * kWave + lane, M - 1);                                       // clamped: always a legal address
+        yc[k] = yv[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kRoadRC; ++k) {
+        const double y = yc[k];
+        const bool inr = ((valid >> k) & 1u) && (y >= 0.0) && (y <= bin_edge(kBins));
+        const int g = inr ? min((int)(y * 10.0), kBins - 1) : 0;
+        const double2 e = edges[g];
+        int bin = g + ((g < kBins - 1 && y >= e.y) ? 1 : 0) - ((y < e.x) ? 1 : 0);
+        bin = inr ? bin : kTrash;
+        atomicAdd(&hist[bin], 1);
+        binc[k] = bin;
     }
     for (int i = kRoadRC * kWave + lane; i < M; i += kWave) {
-        const int bin = bin_of(yv[i]);
+        const int bin = bin_of_table(yv[i], edges);
         if (bin >= 0) atomicAdd(&hist[bin], 1);
     }
+    MVOSR_RSTAMP(2);
     // (one wave: its LDS operations execute in order, the reads below see the atomics above)
     int hraw[3], hz[3];
     Bits192 single, modes, mins;
@@ -533,58 +561,66 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, const double *yv, dou
 #pragma unroll
         for (int c = 0; c < 3; ++c) { const int b = lane + 64 * c; if (b < kBins) { g_hist[b] = hraw[c]; g_hist[kBins + b] = hz[c]; } }
     }
+    MVOSR_RSTAMP(3);
     const int first_single = single.lowest_from(0);
     // a value can only be dropped if its own bin or a neighbouring one has count 1
     Bits192 near;
     near.w[0] = single.w[0] | (single.w[0] << 1) | (single.w[0] >> 1) | (single.w[1] << 63);
     near.w[1] = single.w[1] | (single.w[1] << 1) | (single.w[1] >> 1) | (single.w[0] >> 63) | (single.w[2] << 63);
     near.w[2] = single.w[2] | (single.w[2] << 1) | (single.w[2] >> 1) | (single.w[1] >> 63);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const int b = lane + 64 * c; if (b < 176) nearflag[b] = (b < kBins) ? (int)((near.w[c] >> lane) & 1ull) : 0; }
     // check_mode returns no modes iff max <= 2 (:451-452); otherwise the maximum bin itself is one
     const bool have_modes = mx > P.mode_min;
 
-    // second pass: drop the points inside a single bin's interval (:284-293), accumulate the mean
-    double sum = 0.0, cntd = 0.0;
-    unsigned kept = 0u;
-    int nlist = 0;                               // median fallback: kept values packed into `scratch`
+    // second pass: drop the points inside a single bin's interval (:284-293), accumulate the mean.
+    // Only values whose own or neighbouring bin has count 1 can be dropped: they are flagged here
+    // (one LDS read each) and examined in a rolled loop below, which most iterations skip.
+    unsigned kept = valid, susp = 0u;
 #pragma unroll
-    for (int k = 0; k < kRoadRC; ++k) {
-        const int i = k * kWave + lane;
-        bool keep = false;
-        if (i < M) {
-            const int bin = binc[k];
-            keep = !(bin >= 0 && first_single >= 0 && near.test_lane(bin) && dropped_by_single(yc[k], bin, single, first_single));
-        }
-        if (keep) { kept |= 1u << k; sum += yc[k]; cntd += 1.0; }
-        if (!have_modes) {                       // wave-uniform
-            const unsigned long long m = __ballot(keep);
-            if (keep) scratch[nlist + __popcll(m & ((1ull << lane) - 1ull))] = yc[k];
-            nlist += __popcll(m);
+    for (int k = 0; k < kRoadRC; ++k) susp |= (nearflag[binc[k]] ? 1u : 0u) << k;         // nearflag[kTrash] == 0
+    if (__ballot(susp != 0u)) {
+#pragma unroll
+        for (int k = 0; k < kRoadRC; ++k) {
+            if (!__ballot((susp >> k) & 1u)) continue;                        // wave-uniform skip
+            if (((susp >> k) & 1u) && dropped_by_single(yc[k], binc[k], single, first_single)) kept &= ~(1u << k);
         }
     }
-    for (int i0 = kRoadRC * kWave; i0 < M; i0 += kWave) {
-        const int i = i0 + lane;
-        bool keep = false;
-        double y = 0.0;
-        if (i < M) {
-            y = yv[i];
-            const int bin = bin_of(y);
-            keep = !(bin >= 0 && first_single >= 0 && near.test_lane(bin) && dropped_by_single(y, bin, single, first_single));
-        }
-        if (keep) { sum += y; cntd += 1.0; }
-        if (!have_modes) {
-            const unsigned long long m = __ballot(keep);
-            if (keep) scratch[nlist + __popcll(m & ((1ull << lane) - 1ull))] = y;     // index <= i: in-place safe when scratch == yv
-            nlist += __popcll(m);
-        }
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < kRoadRC; ++k) sum += ((kept >> k) & 1u) ? yc[k] : 0.0;
+    double cntd = (double)__popc(kept);
+    for (int i = kRoadRC * kWave + lane; i < M; i += kWave) {              // lists longer than the register cache
+        const double y = yv[i];
+        const int bin = bin_of_table(y, edges);
+        if (bin >= 0 && nearflag[bin] && dropped_by_single(y, bin, single, first_single)) continue;
+        sum += y; cntd += 1.0;
     }
     sum = wave_sum(sum);
     cntd = wave_sum(cntd);
+    MVOSR_RSTAMP(4);
     const int nkept = (int)cntd;
     R.n_kept = nkept;
 
     if (!have_modes) {
         if (nkept == 0) { R.height = height_level; R.status = MVOSR_ST_LEVEL; return R; }   // :334-335
-        // np.median (:333) by rank counting over the packed list: the two middle order statistics
+        // np.median (:333): pack the kept values into `scratch` (index <= source index, so in place
+        // is safe when scratch == yv), then rank counting: the two middle order statistics
+        int nlist = 0;
+#pragma unroll 1
+        for (int i0 = 0; i0 < M; i0 += kWave) {
+            const int i = i0 + lane;
+            bool keep = false;
+            double y = 0.0;
+            if (i < M) {
+                y = yv[i];
+                const int bin = bin_of_table(y, edges);
+                keep = !(bin >= 0 && nearflag[bin] && dropped_by_single(y, bin, single, first_single));
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) scratch[nlist + __popcll(m & ((1ull << lane) - 1ull))] = y;
+            nlist += __popcll(m);
+        }
         __threadfence_block();                   // the wave's own stores, visible to all its lanes
         const int klo = (nkept - 1) >> 1, khi = nkept >> 1;
         double mlo = 0.0, mhi = 0.0;
@@ -613,18 +649,18 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, const double *yv, dou
     double ss = 0.0;
 #pragma unroll
     for (int k = 0; k < kRoadRC; ++k) {
-        if (!((kept >> k) & 1u)) continue;
-        const double d = yc[k] - mean;
+        const double d = ((kept >> k) & 1u) ? yc[k] - mean : 0.0;
         ss += d * d;
     }
     for (int i = kRoadRC * kWave + lane; i < M; i += kWave) {
         const double y = yv[i];
-        const int bin = bin_of(y);
-        if (bin >= 0 && first_single >= 0 && near.test_lane(bin) && dropped_by_single(y, bin, single, first_single)) continue;
+        const int bin = bin_of_table(y, edges);
+        if (bin >= 0 && nearflag[bin] && dropped_by_single(y, bin, single, first_single)) continue;
         const double d = y - mean;
         ss += d * d;
     }
     ss = wave_sum(ss);
+    MVOSR_RSTAMP(5);
 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -666,16 +702,29 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, const double *yv, dou
     return R;
 }
 
-__global__ __launch_bounds__(kRoadWaves *kWave) void road_model_kernel(const RoadArgs a) {
-    __shared__ int hist_all[kRoadWaves][176];
+#ifndef MVOSR_ROAD_MINW
+#define MVOSR_ROAD_MINW 1
+#endif
+__global__ __launch_bounds__(kRoadWaves *kWave, MVOSR_ROAD_MINW) void road_model_kernel(const RoadArgs a) {
+    __shared__ int hist_all[kRoadWaves][2][176];
+    __shared__ double2 edges[kBins + 1];
+    for (int k = threadIdx.x; k < kBins; k += kRoadWaves * kWave) { double2 e; e.x = bin_edge(k); e.y = bin_edge(k + 1); edges[k] = e; }
+    __syncthreads();
     const int64_t f = a.first_frame + (int64_t)blockIdx.x * kRoadWaves + wave_id();
     if (f >= a.first_frame + a.n_frames) return;
     if (a.pending_only && a.o.status[f] != kStPending) return;
+    MVOSR_STAMP_DECL
+    MVOSR_RSTAMP(0);
     const int M = a.cnt[f];
     const int64_t off = a.off[f];
     const double hl = a.height_level ? a.height_level[f] : nan("");
-    const RoadResult R = road_wave(hist_all[wave_id()], a.y + off, a.scratch + off, M, hl, a.P,
-                                   a.o.hist ? a.o.hist + f * 2 * kBins : nullptr);
+    MVOSR_RSTAMP(1);
+    const RoadResult R = road_wave(hist_all[wave_id()][0], hist_all[wave_id()][1], edges, a.y + off, a.scratch + off, M, hl, a.P,
+                                   a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
+    MVOSR_RSTAMP(6);
+#ifdef MVOSR_STAMPS
+    if (lane_id() == 0 && a.o.hist) { unsigned long long *d = reinterpret_cast<unsigned long long *>(a.o.hist + f * 2 * kBins) + 16; for (int i = 0; i < 8; ++i) d[i] = stamps[i]; }
+#endif
     if (lane_id() == 0) {
         double height = nan(""), raw = nan("");
         if (R.status == MVOSR_ST_NO_FLAT) raw = a.P.absolute_reference / hl;                        // :421

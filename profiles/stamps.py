@@ -30,7 +30,9 @@ out = DeviceOutputs(ctx, db, counts=True, hist=True)
 for _ in range(3):
     eng.scale_batch(db, out)
 ctx.sync()
-h = out.get("hist").reshape(pf.n_frames, -1).view(np.uint64)[:, :10].astype(np.float64)
+raw = out.get("hist").reshape(pf.n_frames, -1).view(np.uint64)
+h = raw[:, :10].astype(np.float64)
+road = raw[:, 16:23].astype(np.float64)
 cols = [0, 1, 2, 3, 4, 5, 9]            # stamps the scale kernel sets (6-8 belonged to the old fused road phase)
 names = ["load y,z,v + barrier", "vote sweep (tri1) + barrier", "compaction (2 barriers)", "select sweep 1 + reduce",
          "select sweep 2 + reduce", "pack selected + store list"]
@@ -40,3 +42,10 @@ tot = h[:, -1] - h[:, 0]
 print("workgroup life: mean %.0f ticks (s_memtime), median %.0f" % (tot.mean(), np.median(tot)))
 for i, n in enumerate(names):
     print("%-36s mean %9.0f  share %5.1f%%" % (n, d[:, i].mean(), 100 * d[:, i].mean() / tot.mean()))
+
+rn = ["start -> cnt/off/level loaded", "values loaded + histogram atomics", "hist read, ballots, max/min", "near flags, kept pass, mean reduce", "std pass + reduce", "mode logic + return"]
+rd = np.diff(road, axis=1)
+rt = road[:, -1] - road[:, 0]
+print("road-model wave life: mean %.0f ticks, median %.0f" % (rt.mean(), np.median(rt)))
+for i, n in enumerate(rn):
+    print("%-36s mean %9.0f  share %5.1f%%" % (n, rd[:, i].mean(), 100 * rd[:, i].mean() / rt.mean()))
