@@ -860,6 +860,209 @@ __global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense frames (more features than fit LDS in fp64, e.g. N = 20000): same algorithm, but the
+// remapped planes live in a per-frame workspace in global memory and the triangle sweeps gather
+// from it through L1/L2 ("L2-gather variant").  LDS keeps only what is hit by atomics: the 16-bit
+// vote counters and the selected bit-set.  One workgroup of 16 wavefronts per frame.  Survivors are
+// compacted into a second workspace copy (no in-place hazard, no registers held across barriers).
+// ---------------------------------------------------------------------------------------------
+constexpr int kDenseWaves = 16;
+struct DenseWs { double2 *P, *P2; double *Y, *Y2; };      // per-batch planes laid out like x (feat_off)
+
+__host__ __device__ inline uint32_t dense_lds_bytes(int n) {
+    const uint32_t npad = (uint32_t)((n + 1) & ~1);
+    return align16(2u * npad + 16u) + align16(4u * ((uint32_t)(n + 31) / 32u)) + 8u * (uint32_t)(kRedSlots * 2 * kDenseWaves) + 4u * 32u;
+}
+
+template <bool FUSED>
+__device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n, const double *gx, const double *gy, const double *gz,
+                                                const double *gv, const int32_t *tri1, int64_t t1_begin, int t1_count,
+                                                double cp, double sp, int32_t *g_counters, int &bad,
+                                                double2 *P, double *Y, double2 *P2, double *Y2) {
+    constexpr int B = kDenseWaves * kWave;
+    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    const uint16_t *c16 = reinterpret_cast<const uint16_t *>(c32);
+    const uint32_t ones = ((uint32_t)(kCounterBias + 1) << 16) | (uint32_t)(kCounterBias + 1);     // np.ones, :153
+    for (int i = tid; i < n; i += B) {
+        const double yy = gy[i], zz = gz[i];
+        double2 pv; pv.x = gv[i]; pv.y = yy * sp + zz * cp;                // :392
+        P[i] = pv;
+        Y[i] = yy * cp - zz * sp;                                          // :391
+    }
+    for (int i = tid; i < ((n + 1) >> 1); i += B) c32[i] = ones;
+    __threadfence_block();
+    __syncthreads();
+    for (int t = tid; t < t1_count; t += B) {
+        const TriIds q = load_tri(tri1, t1_begin + t);
+        if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
+        const double2 p0 = P[q.a], p1 = P[q.b], p2 = P[q.c];              // {v, z'} through L1/L2
+        const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
+        const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
+        const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
+        const bool f0 = pa | pb, f1 = pa | pb | pc, f2 = pc;
+        const uint32_t u0 = 1u << ((q.a & 1) * 16), u1 = 1u << ((q.b & 1) * 16), u2 = 1u << ((q.c & 1) * 16);
+        atomicAdd(&c32[q.a >> 1], f0 ? 0u - u0 : u0);
+        atomicAdd(&c32[q.b >> 1], f1 ? 0u - u1 : u1);
+        atomicAdd(&c32[q.c >> 1], f2 ? 0u - u2 : u2);
+    }
+    __syncthreads();
+    const int per = ((n + B - 1) / B) * kWave;
+    const int begin = w * per, end = min(n, begin + per);
+    int cnt = 0;
+    for (int i0 = begin; i0 < end; i0 += kWave) {
+        const int i = i0 + lane;
+        bool keep = false;
+        if (i < end) {
+            const int c = (int)c16[i] - kCounterBias;
+            keep = c >= 0;                                                    // :166
+            if (g_counters) g_counters[i] = c;
+        }
+        cnt += __popcll(__ballot(keep));
+    }
+    if (lane == 0) misc[M_WCNT + w] = cnt;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < kDenseWaves; ++i) { const int c = misc[M_WCNT + i]; if (i < w) base += c; total += c; }
+    if constexpr (FUSED) {
+        for (int i0 = begin; i0 < end; i0 += kWave) {
+            const int i = i0 + lane;
+            const bool keep = (i < end) && ((int)c16[i] - kCounterBias >= 0);
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                double2 pv; pv.x = gx[i]; pv.y = P[i].y;
+                P2[pos] = pv;                                                 // {x, z'} of the survivor (:264-265)
+                Y2[pos] = Y[i];
+            }
+            base += __popcll(m);
+        }
+        __threadfence_block();
+    }
+    __syncthreads();
+    return total;
+}
+
+struct DenseArgs { KArgs k; DenseWs ws; };
+
+template <bool FULL>
+__global__ __launch_bounds__(kDenseWaves *kWave) void scale_frames_dense_kernel(const DenseArgs da) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KArgs &a = da.k;
+    constexpr int B = kDenseWaves * kWave;
+    const int tid = threadIdx.x;
+    const int64_t f = a.first_frame + blockIdx.x;
+    const int n = a.b.feat_cnt[f];
+    const int64_t off = a.b.feat_off[f];
+    const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
+    const int t1n = (int)(a.b.tri1_off[f + 1] - t1b), t2n = (int)(a.b.tri2_off[f + 1] - t2b);
+    RoadResult R;
+    R.height = nan(""); R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
+    R.mean = R.std = R.skew = R.median = nan("");
+    if (n <= 0 || t2n <= 0) {
+        if (tid == 0) {
+            a.o.raw_scale[f] = nan(""); a.o.height[f] = nan(""); a.o.height_level[f] = nan("");
+            a.o.status[f] = MVOSR_ST_ERR_EMPTY; a.nsel[f] = 0;
+            write_counts(a, f, 0, 0, 0, R);
+        }
+        return;
+    }
+    const uint32_t npad = (uint32_t)((n + 1) & ~1);
+    Smem s;
+    s.c32 = reinterpret_cast<uint32_t *>(smem);
+    s.c16 = reinterpret_cast<uint16_t *>(smem);
+    s.sel = reinterpret_cast<uint32_t *>(smem + align16(2u * npad + 16u));
+    s.red = reinterpret_cast<double *>(smem + align16(2u * npad + 16u) + align16(4u * ((uint32_t)(n + 31) / 32u)));
+    s.misc = reinterpret_cast<int *>(s.red + kRedSlots * 2 * kDenseWaves);
+    s.hist = nullptr;
+    s.P = da.ws.P2 + off;              // what the second triangulation indexes: the compacted copy
+    s.Y = da.ws.Y2 + off;
+    for (int i = tid; i < (n + 31) / 32; i += B) s.sel[i] = 0u;
+    int bad = 0;
+    const int nvalid = phase_vote_dense<true>(s.c32, s.misc, n, a.b.x + off, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
+                                              a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad,
+                                              da.ws.P + off, da.ws.Y + off, da.ws.P2 + off, da.ws.Y2 + off);
+    const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
+    SelectResult S;
+    S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 1;
+    if (!mask_mismatch) {
+        TriChunk<B> tc2;
+        tc2.load(a.b.tri2, t2b, t2n, 0, tid);
+        S = phase_select<kDenseWaves, FULL>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
+                                            a.o.tri_heights, bad, 0);
+    }
+    int status = kStPending;
+    double raw = nan("");
+    int nsel = 0;
+    if (mask_mismatch || S.bad) {
+        status = MVOSR_ST_ERR_MASK;
+    } else if (S.singular) {
+        status = MVOSR_ST_ERR_SINGULAR;
+    } else {
+        // dense list of the selected y' for the road-model kernel: count per wave slice, then store
+        const int w = wave_id(), lane = lane_id();
+        const int per = ((nvalid + B - 1) / B) * kWave;
+        const int begin = w * per, end = min(nvalid, begin + per);
+        int cnt = 0;
+        for (int j0 = begin; j0 < end; j0 += kWave) {
+            const int j = j0 + lane;
+            const bool sel = (j < end) && ((s.sel[j >> 5] >> (j & 31)) & 1u);
+            if (a.o.selected && j < end) a.o.selected[off + j] = (uint8_t)sel;                   // :247
+            cnt += __popcll(__ballot(sel));
+        }
+        if (lane == 0) s.misc[M_WCNT + w] = cnt;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < kDenseWaves; ++i) { const int c = s.misc[M_WCNT + i]; if (i < w) base += c; nsel += c; }
+        double *dst = a.ysel + off;
+        for (int j0 = begin; j0 < end; j0 += kWave) {
+            const int j = j0 + lane;
+            const bool sel = (j < end) && ((s.sel[j >> 5] >> (j & 31)) & 1u);
+            const unsigned long long m = __ballot(sel);
+            if (sel) dst[base + __popcll(m & ((1ull << lane) - 1ull))] = s.Y[j];
+            base += __popcll(m);
+        }
+        if (nsel == 0) { status = MVOSR_ST_NO_FLAT; raw = a.P.absolute_reference / S.height_level; }   // :277-279,:421
+    }
+    if (tid == 0) {
+        a.o.raw_scale[f] = raw;
+        a.o.height[f] = nan("");
+        a.o.height_level[f] = S.height_level;
+        a.o.status[f] = status;
+        a.nsel[f] = nsel;
+        R.n_sel = nsel;
+        write_counts(a, f, nvalid, S.n_pitch, S.n_tri_valid, R);
+        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = st[1] = st[2] = st[3] = nan(""); }
+    }
+}
+
+__global__ __launch_bounds__(kDenseWaves *kWave) void outlier_vote_dense_kernel(const DenseArgs da) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KArgs &a = da.k;
+    const int64_t f = a.first_frame + blockIdx.x;
+    const int n = a.b.feat_cnt[f];
+    if (n <= 0) { if (threadIdx.x == 0 && a.o.counts) a.o.counts[f * MVOSR_N_COUNTS + MVOSR_CNT_VALID] = 0; return; }
+    const int64_t off = a.b.feat_off[f];
+    const int64_t t1b = a.b.tri1_off[f];
+    const int t1n = (int)(a.b.tri1_off[f + 1] - t1b);
+    const uint32_t npad = (uint32_t)((n + 1) & ~1);
+    uint32_t *c32 = reinterpret_cast<uint32_t *>(smem);
+    double *red = reinterpret_cast<double *>(smem + align16(2u * npad + 16u) + align16(4u * ((uint32_t)(n + 31) / 32u)));
+    int *misc = reinterpret_cast<int *>(red + kRedSlots * 2 * kDenseWaves);
+    int bad = 0;
+    const int nvalid = phase_vote_dense<false>(c32, misc, n, nullptr, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
+                                               a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters + off, bad,
+                                               da.ws.P + off, da.ws.Y + off, nullptr, nullptr);
+    int b0 = bad, b1 = 0, b2 = 0, b3 = 0;
+    block_sum4i<kDenseWaves>(b0, b1, b2, b3, red + R_MISC * 2 * kDenseWaves);
+    if (threadIdx.x == 0) {
+        if (a.o.counts) a.o.counts[f * MVOSR_N_COUNTS + MVOSR_CNT_VALID] = nvalid;
+        if (a.o.status) a.o.status[f] = b0 ? MVOSR_ST_ERR_MASK : MVOSR_ST_MODE;
+    }
+}
+
 // K1 alone
 template <int WAVES, int SC>
 __global__ __launch_bounds__(WAVES *kWave) void outlier_vote_kernel(const KArgs a) {
@@ -959,6 +1162,15 @@ static int pick_waves(int requested, int max_feat) {
     return 16;
 }
 static int variant_capacity(int waves, int sc) { return waves * sc * kWave; }
+// largest frame the LDS-resident variant takes (16 wavefronts): above it the dense variant runs
+static int lds_capacity_features() {
+    int lo = 1, hi = variant_capacity(16, 8);
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if ((int64_t)lds_plan(mid, 16).total <= (int64_t)g_max_dyn_lds) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
 
 static int check_common(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const mvosr_outputs *o) {
     if (!ctx || !p || !b || !o) return set_error(MVOSR_ERR_ARG, "null argument");
@@ -1002,6 +1214,36 @@ static int launch_vote(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
     if ((rc = prepare_kernel(outlier_vote_kernel<WAVES, SC>, lds))) return rc;
     hipLaunchKernelGGL((outlier_vote_kernel<WAVES, SC>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
     return check_launch("outlier_vote_kernel");
+}
+
+// dense frames: planes in a global workspace (48 B per feature), 16 wavefronts per frame
+static int launch_scale_dense(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool full, bool vote_only) {
+    if (ka.b.max_feat > 65535) return set_error(MVOSR_ERR_TOO_LARGE, "more than 65535 features per frame");
+    if ((int64_t)2 * ka.b.max_feat > (int64_t)64 * kWave * kDenseWaves)
+        return set_error(MVOSR_ERR_TOO_LARGE, "%d features give more triangles than %d wavefronts sweep", ka.b.max_feat, kDenseWaves);
+    const size_t lds = dense_lds_bytes(ka.b.max_feat);
+    if ((int64_t)lds > (int64_t)g_max_dyn_lds)
+        return set_error(MVOSR_ERR_TOO_LARGE, "frame of %d features needs %zu B of LDS (> %d)", ka.b.max_feat, lds, g_max_dyn_lds);
+    DenseArgs da;
+    da.k = ka;
+    void *p[4];
+    int rc = ctx_workspace_dense(ctx, ka.b.total_feat, p);
+    if (rc) return rc;
+    da.ws.P = reinterpret_cast<double2 *>(p[0]); da.ws.P2 = reinterpret_cast<double2 *>(p[1]);
+    da.ws.Y = reinterpret_cast<double *>(p[2]); da.ws.Y2 = reinterpret_cast<double *>(p[3]);
+    if (vote_only) {
+        if ((rc = prepare_kernel(outlier_vote_dense_kernel, lds))) return rc;
+        hipLaunchKernelGGL(outlier_vote_dense_kernel, dim3((unsigned)nl), dim3(kDenseWaves * kWave), lds, ctx_stream(ctx), da);
+        return check_launch("outlier_vote_dense_kernel");
+    }
+    if (full) {
+        if ((rc = prepare_kernel(scale_frames_dense_kernel<true>, lds))) return rc;
+        hipLaunchKernelGGL((scale_frames_dense_kernel<true>), dim3((unsigned)nl), dim3(kDenseWaves * kWave), lds, ctx_stream(ctx), da);
+    } else {
+        if ((rc = prepare_kernel(scale_frames_dense_kernel<false>, lds))) return rc;
+        hipLaunchKernelGGL((scale_frames_dense_kernel<false>), dim3((unsigned)nl), dim3(kDenseWaves * kWave), lds, ctx_stream(ctx), da);
+    }
+    return check_launch("scale_frames_dense_kernel");
 }
 
 // one wavefront per frame, kRoadWaves frames per workgroup
@@ -1053,14 +1295,7 @@ size_t mvosr_lds_bytes(int n_features) {
     return lds_plan(n, pick_waves(0, n)).total;
 }
 
-int mvosr_max_lds_features(void) {
-    int lo = 1, hi = 8192;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) / 2;
-        if ((int64_t)lds_plan(mid, 16).total <= (int64_t)g_max_dyn_lds) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
+int mvosr_max_lds_features(void) { return lds_capacity_features(); }
 
 int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const mvosr_outputs *o,
                       int waves_per_frame, int64_t first_frame, int64_t n_launch) {
@@ -1089,9 +1324,10 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     // chunks to run the road model of one chunk under the scale kernel of the next was measured
     // and lost 10%: smaller grids pay more tail than the overlap returns.)
     ka.first_frame = first_frame;
+    const bool dense = (waves_per_frame == 0 || waves_per_frame == 16) && b->max_feat > lds_capacity_features();
     hipEvent_t *pev = (ctx->prof_on && ctx->prof_calls < kProfRing) ? ctx->prof_ev[ctx->prof_calls] : nullptr;
     if (pev) (void)hipEventRecord(pev[0], ctx_stream(ctx));
-    if ((rc = dispatch_scale(ctx, ka, waves, n_launch, full))) return rc;
+    if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, full, false) : dispatch_scale(ctx, ka, waves, n_launch, full))) return rc;
     if (pev) (void)hipEventRecord(pev[1], ctx_stream(ctx));
     ra.first_frame = first_frame; ra.n_frames = n_launch;
     if (!(debug_skip_env() & 16)) { if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc; }
@@ -1109,7 +1345,11 @@ int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_
     if ((rc = ctx_activate(ctx))) return rc;
     KArgs ka;
     ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
-    ka.first_frame = 0; ka.height_level_in = nullptr; ka.debug_skip = 0;
+    ka.first_frame = 0; ka.height_level_in = nullptr; ka.debug_skip = 0; ka.ysel = nullptr; ka.nsel = nullptr;
+    if ((waves_per_frame == 0 || waves_per_frame == 16) && b->max_feat > lds_capacity_features()) {
+        if (b->total_feat <= 0) return set_error(MVOSR_ERR_ARG, "outlier_vote: batch.total_feat not set");
+        return launch_scale_dense(ctx, ka, b->n_frames, false, true);
+    }
     return dispatch_vote(ctx, ka, pick_waves(waves_per_frame, b->max_feat), b->n_frames);
 }
 

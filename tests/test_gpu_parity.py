@@ -152,15 +152,39 @@ def test_one_wave_per_frame_small_frames(gpu, stages):
         _assert_frame_equal(so, ores[f], res, pf, f)
 
 
-def test_dense_frame_too_large_for_lds_is_refused(gpu):
-    """N=20000 does not fit LDS: the LDS-resident variant must refuse, not corrupt."""
+def test_dense_golden_and_lds_refusal(gpu):
+    """Config C5 shape, N=20000 (T1~40000): does not fit LDS in fp64.  The dense variant (planes in
+    a global workspace, gathers through L2) must reproduce the reference's golden; the LDS-resident
+    variant, when asked for explicitly, must refuse rather than corrupt."""
     from mvoscalerecovery_amd import _lib, synth
-    f3, f2 = synth.synth_frame(7, 20000, base_seed=555)
     so = _oracle()
     z, meta = load_npz("dense.npz")
-    r = so.frame_raw_scale(f3, f2, 1.75, z["tri1"].astype(np.int32), z["tri2"].astype(np.int32))
+    f3, f2 = synth.synth_frame(meta["frame_idx"], meta["n"], base_seed=meta["seed"])
+    r = so.frame_raw_scale(f3, f2, meta["abs_ref"], z["tri1"].astype(np.int32), z["tri2"].astype(np.int32))
     with pytest.raises(_lib.MvosrLibraryError, match="LDS|features"):
-        _run_fused(gpu, [(f3, f2)], [r])
+        _run_fused(gpu, [(f3, f2)], [r], waves=8)
+    pf, res = _run_fused(gpu, [(f3, f2)], [r], per_triangle=True)
+    sl = pf.frame_slice(0)
+    assert np.array_equal(res["vote_counters"][sl] >= 0, z["valid"])
+    nv = int(z["valid"].sum())
+    assert np.array_equal(np.nonzero(res["selected"][sl][:nv])[0], z["selected_ids"])
+    assert res["height"][0] == float(z["height"])
+    assert np.array_equal(res["hist"][0, 0], z["hist_raw"])
+    _assert_frame_equal(so, r, res, pf, 0)
+
+
+@pytest.mark.parametrize("n,count", [(7000, 4), (20000, 3)])
+def test_dense_seeded_batches(gpu, n, count):
+    from mvoscalerecovery_amd import synth
+    so = _oracle()
+    frames = [synth.synth_frame(i, n, base_seed=9000 + n, upper_fraction=0.05 * (i % 2)) for i in range(count)]
+    ores = _oracle_frames(frames)
+    pf, res = _run_fused(gpu, frames, ores)
+    for f in range(count):
+        _assert_frame_equal(so, ores[f], res, pf, f)
+    pf2, res2 = _run_fused(gpu, frames, ores, stage=False, hist=False)
+    for k in ("raw_scale", "height", "height_level", "status"):
+        assert np.array_equal(res[k], res2[k], equal_nan=True)
 
 
 def test_road_cases_kernel(gpu):
