@@ -210,7 +210,8 @@ def main():
                        "waves_per_frame": args.waves if args.waves else "auto"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "scale_frames_kernel", "kernel_ms_avg": kernel_ms_avg,
+                         "kernel": ("scale_frames_dense_kernel" if args.features > ctx.lib.mvosr_max_lds_features() else "scale_frames_kernel"),
+                         "kernel_ms_avg": kernel_ms_avg,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "algorithmic_bytes_per_frame": bytes_per_launch / F,
                          "frames_per_s_kernel_only": F / (kernel_ms_avg * 1e-3),
