@@ -1,5 +1,6 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
 vectors of the reference.  Needs a real MI355X:  python -m pytest tests -m gpu"""
+import os
 import numpy as np
 import pytest
 
@@ -404,3 +405,44 @@ def test_seq4541_golden_batched(gpu):
     assert np.count_nonzero(res["scales"] != z["scales"]) <= int(nf.sum()) * meta["window"]
     np.testing.assert_array_equal(res["error"], z["error"])
     np.testing.assert_array_equal(res["pitchs"], z["pitchs"])
+
+
+def test_rccl_gather_and_gpu_median_world1(gpu, tmp_path):
+    """The multi-GPU step on one GPU: torch.distributed `nccl` (= RCCL) group of size 1, all-gather of
+    device tensors, window-median kernel on the stream torch and the context share."""
+    import subprocess
+    import sys
+    import textwrap
+    from conftest import ROOT
+    script = tmp_path / "w1.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        sys.path.insert(0, %r)
+        from mvoscalerecovery_amd import _lib, sharding
+        from mvoscalerecovery_amd.engine import ScaleEngine
+        from oracle import scale_oracle as so
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        ctx = _lib.Context(0)
+        stream = torch.cuda.Stream(device=0)
+        torch.cuda.set_stream(stream)
+        ctx.set_stream(stream.cuda_stream)
+        eng = ScaleEngine(1.75, ctx=ctx)
+        rng = np.random.default_rng(1)
+        raw = rng.uniform(0.5, 3.0, 10001)
+        st = rng.integers(0, 5, 10001).astype(np.int32)
+        filt, graw, gst = sharding.gather_and_filter(torch.from_numpy(raw).cuda(), torch.from_numpy(st).cuda(), 10001, 5,
+                                                     sharding.make_gpu_median(eng), queue=[2.0])
+        torch.cuda.synchronize()
+        want, _ = so.window_median(raw, 5, [2.0])
+        assert np.array_equal(filt.cpu().numpy(), want)
+        assert np.array_equal(graw.cpu().numpy(), raw) and np.array_equal(gst.cpu().numpy(), st)
+        dist.destroy_process_group()
+        print("world1 ok")
+    """ % ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "world1 ok" in p.stdout, p.stdout + p.stderr
