@@ -219,6 +219,47 @@ int mvosr_road_model_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_ba
 int mvosr_window_median(mvosr_ctx *ctx, const double *raw, int64_t n, int window,
                         const double *queue_in, int n_queue, double *out);
 
+/* ---- the `rescale` variant (the estimator /root/reference/src/main.py:20 imports) ------------- */
+
+/*
+ * GraphChecker.find_inliers (/root/reference/src/graph.py:18-36): per feature the number of incident
+ * triangles of tri1 (`total`) and how many of them give the vertex a marginal > 0.6 (`good`); the host
+ * keeps a feature when good/total > 0.5 (graph.py:35; 0/0 -> dropped).  `good_bits`: bit 3*code+k is
+ * set when vertex k of a triangle with edge-order code `code` (graph.py:124-129) has marginal > 0.6
+ * under the 8x8 triangle potential (graph.py:6-17,134-145) — 24 bits computed once on the host.
+ * Reads feat_off/feat_cnt/z/v/tri1_off/tri1 of `b` (no remap: rescale.py:25 sets camera_pitch = 0).
+ * total/good: int32 device arrays laid out like z.  status [F] (optional): 0 or MVOSR_ST_ERR_MASK.
+ */
+int mvosr_graph_inliers_batch(mvosr_ctx *ctx, const mvosr_batch *b, uint32_t good_bits, int32_t *total, int32_t *good,
+                              int32_t *status);
+
+/*
+ * ScaleEstimator.flat_selection (/root/reference/src/rescale.py:75-102) on the features that
+ * survived (x/y/z of `b`, already compacted by the host) and tri2: per triangle heights = 1/|n| with
+ * n = A^-1.1, flags bit0 pitch < loose_deg (-80), bit1 pitch < tight_deg (-85), bit2 kept = bit1 and
+ * heights > height_factor (0.9) * median(heights[bit0]).  tri_height/tri_flags: per triangle of tri2;
+ * height_level/n_kept/status: per frame (status 0, MVOSR_ST_ERR_SINGULAR, _MASK or _EMPTY).
+ * max_tri: largest triangle count of a frame (sizes LDS; <= 0: 2*max_feat).
+ */
+int mvosr_flat_selection_batch(mvosr_ctx *ctx, const mvosr_batch *b, double loose_deg, double tight_deg, double height_factor,
+                               double *tri_height, uint8_t *tri_flags, double *height_level, int32_t *n_kept, int32_t *status,
+                               int64_t max_tri);
+
+/*
+ * run_ransac (/root/reference/src/thirdparty/Ransac/ransac.py:3-23) with estimate / is_inlier of
+ * /root/reference/src/estimate_road_norm.py:8-18 for every frame, made deterministic by taking the
+ * sample sequence as input: triples[f][h][0..2] are row indices into frame f's points (planes
+ * px/py/pz, pts_off/pts_cnt per frame), consumed in order h = 0..n_hyp-1.  A hypothesis replaces the
+ * best when its inlier count (|m.[p,1]| < threshold over ALL points) is strictly larger; the scan
+ * stops at the first improvement whose count exceeds goal_fraction * n_points.  Outputs: counts
+ * [F][n_hyp] (optional), model [F][4] = unit (n, d) of the best plane with n_y >= 0
+ * (/root/reference/src/rescale.py:159-161), best_ic [F], used [F] (hypotheses consumed).
+ */
+int mvosr_ransac_plane_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                             const double *px, const double *py, const double *pz, const int32_t *triples, int n_hyp,
+                             double threshold, double goal_fraction, int32_t *counts, double *model, int32_t *best_ic,
+                             int32_t *used);
+
 /* LDS bytes the fused kernel requests for a frame of n features (host-side planning). */
 size_t mvosr_lds_bytes(int n_features);
 /* Largest frame the LDS-resident variant accepts on this build. */

@@ -72,6 +72,11 @@ SYMBOLS = {
     "mvosr_outlier_vote_batch": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Batch), C.POINTER(Outputs), C.c_int]),
     "mvosr_road_model_batch": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Batch), _P, C.POINTER(Outputs), C.c_int]),
     "mvosr_window_median": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, _P]),
+    "mvosr_graph_inliers_batch": (C.c_int, [_P, C.POINTER(Batch), C.c_uint32, _P, _P, _P]),
+    "mvosr_flat_selection_batch": (C.c_int, [_P, C.POINTER(Batch), C.c_double, C.c_double, C.c_double, _P, _P, _P, _P, _P,
+                                             C.c_int64]),
+    "mvosr_ransac_plane_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int, C.c_double, C.c_double,
+                                           _P, _P, _P, _P]),
     "mvosr_lds_bytes": (C.c_size_t, [C.c_int]),
     "mvosr_max_lds_features": (C.c_int, []),
 }

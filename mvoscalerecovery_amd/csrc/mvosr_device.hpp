@@ -19,6 +19,15 @@ constexpr int kCounterBias = 0x8000;        // 16-bit vote counters are stored b
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// one row of scipy's `simplices`: three int32 vertex ids, loaded with one global_load_dwordx3
+struct TriIds { int a, b, c; };
+__device__ __forceinline__ TriIds load_tri(const int32_t *tri, int64_t t) {
+    const int32_t *p = tri + 3 * t;
+    TriIds r;
+    r.a = p[0]; r.b = p[1]; r.c = p[2];
+    return r;
+}
+
 // ---- wave reductions on DPP (no LDS crossbar traffic) -----------------------------------------
 // Four DPP steps (quad xor 1, quad xor 2, row_half_mirror, row_mirror) leave every lane with the
 // sum of its row of 16; the four row sums are then read with v_readlane and added in a fixed

@@ -97,13 +97,6 @@ __device__ __forceinline__ Smem carve(char *base, int n, int waves) {
 // misc[] slots
 enum { M_WCNT = 0 /* [0..15] per-wave survivor counts */, M_LIST = 16, M_MEDLO = 18, M_MEDHI = 20 /* doubles at 18..21 */ };
 
-struct TriIds { int a, b, c; };
-__device__ __forceinline__ TriIds load_tri(const int32_t *tri, int64_t t) {
-    const int32_t *p = tri + 3 * t;
-    TriIds r;
-    r.a = p[0]; r.b = p[1]; r.c = p[2];
-    return r;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Triangle ids are streamed in chunks of kTC triangles per thread: all loads of a chunk are in

@@ -1,0 +1,320 @@
+// mvosr_rescale.hip — kernels for the `rescale` variant of the scale estimator (the one
+// /root/reference/src/main.py:20 imports): GraphChecker vote, flat_selection, and the RANSAC plane
+// fit made deterministic by taking its sample triples as input.  SURVEY.md §8 rows f2, f4, a11, a13.
+//
+//   graph_inliers_kernel   GraphChecker.find_inliers        /root/reference/src/graph.py:18-36,124-145
+//   flat_selection_kernel  ScaleEstimator.flat_selection    /root/reference/src/rescale.py:75-102
+//   ransac_plane_kernel    run_ransac + estimate/is_inlier  /root/reference/src/thirdparty/Ransac/ransac.py:3-23,
+//                                                           /root/reference/src/estimate_road_norm.py:8-18,66-70
+//
+// Same conventions as mvosr_kernels.hip: one frame per workgroup, fp64, planes staged in LDS,
+// compiled with -ffp-contract=off.  These are "next" rows: built for parity first, not tuned.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mvosr.h"
+#include "mvosr_device.hpp"
+#include "mvosr_host.hpp"
+
+namespace mvosr {
+
+constexpr int kRsWaves = 8;
+constexpr int kRsBlock = kRsWaves * kWave;
+
+// ---------------------------------------------------------------------------------------------
+// GraphChecker.find_inliers: per triangle the edge-order code a*4+b*2+c with
+// a=(v0-v1)(d0-d1)<0, b=(v1-v2)(d1-d2)<0, c=(v0-v2)(d0-d2)<0 selects a column of the 8x8 triangle
+// potential; the three vertex marginals of that column are compared with 0.6 on the HOST once (they
+// depend on the code only), so the kernel receives 8x3 flag bits.  Each vertex tallies
+// (incident triangles, triangles that vouch for it) in one 32-bit LDS word (low/high half).
+// ---------------------------------------------------------------------------------------------
+struct GraphArgs {
+    int64_t n_frames;
+    const int64_t *feat_off; const int32_t *feat_cnt;
+    const double *z, *v;
+    const int64_t *tri_off; const int32_t *tri;
+    uint32_t good_bits;            // bit 3*code+k: vertex k of a triangle with this code has marginal > 0.6
+    int32_t *total, *good;         // [like z] outputs
+    int32_t *status;               // [F] 0 ok / MVOSR_ST_ERR_MASK on a bad vertex id
+};
+
+__global__ __launch_bounds__(kRsBlock) void graph_inliers_kernel(const GraphArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t f = blockIdx.x;
+    const int n = a.feat_cnt[f];
+    if (n <= 0) { if (threadIdx.x == 0 && a.status) a.status[f] = MVOSR_ST_ERR_EMPTY; return; }
+    const int64_t off = a.feat_off[f];
+    const int64_t tb = a.tri_off[f];
+    const int tn = (int)(a.tri_off[f + 1] - tb);
+    double2 *P = reinterpret_cast<double2 *>(smem);                       // {v, z}
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + 16u * (uint32_t)((n + 1) & ~1));
+    int *flag = reinterpret_cast<int *>(cnt + n + 4);
+    const int tid = threadIdx.x;
+    if (tid == 0) *flag = 0;
+    for (int i = tid; i < n; i += kRsBlock) {
+        double2 p; p.x = a.v[off + i]; p.y = a.z[off + i];               // rescale.py:25: camera_pitch = 0, no remap
+        P[i] = p;
+        cnt[i] = 0u;
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int t = tid; t < tn; t += kRsBlock) {
+        const TriIds q = load_tri(a.tri, tb + t);
+        if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
+        const double2 p0 = P[q.a], p1 = P[q.b], p2 = P[q.c];
+        const int ca = (p0.x - p1.x) * (p0.y - p1.y) < 0.0;              // graph.py:125
+        const int cb = (p1.x - p2.x) * (p1.y - p2.y) < 0.0;              // graph.py:126
+        const int cc = (p0.x - p2.x) * (p0.y - p2.y) < 0.0;              // graph.py:127
+        const uint32_t g = a.good_bits >> (3 * (ca * 4 + cb * 2 + cc));  // graph.py:128,140-145
+        atomicAdd(&cnt[q.a], 1u + ((g & 1u) << 16));                     // graph.py:28-30
+        atomicAdd(&cnt[q.b], 1u + (((g >> 1) & 1u) << 16));
+        atomicAdd(&cnt[q.c], 1u + (((g >> 2) & 1u) << 16));
+    }
+    if (bad) *flag = 1;
+    __syncthreads();
+    for (int i = tid; i < n; i += kRsBlock) {
+        const uint32_t c = cnt[i];
+        a.total[off + i] = (int32_t)(c & 0xFFFFu);
+        a.good[off + i] = (int32_t)(c >> 16);
+    }
+    if (tid == 0 && a.status) a.status[f] = *flag ? MVOSR_ST_ERR_MASK : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat_selection: per triangle n = A^-1 . 1 (LU, like np.matrix.I), heights = 1/|n|,
+// pitch = asin(-n_y/|n|) deg; level = 0.9 * median(heights[pitch < -80]); a triangle is kept when
+// pitch < -85 and heights > level.  The median is the mean of the two middle order statistics,
+// found by rank counting over the list of loose heights in LDS.
+// ---------------------------------------------------------------------------------------------
+struct FlatArgs {
+    int64_t n_frames;
+    const int64_t *feat_off; const int32_t *feat_cnt;
+    const double *x, *y, *z;
+    const int64_t *tri_off; const int32_t *tri;
+    double loose_deg, tight_deg, height_factor;
+    double *tri_height;            // [T] 1/|n|
+    uint8_t *tri_flags;            // [T] bit0: pitch < loose, bit1: pitch < tight, bit2: kept
+    double *height_level;          // [F]
+    int32_t *status;               // [F] 0 / MVOSR_ST_ERR_SINGULAR / MVOSR_ST_ERR_MASK / MVOSR_ST_ERR_EMPTY
+    int32_t *n_kept;               // [F]
+};
+
+__global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t f = blockIdx.x;
+    const int n = a.feat_cnt[f];
+    const int64_t off = a.feat_off[f];
+    const int64_t tb = a.tri_off[f];
+    const int tn = (int)(a.tri_off[f + 1] - tb);
+    const int tid = threadIdx.x;
+    if (n <= 0 || tn <= 0) {
+        if (tid == 0) { a.status[f] = MVOSR_ST_ERR_EMPTY; a.height_level[f] = nan(""); a.n_kept[f] = 0; }
+        return;
+    }
+    const uint32_t npad = (uint32_t)((n + 1) & ~1);
+    double *X = reinterpret_cast<double *>(smem);
+    double *Y = X + npad;
+    double *Z = Y + npad;
+    double *L = Z + npad;                                        // loose heights, up to tn
+    int *misc = reinterpret_cast<int *>(L + tn);
+    double *med = reinterpret_cast<double *>(misc + 8);
+    if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0; misc[3] = 0; }
+    for (int i = tid; i < n; i += kRsBlock) { X[i] = a.x[off + i]; Y[i] = a.y[off + i]; Z[i] = a.z[off + i]; }
+    __syncthreads();
+    for (int t = tid; t < tn; t += kRsBlock) {
+        const TriIds q = load_tri(a.tri, tb + t);
+        if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) {
+            misc[2] = 1; a.tri_flags[tb + t] = 0; a.tri_height[tb + t] = nan(""); continue;
+        }
+        double nx, ny, nz;
+        if (!plane_normal(X[q.a], Y[q.a], Z[q.a], X[q.b], Y[q.b], Z[q.b], X[q.c], Y[q.c], Z[q.c], nx, ny, nz)) misc[1] = 1;   // rescale.py:79-80
+        const double len = sqrt((nx * nx + ny * ny) + nz * nz);                          // :81
+        const double pitch = asin(-(ny / len)) * 180.0 / 3.141592653589793;              // :82-83
+        const double h = 1.0 / len;                                                      // :89
+        uint8_t fl = 0;
+        if (pitch < a.loose_deg) { fl |= 1; L[atomicAdd(&misc[0], 1)] = h; }              // :85
+        if (pitch < a.tight_deg) fl |= 2;                                                // :86
+        a.tri_flags[tb + t] = fl;
+        a.tri_height[tb + t] = h;
+    }
+    __syncthreads();
+    const int k = misc[0];
+    if (k > 0) {                                                                         // np.median, :91
+        const int klo = (k - 1) >> 1, khi = k >> 1;
+        for (int i = tid; i < k; i += kRsBlock) {
+            const double hi = L[i];
+            int rank = 0;
+            for (int j = 0; j < k; ++j) { const double hj = L[j]; rank += (hj < hi) || (hj == hi && j < i); }
+            if (rank == klo) med[0] = hi;
+            if (rank == khi) med[1] = hi;
+        }
+    }
+    __syncthreads();
+    const double level = (k > 0) ? a.height_factor * ((((k - 1) >> 1) == (k >> 1)) ? med[0] : (med[0] + med[1]) / 2.0)
+                                 : nan("");                      // median of an empty set is nan (nothing passes)
+    int kept = 0;
+    for (int t = tid; t < tn; t += kRsBlock) {
+        const uint8_t fl = a.tri_flags[tb + t];
+        if ((fl & 2) && a.tri_height[tb + t] > level) { a.tri_flags[tb + t] = fl | 4; ++kept; }   // :94-96
+    }
+    kept = wave_sum(kept);
+    if (lane_id() == 0) atomicAdd(&misc[3], kept);
+    __syncthreads();
+    if (tid == 0) {
+        a.height_level[f] = level;
+        a.n_kept[f] = misc[3];
+        a.status[f] = misc[2] ? MVOSR_ST_ERR_MASK : (misc[1] ? MVOSR_ST_ERR_SINGULAR : 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RANSAC plane fit with the sample triples given (ransac.py:3-23).  One workgroup per frame; a wave
+// takes hypotheses w, w+8, ...: the plane through its three sample points as the unit 4-vector
+// (n, d)/|(n, d)| — the null vector the reference gets from the SVD of [x y z 1]
+// (estimate_road_norm.py:13-15), up to sign — and all 64 lanes count |m.[p,1]| < threshold over the
+// frame's points (estimate_road_norm.py:17-18).  One lane then replays the reference's sequential
+// rule: a hypothesis replaces the best when its count is strictly larger, and the loop stops at
+// the first such improvement that exceeds the goal.
+// ---------------------------------------------------------------------------------------------
+struct RansacArgs {
+    int64_t n_frames;
+    const int64_t *pts_off; const int32_t *pts_cnt;     // [F]
+    const double *px, *py, *pz;                          // planes of the selected points (with repeats, :101)
+    const int32_t *triples;                              // [F][H][3] row indices into the frame's points
+    int32_t n_hyp;                                       // H (<= kMaxHyp)
+    double threshold, goal_fraction;
+    int32_t *counts;                                     // [F][H] inlier counts (or NULL)
+    double *model;                                       // [F][4] best model, sign fixed so that n_y >= 0
+    int32_t *best_ic, *used;                             // [F]
+};
+constexpr int kMaxHyp = 512;
+
+__global__ __launch_bounds__(kRsBlock) void ransac_plane_kernel(const RansacArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t f = blockIdx.x;
+    const int M = a.pts_cnt[f];
+    const int64_t off = a.pts_off[f];
+    const int H = a.n_hyp;
+    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    int *cnts = reinterpret_cast<int *>(smem);                            // [H]
+    double *mods = reinterpret_cast<double *>(smem + 4u * (uint32_t)((H + 3) & ~3));   // [H][4]
+    if (M <= 0) {
+        if (tid == 0) { a.best_ic[f] = 0; a.used[f] = 0; for (int k = 0; k < 4; ++k) a.model[4 * f + k] = nan(""); }
+        return;
+    }
+    const double *px = a.px + off, *py = a.py + off, *pz = a.pz + off;
+    for (int h = w; h < H; h += kRsWaves) {
+        const int32_t *t = a.triples + ((int64_t)f * H + h) * 3;
+        const int i0 = t[0], i1 = t[1], i2 = t[2];
+        const double x0 = px[i0], y0 = py[i0], z0 = pz[i0];
+        const double e1x = px[i1] - x0, e1y = py[i1] - y0, e1z = pz[i1] - z0;
+        const double e2x = px[i2] - x0, e2y = py[i2] - y0, e2z = pz[i2] - z0;
+        double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+        double d = -((nx * x0 + ny * y0) + nz * z0);
+        const double inv = 1.0 / sqrt(((nx * nx + ny * ny) + nz * nz) + d * d);
+        nx *= inv; ny *= inv; nz *= inv; d *= inv;
+        int ic = 0;
+        for (int j = lane; j < M; j += kWave)
+            ic += fabs(((px[j] * nx + py[j] * ny) + pz[j] * nz) + d) < a.threshold;          // estimate_road_norm.py:18
+        ic = wave_sum(ic);
+        if (lane == 0) {
+            cnts[h] = ic;
+            mods[4 * h] = nx; mods[4 * h + 1] = ny; mods[4 * h + 2] = nz; mods[4 * h + 3] = d;
+            if (a.counts) a.counts[(int64_t)f * H + h] = ic;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double goal = (double)M * a.goal_fraction;                  // estimate_road_norm.py:68
+        int best = -1, best_ic = 0, used = 0;
+        for (int h = 0; h < H; ++h) {                                     // ransac.py:9-22
+            used = h + 1;
+            if (cnts[h] > best_ic) {
+                best_ic = cnts[h]; best = h;
+                if ((double)best_ic > goal) break;
+            }
+        }
+        a.best_ic[f] = best_ic; a.used[f] = used;
+        double m[4] = {nan(""), nan(""), nan(""), nan("")};
+        if (best >= 0) {
+            const double sgn = (mods[4 * best + 1] < 0.0) ? -1.0 : 1.0;   // rescale.py:159-161
+            for (int k = 0; k < 4; ++k) m[k] = sgn * mods[4 * best + k];
+        }
+        for (int k = 0; k < 4; ++k) a.model[4 * f + k] = m[k];
+    }
+}
+
+static int g_rs_max_lds = 160 * 1024;
+
+template <typename K>
+static int rs_prepare(K kernel, size_t lds) {
+    if ((int64_t)lds > (int64_t)g_rs_max_lds) return set_error(MVOSR_ERR_TOO_LARGE, "frame needs %zu B of LDS (> %d) in the rescale-variant kernels", lds, g_rs_max_lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_hip_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
+    return MVOSR_OK;
+}
+
+}  // namespace mvosr
+
+using namespace mvosr;
+
+extern "C" {
+
+int mvosr_graph_inliers_batch(mvosr_ctx *ctx, const mvosr_batch *b, uint32_t good_bits, int32_t *total, int32_t *good,
+                              int32_t *status) {
+    if (!ctx || !b || !total || !good) return set_error(MVOSR_ERR_ARG, "graph_inliers: null argument");
+    if (!b->feat_off || !b->feat_cnt || !b->z || !b->v || !b->tri1_off || !b->tri1) return set_error(MVOSR_ERR_ARG, "graph_inliers: missing z/v/tri1");
+    if (b->n_frames <= 0) return MVOSR_OK;
+    int rc = ctx_activate(ctx);
+    if (rc) return rc;
+    g_rs_max_lds = ctx->max_lds_per_block;
+    GraphArgs a;
+    a.n_frames = b->n_frames; a.feat_off = b->feat_off; a.feat_cnt = b->feat_cnt; a.z = b->z; a.v = b->v;
+    a.tri_off = b->tri1_off; a.tri = b->tri1; a.good_bits = good_bits; a.total = total; a.good = good; a.status = status;
+    const size_t lds = 16u * (size_t)((b->max_feat + 1) & ~1) + 4u * ((size_t)b->max_feat + 4) + 16;
+    if ((rc = rs_prepare(graph_inliers_kernel, lds))) return rc;
+    hipLaunchKernelGGL(graph_inliers_kernel, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
+    return check_launch("graph_inliers_kernel");
+}
+
+int mvosr_flat_selection_batch(mvosr_ctx *ctx, const mvosr_batch *b, double loose_deg, double tight_deg, double height_factor,
+                               double *tri_height, uint8_t *tri_flags, double *height_level, int32_t *n_kept, int32_t *status,
+                               int64_t max_tri) {
+    if (!ctx || !b || !tri_height || !tri_flags || !height_level || !n_kept || !status) return set_error(MVOSR_ERR_ARG, "flat_selection: null argument");
+    if (!b->feat_off || !b->feat_cnt || !b->x || !b->y || !b->z || !b->tri2_off || !b->tri2) return set_error(MVOSR_ERR_ARG, "flat_selection: missing x/y/z/tri2");
+    if (b->n_frames <= 0) return MVOSR_OK;
+    int rc = ctx_activate(ctx);
+    if (rc) return rc;
+    g_rs_max_lds = ctx->max_lds_per_block;
+    FlatArgs a;
+    a.n_frames = b->n_frames; a.feat_off = b->feat_off; a.feat_cnt = b->feat_cnt; a.x = b->x; a.y = b->y; a.z = b->z;
+    a.tri_off = b->tri2_off; a.tri = b->tri2; a.loose_deg = loose_deg; a.tight_deg = tight_deg; a.height_factor = height_factor;
+    a.tri_height = tri_height; a.tri_flags = tri_flags; a.height_level = height_level; a.status = status; a.n_kept = n_kept;
+    if (max_tri <= 0) max_tri = 2 * (int64_t)b->max_feat;
+    const size_t lds = 24u * (size_t)((b->max_feat + 1) & ~1) + 8u * (size_t)max_tri + 64;
+    if ((rc = rs_prepare(flat_selection_kernel, lds))) return rc;
+    hipLaunchKernelGGL(flat_selection_kernel, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
+    return check_launch("flat_selection_kernel");
+}
+
+int mvosr_ransac_plane_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                             const double *px, const double *py, const double *pz, const int32_t *triples, int n_hyp,
+                             double threshold, double goal_fraction, int32_t *counts, double *model, int32_t *best_ic,
+                             int32_t *used) {
+    if (!ctx || !pts_off || !pts_cnt || !px || !py || !pz || !triples || !model || !best_ic || !used)
+        return set_error(MVOSR_ERR_ARG, "ransac_plane: null argument");
+    if (n_hyp < 1 || n_hyp > kMaxHyp) return set_error(MVOSR_ERR_ARG, "ransac_plane: n_hyp must be in 1..%d", kMaxHyp);
+    if (n_frames <= 0) return MVOSR_OK;
+    int rc = ctx_activate(ctx);
+    if (rc) return rc;
+    RansacArgs a;
+    a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.px = px; a.py = py; a.pz = pz; a.triples = triples;
+    a.n_hyp = n_hyp; a.threshold = threshold; a.goal_fraction = goal_fraction; a.counts = counts; a.model = model;
+    a.best_ic = best_ic; a.used = used;
+    const size_t lds = 4u * (size_t)((n_hyp + 3) & ~3) + 32u * (size_t)n_hyp + 16;
+    hipLaunchKernelGGL(ransac_plane_kernel, dim3((unsigned)n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
+    return check_launch("ransac_plane_kernel");
+}
+
+}  // extern "C"

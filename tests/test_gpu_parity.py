@@ -446,3 +446,53 @@ def test_rccl_gather_and_gpu_median_world1(gpu, tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733")
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "world1 ok" in p.stdout, p.stdout + p.stderr
+
+
+# ---------------------------------------------------------------- the `rescale` variant (f2/f4)
+def _ransac_triples(seed, call, n, h=100):
+    rng = np.random.default_rng([seed, call])
+    return np.stack([rng.choice(n, 3, replace=False) for _ in range(h)]).astype(np.int32)
+
+
+def test_rescale_variant_golden(gpu):
+    """mvoscalerecovery_amd.rescale.ScaleEstimator against the reference's rescale.ScaleEstimator run
+    with the same RANSAC sample triples (tests/golden/rescale.npz): vote masks, kept-triangle vertex
+    lists, inlier counts exact; continuous values (heights from an LU solve vs LAPACK's inverse, the
+    plane from a cross product vs an SVD null vector) within 1e-9 relative; north-star bound 1e-4."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    z, meta = load_npz("rescale.npz")
+    call = {"k": -1}
+
+    def sampler(n):
+        call["k"] += 1
+        return _ransac_triples(meta["ransac_seed"], call["k"], n)
+    est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], sampler=sampler)
+    for i, fr in enumerate(meta["frames"]):
+        f3, f2 = synth.synth_frame(fr["frame_idx"], fr["n"], base_seed=fr["seed"], upper_fraction=fr["upper_fraction"])
+        s, sd = est.scale_calculation(f3, f2)
+        assert np.array_equal(est.last["valid"][0], z["f%d_valid" % i]), i
+        pf2, fl = est.last["pf2"], est.last["tri_flags"]
+        ids = est.last["tris2"][0][(fl[:int(pf2.tri2_off[1])] & 4) != 0].reshape(-1)
+        assert np.array_equal(ids, z["f%d_ids" % i]), i
+        np.testing.assert_allclose(est.height_level, float(z["f%d_height_level" % i]), rtol=1e-9)
+        if "f%d_model" % i in z.files:
+            m_ref = z["f%d_model" % i]
+            m_ref = m_ref if m_ref[1] >= 0 else -m_ref
+            np.testing.assert_allclose(est.last["model"][0], m_ref, rtol=1e-8, atol=1e-12)
+            assert int(est.last["best_ic"][0]) == int(z["f%d_best_ic" % i]), i
+            assert int(est.last["used"][0]) == int(z["f%d_used" % i]), i
+        assert sd == 1
+        assert abs(s - float(z["f%d_scale" % i])) <= 1e-9 * abs(float(z["f%d_scale" % i])), (i, s)
+
+
+def test_rescale_variant_batch_equals_per_frame(gpu):
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    frames = [synth.synth_frame(i, 500 + 40 * i, base_seed=1357, upper_fraction=0.1) for i in range(8)]
+    a = ScaleEstimator(1.75, window_size=5, ransac_seed=11)
+    b = ScaleEstimator(1.75, window_size=5, ransac_seed=11)
+    seq = [a.scale_calculation(f3, f2)[0] for f3, f2 in frames]
+    bat, _ = b.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames])
+    assert seq == list(bat)
+    assert list(a.scale_queue) == list(b.scale_queue)
