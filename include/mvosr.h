@@ -260,6 +260,22 @@ int mvosr_ransac_plane_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pt
                              double threshold, double goal_fraction, int32_t *counts, double *model, int32_t *best_ic,
                              int32_t *used);
 
+/*
+ * The legacy per-triangle batch of /root/reference/src/triangle_batch.py:14-68: features are
+ * [u, v, depth] (b->x = u, b->v = v, b->z = depth; b->tri1 = Delaunay over (u,v), :23-25).  Per
+ * triangle: back-projection with (focus, cx, cy) (:32-33), n = A^-1.1 (:36-37), s = n_y/|n| (:43),
+ * h = mean y (:40); keep s > s_min (0.98) and h > 0 (:54-55); mean/std (:57-58); drop values outside
+ * mean +- n_sigma (3) std (:60-61); height[f] = mean of the rest (:62).  counts [F][2] = kept / kept
+ * after the clip; status [F] = 0, MVOSR_ST_ERR_SINGULAR, _MASK or _EMPTY.
+ */
+int mvosr_triangle_batch(mvosr_ctx *ctx, const mvosr_batch *b, double focus, double cx, double cy, double s_min,
+                         double n_sigma, double *height, int32_t *counts, int32_t *status);
+
+/* get_inliers, /root/reference/src/estimate_road_norm.py:71-78: mask[i] = |n.p_i + d| < threshold for a
+ * plane model4 = (n, d) given on the HOST; px/py/pz/mask are device arrays of n elements. */
+int mvosr_plane_inliers(mvosr_ctx *ctx, int64_t n, const double *px, const double *py, const double *pz, const double *model4,
+                        double threshold, uint8_t *mask);
+
 /* LDS bytes the fused kernel requests for a frame of n features (host-side planning). */
 size_t mvosr_lds_bytes(int n_features);
 /* Largest frame the LDS-resident variant accepts on this build. */

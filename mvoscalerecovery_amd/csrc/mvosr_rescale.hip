@@ -245,6 +245,89 @@ __global__ __launch_bounds__(kRsBlock) void ransac_plane_kernel(const RansacArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Legacy per-triangle batch, /root/reference/src/triangle_batch.py:14-68: features
+// are [u, v, depth]; every Delaunay triangle is back-projected (:32-33), n = A^-1 . 1 (:36-37),
+// s = n_y/|n| (:43), h = mean y (:40); triangles with s > 0.98 and h > 0 (:54-55) give mean and std
+// (:57-58), values outside mean +- 3 std are clipped (:60-61) and the mean of the rest is the camera
+// height (:62).  Three sweeps over the triangles (sum / squared deviations / clipped sum), each
+// thread visiting its triangles in a fixed order, so the result is run-to-run identical.
+// ---------------------------------------------------------------------------------------------
+struct TriBatchArgs {
+    int64_t n_frames;
+    const int64_t *feat_off; const int32_t *feat_cnt;
+    const double *u, *v, *depth;
+    const int64_t *tri_off; const int32_t *tri;
+    double focus, cx, cy, s_min, n_sigma;
+    double *height;                // [F]
+    int32_t *counts;               // [F][2]: kept, kept after the clip
+    int32_t *status;               // [F]
+};
+
+__global__ __launch_bounds__(kRsBlock) void triangle_batch_kernel(const TriBatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t f = blockIdx.x;
+    const int n = a.feat_cnt[f];
+    const int64_t off = a.feat_off[f];
+    const int64_t tb = a.tri_off[f];
+    const int tn = (int)(a.tri_off[f + 1] - tb);
+    const int tid = threadIdx.x;
+    if (n <= 0 || tn <= 0) {
+        if (tid == 0) { a.status[f] = MVOSR_ST_ERR_EMPTY; a.height[f] = nan(""); a.counts[2 * f] = a.counts[2 * f + 1] = 0; }
+        return;
+    }
+    const uint32_t npad = (uint32_t)((n + 1) & ~1);
+    double *X = reinterpret_cast<double *>(smem);
+    double *Y = X + npad;
+    double *Z = Y + npad;
+    double *red = Z + npad;                                     // 3 slots x 2*kRsWaves doubles
+    int *flag = reinterpret_cast<int *>(red + 3 * 2 * kRsWaves);
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+    for (int i = tid; i < n; i += kRsBlock) {
+        const double d = a.depth[off + i];
+        X[i] = d * (a.u[off + i] - a.cx) / a.focus;                                  // :32
+        Y[i] = d * (a.v[off + i] - a.cy) / a.focus;                                  // :33
+        Z[i] = d;
+    }
+    __syncthreads();
+    // height of triangle t if it is kept, NaN otherwise
+    auto kept_height = [&](int t) -> double {
+        const TriIds q = load_tri(a.tri, tb + t);
+        if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { flag[1] = 1; return nan(""); }
+        double nx, ny, nz;
+        if (!plane_normal(X[q.a], Y[q.a], Z[q.a], X[q.b], Y[q.b], Z[q.b], X[q.c], Y[q.c], Z[q.c], nx, ny, nz)) flag[0] = 1;   // :36
+        const double s = ny / sqrt((nx * nx + ny * ny) + nz * nz);                   // :38-39,:43
+        const double h = div3((Y[q.a] + Y[q.b]) + Y[q.c]);                           // :40
+        return (s > a.s_min && h > 0.0) ? h : nan("");                               // :54-55
+    };
+    double sum = 0.0, cnt = 0.0;
+    for (int t = tid; t < tn; t += kRsBlock) { const double h = kept_height(t); if (h == h) { sum += h; cnt += 1.0; } }
+    block_sum2<kRsWaves>(sum, cnt, red);
+    const double mean = sum / cnt;                                                   // :57
+    double ss = 0.0, dummy = 0.0;
+    for (int t = tid; t < tn; t += kRsBlock) { const double h = kept_height(t); if (h == h) { const double d = h - mean; ss += d * d; } }
+    block_sum2<kRsWaves>(ss, dummy, red + 2 * kRsWaves);
+    const double sd = sqrt(ss / cnt);                                                // :58
+    const double lo = mean - a.n_sigma * sd, hi = mean + a.n_sigma * sd;             // :60-61
+    double sum2 = 0.0, cnt2 = 0.0;
+    for (int t = tid; t < tn; t += kRsBlock) { const double h = kept_height(t); if (h == h && h > lo && h < hi) { sum2 += h; cnt2 += 1.0; } }
+    block_sum2<kRsWaves>(sum2, cnt2, red + 4 * kRsWaves);
+    __syncthreads();
+    if (tid == 0) {
+        a.height[f] = sum2 / cnt2;                                                   // :62
+        a.counts[2 * f] = (int)cnt; a.counts[2 * f + 1] = (int)cnt2;
+        a.status[f] = flag[1] ? MVOSR_ST_ERR_MASK : (flag[0] ? MVOSR_ST_ERR_SINGULAR : 0);
+    }
+}
+
+// get_inliers, /root/reference/src/estimate_road_norm.py:71-78: |n.p + d| < threshold per point
+__global__ __launch_bounds__(256) void plane_inliers_kernel(int64_t n, const double *px, const double *py, const double *pz,
+                                                            double m0, double m1, double m2, double m3, double threshold,
+                                                            uint8_t *mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mask[i] = fabs(((px[i] * m0 + py[i] * m1) + pz[i] * m2) + m3) < threshold;
+}
+
 static int g_rs_max_lds = 160 * 1024;
 
 template <typename K>
@@ -315,6 +398,36 @@ int mvosr_ransac_plane_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pt
     const size_t lds = 4u * (size_t)((n_hyp + 3) & ~3) + 32u * (size_t)n_hyp + 16;
     hipLaunchKernelGGL(ransac_plane_kernel, dim3((unsigned)n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
     return check_launch("ransac_plane_kernel");
+}
+
+int mvosr_triangle_batch(mvosr_ctx *ctx, const mvosr_batch *b, double focus, double cx, double cy, double s_min,
+                         double n_sigma, double *height, int32_t *counts, int32_t *status) {
+    if (!ctx || !b || !height || !counts || !status) return set_error(MVOSR_ERR_ARG, "triangle_batch: null argument");
+    if (!b->feat_off || !b->feat_cnt || !b->x || !b->v || !b->z || !b->tri1_off || !b->tri1)
+        return set_error(MVOSR_ERR_ARG, "triangle_batch: missing u (x) / v / depth (z) / tri1");
+    if (b->n_frames <= 0) return MVOSR_OK;
+    int rc = ctx_activate(ctx);
+    if (rc) return rc;
+    g_rs_max_lds = ctx->max_lds_per_block;
+    TriBatchArgs a;
+    a.n_frames = b->n_frames; a.feat_off = b->feat_off; a.feat_cnt = b->feat_cnt; a.u = b->x; a.v = b->v; a.depth = b->z;
+    a.tri_off = b->tri1_off; a.tri = b->tri1; a.focus = focus; a.cx = cx; a.cy = cy; a.s_min = s_min; a.n_sigma = n_sigma;
+    a.height = height; a.counts = counts; a.status = status;
+    const size_t lds = 24u * (size_t)((b->max_feat + 1) & ~1) + 8u * 3 * 2 * kRsWaves + 32;
+    if ((rc = rs_prepare(triangle_batch_kernel, lds))) return rc;
+    hipLaunchKernelGGL(triangle_batch_kernel, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
+    return check_launch("triangle_batch_kernel");
+}
+
+int mvosr_plane_inliers(mvosr_ctx *ctx, int64_t n, const double *px, const double *py, const double *pz, const double *model4,
+                        double threshold, uint8_t *mask) {
+    if (!ctx || !model4 || (n > 0 && (!px || !py || !pz || !mask))) return set_error(MVOSR_ERR_ARG, "plane_inliers: null argument");
+    if (n <= 0) return MVOSR_OK;
+    int rc = ctx_activate(ctx);
+    if (rc) return rc;
+    hipLaunchKernelGGL(plane_inliers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx_stream(ctx), n, px, py, pz,
+                       model4[0], model4[1], model4[2], model4[3], threshold, mask);
+    return check_launch("plane_inliers_kernel");
 }
 
 }  // extern "C"

@@ -496,3 +496,40 @@ def test_rescale_variant_batch_equals_per_frame(gpu):
     bat, _ = b.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames])
     assert seq == list(bat)
     assert list(a.scale_queue) == list(b.scale_queue)
+
+
+def test_triangle_batch_golden(gpu):
+    """Row a12: the legacy per-triangle batch vs what /root/reference/src/triangle_batch.py printed."""
+    from mvoscalerecovery_amd import synth, triangle_batch
+    from oracle import triangle_batch_oracle as tbo
+    g = load_json("triangle_batch.json")
+    pts = []
+    for fr in g["frames"]:
+        f3, f2 = synth.synth_frame(fr["frame_idx"], fr["n"], base_seed=fr["seed"])
+        pts.append(np.stack([f2[:, 0], f2[:, 1], f3[:, 2]], axis=1))
+    h, counts, status = triangle_batch.camera_heights(pts)
+    assert np.all(status == 0)
+    # same kept sets (integer counts exact); the means are sums in a different order than NumPy's
+    for i, p in enumerate(pts):
+        want, n_kept, n_clip = tbo.camera_height(p)
+        assert (counts[i, 0], counts[i, 1]) == (n_kept, n_clip), i
+        assert want == g["heights"][i]
+    np.testing.assert_allclose(h, g["heights"], rtol=1e-13)
+
+
+def test_road_norm_helpers(gpu):
+    """Row a11: get_pitch_ransac / get_inliers on the GPU vs the oracle's restatement."""
+    from mvoscalerecovery_amd import estimate_road_norm as ern
+    from oracle import rescale_oracle as ro
+    rng = np.random.default_rng(4)
+    pts = np.stack([rng.uniform(-5, 5, 800), 0.8 + 0.02 * rng.uniform(-5, 5, 800) + rng.normal(0, 0.002, 800),
+                    rng.uniform(4, 40, 800)], axis=1)
+    pts[::9, 1] += rng.uniform(0.05, 0.5, pts[::9].shape[0])
+    triples = np.stack([rng.choice(800, 3, replace=False) for _ in range(30)]).astype(np.int32)
+    m, ic = ern.get_pitch_ransac(pts, 30, 0.005, triples=triples)
+    m_ref, ic_ref, used = ro.run_ransac(pts, triples, 0.005)
+    m_ref = m_ref if m_ref[1] >= 0 else -m_ref
+    assert ic == ic_ref
+    np.testing.assert_allclose(m, m_ref, rtol=1e-9, atol=1e-13)
+    mask = ern.get_inliers(m_ref, pts, 0.01)
+    assert np.array_equal(mask, np.abs(pts @ m_ref[:3] + m_ref[3]) < 0.01)
