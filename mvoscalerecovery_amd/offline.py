@@ -102,6 +102,15 @@ def run_sequence_batched(data, estimator, minimum_feature_for_scale=MINIMUM_FEAT
             "pitchs": np.array(pitchs, dtype=np.float64), "kinds": kinds}
 
 
+def save_outputs(res_addr, tag, scales, motions):
+    """/root/reference/src/main_offline.py:90-93: ``<res_addr>scales.txt<tag>`` and ``<res_addr>path.txt<tag>``
+    (the integrated trajectory, one 3x4 pose per line).  Returns the poses."""
+    np.savetxt(res_addr + 'scales.txt' + tag, scales)
+    poses = get_path(np.array(motions, dtype=np.float64), np.asarray(scales, dtype=np.float64))
+    np.savetxt(res_addr + 'path.txt' + tag, poses)
+    return poses
+
+
 # ---- pose integration (SURVEY.md §8 f3) -----------------------------------------------------
 def motion2pose(motions):
     """/root/reference/src/main_offline.py:100-111 (= script/transformation.py:10-21): chain the
