@@ -533,3 +533,69 @@ def test_road_norm_helpers(gpu):
     np.testing.assert_allclose(m, m_ref, rtol=1e-9, atol=1e-13)
     mask = ern.get_inliers(m_ref, pts, 0.01)
     assert np.array_equal(mask, np.abs(pts @ m_ref[:3] + m_ref[3]) < 0.01)
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE configs[1])
+def test_full_size_properties(gpu):
+    """16 384 frames x 2000 features (the bench workload): results cannot be compared frame by frame
+    with the CPU oracle in seconds, so size-independent properties are checked instead:
+    (1) every tiled copy of a pool frame gives bit-identical outputs (a checksum of checksums);
+    (2) the pool frames themselves equal the oracle; (3) permuting the ROWS of both triangulations
+    changes nothing (SURVEY fact 4); (4) reversing the frame order reverses the outputs;
+    (5) two launches are bit-identical; (6) the window median of the 16 384 raw scales equals the
+    oracle's sliding median."""
+    import zlib
+    from mvoscalerecovery_amd import packing, synth
+    from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs, ScaleEngine
+    so = _oracle()
+    pool, repeats = 32, 512
+    frames = [synth.synth_frame(i, 2000, base_seed=2024) for i in range(pool)]
+    ores = _oracle_frames(frames)
+    eng = ScaleEngine(1.75, ctx=gpu)
+
+    def run(pf):
+        db = DeviceBatch(gpu, pf)
+        out = DeviceOutputs(gpu, db, counts=True)
+        eng.scale_batch(db, out)
+        gpu.sync()
+        r = {k: out.get(k) for k in ("raw_scale", "height", "height_level", "status", "counts")}
+        out.free()
+        db.free()
+        return r
+
+    pf_pool = _pack(frames, [r.tri1 for r in ores], [r.tri2 for r in ores], [r.valid for r in ores])
+    pf = packing.tile_frames(pf_pool, repeats)
+    assert pf.n_frames == 16384
+    res = run(pf)
+    # (2) pool == oracle
+    for f in range(pool):
+        assert res["status"][f] == ores[f].status and res["raw_scale"][f] == ores[f].raw_scale, f
+    # (1) checksum of checksums over the copies
+    def crc(r, sl):
+        c = 0
+        for k in ("raw_scale", "height", "height_level", "status", "counts"):
+            c = zlib.crc32(np.ascontiguousarray(r[k][sl]).tobytes(), c)
+        return c
+    sums = {crc(res, slice(r * pool, (r + 1) * pool)) for r in range(repeats)}
+    assert len(sums) == 1
+    # (5) determinism
+    res_b = run(pf)
+    assert crc(res, slice(None)) == crc(res_b, slice(None))
+    # (3) triangle rows permuted (vertex order inside rows untouched)
+    rng = np.random.default_rng(0)
+    t1 = [r.tri1[rng.permutation(len(r.tri1))] for r in ores]
+    t2 = [r.tri2[rng.permutation(len(r.tri2))] for r in ores]
+    pf_perm = packing.tile_frames(_pack(frames, t1, t2, [r.valid for r in ores]), repeats)
+    res_p = run(pf_perm)
+    for k in ("raw_scale", "height", "status", "counts"):
+        assert np.array_equal(res[k], res_p[k], equal_nan=True), k
+    np.testing.assert_allclose(res_p["height_level"], res["height_level"], rtol=1e-13)     # a sum in another order
+    # (4) frame order reversed
+    rev = list(range(pool))[::-1]
+    pf_rev = _pack([frames[i] for i in rev], [ores[i].tri1 for i in rev], [ores[i].tri2 for i in rev], [ores[i].valid for i in rev])
+    res_r = run(pf_rev)
+    for k in ("raw_scale", "height", "height_level", "status"):
+        assert np.array_equal(res_r[k], res[k][:pool][::-1], equal_nan=True), k
+    # (6) window median over the whole sequence
+    want, _ = so.window_median(res["raw_scale"], 5)
+    assert np.array_equal(eng.window_median_host(res["raw_scale"], 5), want)
