@@ -34,13 +34,38 @@ def _delaunay_job(points2d):
         return exc
 
 
-def delaunay_many(point_sets, workers=0):
-    """Triangulate many point sets, optionally on a process pool (Qhull is ~8 ms per 2000
-    points; this is the host stage that bounds end-to-end throughput — SURVEY.md §7 hard part 1)."""
-    if workers and workers > 1 and len(point_sets) > 1:
+_pool = None
+_pool_size = 0
+
+
+def _get_pool(workers):
+    """A process pool kept alive between calls (forking hundreds of workers per call costs more
+    than the triangulations themselves)."""
+    global _pool, _pool_size
+    if _pool is None or _pool_size != workers:
+        if _pool is not None:
+            _pool.terminate()
         import multiprocessing as mp
-        with mp.get_context("fork").Pool(workers) as pool:
-            return pool.map(_delaunay_job, point_sets, chunksize=max(1, len(point_sets) // (workers * 8)))
+        _pool = mp.get_context("fork").Pool(workers)
+        _pool_size = workers
+    return _pool
+
+
+def shutdown_pool():
+    global _pool, _pool_size
+    if _pool is not None:
+        _pool.terminate()
+        _pool, _pool_size = None, 0
+
+
+def delaunay_many(point_sets, workers=0):
+    """Triangulate many point sets, optionally on a process pool (Qhull is a few ms per 2000
+    points; this is the host stage that bounds end-to-end throughput — SURVEY.md §7 hard part 1)."""
+    n = len(point_sets)
+    if workers and workers > 1 and n > 1:
+        workers = max(2, min(int(workers), (n + 3) // 4))          # at least ~4 frames per process
+        pool = _get_pool(workers)
+        return pool.map(_delaunay_job, point_sets, chunksize=max(1, n // (workers * 4)))
     return [_delaunay_job(p) for p in point_sets]
 
 
