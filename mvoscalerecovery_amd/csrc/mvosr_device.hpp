@@ -21,7 +21,9 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 // one row of scipy's `simplices`: three int32 vertex ids, loaded with one global_load_dwordx3
 struct TriIds { int a, b, c; };
-__device__ __forceinline__ TriIds load_tri(const int32_t *tri, int64_t t) {
+// `tri` is the FRAME's first row (a wave-uniform base) and `t` a 32-bit row index, so that the load
+// takes the scalar-base + 32-bit-offset addressing form instead of 64-bit VGPR arithmetic.
+__device__ __forceinline__ TriIds load_tri(const int32_t *tri, int t) {
     const int32_t *p = tri + 3 * t;
     TriIds r;
     r.a = p[0]; r.b = p[1]; r.c = p[2];

@@ -119,7 +119,7 @@ struct TriChunk {
 #pragma unroll
         for (int k = 0; k < kTC; ++k) {
             const int t = base + k * B + tid;
-            if (t < count) q[k] = load_tri(tri, begin + t);
+            if (t < count) q[k] = load_tri(tri + 3 * begin, t);
         }
     }
 };
@@ -887,7 +887,7 @@ __device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n,
     __threadfence_block();
     __syncthreads();
     for (int t = tid; t < t1_count; t += B) {
-        const TriIds q = load_tri(tri1, t1_begin + t);
+        const TriIds q = load_tri(tri1 + 3 * t1_begin, t);
         if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
         const double2 p0 = P[q.a], p1 = P[q.b], p2 = P[q.c];              // {v, z'} through L1/L2
         const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110

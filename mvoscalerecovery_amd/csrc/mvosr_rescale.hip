@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kRsBlock) void graph_inliers_kernel(const GraphArgs
     __syncthreads();
     int bad = 0;
     for (int t = tid; t < tn; t += kRsBlock) {
-        const TriIds q = load_tri(a.tri, tb + t);
+        const TriIds q = load_tri(a.tri + 3 * tb, t);
         if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
         const double2 p0 = P[q.a], p1 = P[q.b], p2 = P[q.c];
         const int ca = (p0.x - p1.x) * (p0.y - p1.y) < 0.0;              // graph.py:125
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
     for (int i = tid; i < n; i += kRsBlock) { X[i] = a.x[off + i]; Y[i] = a.y[off + i]; Z[i] = a.z[off + i]; }
     __syncthreads();
     for (int t = tid; t < tn; t += kRsBlock) {
-        const TriIds q = load_tri(a.tri, tb + t);
+        const TriIds q = load_tri(a.tri + 3 * tb, t);
         if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) {
             misc[2] = 1; a.tri_flags[tb + t] = 0; a.tri_height[tb + t] = nan(""); continue;
         }
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kRsBlock) void triangle_batch_kernel(const TriBatch
     __syncthreads();
     // height of triangle t if it is kept, NaN otherwise
     auto kept_height = [&](int t) -> double {
-        const TriIds q = load_tri(a.tri, tb + t);
+        const TriIds q = load_tri(a.tri + 3 * tb, t);
         if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { flag[1] = 1; return nan(""); }
         double nx, ny, nz;
         if (!plane_normal(X[q.a], Y[q.a], Z[q.a], X[q.b], Y[q.b], Z[q.b], X[q.c], Y[q.c], Z[q.c], nx, ny, nz)) flag[0] = 1;   // :36
