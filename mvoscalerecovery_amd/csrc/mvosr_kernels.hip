@@ -465,10 +465,7 @@ __device__ __forceinline__ bool dropped_by_single(double y, int bin, const Bits1
     return d;
 }
 
-#ifndef MVOSR_ROAD_RC
-#define MVOSR_ROAD_RC 16
-#endif
-constexpr int kRoadRC = MVOSR_ROAD_RC;   // values per lane kept in registers (lists up to 64*RC values; longer ones re-read)
+constexpr int kRoadRC = 16;   // values per lane kept in registers (lists up to 64*RC values; longer ones re-read)
 constexpr int kRoadWaves = 4;          // frames (wavefronts) per workgroup
 constexpr int kTrash = 175;            // histogram slot for values that are not binned (bins are 0..168)
 constexpr int kStPending = -1;         // scale kernel -> road kernel: "road model still to run"
@@ -495,7 +492,8 @@ __device__ __forceinline__ int bin_of_table(double y, const double2 *edges) {
     return k;
 }
 
-__device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, const double2 *edges, const double *yv, double *scratch,
+__device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16_t *slots, uint8_t *dropb, const double2 *edges,
+                                                const double *yv, double *scratch,
                                                 int M, double height_level, const mvosr_params &P, int32_t *g_hist MVOSR_STAMP_ARG) {
     const int lane = lane_id();
     RoadResult R;
@@ -569,14 +567,33 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, const 
     // second pass: drop the points inside a single bin's interval (:284-293), accumulate the mean.
     // Only values whose own or neighbouring bin has count 1 can be dropped: they are flagged here
     // (one LDS read each) and examined in a rolled loop below, which most iterations skip.
-    unsigned kept = valid, susp = 0u;
-#pragma unroll
-    for (int k = 0; k < kRoadRC; ++k) susp |= (nearflag[binc[k]] ? 1u : 0u) << k;         // nearflag[kTrash] == 0
-    if (__ballot(susp != 0u)) {
+    // The few suspects of the whole list are packed into one dense list (slot numbers, ballot prefix)
+    // and examined with full lanes — row by row almost every row would run the whole interval test
+    // for one or two lanes.  Verdicts return through a byte per slot, 16 contiguous bytes per lane.
+    unsigned kept = valid;
+    {
+        uint4 zero; zero.x = zero.y = zero.z = zero.w = 0u;
+        reinterpret_cast<uint4 *>(dropb)[lane] = zero;
+        int ns = 0;
 #pragma unroll
         for (int k = 0; k < kRoadRC; ++k) {
-            if (!__ballot((susp >> k) & 1u)) continue;                        // wave-uniform skip
-            if (((susp >> k) & 1u) && dropped_by_single(yc[k], binc[k], single, first_single)) kept &= ~(1u << k);
+            const bool sus = nearflag[binc[k]] != 0;                          // nearflag[kTrash] == 0
+            const unsigned long long m = __ballot(sus);
+            if (sus) slots[ns + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * kWave + lane);
+            ns += __popcll(m);
+        }
+        for (int i = lane; i < ns; i += kWave) {
+            const int e = slots[i];
+            const double y = yv[e];                                           // (a cache hit; avoids indexing the register array)
+            if (dropped_by_single(y, bin_of_table(y, edges), single, first_single)) dropb[(e & (kWave - 1)) * kRoadRC + (e >> 6)] = 1;
+        }
+        if (ns > 0) {
+            const uint4 d = reinterpret_cast<const uint4 *>(dropb)[lane];
+#pragma unroll
+            for (int k = 0; k < kRoadRC; ++k) {
+                const unsigned w = (k >> 2) == 0 ? d.x : ((k >> 2) == 1 ? d.y : ((k >> 2) == 2 ? d.z : d.w));
+                if ((w >> (8 * (k & 3))) & 0xFFu) kept &= ~(1u << k);
+            }
         }
     }
     double sum = 0.0;
@@ -699,8 +716,11 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, const 
 #define MVOSR_ROAD_MINW 1
 #endif
 __global__ __launch_bounds__(kRoadWaves *kWave, MVOSR_ROAD_MINW) void road_model_kernel(const RoadArgs a) {
+    static_assert(kRoadRC == 16, "the verdict bytes of a lane are read as one 16-byte word");
     __shared__ int hist_all[kRoadWaves][2][176];
     __shared__ double2 edges[kBins + 1];
+    __shared__ uint16_t slots_all[kRoadWaves][kRoadRC * kWave];
+    __shared__ __attribute__((aligned(16))) uint8_t drop_all[kRoadWaves][kRoadRC * kWave];
     for (int k = threadIdx.x; k < kBins; k += kRoadWaves * kWave) { double2 e; e.x = bin_edge(k); e.y = bin_edge(k + 1); edges[k] = e; }
     __syncthreads();
     const int64_t f = a.first_frame + (int64_t)blockIdx.x * kRoadWaves + wave_id();
@@ -712,7 +732,8 @@ __global__ __launch_bounds__(kRoadWaves *kWave, MVOSR_ROAD_MINW) void road_model
     const int64_t off = a.off[f];
     const double hl = a.height_level ? a.height_level[f] : nan("");
     MVOSR_RSTAMP(1);
-    const RoadResult R = road_wave(hist_all[wave_id()][0], hist_all[wave_id()][1], edges, a.y + off, a.scratch + off, M, hl, a.P,
+    const RoadResult R = road_wave(hist_all[wave_id()][0], hist_all[wave_id()][1], slots_all[wave_id()], drop_all[wave_id()], edges,
+                                   a.y + off, a.scratch + off, M, hl, a.P,
                                    a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
     MVOSR_RSTAMP(6);
 #ifdef MVOSR_STAMPS
