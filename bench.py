@@ -53,6 +53,9 @@ def build_pool(ctx, engine, n_features, pool, seed):
     t0 = time.perf_counter()
     packing.attach_tri1(pf)
     t_del1 = time.perf_counter() - t0
+    cap = int(ctx.lib.mvosr_max_lds_features())
+    if n_features > cap:            # dense frames: Z-order layout (what ScaleEstimator.scale_calculation_batch does)
+        packing.apply_locality_order(pf, min_features=cap + 1)
     db = DeviceBatch(ctx, pf, with_tri2=False)
     out = DeviceOutputs(ctx, db, counts=True, stage=True)
     engine.outlier_vote_batch(db, out)
@@ -73,12 +76,20 @@ def cpu_baseline(frames, pf, gpu_raw, gpu_status, budget_s=12.0):
     from oracle import scale_oracle as so
     done, t_used = 0, 0.0
     mismatches = 0
+    reordered = any(p is not None for p in (pf.extra.get("perm") or []))
+    tris = {}
     i = 0
     P = len(frames)
     while t_used < budget_s and done < 4 * P:
         f = i % P
-        tri1 = pf.tri1[pf.tri1_off[f]:pf.tri1_off[f + 1]]
-        tri2 = pf.tri2[pf.tri2_off[f]:pf.tri2_off[f + 1]]
+        if reordered:                      # dense frames were re-laid out for the GPU: the oracle triangulates itself (untimed)
+            if f not in tris:
+                r0 = so.frame_raw_scale(frames[f][0], frames[f][1], ABS_REF)
+                tris[f] = (r0.tri1, r0.tri2)
+            tri1, tri2 = tris[f]
+        else:
+            tri1 = pf.tri1[pf.tri1_off[f]:pf.tri1_off[f + 1]]
+            tri2 = pf.tri2[pf.tri2_off[f]:pf.tri2_off[f + 1]]
         t0 = time.perf_counter()
         r = so.frame_raw_scale(frames[f][0], frames[f][1], ABS_REF, tri1, tri2, keep=False)
         t_used += time.perf_counter() - t0

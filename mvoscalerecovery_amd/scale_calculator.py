@@ -134,6 +134,11 @@ class ScaleEstimator:
                 if isinstance(f3, np.ndarray) and f3.size:
                     self.feature_remap(f3)                                   # :414
         packing.attach_tri1(pf, tri1s, self.delaunay_workers)
+        cap = int(ctx.lib.mvosr_max_lds_features())
+        if pf.max_feat > cap:
+            # dense frames gather from global memory: lay them out along a Z-order curve (results are
+            # order-independent; vertex order inside triangle rows is untouched)
+            packing.apply_locality_order(pf, min_features=cap + 1)
         dbatch = DeviceBatch(ctx, pf, with_tri2=False)
         stage = _single or tri2s is None
         valid_masks = None
@@ -148,6 +153,8 @@ class ScaleEstimator:
                     print('feature rejected ', int(np.sum(~m)))
                     print('feature left     ', int(np.sum(m)))
             vote_out.free()
+        if tri2s is not None and valid_masks is None and any(p is not None for p in (pf.extra.get("perm") or [])):
+            raise ValueError("precomputed tri2s for dense (re-ordered) frames need the vote mask: pass tri1s only")
         packing.attach_tri2(pf, tri2s, valid_masks, self.delaunay_workers)
         dbatch.set_tri2(pf)
         out = DeviceOutputs(ctx, dbatch, counts=True, stage=stage)
@@ -206,7 +213,7 @@ class ScaleEstimator:
         valid = valid_masks[f]
         nvalid = int(np.count_nonzero(valid))
         picked = np.nonzero(sel[:nvalid])[0]                                   # np.unique order, :247
-        idx = pf.lower_index[f][np.nonzero(valid)[0][picked]]
+        idx = np.sort(pf.lower_index[f][np.nonzero(valid)[0][picked]])                # np.unique order (:247), whatever the packed order
         f3 = np.asarray(feature3ds[f], dtype=np.float64)
         if not self.mutate_inputs:
             f3 = f3.copy()

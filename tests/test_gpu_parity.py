@@ -599,3 +599,25 @@ def test_full_size_properties(gpu):
     # (6) window median over the whole sequence
     want, _ = so.window_median(res["raw_scale"], 5)
     assert np.array_equal(eng.window_median_host(res["raw_scale"], 5), want)
+
+
+def test_estimator_dense_frames_with_locality_layout(gpu):
+    """The drop-in class on frames that do not fit LDS: they are laid out along a Z-order curve for
+    the dense kernel; scales, flat_feature rows and their order must still equal the oracle's."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False)
+    ref = so.OracleScaleEstimator(1.75, window_size=5)
+    frames = [synth.synth_frame(i, n, base_seed=606, upper_fraction=0.1) for i, n in enumerate((7500, 900, 9000))]
+    for f3, f2 in frames:                       # per frame: sizes straddle the LDS capacity
+        s, sd = est.scale_calculation(f3, f2)
+        rs, rsd = ref.scale_calculation(f3, f2)
+        assert (s, sd) == (rs, rsd)
+        assert np.array_equal(est.flat_feature, ref.flat_feature)
+        assert np.array_equal(est.flat_feature_2d, ref.flat_feature_2d)
+    est2 = ScaleEstimator(1.75, window_size=5, mutate_inputs=False)
+    ref2 = so.OracleScaleEstimator(1.75, window_size=5)
+    bs, bd = est2.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames])      # mixed batch -> dense variant
+    want = [ref2.scale_calculation(f3, f2) for f3, f2 in frames]
+    assert list(bs) == [w[0] for w in want] and list(bd) == [w[1] for w in want]
