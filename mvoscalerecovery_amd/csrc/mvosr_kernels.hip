@@ -107,10 +107,7 @@ enum { M_WCNT = 0 /* [0..15] per-wave survivor counts */, M_LIST = 16, M_MEDLO =
 #define MVOSR_TC 2
 #endif
 constexpr int kTC = MVOSR_TC;   // triangles per thread per chunk (3 VGPRs each)
-#ifndef MVOSR_KEEP
-#define MVOSR_KEEP 1
-#endif
-constexpr int kKeep = MVOSR_KEEP;   // tri2 chunks whose ids stay in registers (16-bit packed) for the second sweep
+
 
 template <int B>
 struct TriChunk {
@@ -181,8 +178,11 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
     }
 
     // the vote: +1 on a vertex the triangle does not flag, -1 on one it flags (:160-163)
-    for (int base = 0; base < ((dbg & 1) ? 0 : t1_count); base += kTC * B) {
-        if (base > 0) tc.load(tri1, t1_begin, t1_count, base, tid);
+    const int t1c = (dbg & 1) ? 0 : t1_count;
+    TriChunk<B> tn;                                   // the next chunk streams in while this one is processed
+    for (int base = 0; base < t1c; base += kTC * B) {
+        const bool more = base + kTC * B < t1c;
+        if (more) tn.load(tri1, t1_begin, t1_count, base + kTC * B, tid);
 #pragma unroll
         for (int k = 0; k < kTC; ++k) {
             const int t = base + k * B + tid;
@@ -201,6 +201,7 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
             atomicAdd(&s.c32[q.b >> 1], f1 ? 0u - u1 : u1);
             atomicAdd(&s.c32[q.c >> 1], f2 ? 0u - u2 : u2);
         }
+        if (more) tc = tn;
     }
     if (tri2) next.load(tri2, t2_begin, t2_count, 0, tid);   // lands while the survivors are compacted
     __syncthreads();
@@ -353,40 +354,25 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     if (is_steep) { hsum += h; hcnt += 1.0; }                                            // :240
     if (is_flat) { flat |= 1ull << kk; ++npitch; }
     };
-    // `tc` arrives with the first chunk of tri2 already loaded (phase_vote).  The ids of the first
-    // kKeep chunks stay in registers for the second sweep, packed to 16 bits (1.5 VGPRs per
-    // triangle): re-reading tri2 costs a second pass over its 45 KB through the fabric otherwise.
+    // `tc` arrives with the first chunk of tri2 already loaded (phase_vote); the next chunk streams
+    // in while the current one is processed.
     const int t2c = (dbg & 2) ? 0 : t2_count;
-    uint32_t pab[kKeep * kTC], pcc[(kKeep * kTC + 1) / 2];
-#pragma unroll
-    for (int i = 0; i < (kKeep * kTC + 1) / 2; ++i) pcc[i] = 0u;
-#pragma unroll
-    for (int ch = 0; ch < kKeep; ++ch) {
-        const int base = ch * kTC * B;
-        if (base < t2c) {
-            if (ch > 0) tc.load(tri2, t2_begin, t2_count, base, tid);
-#pragma unroll
-            for (int k = 0; k < kTC; ++k) {
-                const int t = base + k * B + tid;
-                const int idx = ch * kTC + k;
-                pab[idx] = 0u;
-                if (t < t2c) {
-                    const TriIds q = tc.q[k];
-                    pab[idx] = ((uint32_t)q.a & 0xFFFFu) | ((uint32_t)q.b << 16);
-                    pcc[idx >> 1] |= ((uint32_t)q.c & 0xFFFFu) << (16 * (idx & 1));
-                    test_triangle(t, ch * kTC + k, q);
-                }
-            }
-        }
-    }
-    for (int base = kKeep * kTC * B; base < t2c; base += kTC * B) {       // frames with more than kKeep chunks
-        tc.load(tri2, t2_begin, t2_count, base, tid);
+    TriChunk<B> tn;
+    for (int base = 0; base < t2c; base += kTC * B) {
+        const bool more = base + kTC * B < t2c;
+        if (more) tn.load(tri2, t2_begin, t2_count, base + kTC * B, tid);
 #pragma unroll
         for (int k = 0; k < kTC; ++k) {
             const int t = base + k * B + tid;
             if (t < t2c) test_triangle(t, base / B + k, tc.q[k]);
         }
+        if (more) tc = tn;
     }
+    // second sweep: its first chunk is re-read now, under the reduction's barrier (unless the whole
+    // triangulation was one chunk and is still in registers)
+    const int t2d = (dbg & 4) ? 0 : t2_count;
+    const bool in_regs = t2_count <= kTC * B;
+    if (!in_regs && t2d > 0) tc.load(tri2, t2_begin, t2_count, 0, tid);
     block_sum2<WAVES>(hsum, hcnt, s.red + R_SEL_H * 2 * WAVES);
     MVOSR_STAMP(4);
     SelectResult r;
@@ -404,25 +390,14 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
             atomicOr(&s.sel[qc >> 5], 1u << (qc & 31));
         }
     };
-    const int t2d = (dbg & 4) ? 0 : t2_count;
-#pragma unroll
-    for (int ch = 0; ch < kKeep; ++ch) {
-        const int base = ch * kTC * B;
-        if (base < t2d) {
-#pragma unroll
-            for (int k = 0; k < kTC; ++k) {
-                const int idx = ch * kTC + k;
-                if (base + k * B + tid < t2d)
-                    mark_triangle(idx, (int)(pab[idx] & 0xFFFFu), (int)(pab[idx] >> 16), (int)((pcc[idx >> 1] >> (16 * (idx & 1))) & 0xFFFFu));
-            }
-        }
-    }
-    for (int base = kKeep * kTC * B; base < t2d; base += kTC * B) {
-        tc.load(tri2, t2_begin, t2_count, base, tid);
+    for (int base = 0; base < t2d; base += kTC * B) {
+        const bool more = base + kTC * B < t2d;
+        if (more) tn.load(tri2, t2_begin, t2_count, base + kTC * B, tid);
 #pragma unroll
         for (int k = 0; k < kTC; ++k) {
             if (base + k * B + tid < t2d) mark_triangle(base / B + k, tc.q[k].a, tc.q[k].b, tc.q[k].c);
         }
+        if (more) tc = tn;
     }
     bad |= bad_in;
     block_sum4i<WAVES>(npitch, ntv, singular, bad, s.red + R_SEL_CNT * 2 * WAVES);   // also orders the atomicOr's
