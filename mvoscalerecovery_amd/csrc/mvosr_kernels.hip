@@ -320,8 +320,8 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
         // det = p0 . c, so  pitch_deg < thr  <=>  n_y/|n| > sin(|thr|)  <=>  c_y det > 0 and
         // c_y^2 > sin^2(|thr|) |c|^2 : no division, square root or asin.  Only inside a 1e-9
         // band around the threshold (where the outcome depends on how the LU solve and asin
-        // round), for needle triangles and when det is lost to cancellation (possible exact
-        // singularity) is the reference's own formulation evaluated below.
+        // round), for collinear vertices (c = 0 fails both comparisons) and when det is lost to
+        // cancellation (possible exact singularity) is the reference's own formulation evaluated below.
         const double e1x = x1 - x0, e1y = y1 - y0, e1z = z1 - z0;
         const double e2x = x2 - x0, e2y = y2 - y0, e2z = z2 - z0;
         const double cx = __builtin_fma(e1y, e2z, -(e1z * e2y));
@@ -331,9 +331,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
         const double det = (tx + ty) + tz;
         const double mag = (fabs(tx) + fabs(ty)) + fabs(tz);
         const double c2 = __builtin_fma(cz, cz, __builtin_fma(cy, cy, cx * cx));
-        const double l1 = __builtin_fma(e1z, e1z, __builtin_fma(e1y, e1y, e1x * e1x));
-        const double l2 = __builtin_fma(e2z, e2z, __builtin_fma(e2y, e2y, e2x * e2x));
-        const bool safe = (fabs(det) > 1e-9 * mag) && (c2 > 1e-14 * (l1 * l2));
+        const bool safe = fabs(det) > 1e-9 * mag;
         const double q2 = cy * cy;
         const double sy = cy * det;
         if (safe && sy > 0.0 && q2 > pt.s2_hi * c2) { is_flat = true; decided = true; }
