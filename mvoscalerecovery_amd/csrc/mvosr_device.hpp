@@ -182,10 +182,11 @@ __device__ __forceinline__ int bin_of(double y) {
 __device__ __forceinline__ double div3(double x) {
     const double c = 0x1.5555555555555p-2;
     const double ax = fabs(x);
-    if (!(ax > 0x1p-900 && ax < 0x1p900)) return x / 3.0;
     const double q = x * c;
     const double r = __builtin_fma(-3.0, q, x);
-    return __builtin_fma(r, c, q);
+    double res = __builtin_fma(r, c, q);
+    if (!((ax > 0x1p-900) & (ax < 0x1p900))) res = x / 3.0;      // rare: one skipped region, no else-part
+    return res;
 }
 
 // Solve A n = (1,1,1)^T for the 3x3 matrix whose ROWS are the triangle's vertices — the plane

@@ -331,11 +331,13 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
         const double det = (tx + ty) + tz;
         const double mag = (fabs(tx) + fabs(ty)) + fabs(tz);
         const double c2 = __builtin_fma(cz, cz, __builtin_fma(cy, cy, cx * cx));
-        const bool safe = fabs(det) > 1e-9 * mag;
         const double q2 = cy * cy;
         const double sy = cy * det;
-        if (safe && sy > 0.0 && q2 > pt.s2_hi * c2) { is_flat = true; decided = true; }
-        else if (safe && (sy <= 0.0 || q2 < pt.s2_lo * c2)) { is_steep = true; decided = true; }
+        const bool safe = fabs(det) > 1e-9 * mag;
+        // (bitwise, not short-circuit: no control flow for five comparisons)
+        is_flat = safe & (sy > 0.0) & (q2 > pt.s2_hi * c2);
+        is_steep = safe & ((sy <= 0.0) | (q2 < pt.s2_lo * c2));       // exclusive with is_flat: s2_lo < s2_hi
+        decided = is_flat | is_steep;
     }
     if (!decided) {
         double nx, ny, nz, pitch;
