@@ -25,10 +25,15 @@ def shard_sizes(n_frames: int, world_size: int):
     return [partition(n_frames, world_size, r)[1] - partition(n_frames, world_size, r)[0] for r in range(world_size)]
 
 
+_bufs = {}
+
+
 def all_gather_frames(local_raw, local_status, n_frames, group=None):
     """All-gather the per-rank raw scales (float64) and statuses (int32) into the full-sequence
-    arrays, on whatever device the local tensors live on.  Shards are padded to the largest shard
-    so a single ``all_gather_into_tensor`` per array suffices; the padding is dropped afterwards.
+    arrays, on whatever device the local tensors live on.  ONE collective per step: scale and
+    status travel as the two columns of a float64 (cap, 2) record array (statuses are small ints,
+    exact in float64); shards are padded to the largest shard and the padding dropped afterwards.
+    Buffers are cached between steps.
 
     ``local_raw`` / ``local_status`` are torch tensors of this rank's block (partition order).
     Returns ``(raw[n_frames], status[n_frames])`` torch tensors.
@@ -39,20 +44,24 @@ def all_gather_frames(local_raw, local_status, n_frames, group=None):
     sizes = shard_sizes(n_frames, world)
     cap = max(sizes) if sizes else 0
     dev = local_raw.device
-    # one 12-byte record per frame would need a struct dtype; two flat gathers are as cheap
-    pad_raw = torch.full((cap,), float("nan"), dtype=torch.float64, device=dev)
-    pad_st = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+    key = (str(dev), cap, world)
+    if key not in _bufs:
+        _bufs[key] = (torch.empty((cap, 2), dtype=torch.float64, device=dev),
+                      torch.empty((world * cap, 2), dtype=torch.float64, device=dev))
+    send, recv = _bufs[key]
     n_local = local_raw.shape[0]
-    pad_raw[:n_local] = local_raw
-    pad_st[:n_local] = local_status
-    all_raw = torch.empty((world * cap,), dtype=torch.float64, device=dev)
-    all_st = torch.empty((world * cap,), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(all_raw, pad_raw, group=group)
-    dist.all_gather_into_tensor(all_st, pad_st, group=group)
+    send[:n_local, 0] = local_raw
+    send[:n_local, 1] = local_status
+    if n_local < cap:
+        send[n_local:, 0] = float("nan")
+        send[n_local:, 1] = -1
+    dist.all_gather_into_tensor(recv, send, group=group)
     if all(s == cap for s in sizes):
-        return all_raw, all_st
-    keep = torch.cat([torch.arange(r * cap, r * cap + s, device=dev) for r, s in enumerate(sizes)])
-    return all_raw[keep], all_st[keep]
+        rec = recv
+    else:
+        keep = torch.cat([torch.arange(r * cap, r * cap + s, device=dev) for r, s in enumerate(sizes)])
+        rec = recv[keep]
+    return rec[:, 0].contiguous(), rec[:, 1].to(torch.int32)
 
 
 def gather_and_filter(local_raw, local_status, n_frames, window, median_fn, queue=(), group=None):

@@ -43,7 +43,7 @@ def main():
                 road.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     med = {k: statistics.median(v) for k, v in counters.items()}
     road = {k: statistics.median(v) for k, v in road.items()}
-    F = a.frames
+    F = int(bench.get("config", {}).get("frames_per_step_per_gpu", a.frames))
     lines = ["# rocprofv3 summary %s — `python bench.py` (N=1, %d frames x %d features per launch)" % (a.tag, F, a.features), ""]
     lines += ["## kernel trace (`rocprofv3 --kernel-trace --stats`, 10 timed + 2 warm-up steps)", "",
               "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
