@@ -109,6 +109,100 @@ class ScaleEstimator:
         scales, stds = self.scale_calculation_batch([feature3d], [feature2d], _single=True)
         return scales[0], stds[0]
 
+    # ---- the reference's stage methods, for callers that drive the stages themselves ------------
+    # They take arrays that are ALREADY remapped (the reference calls feature_remap first, :414), so
+    # they run on an engine whose remap is the identity.
+    def _plain_engine(self):
+        if getattr(self, "_plain", None) is None:
+            self._plain = ScaleEngine(self.absolute_reference, ctx=self.engine.ctx, camera_pitch=0.0)
+        return self._plain
+
+    def _pack_plain(self, feature3d, v_rows):
+        f3 = np.asarray(feature3d, dtype=np.float64)
+        f2 = np.stack([np.zeros(f3.shape[0]), np.asarray(v_rows, dtype=np.float64)], axis=1)
+        return packing.pack_features([f3], [f2], -np.inf)
+
+    def find_outliers(self, feature3d, feature2d, triangle_ids):
+        """scale_calculator.py:151-167: boolean mask of the features whose vote counter is >= 0."""
+        eng, ctx = self._plain_engine(), self.engine.ctx
+        pf = self._pack_plain(feature3d, np.asarray(feature2d)[:, 1])
+        packing.attach_tri1(pf, [np.asarray(triangle_ids)])
+        db = DeviceBatch(ctx, pf, with_tri2=False)
+        out = DeviceOutputs(ctx, db, counts=True, stage=True)
+        eng.outlier_vote_batch(db, out)
+        ctx.sync()
+        counters = out.get("vote_counters")[pf.frame_slice(0)]
+        out.free()
+        db.free()
+        if self.verbose:
+            print('feature rejected ', int(np.sum(counters < 0)))
+            print('feature left     ', int(np.sum(counters >= 0)))
+        return counters >= 0
+
+    def feature_selection_by_tri(self, feature3d, triangle_ids):
+        """scale_calculator.py:225-248: sorted unique vertex ids of the flat, low triangles; sets
+        ``self.height_level``."""
+        eng, ctx = self._plain_engine(), self.engine.ctx
+        f3 = np.asarray(feature3d, dtype=np.float64)
+        pf = self._pack_plain(f3, np.zeros(f3.shape[0]))
+        packing.attach_tri1(pf, [np.zeros((0, 3), dtype=np.int32)])          # no vote: every feature survives
+        packing.attach_tri2(pf, [np.asarray(triangle_ids)], [np.ones(f3.shape[0], dtype=bool)])
+        db = DeviceBatch(ctx, pf)
+        out = DeviceOutputs(ctx, db, counts=True, stage=True)
+        eng.scale_batch(db, out)
+        ctx.sync()
+        st = int(out.get("status")[0])
+        sel = out.get("selected")[pf.frame_slice(0)]
+        self.height_level = out.get("height_level")[0]                        # :241
+        out.free()
+        db.free()
+        if st in (K.ST_ERR_SINGULAR, K.ST_ERR_MASK, K.ST_ERR_EMPTY):
+            raise_for_status(st)
+        return np.nonzero(sel)[0]                                             # :247
+
+    def feature_selection(self, feature3d, feature2d):
+        """scale_calculator.py:250-279 on remapped input: the selected road points, or None."""
+        from .packing import delaunay_simplices
+        feature3d, feature2d = np.asarray(feature3d, dtype=np.float64), np.asarray(feature2d, dtype=np.float64)
+        low = feature2d[:, 1] > self.vanish                                   # :252-254
+        feature2d, feature3d = feature2d[low, :], feature3d[low, :]
+        valid = self.find_outliers(feature3d, feature2d, delaunay_simplices(feature2d))     # :257-260
+        feature2d, feature3d = feature2d[valid, :], feature3d[valid, :]       # :264-265
+        selected = self.feature_selection_by_tri(feature3d, delaunay_simplices(feature2d))  # :266-273
+        if len(selected) > 0:
+            self.flat_feature_2d = feature2d[selected]                        # :275
+            return feature3d[selected]
+        if self.verbose:
+            print('no enough flat feature')
+        return None
+
+    def road_model_calculation_static(self, feature3d):
+        """scale_calculator.py:324-354: ``(height, 0, 1)`` from the y column of the selected points;
+        raises IndexError where the reference does (:343-344)."""
+        eng, ctx = self._plain_engine(), self.engine.ctx
+        f3 = np.asarray(feature3d, dtype=np.float64).reshape(-1, 3)
+        pf = self._pack_plain(f3, np.zeros(f3.shape[0]))
+        db = DeviceBatch(ctx, pf, with_tri2=False)
+        out = DeviceOutputs(ctx, db, counts=True)
+        eng.road_model_batch(db, out, np.array([getattr(self, "height_level", np.nan)], dtype=np.float64))
+        st, h = int(out.get("status")[0]), float(out.get("height")[0])
+        out.free()
+        db.free()
+        if st == K.ST_NO_FLAT:                                                # an empty list: the reference's np.histogram
+            st, h = K.ST_LEVEL, float(getattr(self, "height_level", np.nan))  # of nothing has no modes and no points (:334-335)
+        raise_for_status(st)
+        return h, 0, 1
+
+    def road_model_calculation(self, feature3d):
+        return self.road_model_calculation_static(feature3d)                  # :281-282
+
+    def scale_calculation_static(self, point_selected):
+        """scale_calculator.py:401-409 (remaps ``point_selected`` in place, like the reference)."""
+        self.feature_remap(point_selected)
+        height, pitch, std = self.road_model_calculation(point_selected)
+        scale = self.absolute_reference / height
+        return self.scale_filtering(scale), std
+
     # dead-but-referenced methods of the reference (main.py:117-123 under ``if(False)``)
     def check_full_distribution(self, *a, **k):
         raise NotImplementedError("visualisation helper of the reference; not part of the hot path")

@@ -621,3 +621,38 @@ def test_estimator_dense_frames_with_locality_layout(gpu):
     bs, bd = est2.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames])      # mixed batch -> dense variant
     want = [ref2.scale_calculation(f3, f2) for f3, f2 in frames]
     assert list(bs) == [w[0] for w in want] and list(bd) == [w[1] for w in want]
+
+
+def test_estimator_stage_methods(gpu, stages):
+    """The reference's stage methods on the drop-in class (find_outliers, feature_selection_by_tri,
+    feature_selection, road_model_calculation_static, scale_calculation_static) vs the goldens."""
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    for g in stages[:6] + stages[8:10]:
+        est = ScaleEstimator(g["abs_ref"], window_size=5)
+        f3 = so.remap(g["f3"])
+        low = so.lower_mask(g["f2"])
+        f3l, f2l = f3[low], g["f2"][low]
+        valid = est.find_outliers(f3l, f2l, g["tri1"])
+        assert np.array_equal(valid, g["valid"])
+        ids = est.feature_selection_by_tri(f3l[valid], g["tri2"])
+        assert np.array_equal(ids, g["selected_ids"])
+        assert abs(est.height_level - float(g["height_level"])) <= 1e-13 * abs(float(g["height_level"]))
+        pts = est.feature_selection(f3, g["f2"])
+        assert np.array_equal(pts, f3l[valid][g["selected_ids"]])
+        h, p, sd = est.road_model_calculation_static(pts)
+        assert (h, p, sd) == (float(g["height"]), 0, 1)
+        raw = g["f3"][low][valid][g["selected_ids"]].copy()
+        s, sd = est.scale_calculation_static(raw)
+        assert s == g["abs_ref"] / float(g["height"]) and np.array_equal(raw, pts)
+    cases = load_json("road_cases.json")
+    est = ScaleEstimator(1.75)
+    for name in ("all_singles", "no_modes_median_odd", "kat_right_skew"):
+        c = cases[name]
+        est.height_level = c["height_level"]
+        pts = np.zeros((len(c["y"]), 3)); pts[:, 1] = c["y"]
+        assert est.road_model_calculation_static(pts)[0] == c["height"], name
+    c = cases["no_left_min"]
+    pts = np.zeros((len(c["y"]), 3)); pts[:, 1] = c["y"]
+    with pytest.raises(IndexError):
+        est.road_model_calculation_static(pts)
