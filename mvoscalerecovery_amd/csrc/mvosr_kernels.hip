@@ -296,7 +296,7 @@ struct PitchTest {
     double s2_hi, s2_lo; // sin^2(|thr|) * (1 +- 1e-9): outside this band the decision needs no asin
 };
 
-template <int WAVES, bool FULL>
+template <int WAVES, bool FULL, int FW = 1>
 __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid, const int32_t *tri2, int64_t t2_begin,
                                                      int t2_count, TriChunk<WAVES * kWave> &tc, PitchTest pt,
                                                      double *g_normals, double *g_pitch, double *g_heights, int bad_in,
@@ -304,6 +304,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     constexpr int B = WAVES * kWave;
     const int tid = threadIdx.x;
     unsigned long long flat = 0ull;          // bit kk: my kk-th triangle has pitch_deg < thr
+    unsigned long long flat_hi = 0ull;       // bits 64..127 (FW == 2: dense frames, up to 128 triangles per thread)
     double hsum = 0.0, hcnt = 0.0;
     int npitch = 0, singular = 0, bad = 0;
     // One triangle of the first sweep (:229-240).
@@ -352,7 +353,10 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
         }
     }
     if (is_steep) { hsum += h; hcnt += 1.0; }                                            // :240
-    if (is_flat) { flat |= 1ull << kk; ++npitch; }
+    if (is_flat) {
+        if (FW == 1 || kk < 64) flat |= 1ull << (kk & 63); else flat_hi |= 1ull << (kk & 63);
+        ++npitch;
+    }
     };
     // `tc` arrives with the first chunk of tri2 already loaded (phase_vote); the next chunk streams
     // in while the current one is processed.
@@ -380,7 +384,8 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     const double hl = r.height_level;
     int ntv = 0;
     auto mark_triangle = [&](int kk, int qa, int qb, int qc) {
-        if (!((flat >> kk) & 1ull)) return;
+        const unsigned long long fw = (FW == 1 || kk < 64) ? flat : flat_hi;
+        if (!((fw >> (kk & 63)) & 1ull)) return;
         const double y0 = s.Y[qa], y1 = s.Y[qb], y2 = s.Y[qc];
         const double h = div3((y0 + y1) + y2);
         if (h > hl) {                                                                        // :243-244
@@ -853,23 +858,23 @@ __global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(
 // Dense frames (more features than fit LDS in fp64, e.g. N = 20000): same algorithm, but the
 // remapped planes live in a per-frame workspace in global memory and the triangle sweeps gather
 // from it through L1/L2 ("L2-gather variant").  LDS keeps only what is hit by atomics: the 16-bit
-// vote counters and the selected bit-set.  One workgroup of 16 wavefronts per frame.  Survivors are
+// vote counters and the selected bit-set.  One workgroup of 16 wavefronts per frame (128 flag bits per
+// thread: up to 131072 triangles, i.e. the 65535-feature limit of the 16-bit counters' index space).  Survivors are
 // compacted into a second workspace copy (no in-place hazard, no registers held across barriers).
 // ---------------------------------------------------------------------------------------------
-constexpr int kDenseWaves = 16;
 struct DenseWs { double2 *P, *P2; double *Y, *Y2; };      // per-batch planes laid out like x (feat_off)
 
-__host__ __device__ inline uint32_t dense_lds_bytes(int n) {
+__host__ __device__ inline uint32_t dense_lds_bytes(int n, int waves) {
     const uint32_t npad = (uint32_t)((n + 1) & ~1);
-    return align16(2u * npad + 16u) + align16(4u * ((uint32_t)(n + 31) / 32u)) + 8u * (uint32_t)(kRedSlots * 2 * kDenseWaves) + 4u * 32u;
+    return align16(2u * npad + 16u) + align16(4u * ((uint32_t)(n + 31) / 32u)) + 8u * (uint32_t)(kRedSlots * 2 * waves) + 4u * 32u;
 }
 
-template <bool FUSED>
+template <int DW, bool FUSED>
 __device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n, const double *gx, const double *gy, const double *gz,
                                                 const double *gv, const int32_t *tri1, int64_t t1_begin, int t1_count,
                                                 double cp, double sp, int32_t *g_counters, int &bad,
                                                 double2 *P, double *Y, double2 *P2, double *Y2) {
-    constexpr int B = kDenseWaves * kWave;
+    constexpr int B = DW * kWave;
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
     const uint16_t *c16 = reinterpret_cast<const uint16_t *>(c32);
     const uint32_t ones = ((uint32_t)(kCounterBias + 1) << 16) | (uint32_t)(kCounterBias + 1);     // np.ones, :153
@@ -913,7 +918,7 @@ __device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n,
     __syncthreads();
     int base = 0, total = 0;
 #pragma unroll
-    for (int i = 0; i < kDenseWaves; ++i) { const int c = misc[M_WCNT + i]; if (i < w) base += c; total += c; }
+    for (int i = 0; i < DW; ++i) { const int c = misc[M_WCNT + i]; if (i < w) base += c; total += c; }
     if constexpr (FUSED) {
         for (int i0 = begin; i0 < end; i0 += kWave) {
             const int i = i0 + lane;
@@ -935,11 +940,11 @@ __device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n,
 
 struct DenseArgs { KArgs k; DenseWs ws; };
 
-template <bool FULL>
-__global__ __launch_bounds__(kDenseWaves *kWave) void scale_frames_dense_kernel(const DenseArgs da) {
+template <int DW, bool FULL>
+__global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const DenseArgs da) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KArgs &a = da.k;
-    constexpr int B = kDenseWaves * kWave;
+    constexpr int B = DW * kWave;
     const int tid = threadIdx.x;
     const int64_t f = a.first_frame + blockIdx.x;
     const int n = a.b.feat_cnt[f];
@@ -963,13 +968,13 @@ __global__ __launch_bounds__(kDenseWaves *kWave) void scale_frames_dense_kernel(
     s.c16 = reinterpret_cast<uint16_t *>(smem);
     s.sel = reinterpret_cast<uint32_t *>(smem + align16(2u * npad + 16u));
     s.red = reinterpret_cast<double *>(smem + align16(2u * npad + 16u) + align16(4u * ((uint32_t)(n + 31) / 32u)));
-    s.misc = reinterpret_cast<int *>(s.red + kRedSlots * 2 * kDenseWaves);
+    s.misc = reinterpret_cast<int *>(s.red + kRedSlots * 2 * DW);
     s.hist = nullptr;
     s.P = da.ws.P2 + off;              // what the second triangulation indexes: the compacted copy
     s.Y = da.ws.Y2 + off;
     for (int i = tid; i < (n + 31) / 32; i += B) s.sel[i] = 0u;
     int bad = 0;
-    const int nvalid = phase_vote_dense<true>(s.c32, s.misc, n, a.b.x + off, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
+    const int nvalid = phase_vote_dense<DW, true>(s.c32, s.misc, n, a.b.x + off, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
                                               a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad,
                                               da.ws.P + off, da.ws.Y + off, da.ws.P2 + off, da.ws.Y2 + off);
     const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
@@ -978,7 +983,7 @@ __global__ __launch_bounds__(kDenseWaves *kWave) void scale_frames_dense_kernel(
     if (!mask_mismatch) {
         TriChunk<B> tc2;
         tc2.load(a.b.tri2, t2b, t2n, 0, tid);
-        S = phase_select<kDenseWaves, FULL>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
+        S = phase_select<DW, FULL, 2>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
                                             a.o.tri_heights, bad, 0);
     }
     int status = kStPending;
@@ -1004,7 +1009,7 @@ __global__ __launch_bounds__(kDenseWaves *kWave) void scale_frames_dense_kernel(
         __syncthreads();
         int base = 0;
 #pragma unroll
-        for (int i = 0; i < kDenseWaves; ++i) { const int c = s.misc[M_WCNT + i]; if (i < w) base += c; nsel += c; }
+        for (int i = 0; i < DW; ++i) { const int c = s.misc[M_WCNT + i]; if (i < w) base += c; nsel += c; }
         double *dst = a.ysel + off;
         for (int j0 = begin; j0 < end; j0 += kWave) {
             const int j = j0 + lane;
@@ -1027,7 +1032,8 @@ __global__ __launch_bounds__(kDenseWaves *kWave) void scale_frames_dense_kernel(
     }
 }
 
-__global__ __launch_bounds__(kDenseWaves *kWave) void outlier_vote_dense_kernel(const DenseArgs da) {
+template <int DW>
+__global__ __launch_bounds__(DW *kWave) void outlier_vote_dense_kernel(const DenseArgs da) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KArgs &a = da.k;
     const int64_t f = a.first_frame + blockIdx.x;
@@ -1039,13 +1045,13 @@ __global__ __launch_bounds__(kDenseWaves *kWave) void outlier_vote_dense_kernel(
     const uint32_t npad = (uint32_t)((n + 1) & ~1);
     uint32_t *c32 = reinterpret_cast<uint32_t *>(smem);
     double *red = reinterpret_cast<double *>(smem + align16(2u * npad + 16u) + align16(4u * ((uint32_t)(n + 31) / 32u)));
-    int *misc = reinterpret_cast<int *>(red + kRedSlots * 2 * kDenseWaves);
+    int *misc = reinterpret_cast<int *>(red + kRedSlots * 2 * DW);
     int bad = 0;
-    const int nvalid = phase_vote_dense<false>(c32, misc, n, nullptr, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
+    const int nvalid = phase_vote_dense<DW, false>(c32, misc, n, nullptr, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
                                                a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters + off, bad,
                                                da.ws.P + off, da.ws.Y + off, nullptr, nullptr);
     int b0 = bad, b1 = 0, b2 = 0, b3 = 0;
-    block_sum4i<kDenseWaves>(b0, b1, b2, b3, red + R_MISC * 2 * kDenseWaves);
+    block_sum4i<DW>(b0, b1, b2, b3, red + R_MISC * 2 * DW);
     if (threadIdx.x == 0) {
         if (a.o.counts) a.o.counts[f * MVOSR_N_COUNTS + MVOSR_CNT_VALID] = nvalid;
         if (a.o.status) a.o.status[f] = b0 ? MVOSR_ST_ERR_MASK : MVOSR_ST_MODE;
@@ -1205,12 +1211,15 @@ static int launch_vote(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
     return check_launch("outlier_vote_kernel");
 }
 
-// dense frames: planes in a global workspace (48 B per feature), 16 wavefronts per frame
-static int launch_scale_dense(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool full, bool vote_only) {
-    if (ka.b.max_feat > 65535) return set_error(MVOSR_ERR_TOO_LARGE, "more than 65535 features per frame");
-    if ((int64_t)2 * ka.b.max_feat > (int64_t)64 * kWave * kDenseWaves)
-        return set_error(MVOSR_ERR_TOO_LARGE, "%d features give more triangles than %d wavefronts sweep", ka.b.max_feat, kDenseWaves);
-    const size_t lds = dense_lds_bytes(ka.b.max_feat);
+// dense frames: planes in a global workspace (48 B per feature), 16 wavefronts per frame.  (8 wavefronts
+// per frame, three workgroups per CU, measured the same: the sweeps are bound by L2 gather traffic, not occupancy.)
+constexpr int kDenseWaves = 16;
+
+template <int DW>
+static int launch_scale_dense_w(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool full, bool vote_only) {
+    if ((int64_t)2 * ka.b.max_feat > (int64_t)128 * kWave * DW)
+        return set_error(MVOSR_ERR_TOO_LARGE, "%d features give more triangles than %d wavefronts sweep", ka.b.max_feat, DW);
+    const size_t lds = dense_lds_bytes(ka.b.max_feat, DW);
     if ((int64_t)lds > (int64_t)g_max_dyn_lds)
         return set_error(MVOSR_ERR_TOO_LARGE, "frame of %d features needs %zu B of LDS (> %d)", ka.b.max_feat, lds, g_max_dyn_lds);
     DenseArgs da;
@@ -1221,18 +1230,23 @@ static int launch_scale_dense(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool 
     da.ws.P = reinterpret_cast<double2 *>(p[0]); da.ws.P2 = reinterpret_cast<double2 *>(p[1]);
     da.ws.Y = reinterpret_cast<double *>(p[2]); da.ws.Y2 = reinterpret_cast<double *>(p[3]);
     if (vote_only) {
-        if ((rc = prepare_kernel(outlier_vote_dense_kernel, lds))) return rc;
-        hipLaunchKernelGGL(outlier_vote_dense_kernel, dim3((unsigned)nl), dim3(kDenseWaves * kWave), lds, ctx_stream(ctx), da);
+        if ((rc = prepare_kernel(outlier_vote_dense_kernel<DW>, lds))) return rc;
+        hipLaunchKernelGGL((outlier_vote_dense_kernel<DW>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
         return check_launch("outlier_vote_dense_kernel");
     }
     if (full) {
-        if ((rc = prepare_kernel(scale_frames_dense_kernel<true>, lds))) return rc;
-        hipLaunchKernelGGL((scale_frames_dense_kernel<true>), dim3((unsigned)nl), dim3(kDenseWaves * kWave), lds, ctx_stream(ctx), da);
+        if ((rc = prepare_kernel(scale_frames_dense_kernel<DW, true>, lds))) return rc;
+        hipLaunchKernelGGL((scale_frames_dense_kernel<DW, true>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
     } else {
-        if ((rc = prepare_kernel(scale_frames_dense_kernel<false>, lds))) return rc;
-        hipLaunchKernelGGL((scale_frames_dense_kernel<false>), dim3((unsigned)nl), dim3(kDenseWaves * kWave), lds, ctx_stream(ctx), da);
+        if ((rc = prepare_kernel(scale_frames_dense_kernel<DW, false>, lds))) return rc;
+        hipLaunchKernelGGL((scale_frames_dense_kernel<DW, false>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
     }
     return check_launch("scale_frames_dense_kernel");
+}
+
+static int launch_scale_dense(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool full, bool vote_only) {
+    if (ka.b.max_feat > 65535) return set_error(MVOSR_ERR_TOO_LARGE, "more than 65535 features per frame");
+    return launch_scale_dense_w<kDenseWaves>(ctx, ka, nl, full, vote_only);
 }
 
 // one wavefront per frame, kRoadWaves frames per workgroup
