@@ -97,8 +97,12 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+            backend = os.environ.get("MVOSR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            # MVOSR_SHARE_GPU=1: dry runs of the N-rank path on a box with fewer GPUs (gloo only;
+            # RCCL refuses two ranks on one device)
+            if os.environ.get("MVOSR_SHARE_GPU") == "1":
+                local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
