@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--pool", type=int, default=128, help="unique synthetic frames tiled to --frames")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts per frame (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--alias-pool", action="store_true",
+                    help="diagnostic: every tile reads the feature planes of the SAME pool frames (cache-resident: 41 %% "
+                         "less HBM traffic); the JSON line is marked and is not a benchmark result")
     args = ap.parse_args()
 
     import torch
@@ -146,7 +149,10 @@ def main():
         return keep[name].data_ptr()
 
     def offs(name, per_pool, stride, closing):
-        o = np.concatenate([per_pool + r * stride for r in range(repeats)] + ([np.array([repeats * stride], np.int64)] if closing else []))
+        if args.alias_pool and not closing:
+            o = np.concatenate([per_pool for r in range(repeats)])      # feature planes only (tri*_off are CSR)
+        else:
+            o = np.concatenate([per_pool + r * stride for r in range(repeats)] + ([np.array([repeats * stride], np.int64)] if closing else []))
         keep[name] = torch.from_numpy(o.astype(np.int64)).to(dev)
         return keep[name].data_ptr()
 
@@ -250,6 +256,8 @@ def main():
             "status_histogram": {str(k): int(v) for k, v in zip(*np.unique(st_all, return_counts=True))},
             "host_delaunay_ms_per_frame": delaunay_s * 1e3,
         }
+        if args.alias_pool:
+            line["diagnostic"] = "alias-pool: NOT a benchmark result"
         if n_gpus == 1 and not args.no_cpu_baseline:
             fps, sample_n, mism = cpu_baseline(frames, pf_pool, gpu_raw, gpu_status)
             line["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",

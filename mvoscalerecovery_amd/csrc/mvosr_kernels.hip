@@ -183,13 +183,22 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
     for (int base = 0; base < t1c; base += kTC * B) {
         const bool more = base + kTC * B < t1c;
         if (more) tn.load(tri1, t1_begin, t1_count, base + kTC * B, tid);
+        // all vertex reads of the chunk first: the reads of one triangle cannot be moved across the
+        // LDS atomics of another by the compiler, and issued together their latencies overlap
+        double2 vp[kTC][3];
+        bool vok[kTC];
 #pragma unroll
         for (int k = 0; k < kTC; ++k) {
-            const int t = base + k * B + tid;
-            if (t >= t1_count) continue;
             const TriIds q = tc.q[k];
-            if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
-            const double2 p0 = s.P[q.a], p1 = s.P[q.b], p2 = s.P[q.c];      // {v, z'}
+            vok[k] = base + k * B + tid < t1_count;
+            if (vok[k] && ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n)) { bad = 1; vok[k] = false; }
+            if (vok[k]) { vp[k][0] = s.P[q.a]; vp[k][1] = s.P[q.b]; vp[k][2] = s.P[q.c]; }      // {v, z'}
+        }
+#pragma unroll
+        for (int k = 0; k < kTC; ++k) {
+            if (!vok[k]) continue;
+            const TriIds q = tc.q[k];
+            const double2 p0 = vp[k][0], p1 = vp[k][1], p2 = vp[k][2];
             const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
             const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
             const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
@@ -296,25 +305,13 @@ struct PitchTest {
     double s2_hi, s2_lo; // sin^2(|thr|) * (1 +- 1e-9): outside this band the decision needs no asin
 };
 
-template <int WAVES, bool FULL, int FW = 1>
-__device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid, const int32_t *tri2, int64_t t2_begin,
-                                                     int t2_count, TriChunk<WAVES * kWave> &tc, PitchTest pt,
-                                                     double *g_normals, double *g_pitch, double *g_heights, int bad_in,
-                                                     int dbg = 0 MVOSR_STAMP_ARG) {
-    constexpr int B = WAVES * kWave;
-    const int tid = threadIdx.x;
-    unsigned long long flat = 0ull;          // bit kk: my kk-th triangle has pitch_deg < thr
-    unsigned long long flat_hi = 0ull;       // bits 64..127 (FW == 2: dense frames, up to 128 triangles per thread)
-    double hsum = 0.0, hcnt = 0.0;
-    int npitch = 0, singular = 0, bad = 0;
-    // One triangle of the first sweep (:229-240).
-    auto test_triangle = [&](int t, int kk, const TriIds q) {
-    if ((unsigned)q.a >= (unsigned)n_valid || (unsigned)q.b >= (unsigned)n_valid || (unsigned)q.c >= (unsigned)n_valid) { bad = 1; return; }
-    const double2 p0 = s.P[q.a], p1 = s.P[q.b], p2 = s.P[q.c];      // {x, z'}
-    const double y0 = s.Y[q.a], y1 = s.Y[q.b], y2 = s.Y[q.c];
-    const double x0 = p0.x, z0 = p0.y, x1 = p1.x, z1 = p1.y, x2 = p2.x, z2 = p2.y;
-    const double h = div3((y0 + y1) + y2);                                               // :238
-    bool is_flat = false, is_steep = false;
+// One triangle of the first sweep (:229-240): bit 0 = pitch_deg < thr (flat), bit 1 = pitch_deg >= thr,
+// bit 2 = exactly singular.  `h` is the triangle's mean y' (only written out in FULL mode).
+template <bool FULL>
+__device__ __forceinline__ int classify_triangle(double x0, double y0, double z0, double x1, double y1, double z1,
+                                                 double x2, double y2, double z2, double h, const PitchTest &pt,
+                                                 double *g_normals, double *g_pitch, double *g_heights, int64_t tg) {
+    bool is_flat = false, is_steep = false, is_singular = false;
     bool decided = false;
     if constexpr (!FULL) {
         // The plane n.p = 1 through the vertices has n = c / det with c = (p1-p0) x (p2-p0) and
@@ -343,15 +340,39 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     if (!decided) {
         double nx, ny, nz, pitch;
         const int r = pitch_reference<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, pt.thr_deg, nx, ny, nz, pitch);
-        if (r & 4) singular = 1;
+        is_singular = r & 4;
         is_flat = r & 1;
         is_steep = r & 2;
         if constexpr (FULL) {
-            if (g_normals) { double *o = g_normals + 3 * (t2_begin + t); o[0] = nx; o[1] = ny; o[2] = nz; }
-            if (g_pitch) g_pitch[t2_begin + t] = pitch;
-            if (g_heights) g_heights[t2_begin + t] = h;
+            if (g_normals) { double *o = g_normals + 3 * tg; o[0] = nx; o[1] = ny; o[2] = nz; }
+            if (g_pitch) g_pitch[tg] = pitch;
+            if (g_heights) g_heights[tg] = h;
         }
     }
+    return (is_flat ? 1 : 0) | (is_steep ? 2 : 0) | (is_singular ? 4 : 0);
+}
+
+template <int WAVES, bool FULL, int FW = 1>
+__device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid, const int32_t *tri2, int64_t t2_begin,
+                                                     int t2_count, TriChunk<WAVES * kWave> &tc, PitchTest pt,
+                                                     double *g_normals, double *g_pitch, double *g_heights, int bad_in,
+                                                     int dbg = 0 MVOSR_STAMP_ARG) {
+    constexpr int B = WAVES * kWave;
+    const int tid = threadIdx.x;
+    unsigned long long flat = 0ull;          // bit kk: my kk-th triangle has pitch_deg < thr
+    unsigned long long flat_hi = 0ull;       // bits 64..127 (FW == 2: dense frames, up to 128 triangles per thread)
+    double hsum = 0.0, hcnt = 0.0;
+    int npitch = 0, singular = 0, bad = 0;
+    // One triangle of the first sweep (:229-240).
+    auto test_triangle = [&](int t, int kk, const TriIds q) {
+    if ((unsigned)q.a >= (unsigned)n_valid || (unsigned)q.b >= (unsigned)n_valid || (unsigned)q.c >= (unsigned)n_valid) { bad = 1; return; }
+    const double2 p0 = s.P[q.a], p1 = s.P[q.b], p2 = s.P[q.c];      // {x, z'}
+    const double y0 = s.Y[q.a], y1 = s.Y[q.b], y2 = s.Y[q.c];
+    const double x0 = p0.x, z0 = p0.y, x1 = p1.x, z1 = p1.y, x2 = p2.x, z2 = p2.y;
+    const double h = div3((y0 + y1) + y2);                                               // :238
+    const int r = classify_triangle<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, h, pt, g_normals, g_pitch, g_heights, t2_begin + t);
+    const bool is_flat = r & 1, is_steep = r & 2;
+    if (r & 4) singular = 1;
     if (is_steep) { hsum += h; hcnt += 1.0; }                                            // :240
     if (is_flat) {
         if (FW == 1 || kk < 64) flat |= 1ull << (kk & 63); else flat_hi |= 1ull << (kk & 63);
@@ -940,6 +961,60 @@ __device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n,
 
 struct DenseArgs { KArgs k; DenseWs ws; };
 
+// Tail shared by the dense variants: status, the dense list of selected y' for the road-model kernel
+// (count per wave slice -> barrier -> ordered store), per-frame outputs.
+template <int DW>
+__device__ __forceinline__ void dense_tail(const KArgs &a, const Smem &s, int64_t f, int64_t off, int nvalid, bool mask_mismatch,
+                                           const SelectResult &S, RoadResult &R) {
+    constexpr int B = DW * kWave;
+    const int tid = threadIdx.x;
+    int status = kStPending;
+    double raw = nan("");
+    int nsel = 0;
+    if (mask_mismatch || S.bad) {
+        status = MVOSR_ST_ERR_MASK;
+    } else if (S.singular) {
+        status = MVOSR_ST_ERR_SINGULAR;
+    } else {
+        // dense list of the selected y' for the road-model kernel: count per wave slice, then store
+        const int w = wave_id(), lane = lane_id();
+        const int per = ((nvalid + B - 1) / B) * kWave;
+        const int begin = w * per, end = min(nvalid, begin + per);
+        int cnt = 0;
+        for (int j0 = begin; j0 < end; j0 += kWave) {
+            const int j = j0 + lane;
+            const bool sel = (j < end) && ((s.sel[j >> 5] >> (j & 31)) & 1u);
+            if (a.o.selected && j < end) a.o.selected[off + j] = (uint8_t)sel;                   // :247
+            cnt += __popcll(__ballot(sel));
+        }
+        if (lane == 0) s.misc[M_WCNT + w] = cnt;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < DW; ++i) { const int c = s.misc[M_WCNT + i]; if (i < w) base += c; nsel += c; }
+        double *dst = a.ysel + off;
+        for (int j0 = begin; j0 < end; j0 += kWave) {
+            const int j = j0 + lane;
+            const bool sel = (j < end) && ((s.sel[j >> 5] >> (j & 31)) & 1u);
+            const unsigned long long m = __ballot(sel);
+            if (sel) dst[base + __popcll(m & ((1ull << lane) - 1ull))] = s.Y[j];
+            base += __popcll(m);
+        }
+        if (nsel == 0) { status = MVOSR_ST_NO_FLAT; raw = a.P.absolute_reference / S.height_level; }   // :277-279,:421
+    }
+    if (tid == 0) {
+        a.o.raw_scale[f] = raw;
+        a.o.height[f] = nan("");
+        a.o.height_level[f] = S.height_level;
+        a.o.status[f] = status;
+        a.nsel[f] = nsel;
+        R.n_sel = nsel;
+        write_counts(a, f, nvalid, S.n_pitch, S.n_tri_valid, R);
+        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = st[1] = st[2] = st[3] = nan(""); }
+    }
+}
+
+
 template <int DW, bool FULL>
 __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const DenseArgs da) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -986,50 +1061,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const Den
         S = phase_select<DW, FULL, 2>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
                                             a.o.tri_heights, bad, 0);
     }
-    int status = kStPending;
-    double raw = nan("");
-    int nsel = 0;
-    if (mask_mismatch || S.bad) {
-        status = MVOSR_ST_ERR_MASK;
-    } else if (S.singular) {
-        status = MVOSR_ST_ERR_SINGULAR;
-    } else {
-        // dense list of the selected y' for the road-model kernel: count per wave slice, then store
-        const int w = wave_id(), lane = lane_id();
-        const int per = ((nvalid + B - 1) / B) * kWave;
-        const int begin = w * per, end = min(nvalid, begin + per);
-        int cnt = 0;
-        for (int j0 = begin; j0 < end; j0 += kWave) {
-            const int j = j0 + lane;
-            const bool sel = (j < end) && ((s.sel[j >> 5] >> (j & 31)) & 1u);
-            if (a.o.selected && j < end) a.o.selected[off + j] = (uint8_t)sel;                   // :247
-            cnt += __popcll(__ballot(sel));
-        }
-        if (lane == 0) s.misc[M_WCNT + w] = cnt;
-        __syncthreads();
-        int base = 0;
-#pragma unroll
-        for (int i = 0; i < DW; ++i) { const int c = s.misc[M_WCNT + i]; if (i < w) base += c; nsel += c; }
-        double *dst = a.ysel + off;
-        for (int j0 = begin; j0 < end; j0 += kWave) {
-            const int j = j0 + lane;
-            const bool sel = (j < end) && ((s.sel[j >> 5] >> (j & 31)) & 1u);
-            const unsigned long long m = __ballot(sel);
-            if (sel) dst[base + __popcll(m & ((1ull << lane) - 1ull))] = s.Y[j];
-            base += __popcll(m);
-        }
-        if (nsel == 0) { status = MVOSR_ST_NO_FLAT; raw = a.P.absolute_reference / S.height_level; }   // :277-279,:421
-    }
-    if (tid == 0) {
-        a.o.raw_scale[f] = raw;
-        a.o.height[f] = nan("");
-        a.o.height_level[f] = S.height_level;
-        a.o.status[f] = status;
-        a.nsel[f] = nsel;
-        R.n_sel = nsel;
-        write_counts(a, f, nvalid, S.n_pitch, S.n_tri_valid, R);
-        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = st[1] = st[2] = st[3] = nan(""); }
-    }
+    dense_tail<DW>(a, s, f, off, nvalid, mask_mismatch, S, R);
 }
 
 template <int DW>
