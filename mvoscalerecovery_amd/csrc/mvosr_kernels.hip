@@ -109,14 +109,36 @@ enum { M_WCNT = 0 /* [0..15] per-wave survivor counts */, M_LIST = 16, M_MEDLO =
 constexpr int kTC = MVOSR_TC;   // triangles per thread per chunk (3 VGPRs each)
 
 
+// Inputs that are read exactly once are loaded non-temporally: measured, the L2-miss traffic of the
+// fused kernel drops from 1.23x to 0.99x the algorithmic bytes (the second read of tri2 then hits L2).
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 stream_load2(const double2 *p) {
+    const dvec2 v = __builtin_nontemporal_load(reinterpret_cast<const dvec2 *>(p));
+    double2 r; r.x = v.x; r.y = v.y;
+    return r;
+}
+__device__ __forceinline__ double stream_load(const double *p) {
+    return __builtin_nontemporal_load(p);
+}
+
 template <int B>
 struct TriChunk {
     TriIds q[kTC];
+    // STREAM: the rows are not read again (non-temporal loads, so that they do not push rows that are
+    // read twice — the second triangulation — out of L2)
+    template <bool STREAM = false>
     __device__ __forceinline__ void load(const int32_t *tri, int64_t begin, int count, int base, int tid) {
 #pragma unroll
         for (int k = 0; k < kTC; ++k) {
             const int t = base + k * B + tid;
-            if (t < count) q[k] = load_tri(tri + 3 * begin, t);
+            if (t < count) {
+                if constexpr (STREAM) {
+                    const int32_t *p = tri + 3 * begin + 3 * t;
+                    q[k].a = __builtin_nontemporal_load(p); q[k].b = __builtin_nontemporal_load(p + 1); q[k].c = __builtin_nontemporal_load(p + 2);
+                } else {
+                    q[k] = load_tri(tri + 3 * begin, t);
+                }
+            }
         }
     }
 };
@@ -139,7 +161,7 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
     const int tid = threadIdx.x;
     const int npad2 = (n + 1) >> 1;
     TriChunk<B> tc;
-    tc.load(tri1, t1_begin, t1_count, 0, tid);          // in flight while the features stream in
+    tc.template load<true>(tri1, t1_begin, t1_count, 0, tid);          // in flight while the features stream in
     // planes are 16-byte aligned per frame: two features per lane and load, two loads per plane in flight
     const double2 *gy2 = reinterpret_cast<const double2 *>(gy);
     const double2 *gz2 = reinterpret_cast<const double2 *>(gz);
@@ -149,9 +171,9 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
     for (int i0 = tid; i0 < npad2; i0 += 2 * B) {
         const int i1 = i0 + B;
         const bool two = i1 < npad2;
-        const double2 ya = gy2[i0], za = gz2[i0], va = gv2[i0];
+        const double2 ya = stream_load2(gy2 + i0), za = stream_load2(gz2 + i0), va = stream_load2(gv2 + i0);
         double2 yb = ya, zb = za, vb = va;
-        if (two) { yb = gy2[i1]; zb = gz2[i1]; vb = gv2[i1]; }
+        if (two) { yb = stream_load2(gy2 + i1); zb = stream_load2(gz2 + i1); vb = stream_load2(gv2 + i1); }
         double2 yr, p0, p1;
         yr.x = ya.x * cp - za.x * sp;  yr.y = ya.y * cp - za.y * sp;      // :391
         p0.x = va.x; p0.y = ya.x * sp + za.x * cp;                        // :392
@@ -174,7 +196,7 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
 #pragma unroll
     for (int k = 0; k < SC; ++k) {
         const int i = begin + k * kWave + lane;
-        xs[k] = (gx && i < n) ? gx[i] : 0.0;
+        xs[k] = (gx && i < n) ? stream_load(gx + i) : 0.0;
     }
 
     // the vote: +1 on a vertex the triangle does not flag, -1 on one it flags (:160-163)
@@ -182,7 +204,7 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
     TriChunk<B> tn;                                   // the next chunk streams in while this one is processed
     for (int base = 0; base < t1c; base += kTC * B) {
         const bool more = base + kTC * B < t1c;
-        if (more) tn.load(tri1, t1_begin, t1_count, base + kTC * B, tid);
+        if (more) tn.template load<true>(tri1, t1_begin, t1_count, base + kTC * B, tid);
         // all vertex reads of the chunk first: the reads of one triangle cannot be moved across the
         // LDS atomics of another by the compiler, and issued together their latencies overlap
         double2 vp[kTC][3];
@@ -397,7 +419,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     // triangulation was one chunk and is still in registers)
     const int t2d = (dbg & 4) ? 0 : t2_count;
     const bool in_regs = t2_count <= kTC * B;
-    if (!in_regs && t2d > 0) tc.load(tri2, t2_begin, t2_count, 0, tid);
+    if (!in_regs && t2d > 0) tc.template load<true>(tri2, t2_begin, t2_count, 0, tid);
     block_sum2<WAVES>(hsum, hcnt, s.red + R_SEL_H * 2 * WAVES);
     MVOSR_STAMP(4);
     SelectResult r;
@@ -418,7 +440,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     };
     for (int base = 0; base < t2d; base += kTC * B) {
         const bool more = base + kTC * B < t2d;
-        if (more) tn.load(tri2, t2_begin, t2_count, base + kTC * B, tid);
+        if (more) tn.template load<true>(tri2, t2_begin, t2_count, base + kTC * B, tid);
 #pragma unroll
         for (int k = 0; k < kTC; ++k) {
             if (base + k * B + tid < t2d) mark_triangle(base / B + k, tc.q[k].a, tc.q[k].b, tc.q[k].c);
@@ -493,9 +515,57 @@ __device__ __forceinline__ int bin_of_table(double y, const double2 *edges) {
     return k;
 }
 
+// np.add.reduce's summation order for a 1-D float64 array (numpy/core/src/umath/loops_utils.h.src,
+// @TYPE@_pairwise_sum: below 8 values a plain loop; up to 128 eight strided accumulators combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the remainder added one by one; above that the halves —
+// the first rounded down to a multiple of 8 — summed recursively).  With sq the terms are
+// (a[i]-shift)^2, as in np.std's  x = arr - mean; x = x*x; sum(x).  Every lane of the wavefront runs it
+// redundantly on the same packed list; it is the cold path behind the skewness decision (road_wave).
+__device__ __forceinline__ double np_term(const double *a, int i, double shift, bool sq) {
+    const double v = a[i];
+    if (!sq) return v;
+    const double d = v - shift;
+    return d * d;
+}
+__device__ double np_leaf_sum(const double *a, int n, double shift, bool sq) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += np_term(a, i, shift, sq);
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = np_term(a, j, shift, sq);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += np_term(a, i + j, shift, sq);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += np_term(a, i, shift, sq);
+    return res;
+}
+__device__ __attribute__((noinline)) double np_pairwise_sum_cold(const double *a, int n, double shift, int sq) {
+    constexpr int kDepth = 32;                               // > log2 of any list length
+    int lo_s[kDepth], n_s[kDepth], stage_s[kDepth];
+    double val[kDepth];
+    int sp = 0, vp = 0;
+    lo_s[0] = 0; n_s[0] = n; stage_s[0] = 0; sp = 1;
+    while (sp > 0) {
+        const int lo = lo_s[sp - 1], m = n_s[sp - 1], stage = stage_s[sp - 1];
+        if (m <= 128) { val[vp++] = np_leaf_sum(a + lo, m, shift, sq != 0); --sp; continue; }
+        int m2 = m / 2;
+        m2 -= m2 % 8;
+        if (stage == 0) { stage_s[sp - 1] = 1; lo_s[sp] = lo; n_s[sp] = m2; stage_s[sp] = 0; ++sp; }
+        else if (stage == 1) { stage_s[sp - 1] = 2; lo_s[sp] = lo + m2; n_s[sp] = m - m2; stage_s[sp] = 0; ++sp; }
+        else { const double r = val[--vp], l = val[--vp]; val[vp++] = l + r; --sp; }
+    }
+    return val[0];
+}
+
 __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16_t *slots, uint8_t *dropb, const double2 *edges,
                                                 const double *yv, double *scratch,
-                                                int M, double height_level, const mvosr_params &P, int32_t *g_hist MVOSR_STAMP_ARG) {
+                                                int M, double height_level, const mvosr_params &P, int32_t *g_hist, bool exact_stats MVOSR_STAMP_ARG) {
     const int lane = lane_id();
     RoadResult R;
     R.height = nan(""); R.status = MVOSR_ST_MODE; R.n_sel = M; R.n_kept = 0; R.n_modes = 0; R.mode_left = -1; R.mode_right = -1;
@@ -613,10 +683,8 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     const int nkept = (int)cntd;
     R.n_kept = nkept;
 
-    if (!have_modes) {
-        if (nkept == 0) { R.height = height_level; R.status = MVOSR_ST_LEVEL; return R; }   // :334-335
-        // np.median (:333): pack the kept values into `scratch` (index <= source index, so in place
-        // is safe when scratch == yv), then rank counting: the two middle order statistics
+    // the kept values in list order, packed into `scratch` (for the median fallback and the exact sums)
+    auto pack_kept = [&]() {
         int nlist = 0;
 #pragma unroll 1
         for (int i0 = 0; i0 < M; i0 += kWave) {
@@ -632,6 +700,14 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
             if (keep) scratch[nlist + __popcll(m & ((1ull << lane) - 1ull))] = y;
             nlist += __popcll(m);
         }
+        return nlist;
+    };
+
+    if (!have_modes) {
+        if (nkept == 0) { R.height = height_level; R.status = MVOSR_ST_LEVEL; return R; }   // :334-335
+        // np.median (:333): pack the kept values into `scratch` (index <= source index, so in place
+        // is safe when scratch == yv), then rank counting: the two middle order statistics
+        pack_kept();
         __threadfence_block();                   // the wave's own stores, visible to all its lanes
         const int klo = (nkept - 1) >> 1, khi = nkept >> 1;
         double mlo = 0.0, mhi = 0.0;
@@ -705,9 +781,25 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     const int ir = mins.lowest_from(mr);                                        // :342,:344  bins mr..168
     if (ir < 0) { R.status = MVOSR_ST_ERR_RIGHT; return R; }
     const double right = bin_edge(ir + 1);
-    const double sd = sqrt(ss / cntd);                                          // np.std
-    const double skew = (mean - mode / 10.0) / sd;                              // :496
-    R.mean = mean; R.std = sd; R.skew = skew;
+    double mean_o = mean;
+    double sd = sqrt(ss / cntd);                                                // np.std
+    // The sums above run in the wavefront's order, NumPy's in its pairwise order: mean and std agree to
+    // ~1e-15 relative, which decides `skew > 0.3` the same way unless the two sides are that close — in
+    // practice only for (nearly) constant lists, where std is rounding noise.  Then, and when exact
+    // statistics are asked for, both sums are redone in NumPy's own order on the packed list.
+    {
+        const double var = ss / cntd, rms = sqrt(mean * mean + var);
+        const double margin = fabs((mean - mode / 10.0) - P.skew_threshold * sd);
+        const double bound = 1e-11 * (rms + sd) + 1e-22 * rms * rms / sd;
+        if (!(margin > bound) || exact_stats) {
+            const int nl = pack_kept();
+            __threadfence_block();               // the wave's own stores, visible to all its lanes
+            mean_o = np_pairwise_sum_cold(scratch, nl, 0.0, 0) / (double)nl;    // np.mean
+            sd = sqrt(np_pairwise_sum_cold(scratch, nl, mean_o, 1) / (double)nl);
+        }
+    }
+    const double skew = (mean_o - mode / 10.0) / sd;                            // :496
+    R.mean = mean_o; R.std = sd; R.skew = skew;
     if (skew > P.skew_threshold) { R.height = right; R.status = MVOSR_ST_RIGHT; }   // :348-352
     else { R.height = mode / 10.0; R.status = MVOSR_ST_MODE; }                      // :354
     return R;
@@ -735,7 +827,7 @@ __global__ __launch_bounds__(kRoadWaves *kWave, MVOSR_ROAD_MINW) void road_model
     MVOSR_RSTAMP(1);
     const RoadResult R = road_wave(hist_all[wave_id()][0], hist_all[wave_id()][1], slots_all[wave_id()], drop_all[wave_id()], edges,
                                    a.y + off, a.scratch + off, M, hl, a.P,
-                                   a.o.hist ? a.o.hist + f * 2 * kBins : nullptr MVOSR_STAMP_PASS);
+                                   a.o.hist ? a.o.hist + f * 2 * kBins : nullptr, a.o.stats != nullptr MVOSR_STAMP_PASS);
     MVOSR_RSTAMP(6);
 #ifdef MVOSR_STAMPS
     if (lane_id() == 0 && a.o.hist) { unsigned long long *d = reinterpret_cast<unsigned long long *>(a.o.hist + f * 2 * kBins) + 16; for (int i = 0; i < 8; ++i) d[i] = stamps[i]; }

@@ -111,3 +111,51 @@ def checksum(*arrays) -> int:
     for a in arrays:
         c = zlib.crc32(np.ascontiguousarray(a).tobytes(), c)
     return c
+
+
+def road_fuzz_list(i: int, seed: int = 777) -> np.ndarray:
+    """The i-th list of y values of the road-model fuzz set (tests/golden/road_fuzz.npz holds what
+    the reference's ``road_model_calculation_static`` returns for each): ten families aimed at the
+    corners of `/root/reference/src/scale_calculator.py:284-354,428-497` — values exactly on bin
+    edges, bins of count one next to modes, mode candidates around the 0.33*max and >=2 thresholds,
+    several clusters, out-of-range values, very short lists and lists longer than the kernel's
+    register cache (1024 values)."""
+    rng = np.random.default_rng([seed, i])
+    kind = i % 10
+    if kind == 0:
+        y = rng.normal(rng.uniform(0.4, 3.0), rng.uniform(0.03, 0.4), int(rng.integers(5, 900)))
+    elif kind == 1:
+        m = int(rng.integers(20, 700))
+        y = np.concatenate([rng.normal(1.7, 0.06, m), 1.7 + rng.exponential(rng.uniform(0.2, 1.5), m // 2)])
+    elif kind == 2:
+        y = rng.uniform(-1.0, 18.0, int(rng.integers(5, 1200)))
+    elif kind == 3:
+        y = np.round(rng.normal(rng.uniform(0.5, 2.5), rng.uniform(0.1, 0.6), int(rng.integers(5, 600))), 1)
+    elif kind == 4:
+        y = rng.uniform(0.0, 3.0, int(rng.integers(1, 7)))
+    elif kind == 5:
+        m = int(rng.integers(1030, 2600))
+        y = np.concatenate([rng.normal(1.72, rng.uniform(0.02, 0.15), m), rng.uniform(0.0, 16.9, m // 20)])
+    elif kind == 6:
+        centres = np.sort(rng.choice(np.arange(3, 60), size=int(rng.integers(2, 5)), replace=False)) * 0.1 + 0.05
+        top = int(rng.integers(6, 40))
+        parts = []
+        for c in centres:
+            k = int(max(1, round(top * rng.choice([1.0, 0.34, 0.33, 0.32, 0.5, 0.1]))))
+            parts.append(np.full(k, c) + rng.uniform(-0.04, 0.04, k))
+        y = np.concatenate(parts)
+    elif kind == 7:
+        k = rng.integers(0, 170, int(rng.integers(5, 300))).astype(np.float64)
+        y = k * 0.1
+        nudge = rng.integers(0, 3, y.size)
+        y = np.where(nudge == 1, np.nextafter(y, np.inf), np.where(nudge == 2, np.nextafter(y, -np.inf), y))
+    elif kind == 8:
+        base = np.repeat(rng.choice(np.arange(2, 40), size=int(rng.integers(2, 6)), replace=False) * 0.1 + 0.05,
+                         int(rng.integers(3, 12)))
+        singles = rng.choice(np.arange(0, 60), size=int(rng.integers(1, 12)), replace=False) * 0.1 + rng.uniform(0.0, 0.1)
+        y = np.concatenate([base + rng.uniform(-0.049, 0.049, base.size), singles])
+    else:
+        y = np.full(int(rng.integers(1, 50)), rng.choice([0.85, 0.3, 16.9, 0.0, 1.7000000000000002]))
+    y = np.asarray(y, dtype=np.float64)
+    rng.shuffle(y)
+    return y

@@ -225,6 +225,53 @@ def test_road_cases_kernel(gpu):
         db.free()
 
 
+def test_road_fuzz_kernel(gpu):
+    """K3 alone on the 800 generated lists of tests/golden/road_fuzz.npz: status and height against
+    the reference's outputs, histogram / kept count / modes against the oracle."""
+    from mvoscalerecovery_amd import packing, synth
+    from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs, ScaleEngine
+    so = _oracle()
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "road_fuzz.npz"))
+    seed, F = int(z["seed"]), len(z["heights"])
+    lists = [synth.road_fuzz_list(i, seed) for i in range(F)]
+    cnt = np.array([len(y) for y in lists], dtype=np.int32)
+    padded = (cnt.astype(np.int64) + 1) & ~np.int64(1)
+    off = np.concatenate([[0], np.cumsum(padded)[:-1]]).astype(np.int64)
+    y = np.zeros(int(padded.sum()), dtype=np.float64)
+    for i, v in enumerate(lists):
+        y[off[i]:off[i] + cnt[i]] = v
+    pf = packing.PackedFrames(F, off, cnt, y.copy(), y, y.copy(), y.copy(), y.copy(), [None] * F, max_feat=int(cnt.max()))
+    hl = 0.5 + 0.001 * np.arange(F)
+    eng = ScaleEngine(1.75, ctx=gpu)
+    db = DeviceBatch(gpu, pf, with_tri2=False)
+    # with the statistics output the sums are made in NumPy's own order: mean / std / skew bit-equal
+    out = DeviceOutputs(gpu, db, counts=True, hist=True)
+    eng.road_model_batch(db, out, hl)
+    st, h = out.get("status"), out.get("height")
+    counts, hist, stats = out.get("counts"), out.get("hist"), out.get("stats")
+    # without it the wavefront's own summation order decides, NumPy's only where the two could differ
+    out2 = DeviceOutputs(gpu, db, counts=True)
+    eng.road_model_batch(db, out2, hl)
+    st2, h2 = out2.get("status"), out2.get("height")
+    n_stats = 0
+    for i in range(F):
+        rm = so.road_model(lists[i], hl[i])
+        assert st[i] == rm.status and st2[i] == rm.status, (i, st[i], st2[i], rm.status)
+        assert np.array_equal(hist[i, 0], rm.hist_raw), i
+        assert counts[i, 4] == rm.n_kept, i
+        if z["raises"][i]:
+            assert st[i] in (so.ST_ERR_LEFT, so.ST_ERR_RIGHT), i
+        else:
+            assert h[i] == z["heights"][i] and h2[i] == z["heights"][i], (i, h[i], h2[i], z["heights"][i])
+        if rm.status in (so.ST_MODE, so.ST_RIGHT):
+            n_stats += 1
+            assert np.array_equal(stats[i, :3], [rm.mean, rm.std, rm.skew], equal_nan=True), (i, stats[i], rm.mean, rm.std, rm.skew)
+    assert n_stats > 300
+    out.free()
+    out2.free()
+    db.free()
+
+
 def test_window_median_kernel(gpu):
     from mvoscalerecovery_amd.engine import ScaleEngine
     so = _oracle()

@@ -1,5 +1,7 @@
 """The CPU oracle against golden vectors produced by the reference itself
 (tests/golden/make_golden.py).  Runs without a GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -76,6 +78,26 @@ def test_road_cases():
             assert rm.status in (so.ST_MODE, so.ST_RIGHT, so.ST_MEDIAN, so.ST_LEVEL), name
             assert rm.height == c["height"], (name, rm.height, c["height"])
     assert {so.ST_MODE, so.ST_RIGHT, so.ST_MEDIAN, so.ST_LEVEL, so.ST_ERR_LEFT, so.ST_ERR_RIGHT} <= seen
+
+
+def test_road_fuzz_golden():
+    """800 generated lists (synth.road_fuzz_list) against what the reference returned for them
+    (tests/golden/road_fuzz.npz, made by make_golden.py --sets road_fuzz): heights bit-equal, IndexError
+    where the reference raised."""
+    from mvoscalerecovery_amd import synth
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "road_fuzz.npz"))
+    seed = int(z["seed"])
+    statuses = set()
+    for i in range(len(z["heights"])):
+        y = synth.road_fuzz_list(i, seed)
+        assert len(y) == z["sizes"][i] and float(np.sum(y)) == z["sums"][i], i
+        rm = so.road_model(y, 0.5 + 0.001 * i)
+        statuses.add(rm.status)
+        if z["raises"][i]:
+            assert rm.status in (so.ST_ERR_LEFT, so.ST_ERR_RIGHT), i
+        else:
+            assert rm.status <= so.ST_LEVEL and rm.height == z["heights"][i], (i, rm.status, rm.height, z["heights"][i])
+    assert {so.ST_MODE, so.ST_RIGHT, so.ST_MEDIAN, so.ST_LEVEL, so.ST_ERR_LEFT, so.ST_ERR_RIGHT} <= statuses
 
 
 def test_histogram_restatement_equals_numpy():
