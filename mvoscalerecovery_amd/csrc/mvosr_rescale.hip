@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kRsBlock) void graph_inliers_kernel(const GraphArgs
 // flat_selection: per triangle n = A^-1 . 1 (LU, like np.matrix.I), heights = 1/|n|,
 // pitch = asin(-n_y/|n|) deg; level = 0.9 * median(heights[pitch < -80]); a triangle is kept when
 // pitch < -85 and heights > level.  The median is the mean of the two middle order statistics,
-// found by rank counting over the list of loose heights in LDS.
+// found by radix selection over the list of loose heights in LDS.
 // ---------------------------------------------------------------------------------------------
 struct FlatArgs {
     int64_t n_frames;
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
     double *Y = X + npad;
     double *Z = Y + npad;
     double *L = Z + npad;                                        // loose heights, up to tn
-    int *misc = reinterpret_cast<int *>(L + tn);
-    double *med = reinterpret_cast<double *>(misc + 8);
+    int *misc = reinterpret_cast<int *>(L + tn);                 // 16 scalars + 256 histogram bins
+    double *med = reinterpret_cast<double *>(misc + 16 + 256);
     if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0; misc[3] = 0; }
     for (int i = tid; i < n; i += kRsBlock) { X[i] = a.x[off + i]; Y[i] = a.y[off + i]; Z[i] = a.z[off + i]; }
     __syncthreads();
@@ -140,19 +140,62 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
     }
     __syncthreads();
     const int k = misc[0];
+    double level = nan("");                                      // median of an empty set is nan (nothing passes)
     if (k > 0) {                                                                         // np.median, :91
+        // the two middle order statistics by radix selection on the bit patterns (heights are >= 0, so the
+        // patterns order like the values): eight passes of a 256-bin histogram over the candidates that
+        // still share the prefix found so far
         const int klo = (k - 1) >> 1, khi = k >> 1;
-        for (int i = tid; i < k; i += kRsBlock) {
-            const double hi = L[i];
-            int rank = 0;
-            for (int j = 0; j < k; ++j) { const double hj = L[j]; rank += (hj < hi) || (hj == hi && j < i); }
-            if (rank == klo) med[0] = hi;
-            if (rank == khi) med[1] = hi;
+        const unsigned long long *LU = reinterpret_cast<const unsigned long long *>(L);
+        int *hist = misc + 16;                                   // 256 bins
+        unsigned long long prefix = 0ull;
+        int rank = klo;                                          // rank of the wanted value among the candidates
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < k; i += kRsBlock) {
+                const unsigned long long u = LU[i];
+                if (shift == 56 || (u >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(int)((u >> shift) & 255ull)], 1);
+            }
+            __syncthreads();
+            if (tid < kWave) {                                   // wave 0: digit whose cumulative count passes the rank
+                const int b0 = hist[4 * tid], b1 = hist[4 * tid + 1], b2 = hist[4 * tid + 2], b3 = hist[4 * tid + 3];
+                int incl = (b0 + b1) + (b2 + b3);
+#pragma unroll
+                for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (tid >= o) incl += up; }
+                const int excl = incl - ((b0 + b1) + (b2 + b3));
+                if (rank >= excl && rank < incl) {               // exactly one lane
+                    int r = rank - excl, dgt = 4 * tid;
+                    if (r >= b0) { r -= b0; ++dgt; if (r >= b1) { r -= b1; ++dgt; if (r >= b2) { r -= b2; ++dgt; } } }
+                    misc[4] = dgt; misc[5] = r;
+                }
+            }
+            __syncthreads();
+            prefix |= (unsigned long long)misc[4] << shift;
+            rank = misc[5];
+            __syncthreads();
         }
+        const double vlo = __longlong_as_double((long long)prefix);
+        double vhi = vlo;
+        if (khi != klo) {
+            // the next order statistic: vlo again if it occurs often enough, else the smallest value above it
+            unsigned long long *mn = reinterpret_cast<unsigned long long *>(med);
+            if (tid == 0) { misc[6] = 0; *mn = ~0ull; }
+            __syncthreads();
+            int le = 0;
+            unsigned long long above = ~0ull;
+            for (int i = tid; i < k; i += kRsBlock) {
+                const unsigned long long u = LU[i];
+                if (u <= prefix) ++le; else above = u < above ? u : above;
+            }
+            le = wave_sum(le);
+            if (lane_id() == 0) atomicAdd(&misc[6], le);
+            atomicMin(mn, above);
+            __syncthreads();
+            if (misc[6] < khi + 1) vhi = __longlong_as_double((long long)*mn);
+        }
+        level = a.height_factor * ((klo == khi) ? vlo : (vlo + vhi) / 2.0);
     }
-    __syncthreads();
-    const double level = (k > 0) ? a.height_factor * ((((k - 1) >> 1) == (k >> 1)) ? med[0] : (med[0] + med[1]) / 2.0)
-                                 : nan("");                      // median of an empty set is nan (nothing passes)
     int kept = 0;
     for (int t = tid; t < tn; t += kRsBlock) {
         const uint8_t fl = a.tri_flags[tb + t];
@@ -169,11 +212,11 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
 }
 
 // ---------------------------------------------------------------------------------------------
-// RANSAC plane fit with the sample triples given (ransac.py:3-23).  One workgroup per frame; a wave
-// takes hypotheses w, w+8, ...: the plane through its three sample points as the unit 4-vector
-// (n, d)/|(n, d)| — the null vector the reference gets from the SVD of [x y z 1]
-// (estimate_road_norm.py:13-15), up to sign — and all 64 lanes count |m.[p,1]| < threshold over the
-// frame's points (estimate_road_norm.py:17-18).  One lane then replays the reference's sequential
+// RANSAC plane fit with the sample triples given (ransac.py:3-23).  One workgroup per frame; every
+// hypothesis is the plane through its three sample points as the unit 4-vector (n, d)/|(n, d)| — the
+// null vector the reference gets from the SVD of [x y z 1] (estimate_road_norm.py:13-15), up to sign
+// — and |m.[p,1]| < threshold is counted over the frame's points (estimate_road_norm.py:17-18), the
+// points held in registers, the hypotheses streamed from LDS.  One lane then replays the reference's sequential
 // rule: a hypothesis replaces the best when its count is strictly larger, and the loop stops at
 // the first such improvement that exceeds the goal.
 // ---------------------------------------------------------------------------------------------
@@ -190,21 +233,24 @@ struct RansacArgs {
 };
 constexpr int kMaxHyp = 512;
 
+constexpr int kRansacPPT = 8;           // points per thread per chunk (chunks of 4096 points)
+
 __global__ __launch_bounds__(kRsBlock) void ransac_plane_kernel(const RansacArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = blockIdx.x;
     const int M = a.pts_cnt[f];
     const int64_t off = a.pts_off[f];
     const int H = a.n_hyp;
-    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    int *cnts = reinterpret_cast<int *>(smem);                            // [H]
-    double *mods = reinterpret_cast<double *>(smem + 4u * (uint32_t)((H + 3) & ~3));   // [H][4]
+    const int tid = threadIdx.x, lane = lane_id();
+    double4 *mods = reinterpret_cast<double4 *>(smem);                    // [H] unit (n, d)
+    int *cnts = reinterpret_cast<int *>(mods + H);                        // [H] inlier counts
     if (M <= 0) {
         if (tid == 0) { a.best_ic[f] = 0; a.used[f] = 0; for (int k = 0; k < 4; ++k) a.model[4 * f + k] = nan(""); }
         return;
     }
     const double *px = a.px + off, *py = a.py + off, *pz = a.pz + off;
-    for (int h = w; h < H; h += kRsWaves) {
+    // the hypotheses' planes, one thread each
+    for (int h = tid; h < H; h += kRsBlock) {
         const int32_t *t = a.triples + ((int64_t)f * H + h) * 3;
         const int i0 = t[0], i1 = t[1], i2 = t[2];
         const double x0 = px[i0], y0 = py[i0], z0 = pz[i0];
@@ -213,18 +259,35 @@ __global__ __launch_bounds__(kRsBlock) void ransac_plane_kernel(const RansacArgs
         double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
         double d = -((nx * x0 + ny * y0) + nz * z0);
         const double inv = 1.0 / sqrt(((nx * nx + ny * ny) + nz * nz) + d * d);
-        nx *= inv; ny *= inv; nz *= inv; d *= inv;
-        int ic = 0;
-        for (int j = lane; j < M; j += kWave)
-            ic += fabs(((px[j] * nx + py[j] * ny) + pz[j] * nz) + d) < a.threshold;          // estimate_road_norm.py:18
-        ic = wave_sum(ic);
-        if (lane == 0) {
-            cnts[h] = ic;
-            mods[4 * h] = nx; mods[4 * h + 1] = ny; mods[4 * h + 2] = nz; mods[4 * h + 3] = d;
-            if (a.counts) a.counts[(int64_t)f * H + h] = ic;
+        double4 m; m.x = nx * inv; m.y = ny * inv; m.z = nz * inv; m.w = d * inv;
+        mods[h] = m;
+        cnts[h] = 0;
+    }
+    __syncthreads();
+    // Every thread keeps up to kRansacPPT points in registers (read from HBM once, coalesced) and the
+    // hypotheses stream past them from LDS (wave-uniform reads); a hypothesis' inliers among a
+    // wavefront's points are counted on the scalar unit (ballot + popcount), one LDS add per wave.
+    for (int c0 = 0; c0 < M; c0 += kRsBlock * kRansacPPT) {
+        double qx[kRansacPPT], qy[kRansacPPT], qz[kRansacPPT];
+#pragma unroll
+        for (int k = 0; k < kRansacPPT; ++k) {
+            const int j = c0 + k * kRsBlock + tid;
+            const int jc = min(j, M - 1);
+            qx[k] = px[jc]; qy[k] = py[jc]; qz[k] = pz[jc];
+            if (j >= M) qx[k] = nan("");                         // never an inlier: no masks or branches in the loop below
+        }
+#pragma unroll 4
+        for (int h = 0; h < H; ++h) {
+            const double4 m = mods[h];
+            int ic = 0;
+#pragma unroll
+            for (int k = 0; k < kRansacPPT; ++k)
+                ic += __popcll(__ballot(fabs(((qx[k] * m.x + qy[k] * m.y) + qz[k] * m.z) + m.w) < a.threshold));   // estimate_road_norm.py:18
+            if (lane == 0 && ic) atomicAdd(&cnts[h], ic);
         }
     }
     __syncthreads();
+    if (a.counts) for (int h = tid; h < H; h += kRsBlock) a.counts[(int64_t)f * H + h] = cnts[h];
     if (tid == 0) {
         const double goal = (double)M * a.goal_fraction;                  // estimate_road_norm.py:68
         int best = -1, best_ic = 0, used = 0;
@@ -238,8 +301,9 @@ __global__ __launch_bounds__(kRsBlock) void ransac_plane_kernel(const RansacArgs
         a.best_ic[f] = best_ic; a.used[f] = used;
         double m[4] = {nan(""), nan(""), nan(""), nan("")};
         if (best >= 0) {
-            const double sgn = (mods[4 * best + 1] < 0.0) ? -1.0 : 1.0;   // rescale.py:159-161
-            for (int k = 0; k < 4; ++k) m[k] = sgn * mods[4 * best + k];
+            const double4 bm = mods[best];
+            const double sgn = (bm.y < 0.0) ? -1.0 : 1.0;                 // rescale.py:159-161
+            m[0] = sgn * bm.x; m[1] = sgn * bm.y; m[2] = sgn * bm.z; m[3] = sgn * bm.w;
         }
         for (int k = 0; k < 4; ++k) a.model[4 * f + k] = m[k];
     }
@@ -375,7 +439,7 @@ int mvosr_flat_selection_batch(mvosr_ctx *ctx, const mvosr_batch *b, double loos
     a.tri_off = b->tri2_off; a.tri = b->tri2; a.loose_deg = loose_deg; a.tight_deg = tight_deg; a.height_factor = height_factor;
     a.tri_height = tri_height; a.tri_flags = tri_flags; a.height_level = height_level; a.status = status; a.n_kept = n_kept;
     if (max_tri <= 0) max_tri = 2 * (int64_t)b->max_feat;
-    const size_t lds = 24u * (size_t)((b->max_feat + 1) & ~1) + 8u * (size_t)max_tri + 64;
+    const size_t lds = 24u * (size_t)((b->max_feat + 1) & ~1) + 8u * (size_t)max_tri + 4u * (16 + 256) + 16;
     if ((rc = rs_prepare(flat_selection_kernel, lds))) return rc;
     hipLaunchKernelGGL(flat_selection_kernel, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
     return check_launch("flat_selection_kernel");
@@ -395,7 +459,7 @@ int mvosr_ransac_plane_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pt
     a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.px = px; a.py = py; a.pz = pz; a.triples = triples;
     a.n_hyp = n_hyp; a.threshold = threshold; a.goal_fraction = goal_fraction; a.counts = counts; a.model = model;
     a.best_ic = best_ic; a.used = used;
-    const size_t lds = 4u * (size_t)((n_hyp + 3) & ~3) + 32u * (size_t)n_hyp + 16;
+    const size_t lds = 36u * (size_t)n_hyp + 16;
     hipLaunchKernelGGL(ransac_plane_kernel, dim3((unsigned)n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
     return check_launch("ransac_plane_kernel");
 }
