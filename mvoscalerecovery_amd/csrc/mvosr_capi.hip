@@ -54,18 +54,18 @@ int ctx_workspace(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat, double *
     return MVOSR_OK;
 }
 
-int ctx_workspace_dense(mvosr_ctx *ctx, int64_t total_feat, void *planes[4]) {
+int ctx_workspace_dense(mvosr_ctx *ctx, int64_t total_feat, void *planes[2]) {
     if ((size_t)total_feat > ctx->ws_dense_len) {
         (void)hipStreamSynchronize(ctx->stream);
-        for (int i = 0; i < 4; ++i) { if (ctx->ws_dense[i]) (void)hipFree(ctx->ws_dense[i]); ctx->ws_dense[i] = nullptr; }
+        for (int i = 0; i < 2; ++i) { if (ctx->ws_dense[i]) (void)hipFree(ctx->ws_dense[i]); ctx->ws_dense[i] = nullptr; }
         ctx->ws_dense_len = 0;
-        for (int i = 0; i < 4; ++i) {
-            hipError_t e = hipMalloc(&ctx->ws_dense[i], (size_t)total_feat * (i < 2 ? 16 : 8));
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipMalloc(&ctx->ws_dense[i], (size_t)total_feat * (i == 0 ? 16 : 8));
             if (e != hipSuccess) return set_hip_error("hipMalloc(workspace: dense-frame planes)", e);
         }
         ctx->ws_dense_len = (size_t)total_feat;
     }
-    for (int i = 0; i < 4; ++i) planes[i] = ctx->ws_dense[i];
+    for (int i = 0; i < 2; ++i) planes[i] = ctx->ws_dense[i];
     return MVOSR_OK;
 }
 
@@ -109,7 +109,7 @@ int mvosr_ctx_create(int device, mvosr_ctx **out) {
     if (e != hipSuccess) { delete ctx; return set_hip_error("hipStreamCreateWithFlags", e); }
     ctx->stream = ctx->own_stream;
     ctx->prof_on = 0; ctx->prof_calls = 0;
-    for (int i = 0; i < 4; ++i) ctx->ws_dense[i] = nullptr;
+    for (int i = 0; i < 2; ++i) ctx->ws_dense[i] = nullptr;
     ctx->ws_dense_len = 0;
     for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) ctx->prof_ev[i][j] = nullptr;
     ctx->ws_ysel = nullptr; ctx->ws_ysel_len = 0; ctx->ws_nsel = nullptr; ctx->ws_nsel_len = 0;
@@ -130,7 +130,7 @@ int mvosr_ctx_destroy(mvosr_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) if (ctx->prof_ev[i][j]) (void)hipEventDestroy(ctx->prof_ev[i][j]);
-    for (int i = 0; i < 4; ++i) if (ctx->ws_dense[i]) (void)hipFree(ctx->ws_dense[i]);
+    for (int i = 0; i < 2; ++i) if (ctx->ws_dense[i]) (void)hipFree(ctx->ws_dense[i]);
     if (ctx->ws_ysel) (void)hipFree(ctx->ws_ysel);
     if (ctx->ws_nsel) (void)hipFree(ctx->ws_nsel);
     (void)hipStreamDestroy(ctx->own_stream);

@@ -969,13 +969,13 @@ __global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // Dense frames (more features than fit LDS in fp64, e.g. N = 20000): same algorithm, but the
-// remapped planes live in a per-frame workspace in global memory and the triangle sweeps gather
-// from it through L1/L2 ("L2-gather variant").  LDS keeps only what is hit by atomics: the 16-bit
+// triangle sweeps gather through L1/L2 ("L2-gather variant"): the vote from the caller's planes
+// (remap on the fly), the selection from the compacted survivors' planes in a per-frame workspace.  LDS keeps only what is hit by atomics: the 16-bit
 // vote counters and the selected bit-set.  One workgroup of 16 wavefronts per frame (128 flag bits per
 // thread: up to 131072 triangles, i.e. the 65535-feature limit of the 16-bit counters' index space).  Survivors are
 // compacted into a second workspace copy (no in-place hazard, no registers held across barriers).
 // ---------------------------------------------------------------------------------------------
-struct DenseWs { double2 *P, *P2; double *Y, *Y2; };      // per-batch planes laid out like x (feat_off)
+struct DenseWs { double2 *P2; double *Y2; };      // per-batch planes of the survivors, laid out like x (feat_off)
 
 __host__ __device__ inline uint32_t dense_lds_bytes(int n, int waves) {
     const uint32_t npad = (uint32_t)((n + 1) & ~1);
@@ -986,24 +986,23 @@ template <int DW, bool FUSED>
 __device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n, const double *gx, const double *gy, const double *gz,
                                                 const double *gv, const int32_t *tri1, int64_t t1_begin, int t1_count,
                                                 double cp, double sp, int32_t *g_counters, int &bad,
-                                                double2 *P, double *Y, double2 *P2, double *Y2) {
+                                                double2 *P2, double *Y2) {
     constexpr int B = DW * kWave;
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
     const uint16_t *c16 = reinterpret_cast<const uint16_t *>(c32);
     const uint32_t ones = ((uint32_t)(kCounterBias + 1) << 16) | (uint32_t)(kCounterBias + 1);     // np.ones, :153
-    for (int i = tid; i < n; i += B) {
-        const double yy = gy[i], zz = gz[i];
-        double2 pv; pv.x = gv[i]; pv.y = yy * sp + zz * cp;                // :392
-        P[i] = pv;
-        Y[i] = yy * cp - zz * sp;                                          // :391
-    }
     for (int i = tid; i < ((n + 1) >> 1); i += B) c32[i] = ones;
     __threadfence_block();
     __syncthreads();
     for (int t = tid; t < t1_count; t += B) {
         const TriIds q = load_tri(tri1 + 3 * t1_begin, t);
         if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
-        const double2 p0 = P[q.a], p1 = P[q.b], p2 = P[q.c];              // {v, z'} through L1/L2
+        // {v, z'} gathered from the caller's planes through L1/L2, remap (:392) on the fly: a staged copy
+        // would cost a write and two more reads of every feature in HBM traffic
+        double2 p0, p1, p2;
+        p0.x = gv[q.a]; p0.y = gy[q.a] * sp + gz[q.a] * cp;
+        p1.x = gv[q.b]; p1.y = gy[q.b] * sp + gz[q.b] * cp;
+        p2.x = gv[q.c]; p2.y = gy[q.c] * sp + gz[q.c] * cp;
         const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
         const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
         const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
@@ -1039,9 +1038,10 @@ __device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n,
             const unsigned long long m = __ballot(keep);
             if (keep) {
                 const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                double2 pv; pv.x = gx[i]; pv.y = P[i].y;
-                P2[pos] = pv;                                                 // {x, z'} of the survivor (:264-265)
-                Y2[pos] = Y[i];
+                const double yy = gy[i], zz = gz[i];
+                double2 pv; pv.x = gx[i]; pv.y = yy * sp + zz * cp;           // {x, z'} of the survivor (:264-265, :392)
+                P2[pos] = pv;
+                Y2[pos] = yy * cp - zz * sp;                                  // :391
             }
             base += __popcll(m);
         }
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const Den
     int bad = 0;
     const int nvalid = phase_vote_dense<DW, true>(s.c32, s.misc, n, a.b.x + off, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
                                               a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad,
-                                              da.ws.P + off, da.ws.Y + off, da.ws.P2 + off, da.ws.Y2 + off);
+                                              da.ws.P2 + off, da.ws.Y2 + off);
     const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
     SelectResult S;
     S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 1;
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(DW *kWave) void outlier_vote_dense_kernel(const Den
     int bad = 0;
     const int nvalid = phase_vote_dense<DW, false>(c32, misc, n, nullptr, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
                                                a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters + off, bad,
-                                               da.ws.P + off, da.ws.Y + off, nullptr, nullptr);
+                                               nullptr, nullptr);
     int b0 = bad, b1 = 0, b2 = 0, b3 = 0;
     block_sum4i<DW>(b0, b1, b2, b3, red + R_MISC * 2 * DW);
     if (threadIdx.x == 0) {
@@ -1335,7 +1335,7 @@ static int launch_vote(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
     return check_launch("outlier_vote_kernel");
 }
 
-// dense frames: planes in a global workspace (48 B per feature), 16 wavefronts per frame.  (8 wavefronts
+// dense frames: survivors' planes in a global workspace (24 B per feature), 16 wavefronts per frame.  (8 wavefronts
 // per frame, three workgroups per CU, measured the same: the sweeps are bound by L2 gather traffic, not occupancy.)
 constexpr int kDenseWaves = 16;
 
@@ -1348,11 +1348,13 @@ static int launch_scale_dense_w(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, boo
         return set_error(MVOSR_ERR_TOO_LARGE, "frame of %d features needs %zu B of LDS (> %d)", ka.b.max_feat, lds, g_max_dyn_lds);
     DenseArgs da;
     da.k = ka;
-    void *p[4];
-    int rc = ctx_workspace_dense(ctx, ka.b.total_feat, p);
-    if (rc) return rc;
-    da.ws.P = reinterpret_cast<double2 *>(p[0]); da.ws.P2 = reinterpret_cast<double2 *>(p[1]);
-    da.ws.Y = reinterpret_cast<double *>(p[2]); da.ws.Y2 = reinterpret_cast<double *>(p[3]);
+    da.ws.P2 = nullptr; da.ws.Y2 = nullptr;
+    int rc = MVOSR_OK;
+    if (!vote_only) {                             // the vote alone needs no workspace
+        void *p[2];
+        if ((rc = ctx_workspace_dense(ctx, ka.b.total_feat, p))) return rc;
+        da.ws.P2 = reinterpret_cast<double2 *>(p[0]); da.ws.Y2 = reinterpret_cast<double *>(p[1]);
+    }
     if (vote_only) {
         if ((rc = prepare_kernel(outlier_vote_dense_kernel<DW>, lds))) return rc;
         hipLaunchKernelGGL((outlier_vote_dense_kernel<DW>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
