@@ -65,7 +65,7 @@ def build_pool(ctx, engine, n_features, pool, seed):
     out.free()
     db.free()
     t0 = time.perf_counter()
-    packing.attach_tri2(pf, None, masks)
+    packing.attach_tri2(pf, None, masks, feature_ids=n_features > cap)    # dense: rows numbered over the features (no compaction)
     t_del2 = time.perf_counter() - t0
     return frames, pf, masks, (t_del1 + t_del2) / pool
 
@@ -161,7 +161,7 @@ def main():
                          rep("v", pf_pool.v, np.float64),
                          offs("tri1_off", pf_pool.tri1_off[:-1], t1p, True), rep("tri1", pf_pool.tri1[:t1p].reshape(-1), np.int32),
                          offs("tri2_off", pf_pool.tri2_off[:-1], t2p, True), rep("tri2", pf_pool.tri2[:t2p].reshape(-1), np.int32),
-                         rep("n2", pf_pool.n2_expected, np.int32), pf_pool.max_feat, 0, pool_pad * repeats)
+                         rep("n2", pf_pool.n2_expected, np.int32), pf_pool.max_feat, int(pf_pool.tri2_ids), pool_pad * repeats)
     bytes_per_launch = pf_pool.algorithmic_bytes() * repeats
     n_mean = float(pf_pool.feat_cnt.mean())
     t1_mean = float(pf_pool.tri1_off[-1]) / pool

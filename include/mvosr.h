@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MVOSR_ABI_VERSION 1
+#define MVOSR_ABI_VERSION 2
 
 /* error codes (function return values) */
 enum mvosr_err {
@@ -96,6 +96,9 @@ typedef struct mvosr_params {
  * vanishing-row filter (:252-254), stored as planes (structure of arrays) with the frames'
  * segments back to back; segment starts are even (16-byte aligned doubles).  x/y/z are the
  * caller's raw feature3d columns — feature_remap (:390-394) is applied by the kernels at load. */
+#define MVOSR_TRI2_SURVIVORS 0
+#define MVOSR_TRI2_FEATURES 1
+
 typedef struct mvosr_batch {
     int64_t n_frames;
     const int64_t *feat_off;     /* [F]   start of frame f in x/y/z/v (multiple of 2)          */
@@ -110,7 +113,11 @@ typedef struct mvosr_batch {
     const int32_t *n2_expected;  /* [F] or NULL: number of points tri2 was built on; a frame whose
                                     vote keeps a different number gets MVOSR_ST_ERR_MASK        */
     int32_t max_feat;            /* max(feat_cnt) — sizes the LDS request                      */
-    int32_t reserved;
+    int32_t tri2_ids;            /* MVOSR_TRI2_SURVIVORS (0): tri2 as SciPy returns it, ids index the survivors;
+                                    MVOSR_TRI2_FEATURES (1): the same rows relabelled to index the frame's features
+                                    (every vertex a survivor, else MVOSR_ST_ERR_MASK) — the frames then run the
+                                    gather variant without compacting, whatever their size (meant for dense frames:
+                                    a quarter less HBM traffic; results identical)                              */
     int64_t total_feat;          /* length (elements) of the x/y/z/v planes: feat_off[F-1] + padded
                                     count of the last frame; sizes the context's workspace      */
 } mvosr_batch;

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
+TRI2_SURVIVORS, TRI2_FEATURES = 0, 1      # mvosr_batch.tri2_ids
 N_COUNTS = 8
 HIST_BINS = 169
 
@@ -31,7 +32,7 @@ class Batch(C.Structure):
     _fields_ = [("n_frames", C.c_int64), ("feat_off", C.c_void_p), ("feat_cnt", C.c_void_p),
                 ("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("v", C.c_void_p),
                 ("tri1_off", C.c_void_p), ("tri1", C.c_void_p), ("tri2_off", C.c_void_p), ("tri2", C.c_void_p),
-                ("n2_expected", C.c_void_p), ("max_feat", C.c_int32), ("reserved", C.c_int32),
+                ("n2_expected", C.c_void_p), ("max_feat", C.c_int32), ("tri2_ids", C.c_int32),
                 ("total_feat", C.c_int64)]
 
 

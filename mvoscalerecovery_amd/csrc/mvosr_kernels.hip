@@ -1156,6 +1156,154 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const Den
     dense_tail<DW>(a, s, f, off, nvalid, mask_mismatch, S, R);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense frames whose second triangulation is numbered over the frame's FEATURES
+// (mvosr_batch.tri2_ids == MVOSR_TRI2_FEATURES; the host relabels SciPy's rows with the vote mask
+// it already holds).  Nothing is compacted and no workspace is touched: both selection sweeps
+// gather x, y, z from the caller's planes and remap on the fly, the vote counters stay in LDS to
+// check that every vertex is a survivor, and the selected bit-set is indexed by feature.  HBM
+// traffic: the planes twice (two gather sweeps) and the triangle rows — about a quarter less than
+// the variant that writes and re-reads the survivors' planes.
+// ---------------------------------------------------------------------------------------------
+template <int DW, bool FULL>
+__global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(const DenseArgs da) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KArgs &a = da.k;
+    constexpr int B = DW * kWave;
+    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    const int64_t f = a.first_frame + blockIdx.x;
+    const int n = a.b.feat_cnt[f];
+    const int64_t off = a.b.feat_off[f];
+    const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
+    const int t1n = (int)(a.b.tri1_off[f + 1] - t1b), t2n = (int)(a.b.tri2_off[f + 1] - t2b);
+    RoadResult R;
+    R.height = nan(""); R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
+    R.mean = R.std = R.skew = R.median = nan("");
+    if (n <= 0 || t2n <= 0) {
+        if (tid == 0) {
+            a.o.raw_scale[f] = nan(""); a.o.height[f] = nan(""); a.o.height_level[f] = nan("");
+            a.o.status[f] = MVOSR_ST_ERR_EMPTY; a.nsel[f] = 0;
+            write_counts(a, f, 0, 0, 0, R);
+        }
+        return;
+    }
+    const uint32_t npad = (uint32_t)((n + 1) & ~1);
+    uint32_t *c32 = reinterpret_cast<uint32_t *>(smem);
+    const uint16_t *c16 = reinterpret_cast<const uint16_t *>(smem);
+    uint32_t *sel = reinterpret_cast<uint32_t *>(smem + align16(2u * npad + 16u));
+    double *red = reinterpret_cast<double *>(smem + align16(2u * npad + 16u) + align16(4u * ((uint32_t)(n + 31) / 32u)));
+    int *misc = reinterpret_cast<int *>(red + kRedSlots * 2 * DW);
+    const double *gx = a.b.x + off, *gy = a.b.y + off, *gz = a.b.z + off;
+    const double cp = a.P.cos_pitch, sp = a.P.sin_pitch;
+    for (int i = tid; i < (n + 31) / 32; i += B) sel[i] = 0u;
+    int bad = 0;
+    const int nvalid = phase_vote_dense<DW, false>(c32, misc, n, nullptr, gy, gz, a.b.v + off, a.b.tri1, t1b, t1n, cp, sp,
+                                                   a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad, nullptr, nullptr);
+    const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
+    SelectResult S;
+    S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 1;
+    if (!mask_mismatch) {
+        const int32_t *tri = a.b.tri2 + 3 * t2b;
+        unsigned long long flat = 0ull, flat_hi = 0ull;      // bit kk: my kk-th triangle has pitch_deg < thr
+        double hsum = 0.0, hcnt = 0.0;
+        int npitch = 0, singular = 0, ntv = 0;
+        TriIds cur = {0, 0, 0};
+        if (tid < t2n) cur = load_tri(tri, tid);
+        for (int base = 0, kk = 0; base < t2n; base += B, ++kk) {
+            const TriIds q = cur;
+            if (base + B + tid < t2n) cur = load_tri(tri, base + B + tid);
+            if (base + tid >= t2n) continue;
+            const bool ok = (unsigned)q.a < (unsigned)n && (unsigned)q.b < (unsigned)n && (unsigned)q.c < (unsigned)n &&
+                            c16[q.a] >= kCounterBias && c16[q.b] >= kCounterBias && c16[q.c] >= kCounterBias;      // survivors only (:166)
+            if (!ok) { bad = 1; continue; }
+            const double ya = gy[q.a], za = gz[q.a], yb = gy[q.b], zb = gz[q.b], yc = gy[q.c], zc = gz[q.c];
+            const double x0 = gx[q.a], x1 = gx[q.b], x2 = gx[q.c];
+            const double y0 = ya * cp - za * sp, y1 = yb * cp - zb * sp, y2 = yc * cp - zc * sp;       // :391
+            const double z0 = ya * sp + za * cp, z1 = yb * sp + zb * cp, z2 = yc * sp + zc * cp;       // :392
+            const double h = div3((y0 + y1) + y2);                                               // :238
+            const int r = classify_triangle<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, h, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
+                                                  a.o.tri_heights, t2b + base + tid);
+            if (r & 4) singular = 1;
+            if (r & 2) { hsum += h; hcnt += 1.0; }                                               // :240
+            if (r & 1) {
+                if (kk < 64) flat |= 1ull << (kk & 63); else flat_hi |= 1ull << (kk & 63);
+                ++npitch;
+            }
+        }
+        cur = {0, 0, 0};
+        if (tid < t2n) cur = load_tri(tri, tid);
+        block_sum2<DW>(hsum, hcnt, red + R_SEL_H * 2 * DW);
+        S.height_level = hsum / hcnt;                 // np.mean of an empty set -> 0/0 = NaN, like :240
+        const double hl = S.height_level;
+        for (int base = 0, kk = 0; base < t2n; base += B, ++kk) {
+            const TriIds q = cur;
+            if (base + B + tid < t2n) cur = load_tri(tri, base + B + tid);
+            const unsigned long long fw = kk < 64 ? flat : flat_hi;
+            if (base + tid < t2n && ((fw >> (kk & 63)) & 1ull)) {
+                const double y0 = gy[q.a] * cp - gz[q.a] * sp, y1 = gy[q.b] * cp - gz[q.b] * sp, y2 = gy[q.c] * cp - gz[q.c] * sp;
+                const double h = div3((y0 + y1) + y2);
+                if (h > hl) {                                                                    // :243-244
+                    ++ntv;
+                    atomicOr(&sel[q.a >> 5], 1u << (q.a & 31));                                  // :247
+                    atomicOr(&sel[q.b >> 5], 1u << (q.b & 31));
+                    atomicOr(&sel[q.c >> 5], 1u << (q.c & 31));
+                }
+            }
+        }
+        block_sum4i<DW>(npitch, ntv, singular, bad, red + R_SEL_CNT * 2 * DW);   // also orders the atomicOr's
+        S.n_pitch = npitch; S.n_tri_valid = ntv; S.singular = singular; S.bad = bad;
+    }
+    int status = kStPending;
+    double raw = nan("");
+    int nsel = 0;
+    if (mask_mismatch || S.bad) {
+        status = MVOSR_ST_ERR_MASK;
+    } else if (S.singular) {
+        status = MVOSR_ST_ERR_SINGULAR;
+    } else {
+        // per wave slice of the features: survivors before it (for the `selected` output, which is indexed
+        // by survivor) and selected ones before it (for the dense list of y' handed to the road-model kernel)
+        const int per = ((n + B - 1) / B) * kWave;
+        const int begin = w * per, end = min(n, begin + per);
+        int nv = 0, ns = 0;
+        for (int i0 = begin; i0 < end; i0 += kWave) {
+            const int i = i0 + lane;
+            const bool valid = (i < end) && c16[i] >= kCounterBias;
+            const bool on = valid && ((sel[i >> 5] >> (i & 31)) & 1u);
+            nv += __popcll(__ballot(valid));
+            ns += __popcll(__ballot(on));
+        }
+        if (lane == 0) { misc[M_WCNT + w] = ns; misc[M_WCNT + DW + w] = nv; }
+        __syncthreads();
+        int base_s = 0, base_v = 0;
+#pragma unroll
+        for (int i = 0; i < DW; ++i) { const int c = misc[M_WCNT + i]; if (i < w) { base_s += c; base_v += misc[M_WCNT + DW + i]; } nsel += c; }
+        double *dst = a.ysel + off;
+        for (int i0 = begin; i0 < end; i0 += kWave) {
+            const int i = i0 + lane;
+            const bool valid = (i < end) && c16[i] >= kCounterBias;
+            const bool on = valid && ((sel[i >> 5] >> (i & 31)) & 1u);
+            const unsigned long long mv = __ballot(valid), ms = __ballot(on);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (valid && a.o.selected) a.o.selected[off + base_v + __popcll(mv & below)] = (uint8_t)on;      // :247
+            if (on) dst[base_s + __popcll(ms & below)] = gy[i] * cp - gz[i] * sp;
+            base_v += __popcll(mv);
+            base_s += __popcll(ms);
+        }
+        if (nsel == 0) { status = MVOSR_ST_NO_FLAT; raw = a.P.absolute_reference / S.height_level; }   // :277-279,:421
+    }
+    if (tid == 0) {
+        a.o.raw_scale[f] = raw;
+        a.o.height[f] = nan("");
+        a.o.height_level[f] = S.height_level;
+        a.o.status[f] = status;
+        a.nsel[f] = nsel;
+        R.n_sel = nsel;
+        write_counts(a, f, nvalid, S.n_pitch, S.n_tri_valid, R);
+        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = st[1] = st[2] = st[3] = nan(""); }
+    }
+}
+
 template <int DW>
 __global__ __launch_bounds__(DW *kWave) void outlier_vote_dense_kernel(const DenseArgs da) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1350,7 +1498,7 @@ static int launch_scale_dense_w(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, boo
     da.k = ka;
     da.ws.P2 = nullptr; da.ws.Y2 = nullptr;
     int rc = MVOSR_OK;
-    if (!vote_only) {                             // the vote alone needs no workspace
+    if (!vote_only && ka.b.tri2_ids != MVOSR_TRI2_FEATURES) {    // neither the vote alone nor feature-numbered rows need the workspace
         void *p[2];
         if ((rc = ctx_workspace_dense(ctx, ka.b.total_feat, p))) return rc;
         da.ws.P2 = reinterpret_cast<double2 *>(p[0]); da.ws.Y2 = reinterpret_cast<double *>(p[1]);
@@ -1359,6 +1507,16 @@ static int launch_scale_dense_w(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, boo
         if ((rc = prepare_kernel(outlier_vote_dense_kernel<DW>, lds))) return rc;
         hipLaunchKernelGGL((outlier_vote_dense_kernel<DW>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
         return check_launch("outlier_vote_dense_kernel");
+    }
+    if (ka.b.tri2_ids == MVOSR_TRI2_FEATURES) {
+        if (full) {
+            if ((rc = prepare_kernel(scale_frames_dense_feat_kernel<DW, true>, lds))) return rc;
+            hipLaunchKernelGGL((scale_frames_dense_feat_kernel<DW, true>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
+        } else {
+            if ((rc = prepare_kernel(scale_frames_dense_feat_kernel<DW, false>, lds))) return rc;
+            hipLaunchKernelGGL((scale_frames_dense_feat_kernel<DW, false>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
+        }
+        return check_launch("scale_frames_dense_feat_kernel");
     }
     if (full) {
         if ((rc = prepare_kernel(scale_frames_dense_kernel<DW, true>, lds))) return rc;
@@ -1453,7 +1611,12 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     // chunks to run the road model of one chunk under the scale kernel of the next was measured
     // and lost 10%: smaller grids pay more tail than the overlap returns.)
     ka.first_frame = first_frame;
-    const bool dense = (waves_per_frame == 0 || waves_per_frame == 16) && b->max_feat > lds_capacity_features();
+    if (b->tri2_ids != MVOSR_TRI2_SURVIVORS && b->tri2_ids != MVOSR_TRI2_FEATURES)
+        return set_error(MVOSR_ERR_ARG, "scale_batch: batch.tri2_ids must be MVOSR_TRI2_SURVIVORS or MVOSR_TRI2_FEATURES");
+    if (b->tri2_ids == MVOSR_TRI2_FEATURES && !(waves_per_frame == 0 || waves_per_frame == 16))
+        return set_error(MVOSR_ERR_ARG, "scale_batch: feature-numbered tri2 runs the gather variant (waves_per_frame 0 or 16)");
+    const bool dense = (waves_per_frame == 0 || waves_per_frame == 16) &&
+                       (b->max_feat > lds_capacity_features() || b->tri2_ids == MVOSR_TRI2_FEATURES);
     hipEvent_t *pev = (ctx->prof_on && ctx->prof_calls < kProfRing) ? ctx->prof_ev[ctx->prof_calls] : nullptr;
     if (pev) (void)hipEventRecord(pev[0], ctx_stream(ctx));
     if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, full, false) : dispatch_scale(ctx, ka, waves, n_launch, full))) return rc;

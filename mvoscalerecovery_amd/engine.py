@@ -33,6 +33,7 @@ class DeviceBatch:
         self.n_tri1 = int(pf.tri1_off[-1]) if pf.tri1_off is not None else 0
         self.n_tri2 = int(pf.tri2_off[-1]) if (with_tri2 and pf.tri2_off is not None) else 0
         self.algorithmic_bytes = pf.algorithmic_bytes()
+        self.tri2_ids = 0
         self.bufs = {}
         up = self.bufs
         up["feat_off"] = ctx.to_device(pf.feat_off, np.int64)
@@ -50,6 +51,7 @@ class DeviceBatch:
         self.bufs["tri2_off"] = self.ctx.to_device(pf.tri2_off, np.int64)
         self.bufs["tri2"] = self.ctx.to_device(pf.tri2, np.int32)
         self.n_tri2 = int(pf.tri2_off[-1])
+        self.tri2_ids = int(pf.tri2_ids)
         if pf.n2_expected is not None:
             self.bufs["n2_expected"] = self.ctx.to_device(pf.n2_expected, np.int32)
         self.algorithmic_bytes = pf.algorithmic_bytes()
@@ -60,7 +62,7 @@ class DeviceBatch:
             p = lambda k: (self.bufs[k].ptr if k in self.bufs else None)
             self._struct = _lib.Batch(self.n_frames, p("feat_off"), p("feat_cnt"), p("x"), p("y"), p("z"), p("v"),
                                       p("tri1_off"), p("tri1"), p("tri2_off"), p("tri2"), p("n2_expected"),
-                                      self.max_feat, 0, self.total_padded)
+                                      self.max_feat, self.tri2_ids, self.total_padded)
         return self._struct
 
     def free(self):

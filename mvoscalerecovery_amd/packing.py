@@ -87,6 +87,7 @@ class PackedFrames:
     tri2: np.ndarray = None
     n2_expected: np.ndarray = None  # int32 [F]
     max_feat: int = 0
+    tri2_ids: int = 0               # 0: tri2 indexes the survivors (SciPy's numbering), 1: the frame's features
     extra: dict = field(default_factory=dict)
 
     @property
@@ -167,13 +168,17 @@ def attach_tri1(pf: PackedFrames, tri1s=None, workers=0):
     return pf
 
 
-def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0):
+def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0, feature_ids=False):
     """Second triangulation per frame: given (numbered over the survivors in the caller's / original
     order, as SciPy returns it), or SciPy over the features with ``valid_masks[f]`` (the vote result
     that came back from the GPU, in the PACKED order).  For frames that :func:`apply_locality_order`
     permuted, Delaunay still runs on the survivors in their original order — the reference's exact
-    call — and the rows are relabelled afterwards."""
+    call — and the rows are relabelled afterwards.  ``feature_ids=True`` (needs the masks) renumbers
+    the rows over the frame's packed features instead of over the survivors
+    (``mvosr_batch.tri2_ids = MVOSR_TRI2_FEATURES``): dense frames then run without compaction."""
     perms = pf.extra.get("perm") or [None] * pf.n_frames
+    if feature_ids and valid_masks is None:
+        raise ValueError("feature-numbered tri2 needs the vote masks")
     if tri2s is None:
         assert valid_masks is not None
         pts = []
@@ -196,6 +201,12 @@ def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0):
                 m_old = np.empty_like(m_new)
                 m_old[perms[f]] = m_new
                 tri2s[f] = _relabel_tri2(tri2s[f], m_old, perms[f])
+    if feature_ids:
+        for f in range(pf.n_frames):
+            if tri2s[f] is not None and tri2s[f].shape[0]:
+                survivors = np.nonzero(np.asarray(valid_masks[f], dtype=bool))[0].astype(np.int32)   # increasing: row order is kept
+                tri2s[f] = survivors[tri2s[f]]
+    pf.tri2_ids = 1 if feature_ids else 0
     pf.tri2_off, pf.tri2 = _pack_tris(tri2s)
     if valid_masks is not None:
         pf.n2_expected = np.array([int(np.count_nonzero(m)) for m in valid_masks], dtype=np.int32)
@@ -223,6 +234,7 @@ def tile_frames(pf: PackedFrames, repeats: int) -> PackedFrames:
         setattr(out, name, np.tile(arr[:max(t, 1)], (repeats, 1)))
     if pf.n2_expected is not None:
         out.n2_expected = np.tile(pf.n2_expected, repeats)
+    out.tri2_ids = pf.tri2_ids
     return out
 
 

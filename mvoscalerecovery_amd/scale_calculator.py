@@ -249,7 +249,9 @@ class ScaleEstimator:
             vote_out.free()
         if tri2s is not None and valid_masks is None and any(p is not None for p in (pf.extra.get("perm") or [])):
             raise ValueError("precomputed tri2s for dense (re-ordered) frames need the vote mask: pass tri1s only")
-        packing.attach_tri2(pf, tri2s, valid_masks, self.delaunay_workers)
+        # dense frames: rows renumbered over the features, so that the kernel need not compact (less HBM traffic)
+        packing.attach_tri2(pf, tri2s, valid_masks, self.delaunay_workers,
+                            feature_ids=(valid_masks is not None and pf.max_feat > cap))
         dbatch.set_tri2(pf)
         out = DeviceOutputs(ctx, dbatch, counts=True, stage=stage)
         eng.scale_batch(dbatch, out)

@@ -22,12 +22,12 @@ def _oracle():
     return so
 
 
-def _pack(frames, tri1s=None, tri2s=None, masks=None):
+def _pack(frames, tri1s=None, tri2s=None, masks=None, feature_ids=False):
     from mvoscalerecovery_amd import packing
     pf = packing.pack_features([f[0] for f in frames], [f[1] for f in frames])
     packing.attach_tri1(pf, tri1s)
     if tri2s is not None:
-        packing.attach_tri2(pf, tri2s, masks)
+        packing.attach_tri2(pf, tri2s, masks, feature_ids=feature_ids)
     return pf
 
 
@@ -36,9 +36,9 @@ def _oracle_frames(frames, abs_ref=1.75):
     return [so.frame_raw_scale(f3, f2, abs_ref) for f3, f2 in frames]
 
 
-def _run_fused(gpu, frames, oracle_res, waves=0, abs_ref=1.75, stage=True, per_triangle=False, hist=True):
+def _run_fused(gpu, frames, oracle_res, waves=0, abs_ref=1.75, stage=True, per_triangle=False, hist=True, feature_ids=False):
     from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs, ScaleEngine
-    pf = _pack(frames, [r.tri1 for r in oracle_res], [r.tri2 for r in oracle_res], [r.valid for r in oracle_res])
+    pf = _pack(frames, [r.tri1 for r in oracle_res], [r.tri2 for r in oracle_res], [r.valid for r in oracle_res], feature_ids)
     eng = ScaleEngine(abs_ref, ctx=gpu)
     db = DeviceBatch(gpu, pf)
     out = DeviceOutputs(gpu, db, counts=True, stage=stage, per_triangle=per_triangle, hist=hist)
@@ -89,7 +89,7 @@ def _assert_frame_equal(so, r, res, pf, f, check_stage=True):
 def test_library_loaded_and_device(gpu):
     from mvoscalerecovery_amd import _lib
     lib = _lib.load()
-    assert lib.mvosr_abi_version() == 1
+    assert lib.mvosr_abi_version() == 2
     assert lib.mvosr_device_count() >= 1
     assert gpu.n_cu >= 200
     assert lib.mvosr_max_lds_features() >= 6000
@@ -172,6 +172,22 @@ def test_dense_golden_and_lds_refusal(gpu):
     assert res["height"][0] == float(z["height"])
     assert np.array_equal(res["hist"][0, 0], z["hist_raw"])
     _assert_frame_equal(so, r, res, pf, 0)
+    # the same frame with the second triangulation numbered over the features (no compaction)
+    pf_f, res_f = _run_fused(gpu, [(f3, f2)], [r], per_triangle=True, feature_ids=True)
+    _assert_frame_equal(so, r, res_f, pf_f, 0)
+    for k in ("raw_scale", "height", "status", "selected", "counts", "tri_pitch_deg", "tri_heights", "tri_normals", "hist"):
+        assert np.array_equal(res[k], res_f[k], equal_nan=True), k
+    # ... and a row that names a feature the vote dropped is an error, not a silent use of that feature
+    from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs, ScaleEngine
+    pf_b = _pack([(f3, f2)], [r.tri1], [r.tri2], [r.valid], feature_ids=True)
+    pf_b.tri2[5, 1] = int(np.nonzero(~r.valid)[0][0])
+    db = DeviceBatch(gpu, pf_b)
+    out = DeviceOutputs(gpu, db)
+    ScaleEngine(meta["abs_ref"], ctx=gpu).scale_batch(db, out)
+    gpu.sync()
+    assert out.get("status")[0] == so.ST_ERR_MASK
+    out.free()
+    db.free()
 
 
 @pytest.mark.parametrize("n,count", [(7000, 4), (20000, 3), (40000, 1)])
@@ -187,6 +203,13 @@ def test_dense_seeded_batches(gpu, n, count):
     pf2, res2 = _run_fused(gpu, frames, ores, stage=False, hist=False)
     for k in ("raw_scale", "height", "height_level", "status"):
         assert np.array_equal(res[k], res2[k], equal_nan=True)
+    # second triangulation renumbered over the features (no compaction in the kernel): same results
+    pf3, res3 = _run_fused(gpu, frames, ores, feature_ids=True)
+    assert pf3.tri2_ids == 1
+    for f in range(count):
+        _assert_frame_equal(so, ores[f], res3, pf3, f)
+    for k in ("raw_scale", "height", "status", "selected", "vote_counters", "counts"):
+        assert np.array_equal(res[k], res3[k], equal_nan=True), k
 
 
 def test_road_cases_kernel(gpu):
