@@ -34,21 +34,89 @@ def _delaunay_job(points2d):
         return exc
 
 
+# ---- the host's Delaunay stage on a persistent process pool -------------------------------------
+# Qhull is a few ms per 2000 points and holds the GIL for about a third of that, so the stage scales
+# with processes, not threads.  The pool is created once per worker count and kept (forking per call
+# costs more than the triangulations); SciPy is imported BEFORE the fork so that the children inherit
+# it instead of importing it each on their first job; points and simplices travel through two
+# shared-memory segments (files in /dev/shm, grow-only, reused between calls), so that the parent handles a few bytes
+# per frame instead of pickling ~70 KB through a pipe — with 64 workers the pipe was the bottleneck.
 _pool = None
 _pool_size = 0
+_shm = {}                 # role -> _Segment owned by this (parent) process
+_shm_attached = {}        # worker side: path -> _Segment
 
 
 def _get_pool(workers):
-    """A process pool kept alive between calls (forking hundreds of workers per call costs more
-    than the triangulations themselves)."""
     global _pool, _pool_size
     if _pool is None or _pool_size != workers:
         if _pool is not None:
             _pool.terminate()
         import multiprocessing as mp
+        import scipy.spatial                                   # noqa: F401  (inherited by the forked workers)
         _pool = mp.get_context("fork").Pool(workers)
         _pool_size = workers
     return _pool
+
+
+class _Segment:
+    """A file in /dev/shm (or the temp dir) mapped into memory: plain mmap, so that neither side
+    involves multiprocessing's resource tracker."""
+
+    def __init__(self, path, size=None):
+        import mmap
+        import os
+        self.path = path
+        flags = os.O_RDWR | (os.O_CREAT | os.O_EXCL if size is not None else 0)
+        fd = os.open(path, flags, 0o600)
+        try:
+            if size is not None:
+                os.ftruncate(fd, size)
+            self.size = os.fstat(fd).st_size
+            self.buf = mmap.mmap(fd, self.size)
+        finally:
+            os.close(fd)
+
+    def close(self, unlink=False):
+        import os
+        try:
+            self.buf.close()
+        except (BufferError, ValueError):
+            pass                                               # a NumPy view is still alive; the mapping goes with it
+        if unlink:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+
+
+_seg_serial = 0
+
+
+def _shm_segment(role, nbytes):
+    """Grow-only segment owned by the parent."""
+    global _seg_serial
+    import os
+    import tempfile
+    seg = _shm.get(role)
+    if seg is None or seg.size < nbytes:
+        if seg is not None:
+            seg.close(unlink=True)
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+        _seg_serial += 1
+        seg = _Segment(os.path.join(base, "mvosr_%d_%s_%d" % (os.getpid(), role, _seg_serial)), max(int(nbytes * 1.25), 1 << 20))
+        _shm[role] = seg
+    return seg
+
+
+def _shm_attach(path, keep):
+    """Worker side: map a segment by path; mappings of segments the parent has replaced are dropped."""
+    for old in [k for k in _shm_attached if k not in keep]:
+        _shm_attached.pop(old).close()
+    seg = _shm_attached.get(path)
+    if seg is None:
+        seg = _shm_attached[path] = _Segment(path)
+    return seg
 
 
 def shutdown_pool():
@@ -56,17 +124,90 @@ def shutdown_pool():
     if _pool is not None:
         _pool.terminate()
         _pool, _pool_size = None, 0
+    for role in list(_shm):
+        _shm.pop(role).close(unlink=True)
+
+
+import atexit as _atexit                                           # noqa: E402
+_atexit.register(shutdown_pool)
+
+
+def _delaunay_shm_job(job):
+    """Worker: triangulate the listed point sets of the input segment, write the rows to the output segment."""
+    in_name, out_name, items = job
+    pin, pout = _shm_attach(in_name, (in_name, out_name)), _shm_attach(out_name, (in_name, out_name))
+    results = []
+    for in_off, n, out_off, cap in items:
+        pts = np.ndarray((n, 2), dtype=np.float64, buffer=pin.buf, offset=16 * in_off)
+        r = _delaunay_job(pts)
+        if isinstance(r, Exception):
+            results.append(r)
+        elif r.shape[0] > cap:
+            results.append(RuntimeError("Delaunay returned %d rows for %d points" % (r.shape[0], n)))
+        else:
+            np.ndarray((r.shape[0], 3), dtype=np.int32, buffer=pout.buf, offset=12 * out_off)[:] = r
+            results.append(int(r.shape[0]))
+    return results
+
+
+def available_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a container
+    on a 256-thread host may be limited to 16 — more Delaunay workers than that only get throttled)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                quota, period = int(fq.read()), int(fp.read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def resolve_workers(workers):
+    """``None`` -> one worker per available CPU (batch paths), anything else as given."""
+    return available_cpus() if workers is None else int(workers)
 
 
 def delaunay_many(point_sets, workers=0):
-    """Triangulate many point sets, optionally on a process pool (Qhull is a few ms per 2000
-    points; this is the host stage that bounds end-to-end throughput — SURVEY.md §7 hard part 1)."""
+    """Triangulate many point sets, optionally on the process pool (this is the host stage that bounds
+    end-to-end throughput — SURVEY.md §7 hard part 1).  Returns per set the (T,3) int32 simplices, or
+    the exception SciPy raised for it."""
     n = len(point_sets)
-    if workers and workers > 1 and n > 1:
-        workers = max(2, min(int(workers), (n + 3) // 4))          # at least ~4 frames per process
-        pool = _get_pool(workers)
-        return pool.map(_delaunay_job, point_sets, chunksize=max(1, n // (workers * 4)))
-    return [_delaunay_job(p) for p in point_sets]
+    workers = resolve_workers(workers)
+    if not (workers and workers > 1 and n > 1):
+        return [_delaunay_job(p) for p in point_sets]
+    pool = _get_pool(int(workers))
+    counts = np.array([len(p) for p in point_sets], dtype=np.int64)
+    in_off = np.concatenate([[0], np.cumsum(counts)])
+    caps = 2 * counts + 8                                       # a planar triangulation has < 2n triangles
+    out_off = np.concatenate([[0], np.cumsum(caps)])
+    pin = _shm_segment("in", 16 * max(int(in_off[-1]), 1))
+    pout = _shm_segment("out", 12 * max(int(out_off[-1]), 1))
+    allpts = np.ndarray((int(in_off[-1]), 2), dtype=np.float64, buffer=pin.buf)
+    for f, p in enumerate(point_sets):
+        allpts[in_off[f]:in_off[f + 1]] = p
+    per_job = max(1, min(16, n // (int(workers) * 4)))
+    jobs = [(pin.path, pout.path, [(int(in_off[f]), int(counts[f]), int(out_off[f]), int(caps[f]))
+                                    for f in range(j, min(n, j + per_job))]) for j in range(0, n, per_job)]
+    rows = np.ndarray((int(out_off[-1]), 3), dtype=np.int32, buffer=pout.buf)
+    out = []
+    f = 0
+    for res in pool.map(_delaunay_shm_job, jobs):
+        for r in res:
+            out.append(r if isinstance(r, Exception) else rows[out_off[f]:out_off[f] + r].copy())
+            f += 1
+    return out
 
 
 @dataclass

@@ -66,7 +66,7 @@ def good_bits(edge_potential=EDGE_POTENTIAL, prob_threshold=0.6):
 
 class ScaleEstimator:
     def __init__(self, absolute_reference, window_size=6, device=0, ransac_seed=None, sampler=None,
-                 delaunay_workers=0, verbose=False):
+                 delaunay_workers=None, verbose=False):
         # reference attributes (rescale.py:24-35)
         self.absolute_reference = absolute_reference
         self.camera_pitch = 0

@@ -48,7 +48,7 @@ def raise_for_status(status, frame=None):
 
 class ScaleEstimator:
     def __init__(self, absolute_reference, window_size=6, vanish=K.VANISH, focus=K.FOCUS, device=0,
-                 delaunay_workers=0, verbose=False, mutate_inputs=True):
+                 delaunay_workers=None, verbose=False, mutate_inputs=True):
         # reference attributes (scale_calculator.py:23-40)
         self.absolute_reference = absolute_reference
         self.camera_pitch = K.CAMERA_PITCH

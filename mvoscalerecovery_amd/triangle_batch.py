@@ -18,7 +18,7 @@ S_MIN = 0.98                                        # :54
 N_SIGMA = 3.0                                       # :60-61
 
 
-def camera_heights(points3d_list, tris=None, focus=FOCUS, cx=CX, cy=CY, device=0, delaunay_workers=0):
+def camera_heights(points3d_list, tris=None, focus=FOCUS, cx=CX, cy=CY, device=0, delaunay_workers=None):
     """``points3d_list``: list of (N,3) arrays ``[u, v, depth]`` (:19).  ``tris``: optional
     precomputed ``Delaunay(points[:, :2]).simplices`` per frame (:23-25).  Returns
     ``(heights[F], counts[F,2], status[F])``; a frame whose status is MVOSR_ST_ERR_SINGULAR is one
