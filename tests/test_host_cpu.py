@@ -166,3 +166,34 @@ def test_sequence_dict_roundtrip(tmp_path):
     back = offline.load_sequence_dict(p)
     assert list(back) == ["motions", "move_flags", "feature2ds", "feature3ds"]
     assert np.array_equal(back["feature3ds"][0], data["feature3ds"][0])
+
+
+def test_delaunay_pool_equals_in_process():
+    """The shared-memory process pool returns SciPy's rows verbatim, in order, exceptions included —
+    also right after its segments had to grow (workers must re-map, not read a stale mapping)."""
+    from mvoscalerecovery_amd import packing
+    rng = np.random.default_rng(5)
+    sets = [np.column_stack([rng.uniform(0, 1241, n), rng.uniform(185, 376, n)]) for n in rng.integers(20, 900, 60)]
+    sets[7] = sets[7][:2]                                        # too few points: QhullError
+    want = packing.delaunay_many(sets, 0)
+    try:
+        small = packing.delaunay_many(sets[:6], 3)                # creates small segments
+        big = packing.delaunay_many([np.tile(s, (1, 1)) for s in sets] * 3, 3)      # forces them to grow
+        again = packing.delaunay_many(sets, 3)
+    finally:
+        packing.shutdown_pool()
+    for got, ref in ((small, want[:6]), (big, want * 3), (again, want)):
+        assert len(got) == len(ref)
+        for g, r in zip(got, ref):
+            if isinstance(r, Exception):
+                assert type(g) is type(r)
+            else:
+                assert g.dtype == np.int32 and np.array_equal(g, r)
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("mvosr_%d_" % os.getpid())]
+
+
+def test_available_cpus_is_sane():
+    from mvoscalerecovery_amd import packing
+    n = packing.available_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert packing.resolve_workers(None) == n and packing.resolve_workers(0) == 0 and packing.resolve_workers(5) == 5
