@@ -101,6 +101,35 @@ def cpu_baseline(frames, pf, gpu_raw, gpu_status, budget_s=12.0):
     return done / t_used, done, mismatches
 
 
+_ALL_CORES_JOBS = None          # inherited by the forked workers of cpu_baseline_all_cores
+
+
+def _all_cores_job(i):
+    from oracle import scale_oracle as so
+    f3, f2, t1, t2 = _ALL_CORES_JOBS[i % len(_ALL_CORES_JOBS)]
+    return so.frame_raw_scale(f3.copy(), f2, ABS_REF, t1, t2).raw_scale
+
+
+def cpu_baseline_all_cores(frames, pf, per_worker=1500):
+    """The same oracle on every CPU the process may use (cgroup quota respected), one process per CPU,
+    frames dealt round-robin from the pool, triangulations supplied.  Skipped for re-laid-out (dense) pools."""
+    global _ALL_CORES_JOBS
+    import multiprocessing as mp
+    from mvoscalerecovery_amd import packing
+    if any(p is not None for p in (pf.extra.get("perm") or [])) or pf.tri2_ids:
+        return None
+    workers = packing.available_cpus()
+    _ALL_CORES_JOBS = [(frames[i][0], frames[i][1], pf.tri1[pf.tri1_off[i]:pf.tri1_off[i + 1]], pf.tri2[pf.tri2_off[i]:pf.tri2_off[i + 1]])
+                       for i in range(len(frames))]
+    n = workers * per_worker
+    with mp.get_context("fork").Pool(workers) as pool:
+        pool.map(_all_cores_job, range(workers * 4))                       # imports + first touches
+        t0 = time.perf_counter()
+        pool.map(_all_cores_job, range(n), chunksize=25)
+        dt = time.perf_counter() - t0
+    return n / dt, n, workers
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,6 +294,12 @@ def main():
                                               "(NumPy oracle, one thread; host Delaunay %.1f ms/frame not included)"
                                               % (sample_n, args.features, delaunay_s * 1e3)}
             line["parity_mismatches_vs_oracle"] = mism
+            allc = cpu_baseline_all_cores(frames, pf_pool)
+            if allc is not None:
+                line["cpu_baseline_all_cores"] = {"value": allc[0], "unit": "frames/s", "cores": allc[2], "kind": "port",
+                                                  "sample": "%d frames dealt from the same pool to %d processes (the CPUs this "
+                                                            "process may use: affinity and cgroup quota), triangulations supplied"
+                                                            % (allc[1], allc[2])}
         print(json.dumps(line))
     if n_gpus > 1:
         dist.barrier()
