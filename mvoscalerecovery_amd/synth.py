@@ -159,3 +159,41 @@ def road_fuzz_list(i: int, seed: int = 777) -> np.ndarray:
     y = np.asarray(y, dtype=np.float64)
     rng.shuffle(y)
     return y
+
+
+def fuzz_frame(i: int, seed: int = 4321):
+    """The i-th frame of the frame-level fuzz set (tests/golden/frame_fuzz.npz holds what the
+    reference's ``ScaleEstimator.scale_calculation`` returns or raises for each): small frames with
+    the structure the happy-path generator avoids — duplicate and grid-aligned pixels, tied depths
+    (vote products exactly zero), nearly collinear pixel rows, extreme depth scales, ground-only and
+    obstacle-only scenes, very few points, features above the vanishing row, negative heights."""
+    rng = np.random.default_rng([seed, i])
+    kind = i % 10
+    n = int(rng.integers(12, 420))
+    f3, f2 = synth_frame(i, n, base_seed=seed, upper_fraction=0.0)
+    u, v = f2[:, 0].copy(), f2[:, 1].copy()
+    x, y, z = f3[:, 0].copy(), f3[:, 1].copy(), f3[:, 2].copy()
+    if kind == 1:                                   # coarse pixel grid: many exact duplicates
+        u, v = np.round(u / 40.0) * 40.0, np.round(v / 12.0) * 12.0 + 1.0
+    elif kind == 2:                                 # tied depths
+        z = np.maximum(np.round(z * 2.0) / 2.0, 0.5)
+    elif kind == 3:                                 # a few pixel rows only
+        v = 190.0 + 30.0 * rng.integers(0, 4, n) + rng.uniform(0.0, 1e-3, n)
+    elif kind == 4:                                 # extreme depth scale
+        z = z * (1e6 if i % 20 == 4 else 1e-6)
+    elif kind == 5:                                 # ground only
+        z = 0.8 * FX / np.maximum(v - CY, 1.0) * (1.0 + 1e-3 * rng.standard_normal(n))
+    elif kind == 6:                                 # a wall
+        z = np.full(n, 12.0) + rng.normal(0.0, 0.05, n)
+    elif kind == 7:                                 # very few points
+        keep = int(rng.integers(4, 12))
+        u, v, z = u[:keep], v[:keep], z[:keep]
+    elif kind == 8:                                 # a third of the features above the vanishing row
+        up = rng.uniform(0.0, 1.0, len(v)) < 0.35
+        v = np.where(up, rng.uniform(0.0, 185.0, len(v)), v)
+    elif kind == 9:                                 # the camera below the road: negative heights
+        v = 2.0 * CY - v + 190.0
+    if kind in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+        x = (u - CX) * z / FX
+        y = (v - CY) * z / FX
+    return np.stack([x, y, z], axis=1).astype(np.float64), np.stack([u, v], axis=1).astype(np.float64)

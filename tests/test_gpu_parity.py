@@ -295,6 +295,40 @@ def test_road_fuzz_kernel(gpu):
     db.free()
 
 
+def test_frame_fuzz_through_drop_in(gpu):
+    """The drop-in class on the 400 adversarial frames of tests/golden/frame_fuzz.npz: the scale the
+    reference returned (bit-equal; 1e-13 where it is ref/height_level, a mean) or the exception it raised."""
+    from mvoscalerecovery_amd import constants as K, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_fuzz.npz"))
+    names = list(z["exception_names"])
+    seen = set()
+    for i in range(len(z["scale"])):
+        f3, f2 = synth.fuzz_frame(i, int(z["seed"]))
+        est = ScaleEstimator(1.75, window_size=5, device=gpu.device)
+        want_exc = names[z["raised"][i] - 1] if z["raised"][i] else None
+        try:
+            s, sd = est.scale_calculation(f3.copy(), f2.copy())
+            got_exc = None
+        except Exception as exc:  # noqa: BLE001 - the type is what is compared
+            got_exc = type(exc).__name__
+        assert got_exc == want_exc, (i, got_exc, want_exc)
+        if want_exc is None:
+            want = z["scale"][i]
+            st = int(est.last_status[0])
+            seen.add(st)
+            assert sd == z["std"][i], (i, sd, z["std"][i])
+            if np.isnan(want):
+                assert np.isnan(s), (i, s)
+            elif st in (K.ST_LEVEL, K.ST_NO_FLAT):
+                assert abs(s - want) <= 1e-13 * abs(want), (i, s, want)
+            else:
+                assert s == want, (i, s, want, st)
+            n_flat = -1 if est.flat_feature is None else len(est.flat_feature)
+            assert n_flat == z["n_flat"][i], (i, n_flat, z["n_flat"][i])
+    assert {K.ST_MODE, K.ST_RIGHT, K.ST_MEDIAN, K.ST_NO_FLAT} <= seen
+
+
 def test_window_median_kernel(gpu):
     from mvoscalerecovery_amd.engine import ScaleEngine
     so = _oracle()

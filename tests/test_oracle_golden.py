@@ -100,6 +100,30 @@ def test_road_fuzz_golden():
     assert {so.ST_MODE, so.ST_RIGHT, so.ST_MEDIAN, so.ST_LEVEL, so.ST_ERR_LEFT, so.ST_ERR_RIGHT} <= statuses
 
 
+def test_frame_fuzz_golden():
+    """400 small adversarial frames (synth.fuzz_frame: duplicate pixels, tied depths, few pixel rows,
+    extreme depth scales, ground-only / wall scenes, a handful of points, negative heights) against what
+    the reference's scale_calculation returned or raised for them (tests/golden/frame_fuzz.npz)."""
+    from mvoscalerecovery_amd import synth
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_fuzz.npz"))
+    names = list(z["exception_names"])
+    assert {"IndexError", "QhullError"} <= set(names)
+    for i in range(len(z["scale"])):
+        f3, f2 = synth.fuzz_frame(i, int(z["seed"]))
+        assert float(np.sum(f3)) + float(np.sum(f2)) == z["sums"][i], i
+        est = so.OracleScaleEstimator(1.75, window_size=5)
+        want_exc = names[z["raised"][i] - 1] if z["raised"][i] else None
+        try:
+            s, sd = est.scale_calculation(f3.copy(), f2.copy())
+            got_exc = None
+        except Exception as exc:  # noqa: BLE001 - the type is what is compared
+            got_exc = type(exc).__name__
+        assert got_exc == want_exc, (i, got_exc, want_exc)
+        if want_exc is None:
+            assert sd == z["std"][i], i
+            assert (np.isnan(s) and np.isnan(z["scale"][i])) or s == z["scale"][i], (i, s, z["scale"][i])
+
+
 def test_histogram_restatement_equals_numpy():
     rng = np.random.default_rng(0)
     for _ in range(20):
