@@ -102,6 +102,60 @@ def run_sequence_batched(data, estimator, minimum_feature_for_scale=MINIMUM_FEAT
             "pitchs": np.array(pitchs, dtype=np.float64), "kinds": kinds}
 
 
+# ---- the same replay sharded over the GPUs of a node (SURVEY.md §8e, config C4 in driver form) ------
+ST_HOST_QHULL = 100        # codes carried in the gathered status array for frames whose Delaunay call raised
+ST_HOST_OTHER = 101
+
+
+def run_sequence_sharded(data, estimator, group=None, minimum_feature_for_scale=MINIMUM_FEATURE_FOR_SCALE):
+    """:func:`run_sequence_batched` with the processed frames split into contiguous blocks, one per rank
+    of ``torch.distributed`` (one process per GPU).  Every rank runs the per-frame half on its block
+    (``estimator.raw_scale_batch``: host Delaunay on its own CPUs, kernels on its GPU), ONE all-gather
+    reassembles ``(raw_scale, status, height_level)`` for the whole sequence, and every rank applies the
+    cross-frame half (``estimator.push_raw_scales``: window median, raise sites) to it — so all ranks
+    return the same dict, equal to the single-process result.  Without an initialised process group it
+    runs as one rank."""
+    import torch
+    import torch.distributed as dist
+    from . import sharding
+    kinds = plan_sequence(data, minimum_feature_for_scale)
+    idx = [i for i, k in enumerate(kinds) if k == 1]
+    pitchs = [estimator.initial_estimation(np.asarray(data["motions"][i], dtype=np.float64)[3:12:4].reshape(-1))
+              for i in idx]
+    multi = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    start, stop = sharding.partition(len(idx), world, rank)
+    mine = idx[start:stop]
+    f3 = [np.asarray(data["feature3ds"][i], dtype=np.float64) for i in mine]
+    f2 = [np.asarray(data["feature2ds"][i], dtype=np.float64) for i in mine]
+    raw, status, level, host_errors = estimator.raw_scale_batch(f3, f2)
+    status = np.array(status, dtype=np.int32)
+    for f, exc in host_errors.items():
+        status[f] = ST_HOST_QHULL if type(exc).__name__ == "QhullError" else ST_HOST_OTHER
+    if world > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t_raw = torch.from_numpy(np.ascontiguousarray(raw, dtype=np.float64)).to(dev)
+        t_lvl = torch.from_numpy(np.ascontiguousarray(level, dtype=np.float64)).to(dev)
+        t_st = torch.from_numpy(status).to(dev)
+        raw_all, st_all = sharding.all_gather_frames(t_raw, t_st, len(idx), group)
+        lvl_all, _ = sharding.all_gather_frames(t_lvl, t_st, len(idx), group)
+        raw, status, level = raw_all.cpu().numpy(), st_all.cpu().numpy(), lvl_all.cpu().numpy()
+    errors = {}
+    for f in (int(v) for v in np.nonzero(status >= ST_HOST_QHULL)[0]):
+        if start <= f < stop:
+            errors[f] = host_errors[f - start]                                # the exception itself
+        elif status[f] == ST_HOST_QHULL:
+            from scipy.spatial import QhullError
+            errors[f] = QhullError("Delaunay failed for processed frame %d (raised on another rank)" % f)
+        else:
+            errors[f] = RuntimeError("host stage failed for processed frame %d (raised on another rank)" % f)
+    est_scales, est_stds = estimator.push_raw_scales(raw, np.where(status >= ST_HOST_QHULL, 0, status), level, errors)
+    scales, error = assemble_outputs(kinds, list(est_scales), list(est_stds))
+    return {"scales": np.array(scales[1:], dtype=np.float64), "error": np.array(error, dtype=np.float64),
+            "pitchs": np.array(pitchs, dtype=np.float64), "kinds": kinds}
+
+
 def save_outputs(res_addr, tag, scales, motions):
     """/root/reference/src/main_offline.py:90-93: ``<res_addr>scales.txt<tag>`` and ``<res_addr>path.txt<tag>``
     (the integrated trajectory, one 3x4 pose per line).  Returns the poses."""

@@ -211,7 +211,7 @@ class ScaleEstimator:
         raise NotImplementedError("visualisation helper of the reference; not part of the hot path")
 
     # ---- batched surface ---------------------------------------------------------------------
-    def scale_calculation_batch(self, feature3ds, feature2ds, tri1s=None, tri2s=None, _single=False):
+    def scale_calculation_batch(self, feature3ds, feature2ds, tri1s=None, tri2s=None, _single=False, _raw_only=False):
         """Equivalent to calling ``scale_calculation`` once per frame, in order, on this
         estimator: returns ``(scales[F], stds[F])`` (filtered scales).  ``tri1s``/``tri2s`` may
         carry precomputed triangulations (lists of (T,3) int arrays, SciPy ``simplices`` verbatim).
@@ -261,40 +261,69 @@ class ScaleEstimator:
         level = out.get("height_level")
         counts = out.get("counts")
         self.last_status, self.last_counts, self.last_raw_scale = status, counts, raw
+        host_errors = dict(pf.extra["tri2_errors"])                           # QhullError at :266
+        host_errors.update(pf.extra["tri1_errors"])                           # ... or already at :257
+        if _raw_only:
+            out.free()
+            dbatch.free()
+            return raw, status, level, host_errors
+        filtered, stds, n_ok, raise_late = self._push(raw, status, level, host_errors, _single)
+        if n_ok and stage:
+            self._store_flat_feature(pf, out, feature3ds, feature2ds, valid_masks, n_ok - 1, status[n_ok - 1])
+        out.free()
+        dbatch.free()
+        raise_late()
+        return filtered, stds
 
-        # first frame at which the reference would have raised
-        err_at = F
-        err = None
+    def _push(self, raw, status, level, host_errors, single=False):
+        """The cross-frame half of scale_calculation for a run of frames (:396-400, :413-422): window
+        median over the raw scales up to the first frame at which the reference would have raised,
+        queue update, ``height_level`` of the last good frame.  Returns ``(filtered, stds, n_ok,
+        raise_late)``; ``raise_late()`` raises what the reference raises at that frame, if anything."""
+        F = len(raw)
+        err_at, err = F, None
         for f in range(F):
-            if f in pf.extra["tri1_errors"]:
-                err_at, err = f, pf.extra["tri1_errors"][f]
-                break
-            if f in pf.extra["tri2_errors"]:
-                err_at, err = f, pf.extra["tri2_errors"][f]                  # QhullError at :266
+            if f in host_errors:
+                err_at, err = f, host_errors[f]
                 break
             if status[f] >= K.ST_ERR_LEFT:
                 err_at = f
                 break
         n_ok = err_at
         stds = np.where(status[:n_ok] == K.ST_NO_FLAT, 100, 1).astype(np.float64)   # :413,:333-354
-        filtered = eng.window_median_host(raw[:n_ok], self.window_size, list(self.scale_queue))   # :396-400
+        filtered = self.engine.window_median_host(raw[:n_ok], self.window_size, list(self.scale_queue))   # :396-400
         for s in raw[:n_ok]:
             self.scale_queue.append(s)
             if len(self.scale_queue) > self.window_size:
                 self.scale_queue.popleft()
         if n_ok:
-            last = n_ok - 1
-            self.height_level = level[last]                                   # :241
-            if stage:
-                self._store_flat_feature(pf, out, feature3ds, feature2ds, valid_masks, last, status[last])
+            self.height_level = level[n_ok - 1]                               # :241
             if self.verbose:
                 print('height level', self.height_level)
-        out.free()
-        dbatch.free()
-        if err is not None:
-            raise err
-        if err_at < F:
-            raise_for_status(int(status[err_at]), None if _single else err_at)
+
+        def raise_late():
+            if err is not None:
+                raise err
+            if err_at < F:
+                raise_for_status(int(status[err_at]), None if single else err_at)
+        return filtered, stds, n_ok, raise_late
+
+    # ---- the two halves on their own: what a driver that shards a sequence over GPUs needs ---------
+    def raw_scale_batch(self, feature3ds, feature2ds, tri1s=None, tri2s=None):
+        """Per-frame half only (no window state touched): ``(raw_scale[F], status[F], height_level[F],
+        host_errors)`` — ``host_errors`` maps a frame index to the exception SciPy's Delaunay raised for it."""
+        if len(feature3ds) == 0:
+            return np.zeros(0), np.zeros(0, dtype=np.int32), np.zeros(0), {}
+        return self.scale_calculation_batch(feature3ds, feature2ds, tri1s, tri2s, _raw_only=True)
+
+    def push_raw_scales(self, raw, status, level=None, host_errors=None):
+        """Cross-frame half for raw scales computed elsewhere (other ranks): returns ``(scales, stds)`` like
+        ``scale_calculation_batch``, raises where the reference would have."""
+        raw = np.asarray(raw, dtype=np.float64)
+        status = np.asarray(status, dtype=np.int32)
+        level = np.full(len(raw), np.nan) if level is None else np.asarray(level, dtype=np.float64)
+        filtered, stds, _, raise_late = self._push(raw, status, level, host_errors or {})
+        raise_late()
         return filtered, stds
 
     def _store_flat_feature(self, pf, out, feature3ds, feature2ds, valid_masks, f, st):

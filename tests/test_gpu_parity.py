@@ -761,3 +761,56 @@ def test_estimator_stage_methods(gpu, stages):
     pts = np.zeros((len(c["y"]), 3)); pts[:, 1] = c["y"]
     with pytest.raises(IndexError):
         est.road_model_calculation_static(pts)
+
+
+def test_sharded_sequence_driver_two_ranks_one_gpu(gpu, tmp_path):
+    """Config C4 in driver form: offline.run_sequence_sharded with the real ScaleEstimator on two ranks
+    (gloo, both on this GPU: MVOSR_SHARE_GPU) reproduces the reference's 200-frame golden on every rank;
+    without a process group the same call is the single-rank replay."""
+    import subprocess
+    import sys
+    import textwrap
+    from conftest import ROOT
+    from mvoscalerecovery_amd import offline, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z, meta = load_npz("seq200.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    res = offline.run_sequence_sharded(data, ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False,
+                                                            delaunay_workers=4))
+    np.testing.assert_array_equal(res["scales"], z["scales"])
+    np.testing.assert_array_equal(res["error"], z["error"])
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, json
+        sys.path.insert(0, %(root)r)
+        sys.path.insert(0, os.path.join(%(root)r, "tests"))
+        import numpy as np
+        import torch.distributed as dist
+        from conftest import load_npz
+        from mvoscalerecovery_amd import offline, sharding, synth
+        from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+        rank, local, world = sharding.init_distributed("gloo")
+        z, meta = load_npz("seq200.npz")
+        data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+        est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, delaunay_workers=4)
+        res = offline.run_sequence_sharded(data, est)
+        assert np.array_equal(res["scales"], z["scales"]) and np.array_equal(res["error"], z["error"])
+        assert np.array_equal(res["pitchs"], z["pitchs"]) and np.array_equal(res["kinds"], z["kinds"])
+        dist.barrier()
+        dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """) % {"root": ROOT})
+    port = 29800 + os.getpid() % 150
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MVOSR_SHARE_GPU="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for rank, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        assert p.returncode == 0, out
+        assert "rank %d ok" % rank in out

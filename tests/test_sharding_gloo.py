@@ -81,3 +81,63 @@ def test_world_size_2_gather_and_filter(tmp_path, n):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert "rank %d ok" % rank in out
+
+
+WORKER_SEQ = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    import torch.distributed as dist
+    from mvoscalerecovery_amd import offline, sharding, synth
+    from oracle import scale_oracle as so
+
+    class OracleAdapter:
+        # the two halves the sharded driver needs, on the CPU oracle
+        def __init__(self):
+            self.queue = []
+        def initial_estimation(self, motion_t):
+            return so.OracleScaleEstimator(1.75, window_size=5).initial_estimation(motion_t)
+        def raw_scale_batch(self, f3s, f2s):
+            rs = [so.frame_raw_scale(a.copy(), b, 1.75) for a, b in zip(f3s, f2s)]
+            return (np.array([r.raw_scale for r in rs]), np.array([r.status for r in rs], dtype=np.int32),
+                    np.array([r.height_level for r in rs]), {})
+        def push_raw_scales(self, raw, status, level=None, host_errors=None):
+            assert not host_errors and np.all(status < so.ST_ERR_LEFT)
+            out, self.queue = so.window_median(np.asarray(raw), 5, self.queue)
+            return out, np.where(status == so.ST_NO_FLAT, 100, 1).astype(float)
+
+    rank, local, world = sharding.init_distributed("gloo")
+    data = synth.synth_sequence_dict(%(n)d, base_seed=99, n_lo=120, n_hi=260)
+    got = offline.run_sequence_sharded(data, OracleAdapter())
+    want = offline.run_sequence(data, so.OracleScaleEstimator(1.75, window_size=5))
+    for k in ("scales", "error", "pitchs", "kinds"):
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_world_size_2_sharded_sequence_driver(tmp_path):
+    """offline.run_sequence_sharded on two gloo ranks (CPU oracle behind the estimator interface) equals the
+    frame-at-a-time replay of the whole sequence on one process, not-moving / too-few-feature frames included."""
+    script = tmp_path / "worker_seq.py"
+    script.write_text(WORKER_SEQ % {"root": ROOT, "n": 41})
+    port = 29300 + os.getpid() % 250
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert "rank %d ok" % rank in out
