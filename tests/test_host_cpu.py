@@ -197,3 +197,61 @@ def test_available_cpus_is_sane():
     n = packing.available_cpus()
     assert 1 <= n <= (os.cpu_count() or 1)
     assert packing.resolve_workers(None) == n and packing.resolve_workers(0) == 0 and packing.resolve_workers(5) == 5
+
+
+def _rows_as_pixels(pf, f, tri, ids_are_features, valid=None):
+    """Every triangle row as its three (u, v) pixel pairs, in vertex order (what must survive any relabelling)."""
+    sl = pf.frame_slice(f)
+    u, v = pf.u[sl], pf.v[sl]
+    if not ids_are_features:
+        keep = np.nonzero(valid)[0]
+        u, v = u[keep], v[keep]
+    return np.stack([u[tri], v[tri]], axis=-1)
+
+
+def test_relabellings_keep_every_triangle():
+    """packing's two relabellings of the second triangulation — over the Z-ordered survivors (dense frames)
+    and over the frame's features (mvosr_batch.tri2_ids = 1) — describe exactly SciPy's triangles: same
+    pixel coordinates per row and per vertex position, rows only permuted."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import packing, synth
+    rng = np.random.default_rng(11)
+    frames = [synth.synth_frame(i, n, base_seed=31, upper_fraction=0.1) for i, n in enumerate((400, 900, 150))]
+    f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
+
+    def canon(rows):                       # rows as a sorted list of byte strings: order of rows is free
+        return sorted(r.tobytes() for r in np.ascontiguousarray(rows))
+
+    for locality in (False, True):
+        for feature_ids in (False, True):
+            pf = packing.pack_features(f3s, f2s)
+            packing.attach_tri1(pf)
+            plain = packing.pack_features(f3s, f2s)                      # the untouched layout, for reference
+            packing.attach_tri1(plain)
+            if locality:
+                packing.apply_locality_order(pf, min_features=1)
+            masks = [rng.uniform(0, 1, int(c)) > 0.07 for c in pf.feat_cnt]            # in the PACKED order
+            packing.attach_tri2(pf, None, masks, feature_ids=feature_ids)
+            assert pf.tri2_ids == int(feature_ids)
+            for f in range(pf.n_frames):
+                sl = pf.frame_slice(f)
+                # first triangulation: same triangles as SciPy's on the caller's order
+                t1 = pf.tri1[pf.tri1_off[f]:pf.tri1_off[f + 1]]
+                t1_ref = plain.tri1[plain.tri1_off[f]:plain.tri1_off[f + 1]]
+                assert canon(_rows_as_pixels(pf, f, t1, True)) == canon(_rows_as_pixels(plain, f, t1_ref, True))
+                # second triangulation: SciPy on the survivors taken in the CALLER's order
+                perm = (pf.extra.get("perm") or [None] * pf.n_frames)[f]
+                m = masks[f]
+                m_orig = m.copy()
+                if perm is not None:
+                    m_orig = np.empty_like(m)
+                    m_orig[perm] = m
+                psl = plain.frame_slice(f)
+                pts = np.stack([plain.u[psl][m_orig], plain.v[psl][m_orig]], axis=1)
+                want = pts[Delaunay(pts).simplices]
+                t2 = pf.tri2[pf.tri2_off[f]:pf.tri2_off[f + 1]]
+                got = _rows_as_pixels(pf, f, t2, feature_ids, m)
+                assert canon(got) == canon(want), (locality, feature_ids, f)
+                if feature_ids:
+                    assert np.all(m[t2])                                 # every vertex is a survivor
+                assert pf.n2_expected[f] == int(m.sum())
