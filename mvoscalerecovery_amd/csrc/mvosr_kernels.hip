@@ -563,6 +563,7 @@ __device__ __attribute__((noinline)) double np_pairwise_sum_cold(const double *a
     return val[0];
 }
 
+template <int RC>
 __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16_t *slots, uint8_t *dropb, const double2 *edges,
                                                 const double *yv, double *scratch,
                                                 int M, double height_level, const mvosr_params &P, int32_t *g_hist, bool exact_stats MVOSR_STAMP_ARG) {
@@ -574,22 +575,22 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
 #pragma unroll
     for (int c = 0; c < 3; ++c) { const int b = lane + 64 * c; if (b < 176) hist[b] = 0; }
 
-    // histogram (np.histogram, :326); the first kRoadRC values of every lane stay in registers
-    double yc[kRoadRC];
-    int binc[kRoadRC];
+    // histogram (np.histogram, :326); the first RC values of every lane stay in registers
+    double yc[RC];
+    int binc[RC];
     // Branch-free on purpose: with no control flow between them the 16 loads, table reads and
     // atomics of a lane are scheduled in batches instead of one dependent round trip per value.
     // Values that take no part (beyond the list, or outside [0,16.9]) go to the trash bin kTrash.
     const int nfull = M / kWave;
-    const unsigned valid = (nfull >= kRoadRC) ? ((1u << kRoadRC) - 1u)                  // bit k: value k*64+lane exists
+    const unsigned valid = (nfull >= RC) ? ((1u << RC) - 1u)                  // bit k: value k*64+lane exists
                                               : (((1u << nfull) - 1u) | ((lane < M - nfull * kWave ? 1u : 0u) << nfull));
 #pragma unroll
-    for (int k = 0; k < kRoadRC; ++k) {
+    for (int k = 0; k < RC; ++k) {
         const int i = min(k * kWave + lane, M - 1);                                       // clamped: always a legal address
         yc[k] = yv[i];
     }
 #pragma unroll
-    for (int k = 0; k < kRoadRC; ++k) {
+    for (int k = 0; k < RC; ++k) {
         const double y = yc[k];
         const bool inr = ((valid >> k) & 1u) && (y >= 0.0) && (y <= bin_edge(kBins));
         const int g = inr ? min((int)(y * 10.0), kBins - 1) : 0;
@@ -599,7 +600,7 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
         atomicAdd(&hist[bin], 1);
         binc[k] = bin;
     }
-    for (int i = kRoadRC * kWave + lane; i < M; i += kWave) {
+    for (int i = RC * kWave + lane; i < M; i += kWave) {
         const int bin = bin_of_table(yv[i], edges);
         if (bin >= 0) atomicAdd(&hist[bin], 1);
     }
@@ -647,7 +648,7 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
         reinterpret_cast<uint4 *>(dropb)[lane] = zero;
         int ns = 0;
 #pragma unroll
-        for (int k = 0; k < kRoadRC; ++k) {
+        for (int k = 0; k < RC; ++k) {
             const bool sus = nearflag[binc[k]] != 0;                          // nearflag[kTrash] == 0
             const unsigned long long m = __ballot(sus);
             if (sus) slots[ns + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * kWave + lane);
@@ -656,12 +657,12 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
         for (int i = lane; i < ns; i += kWave) {
             const int e = slots[i];
             const double y = yv[e];                                           // (a cache hit; avoids indexing the register array)
-            if (dropped_by_single(y, bin_of_table(y, edges), single, first_single)) dropb[(e & (kWave - 1)) * kRoadRC + (e >> 6)] = 1;
+            if (dropped_by_single(y, bin_of_table(y, edges), single, first_single)) dropb[(e & (kWave - 1)) * kRoadRC + (e >> 6)] = 1;   // 16 verdict bytes per lane whatever RC
         }
         if (ns > 0) {
             const uint4 d = reinterpret_cast<const uint4 *>(dropb)[lane];
 #pragma unroll
-            for (int k = 0; k < kRoadRC; ++k) {
+            for (int k = 0; k < RC; ++k) {
                 const unsigned w = (k >> 2) == 0 ? d.x : ((k >> 2) == 1 ? d.y : ((k >> 2) == 2 ? d.z : d.w));
                 if ((w >> (8 * (k & 3))) & 0xFFu) kept &= ~(1u << k);
             }
@@ -669,9 +670,9 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     }
     double sum = 0.0;
 #pragma unroll
-    for (int k = 0; k < kRoadRC; ++k) sum += ((kept >> k) & 1u) ? yc[k] : 0.0;
+    for (int k = 0; k < RC; ++k) sum += ((kept >> k) & 1u) ? yc[k] : 0.0;
     double cntd = (double)__popc(kept);
-    for (int i = kRoadRC * kWave + lane; i < M; i += kWave) {              // lists longer than the register cache
+    for (int i = RC * kWave + lane; i < M; i += kWave) {              // lists longer than the register cache
         const double y = yv[i];
         const int bin = bin_of_table(y, edges);
         if (bin >= 0 && nearflag[bin] && dropped_by_single(y, bin, single, first_single)) continue;
@@ -735,11 +736,11 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     const double mean = sum / cntd;                                             // np.mean
     double ss = 0.0;
 #pragma unroll
-    for (int k = 0; k < kRoadRC; ++k) {
+    for (int k = 0; k < RC; ++k) {
         const double d = ((kept >> k) & 1u) ? yc[k] - mean : 0.0;
         ss += d * d;
     }
-    for (int i = kRoadRC * kWave + lane; i < M; i += kWave) {
+    for (int i = RC * kWave + lane; i < M; i += kWave) {
         const double y = yv[i];
         const int bin = bin_of_table(y, edges);
         if (bin >= 0 && nearflag[bin] && dropped_by_single(y, bin, single, first_single)) continue;
@@ -825,9 +826,14 @@ __global__ __launch_bounds__(kRoadWaves *kWave, MVOSR_ROAD_MINW) void road_model
     const int64_t off = a.off[f];
     const double hl = a.height_level ? a.height_level[f] : nan("");
     MVOSR_RSTAMP(1);
-    const RoadResult R = road_wave(hist_all[wave_id()][0], hist_all[wave_id()][1], slots_all[wave_id()], drop_all[wave_id()], edges,
-                                   a.y + off, a.scratch + off, M, hl, a.P,
-                                   a.o.hist ? a.o.hist + f * 2 * kBins : nullptr, a.o.stats != nullptr MVOSR_STAMP_PASS);
+    // values per lane kept in registers: as few as the list needs (the passes over them are branch-free, so
+    // a short list would otherwise pay for sixteen rows of padding)
+    int *h0 = hist_all[wave_id()][0], *h1 = hist_all[wave_id()][1];
+    int32_t *gh = a.o.hist ? a.o.hist + f * 2 * kBins : nullptr;
+    const bool ex = a.o.stats != nullptr;
+    const RoadResult R = (M <= 4 * kWave) ? road_wave<4>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
+                       : (M <= 8 * kWave) ? road_wave<8>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
+                                          : road_wave<kRoadRC>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS);
     MVOSR_RSTAMP(6);
 #ifdef MVOSR_STAMPS
     if (lane_id() == 0 && a.o.hist) { unsigned long long *d = reinterpret_cast<unsigned long long *>(a.o.hist + f * 2 * kBins) + 16; for (int i = 0; i < 8; ++i) d[i] = stamps[i]; }
