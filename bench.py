@@ -205,6 +205,8 @@ def main():
     median = sharding.make_gpu_median(engine)
     total_frames = F * n_gpus
 
+    force_gather = bool(os.environ.get("MVOSR_BENCH_FORCE_GATHER")) and dist.is_initialized()   # diagnostic: the N>1 step on one rank
+
     def step(ev_pair=None):
         if ev_pair is not None:
             ctx.record(ev_pair[0])
@@ -212,7 +214,7 @@ def main():
                                              args.waves, 0, 0), "mvosr_scale_batch")
         if ev_pair is not None:
             ctx.record(ev_pair[1])
-        if n_gpus > 1:
+        if n_gpus > 1 or force_gather:
             filtered, _, _ = sharding.gather_and_filter(raw, status, total_frames, WINDOW, median)
         else:
             filtered = median(raw, WINDOW)

@@ -4,7 +4,7 @@ The raw scale of a frame depends on that frame only (/root/reference/src/scale_c
 up to the filter), so a sequence shards into contiguous blocks of frames, one block per rank
 (one process per GPU).  The only cross-frame coupling — the window median of
 scale_calculator.py:396-400 — is a sliding-window function of the raw sequence, so it runs after
-ONE all-gather of the per-rank ``(raw_scale, status)`` arrays (RCCL over xGMI through
+the all-gather of the per-rank raw scales (and of their statuses, a second small gather) (RCCL over xGMI through
 ``torch.distributed``'s ``nccl`` backend; ``gloo`` in CPU tests).  No halo, no all-reduce.
 """
 from __future__ import annotations
@@ -30,10 +30,11 @@ _bufs = {}
 
 def all_gather_frames(local_raw, local_status, n_frames, group=None):
     """All-gather the per-rank raw scales (float64) and statuses (int32) into the full-sequence
-    arrays, on whatever device the local tensors live on.  ONE collective per step: scale and
-    status travel as the two columns of a float64 (cap, 2) record array (statuses are small ints,
-    exact in float64); shards are padded to the largest shard and the padding dropped afterwards.
-    Buffers are cached between steps.
+    arrays, on whatever device the local tensors live on.  Equal shards: the two output arrays are gathered
+    as they are (two small collectives back to back, no packing or unpacking kernels — measured on one
+    rank: 0.05 ms per step instead of 0.09).  Ragged shards: ONE collective, scale and status as the two
+    columns of a float64 (cap, 2) record array (statuses are small ints, exact in float64), padded to the
+    largest shard, the padding dropped afterwards.  Buffers are cached between steps.
 
     ``local_raw`` / ``local_status`` are torch tensors of this rank's block (partition order).
     Returns ``(raw[n_frames], status[n_frames])`` torch tensors.
@@ -44,6 +45,17 @@ def all_gather_frames(local_raw, local_status, n_frames, group=None):
     sizes = shard_sizes(n_frames, world)
     cap = max(sizes) if sizes else 0
     dev = local_raw.device
+    if all(s == cap for s in sizes) and local_raw.is_contiguous() and local_status.is_contiguous():
+        # equal shards (the bench, and any batch the caller sizes per GPU): the kernels' output arrays are
+        # gathered as they are, straight into the arrays the window median reads — no packing kernels
+        key = (str(dev), cap, world, "direct")
+        if key not in _bufs:
+            _bufs[key] = (torch.empty(world * cap, dtype=torch.float64, device=dev),
+                          torch.empty(world * cap, dtype=torch.int32, device=dev))
+        recv_raw, recv_st = _bufs[key]
+        dist.all_gather_into_tensor(recv_raw, local_raw, group=group)
+        dist.all_gather_into_tensor(recv_st, local_status, group=group)
+        return recv_raw, recv_st
     key = (str(dev), cap, world)
     if key not in _bufs:
         _bufs[key] = (torch.empty((cap, 2), dtype=torch.float64, device=dev),
@@ -93,7 +105,7 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("MVOSR_FORCE_DIST") == "1") and not dist.is_initialized():   # FORCE_DIST: a group of one, for diagnostics
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
