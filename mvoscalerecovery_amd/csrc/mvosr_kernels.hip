@@ -1429,9 +1429,11 @@ static int debug_skip_env() {
 // than any frame that fits LDS.
 static int pick_waves(int requested, int max_feat) {
     if (requested == 1 || requested == 4 || requested == 8 || requested == 16) return requested;
+    // measured crossovers (frames/s at 256 ... 4096 features per frame): 1 wave up to 384, 4 up to 1024, 8 as
+    // long as two workgroups fit a CU's LDS (about 3000 features: 0.49 of the HBM peak against 0.37 with 16), 16 above
     if (max_feat <= 384) return 1;
     if (max_feat <= 1024) return 4;
-    if (max_feat <= 2048) return 8;
+    if (max_feat <= 2048 || 2 * (int64_t)lds_plan(max_feat, 8).total <= (int64_t)g_max_dyn_lds) return 8;
     return 16;
 }
 static int variant_capacity(int waves, int sc) { return waves * sc * kWave; }
