@@ -276,13 +276,14 @@ __global__ __launch_bounds__(kRsBlock) void ransac_plane_kernel(const RansacArgs
             qx[k] = px[jc]; qy[k] = py[jc]; qz[k] = pz[jc];
             if (j >= M) qx[k] = nan("");                         // never an inlier: no masks or branches in the loop below
         }
+        const int rows = min(kRansacPPT, (M - c0 + kRsBlock - 1) / kRsBlock);      // workgroup-uniform: rows that hold any point
 #pragma unroll 4
         for (int h = 0; h < H; ++h) {
             const double4 m = mods[h];
             int ic = 0;
 #pragma unroll
             for (int k = 0; k < kRansacPPT; ++k)
-                ic += __popcll(__ballot(fabs(((qx[k] * m.x + qy[k] * m.y) + qz[k] * m.z) + m.w) < a.threshold));   // estimate_road_norm.py:18
+                if (k < rows) ic += __popcll(__ballot(fabs(((qx[k] * m.x + qy[k] * m.y) + qz[k] * m.z) + m.w) < a.threshold));   // estimate_road_norm.py:18
             if (lane == 0 && ic) atomicAdd(&cnts[h], ic);
         }
     }
@@ -364,17 +365,31 @@ __global__ __launch_bounds__(kRsBlock) void triangle_batch_kernel(const TriBatch
         const double h = div3((Y[q.a] + Y[q.b]) + Y[q.c]);                           // :40
         return (s > a.s_min && h > 0.0) ? h : nan("");                               // :54-55
     };
+    // the three sweeps need every kept height three times: a thread's first kTbKeep triangles keep theirs
+    // in registers (all of them for frames of up to 4096 triangles), the rest are recomputed
+    constexpr int kTbKeep = 8;
+    double hk[kTbKeep];
     double sum = 0.0, cnt = 0.0;
-    for (int t = tid; t < tn; t += kRsBlock) { const double h = kept_height(t); if (h == h) { sum += h; cnt += 1.0; } }
+#pragma unroll
+    for (int k = 0; k < kTbKeep; ++k) {
+        const int t = tid + k * kRsBlock;
+        hk[k] = (t < tn) ? kept_height(t) : nan("");
+        if (hk[k] == hk[k]) { sum += hk[k]; cnt += 1.0; }
+    }
+    for (int t = tid + kTbKeep * kRsBlock; t < tn; t += kRsBlock) { const double h = kept_height(t); if (h == h) { sum += h; cnt += 1.0; } }
     block_sum2<kRsWaves>(sum, cnt, red);
     const double mean = sum / cnt;                                                   // :57
     double ss = 0.0, dummy = 0.0;
-    for (int t = tid; t < tn; t += kRsBlock) { const double h = kept_height(t); if (h == h) { const double d = h - mean; ss += d * d; } }
+#pragma unroll
+    for (int k = 0; k < kTbKeep; ++k) if (hk[k] == hk[k]) { const double d = hk[k] - mean; ss += d * d; }
+    for (int t = tid + kTbKeep * kRsBlock; t < tn; t += kRsBlock) { const double h = kept_height(t); if (h == h) { const double d = h - mean; ss += d * d; } }
     block_sum2<kRsWaves>(ss, dummy, red + 2 * kRsWaves);
     const double sd = sqrt(ss / cnt);                                                // :58
     const double lo = mean - a.n_sigma * sd, hi = mean + a.n_sigma * sd;             // :60-61
     double sum2 = 0.0, cnt2 = 0.0;
-    for (int t = tid; t < tn; t += kRsBlock) { const double h = kept_height(t); if (h == h && h > lo && h < hi) { sum2 += h; cnt2 += 1.0; } }
+#pragma unroll
+    for (int k = 0; k < kTbKeep; ++k) if (hk[k] == hk[k] && hk[k] > lo && hk[k] < hi) { sum2 += hk[k]; cnt2 += 1.0; }
+    for (int t = tid + kTbKeep * kRsBlock; t < tn; t += kRsBlock) { const double h = kept_height(t); if (h == h && h > lo && h < hi) { sum2 += h; cnt2 += 1.0; } }
     block_sum2<kRsWaves>(sum2, cnt2, red + 4 * kRsWaves);
     __syncthreads();
     if (tid == 0) {
