@@ -121,6 +121,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
     double *med = reinterpret_cast<double *>(misc + 16 + 256);
     if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0; misc[3] = 0; }
     for (int i = tid; i < n; i += kRsBlock) { X[i] = a.x[off + i]; Y[i] = a.y[off + i]; Z[i] = a.z[off + i]; }
+    const double s_loose = sin(a.loose_deg * 3.141592653589793 / 180.0), s_tight = sin(a.tight_deg * 3.141592653589793 / 180.0);
     __syncthreads();
     for (int t = tid; t < tn; t += kRsBlock) {
         const TriIds q = load_tri(a.tri + 3 * tb, t);
@@ -130,11 +131,19 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
         double nx, ny, nz;
         if (!plane_normal(X[q.a], Y[q.a], Z[q.a], X[q.b], Y[q.b], Z[q.b], X[q.c], Y[q.c], Z[q.c], nx, ny, nz)) misc[1] = 1;   // rescale.py:79-80
         const double len = sqrt((nx * nx + ny * ny) + nz * nz);                          // :81
-        const double pitch = asin(-(ny / len)) * 180.0 / 3.141592653589793;              // :82-83
+        const double mu = -(ny / len);                                                   // :82
         const double h = 1.0 / len;                                                      // :89
+        // pitch = asin(mu) * 180/pi (:83) is increasing in mu: away from the two thresholds the comparison is
+        // made on mu itself, within 1e-12 of one (or for NaN) on the reference's own expression
+        bool loose, tight;
+        if (fabs(mu - s_loose) > 1e-12 && fabs(mu - s_tight) > 1e-12) { loose = mu < s_loose; tight = mu < s_tight; }
+        else {
+            const double pitch = asin(mu) * 180.0 / 3.141592653589793;
+            loose = pitch < a.loose_deg; tight = pitch < a.tight_deg;
+        }
         uint8_t fl = 0;
-        if (pitch < a.loose_deg) { fl |= 1; L[atomicAdd(&misc[0], 1)] = h; }              // :85
-        if (pitch < a.tight_deg) fl |= 2;                                                // :86
+        if (loose) { fl |= 1; L[atomicAdd(&misc[0], 1)] = h; }                            // :85
+        if (tight) fl |= 2;                                                              // :86
         a.tri_flags[tb + t] = fl;
         a.tri_height[tb + t] = h;
     }
