@@ -175,8 +175,16 @@ def available_cpus():
 
 
 def resolve_workers(workers):
-    """``None`` -> one worker per available CPU (batch paths), anything else as given."""
-    return available_cpus() if workers is None else int(workers)
+    """``None`` -> one worker per available CPU (batch paths), shared evenly between the ranks of a node
+    (``LOCAL_WORLD_SIZE`` of torch.distributed.run), anything else as given."""
+    if workers is not None:
+        return int(workers)
+    import os
+    try:
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        ranks = 1
+    return max(1, available_cpus() // ranks)
 
 
 def delaunay_many(point_sets, workers=0):

@@ -197,6 +197,11 @@ def test_available_cpus_is_sane():
     n = packing.available_cpus()
     assert 1 <= n <= (os.cpu_count() or 1)
     assert packing.resolve_workers(None) == n and packing.resolve_workers(0) == 0 and packing.resolve_workers(5) == 5
+    os.environ["LOCAL_WORLD_SIZE"] = "4"
+    try:
+        assert packing.resolve_workers(None) == max(1, n // 4)
+    finally:
+        del os.environ["LOCAL_WORLD_SIZE"]
 
 
 def _rows_as_pixels(pf, f, tri, ids_are_features, valid=None):
