@@ -190,9 +190,10 @@ def test_dense_golden_and_lds_refusal(gpu):
     db.free()
 
 
-@pytest.mark.parametrize("n,count", [(7000, 4), (20000, 3), (40000, 1)])
+@pytest.mark.parametrize("n,count", [(500, 6), (7000, 4), (20000, 3), (40000, 1)])
 def test_dense_seeded_batches(gpu, n, count):
-    """40000 features: ~80000 triangles, more than 64 per thread (second flag word of phase_select)."""
+    """40000 features: ~80000 triangles, more than 64 per thread (second flag word of phase_select).
+    500 features: the LDS-resident kernel against the gather variant that feature-numbered rows select."""
     from mvoscalerecovery_amd import synth
     so = _oracle()
     frames = [synth.synth_frame(i, n, base_seed=9000 + n, upper_fraction=0.05 * (i % 2)) for i in range(count)]
