@@ -153,7 +153,8 @@ int mvosr_ctx_set_stream(mvosr_ctx *ctx, void *hip_stream);
 void *mvosr_ctx_stream(mvosr_ctx *ctx);
 int mvosr_ctx_sync(mvosr_ctx *ctx);
 /* Pre-size the context's workspace (the dense lists of selected y' the scale kernel hands to the
- * road-model kernel: total_feat doubles + n_frames int32).  mvosr_scale_batch grows it on demand
+ * road-model kernel: total_feat doubles + n_frames int32; dense batches with survivor-numbered rows
+ * need 24 more bytes per feature, allocated at their first launch).  mvosr_scale_batch grows it on demand
  * with hipMalloc; call this first if the launches must not allocate (e.g. under graph capture). */
 int mvosr_ctx_reserve(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat);
 /* Per-call kernel timing of mvosr_scale_batch with HIP events on the launch stream: after
@@ -190,8 +191,12 @@ void mvosr_default_params(mvosr_params *p, double absolute_reference);
  * sweeps; one workgroup per frame, its features resident in LDS) leaves every frame's selected
  * y' as a dense list in the context's workspace, and the road-model kernel (one WAVEFRONT per
  * frame, no LDS-resident frame, full occupancy) turns each list into height / scale / status.
- * `waves_per_frame` selects the scale kernel's variant: 0 = choose from max_feat, 1 = one
- * wavefront per frame (<= 512 features), 4/8/16 = one workgroup of that many wavefronts.
+ * `waves_per_frame` selects the scale kernel's variant: 0 = choose from max_feat (measured crossovers:
+ * 1 up to 384 features, 4 up to 1024, 8 while two workgroups fit a CU's LDS — about 3000 —, 16 above),
+ * 1 = one wavefront per frame (<= 512 features), 4/8/16 = one workgroup of that many wavefronts.
+ * Frames that do not fit LDS in fp64 (max_feat > mvosr_max_lds_features(), about 6200) and batches with
+ * feature-numbered second triangulations (b->tri2_ids) run the gather variant, which keeps only the vote
+ * counters in LDS; with survivor-numbered rows it uses 24 bytes of context workspace per feature.
  * `first_frame`/`n_launch` restrict the launch to a sub-range of the batch (n_launch <= 0: all).
  */
 int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b,
