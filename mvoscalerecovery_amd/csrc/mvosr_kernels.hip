@@ -227,10 +227,10 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
             const bool f0 = pa | pb, f1 = pa | pb | pc, f2 = pc;
             // one wrap-around add per vertex: +-1 in the vertex's 16-bit half (the halves stay in
             // [1, 0xFFFE], so a -1 never borrows across them)
-            const uint32_t u0 = 1u << ((q.a & 1) * 16), u1 = 1u << ((q.b & 1) * 16), u2 = 1u << ((q.c & 1) * 16);
-            atomicAdd(&s.c32[q.a >> 1], f0 ? 0u - u0 : u0);
-            atomicAdd(&s.c32[q.b >> 1], f1 ? 0u - u1 : u1);
-            atomicAdd(&s.c32[q.c >> 1], f2 ? 0u - u2 : u2);
+            // (-1 << 16 = 0xFFFF0000 = -(1 << 16): the sign is chosen first, then shifted into the vertex's half)
+            atomicAdd(&s.c32[q.a >> 1], (f0 ? 0xFFFFFFFFu : 1u) << ((q.a & 1) * 16));
+            atomicAdd(&s.c32[q.b >> 1], (f1 ? 0xFFFFFFFFu : 1u) << ((q.b & 1) * 16));
+            atomicAdd(&s.c32[q.c >> 1], (f2 ? 0xFFFFFFFFu : 1u) << ((q.c & 1) * 16));
         }
         if (more) tc = tn;
     }
