@@ -488,7 +488,12 @@ __device__ __forceinline__ bool dropped_by_single(double y, int bin, const Bits1
     return d;
 }
 
-constexpr int kRoadRC = 16;   // values per lane kept in registers (lists up to 64*RC values; longer ones re-read)
+#ifndef MVOSR_ROAD_RC
+#define MVOSR_ROAD_RC 20
+#endif
+constexpr int kRoadRC = MVOSR_ROAD_RC;   // deepest register cache: values per lane kept in registers (lists up to 64*RC values; longer ones
+                                         // re-read).  20 keeps the kernel at 4 wavefronts per SIMD (121 VGPRs); 32 was measured: 2 per SIMD, slower
+constexpr int kDropStride = 32;          // verdict bytes per lane in LDS (two 16-byte words)
 constexpr int kRoadWaves = 4;          // frames (wavefronts) per workgroup
 constexpr int kTrash = 175;            // histogram slot for values that are not binned (bins are 0..168)
 constexpr int kStPending = -1;         // scale kernel -> road kernel: "road model still to run"
@@ -582,7 +587,7 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     // atomics of a lane are scheduled in batches instead of one dependent round trip per value.
     // Values that take no part (beyond the list, or outside [0,16.9]) go to the trash bin kTrash.
     const int nfull = M / kWave;
-    const unsigned valid = (nfull >= RC) ? ((1u << RC) - 1u)                  // bit k: value k*64+lane exists
+    const unsigned valid = (nfull >= RC) ? (unsigned)((1ull << RC) - 1ull)     // bit k: value k*64+lane exists
                                               : (((1u << nfull) - 1u) | ((lane < M - nfull * kWave ? 1u : 0u) << nfull));
 #pragma unroll
     for (int k = 0; k < RC; ++k) {
@@ -645,7 +650,8 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     unsigned kept = valid;
     {
         uint4 zero; zero.x = zero.y = zero.z = zero.w = 0u;
-        reinterpret_cast<uint4 *>(dropb)[lane] = zero;
+        reinterpret_cast<uint4 *>(dropb)[2 * lane] = zero;
+        if (RC > 16) reinterpret_cast<uint4 *>(dropb)[2 * lane + 1] = zero;
         int ns = 0;
 #pragma unroll
         for (int k = 0; k < RC; ++k) {
@@ -657,14 +663,18 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
         for (int i = lane; i < ns; i += kWave) {
             const int e = slots[i];
             const double y = yv[e];                                           // (a cache hit; avoids indexing the register array)
-            if (dropped_by_single(y, bin_of_table(y, edges), single, first_single)) dropb[(e & (kWave - 1)) * kRoadRC + (e >> 6)] = 1;   // 16 verdict bytes per lane whatever RC
+            if (dropped_by_single(y, bin_of_table(y, edges), single, first_single)) dropb[(e & (kWave - 1)) * kDropStride + (e >> 6)] = 1;
         }
         if (ns > 0) {
-            const uint4 d = reinterpret_cast<const uint4 *>(dropb)[lane];
 #pragma unroll
-            for (int k = 0; k < RC; ++k) {
-                const unsigned w = (k >> 2) == 0 ? d.x : ((k >> 2) == 1 ? d.y : ((k >> 2) == 2 ? d.z : d.w));
-                if ((w >> (8 * (k & 3))) & 0xFFu) kept &= ~(1u << k);
+            for (int j = 0; j < (RC + 15) / 16; ++j) {
+                const uint4 d = reinterpret_cast<const uint4 *>(dropb)[2 * lane + j];
+#pragma unroll
+                for (int k = 16 * j; k < RC && k < 16 * j + 16; ++k) {
+                    const int kk = k & 15;
+                    const unsigned w = (kk >> 2) == 0 ? d.x : ((kk >> 2) == 1 ? d.y : ((kk >> 2) == 2 ? d.z : d.w));
+                    if ((w >> (8 * (kk & 3))) & 0xFFu) kept &= ~(1u << k);
+                }
             }
         }
     }
@@ -810,11 +820,11 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
 #define MVOSR_ROAD_MINW 1
 #endif
 __global__ __launch_bounds__(kRoadWaves *kWave, MVOSR_ROAD_MINW) void road_model_kernel(const RoadArgs a) {
-    static_assert(kRoadRC == 16, "the verdict bytes of a lane are read as one 16-byte word");
+    static_assert(kRoadRC >= 16 && kRoadRC <= kDropStride, "verdict bytes per lane; the keep masks are 32 bits");
     __shared__ int hist_all[kRoadWaves][2][176];
     __shared__ double2 edges[kBins + 1];
     __shared__ uint16_t slots_all[kRoadWaves][kRoadRC * kWave];
-    __shared__ __attribute__((aligned(16))) uint8_t drop_all[kRoadWaves][kRoadRC * kWave];
+    __shared__ __attribute__((aligned(16))) uint8_t drop_all[kRoadWaves][kDropStride * kWave];
     for (int k = threadIdx.x; k < kBins; k += kRoadWaves * kWave) { double2 e; e.x = bin_edge(k); e.y = bin_edge(k + 1); edges[k] = e; }
     __syncthreads();
     const int64_t f = a.first_frame + (int64_t)blockIdx.x * kRoadWaves + wave_id();
@@ -833,6 +843,7 @@ __global__ __launch_bounds__(kRoadWaves *kWave, MVOSR_ROAD_MINW) void road_model
     const bool ex = a.o.stats != nullptr;
     const RoadResult R = (M <= 4 * kWave) ? road_wave<4>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
                        : (M <= 8 * kWave) ? road_wave<8>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
+                       : (kRoadRC == 16 || M <= 16 * kWave) ? road_wave<16>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
                                           : road_wave<kRoadRC>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS);
     MVOSR_RSTAMP(6);
 #ifdef MVOSR_STAMPS
