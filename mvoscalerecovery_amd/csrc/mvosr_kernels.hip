@@ -843,6 +843,7 @@ __global__ __launch_bounds__(kRoadWaves *kWave, MVOSR_ROAD_MINW) void road_model
     const bool ex = a.o.stats != nullptr;
     const RoadResult R = (M <= 4 * kWave) ? road_wave<4>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
                        : (M <= 8 * kWave) ? road_wave<8>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
+                       : (M <= 12 * kWave) ? road_wave<12>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
                        : (kRoadRC == 16 || M <= 16 * kWave) ? road_wave<16>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
                                           : road_wave<kRoadRC>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS);
     MVOSR_RSTAMP(6);
