@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
 """Headline benchmark: frames/s of scale recovery on synthetic KITTI-shaped flow.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--features 2000]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--features 2000|20000] [--workload c2|kitti]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of F frames per GPU, resident in HBM:
-mvosr_scale_batch = the scale kernel (feature_remap -> depth-order vote on tri1 -> compaction ->
-per-triangle plane normal / pitch / height on tri2 -> height_level -> selected points; one
-workgroup per frame) + the road-model kernel (histogram / modes / skew -> height -> raw scale; one
-wavefront per frame), then (N>1) one RCCL all-gather of the raw scales + statuses, then the
-window-median kernel over the gathered sequence.  Workload = BASELINE.json configs[1]: 2000 features /
-~4000 triangles per frame (T1~3981 + T2~3780), both Delaunay triangulations precomputed on the
-host (they are inputs of the GPU path, like the optical flow itself).  Weak scaling: every rank
-owns F frames.
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment: this process starts the N ranks itself (N child
+processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before anything here touches a GPU), relays rank 0's
+JSON line and exits non-zero if any rank fails.  A box with fewer than N GPUs is refused unless ``--share-gpu``
+(dry run of the N-rank path: ranks share the devices round-robin, gloo instead of RCCL; marked in the line).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     algorithmic bytes per launch (8*(3N+N)+12*(T1+T2)+12 per frame)
-               / average duration of the dominant kernel (scale_frames_kernel), measured with HIP
-               events recorded on its launch stream around that kernel (mvosr_ctx_profile),
-               against the 8 TB/s HBM peak; `step_*` gives the same for both kernels of the step;
-  cpu_baseline the CPU oracle (NumPy port of the reference) timed on this box's host, one
-               core, on a bounded sample of the same frames (N=1 only).
+One "step" = one pass of the hot path over one batch of F frames per GPU, resident in HBM:
+mvosr_scale_batch = the scale kernel (feature_remap -> depth-order vote on tri1 -> compaction -> per-triangle plane
+normal / pitch / height on tri2 -> height_level -> selected points; one workgroup per frame) + its exact pass over the
+(normally empty) list of frames whose result hangs on the last bits of height_level + the road-model kernel
+(histogram / modes / skew -> height -> raw scale; one wavefront per frame); then (N > 1) ONE all-gather of the ranks'
+(raw_scale, height_level, status) records over RCCL and the window-median kernel reading the gathered buffer in
+place.  Workloads (BASELINE.json configs): ``--features 2000`` = configs[1]/[3] (C2/C4: ~4000 triangles per frame),
+``--features 20000`` = configs[4] (C5, dense frames: the gather kernel), ``--workload kitti`` = the size
+distribution of configs[2] (C3: 300-1500 features per frame, ragged).  Both Delaunay triangulations are precomputed
+on the host (they are inputs of the GPU path, like the optical flow itself); `e2e` in the line says what the whole
+drop-in call reaches with them included.  Weak scaling: every rank owns F frames.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline      algorithmic bytes per launch (8*(3N+N)+12*(T1+T2)+12 per frame) / average duration of
+                the dominant kernel, measured with HIP events recorded on its launch stream around that kernel
+                (mvosr_ctx_profile), against the 8 TB/s HBM peak; `step_*` gives the same for all kernels of the step;
+  cpu_baseline  the CPU oracle (vectorised NumPy port of the reference) on one core of this box, on a bounded sample of
+                the same frames, triangulations supplied; `cpu_baseline_reference_shaped` the loop-faithful flavour
+                (per-triangle Python loops, as the reference is written); `cpu_baseline_all_cores` the vectorised one
+                on every CPU the process may use (N = 1 only);
+  e2e           frames/s of ScaleEstimator.scale_calculation_batch on a bounded sample, host Delaunay x2, packing and
+                uploads included, with the number of host CPUs it used.
 """
 from __future__ import annotations
 
@@ -29,6 +39,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -43,18 +54,68 @@ ABS_REF = 1.75                  # param.camera_h
 WINDOW = 5                      # main.py:55
 
 
-def build_pool(ctx, engine, n_features, pool, seed):
+# ---------------------------------------------------------------------------------------------------------------
+# self-launch (no GPU call may precede this: torch.cuda.device_count() does not initialise the runtime)
+# ---------------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    import socket
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not args.share_gpu:
+        print("bench.py: --gpus %d but this box has %d GPU(s); refusing to run (use --share-gpu for a dry run of the "
+              "%d-rank path on fewer devices)" % (args.gpus, n_dev, args.gpus), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if args.share_gpu:
+            env["MVOSR_SHARE_GPU"] = "1"
+            env["MVOSR_DIST_BACKEND"] = "gloo"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(codes):
+        print("bench.py: rank exit codes %s" % codes, file=sys.stderr)
+        sys.stdout.write(out0 or "")
+        return 1
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        print("bench.py: expected one JSON line from rank 0, got %d" % len(lines), file=sys.stderr)
+        return 1
+    print(lines[0])
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------
+def frame_sizes(args, pool):
+    if args.workload == "kitti":
+        # configs[2]: per-frame feature counts after the VO's masks, a few hundred to ~1500 (C3)
+        rng = np.random.default_rng(4541)
+        return [int(v) for v in rng.integers(300, 1501, pool)]
+    return [args.features] * pool
+
+
+def build_pool(ctx, engine, sizes, seed):
     """P unique synthetic frames, both triangulations (SciPy on the host; the vote mask that the
     second triangulation is built on comes from the GPU vote kernel)."""
     from mvoscalerecovery_amd import packing, synth
     from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs
-    frames = [synth.synth_frame(i, n_features, base_seed=seed) for i in range(pool)]
+    pool = len(sizes)
+    frames = [synth.synth_frame(i, sizes[i], base_seed=seed) for i in range(pool)]
     pf = packing.pack_features([f[0] for f in frames], [f[1] for f in frames])
     t0 = time.perf_counter()
-    packing.attach_tri1(pf)
+    packing.attach_tri1(pf, None, None)
     t_del1 = time.perf_counter() - t0
     cap = int(ctx.lib.mvosr_max_lds_features())
-    if n_features > cap:            # dense frames: Z-order layout (what ScaleEstimator.scale_calculation_batch does)
+    dense = pf.max_feat > cap
+    if dense:            # dense frames: locality layout (what ScaleEstimator.scale_calculation_batch does)
         packing.apply_locality_order(pf, min_features=cap + 1)
     db = DeviceBatch(ctx, pf, with_tri2=False)
     out = DeviceOutputs(ctx, db, counts=True, stage=True)
@@ -65,69 +126,84 @@ def build_pool(ctx, engine, n_features, pool, seed):
     out.free()
     db.free()
     t0 = time.perf_counter()
-    packing.attach_tri2(pf, None, masks, feature_ids=n_features > cap)    # dense: rows numbered over the features (no compaction)
+    packing.attach_tri2(pf, None, masks, None, feature_ids=dense)    # dense: rows numbered over the features (no compaction)
     t_del2 = time.perf_counter() - t0
-    return frames, pf, masks, (t_del1 + t_del2) / pool
+    workers = packing.resolve_workers(None)
+    return frames, pf, masks, (t_del1 + t_del2) * workers / pool       # CPU-seconds of Delaunay per frame
 
 
-def cpu_baseline(frames, pf, gpu_raw, gpu_status, budget_s=12.0):
-    """Time the oracle (one core) on the pool frames with the triangulations supplied, i.e. the
-    same work the GPU kernel does; also checks the GPU results against it."""
-    from oracle import scale_oracle as so
-    done, t_used = 0, 0.0
-    mismatches = 0
-    reordered = any(p is not None for p in (pf.extra.get("perm") or []))
-    tris = {}
-    i = 0
-    P = len(frames)
-    while t_used < budget_s and done < 4 * P:
-        f = i % P
-        if reordered:                      # dense frames were re-laid out for the GPU: the oracle triangulates itself (untimed)
-            if f not in tris:
-                r0 = so.frame_raw_scale(frames[f][0], frames[f][1], ABS_REF)
-                tris[f] = (r0.tri1, r0.tri2)
-            tri1, tri2 = tris[f]
-        else:
-            tri1 = pf.tri1[pf.tri1_off[f]:pf.tri1_off[f + 1]]
-            tri2 = pf.tri2[pf.tri2_off[f]:pf.tri2_off[f + 1]]
-        t0 = time.perf_counter()
-        r = so.frame_raw_scale(frames[f][0], frames[f][1], ABS_REF, tri1, tri2, keep=False)
-        t_used += time.perf_counter() - t0
-        if i < P:
-            same = (r.status == gpu_status[f]) and ((np.isnan(r.raw_scale) and np.isnan(gpu_raw[f])) or r.raw_scale == gpu_raw[f])
-            mismatches += 0 if same else 1
-        done += 1
-        i += 1
-    return done / t_used, done, mismatches
-
-
-_ALL_CORES_JOBS = None          # inherited by the forked workers of cpu_baseline_all_cores
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1).  The sample of the all-cores leg is built and its workers are forked BEFORE the GPU
+# runtime starts (a fork with live GPU runtime threads can deadlock the children).
+# ---------------------------------------------------------------------------------------------------------------
+_ALL_CORES_JOBS = None          # inherited by the forked workers
 
 
 def _all_cores_job(i):
     from oracle import scale_oracle as so
     f3, f2, t1, t2 = _ALL_CORES_JOBS[i % len(_ALL_CORES_JOBS)]
-    return so.frame_raw_scale(f3.copy(), f2, ABS_REF, t1, t2).raw_scale
+    return so.frame_raw_scale(f3.copy(), f2, ABS_REF, t1, t2, keep=False).raw_scale
 
 
-def cpu_baseline_all_cores(frames, pf, per_worker=1500):
-    """The same oracle on every CPU the process may use (cgroup quota respected), one process per CPU,
-    frames dealt round-robin from the pool, triangulations supplied.  Skipped for re-laid-out (dense) pools."""
+def prepare_cpu_legs(sizes, seed, sample=24):
+    """CPU-only sample of the workload (triangulations by the oracle itself) and the forked all-cores pool."""
     global _ALL_CORES_JOBS
     import multiprocessing as mp
-    from mvoscalerecovery_amd import packing
-    if any(p is not None for p in (pf.extra.get("perm") or [])) or pf.tri2_ids:
-        return None
+    from mvoscalerecovery_amd import packing, synth
+    from oracle import scale_oracle as so
+    jobs = []
+    for i in range(min(sample, len(sizes))):
+        f3, f2 = synth.synth_frame(i, sizes[i], base_seed=seed)
+        r = so.frame_raw_scale(f3, f2, ABS_REF)
+        jobs.append((f3, f2, np.ascontiguousarray(r.tri1, dtype=np.int32), np.ascontiguousarray(r.tri2, dtype=np.int32), r.raw_scale, r.status))
+    _ALL_CORES_JOBS = [j[:4] for j in jobs]
     workers = packing.available_cpus()
-    _ALL_CORES_JOBS = [(frames[i][0], frames[i][1], pf.tri1[pf.tri1_off[i]:pf.tri1_off[i + 1]], pf.tri2[pf.tri2_off[i]:pf.tri2_off[i + 1]])
-                       for i in range(len(frames))]
-    n = workers * per_worker
-    with mp.get_context("fork").Pool(workers) as pool:
-        pool.map(_all_cores_job, range(workers * 4))                       # imports + first touches
+    pool = mp.get_context("fork").Pool(workers)
+    pool.map(_all_cores_job, range(workers * 4))                           # imports + first touches
+    return jobs, pool, workers
+
+
+def cpu_single_core(jobs, budget_s, loops=False):
+    from oracle import scale_oracle as so
+    from oracle import scale_oracle_loops as sl
+    done, t_used, mism = 0, 0.0, 0
+    while t_used < budget_s:
+        f3, f2, t1, t2, want_raw, want_st = jobs[done % len(jobs)]
         t0 = time.perf_counter()
-        pool.map(_all_cores_job, range(n), chunksize=25)
-        dt = time.perf_counter() - t0
-    return n / dt, n, workers
+        if loops:
+            raw, st = sl.frame_raw_scale(f3, f2, ABS_REF, t1, t2)[:2]
+        else:
+            r = so.frame_raw_scale(f3, f2, ABS_REF, t1, t2, keep=False)
+            raw, st = r.raw_scale, r.status
+        t_used += time.perf_counter() - t0
+        mism += 0 if (st == want_st and ((np.isnan(raw) and np.isnan(want_raw)) or raw == want_raw)) else 1
+        done += 1
+    return done / t_used, done, mism
+
+
+def cpu_all_cores(pool, workers, per_worker_s, single_core_fps):
+    n = max(workers * 50, int(workers * per_worker_s * single_core_fps))
+    t0 = time.perf_counter()
+    pool.map(_all_cores_job, range(n), chunksize=25)
+    dt = time.perf_counter() - t0
+    pool.close()
+    return n / dt, n
+
+
+def e2e_leg(args, device, sizes, seed, budget_frames):
+    """The drop-in batch call end to end (host Delaunay x2 on the worker pool, packing, uploads, kernels)."""
+    from mvoscalerecovery_amd import packing, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    n = min(budget_frames, 4096)
+    frames = [synth.synth_frame(100000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(n)]
+    est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False)
+    est.scale_calculation_batch([f[0] for f in frames[:64]], [f[1] for f in frames[:64]])         # warm-up (pool, workspaces)
+    t0 = time.perf_counter()
+    est.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames])
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "frames": n, "host_cpus": packing.resolve_workers(None),
+            "what": "ScaleEstimator.scale_calculation_batch: vanishing-row filter, packing, SciPy Delaunay x2 on the host "
+                    "process pool (overlapped with the GPU stages chunk by chunk), uploads, kernels, window median"}
 
 
 def main():
@@ -135,26 +211,51 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=65536, help="frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (0: 65536, or 3072 for dense frames)")
     ap.add_argument("--features", type=int, default=2000)
-    ap.add_argument("--pool", type=int, default=128, help="unique synthetic frames tiled to --frames")
+    ap.add_argument("--workload", choices=("c2", "kitti"), default="c2",
+                    help="c2: every frame has --features features (configs[1]); kitti: 300-1500 per frame (configs[2]'s sizes)")
+    ap.add_argument("--pool", type=int, default=0, help="unique synthetic frames tiled to --frames (0: 1024, or 32 for dense frames)")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts per frame (0 = auto)")
+    ap.add_argument("--share-gpu", action="store_true", help="dry run: more ranks than GPUs (gloo, devices shared round-robin)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--alias-pool", action="store_true",
                     help="diagnostic: every tile reads the feature planes of the SAME pool frames (cache-resident: 41 %% "
                          "less HBM traffic); the JSON line is marked and is not a benchmark result")
     args = ap.parse_args()
 
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        print("bench.py: WORLD_SIZE=%s but --gpus %d" % (env_world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+
+    dense_cfg = args.features > 6000 and args.workload == "c2"
+    pool_n = args.pool or (32 if dense_cfg else 1024)
+    frames_req = args.frames or (3072 if dense_cfg else 65536)
+    pool_n = min(pool_n, frames_req)
+    sizes = frame_sizes(args, pool_n)
+    rank_env = int(os.environ.get("RANK", "0"))
+    want_cpu = args.gpus == 1 and rank_env == 0 and not args.no_cpu_baseline
+
+    # ---- everything that forks, before the GPU runtime exists -------------------------------------------------
+    from mvoscalerecovery_amd import packing
+    cpu_jobs = cpu_pool = None
+    if want_cpu:
+        cpu_jobs, cpu_pool, cpu_workers = prepare_cpu_legs(sizes, 2024, sample=8 if dense_cfg else 24)
+    packing.start_pool(None)
+
     import torch
     import torch.distributed as dist
-    from mvoscalerecovery_amd import _lib, packing, sharding
-    from mvoscalerecovery_amd.engine import DeviceBatch, ScaleEngine
+    from mvoscalerecovery_amd import _lib, sharding
+    from mvoscalerecovery_amd.engine import ScaleEngine
 
     rank, local, world = sharding.init_distributed()
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
     n_gpus = world
+    if os.environ.get("MVOSR_SHARE_GPU") == "1":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     ctx = _lib.Context(local)                       # raises if libmvosr.so / the GPU is missing
     stream = torch.cuda.Stream(device=local)        # a real (non-null) stream shared by torch/RCCL and the kernels
@@ -162,10 +263,10 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     engine = ScaleEngine(ABS_REF, ctx=ctx)
 
-    pool = min(args.pool, args.frames)
-    repeats = max(1, args.frames // pool)
-    F = pool * repeats
-    frames, pf_pool, masks, delaunay_s = build_pool(ctx, engine, args.features, pool, seed=2024)
+    repeats = max(1, frames_req // pool_n)
+    F = pool_n * repeats
+    frames, pf_pool, masks, delaunay_cpu_s = build_pool(ctx, engine, sizes, seed=2024)
+    dense = pf_pool.max_feat > int(ctx.lib.mvosr_max_lds_features())
     # The pool is uploaded once and replicated in HBM on the device (torch.repeat): F frames at distinct
     # addresses (F * 156 KB >> the 256 MB Infinity Cache) without building them on the host.
     dev = torch.device("cuda", local)
@@ -193,19 +294,19 @@ def main():
                          rep("n2", pf_pool.n2_expected, np.int32), pf_pool.max_feat, int(pf_pool.tri2_ids), pool_pad * repeats)
     bytes_per_launch = pf_pool.algorithmic_bytes() * repeats
     n_mean = float(pf_pool.feat_cnt.mean())
-    t1_mean = float(pf_pool.tri1_off[-1]) / pool
-    t2_mean = float(pf_pool.tri2_off[-1]) / pool
+    t1_mean = float(pf_pool.tri1_off[-1]) / pool_n
+    t2_mean = float(pf_pool.tri2_off[-1]) / pool_n
 
-    raw = torch.empty(F, dtype=torch.float64, device=dev)
-    height = torch.empty(F, dtype=torch.float64, device=dev)
-    level = torch.empty(F, dtype=torch.float64, device=dev)
-    status = torch.empty(F, dtype=torch.int32, device=dev)
-    outs = _lib.Outputs(raw.data_ptr(), height.data_ptr(), level.data_ptr(), status.data_ptr(),
-                        None, None, None, None, None, None, None, None)
-    median = sharding.make_gpu_median(engine)
+    # the kernels write this rank's outputs straight into its record; the N-rank step all-gathers the record
     total_frames = F * n_gpus
-
+    rec = sharding.RankRecord(F, dev)
+    height = torch.empty(F, dtype=torch.float64, device=dev)
+    outs = _lib.Outputs(rec.raw.data_ptr(), height.data_ptr(), rec.level.data_ptr(), rec.status.data_ptr(),
+                        None, None, None, None, None, None, None, None)
+    _lib.check(ctx.lib.mvosr_ctx_reserve(ctx.handle, F, pool_pad * repeats), "mvosr_ctx_reserve")    # no hipMalloc inside the timed steps
+    median = sharding.make_gpu_median(engine)
     force_gather = bool(os.environ.get("MVOSR_BENCH_FORCE_GATHER")) and dist.is_initialized()   # diagnostic: the N>1 step on one rank
+    gathered = n_gpus > 1 or force_gather
 
     def step(ev_pair=None):
         if ev_pair is not None:
@@ -214,10 +315,10 @@ def main():
                                              args.waves, 0, 0), "mvosr_scale_batch")
         if ev_pair is not None:
             ctx.record(ev_pair[1])
-        if n_gpus > 1 or force_gather:
-            filtered, _, _ = sharding.gather_and_filter(raw, status, total_frames, WINDOW, median)
+        if gathered:
+            filtered, _ = sharding.gather_and_filter(rec, total_frames, WINDOW, median)
         else:
-            filtered = median(raw, WINDOW)
+            filtered = median(rec.raw, WINDOW)
         return filtered
 
     def barrier():
@@ -227,8 +328,9 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    ctx.profile(True)                    # HIP events around each of the step's two kernels, on the launch stream
+    ctx.profile(True)                    # HIP events around each of the step's kernels, on the launch stream
     events = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
+    c0 = sharding.collectives_issued
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -237,47 +339,55 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    collectives_per_step = (sharding.collectives_issued - c0) / max(args.steps, 1)
     if n_gpus > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    step_ms_avg = float(np.mean([ctx.elapsed_ms(a, b) for a, b in events]))       # both kernels of the step
+    step_ms_avg = float(np.mean([ctx.elapsed_ms(a, b) for a, b in events]))       # all kernels of the step
     prof = [ctx.profile_read(k) for k in range(min(args.steps, 64))]
-    kernel_ms_avg = float(np.mean([p[0] for p in prof]))                               # scale_frames_kernel
+    kernel_ms_avg = float(np.mean([p[0] for p in prof]))                               # scale kernel (+ its exact pass)
     road_ms_avg = float(np.mean([p[1] for p in prof]))                                 # road_model_kernel
     ctx.profile(False)
 
-    gpu_raw = raw[:pool].cpu().numpy()
-    gpu_status = status[:pool].cpu().numpy()
-    st_all = status.cpu().numpy()
+    gpu_raw = rec.raw[:pool_n].cpu().numpy()
+    gpu_status = rec.status[:pool_n].cpu().numpy()
+    st_all = rec.status.cpu().numpy()
 
     if rank == 0:
         value = total_frames * args.steps / elapsed
         achieved = bytes_per_launch / (kernel_ms_avg * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("frames") and tj.get("features") == args.features:
-                    traffic = tj["hbm_bytes_per_frame"] * F          # per launch, like `achieved`
+                ent = tj.get("entries", {}).get("%s_%d" % (args.workload, args.features)) or (tj if tj.get("features") == args.features and args.workload == "c2" else None)
+                if ent and ent.get("frames"):
+                    traffic = ent["hbm_bytes_per_frame"] * F          # per launch, like `achieved`
+                    traffic_src = "profiles/traffic.json (rocprofv3 --pmc passes of this command; not measured in this run)"
             except Exception:
                 traffic = None
+        kname = ("scale_frames_dense_feat_kernel" if (dense and pf_pool.tri2_ids) else "scale_frames_dense_kernel") if dense else "scale_frames_kernel"
+        wl = ("synthetic %d-feature / ~%d-triangle frames (T1~%d, T2~%d)" % (args.features, round(t1_mean + t2_mean), round(t1_mean), round(t2_mean))
+              if args.workload == "c2" else
+              "synthetic KITTI-sized frames, 300-1500 features each (mean %.0f; T1~%d, T2~%d)" % (n_mean, round(t1_mean), round(t2_mean)))
         line = {
             "metric": "frames/sec scale-recovery, KITTI-00 flow (~2k feats/frame), 1/2/4/8 GPU",
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic %d-feature / ~%d-triangle frames (T1~%d, T2~%d), %d frames per step per GPU "
-                                   "(pool of %d unique frames tiled in HBM), precomputed Delaunay x2, single stream"
-                                   % (args.features, round(t1_mean + t2_mean), round(t1_mean), round(t2_mean), F, pool),
+            "config": {"workload": wl + ", %d frames per step per GPU (pool of %d unique frames tiled in HBM), GPU stages only: "
+                                     "both Delaunay triangulations precomputed on the host (see e2e), single stream" % (F, pool_n),
                        "frames_per_step_per_gpu": F, "features_per_frame": n_mean, "tri1_per_frame": t1_mean,
                        "tri2_per_frame": t2_mean, "window": WINDOW, "parallelism": "frames sharded x%d" % n_gpus,
                        "waves_per_frame": args.waves if args.waves else "auto"},
+            "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+            "backend": (dist.get_backend() if dist.is_initialized() else None),
+            "collectives_per_step": collectives_per_step,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("scale_frames_dense_kernel" if args.features > ctx.lib.mvosr_max_lds_features() else "scale_frames_kernel"),
-                         "kernel_ms_avg": kernel_ms_avg,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kname, "kernel_ms_avg": kernel_ms_avg,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "algorithmic_bytes_per_frame": bytes_per_launch / F,
                          "frames_per_s_kernel_only": F / (kernel_ms_avg * 1e-3),
@@ -285,24 +395,39 @@ def main():
                          "step_achieved": bytes_per_launch / (step_ms_avg * 1e-3) / 1e9,
                          "step_frac": bytes_per_launch / (step_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             "status_histogram": {str(k): int(v) for k, v in zip(*np.unique(st_all, return_counts=True))},
-            "host_delaunay_ms_per_frame": delaunay_s * 1e3,
+            "host_delaunay_cpu_ms_per_frame": delaunay_cpu_s * 1e3,
         }
+        if os.environ.get("MVOSR_SHARE_GPU") == "1":
+            line["diagnostic"] = "share-gpu dry run: %d ranks on %d device(s), gloo — NOT a scaling result" % (n_gpus, torch.cuda.device_count())
         if args.alias_pool:
             line["diagnostic"] = "alias-pool: NOT a benchmark result"
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            fps, sample_n, mism = cpu_baseline(frames, pf_pool, gpu_raw, gpu_status)
+        if want_cpu:
+            # the GPU's results for the sample frames (pool frames 0..len(jobs)-1 are the same seeds)
+            mism_gpu = 0
+            for i, j in enumerate(cpu_jobs):
+                ok = gpu_status[i] == j[5] and ((np.isnan(gpu_raw[i]) and np.isnan(j[4])) or gpu_raw[i] == j[4])
+                mism_gpu += 0 if ok else 1
+            line["parity_mismatches_vs_oracle"] = mism_gpu
+            fps, sample_n, _ = cpu_single_core(cpu_jobs, 10.0)
             line["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
-                                    "sample": "%d frames of the same %d-feature pool, triangulations supplied "
-                                              "(NumPy oracle, one thread; host Delaunay %.1f ms/frame not included)"
-                                              % (sample_n, args.features, delaunay_s * 1e3)}
-            line["parity_mismatches_vs_oracle"] = mism
-            allc = cpu_baseline_all_cores(frames, pf_pool)
-            if allc is not None:
-                line["cpu_baseline_all_cores"] = {"value": allc[0], "unit": "frames/s", "cores": allc[2], "kind": "port",
-                                                  "sample": "%d frames dealt from the same pool to %d processes (the CPUs this "
-                                                            "process may use: affinity and cgroup quota), triangulations supplied"
-                                                            % (allc[1], allc[2])}
+                                    "sample": "%d runs over %d frames of the same workload, triangulations supplied (vectorised NumPy "
+                                              "oracle, one thread; host Delaunay %.1f CPU-ms/frame not included)"
+                                              % (sample_n, len(cpu_jobs), delaunay_cpu_s * 1e3)}
+            fps_l, sample_l, mism_l = cpu_single_core(cpu_jobs, 10.0, loops=True)
+            line["cpu_baseline_reference_shaped"] = {
+                "value": fps_l, "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d runs over the same frames; loop-faithful flavour of the oracle (one Python iteration per triangle "
+                          "in find_outliers / feature_selection_by_tri, np.matrix(...).I per triangle, as "
+                          "scale_calculator.py:151-167,228-229 are written), triangulations supplied; %d mismatches vs the vectorised oracle"
+                          % (sample_l, mism_l)}
+            allv, alln = cpu_all_cores(cpu_pool, cpu_workers, 8.0, fps)
+            line["cpu_baseline_all_cores"] = {"value": allv, "unit": "frames/s", "cores": cpu_workers, "kind": "port",
+                                              "sample": "%d frames dealt from the same sample to %d processes (the CPUs this process "
+                                                        "may use: affinity and cgroup quota), triangulations supplied" % (alln, cpu_workers)}
+        if n_gpus == 1 and not args.no_e2e and not dense:
+            line["e2e"] = e2e_leg(args, local, sizes, 2024, 4096)
         print(json.dumps(line))
+        sys.stdout.flush()
     if n_gpus > 1:
         dist.barrier()
         dist.destroy_process_group()

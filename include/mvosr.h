@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MVOSR_ABI_VERSION 2
+#define MVOSR_ABI_VERSION 3
 
 /* error codes (function return values) */
 enum mvosr_err {
@@ -59,7 +59,11 @@ enum mvosr_status {
     MVOSR_ST_ERR_SINGULAR = 7,  /* LinAlgError at scale_calculator.py:229 */
     MVOSR_ST_ERR_MASK = 8,      /* tri2 inconsistent with the vote computed on the GPU, or a
                                    vertex id out of range (build-side check, no reference analogue) */
-    MVOSR_ST_ERR_EMPTY = 9      /* frame without features/triangles (build-side check) */
+    MVOSR_ST_ERR_EMPTY = 9,     /* frame without features/triangles (build-side check) */
+    MVOSR_ST_TOO_FEW = 10       /* 1..3 features below the vanishing row: the reference skips the second
+                                   triangulation (:263-270) and divides by the PREVIOUS frame's height_level
+                                   (:420-422, std 100); raw_scale/height_level are NaN here and the host's
+                                   cross-frame step supplies that level */
 };
 
 /* number of int32 per frame in mvosr_outputs.counts */
@@ -230,6 +234,16 @@ int mvosr_road_model_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_ba
  */
 int mvosr_window_median(mvosr_ctx *ctx, const double *raw, int64_t n, int window,
                         const double *queue_in, int n_queue, double *out);
+
+/*
+ * K4 on a sequence that was all-gathered from `n_blocks` ranks and is still in its gathered form:
+ * block r starts at blocks + r*block_stride (in doubles) and holds rank r's contiguous share of the
+ * n frames (shares as in a contiguous partition: the first n % n_blocks ranks one frame more than
+ * n / n_blocks).  Same result as mvosr_window_median on the concatenated sequence; the gathered
+ * buffer is read in place, so the multi-GPU step is ONE collective and no repacking kernel.
+ */
+int mvosr_window_median_blocked(mvosr_ctx *ctx, const double *blocks, int64_t n, int n_blocks, int64_t block_stride,
+                                int window, const double *queue_in, int n_queue, double *out);
 
 /* ---- the `rescale` variant (the estimator /root/reference/src/main.py:20 imports) ------------- */
 

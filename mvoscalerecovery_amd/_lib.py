@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 TRI2_SURVIVORS, TRI2_FEATURES = 0, 1      # mvosr_batch.tri2_ids
 N_COUNTS = 8
 HIST_BINS = 169
@@ -73,6 +73,7 @@ SYMBOLS = {
     "mvosr_outlier_vote_batch": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Batch), C.POINTER(Outputs), C.c_int]),
     "mvosr_road_model_batch": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Batch), _P, C.POINTER(Outputs), C.c_int]),
     "mvosr_window_median": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, _P]),
+    "mvosr_window_median_blocked": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int, _P, C.c_int, _P]),
     "mvosr_graph_inliers_batch": (C.c_int, [_P, C.POINTER(Batch), C.c_uint32, _P, _P, _P]),
     "mvosr_flat_selection_batch": (C.c_int, [_P, C.POINTER(Batch), C.c_double, C.c_double, C.c_double, _P, _P, _P, _P, _P,
                                              C.c_int64]),

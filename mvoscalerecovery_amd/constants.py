@@ -22,12 +22,14 @@ ST_ERR_RIGHT = 6
 ST_ERR_SINGULAR = 7
 ST_ERR_MASK = 8
 ST_ERR_EMPTY = 9
+ST_TOO_FEW = 10
 
 STATUS_NAMES = {ST_MODE: "mode", ST_RIGHT: "right-edge (skew)", ST_MEDIAN: "median (no modes)",
                 ST_LEVEL: "height_level (no points left)", ST_NO_FLAT: "no flat feature",
                 ST_ERR_LEFT: "IndexError (left)", ST_ERR_RIGHT: "IndexError (right)",
                 ST_ERR_SINGULAR: "LinAlgError (singular triangle)", ST_ERR_MASK: "inconsistent triangulation",
-                ST_ERR_EMPTY: "empty frame"}
+                ST_ERR_EMPTY: "empty frame", ST_TOO_FEW: "too few features below the vanishing row (previous height_level)"}
+ERROR_STATUSES = (ST_ERR_LEFT, ST_ERR_RIGHT, ST_ERR_SINGULAR, ST_ERR_MASK, ST_ERR_EMPTY)   # the frame raises
 
 # enum mvosr_count_slot
 CNT_VALID, CNT_TRI_PITCH, CNT_TRI_VALID, CNT_SELECTED, CNT_KEPT, CNT_MODES, CNT_MODE_LEFT, CNT_MODE_RIGHT = range(8)

@@ -281,6 +281,110 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
     return total;
 }
 
+// np.add.reduce's summation order for a 1-D float64 array (numpy/core/src/umath/loops_utils.h.src,
+// @TYPE@_pairwise_sum: below 8 values a plain loop; up to 128 eight strided accumulators combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the remainder added one by one; above that the halves —
+// the first rounded down to a multiple of 8 — summed recursively).  With sq the terms are
+// (a[i]-shift)^2, as in np.std's  x = arr - mean; x = x*x; sum(x).  Every lane of the wavefront runs it
+// redundantly on the same packed list; it is the cold path behind the skewness decision (road_wave).
+__device__ __forceinline__ double np_term(const double *a, int i, double shift, bool sq) {
+    const double v = a[i];
+    if (!sq) return v;
+    const double d = v - shift;
+    return d * d;
+}
+__device__ double np_leaf_sum(const double *a, int n, double shift, bool sq) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += np_term(a, i, shift, sq);
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = np_term(a, j, shift, sq);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += np_term(a, i + j, shift, sq);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += np_term(a, i, shift, sq);
+    return res;
+}
+__device__ __attribute__((noinline)) double np_pairwise_chunk_cold(const double *a, int n, double shift, int sq) {
+    constexpr int kDepth = 32;                               // > log2 of any list length
+    int lo_s[kDepth], n_s[kDepth], stage_s[kDepth];
+    double val[kDepth];
+    int sp = 0, vp = 0;
+    lo_s[0] = 0; n_s[0] = n; stage_s[0] = 0; sp = 1;
+    while (sp > 0) {
+        const int lo = lo_s[sp - 1], m = n_s[sp - 1], stage = stage_s[sp - 1];
+        if (m <= 128) { val[vp++] = np_leaf_sum(a + lo, m, shift, sq != 0); --sp; continue; }
+        int m2 = m / 2;
+        m2 -= m2 % 8;
+        if (stage == 0) { stage_s[sp - 1] = 1; lo_s[sp] = lo; n_s[sp] = m2; stage_s[sp] = 0; ++sp; }
+        else if (stage == 1) { stage_s[sp - 1] = 2; lo_s[sp] = lo + m2; n_s[sp] = m - m2; stage_s[sp] = 0; ++sp; }
+        else { const double r = val[--vp], l = val[--vp]; val[vp++] = l + r; --sp; }
+    }
+    return val[0];
+}
+
+// np.add.reduce hands its inner loop at most `bufsize` (8192, np.getbufsize()) elements at a time and adds the
+// chunks' pairwise sums up from left to right (checked against NumPy 2.2 for lists of 10^4 - 2*10^5 elements: a single
+// pairwise recursion over the whole list differs in the last bits from 10291 elements on).
+constexpr int kNpBufSize = 8192;
+__device__ __forceinline__ double np_pairwise_sum_cold(const double *a, int n, double shift, int sq) {
+    double res = np_pairwise_chunk_cold(a, min(n, kNpBufSize), shift, sq);
+    for (int lo = kNpBufSize; lo < n; lo += kNpBufSize) res += np_pairwise_chunk_cold(a + lo, min(kNpBufSize, n - lo), shift, sq);
+    return res;
+}
+// The same summation over a STREAM of values (next() hands out the list's elements in order; all lanes of
+// the wavefront run it redundantly with wave-uniform values): the cold path that makes height_level the very
+// double np.mean(heights[pitch_deg >= -80]) is (scale_calculator.py:239-240).
+template <class S>
+__device__ __forceinline__ double np_leaf_stream(S &st, int n) {
+    if (n < 8) {
+        double res = 0.0;
+#pragma unroll 1
+        for (int i = 0; i < n; ++i) res += st.next();
+        return res;
+    }
+    double r[8];
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j) r[j] = st.next();
+    int i = 8;
+#pragma unroll 1
+    for (; i < n - (n % 8); ++i) r[i & 7] = r[i & 7] + st.next();
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll 1
+    for (; i < n; ++i) res += st.next();
+    return res;
+}
+template <class S>
+__device__ __forceinline__ double np_pairwise_chunk_stream(S &st, int n) {
+    constexpr int kDepth = 32;
+    int n_s[kDepth], stage_s[kDepth];
+    double val[kDepth];
+    int sp = 1, vp = 0;
+    n_s[0] = n; stage_s[0] = 0;
+    while (sp > 0) {
+        const int m = n_s[sp - 1], stage = stage_s[sp - 1];
+        if (m <= 128) { val[vp++] = np_leaf_stream(st, m); --sp; continue; }
+        int m2 = m / 2;
+        m2 -= m2 % 8;
+        if (stage == 0) { stage_s[sp - 1] = 1; n_s[sp] = m2; stage_s[sp] = 0; ++sp; }
+        else if (stage == 1) { stage_s[sp - 1] = 2; n_s[sp] = m - m2; stage_s[sp] = 0; ++sp; }
+        else { const double r = val[--vp], l = val[--vp]; val[vp++] = l + r; --sp; }
+    }
+    return val[0];
+}
+template <class S>
+__device__ __forceinline__ double np_pairwise_stream(S &st, int n) {
+    double res = np_pairwise_chunk_stream(st, min(n, kNpBufSize));
+    for (int lo = kNpBufSize; lo < n; lo += kNpBufSize) res += np_pairwise_chunk_stream(st, min(kNpBufSize, n - lo));
+    return res;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Phase B: plane normals / pitch / height over the second triangulation, height_level, and the
 // bit-set of selected (surviving-feature) indices.
@@ -320,7 +424,16 @@ struct SelectResult {
     double height_level;
     int n_pitch, n_tri_valid;
     int singular, bad;
+    int n_steep;          // triangles with pitch_deg >= thr (what height_level averages over)
+    int near;             // a flat triangle's height is within rounding of height_level (hot mode only)
 };
+
+// Kernel modes.  HOT: the product path — height_level from the sweep's own fixed-order sum; a frame whose result could
+// depend on the last bits of that sum (a flat triangle within kLevelGuard of the level, or so few selected points that
+// the level itself may become the height) is not finished but put on the context's redo list.  EXACT: height_level in
+// NumPy's summation order before it is used — the redo pass over that list, and every frame when stage outputs are
+// requested.  FULL: EXACT plus the reference's literal per-triangle formulation and the per-triangle debug outputs.
+enum { MODE_HOT = 0, MODE_EXACT = 1, MODE_FULL = 2 };
 
 struct PitchTest {
     double thr_deg;      // -80
@@ -374,17 +487,86 @@ __device__ __forceinline__ int classify_triangle(double x0, double y0, double z0
     return (is_flat ? 1 : 0) | (is_steep ? 2 : 0) | (is_singular ? 4 : 0);
 }
 
-template <int WAVES, bool FULL, int FW = 1>
+// The heights of the frame's STEEP triangles (pitch_deg >= thr, :239) in the row order of tri2, one at a time and
+// wave-uniform: 64 rows are classified per refill (same decisions as the sweep), the ballot of the steep ones is
+// consumed lowest lane first.  `fetch(q, x0..z2)` supplies a row's vertices (LDS or global) and says whether its
+// ids are legal.
+template <bool FULL, class Fetch>
+struct SteepStream {
+    const int32_t *tri;           // the frame's first row
+    int t2n;
+    const PitchTest &pt;
+    Fetch fetch;
+    int t_next;
+    unsigned long long mask;
+    double h;
+    __device__ __forceinline__ void refill() {
+        const int t = t_next + lane_id();
+        bool steep = false;
+        h = 0.0;
+        if (t < t2n) {
+            const TriIds q = load_tri(tri, t);
+            double x0, y0, z0, x1, y1, z1, x2, y2, z2;
+            if (fetch(q, x0, y0, z0, x1, y1, z1, x2, y2, z2)) {
+                h = div3((y0 + y1) + y2);
+                steep = classify_triangle<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, h, pt, nullptr, nullptr, nullptr, 0) & 2;
+            }
+        }
+        mask = __ballot(steep);
+        t_next += kWave;
+    }
+    __device__ __forceinline__ double next() {
+        while (mask == 0ull) {
+            if (t_next >= t2n) return nan("");                 // (cannot happen: the caller asks for exactly the steep count)
+            refill();
+        }
+        const int l = (int)__ffsll((long long)mask) - 1;
+        mask &= mask - 1ull;
+        return readlane_d(h, l);
+    }
+};
+
+// height_level exactly as NumPy computes it (:239-240): np.mean = pairwise add.reduce over heights[pitch_deg >= -80]
+// in row order, divided by the count.  `n_steep` is the count the sweep found.  Every wavefront that calls it
+// computes the same value (no barrier, nothing written).  Only the EXACT / FULL kernel variants contain it.
+template <bool FULL, class Fetch>
+__device__ __forceinline__ double exact_height_level(const int32_t *tri, int t2n, int n_steep, const PitchTest &pt, Fetch fetch) {
+    if (n_steep <= 0) return nan("");                           // np.mean of an empty slice
+    SteepStream<FULL, Fetch> st{tri, t2n, pt, fetch, 0, 0ull, 0.0};
+    return (0.0 + np_pairwise_stream(st, n_steep)) / (double)n_steep;
+}
+
+struct LdsFetch {            // rows of tri2 index the compacted survivors in LDS
+    const double2 *P; const double *Y; int n_valid;
+    __device__ __forceinline__ bool operator()(const TriIds q, double &x0, double &y0, double &z0, double &x1, double &y1, double &z1,
+                                               double &x2, double &y2, double &z2) const {
+        if ((unsigned)q.a >= (unsigned)n_valid || (unsigned)q.b >= (unsigned)n_valid || (unsigned)q.c >= (unsigned)n_valid) return false;
+        const double2 p0 = P[q.a], p1 = P[q.b], p2 = P[q.c];
+        x0 = p0.x; z0 = p0.y; x1 = p1.x; z1 = p1.y; x2 = p2.x; z2 = p2.y;
+        y0 = Y[q.a]; y1 = Y[q.b]; y2 = Y[q.c];
+        return true;
+    }
+};
+
+// |h - level| within this relative distance: the comparison h > level (:243) may depend on the summation order behind
+// the level, so the level is recomputed in NumPy's order before it is trusted (the sweep's own sum agrees with NumPy's
+// to ~1e-15 relative)
+constexpr double kLevelGuard = 1e-12;
+
+template <int WAVES, int MODE, int FW = 1>
 __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid, const int32_t *tri2, int64_t t2_begin,
                                                      int t2_count, TriChunk<WAVES * kWave> &tc, PitchTest pt,
                                                      double *g_normals, double *g_pitch, double *g_heights, int bad_in,
                                                      int dbg = 0 MVOSR_STAMP_ARG) {
     constexpr int B = WAVES * kWave;
+    constexpr bool FULL = MODE == MODE_FULL;
     const int tid = threadIdx.x;
     unsigned long long flat = 0ull;          // bit kk: my kk-th triangle has pitch_deg < thr
     unsigned long long flat_hi = 0ull;       // bits 64..127 (FW == 2: dense frames, up to 128 triangles per thread)
     double hsum = 0.0, hcnt = 0.0;
     int npitch = 0, singular = 0, bad = 0;
+    // more rows than the per-thread flag words can name (not a triangulation of this frame's points): refuse
+    if (t2_count > 64 * FW * B) { bad = 1; t2_count = 0; }
     // One triangle of the first sweep (:229-240).
     auto test_triangle = [&](int t, int kk, const TriIds q) {
     if ((unsigned)q.a >= (unsigned)n_valid || (unsigned)q.b >= (unsigned)n_valid || (unsigned)q.c >= (unsigned)n_valid) { bad = 1; return; }
@@ -423,14 +605,16 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     block_sum2<WAVES>(hsum, hcnt, s.red + R_SEL_H * 2 * WAVES);
     MVOSR_STAMP(4);
     SelectResult r;
-    r.height_level = hsum / hcnt;                 // np.mean of an empty set -> 0/0 = NaN, like :240
-    const double hl = r.height_level;
-    int ntv = 0;
+    double hl = hsum / hcnt;                      // np.mean of an empty set -> 0/0 = NaN, like :240
+    if constexpr (MODE != MODE_HOT)
+        hl = exact_height_level<FULL>(tri2 + 3 * t2_begin, t2_count, (int)hcnt, pt, LdsFetch{s.P, s.Y, n_valid});
+    int ntv = 0, near = 0;
     auto mark_triangle = [&](int kk, int qa, int qb, int qc) {
         const unsigned long long fw = (FW == 1 || kk < 64) ? flat : flat_hi;
         if (!((fw >> (kk & 63)) & 1ull)) return;
         const double y0 = s.Y[qa], y1 = s.Y[qb], y2 = s.Y[qc];
         const double h = div3((y0 + y1) + y2);
+        if constexpr (MODE == MODE_HOT) { if (fabs(h - hl) <= kLevelGuard * fabs(hl)) near = 1; }
         if (h > hl) {                                                                        // :243-244
             ++ntv;
             atomicOr(&s.sel[qa >> 5], 1u << (qa & 31));                                      // :247
@@ -448,8 +632,13 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
         if (more) tc = tn;
     }
     bad |= bad_in;
-    block_sum4i<WAVES>(npitch, ntv, singular, bad, s.red + R_SEL_CNT * 2 * WAVES);   // also orders the atomicOr's
+    int sn = singular | (near << 16);
+    block_sum4i<WAVES>(npitch, ntv, sn, bad, s.red + R_SEL_CNT * 2 * WAVES);   // also orders the atomicOr's
+    singular = sn & 0xFFFF;
+    r.near = sn >> 16;
     MVOSR_STAMP(5);
+    r.height_level = hl;
+    r.n_steep = (int)hcnt;
     r.n_pitch = npitch; r.n_tri_valid = ntv; r.singular = singular; r.bad = bad;
     return r;
 }
@@ -497,6 +686,8 @@ constexpr int kDropStride = 32;          // verdict bytes per lane in LDS (two 1
 constexpr int kRoadWaves = 4;          // frames (wavefronts) per workgroup
 constexpr int kTrash = 175;            // histogram slot for values that are not binned (bins are 0..168)
 constexpr int kStPending = -1;         // scale kernel -> road kernel: "road model still to run"
+constexpr int kStRedo = -2;            // HOT scale kernel -> EXACT pass: "needs height_level in NumPy's summation order"
+constexpr int kMaxVoteRows = 32765;    // a 16-bit biased vote counter stays in [1, 0xFFFE] whatever the rows say while a vertex has at most this many
 
 struct RoadArgs {
     mvosr_params P;
@@ -518,54 +709,6 @@ __device__ __forceinline__ int bin_of_table(double y, const double2 *edges) {
     k += (k < kBins - 1 && y >= e.y) ? 1 : 0;
     k -= (y < e.x) ? 1 : 0;
     return k;
-}
-
-// np.add.reduce's summation order for a 1-D float64 array (numpy/core/src/umath/loops_utils.h.src,
-// @TYPE@_pairwise_sum: below 8 values a plain loop; up to 128 eight strided accumulators combined as
-// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the remainder added one by one; above that the halves —
-// the first rounded down to a multiple of 8 — summed recursively).  With sq the terms are
-// (a[i]-shift)^2, as in np.std's  x = arr - mean; x = x*x; sum(x).  Every lane of the wavefront runs it
-// redundantly on the same packed list; it is the cold path behind the skewness decision (road_wave).
-__device__ __forceinline__ double np_term(const double *a, int i, double shift, bool sq) {
-    const double v = a[i];
-    if (!sq) return v;
-    const double d = v - shift;
-    return d * d;
-}
-__device__ double np_leaf_sum(const double *a, int n, double shift, bool sq) {
-    if (n < 8) {
-        double res = 0.0;
-        for (int i = 0; i < n; ++i) res += np_term(a, i, shift, sq);
-        return res;
-    }
-    double r[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = np_term(a, j, shift, sq);
-    int i = 8;
-    for (; i < n - (n % 8); i += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] += np_term(a, i + j, shift, sq);
-    }
-    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; ++i) res += np_term(a, i, shift, sq);
-    return res;
-}
-__device__ __attribute__((noinline)) double np_pairwise_sum_cold(const double *a, int n, double shift, int sq) {
-    constexpr int kDepth = 32;                               // > log2 of any list length
-    int lo_s[kDepth], n_s[kDepth], stage_s[kDepth];
-    double val[kDepth];
-    int sp = 0, vp = 0;
-    lo_s[0] = 0; n_s[0] = n; stage_s[0] = 0; sp = 1;
-    while (sp > 0) {
-        const int lo = lo_s[sp - 1], m = n_s[sp - 1], stage = stage_s[sp - 1];
-        if (m <= 128) { val[vp++] = np_leaf_sum(a + lo, m, shift, sq != 0); --sp; continue; }
-        int m2 = m / 2;
-        m2 -= m2 % 8;
-        if (stage == 0) { stage_s[sp - 1] = 1; lo_s[sp] = lo; n_s[sp] = m2; stage_s[sp] = 0; ++sp; }
-        else if (stage == 1) { stage_s[sp - 1] = 2; lo_s[sp] = lo + m2; n_s[sp] = m - m2; stage_s[sp] = 0; ++sp; }
-        else { const double r = val[--vp], l = val[--vp]; val[vp++] = l + r; --sp; }
-    }
-    return val[0];
 }
 
 template <int RC>
@@ -877,6 +1020,8 @@ struct KArgs {
     int64_t first_frame;
     const double *height_level_in;
     int debug_skip;          // ablation bits for profiling runs (env MVOSR_DEBUG_SKIP); 0 in production
+    int32_t *redo;           // workspace: redo[0] = number of frames the HOT kernel left for the EXACT pass, redo[1..] their indices
+    int redo_pass;           // EXACT kernels: 1 = process the redo list (grid-strided), 0 = frame first_frame + blockIdx.x
     double *ysel;            // workspace plane (laid out like x): the selected y' of every frame, dense
     int32_t *nsel;           // workspace [F]: how many
 };
@@ -889,15 +1034,112 @@ __device__ __forceinline__ void write_counts(const KArgs &a, int64_t f, int nval
     c[MVOSR_CNT_MODE_LEFT] = R.mode_left; c[MVOSR_CNT_MODE_RIGHT] = R.mode_right;
 }
 
+// Frames the sweeps never see: nothing below the vanishing row / no second triangulation (build-side
+// MVOSR_ST_ERR_EMPTY), and the reference's "no enough feature for triangulation" branch
+// (scale_calculator.py:263-270): with at most 3 features below the vanishing row it skips the second
+// triangulation and the scale comes from the previous frame's height_level (:420-422) — a cross-frame
+// quantity, resolved by the host's push step from the MVOSR_ST_TOO_FEW status.
+__device__ __forceinline__ bool early_frame_exit(const KArgs &a, int64_t f, int n, int t2n) {
+    const bool too_few = n >= 1 && n <= 3;
+    if (!(n <= 0 || too_few || t2n <= 0)) return false;
+    if (threadIdx.x == 0) {
+        RoadResult R;
+        R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
+        a.o.raw_scale[f] = nan(""); a.o.height[f] = nan(""); a.o.height_level[f] = nan("");
+        a.o.status[f] = too_few ? MVOSR_ST_TOO_FEW : MVOSR_ST_ERR_EMPTY;
+        a.nsel[f] = 0;
+        write_counts(a, f, too_few ? n : 0, 0, 0, R);
+    }
+    return true;
+}
+
+// Tail shared by the scale kernels: status, the dense list of selected y' for the road-model kernel
+// (count per wave slice -> barrier -> ordered store), per-frame outputs.  HOT mode hands a frame to the EXACT pass
+// when its result could depend on the last bits of height_level: a flat triangle within rounding of the level
+// (S.near), or so few selected points that the level itself may become the height — nothing selected
+// (:277-279,:421) or every point alone in its bin, at most one per bin (:334-335).
+template <int BW, int MODE>
+__device__ __forceinline__ void frame_tail(const KArgs &a, const Smem &s, int64_t f, int64_t off, int nvalid, bool refused,
+                                           SelectResult &S, RoadResult &R) {
+    constexpr int B = BW * kWave;
+    const int tid = threadIdx.x;
+    int status = kStPending;
+    double raw = nan("");
+    int nsel = 0;
+    if (refused || S.bad) {
+        status = MVOSR_ST_ERR_MASK;
+    } else if (S.singular) {
+        status = MVOSR_ST_ERR_SINGULAR;
+    } else {
+        const int w = wave_id(), lane = lane_id();
+        const int per = ((nvalid + B - 1) / B) * kWave;
+        const int begin = w * per, end = min(nvalid, begin + per);
+        int cnt = 0;
+        for (int j0 = begin; j0 < end; j0 += kWave) {
+            const int j = j0 + lane;
+            const bool sel = (j < end) && ((s.sel[j >> 5] >> (j & 31)) & 1u);
+            if (a.o.selected && j < end) a.o.selected[off + j] = (uint8_t)sel;                   // :247
+            cnt += __popcll(__ballot(sel));
+        }
+        if (lane == 0) s.misc[M_WCNT + w] = cnt;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < BW; ++i) { const int c = s.misc[M_WCNT + i]; if (i < w) base += c; nsel += c; }
+        if constexpr (MODE == MODE_HOT) {
+            if (S.near || nsel <= kBins) {
+                if (tid == 0) { a.redo[1 + atomicAdd(a.redo, 1)] = (int32_t)f; a.o.status[f] = kStRedo; a.nsel[f] = 0; }
+                return;
+            }
+        }
+        double *dst = a.ysel + off;
+        for (int j0 = begin; j0 < end; j0 += kWave) {
+            const int j = j0 + lane;
+            const bool sel = (j < end) && ((s.sel[j >> 5] >> (j & 31)) & 1u);
+            const unsigned long long m = __ballot(sel);
+            if (sel) dst[base + __popcll(m & ((1ull << lane) - 1ull))] = s.Y[j];
+            base += __popcll(m);
+        }
+        if (nsel == 0) { status = MVOSR_ST_NO_FLAT; raw = a.P.absolute_reference / S.height_level; }   // :277-279,:421
+    }
+    if (tid == 0) {
+        a.o.raw_scale[f] = raw;
+        a.o.height[f] = nan("");
+        a.o.height_level[f] = S.height_level;
+        a.o.status[f] = status;                  // kStPending: the road-model kernel finishes the frame
+        a.nsel[f] = nsel;
+        R.n_sel = nsel;
+        write_counts(a, f, nvalid, S.n_pitch, S.n_tri_valid, R);
+        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = st[1] = st[2] = st[3] = nan(""); }
+    }
+}
+
+// The frames of a launch: frame first_frame + blockIdx.x — or, in the EXACT pass over the redo list, the list's entries
+// strided over the grid (the list is short or empty; its length is only known on the device).
+template <int MODE, class Body>
+__device__ __forceinline__ void for_frames(const KArgs &a, Body body) {
+    if constexpr (MODE == MODE_EXACT) {
+        if (a.redo_pass) {
+            const int count = a.redo[0];
+            for (int i = blockIdx.x; i < count; i += gridDim.x) {
+                body((int64_t)a.redo[1 + i]);
+                __syncthreads();                  // the next frame reuses the workgroup's LDS
+            }
+            return;
+        }
+    }
+    body(a.first_frame + blockIdx.x);
+}
+
 #ifndef MVOSR_MINW
 #define MVOSR_MINW 1
 #endif
-template <int WAVES, int SC, bool FULL>
-__global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(const KArgs a) {
+// (the 8-wavefront product variants must stay within 80 VGPRs: three workgroups per CU are six wavefronts per SIMD)
+template <int WAVES, int SC, int MODE>
+__global__ __launch_bounds__(WAVES *kWave, (WAVES == 8 && MODE == MODE_HOT ? 6 : MVOSR_MINW)) void scale_frames_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    for_frames<MODE>(a, [&](const int64_t f) {
     constexpr int B = WAVES * kWave;
-    const int tid = threadIdx.x;
-    const int64_t f = a.first_frame + blockIdx.x;
     const int n = a.b.feat_cnt[f];
     const int64_t off = a.b.feat_off[f];
     const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
@@ -909,15 +1151,7 @@ __global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(
     RoadResult R;
     R.height = nan(""); R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
     R.mean = R.std = R.skew = R.median = nan("");
-    if (n <= 0 || t2n <= 0) {
-        if (tid == 0) {
-            a.o.raw_scale[f] = nan(""); a.o.height[f] = nan(""); a.o.height_level[f] = nan("");
-            a.o.status[f] = MVOSR_ST_ERR_EMPTY;
-            a.nsel[f] = 0;
-            write_counts(a, f, 0, 0, 0, R);
-        }
-        return;
-    }
+    if (early_frame_exit(a, f, n, t2n)) return;
     int bad = 0;
     TriChunk<B> tc2;
     const int nvalid = phase_vote<WAVES, SC>(s, n, a.b.x + off, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
@@ -927,62 +1161,19 @@ __global__ __launch_bounds__(WAVES *kWave, MVOSR_MINW) void scale_frames_kernel(
     const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
 
     SelectResult S;
-    S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 1;
-    if (!mask_mismatch)
-        S = phase_select<WAVES, FULL>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
+    S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 1; S.n_steep = 0; S.near = 0;
+    // more rows than a vertex's 16-bit vote counter can absorb (|votes| < 32766): not a triangulation of this frame
+    const bool too_many_rows = t1n > kMaxVoteRows;
+    if (!mask_mismatch && !too_many_rows)
+        S = phase_select<WAVES, MODE>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
                                       a.o.tri_heights, bad, a.debug_skip MVOSR_STAMP_PASS);
-    int status = kStPending;
-    double raw = nan("");
-    int nsel = 0;
-    if (mask_mismatch || S.bad || (a.debug_skip & 8)) {      // S.bad: vertex-id errors of both sweeps, summed over the block
-        status = MVOSR_ST_ERR_MASK;
-    } else if (S.singular) {
-        status = MVOSR_ST_ERR_SINGULAR;
-    } else {
-        // Hand the selected y' to the road-model kernel as one dense list: every wave packs its slice
-        // of Y in place (ballot prefix; a value moves to an index <= its own and a sub-chunk is read
-        // by one instruction before any of it is overwritten), then stores it at the wave's offset.
-        const int w = wave_id(), lane = lane_id();
-        const int per = (nvalid + B - 1) / B;
-        const int wbeg = w * per * kWave;
-        double *mine = s.Y + wbeg;
-        int cnt = 0;
-        for (int k = 0; k < per; ++k) {
-            const int j = wbeg + k * kWave + lane;
-            bool sel = false;
-            double y = 0.0;
-            if (j < nvalid) {
-                sel = (s.sel[j >> 5] >> (j & 31)) & 1u;
-                y = s.Y[j];
-                if (a.o.selected) a.o.selected[off + j] = (uint8_t)sel;                          // :247
-            }
-            const unsigned long long m = __ballot(sel);
-            if (sel) mine[cnt + __popcll(m & ((1ull << lane) - 1ull))] = y;
-            cnt += __popcll(m);
-        }
-        if (lane == 0) s.misc[M_WCNT + w] = cnt;
-        __syncthreads();
-        int base = 0;
-#pragma unroll
-        for (int i = 0; i < WAVES; ++i) { const int c = s.misc[M_WCNT + i]; if (i < w) base += c; nsel += c; }
-        double *dst = a.ysel + off + base;
-        for (int i = lane; i < cnt; i += kWave) dst[i] = mine[i];
-        if (nsel == 0) { status = MVOSR_ST_NO_FLAT; raw = a.P.absolute_reference / S.height_level; }   // :277-279,:421
-    }
+    if (a.debug_skip & 8) S.bad = 1;
+    frame_tail<WAVES, MODE>(a, s, f, off, nvalid, mask_mismatch || too_many_rows, S, R);
     MVOSR_STAMP(9);
 #ifdef MVOSR_STAMPS
-    if (tid == 0 && a.o.hist) { unsigned long long *d = reinterpret_cast<unsigned long long *>(a.o.hist + f * 2 * kBins); for (int i = 0; i < 10; ++i) d[i] = stamps[i]; }
+    if (threadIdx.x == 0 && a.o.hist) { unsigned long long *d = reinterpret_cast<unsigned long long *>(a.o.hist + f * 2 * kBins); for (int i = 0; i < 10; ++i) d[i] = stamps[i]; }
 #endif
-    if (tid == 0) {
-        a.o.raw_scale[f] = raw;
-        a.o.height[f] = nan("");
-        a.o.height_level[f] = S.height_level;
-        a.o.status[f] = status;                  // kStPending: the road-model kernel finishes the frame
-        a.nsel[f] = nsel;
-        R.n_sel = nsel;
-        write_counts(a, f, nvalid, S.n_pitch, S.n_tri_valid, R);
-        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = st[1] = st[2] = st[3] = nan(""); }
-    }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1012,6 +1203,7 @@ __device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n,
     for (int i = tid; i < ((n + 1) >> 1); i += B) c32[i] = ones;
     __threadfence_block();
     __syncthreads();
+    const bool checked = t1_count > kMaxVoteRows;
     for (int t = tid; t < t1_count; t += B) {
         const TriIds q = load_tri(tri1 + 3 * t1_begin, t);
         if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
@@ -1025,10 +1217,20 @@ __device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n,
         const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
         const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
         const bool f0 = pa | pb, f1 = pa | pb | pc, f2 = pc;
-        const uint32_t u0 = 1u << ((q.a & 1) * 16), u1 = 1u << ((q.b & 1) * 16), u2 = 1u << ((q.c & 1) * 16);
-        atomicAdd(&c32[q.a >> 1], f0 ? 0u - u0 : u0);
-        atomicAdd(&c32[q.b >> 1], f1 ? 0u - u1 : u1);
-        atomicAdd(&c32[q.c >> 1], f2 ? 0u - u2 : u2);
+        const int s0 = (q.a & 1) * 16, s1 = (q.b & 1) * 16, s2 = (q.c & 1) * 16;
+        const uint32_t u0 = 1u << s0, u1 = 1u << s1, u2 = 1u << s2;
+        if (!checked) {
+            atomicAdd(&c32[q.a >> 1], f0 ? 0u - u0 : u0);
+            atomicAdd(&c32[q.b >> 1], f1 ? 0u - u1 : u1);
+            atomicAdd(&c32[q.c >> 1], f2 ? 0u - u2 : u2);
+        } else {
+            // the frame has enough rows for one vertex to push its 16-bit half over an end: look at the value each
+            // update found (a -1 on 0 borrows from, a +1 on 0xFFFF carries into, the neighbouring feature's half)
+            const uint32_t o0 = (atomicAdd(&c32[q.a >> 1], f0 ? 0u - u0 : u0) >> s0) & 0xFFFFu;
+            const uint32_t o1 = (atomicAdd(&c32[q.b >> 1], f1 ? 0u - u1 : u1) >> s1) & 0xFFFFu;
+            const uint32_t o2 = (atomicAdd(&c32[q.c >> 1], f2 ? 0u - u2 : u2) >> s2) & 0xFFFFu;
+            if (o0 == (f0 ? 0u : 0xFFFFu) || o1 == (f1 ? 0u : 0xFFFFu) || o2 == (f2 ? 0u : 0xFFFFu)) bad = 1;
+        }
     }
     __syncthreads();
     const int per = ((n + B - 1) / B) * kWave;
@@ -1071,67 +1273,13 @@ __device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n,
 
 struct DenseArgs { KArgs k; DenseWs ws; };
 
-// Tail shared by the dense variants: status, the dense list of selected y' for the road-model kernel
-// (count per wave slice -> barrier -> ordered store), per-frame outputs.
-template <int DW>
-__device__ __forceinline__ void dense_tail(const KArgs &a, const Smem &s, int64_t f, int64_t off, int nvalid, bool mask_mismatch,
-                                           const SelectResult &S, RoadResult &R) {
-    constexpr int B = DW * kWave;
-    const int tid = threadIdx.x;
-    int status = kStPending;
-    double raw = nan("");
-    int nsel = 0;
-    if (mask_mismatch || S.bad) {
-        status = MVOSR_ST_ERR_MASK;
-    } else if (S.singular) {
-        status = MVOSR_ST_ERR_SINGULAR;
-    } else {
-        // dense list of the selected y' for the road-model kernel: count per wave slice, then store
-        const int w = wave_id(), lane = lane_id();
-        const int per = ((nvalid + B - 1) / B) * kWave;
-        const int begin = w * per, end = min(nvalid, begin + per);
-        int cnt = 0;
-        for (int j0 = begin; j0 < end; j0 += kWave) {
-            const int j = j0 + lane;
-            const bool sel = (j < end) && ((s.sel[j >> 5] >> (j & 31)) & 1u);
-            if (a.o.selected && j < end) a.o.selected[off + j] = (uint8_t)sel;                   // :247
-            cnt += __popcll(__ballot(sel));
-        }
-        if (lane == 0) s.misc[M_WCNT + w] = cnt;
-        __syncthreads();
-        int base = 0;
-#pragma unroll
-        for (int i = 0; i < DW; ++i) { const int c = s.misc[M_WCNT + i]; if (i < w) base += c; nsel += c; }
-        double *dst = a.ysel + off;
-        for (int j0 = begin; j0 < end; j0 += kWave) {
-            const int j = j0 + lane;
-            const bool sel = (j < end) && ((s.sel[j >> 5] >> (j & 31)) & 1u);
-            const unsigned long long m = __ballot(sel);
-            if (sel) dst[base + __popcll(m & ((1ull << lane) - 1ull))] = s.Y[j];
-            base += __popcll(m);
-        }
-        if (nsel == 0) { status = MVOSR_ST_NO_FLAT; raw = a.P.absolute_reference / S.height_level; }   // :277-279,:421
-    }
-    if (tid == 0) {
-        a.o.raw_scale[f] = raw;
-        a.o.height[f] = nan("");
-        a.o.height_level[f] = S.height_level;
-        a.o.status[f] = status;
-        a.nsel[f] = nsel;
-        R.n_sel = nsel;
-        write_counts(a, f, nvalid, S.n_pitch, S.n_tri_valid, R);
-        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = st[1] = st[2] = st[3] = nan(""); }
-    }
-}
-
-
-template <int DW, bool FULL>
+template <int DW, int MODE>
 __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const DenseArgs da) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KArgs &a = da.k;
+    for_frames<MODE>(a, [&](const int64_t f) {
     constexpr int B = DW * kWave;
     const int tid = threadIdx.x;
-    const int64_t f = a.first_frame + blockIdx.x;
     const int n = a.b.feat_cnt[f];
     const int64_t off = a.b.feat_off[f];
     const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
@@ -1139,14 +1287,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const Den
     RoadResult R;
     R.height = nan(""); R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
     R.mean = R.std = R.skew = R.median = nan("");
-    if (n <= 0 || t2n <= 0) {
-        if (tid == 0) {
-            a.o.raw_scale[f] = nan(""); a.o.height[f] = nan(""); a.o.height_level[f] = nan("");
-            a.o.status[f] = MVOSR_ST_ERR_EMPTY; a.nsel[f] = 0;
-            write_counts(a, f, 0, 0, 0, R);
-        }
-        return;
-    }
+    if (early_frame_exit(a, f, n, t2n)) return;
     const uint32_t npad = (uint32_t)((n + 1) & ~1);
     Smem s;
     s.c32 = reinterpret_cast<uint32_t *>(smem);
@@ -1164,14 +1305,15 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const Den
                                               da.ws.P2 + off, da.ws.Y2 + off);
     const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
     SelectResult S;
-    S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 1;
+    S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 1; S.n_steep = 0; S.near = 0;
     if (!mask_mismatch) {
         TriChunk<B> tc2;
         tc2.load(a.b.tri2, t2b, t2n, 0, tid);
-        S = phase_select<DW, FULL, 2>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
-                                            a.o.tri_heights, bad, 0);
+        S = phase_select<DW, MODE, 2>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
+                                      a.o.tri_heights, bad, 0);
     }
-    dense_tail<DW>(a, s, f, off, nvalid, mask_mismatch, S, R);
+    frame_tail<DW, MODE>(a, s, f, off, nvalid, mask_mismatch, S, R);
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1183,13 +1325,14 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const Den
 // traffic: the planes twice (two gather sweeps) and the triangle rows — about a quarter less than
 // the variant that writes and re-reads the survivors' planes.
 // ---------------------------------------------------------------------------------------------
-template <int DW, bool FULL>
+template <int DW, int MODE>
 __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(const DenseArgs da) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KArgs &a = da.k;
+    for_frames<MODE>(a, [&](const int64_t f) {
     constexpr int B = DW * kWave;
+    constexpr bool FULL = MODE == MODE_FULL;
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    const int64_t f = a.first_frame + blockIdx.x;
     const int n = a.b.feat_cnt[f];
     const int64_t off = a.b.feat_off[f];
     const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
@@ -1197,14 +1340,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
     RoadResult R;
     R.height = nan(""); R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
     R.mean = R.std = R.skew = R.median = nan("");
-    if (n <= 0 || t2n <= 0) {
-        if (tid == 0) {
-            a.o.raw_scale[f] = nan(""); a.o.height[f] = nan(""); a.o.height_level[f] = nan("");
-            a.o.status[f] = MVOSR_ST_ERR_EMPTY; a.nsel[f] = 0;
-            write_counts(a, f, 0, 0, 0, R);
-        }
-        return;
-    }
+    if (early_frame_exit(a, f, n, t2n)) return;
     const uint32_t npad = (uint32_t)((n + 1) & ~1);
     uint32_t *c32 = reinterpret_cast<uint32_t *>(smem);
     const uint16_t *c16 = reinterpret_cast<const uint16_t *>(smem);
@@ -1219,25 +1355,34 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
                                                    a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad, nullptr, nullptr);
     const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
     SelectResult S;
-    S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 1;
+    S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 1; S.n_steep = 0; S.near = 0;
+    const int32_t *tri = a.b.tri2 + 3 * t2b;
+    // a row's vertices from the caller's planes (remap on the fly); legal only if every vertex survived the vote
+    auto fetch = [=](const TriIds q, double &x0, double &y0, double &z0, double &x1, double &y1, double &z1,
+                     double &x2, double &y2, double &z2) -> bool {
+        const bool ok = (unsigned)q.a < (unsigned)n && (unsigned)q.b < (unsigned)n && (unsigned)q.c < (unsigned)n &&
+                        c16[q.a] >= kCounterBias && c16[q.b] >= kCounterBias && c16[q.c] >= kCounterBias;      // survivors only (:166)
+        if (!ok) return false;
+        const double ya = gy[q.a], za = gz[q.a], yb = gy[q.b], zb = gz[q.b], yc = gy[q.c], zc = gz[q.c];
+        x0 = gx[q.a]; x1 = gx[q.b]; x2 = gx[q.c];
+        y0 = ya * cp - za * sp; y1 = yb * cp - zb * sp; y2 = yc * cp - zc * sp;       // :391
+        z0 = ya * sp + za * cp; z1 = yb * sp + zb * cp; z2 = yc * sp + zc * cp;       // :392
+        return true;
+    };
     if (!mask_mismatch) {
-        const int32_t *tri = a.b.tri2 + 3 * t2b;
         unsigned long long flat = 0ull, flat_hi = 0ull;      // bit kk: my kk-th triangle has pitch_deg < thr
         double hsum = 0.0, hcnt = 0.0;
-        int npitch = 0, singular = 0, ntv = 0;
+        int npitch = 0, singular = 0, ntv = 0, near = 0;
+        if (t2n > 128 * B) bad = 1;                          // more rows than the per-thread flag words can name
+        const int t2s = bad ? 0 : t2n;
         TriIds cur = {0, 0, 0};
-        if (tid < t2n) cur = load_tri(tri, tid);
-        for (int base = 0, kk = 0; base < t2n; base += B, ++kk) {
+        if (tid < t2s) cur = load_tri(tri, tid);
+        for (int base = 0, kk = 0; base < t2s; base += B, ++kk) {
             const TriIds q = cur;
-            if (base + B + tid < t2n) cur = load_tri(tri, base + B + tid);
-            if (base + tid >= t2n) continue;
-            const bool ok = (unsigned)q.a < (unsigned)n && (unsigned)q.b < (unsigned)n && (unsigned)q.c < (unsigned)n &&
-                            c16[q.a] >= kCounterBias && c16[q.b] >= kCounterBias && c16[q.c] >= kCounterBias;      // survivors only (:166)
-            if (!ok) { bad = 1; continue; }
-            const double ya = gy[q.a], za = gz[q.a], yb = gy[q.b], zb = gz[q.b], yc = gy[q.c], zc = gz[q.c];
-            const double x0 = gx[q.a], x1 = gx[q.b], x2 = gx[q.c];
-            const double y0 = ya * cp - za * sp, y1 = yb * cp - zb * sp, y2 = yc * cp - zc * sp;       // :391
-            const double z0 = ya * sp + za * cp, z1 = yb * sp + zb * cp, z2 = yc * sp + zc * cp;       // :392
+            if (base + B + tid < t2s) cur = load_tri(tri, base + B + tid);
+            if (base + tid >= t2s) continue;
+            double x0, y0, z0, x1, y1, z1, x2, y2, z2;
+            if (!fetch(q, x0, y0, z0, x1, y1, z1, x2, y2, z2)) { bad = 1; continue; }
             const double h = div3((y0 + y1) + y2);                                               // :238
             const int r = classify_triangle<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, h, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
                                                   a.o.tri_heights, t2b + base + tid);
@@ -1249,17 +1394,18 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
             }
         }
         cur = {0, 0, 0};
-        if (tid < t2n) cur = load_tri(tri, tid);
+        if (tid < t2s) cur = load_tri(tri, tid);
         block_sum2<DW>(hsum, hcnt, red + R_SEL_H * 2 * DW);
-        S.height_level = hsum / hcnt;                 // np.mean of an empty set -> 0/0 = NaN, like :240
-        const double hl = S.height_level;
-        for (int base = 0, kk = 0; base < t2n; base += B, ++kk) {
+        double hl = hsum / hcnt;                      // np.mean of an empty set -> 0/0 = NaN, like :240
+        if constexpr (MODE != MODE_HOT) hl = exact_height_level<FULL>(tri, t2s, (int)hcnt, a.pt, fetch);
+        for (int base = 0, kk = 0; base < t2s; base += B, ++kk) {
             const TriIds q = cur;
-            if (base + B + tid < t2n) cur = load_tri(tri, base + B + tid);
+            if (base + B + tid < t2s) cur = load_tri(tri, base + B + tid);
             const unsigned long long fw = kk < 64 ? flat : flat_hi;
-            if (base + tid < t2n && ((fw >> (kk & 63)) & 1ull)) {
+            if (base + tid < t2s && ((fw >> (kk & 63)) & 1ull)) {
                 const double y0 = gy[q.a] * cp - gz[q.a] * sp, y1 = gy[q.b] * cp - gz[q.b] * sp, y2 = gy[q.c] * cp - gz[q.c] * sp;
                 const double h = div3((y0 + y1) + y2);
+                if constexpr (MODE == MODE_HOT) { if (fabs(h - hl) <= kLevelGuard * fabs(hl)) near = 1; }
                 if (h > hl) {                                                                    // :243-244
                     ++ntv;
                     atomicOr(&sel[q.a >> 5], 1u << (q.a & 31));                                  // :247
@@ -1268,8 +1414,10 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
                 }
             }
         }
-        block_sum4i<DW>(npitch, ntv, singular, bad, red + R_SEL_CNT * 2 * DW);   // also orders the atomicOr's
-        S.n_pitch = npitch; S.n_tri_valid = ntv; S.singular = singular; S.bad = bad;
+        int sn = singular | (near << 16);
+        block_sum4i<DW>(npitch, ntv, sn, bad, red + R_SEL_CNT * 2 * DW);   // also orders the atomicOr's
+        S.height_level = hl; S.n_steep = (int)hcnt; S.near = sn >> 16;
+        S.n_pitch = npitch; S.n_tri_valid = ntv; S.singular = sn & 0xFFFF; S.bad = bad;
     }
     int status = kStPending;
     double raw = nan("");
@@ -1296,6 +1444,12 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
         int base_s = 0, base_v = 0;
 #pragma unroll
         for (int i = 0; i < DW; ++i) { const int c = misc[M_WCNT + i]; if (i < w) { base_s += c; base_v += misc[M_WCNT + DW + i]; } nsel += c; }
+        if constexpr (MODE == MODE_HOT) {
+            if (S.near || nsel <= kBins) {       // the level's last bits may matter: leave the frame to the EXACT pass
+                if (tid == 0) { a.redo[1 + atomicAdd(a.redo, 1)] = (int32_t)f; a.o.status[f] = kStRedo; a.nsel[f] = 0; }
+                return;
+            }
+        }
         double *dst = a.ysel + off;
         for (int i0 = begin; i0 < end; i0 += kWave) {
             const int i = i0 + lane;
@@ -1320,6 +1474,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
         write_counts(a, f, nvalid, S.n_pitch, S.n_tri_valid, R);
         if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = st[1] = st[2] = st[3] = nan(""); }
     }
+    });
 }
 
 template <int DW>
@@ -1365,7 +1520,7 @@ __global__ __launch_bounds__(WAVES *kWave) void outlier_vote_kernel(const KArgs 
     const int nvalid = phase_vote<WAVES, SC>(s, n, nullptr, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
                                              a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters + off, bad, nullptr, 0, 0, unused,
                                              0 MVOSR_STAMP_PASS);
-    int b0 = bad, b1 = 0, b2 = 0, b3 = 0;
+    int b0 = bad | (t1n > kMaxVoteRows ? 1 : 0), b1 = 0, b2 = 0, b3 = 0;
     block_sum4i<WAVES>(b0, b1, b2, b3, s.red + R_MISC * 2 * WAVES);
     if (threadIdx.x == 0) {
         if (a.o.counts) a.o.counts[f * MVOSR_N_COUNTS + MVOSR_CNT_VALID] = nvalid;
@@ -1373,12 +1528,24 @@ __global__ __launch_bounds__(WAVES *kWave) void outlier_vote_kernel(const KArgs 
     }
 }
 
-// K4: sliding-window median of the raw scale sequence (scale_filtering, :396-400)
+// K4: sliding-window median of the raw scale sequence (scale_filtering, :396-400).  The sequence is
+// either one contiguous array or, after the all-gather of the per-rank records, `n_blocks` blocks
+// `stride` doubles apart holding the ranks' contiguous shares (the first `extra` blocks one frame more
+// than `base_len`): element i is read in place, the gathered buffer is never repacked.
 constexpr int kMaxWindow = 64;
 struct MedianArgs {
     const double *raw; double *out; int64_t n; int window; int n_queue;
+    int n_blocks; int64_t base_len, extra, stride;
     double queue[kMaxWindow];
 };
+__device__ __forceinline__ double median_seq_at(const MedianArgs &a, int64_t i) {
+    if (a.n_blocks <= 1) return a.raw[i];
+    const int64_t head = a.extra * (a.base_len + 1);
+    int64_t r, j;
+    if (i < head) { r = i / (a.base_len + 1); j = i - r * (a.base_len + 1); }
+    else { const int64_t k = i - head; r = a.extra + k / a.base_len; j = k - (r - a.extra) * a.base_len; }
+    return a.raw[r * a.stride + j];
+}
 __global__ __launch_bounds__(256) void window_median_kernel(const MedianArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
@@ -1391,7 +1558,7 @@ __global__ __launch_bounds__(256) void window_median_kernel(const MedianArgs a) 
     bool has_nan = false;
     for (int k = 0; k < m; ++k) {
         const int64_t p = first + k;
-        const double x = (p < a.n_queue) ? a.queue[p] : a.raw[p - a.n_queue];
+        const double x = (p < a.n_queue) ? a.queue[p] : median_seq_at(a, p - a.n_queue);
         has_nan |= (x != x);
         int j = k;                                   // insertion sort
         while (j > 0 && w[j - 1] > x) { w[j] = w[j - 1]; --j; }
@@ -1478,19 +1645,46 @@ static int check_fit(const mvosr_batch *b, int waves, int sc, size_t lds) {
     return MVOSR_OK;
 }
 
+// One step of a scale-kernel family (its HOT / EXACT / FULL instantiations): FULL and EXACT run every frame of the
+// range in that mode; HOT runs the product variant and then the EXACT variant over the redo list the HOT kernel
+// filled (a short persistent grid: the list's length is only known on the device, and is almost always zero).
+constexpr int kRedoGrid = 512;
+static inline KArgs &kargs_of(KArgs &a) { return a; }
+static inline KArgs &kargs_of(DenseArgs &a) { return a.k; }
+
+template <class Args>
+static int launch_modes(mvosr_ctx *ctx, void (*k_hot)(const Args), void (*k_exact)(const Args), void (*k_full)(const Args),
+                        Args args, int64_t nl, int threads, size_t lds, int mode, const char *name) {
+    int rc;
+    kargs_of(args).redo_pass = 0;
+    if (mode == MODE_FULL) {
+        if ((rc = prepare_kernel(k_full, lds))) return rc;
+        hipLaunchKernelGGL(k_full, dim3((unsigned)nl), dim3(threads), lds, ctx_stream(ctx), args);
+        return check_launch(name);
+    }
+    if ((rc = prepare_kernel(k_exact, lds))) return rc;
+    if (mode == MODE_EXACT) {
+        hipLaunchKernelGGL(k_exact, dim3((unsigned)nl), dim3(threads), lds, ctx_stream(ctx), args);
+        return check_launch(name);
+    }
+    if ((rc = prepare_kernel(k_hot, lds))) return rc;
+    const hipError_t e = hipMemsetAsync(kargs_of(args).redo, 0, sizeof(int32_t), ctx_stream(ctx));
+    if (e != hipSuccess) return set_hip_error("hipMemsetAsync(redo list)", e);
+    hipLaunchKernelGGL(k_hot, dim3((unsigned)nl), dim3(threads), lds, ctx_stream(ctx), args);
+    if ((rc = check_launch(name))) return rc;
+    kargs_of(args).redo_pass = 1;
+    const unsigned grid = (unsigned)(nl < (int64_t)kRedoGrid ? nl : (int64_t)kRedoGrid);
+    hipLaunchKernelGGL(k_exact, dim3(grid), dim3(threads), lds, ctx_stream(ctx), args);
+    return check_launch(name);
+}
+
 template <int WAVES, int SC>
-static int launch_scale(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool full) {
+static int launch_scale(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, int mode) {
     const size_t lds = lds_plan(ka.b.max_feat, WAVES).total;
     int rc = check_fit(&ka.b, WAVES, SC, lds);
     if (rc) return rc;
-    if (full) {
-        if ((rc = prepare_kernel(scale_frames_kernel<WAVES, SC, true>, lds))) return rc;
-        hipLaunchKernelGGL((scale_frames_kernel<WAVES, SC, true>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
-    } else {
-        if ((rc = prepare_kernel(scale_frames_kernel<WAVES, SC, false>, lds))) return rc;
-        hipLaunchKernelGGL((scale_frames_kernel<WAVES, SC, false>), dim3((unsigned)nl), dim3(WAVES * kWave), lds, ctx_stream(ctx), ka);
-    }
-    return check_launch("scale_frames_kernel");
+    return launch_modes<KArgs>(ctx, scale_frames_kernel<WAVES, SC, MODE_HOT>, scale_frames_kernel<WAVES, SC, MODE_EXACT>,
+                               scale_frames_kernel<WAVES, SC, MODE_FULL>, ka, nl, WAVES * kWave, lds, mode, "scale_frames_kernel");
 }
 
 template <int WAVES, int SC>
@@ -1508,7 +1702,7 @@ static int launch_vote(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
 constexpr int kDenseWaves = 16;
 
 template <int DW>
-static int launch_scale_dense_w(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool full, bool vote_only) {
+static int launch_scale_dense_w(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, int mode, bool vote_only) {
     if ((int64_t)2 * ka.b.max_feat > (int64_t)128 * kWave * DW)
         return set_error(MVOSR_ERR_TOO_LARGE, "%d features give more triangles than %d wavefronts sweep", ka.b.max_feat, DW);
     const size_t lds = dense_lds_bytes(ka.b.max_feat, DW);
@@ -1528,29 +1722,17 @@ static int launch_scale_dense_w(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, boo
         hipLaunchKernelGGL((outlier_vote_dense_kernel<DW>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
         return check_launch("outlier_vote_dense_kernel");
     }
-    if (ka.b.tri2_ids == MVOSR_TRI2_FEATURES) {
-        if (full) {
-            if ((rc = prepare_kernel(scale_frames_dense_feat_kernel<DW, true>, lds))) return rc;
-            hipLaunchKernelGGL((scale_frames_dense_feat_kernel<DW, true>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
-        } else {
-            if ((rc = prepare_kernel(scale_frames_dense_feat_kernel<DW, false>, lds))) return rc;
-            hipLaunchKernelGGL((scale_frames_dense_feat_kernel<DW, false>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
-        }
-        return check_launch("scale_frames_dense_feat_kernel");
-    }
-    if (full) {
-        if ((rc = prepare_kernel(scale_frames_dense_kernel<DW, true>, lds))) return rc;
-        hipLaunchKernelGGL((scale_frames_dense_kernel<DW, true>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
-    } else {
-        if ((rc = prepare_kernel(scale_frames_dense_kernel<DW, false>, lds))) return rc;
-        hipLaunchKernelGGL((scale_frames_dense_kernel<DW, false>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
-    }
-    return check_launch("scale_frames_dense_kernel");
+    if (ka.b.tri2_ids == MVOSR_TRI2_FEATURES)
+        return launch_modes<DenseArgs>(ctx, scale_frames_dense_feat_kernel<DW, MODE_HOT>, scale_frames_dense_feat_kernel<DW, MODE_EXACT>,
+                                       scale_frames_dense_feat_kernel<DW, MODE_FULL>, da, nl, DW * kWave, lds, mode,
+                                       "scale_frames_dense_feat_kernel");
+    return launch_modes<DenseArgs>(ctx, scale_frames_dense_kernel<DW, MODE_HOT>, scale_frames_dense_kernel<DW, MODE_EXACT>,
+                                   scale_frames_dense_kernel<DW, MODE_FULL>, da, nl, DW * kWave, lds, mode, "scale_frames_dense_kernel");
 }
 
-static int launch_scale_dense(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool full, bool vote_only) {
+static int launch_scale_dense(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, int mode, bool vote_only) {
     if (ka.b.max_feat > 65535) return set_error(MVOSR_ERR_TOO_LARGE, "more than 65535 features per frame");
-    return launch_scale_dense_w<kDenseWaves>(ctx, ka, nl, full, vote_only);
+    return launch_scale_dense_w<kDenseWaves>(ctx, ka, nl, mode, vote_only);
 }
 
 // one wavefront per frame, kRoadWaves frames per workgroup
@@ -1573,7 +1755,7 @@ static int launch_road(mvosr_ctx *ctx, const RoadArgs &ra, hipStream_t stream) {
         }                                                                                   \
     } while (0)
 
-static int dispatch_scale(mvosr_ctx *ctx, const KArgs &ka, int waves, int64_t nl, bool full) { MVOSR_DISPATCH(launch_scale, ctx, ka, nl, full); }
+static int dispatch_scale(mvosr_ctx *ctx, const KArgs &ka, int waves, int64_t nl, int mode) { MVOSR_DISPATCH(launch_scale, ctx, ka, nl, mode); }
 static int dispatch_vote(mvosr_ctx *ctx, const KArgs &ka, int waves, int64_t nl) { MVOSR_DISPATCH(launch_vote, ctx, ka, nl); }
 
 void set_max_dynamic_lds(int bytes) { g_max_dyn_lds = bytes; }
@@ -1619,9 +1801,15 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     KArgs ka;
     ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
     ka.first_frame = first_frame; ka.height_level_in = nullptr; ka.debug_skip = debug_skip_env();
+    ka.redo_pass = 0;
     if (b->total_feat <= 0) return set_error(MVOSR_ERR_ARG, "scale_batch: batch.total_feat (length of the feature planes) not set");
+    if (b->n_frames >= ((int64_t)1 << 31) - 1) return set_error(MVOSR_ERR_TOO_LARGE, "scale_batch: more than 2^31-2 frames in one batch");
     if ((rc = ctx_workspace(ctx, b->n_frames, b->total_feat, &ka.ysel, &ka.nsel))) return rc;
-    const bool full = o->tri_normals || o->tri_pitch_deg || o->tri_heights;
+    ka.redo = ka.nsel + b->n_frames;            // [1 + n_frames] ints behind the nsel array
+    // FULL: per-triangle debug outputs; EXACT: stage outputs requested (height_level bit-equal to NumPy's for every
+    // frame); HOT: the product path + its exact pass over the frames that need it
+    const int mode = (o->tri_normals || o->tri_pitch_deg || o->tri_heights) ? MODE_FULL
+                     : ((o->selected || o->vote_counters) ? MODE_EXACT : MODE_HOT);
     const int waves = pick_waves(waves_per_frame, b->max_feat);
     RoadArgs ra;
     ra.P = *p; ra.off = b->feat_off; ra.cnt = ka.nsel; ra.y = ka.ysel; ra.scratch = ka.ysel;
@@ -1638,12 +1826,16 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     const bool dense = (waves_per_frame == 0 || waves_per_frame == 16) &&
                        (b->max_feat > lds_capacity_features() || b->tri2_ids == MVOSR_TRI2_FEATURES);
     hipEvent_t *pev = (ctx->prof_on && ctx->prof_calls < kProfRing) ? ctx->prof_ev[ctx->prof_calls] : nullptr;
-    if (pev) (void)hipEventRecord(pev[0], ctx_stream(ctx));
-    if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, full, false) : dispatch_scale(ctx, ka, waves, n_launch, full))) return rc;
-    if (pev) (void)hipEventRecord(pev[1], ctx_stream(ctx));
+    hipError_t ee = hipSuccess;
+    if (pev && (ee = hipEventRecord(pev[0], ctx_stream(ctx))) != hipSuccess) return set_hip_error("hipEventRecord(profile)", ee);
+    if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, mode, false) : dispatch_scale(ctx, ka, waves, n_launch, mode))) return rc;
+    if (pev && (ee = hipEventRecord(pev[1], ctx_stream(ctx))) != hipSuccess) return set_hip_error("hipEventRecord(profile)", ee);
     ra.first_frame = first_frame; ra.n_frames = n_launch;
     if (!(debug_skip_env() & 16)) { if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc; }
-    if (pev) { (void)hipEventRecord(pev[2], ctx_stream(ctx)); ctx->prof_calls++; }
+    if (pev) {
+        if ((ee = hipEventRecord(pev[2], ctx_stream(ctx))) != hipSuccess) return set_hip_error("hipEventRecord(profile)", ee);
+        ctx->prof_calls++;
+    }
     return MVOSR_OK;
 }
 
@@ -1657,10 +1849,10 @@ int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_
     if ((rc = ctx_activate(ctx))) return rc;
     KArgs ka;
     ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
-    ka.first_frame = 0; ka.height_level_in = nullptr; ka.debug_skip = 0; ka.ysel = nullptr; ka.nsel = nullptr;
+    ka.first_frame = 0; ka.height_level_in = nullptr; ka.debug_skip = 0; ka.ysel = nullptr; ka.nsel = nullptr; ka.redo = nullptr; ka.redo_pass = 0;
     if ((waves_per_frame == 0 || waves_per_frame == 16) && b->max_feat > lds_capacity_features()) {
         if (b->total_feat <= 0) return set_error(MVOSR_ERR_ARG, "outlier_vote: batch.total_feat not set");
-        return launch_scale_dense(ctx, ka, b->n_frames, false, true);
+        return launch_scale_dense(ctx, ka, b->n_frames, MODE_HOT, true);
     }
     return dispatch_vote(ctx, ka, pick_waves(waves_per_frame, b->max_feat), b->n_frames);
 }
@@ -1685,19 +1877,32 @@ int mvosr_road_model_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_ba
     return launch_road(ctx, ra, ctx_stream(ctx));
 }
 
-int mvosr_window_median(mvosr_ctx *ctx, const double *raw, int64_t n, int window, const double *queue_in, int n_queue,
-                        double *out) {
+static int launch_window_median(mvosr_ctx *ctx, const double *raw, int64_t n, int n_blocks, int64_t stride, int window,
+                                const double *queue_in, int n_queue, double *out) {
     if (!ctx || (n > 0 && (!raw || !out))) return set_error(MVOSR_ERR_ARG, "window_median: null argument");
     if (window < 1 || window > kMaxWindow) return set_error(MVOSR_ERR_ARG, "window_median: window must be in 1..%d", kMaxWindow);
     if (n_queue < 0 || n_queue > window || (n_queue > 0 && !queue_in)) return set_error(MVOSR_ERR_ARG, "window_median: bad carried-in queue");
+    if (n_blocks < 1) return set_error(MVOSR_ERR_ARG, "window_median: n_blocks < 1");
     if (n <= 0) return MVOSR_OK;
-    int rc = ctx_activate(ctx);
-    if (rc) return rc;
     MedianArgs ma;
     ma.raw = raw; ma.out = out; ma.n = n; ma.window = window; ma.n_queue = n_queue;
+    ma.n_blocks = n_blocks; ma.base_len = n / n_blocks; ma.extra = n % n_blocks; ma.stride = stride;
+    if (n_blocks > 1 && stride < ma.base_len + (ma.extra ? 1 : 0)) return set_error(MVOSR_ERR_ARG, "window_median: block stride shorter than a block");
+    int rc = ctx_activate(ctx);
+    if (rc) return rc;
     for (int i = 0; i < kMaxWindow; ++i) ma.queue[i] = (i < n_queue) ? queue_in[i] : 0.0;
     hipLaunchKernelGGL(window_median_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx_stream(ctx), ma);
     return check_launch("window_median_kernel");
+}
+
+int mvosr_window_median(mvosr_ctx *ctx, const double *raw, int64_t n, int window, const double *queue_in, int n_queue,
+                        double *out) {
+    return launch_window_median(ctx, raw, n, 1, 0, window, queue_in, n_queue, out);
+}
+
+int mvosr_window_median_blocked(mvosr_ctx *ctx, const double *blocks, int64_t n, int n_blocks, int64_t block_stride, int window,
+                                const double *queue_in, int n_queue, double *out) {
+    return launch_window_median(ctx, blocks, n, n_blocks, block_stride, window, queue_in, n_queue, out);
 }
 
 }  // extern "C"

@@ -145,6 +145,13 @@ class ScaleEngine:
                                                 q.ctypes.data if q.size else None, int(q.size), out_dev_ptr),
                    "mvosr_window_median")
 
+    def window_median_blocked(self, blocks_dev_ptr, n, n_blocks, block_stride, window, queue=(), out_dev_ptr=None):
+        """The window median over an all-gathered sequence read in place (sharding.GatheredFrames)."""
+        q = np.ascontiguousarray(np.asarray(list(queue), dtype=np.float64))
+        _lib.check(self.lib.mvosr_window_median_blocked(self.ctx.handle, blocks_dev_ptr, int(n), int(n_blocks), int(block_stride),
+                                                        int(window), q.ctypes.data if q.size else None, int(q.size), out_dev_ptr),
+                   "mvosr_window_median_blocked")
+
     def window_median_host(self, raw, window, queue=()):
         """Convenience: upload a host sequence, filter on the GPU, download."""
         raw = np.ascontiguousarray(raw, dtype=np.float64)

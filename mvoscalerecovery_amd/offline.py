@@ -111,7 +111,7 @@ def run_sequence_sharded(data, estimator, group=None, minimum_feature_for_scale=
     """:func:`run_sequence_batched` with the processed frames split into contiguous blocks, one per rank
     of ``torch.distributed`` (one process per GPU).  Every rank runs the per-frame half on its block
     (``estimator.raw_scale_batch``: host Delaunay on its own CPUs, kernels on its GPU), ONE all-gather
-    reassembles ``(raw_scale, status, height_level)`` for the whole sequence, and every rank applies the
+    reassembles the ranks' ``(raw_scale, height_level, status)`` records for the whole sequence, and every rank applies the
     cross-frame half (``estimator.push_raw_scales``: window median, raise sites) to it — so all ranks
     return the same dict, equal to the single-process result.  Without an initialised process group it
     runs as one rank."""
@@ -135,12 +135,10 @@ def run_sequence_sharded(data, estimator, group=None, minimum_feature_for_scale=
         status[f] = ST_HOST_QHULL if type(exc).__name__ == "QhullError" else ST_HOST_OTHER
     if world > 1:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        t_raw = torch.from_numpy(np.ascontiguousarray(raw, dtype=np.float64)).to(dev)
-        t_lvl = torch.from_numpy(np.ascontiguousarray(level, dtype=np.float64)).to(dev)
-        t_st = torch.from_numpy(status).to(dev)
-        raw_all, st_all = sharding.all_gather_frames(t_raw, t_st, len(idx), group)
-        lvl_all, _ = sharding.all_gather_frames(t_lvl, t_st, len(idx), group)
-        raw, status, level = raw_all.cpu().numpy(), st_all.cpu().numpy(), lvl_all.cpu().numpy()
+        cap = max(sharding.shard_sizes(len(idx), world))
+        rec = sharding.RankRecord(cap, dev).fill(raw, status, level)
+        g = sharding.all_gather_record(rec, len(idx), group)                  # the ONE collective of the path
+        raw, status, level = g.raw().cpu().numpy(), g.status().cpu().numpy(), g.level().cpu().numpy()
     errors = {}
     for f in (int(v) for v in np.nonzero(status >= ST_HOST_QHULL)[0]):
         if start <= f < stop:

@@ -59,6 +59,18 @@ def _get_pool(workers):
     return _pool
 
 
+def start_pool(workers=None):
+    """Create the Delaunay worker pool NOW.  The workers are forked, so this belongs before the first GPU call of the
+    process (a HIP context, torch.cuda, RCCL all start runtime threads, and a fork taken while one of them holds a
+    lock can deadlock the child): ``ScaleEstimator.__init__`` and ``bench.py`` call it before they create the context.
+    Returns the number of workers (0: the stage runs in this process)."""
+    workers = resolve_workers(workers)
+    if workers > 1:
+        _get_pool(workers)
+        return workers
+    return 0
+
+
 class _Segment:
     """A file in /dev/shm (or the temp dir) mapped into memory: plain mmap, so that neither side
     involves multiprocessing's resource tracker."""
@@ -339,8 +351,13 @@ def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0, featu
                 inv = np.empty(len(perms[f]), dtype=np.int64)
                 inv[perms[f]] = np.arange(len(perms[f]))
                 u, v, m = u[inv], v[inv], m[inv]
-            pts.append(np.stack([u[m], v[m]], axis=1))
-        tri2s = delaunay_many(pts, workers)
+            # <= 3 features below the vanishing row: the reference never makes the second call (:263-270)
+            pts.append(np.stack([u[m], v[m]], axis=1) if len(m) > 3 else None)
+        todo = [f for f, p in enumerate(pts) if p is not None]
+        done = delaunay_many([pts[f] for f in todo], workers)
+        tri2s = [np.zeros((0, 3), dtype=np.int32)] * pf.n_frames
+        for f, t in zip(todo, done):
+            tri2s[f] = t
     pf.extra["tri2_errors"] = {f: t for f, t in enumerate(tri2s) if isinstance(t, Exception)}
     tri2s = [None if isinstance(t, Exception) else np.ascontiguousarray(t, dtype=np.int32) for t in tri2s]
     if valid_masks is not None:

@@ -72,6 +72,8 @@ class ScaleEstimator:
         self.verbose = verbose
         self.mutate_inputs = mutate_inputs          # the reference remaps the caller's feature3d in place (:414)
         self.delaunay_workers = delaunay_workers
+        if delaunay_workers is None or delaunay_workers > 1:
+            packing.start_pool(delaunay_workers)    # fork the host stage's workers BEFORE the GPU runtime starts its threads
         self.engine = ScaleEngine(absolute_reference, device=device, camera_pitch=self.camera_pitch)
         self.last_status = None
         self.last_counts = None
@@ -167,6 +169,10 @@ class ScaleEstimator:
         low = feature2d[:, 1] > self.vanish                                   # :252-254
         feature2d, feature3d = feature2d[low, :], feature3d[low, :]
         valid = self.find_outliers(feature3d, feature2d, delaunay_simplices(feature2d))     # :257-260
+        if not valid.shape[0] > 3:                                            # :263 (length of the mask)
+            if self.verbose:
+                print('no enough feature for triangulation')
+            return None                                                       # :268-270
         feature2d, feature3d = feature2d[valid, :], feature3d[valid, :]       # :264-265
         selected = self.feature_selection_by_tri(feature3d, delaunay_simplices(feature2d))  # :266-273
         if len(selected) > 0:
@@ -281,30 +287,49 @@ class ScaleEstimator:
         queue update, ``height_level`` of the last good frame.  Returns ``(filtered, stds, n_ok,
         raise_late)``; ``raise_late()`` raises what the reference raises at that frame, if anything."""
         F = len(raw)
-        err_at, err = F, None
-        for f in range(F):
-            if f in host_errors:
-                err_at, err = f, host_errors[f]
+        raw = np.array(raw, dtype=np.float64, copy=True)
+        status = np.asarray(status)
+        bad = np.isin(status, K.ERROR_STATUSES)
+        for f in host_errors:
+            bad[f] = True
+        err_at = int(np.argmax(bad)) if bad.any() else F
+        err = host_errors.get(err_at)
+        # the level :421 reads at a frame that takes the "no enough feature for triangulation" branch (:263-270)
+        # is the one an EARLIER frame left on the estimator at :241; the reference raises AttributeError when
+        # there is none
+        sets_level = status[:err_at] != K.ST_TOO_FEW
+        last_setter = np.maximum.accumulate(np.where(sets_level, np.arange(err_at), -1)) if err_at else np.zeros(0, dtype=np.int64)
+        before = getattr(self, "height_level", None)
+        for f in np.nonzero(~sets_level)[0]:
+            g = int(last_setter[f])
+            lvl = level[g] if g >= 0 else before
+            if lvl is None:
+                err_at, err = int(f), AttributeError("'ScaleEstimator' object has no attribute 'height_level'")
                 break
-            if status[f] >= K.ST_ERR_LEFT:
-                err_at = f
-                break
+            with np.errstate(all="ignore"):
+                raw[f] = np.float64(self.absolute_reference) / np.float64(lvl)
+        cur_level = before
+        if err_at and last_setter[err_at - 1] >= 0:
+            cur_level = level[int(last_setter[err_at - 1])]                   # :241 of the last frame that reached it
         n_ok = err_at
-        stds = np.where(status[:n_ok] == K.ST_NO_FLAT, 100, 1).astype(np.float64)   # :413,:333-354
+        stds = np.where((status[:n_ok] == K.ST_NO_FLAT) | (status[:n_ok] == K.ST_TOO_FEW), 100, 1).astype(np.float64)   # :413,:333-354
         filtered = self.engine.window_median_host(raw[:n_ok], self.window_size, list(self.scale_queue))   # :396-400
         for s in raw[:n_ok]:
             self.scale_queue.append(s)
             if len(self.scale_queue) > self.window_size:
                 self.scale_queue.popleft()
-        if n_ok:
-            self.height_level = level[n_ok - 1]                               # :241
+        if n_ok and cur_level is not None:
+            self.height_level = cur_level
             if self.verbose:
                 print('height level', self.height_level)
+        self.last_raw_scale = raw
 
         def raise_late():
             if err is not None:
                 raise err
             if err_at < F:
+                if status[err_at] in (K.ST_ERR_LEFT, K.ST_ERR_RIGHT):
+                    self.height_level = level[err_at]                         # :241 ran before the road model raised
                 raise_for_status(int(status[err_at]), None if single else err_at)
         return filtered, stds, n_ok, raise_late
 
@@ -328,8 +353,8 @@ class ScaleEstimator:
 
     def _store_flat_feature(self, pf, out, feature3ds, feature2ds, valid_masks, f, st):
         """self.flat_feature / self.flat_feature_2d of the last processed frame (:275-276,:416)."""
-        if st == K.ST_NO_FLAT:
-            self.flat_feature = None                                          # :279,:416
+        if st in (K.ST_NO_FLAT, K.ST_TOO_FEW):
+            self.flat_feature = None                                          # :270,:279,:416
             return
         if valid_masks is None:
             return

@@ -4,8 +4,13 @@ The raw scale of a frame depends on that frame only (/root/reference/src/scale_c
 up to the filter), so a sequence shards into contiguous blocks of frames, one block per rank
 (one process per GPU).  The only cross-frame coupling — the window median of
 scale_calculator.py:396-400 — is a sliding-window function of the raw sequence, so it runs after
-the all-gather of the per-rank raw scales (and of their statuses, a second small gather) (RCCL over xGMI through
-``torch.distributed``'s ``nccl`` backend; ``gloo`` in CPU tests).  No halo, no all-reduce.
+ONE all-gather of the per-rank records (RCCL over xGMI through ``torch.distributed``'s ``nccl``
+backend; ``gloo`` in CPU tests).  No halo, no all-reduce, no second collective.
+
+The record of a rank is one allocation ``[raw_scale f64 x cap | height_level f64 x cap | status i32 x cap]``
+(20 bytes per frame, ``cap`` = largest shard): the kernels write their per-frame outputs straight into
+its three views, the all-gather moves it as bytes, and the window-median kernel reads the gathered
+buffer in place (``mvosr_window_median_blocked``) — no packing or unpacking kernel on the step.
 """
 from __future__ import annotations
 
@@ -25,74 +30,128 @@ def shard_sizes(n_frames: int, world_size: int):
     return [partition(n_frames, world_size, r)[1] - partition(n_frames, world_size, r)[0] for r in range(world_size)]
 
 
-_bufs = {}
+def record_stride_bytes(cap: int) -> int:
+    """Bytes of one rank's record, a multiple of 8 so that every block's raw-scale view stays aligned."""
+    return (20 * cap + 7) & ~7
 
 
-def all_gather_frames(local_raw, local_status, n_frames, group=None):
-    """All-gather the per-rank raw scales (float64) and statuses (int32) into the full-sequence
-    arrays, on whatever device the local tensors live on.  Equal shards: the two output arrays are gathered
-    as they are (two small collectives back to back, no packing or unpacking kernels — measured on one
-    rank: 0.05 ms per step instead of 0.09).  Ragged shards: ONE collective, scale and status as the two
-    columns of a float64 (cap, 2) record array (statuses are small ints, exact in float64), padded to the
-    largest shard, the padding dropped afterwards.  Buffers are cached between steps.
+class RankRecord:
+    """This rank's per-frame outputs in ONE buffer: ``raw`` / ``level`` (float64) and ``status`` (int32)
+    are views into it — hand their ``data_ptr()`` to the kernels, or fill them from host arrays."""
 
-    ``local_raw`` / ``local_status`` are torch tensors of this rank's block (partition order).
-    Returns ``(raw[n_frames], status[n_frames])`` torch tensors.
-    """
+    def __init__(self, cap: int, device):
+        import torch
+        self.cap = int(cap)
+        self.buf = torch.zeros(max(record_stride_bytes(self.cap), 8), dtype=torch.uint8, device=device)
+        c = self.cap
+        self.raw = self.buf[0:8 * c].view(torch.float64)
+        self.level = self.buf[8 * c:16 * c].view(torch.float64)
+        self.status = self.buf[16 * c:20 * c].view(torch.int32)
+
+    def fill(self, raw, status, level=None):
+        """Host arrays of this rank's block -> the record (the tail up to ``cap`` is padding)."""
+        import torch
+        n = len(raw)
+        dev = self.buf.device
+        self.raw[:n] = torch.from_numpy(np.ascontiguousarray(raw, dtype=np.float64)).to(dev)
+        self.status[:n] = torch.from_numpy(np.ascontiguousarray(status, dtype=np.int32)).to(dev)
+        if level is not None:
+            self.level[:n] = torch.from_numpy(np.ascontiguousarray(level, dtype=np.float64)).to(dev)
+        if n < self.cap:
+            self.raw[n:] = float("nan")
+            self.level[n:] = float("nan")
+            self.status[n:] = -1
+        return self
+
+
+class GatheredFrames:
+    """The all-gathered records of every rank, still in gathered (per-rank blocked) form."""
+
+    def __init__(self, recv, n_frames, world, cap):
+        self.recv, self.n_frames, self.world, self.cap = recv, int(n_frames), int(world), int(cap)
+        self.stride_bytes = record_stride_bytes(cap)
+        self.sizes = shard_sizes(self.n_frames, self.world)
+
+    @property
+    def stride_doubles(self):
+        return self.stride_bytes // 8
+
+    def _field(self, lo, hi, dtype):
+        import torch
+        parts = []
+        for r, s in enumerate(self.sizes):
+            blk = self.recv[r * self.stride_bytes:(r + 1) * self.stride_bytes]
+            parts.append(blk[lo * self.cap:hi * self.cap].view(dtype)[:s])
+        return torch.cat(parts) if parts else torch.empty(0, dtype=dtype, device=self.recv.device)
+
+    # fresh tensors in sequence order (never views of the cached receive buffer)
+    def raw(self):
+        import torch
+        return self._field(0, 8, torch.float64)
+
+    def level(self):
+        import torch
+        return self._field(8, 16, torch.float64)
+
+    def status(self):
+        import torch
+        return self._field(16, 20, torch.int32)
+
+
+_recv = {}
+collectives_issued = 0          # counted so that the bench line / tests can state "one per step"
+
+
+def all_gather_record(rec: RankRecord, n_frames: int, group=None) -> GatheredFrames:
+    """THE collective of the path: all-gather of the ranks' records (bytes).  The receive buffer is cached
+    between steps (same device / shard size / world): the returned object reads it in place, so take
+    ``raw()`` / ``status()`` / ``level()`` copies before the next gather if you need them to persist."""
+    global collectives_issued
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    sizes = shard_sizes(n_frames, world)
-    cap = max(sizes) if sizes else 0
-    dev = local_raw.device
-    if all(s == cap for s in sizes) and local_raw.is_contiguous() and local_status.is_contiguous():
-        # equal shards (the bench, and any batch the caller sizes per GPU): the kernels' output arrays are
-        # gathered as they are, straight into the arrays the window median reads — no packing kernels
-        key = (str(dev), cap, world, "direct")
-        if key not in _bufs:
-            _bufs[key] = (torch.empty(world * cap, dtype=torch.float64, device=dev),
-                          torch.empty(world * cap, dtype=torch.int32, device=dev))
-        recv_raw, recv_st = _bufs[key]
-        dist.all_gather_into_tensor(recv_raw, local_raw, group=group)
-        dist.all_gather_into_tensor(recv_st, local_status, group=group)
-        return recv_raw, recv_st
-    key = (str(dev), cap, world)
-    if key not in _bufs:
-        _bufs[key] = (torch.empty((cap, 2), dtype=torch.float64, device=dev),
-                      torch.empty((world * cap, 2), dtype=torch.float64, device=dev))
-    send, recv = _bufs[key]
-    n_local = local_raw.shape[0]
-    send[:n_local, 0] = local_raw
-    send[:n_local, 1] = local_status
-    if n_local < cap:
-        send[n_local:, 0] = float("nan")
-        send[n_local:, 1] = -1
-    dist.all_gather_into_tensor(recv, send, group=group)
-    if all(s == cap for s in sizes):
-        rec = recv
+    cap = max(shard_sizes(n_frames, world)) if n_frames else 0
+    if cap != rec.cap:
+        raise ValueError("record capacity %d != largest shard %d" % (rec.cap, cap))
+    key = (str(rec.buf.device), rec.buf.numel(), world)
+    if key not in _recv:
+        _recv[key] = torch.empty(world * rec.buf.numel(), dtype=torch.uint8, device=rec.buf.device)
+    recv = _recv[key]
+    if rec.buf.is_cuda and dist.get_backend(group) == "gloo":
+        # dry runs of the N-rank path with ranks sharing a GPU (MVOSR_SHARE_GPU; RCCL refuses two ranks on one device):
+        # gloo moves host memory, so the record is staged through the host
+        host = torch.empty(recv.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, rec.buf.cpu(), group=group)
+        recv.copy_(host)
     else:
-        keep = torch.cat([torch.arange(r * cap, r * cap + s, device=dev) for r, s in enumerate(sizes)])
-        rec = recv[keep]
-    return rec[:, 0].contiguous(), rec[:, 1].to(torch.int32)
+        dist.all_gather_into_tensor(recv, rec.buf, group=group)
+    collectives_issued += 1
+    return GatheredFrames(recv, n_frames, world, cap)
 
 
-def gather_and_filter(local_raw, local_status, n_frames, window, median_fn, queue=(), group=None):
-    """Gather the raw scales of all ranks and apply the window median to the whole sequence.
+def gather_and_filter(rec: RankRecord, n_frames, window, median_fn, queue=(), group=None):
+    """Gather the records of all ranks (one collective) and apply the window median to the whole sequence.
 
-    ``median_fn(raw_tensor, window, queue) -> filtered_tensor`` runs the K4 kernel (product) —
-    injected so that the CPU (gloo) tests can drive the same code with the oracle's filter."""
-    raw, status = all_gather_frames(local_raw, local_status, n_frames, group)
-    return median_fn(raw, window, queue), raw, status
+    ``median_fn(gathered, window, queue) -> filtered tensor`` runs the K4 kernel on the gathered buffer
+    in place (product: :func:`make_gpu_median`) — injected so that the CPU (gloo) tests can drive the
+    same code with the oracle's filter.  Returns ``(filtered, gathered)``."""
+    g = all_gather_record(rec, n_frames, group)
+    return median_fn(g, window, queue), g
 
 
 def make_gpu_median(engine):
-    """``median_fn`` backed by mvosr_window_median on torch CUDA tensors (zero-copy: the kernel
-    reads/writes the tensors' device memory on the stream the engine's context has adopted)."""
+    """``median_fn`` backed by the window-median kernel on torch CUDA memory (zero-copy: the kernel reads the
+    gathered records / a plain tensor and writes a torch tensor on the stream the engine's context has adopted)."""
     import torch
 
-    def fn(raw, window, queue=()):
-        out = torch.empty_like(raw)
-        engine.window_median(raw.data_ptr(), raw.numel(), window, queue, out.data_ptr())
+    def fn(seq, window, queue=()):
+        if isinstance(seq, GatheredFrames):
+            out = torch.empty(seq.n_frames, dtype=torch.float64, device=seq.recv.device)
+            engine.window_median_blocked(seq.recv.data_ptr(), seq.n_frames, seq.world, seq.stride_doubles, window, queue,
+                                         out.data_ptr())
+            return out
+        out = torch.empty_like(seq)
+        engine.window_median(seq.data_ptr(), seq.numel(), window, queue, out.data_ptr())
         return out
     return fn
 

@@ -186,7 +186,7 @@ def fuzz_frame(i: int, seed: int = 4321):
     elif kind == 6:                                 # a wall
         z = np.full(n, 12.0) + rng.normal(0.0, 0.05, n)
     elif kind == 7:                                 # very few points
-        keep = int(rng.integers(4, 12))
+        keep = int(rng.integers(1, 12))                # 1-2: QhullError at :257; 3: the :263-270 branch
         u, v, z = u[:keep], v[:keep], z[:keep]
     elif kind == 8:                                 # a third of the features above the vanishing row
         up = rng.uniform(0.0, 1.0, len(v)) < 0.35
@@ -197,3 +197,38 @@ def fuzz_frame(i: int, seed: int = 4321):
         x = (u - CX) * z / FX
         y = (v - CY) * z / FX
     return np.stack([x, y, z], axis=1).astype(np.float64), np.stack([u, v], axis=1).astype(np.float64)
+
+
+def too_few_sequence(seed: int = 2718, n_frames: int = 12, few_at=(0, 4, 5, 9)):
+    """A short sequence in which the frames ``few_at`` have exactly THREE features below the vanishing row
+    (the rest above it): the reference then takes its "no enough feature for triangulation" branch
+    (/root/reference/src/scale_calculator.py:263-270) and divides by the height_level an earlier frame
+    left on the estimator (:420-422) — or raises AttributeError when it is the first frame.
+    tests/golden/too_few.json holds what the reference returns for it.  Returns a list of (f3, f2)."""
+    frames = []
+    for i in range(n_frames):
+        n = 220 + 17 * i
+        if i in few_at:
+            f3, f2 = synth_frame(i, n, base_seed=seed, upper_fraction=0.0)
+            rng = np.random.default_rng([seed, i])
+            low = rng.choice(n, 3, replace=False)
+            v = rng.uniform(0.0, 185.0, n)
+            v[low] = f2[low, 1]
+            z = f3[:, 2]
+            f2 = np.stack([f2[:, 0], v], axis=1)
+            f3 = np.stack([f3[:, 0], (v - CY) * z / FX, z], axis=1)
+        else:
+            f3, f2 = synth_frame(i, n, base_seed=seed, upper_fraction=0.2)
+        frames.append((f3.astype(np.float64), f2.astype(np.float64)))
+    return frames
+
+
+def road_long_list(k: int, seed: int = 8192) -> np.ndarray:
+    """The k-th LONG list of y values (tests/golden/road_long.json holds the reference's outputs for them): longer
+    than np.add.reduce's 8192-element buffer, so np.mean / np.std behind the skewness decision
+    (/root/reference/src/scale_calculator.py:346,:496) are sums of several pairwise-summed chunks."""
+    rng = np.random.default_rng([seed, k])
+    n = (8193, 9000, 20011, 40000)[k % 4]
+    y = np.concatenate([rng.normal(1.72, 0.08, n - n // 5), 1.72 + rng.exponential(0.6, n // 5)])
+    rng.shuffle(y)
+    return y.astype(np.float64)

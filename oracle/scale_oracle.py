@@ -49,6 +49,8 @@ ST_ERR_RIGHT = 6       # IndexError at :344 (no local minimum right of the mode)
 ST_ERR_SINGULAR = 7    # LinAlgError at :229 (exactly singular triangle)
 ST_ERR_MASK = 8        # tri2 was not built on the mask the vote produces (build-side check)
 ST_ERR_EMPTY = 9       # no triangles / no features handed in (build-side check)
+ST_TOO_FEW = 10        # <= 3 features below the vanishing row: no second triangulation, the scale comes from
+                       # the PREVIOUS frame's height_level, std = 100 (:263-270,:420-422)
 
 
 # ---- a4: feature_remap ------------------------------------------------------------------------
@@ -322,6 +324,11 @@ def frame_raw_scale(feature3d, feature2d, absolute_reference, tri1=None, tri2=No
         tri1 = delaunay(f2l)
     counters = outlier_votes(f2l[:, 1], f3l[:, 2], tri1)
     valid = votes_valid(counters)
+    if not valid.shape[0] > 3:                                            # :263 (the LENGTH of the mask, as the reference tests it)
+        res = FrameResult(np.nan, np.nan, np.nan, ST_TOO_FEW, 100)        # :268-270 -> None -> :420-422 with the previous level
+        if keep:
+            res.lower, res.counters, res.valid, res.tri1 = low, counters, valid, tri1
+        return res
     f3v, f2v = f3l[valid], f2l[valid]
     if tri2 is None:
         tri2 = delaunay(f2v)
@@ -396,6 +403,12 @@ class OracleScaleEstimator:
         res = frame_raw_scale(feature3d, feature2d, self.absolute_reference, tri1, tri2,
                               self.camera_pitch, self.vanish)
         self.last = res
+        if res.status == ST_TOO_FEW:
+            # :420-422 reads self.height_level of an earlier frame (AttributeError if there is none)
+            self.flat_feature = None
+            with np.errstate(all="ignore"):
+                res.raw_scale = float(np.float64(self.absolute_reference) / np.float64(self.height_level))
+            return self.scale_filtering(res.raw_scale), res.std
         self.height_level = res.height_level
         raise_for_status(res.status)
         self.flat_feature = res.flat_feature

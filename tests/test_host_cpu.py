@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (mvosr_[a-z0-9_]+)", nm))
     assert set(declared) <= exported
-    assert lib.mvosr_abi_version() == 2
+    assert lib.mvosr_abi_version() == _lib.ABI_VERSION
 
 
 def test_lds_plan_three_frames_per_cu():

@@ -43,15 +43,25 @@ WORKER = textwrap.dedent("""
     st_all = rng.integers(0, 5, n).astype(np.int32)
     a, b = sharding.partition(n, world, rank)
 
-    def median_fn(raw, window, queue=()):
-        out, _ = so.window_median(raw.numpy(), window, queue)
+    lvl_all = rng.uniform(-1.0, 1.0, n)
+
+    def median_fn(g, window, queue=()):
+        out, _ = so.window_median(g.raw().numpy(), window, queue)
         return torch.from_numpy(out)
 
-    filt, raw, st = sharding.gather_and_filter(torch.from_numpy(raw_all[a:b].copy()), torch.from_numpy(st_all[a:b].copy()),
-                                               n, 5, median_fn, queue=[1.0, 2.0])
+    cap = max(sharding.shard_sizes(n, world))
+    rec = sharding.RankRecord(cap, "cpu").fill(raw_all[a:b], st_all[a:b], lvl_all[a:b])
+    before = sharding.collectives_issued
+    filt, g = sharding.gather_and_filter(rec, n, 5, median_fn, queue=[1.0, 2.0])
+    assert sharding.collectives_issued == before + 1          # ONE collective per step
+    raw, st, lvl = g.raw(), g.status(), g.level()
+    # the fields are fresh tensors, not views of the cached receive buffer: a second gather must not change them
+    rec2 = sharding.RankRecord(cap, "cpu").fill(lvl_all[a:b], st_all[a:b], raw_all[a:b])
+    sharding.all_gather_record(rec2, n)
     want, _ = so.window_median(raw_all, 5, [1.0, 2.0])
     assert np.array_equal(raw.numpy(), raw_all, equal_nan=True)
     assert np.array_equal(st.numpy(), st_all)
+    assert np.array_equal(lvl.numpy(), lvl_all)
     assert np.array_equal(filt.numpy(), want, equal_nan=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -118,12 +128,15 @@ WORKER_SEQ = textwrap.dedent("""
 """)
 
 
-def test_world_size_2_sharded_sequence_driver(tmp_path):
+@pytest.mark.parametrize("n", [41, 42])
+def test_world_size_2_sharded_sequence_driver(tmp_path, n):
     """offline.run_sequence_sharded on two gloo ranks (CPU oracle behind the estimator interface) equals the
-    frame-at-a-time replay of the whole sequence on one process, not-moving / too-few-feature frames included."""
+    frame-at-a-time replay of the whole sequence on one process, not-moving / too-few-feature frames included.
+    41 frames give 39 processed ones (ragged shards), 42 give 40 (equal shards: the case in which round 1's
+    two back-to-back gathers handed out the same cached buffer twice)."""
     script = tmp_path / "worker_seq.py"
-    script.write_text(WORKER_SEQ % {"root": ROOT, "n": 41})
-    port = 29300 + os.getpid() % 250
+    script.write_text(WORKER_SEQ % {"root": ROOT, "n": n})
+    port = 29300 + (os.getpid() + 7 * n) % 250
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
