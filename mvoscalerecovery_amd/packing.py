@@ -122,8 +122,9 @@ def _shm_segment(role, nbytes):
 
 
 def _shm_attach(path, keep):
-    """Worker side: map a segment by path; mappings of segments the parent has replaced are dropped."""
-    for old in [k for k in _shm_attached if k not in keep]:
+    """Worker side: map a segment by path; mappings of segments the parent has replaced (unlinked) are dropped."""
+    import os
+    for old in [k for k in _shm_attached if k not in keep and not os.path.exists(k)]:
         _shm_attached.pop(old).close()
     seg = _shm_attached.get(path)
     if seg is None:
@@ -199,21 +200,40 @@ def resolve_workers(workers):
     return max(1, available_cpus() // ranks)
 
 
-def delaunay_many(point_sets, workers=0):
-    """Triangulate many point sets, optionally on the process pool (this is the host stage that bounds
-    end-to-end throughput — SURVEY.md §7 hard part 1).  Returns per set the (T,3) int32 simplices, or
-    the exception SciPy raised for it."""
+class _DelaunayHandle:
+    """Result of :func:`delaunay_submit`: ``get()`` waits for the workers and returns, per point set, the (T,3) int32
+    simplices or the exception SciPy raised for it."""
+
+    def __init__(self, n, done=None, async_result=None, rows=None, out_off=None):
+        self.n, self._done, self._async, self._rows, self._out_off = n, done, async_result, rows, out_off
+
+    def get(self):
+        if self._done is None:
+            out, f = [], 0
+            for res in self._async.get():
+                for r in res:
+                    out.append(r if isinstance(r, Exception) else self._rows[self._out_off[f]:self._out_off[f] + r].copy())
+                    f += 1
+            self._done, self._async, self._rows = out, None, None
+        return self._done
+
+
+def delaunay_submit(point_sets, workers=0, slot=0):
+    """Start triangulating many point sets on the process pool and return at once (a handle with ``get()``): the host
+    stage that bounds end-to-end throughput (SURVEY.md §7 hard part 1) runs while the caller packs, uploads and
+    launches the GPU stages of other chunks.  ``slot`` names the pair of shared-memory segments the call uses — calls
+    that are in flight at the same time need different slots."""
     n = len(point_sets)
     workers = resolve_workers(workers)
     if not (workers and workers > 1 and n > 1):
-        return [_delaunay_job(p) for p in point_sets]
+        return _DelaunayHandle(n, done=[_delaunay_job(p) for p in point_sets])
     pool = _get_pool(int(workers))
     counts = np.array([len(p) for p in point_sets], dtype=np.int64)
     in_off = np.concatenate([[0], np.cumsum(counts)])
     caps = 2 * counts + 8                                       # a planar triangulation has < 2n triangles
     out_off = np.concatenate([[0], np.cumsum(caps)])
-    pin = _shm_segment("in", 16 * max(int(in_off[-1]), 1))
-    pout = _shm_segment("out", 12 * max(int(out_off[-1]), 1))
+    pin = _shm_segment("in%d" % slot, 16 * max(int(in_off[-1]), 1))
+    pout = _shm_segment("out%d" % slot, 12 * max(int(out_off[-1]), 1))
     allpts = np.ndarray((int(in_off[-1]), 2), dtype=np.float64, buffer=pin.buf)
     for f, p in enumerate(point_sets):
         allpts[in_off[f]:in_off[f + 1]] = p
@@ -221,13 +241,13 @@ def delaunay_many(point_sets, workers=0):
     jobs = [(pin.path, pout.path, [(int(in_off[f]), int(counts[f]), int(out_off[f]), int(caps[f]))
                                     for f in range(j, min(n, j + per_job))]) for j in range(0, n, per_job)]
     rows = np.ndarray((int(out_off[-1]), 3), dtype=np.int32, buffer=pout.buf)
-    out = []
-    f = 0
-    for res in pool.map(_delaunay_shm_job, jobs):
-        for r in res:
-            out.append(r if isinstance(r, Exception) else rows[out_off[f]:out_off[f] + r].copy())
-            f += 1
-    return out
+    return _DelaunayHandle(n, async_result=pool.map_async(_delaunay_shm_job, jobs), rows=rows, out_off=out_off)
+
+
+def delaunay_many(point_sets, workers=0):
+    """Triangulate many point sets, optionally on the process pool.  Returns per set the (T,3) int32 simplices, or
+    the exception SciPy raised for it."""
+    return delaunay_submit(point_sets, workers).get()
 
 
 @dataclass
@@ -315,49 +335,72 @@ def _pack_tris(tris):
     return off, flat
 
 
+def submit_tri1(pf: PackedFrames, workers=0, slot=0):
+    """Start the first triangulation of every frame (SciPy on the packed (u,v)); finish with :func:`attach_tri1`."""
+    pts = []
+    for f in range(pf.n_frames):
+        s = pf.frame_slice(f)
+        pts.append(np.stack([pf.u[s], pf.v[s]], axis=1))
+    return delaunay_submit(pts, workers, slot)
+
+
 def attach_tri1(pf: PackedFrames, tri1s=None, workers=0):
-    """First triangulation per frame (given, or SciPy on the packed (u,v))."""
+    """First triangulation per frame: given (a list, or the handle :func:`submit_tri1` returned), or SciPy now."""
     if tri1s is None:
-        pts = []
-        for f in range(pf.n_frames):
-            s = pf.frame_slice(f)
-            pts.append(np.stack([pf.u[s], pf.v[s]], axis=1))
-        tri1s = delaunay_many(pts, workers)
+        tri1s = submit_tri1(pf, workers)
+    if isinstance(tri1s, _DelaunayHandle):
+        tri1s = tri1s.get()
     pf.extra["tri1_errors"] = {f: t for f, t in enumerate(tri1s) if isinstance(t, Exception)}
     tri1s = [None if isinstance(t, Exception) else np.ascontiguousarray(t, dtype=np.int32) for t in tri1s]
     pf.tri1_off, pf.tri1 = _pack_tris(tri1s)
     return pf
 
 
+class _Tri2Handle:
+    def __init__(self, todo, handle, n_frames):
+        self.todo, self.handle, self.n_frames = todo, handle, n_frames
+
+    def get(self):
+        tri2s = [np.zeros((0, 3), dtype=np.int32)] * self.n_frames
+        for f, t in zip(self.todo, self.handle.get()):
+            tri2s[f] = t
+        return tri2s
+
+
+def submit_tri2(pf: PackedFrames, valid_masks, workers=0, slot=1):
+    """Start the second triangulation of every frame: SciPy over the features with ``valid_masks[f]`` (the vote result
+    that came back from the GPU, in the PACKED order).  For frames that :func:`apply_locality_order` permuted, Delaunay
+    still runs on the survivors in their original order — the reference's exact call.  Finish with :func:`attach_tri2`."""
+    perms = pf.extra.get("perm") or [None] * pf.n_frames
+    pts = []
+    for f in range(pf.n_frames):
+        s = pf.frame_slice(f)
+        m = np.asarray(valid_masks[f], dtype=bool)
+        u, v = pf.u[s], pf.v[s]
+        if perms[f] is not None:
+            inv = np.empty(len(perms[f]), dtype=np.int64)
+            inv[perms[f]] = np.arange(len(perms[f]))
+            u, v, m = u[inv], v[inv], m[inv]
+        # <= 3 features below the vanishing row: the reference never makes the second call (:263-270)
+        pts.append(np.stack([u[m], v[m]], axis=1) if len(m) > 3 else None)
+    todo = [f for f, p in enumerate(pts) if p is not None]
+    return _Tri2Handle(todo, delaunay_submit([pts[f] for f in todo], workers, slot), pf.n_frames)
+
+
 def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0, feature_ids=False):
     """Second triangulation per frame: given (numbered over the survivors in the caller's / original
-    order, as SciPy returns it), or SciPy over the features with ``valid_masks[f]`` (the vote result
-    that came back from the GPU, in the PACKED order).  For frames that :func:`apply_locality_order`
-    permuted, Delaunay still runs on the survivors in their original order — the reference's exact
-    call — and the rows are relabelled afterwards.  ``feature_ids=True`` (needs the masks) renumbers
-    the rows over the frame's packed features instead of over the survivors
-    (``mvosr_batch.tri2_ids = MVOSR_TRI2_FEATURES``): dense frames then run without compaction."""
+    order, as SciPy returns it; a list or the handle of :func:`submit_tri2`), or SciPy now over the features with
+    ``valid_masks[f]``.  Rows of frames that :func:`apply_locality_order` permuted are relabelled.
+    ``feature_ids=True`` (needs the masks) renumbers the rows over the frame's packed features instead of over the
+    survivors (``mvosr_batch.tri2_ids = MVOSR_TRI2_FEATURES``): dense frames then run without compaction."""
     perms = pf.extra.get("perm") or [None] * pf.n_frames
     if feature_ids and valid_masks is None:
         raise ValueError("feature-numbered tri2 needs the vote masks")
     if tri2s is None:
         assert valid_masks is not None
-        pts = []
-        for f in range(pf.n_frames):
-            s = pf.frame_slice(f)
-            m = np.asarray(valid_masks[f], dtype=bool)
-            u, v = pf.u[s], pf.v[s]
-            if perms[f] is not None:
-                inv = np.empty(len(perms[f]), dtype=np.int64)
-                inv[perms[f]] = np.arange(len(perms[f]))
-                u, v, m = u[inv], v[inv], m[inv]
-            # <= 3 features below the vanishing row: the reference never makes the second call (:263-270)
-            pts.append(np.stack([u[m], v[m]], axis=1) if len(m) > 3 else None)
-        todo = [f for f, p in enumerate(pts) if p is not None]
-        done = delaunay_many([pts[f] for f in todo], workers)
-        tri2s = [np.zeros((0, 3), dtype=np.int32)] * pf.n_frames
-        for f, t in zip(todo, done):
-            tri2s[f] = t
+        tri2s = submit_tri2(pf, valid_masks, workers)
+    if isinstance(tri2s, _Tri2Handle):
+        tri2s = tri2s.get()
     pf.extra["tri2_errors"] = {f: t for f, t in enumerate(tri2s) if isinstance(t, Exception)}
     tri2s = [None if isinstance(t, Exception) else np.ascontiguousarray(t, dtype=np.int32) for t in tri2s]
     if valid_masks is not None:

@@ -217,69 +217,186 @@ class ScaleEstimator:
         raise NotImplementedError("visualisation helper of the reference; not part of the hot path")
 
     # ---- batched surface ---------------------------------------------------------------------
+    PIPELINE_CHUNK = 512        # frames per chunk of the streaming batch path
+
     def scale_calculation_batch(self, feature3ds, feature2ds, tri1s=None, tri2s=None, _single=False, _raw_only=False):
         """Equivalent to calling ``scale_calculation`` once per frame, in order, on this
         estimator: returns ``(scales[F], stds[F])`` (filtered scales).  ``tri1s``/``tri2s`` may
         carry precomputed triangulations (lists of (T,3) int arrays, SciPy ``simplices`` verbatim).
         If a frame hits one of the reference's raise sites, the frames before it are applied to
-        the window state and the same exception type is raised."""
+        the window state and the same exception type is raised.
+
+        Without precomputed triangulations the batch STREAMS through the stages in chunks of
+        ``PIPELINE_CHUNK`` frames: while the host's worker processes triangulate chunk k+1 (first call, :257)
+        and chunk k (second call, :266), this process packs, uploads and launches the GPU stages of the
+        chunks in between — the Qhull pool never waits for the GPU or for packing."""
         F = len(feature3ds)
         if F == 0:
             return np.zeros(0), np.zeros(0)
-        eng, ctx = self.engine, self.engine.ctx
-        # raw values are packed BEFORE the (optional) in-place remap of the caller's arrays
-        pf = packing.pack_features(feature3ds, feature2ds, self.vanish)
-        if self.mutate_inputs:
-            for f3 in feature3ds:
-                if isinstance(f3, np.ndarray) and f3.size:
-                    self.feature_remap(f3)                                   # :414
-        packing.attach_tri1(pf, tri1s, self.delaunay_workers)
-        cap = int(ctx.lib.mvosr_max_lds_features())
-        if pf.max_feat > cap:
-            # dense frames gather from global memory: lay them out along a Z-order curve (results are
-            # order-independent; vertex order inside triangle rows is untouched)
-            packing.apply_locality_order(pf, min_features=cap + 1)
-        dbatch = DeviceBatch(ctx, pf, with_tri2=False)
-        stage = _single or tri2s is None
-        valid_masks = None
-        if tri2s is None:
-            vote_out = DeviceOutputs(ctx, dbatch, counts=True, stage=True)
-            eng.outlier_vote_batch(dbatch, vote_out)
-            ctx.sync()
-            counters = vote_out.get("vote_counters")
-            valid_masks = [counters[pf.frame_slice(f)] >= 0 for f in range(F)]                  # :166
-            if self.verbose:
-                for m in valid_masks:
-                    print('feature rejected ', int(np.sum(~m)))
-                    print('feature left     ', int(np.sum(m)))
-            vote_out.free()
-        if tri2s is not None and valid_masks is None and any(p is not None for p in (pf.extra.get("perm") or [])):
-            raise ValueError("precomputed tri2s for dense (re-ordered) frames need the vote mask: pass tri1s only")
-        # dense frames: rows renumbered over the features, so that the kernel need not compact (less HBM traffic)
-        packing.attach_tri2(pf, tri2s, valid_masks, self.delaunay_workers,
-                            feature_ids=(valid_masks is not None and pf.max_feat > cap))
-        dbatch.set_tri2(pf)
-        out = DeviceOutputs(ctx, dbatch, counts=True, stage=stage)
-        eng.scale_batch(dbatch, out)
-        ctx.sync()
-        raw = out.get("raw_scale")
-        status = out.get("status")
-        level = out.get("height_level")
-        counts = out.get("counts")
+        stage = bool(_single)
+        if tri1s is None and tri2s is None and not _single and F > self.PIPELINE_CHUNK:
+            raw, status, level, counts, host_errors, last = self._stream_chunks(feature3ds, feature2ds)
+        else:
+            st = self._chunk_begin(feature3ds, feature2ds, 0, tri1s)
+            self._chunk_vote(st, tri2s, 0)
+            raw, status, level, counts, host_errors = self._chunk_scale(st, tri2s, stage, keep=True)
+            last = st
         self.last_status, self.last_counts, self.last_raw_scale = status, counts, raw
-        host_errors = dict(pf.extra["tri2_errors"])                           # QhullError at :266
-        host_errors.update(pf.extra["tri1_errors"])                           # ... or already at :257
         if _raw_only:
-            out.free()
-            dbatch.free()
+            self._chunk_free(last)
             return raw, status, level, host_errors
         filtered, stds, n_ok, raise_late = self._push(raw, status, level, host_errors, _single)
         if n_ok and stage:
-            self._store_flat_feature(pf, out, feature3ds, feature2ds, valid_masks, n_ok - 1, status[n_ok - 1])
-        out.free()
-        dbatch.free()
+            self._store_flat_feature(last["pf"], last["out"], feature3ds, feature2ds, last["masks"], n_ok - 1, status[n_ok - 1])
+        elif n_ok:
+            self._flat_feature_of(feature3ds[n_ok - 1], feature2ds[n_ok - 1], status[n_ok - 1])
+        self._chunk_free(last)
         raise_late()
         return filtered, stds
+
+    # -- one chunk of frames through the stages; the Delaunay calls are submitted to the pool and collected later
+    def _chunk_begin(self, f3s, f2s, k, tri1s=None):
+        """Vanishing-row filter + packing (:252-254) and the start of the first triangulation (:257)."""
+        pf = packing.pack_features(f3s, f2s, self.vanish)          # raw values, packed BEFORE the in-place remap below
+        if self.mutate_inputs:
+            for f3 in f3s:
+                if isinstance(f3, np.ndarray) and f3.size:
+                    self.feature_remap(f3)                                   # :414
+        h1 = tri1s if tri1s is not None else packing.submit_tri1(pf, self.delaunay_workers, slot=k % 4)
+        return {"pf": pf, "h1": h1, "n": len(f3s), "out": None, "dbatch": None, "masks": None}
+
+    def _chunk_vote(self, st, tri2s, k):
+        """First triangulation in, vote on the GPU (:151-167), start of the second triangulation (:266)."""
+        eng, ctx, pf = st.get("eng") or self.engine, self.engine.ctx, st["pf"]
+        packing.attach_tri1(pf, st["h1"], self.delaunay_workers)
+        cap = int(ctx.lib.mvosr_max_lds_features())
+        st["dense"] = pf.max_feat > cap
+        if st["dense"]:
+            # dense frames gather from global memory: lay them out for locality (results are
+            # order-independent; vertex order inside triangle rows is untouched)
+            packing.apply_locality_order(pf, min_features=cap + 1)
+        st["dbatch"] = DeviceBatch(ctx, pf, with_tri2=False)
+        if tri2s is None:
+            vote_out = DeviceOutputs(ctx, st["dbatch"], counts=True, stage=True)
+            eng.outlier_vote_batch(st["dbatch"], vote_out)
+            ctx.sync()
+            counters = vote_out.get("vote_counters")
+            st["masks"] = [counters[pf.frame_slice(f)] >= 0 for f in range(st["n"])]             # :166
+            if self.verbose:
+                for m in st["masks"]:
+                    print('feature rejected ', int(np.sum(~m)))
+                    print('feature left     ', int(np.sum(m)))
+            vote_out.free()
+            st["h2"] = packing.submit_tri2(pf, st["masks"], self.delaunay_workers, slot=4 + k % 4)
+        else:
+            if any(p is not None for p in (pf.extra.get("perm") or [])):
+                raise ValueError("precomputed tri2s for dense (re-ordered) frames need the vote mask: pass tri1s only")
+            st["h2"] = tri2s
+
+    def _chunk_scale(self, st, tri2s, stage, keep=False):
+        """Second triangulation in, the fused GPU stages (:225-248, :324-354, :419), results to the host."""
+        eng, ctx, pf = st.get("eng") or self.engine, self.engine.ctx, st["pf"]
+        # dense frames: rows renumbered over the features, so that the kernel need not compact (less HBM traffic)
+        packing.attach_tri2(pf, st["h2"], st["masks"], self.delaunay_workers,
+                            feature_ids=(st["masks"] is not None and st["dense"]))
+        st["dbatch"].set_tri2(pf)
+        out = DeviceOutputs(ctx, st["dbatch"], counts=True, stage=stage)
+        eng.scale_batch(st["dbatch"], out)
+        if not stage:
+            # A frame with <= 3 features below the vanishing row divides by the height_level its predecessor left
+            # (:263-270,:420-422), so that predecessor's level must be np.mean's own double, not the product kernel's
+            # fixed-order sum: the frames that can be such a predecessor — the one before a too-few frame, and the last
+            # frame of the chunk (what follows is not known here) — run once more, alone, in the exact mode the stage
+            # outputs select.
+            cnt = pf.feat_cnt
+            ok = np.nonzero(cnt > 3)[0]
+            again = set(int(g) for g in ok if g + 1 < len(cnt) and 1 <= cnt[g + 1] <= 3)
+            if len(ok):
+                again.add(int(ok[-1]))
+            if again:
+                ex = DeviceOutputs(ctx, st["dbatch"], counts=False, stage=True)
+                for k in ("raw_scale", "height", "height_level", "status"):
+                    ex.bufs[k].free()
+                    ex.bufs[k] = out.bufs[k]
+                if "counts" in out.bufs:
+                    ex.bufs["counts"] = out.bufs["counts"]
+                for g in sorted(again):
+                    eng.scale_batch(st["dbatch"], ex, first=g, count=1)
+                ctx.sync()
+                for k in ("vote_counters", "selected"):
+                    ex.bufs[k].free()
+                ex.bufs = {}
+        ctx.sync()
+        res = (out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts"))
+        host_errors = dict(pf.extra["tri2_errors"])                           # QhullError at :266
+        host_errors.update(pf.extra["tri1_errors"])                           # ... or already at :257
+        st["out"] = out
+        if not keep:
+            self._chunk_free(st)
+        return res + (host_errors,)
+
+    @staticmethod
+    def _chunk_free(st):
+        if st is None:
+            return
+        if st.get("out") is not None:
+            st["out"].free()
+            st["out"] = None
+        if st.get("dbatch") is not None:
+            st["dbatch"].free()
+            st["dbatch"] = None
+
+    def _stream_chunks(self, feature3ds, feature2ds, depth=2):
+        F, C = len(feature3ds), self.PIPELINE_CHUNK
+        bounds = [(a, min(F, a + C)) for a in range(0, F, C)]
+        n = len(bounds)
+        S = [None] * n
+        results = [None] * n
+
+        def begin(k):
+            a, b = bounds[k]
+            S[k] = self._chunk_begin(feature3ds[a:b], feature2ds[a:b], k)
+
+        for k in range(min(depth, n)):
+            begin(k)
+        for k in range(n):
+            self._chunk_vote(S[k], None, k)            # waits for tri1 of chunk k; tri2 of chunk k goes to the pool
+            if k + depth < n:
+                begin(k + depth)
+            if k >= 1:
+                results[k - 1] = self._chunk_scale(S[k - 1], None, False)
+                S[k - 1] = None
+        results[n - 1] = self._chunk_scale(S[n - 1], None, False, keep=True)
+        raw = np.concatenate([r[0] for r in results])
+        status = np.concatenate([r[1] for r in results])
+        level = np.concatenate([r[2] for r in results])
+        counts = np.concatenate([r[3] for r in results])
+        host_errors = {}
+        for (a, _), r in zip(bounds, results):
+            host_errors.update({a + f: e for f, e in r[4].items()})
+        return raw, status, level, counts, host_errors, S[n - 1]
+
+    def _flat_feature_of(self, feature3d, feature2d, st):
+        """``self.flat_feature`` / ``flat_feature_2d`` after a batch: the selected points of its last processed frame
+        (:275-276,:416), by running that one frame again with the stage outputs.  With ``mutate_inputs`` the
+        caller's array already holds the remapped values (:414), so the re-run uses the identity remap."""
+        if st in (K.ST_NO_FLAT, K.ST_TOO_FEW):
+            self.flat_feature = None
+            return
+        f3 = np.array(feature3d, dtype=np.float64, copy=True)
+        f2 = np.asarray(feature2d, dtype=np.float64)
+        mutate, self.mutate_inputs = self.mutate_inputs, False
+        try:
+            one = self._chunk_begin([f3], [f2], 0)
+            one["eng"] = self._plain_engine() if mutate else self.engine
+            self._chunk_vote(one, None, 0)
+            _, status, _, _, _ = self._chunk_scale(one, None, True, keep=True)
+            if mutate:
+                self.mutate_inputs = True              # (_store_flat_feature then takes f3 as already remapped)
+            self._store_flat_feature(one["pf"], one["out"], [f3], [f2], one["masks"], 0, status[0])
+            self._chunk_free(one)
+        finally:
+            self.mutate_inputs = mutate
 
     def _push(self, raw, status, level, host_errors, single=False):
         """The cross-frame half of scale_calculation for a run of frames (:396-400, :413-422): window

@@ -601,6 +601,40 @@ def test_estimator_batch_equals_per_frame(gpu):
     assert list(est_a.scale_queue) == list(est_b.scale_queue)
 
 
+def test_streaming_batch_equals_per_frame(gpu):
+    """The chunked, pipelined batch path (Delaunay of chunk k+1 / k on the worker pool while the GPU stages of the chunks in
+    between run) against frame-at-a-time calls: scales, stds, window state, height_level and flat_feature, with ragged
+    frames, a too-few frame and — in a second run — a frame at which the reference raises."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    rng = np.random.default_rng(99)
+    frames = [synth.synth_frame(i, int(rng.integers(150, 1400)), base_seed=31415, upper_fraction=0.1) for i in range(45)]
+    frames[17] = synth.too_few_sequence()[4]                       # three features below the vanishing row
+    for mutate in (False, True):
+        est_a = ScaleEstimator(1.75, window_size=5, mutate_inputs=mutate, delaunay_workers=4)
+        est_b = ScaleEstimator(1.75, window_size=5, mutate_inputs=mutate, delaunay_workers=4)
+        est_b.PIPELINE_CHUNK = 7
+        seq = [est_a.scale_calculation(f3.copy(), f2.copy()) for f3, f2 in frames]
+        s, d = est_b.scale_calculation_batch([f[0].copy() for f in frames], [f[1].copy() for f in frames])
+        assert [x[0] for x in seq] == list(s) and [x[1] for x in seq] == list(d)
+        assert list(est_a.scale_queue) == list(est_b.scale_queue)
+        assert est_a.height_level == est_b.height_level
+        assert np.array_equal(est_a.flat_feature, est_b.flat_feature)
+        assert np.array_equal(est_a.flat_feature_2d, est_b.flat_feature_2d)
+    # a frame whose Delaunay call raises, in the middle chunk: the frames before it are pushed, then the error
+    bad = list(frames)
+    bad[23] = (np.zeros((5, 3)) + [[0.0, 1.0, 9.0]], np.array([[10.0, 300.0]] * 5))      # five identical pixels: QhullError at :257
+    est_c = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=4)
+    est_c.PIPELINE_CHUNK = 7
+    with pytest.raises(Exception) as ei:
+        est_c.scale_calculation_batch([f[0] for f in bad], [f[1] for f in bad])
+    assert type(ei.value).__name__ == "QhullError"
+    est_d = ScaleEstimator(1.75, window_size=5, mutate_inputs=False)
+    for f3, f2 in bad[:23]:
+        est_d.scale_calculation(f3, f2)
+    assert list(est_c.scale_queue) == list(est_d.scale_queue)
+
+
 def test_seq200_golden_through_driver(gpu):
     """Config C1: the 200-frame golden of the reference through the main_offline-shaped driver,
     per frame and batched."""
