@@ -115,8 +115,8 @@ def build_pool(ctx, engine, sizes, seed):
     t_del1 = time.perf_counter() - t0
     cap = int(ctx.lib.mvosr_max_lds_features())
     dense = pf.max_feat > cap
-    if dense:            # dense frames: locality layout (what ScaleEstimator.scale_calculation_batch does)
-        packing.apply_locality_order(pf, min_features=cap + 1)
+    if dense:            # dense frames: the tiled layout (what ScaleEstimator.scale_calculation_batch does)
+        packing.apply_tile_order(pf)
     db = DeviceBatch(ctx, pf, with_tri2=False)
     out = DeviceOutputs(ctx, db, counts=True, stage=True)
     engine.outlier_vote_batch(db, out)
@@ -219,6 +219,7 @@ def main():
     ap.add_argument("--waves", type=int, default=0, help="wavefronts per frame (0 = auto)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: more ranks than GPUs (gloo, devices shared round-robin)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tiles", action="store_true", help="diagnostic: dense frames without the tile index (the two-sweep gather kernel)")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--alias-pool", action="store_true",
                     help="diagnostic: every tile reads the feature planes of the SAME pool frames (cache-resident: 41 %% "
@@ -292,6 +293,12 @@ def main():
                          offs("tri1_off", pf_pool.tri1_off[:-1], t1p, True), rep("tri1", pf_pool.tri1[:t1p].reshape(-1), np.int32),
                          offs("tri2_off", pf_pool.tri2_off[:-1], t2p, True), rep("tri2", pf_pool.tri2[:t2p].reshape(-1), np.int32),
                          rep("n2", pf_pool.n2_expected, np.int32), pf_pool.max_feat, int(pf_pool.tri2_ids), pool_pad * repeats)
+    if pf_pool.tile_w and not args.no_tiles:
+        nt = int(pf_pool.tile_base[-1])
+        bstruct.tile_w = int(pf_pool.tile_w)
+        bstruct.tile_base = offs("tile_base", pf_pool.tile_base[:-1], nt, True)
+        bstruct.tile1_off = rep("tile1_off", pf_pool.tile1_off, np.int32)
+        bstruct.tile2_off = rep("tile2_off", pf_pool.tile2_off, np.int32)
     bytes_per_launch = pf_pool.algorithmic_bytes() * repeats
     n_mean = float(pf_pool.feat_cnt.mean())
     t1_mean = float(pf_pool.tri1_off[-1]) / pool_n
@@ -368,7 +375,10 @@ def main():
                     traffic_src = "profiles/traffic.json (rocprofv3 --pmc passes of this command; not measured in this run)"
             except Exception:
                 traffic = None
-        kname = ("scale_frames_dense_feat_kernel" if (dense and pf_pool.tri2_ids) else "scale_frames_dense_kernel") if dense else "scale_frames_kernel"
+        kname = "scale_frames_kernel"
+        if dense:
+            kname = ("scale_frames_tiled_kernel" if (pf_pool.tile_w and not args.no_tiles) else
+                     "scale_frames_dense_feat_kernel" if pf_pool.tri2_ids else "scale_frames_dense_kernel")
         wl = ("synthetic %d-feature / ~%d-triangle frames (T1~%d, T2~%d)" % (args.features, round(t1_mean + t2_mean), round(t1_mean), round(t2_mean))
               if args.workload == "c2" else
               "synthetic KITTI-sized frames, 300-1500 features each (mean %.0f; T1~%d, T2~%d)" % (n_mean, round(t1_mean), round(t2_mean)))

@@ -71,7 +71,8 @@ enum mvosr_status {
 enum mvosr_count_slot {
     MVOSR_CNT_VALID = 0,        /* features with vote counter >= 0            (:164-166) */
     MVOSR_CNT_TRI_PITCH = 1,    /* triangles with pitch_deg < -80             (:235)     */
-    MVOSR_CNT_TRI_VALID = 2,    /* ... and mean height > height_level         (:243-244) */
+    MVOSR_CNT_TRI_VALID = 2,    /* ... and mean height > height_level         (:243-244); -1 where the tiled
+                                   dense variant ran (it keeps per-vertex maxima, not per-triangle flags) */
     MVOSR_CNT_SELECTED = 3,     /* unique vertices of those triangles         (:247)     */
     MVOSR_CNT_KEPT = 4,         /* selected points left after remove_single   (:284-293) */
     MVOSR_CNT_MODES = 5,        /* number of mode clusters                    (:468-481) */
@@ -124,7 +125,24 @@ typedef struct mvosr_batch {
                                     a quarter less HBM traffic; results identical)                              */
     int64_t total_feat;          /* length (elements) of the x/y/z/v planes: feat_off[F-1] + padded
                                     count of the last frame; sizes the context's workspace      */
+    /* Optional tile index of dense frames (all NULL / 0: none).  With feature-numbered rows (tri2_ids ==
+     * MVOSR_TRI2_FEATURES), features sorted so that a triangle's vertices lie close together in memory, and the rows
+     * of both triangulations sorted by smallest vertex, the gather variant reads every input byte once: it walks the
+     * frame in tiles of MVOSR_TILE_W features with two tiles resident in LDS.  Per frame f the index holds
+     * ntiles(f) + 1 = ceil(feat_cnt[f] / MVOSR_TILE_W) + 1 entries starting at tile_base[f]: entry k (k < ntiles) =
+     * index, within the frame's rows, of the first row whose smallest vertex lies in tile k or later (rows sorted by
+     * smallest vertex); entry ntiles = the frame's row count.  Vertices of a row that lie beyond tile k+1 are
+     * fetched from global memory (a few per thousand rows in a Delaunay triangulation laid out this way).  The
+     * kernel checks the index (starts at 0, monotone, ends at the row count) and that no row names a vertex before
+     * its tile; an inconsistent index gives MVOSR_ST_ERR_MASK, never a wrong result. */
+    int32_t tile_w;              /* MVOSR_TILE_W, or 0 */
+    int32_t reserved0;
+    const int64_t *tile_base;    /* [F+1] */
+    const int32_t *tile1_off;    /* [tile_base[F]] index into the frame's tri1 rows */
+    const int32_t *tile2_off;    /* [tile_base[F]] index into the frame's tri2 rows */
 } mvosr_batch;
+
+#define MVOSR_TILE_W 512
 
 /* Outputs (device pointers; any optional pointer may be NULL). */
 typedef struct mvosr_outputs {

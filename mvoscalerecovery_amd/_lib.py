@@ -11,10 +11,11 @@ import os
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")
+LIB_PATH = os.environ.get("MVOSR_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")   # (override: A/B builds in profiles/)
 ABI_VERSION = 3
 TRI2_SURVIVORS, TRI2_FEATURES = 0, 1      # mvosr_batch.tri2_ids
 N_COUNTS = 8
+TILE_W = 512                              # MVOSR_TILE_W
 HIST_BINS = 169
 
 
@@ -33,7 +34,9 @@ class Batch(C.Structure):
                 ("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("v", C.c_void_p),
                 ("tri1_off", C.c_void_p), ("tri1", C.c_void_p), ("tri2_off", C.c_void_p), ("tri2", C.c_void_p),
                 ("n2_expected", C.c_void_p), ("max_feat", C.c_int32), ("tri2_ids", C.c_int32),
-                ("total_feat", C.c_int64)]
+                ("total_feat", C.c_int64),
+                ("tile_w", C.c_int32), ("reserved0", C.c_int32), ("tile_base", C.c_void_p),
+                ("tile1_off", C.c_void_p), ("tile2_off", C.c_void_p)]
 
 
 class Outputs(C.Structure):

@@ -1477,6 +1477,399 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
     });
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense frames, traffic-lean ("tiled") variant: every input byte is read from HBM ONCE, coalesced.
+//
+// The host lays a dense frame out for this kernel (packing.apply_tile_order): features sorted along the
+// image axis of larger extent, both triangulations numbered over the frame's features, their rows sorted by
+// smallest vertex, and a tile index — for tiles of kTileW consecutive features the first row whose smallest
+// vertex lies in the tile.  A Delaunay triangle's vertices are then a few dozen positions apart (median 58,
+// 99th percentile 180 at N = 20000), so the rows of tile k find their vertices in tiles k and k+1 — except in
+// ~0.2 % of the rows (hull slivers), whose far vertices are fetched from global memory and whose contributions
+// to those vertices wait in a short pending list until their tile arrives.
+//
+// One workgroup walks the tiles with a ring of TWO tiles in LDS: per vertex {v, z'}, {x, y'} (fed by coalesced
+// loads of the caller's planes, remap fused, the tile after next in flight in registers), a 32-bit vote counter,
+// the largest height of its flat triangles as an order-preserving 64-bit key (LDS atomic max) and a "named by
+// tri2" flag.  The vote and the selection sweep of a tile's rows run in the same step; nothing is compacted or
+// staged.  When a tile leaves the ring its vertices are final: survivors are counted, tri2's claim that it names
+// survivors only is checked, and the vertices with a flat triangle ("candidates", about a third) park {y', largest
+// flat height} in a scratch plane.  "Some flat triangle at this vertex is higher than the level" (:243-247) — the
+// reference's second pass over the triangles — is then one comparison per candidate once height_level is known.
+// LDS: 62 KB whatever the frame size, two workgroups per CU.
+//
+// HBM traffic per frame: planes 32 B x N + rows 12 B x (T1 + T2), each once, + 32 B per candidate: about 1.2 x the
+// algorithmic bytes (the two-sweep gather variant: 2.2 x).
+//
+// HOT-mode only: a frame in which a candidate's height is within kLevelGuard of the level, whose level may become
+// the result, or whose pending lists overflow goes on the redo list and the EXACT pass runs
+// scale_frames_dense_feat_kernel on it; stage outputs select that kernel too.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTileW = 512;                 // features per tile (MVOSR_TILE_W in the header; the host's index uses the same)
+#ifndef MVOSR_TILED_WAVES
+#define MVOSR_TILED_WAVES 8
+#endif
+constexpr int kTiledWaves = MVOSR_TILED_WAVES;
+constexpr int kPendCap = 1024;              // pending votes / heights for vertices whose tile has not arrived yet
+constexpr int kTileRows = 3;                // rows per thread and triangulation prefetched for the coming step
+
+struct TiledPlan { uint32_t ringA, ringB, ringH, ringC, used, pendV, pendH, gcount, toff, red, misc, total; };
+__host__ __device__ inline TiledPlan tiled_plan(int n, int waves) {
+    TiledPlan p;
+    const uint32_t ntiles = (uint32_t)((n + kTileW - 1) / kTileW);
+    p.ringA = 0;                                                 // double2 {v, z'}  x 2 tiles
+    p.ringB = p.ringA + 16u * 2u * kTileW;                       // double2 {x, y'}  x 2 tiles
+    p.ringH = p.ringB + 16u * 2u * kTileW;                       // uint64 key of the largest flat height x 2 tiles
+    p.ringC = p.ringH + 8u * 2u * kTileW;                        // int32 vote counter x 2 tiles
+    p.used = p.ringC + 4u * 2u * kTileW;                         // uint8 "a tri2 row names this vertex" x 2 tiles
+    p.pendV = align16(p.used + 2u * kTileW);                     // {vertex, +-1}
+    p.pendH = p.pendV + 8u * kPendCap;                           // {vertex, -, key64}
+    p.gcount = p.pendH + 16u * kPendCap;                         // candidates per group of 64 features (uint8)
+    p.toff = align16(p.gcount + (uint32_t)((n + 63) / 64) + 16u); // the frame's tile index: 2 x (ntiles + 1) ints
+    p.red = align16(p.toff + 8u * (ntiles + 2u));
+    p.misc = p.red + 8u * (uint32_t)(kRedSlots * 2 * waves);
+    p.total = p.misc + 4u * 64u;
+    return p;
+}
+
+// order-preserving map of a double onto uint64 (0 is never produced)
+__device__ __forceinline__ unsigned long long height_key64(double h) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(h);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double height_of_key64(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+}
+
+// (two workgroups per CU: with 8 wavefronts each that is 4 per SIMD, i.e. at most 128 VGPRs)
+template <int DW>
+__global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_tiled_kernel(const DenseArgs da) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KArgs &a = da.k;
+    constexpr int B = DW * kWave, W = kTileW, M = 2 * kTileW - 1, VPT = W / B > 0 ? W / B : 1;   // VPT: a tile's vertices per thread
+    static_assert(W % B == 0 || B > W, "tile width / block size");
+    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    const int64_t f = a.first_frame + blockIdx.x;
+    const int n = a.b.feat_cnt[f];
+    const int64_t off = a.b.feat_off[f];
+    const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
+    const int t1n = (int)(a.b.tri1_off[f + 1] - t1b), t2n = (int)(a.b.tri2_off[f + 1] - t2b);
+    RoadResult R;
+    R.height = nan(""); R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
+    R.mean = R.std = R.skew = R.median = nan("");
+    if (early_frame_exit(a, f, n, t2n)) return;
+    const TiledPlan pl = tiled_plan(a.b.max_feat, DW);
+    double2 *ringA = reinterpret_cast<double2 *>(smem + pl.ringA);
+    double2 *ringB = reinterpret_cast<double2 *>(smem + pl.ringB);
+    unsigned long long *ringH = reinterpret_cast<unsigned long long *>(smem + pl.ringH);
+    int *ringC = reinterpret_cast<int *>(smem + pl.ringC);
+    uint8_t *used = reinterpret_cast<uint8_t *>(smem + pl.used);
+    int2 *pendV = reinterpret_cast<int2 *>(smem + pl.pendV);
+    ulonglong2 *pendH = reinterpret_cast<ulonglong2 *>(smem + pl.pendH);
+    uint8_t *gcount = reinterpret_cast<uint8_t *>(smem + pl.gcount);
+    int *toff1 = reinterpret_cast<int *>(smem + pl.toff);
+    double *red = reinterpret_cast<double *>(smem + pl.red);
+    int *misc = reinterpret_cast<int *>(smem + pl.misc);
+    int *n_pendV = misc + 40, *n_pendH = misc + 41;
+    const int ntiles = (n + W - 1) / W;
+    int *toff2 = toff1 + ntiles + 1;
+    const double *gx = a.b.x + off, *gy = a.b.y + off, *gz = a.b.z + off, *gv = a.b.v + off;
+    const double cp = a.P.cos_pitch, sp = a.P.sin_pitch;
+    const int32_t *rows1 = a.b.tri1 + 3 * t1b, *rows2 = a.b.tri2 + 3 * t2b;
+    int bad = 0;
+#ifdef MVOSR_STAMPS
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define MVOSR_TSTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define MVOSR_TSTAMP(i) do {} while (0)
+#endif
+
+    // ---- the frame's tile index (validated: the walk below visits every row exactly once whatever it says)
+    {
+        const int64_t tb = a.b.tile_base[f];
+        if ((int64_t)(a.b.tile_base[f + 1] - tb) != (int64_t)(ntiles + 1)) bad = 1;
+        for (int k = tid; k <= ntiles; k += B) {
+            const int o1 = bad ? 0 : a.b.tile1_off[tb + k], o2 = bad ? 0 : a.b.tile2_off[tb + k];
+            toff1[k] = o1; toff2[k] = o2;
+            if (k == 0 && (o1 != 0 || o2 != 0)) bad = 1;
+            if (k == ntiles && (o1 != t1n || o2 != t2n)) bad = 1;
+            if (k > 0 && !bad && (o1 < a.b.tile1_off[tb + k - 1] || o2 < a.b.tile2_off[tb + k - 1])) bad = 1;
+        }
+    }
+    if (tid == 0) { n_pendV[0] = 0; n_pendH[0] = 0; }
+    // a tile's vertices: coalesced loads of the caller's planes, remap (:391-392) fused
+    double tv[VPT], tx[VPT], ty[VPT], tz[VPT];
+    // (loads that are consumed a step later are issued UNCONDITIONALLY, on a clamped index: a load under a divergent
+    // branch is waited for at the end of that branch, which would put the whole memory latency back on the step)
+    auto tile_load = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int i = min(t * W + j * B + (tid & (W - 1)), n - 1);
+            tv[j] = stream_load(gv + i); tx[j] = stream_load(gx + i); ty[j] = stream_load(gy + i); tz[j] = stream_load(gz + i);
+        }
+    };
+    auto tile_store = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            if (j * B + tid >= W) continue;
+            const int i = t * W + j * B + tid, slot = i & M;
+            double2 pa, pb;
+            pa.x = tv[j]; pa.y = ty[j] * sp + tz[j] * cp;          // {v, z'}
+            pb.x = tx[j]; pb.y = ty[j] * cp - tz[j] * sp;          // {x, y'}
+            if (i < n) { ringA[slot] = pa; ringB[slot] = pb; }
+            ringC[slot] = 1;                                       // np.ones, :153
+            ringH[slot] = 0ull;
+            used[slot] = 0;
+        }
+    };
+    tile_load(0); tile_store(0);
+    tile_load(1); tile_store(1);
+    tile_load(2);
+    // the block agrees on the index before anyone walks it
+    {
+        int b0 = bad, b1 = 0, b2 = 0, b3 = 0;
+        block_sum4i<DW>(b0, b1, b2, b3, red + R_MISC * 2 * DW);
+        bad = b0;
+    }
+    if (bad) {
+        if (tid == 0) {
+            a.o.raw_scale[f] = nan(""); a.o.height[f] = nan(""); a.o.height_level[f] = nan("");
+            a.o.status[f] = MVOSR_ST_ERR_MASK; a.nsel[f] = 0;
+            write_counts(a, f, 0, 0, 0, R);
+        }
+        return;
+    }
+    MVOSR_TSTAMP(0);
+
+    double hsum = 0.0, hcnt = 0.0;
+    int npitch = 0, singular = 0, nvalid = 0, overflow = 0;
+    TriIds n1[kTileRows], n2[kTileRows];              // this thread's first rows of the coming step, in flight
+    const int rid = tid;       // (lane l of wavefront w taking row l*DW + w — neighbouring rows, which share vertices, then meet in
+                               // different LDS atomic instructions — was measured 16 % slower: the row loads lose their coalescing)
+    const int32_t *rows1c = t1n > 0 ? rows1 : rows2;   // (an empty first triangulation: any readable row will do for the clamped loads)
+    const int last1 = max(t1n, 1) - 1, last2 = t2n - 1;
+    auto prefetch_rows = [&](int k) {
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) {
+            n1[j] = load_tri(rows1c, min(toff1[k] + j * B + rid, last1));
+            n2[j] = load_tri(rows2, min(toff2[k] + j * B + rid, last2));
+        }
+    };
+    prefetch_rows(0);
+    double *cand_h = reinterpret_cast<double *>(da.ws.P2 + off), *cand_y = cand_h + ((n + 1) & ~1);     // candidates' largest flat height / y'
+
+    // ---- the walk over the tiles
+    for (int k = 0; k < ntiles; ++k) {
+        const int lo = k * W;
+        const int b1 = toff1[k], e1 = toff1[k + 1], b2 = toff2[k], e2 = toff2[k + 1];
+        TriIds c1[kTileRows], c2[kTileRows];
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) { c1[j] = n1[j]; c2[j] = n2[j]; }
+        prefetch_rows(min(k + 1, ntiles - 1));
+        // contributions that waited for tile k+1 (it entered the ring at the end of the last step)
+        {
+            const int nv = min(n_pendV[0], kPendCap), nh = min(n_pendH[0], kPendCap);
+            for (int e = tid; e < nv; e += B) { const int2 p = pendV[e]; if ((p.x >> 9) == k + 1) atomicAdd(&ringC[p.x & M], p.y); }
+            for (int e = tid; e < nh; e += B) {
+                const ulonglong2 p = pendH[e];
+                const int vtx = (int)(p.x & 0xFFFFFFFFull);
+                if ((vtx >> 9) == k + 1) { if (p.y) atomicMax(&ringH[vtx & M], p.y); used[vtx & M] = 1; }
+            }
+        }
+        // the vote over this tile's rows of tri1 (:151-167): vertices from the ring, 32-bit counters in the ring
+        auto vote_row = [&](const TriIds q) {
+            if ((q.a | q.b | q.c) < 0 || q.a < lo || q.b < lo || q.c < lo || q.a >= n || q.b >= n || q.c >= n) { bad = 1; return; }
+            const bool ia = (unsigned)(q.a - lo) <= (unsigned)M, ib = (unsigned)(q.b - lo) <= (unsigned)M, ic = (unsigned)(q.c - lo) <= (unsigned)M;
+            double2 p0, p1, p2;
+            if (ia & ib & ic) { p0 = ringA[q.a & M]; p1 = ringA[q.b & M]; p2 = ringA[q.c & M]; }      // {v, z'}
+            else {
+                // a far vertex (its tile has not arrived): fetched from the caller's planes
+                if (ia) p0 = ringA[q.a & M]; else { p0.x = gv[q.a]; p0.y = gy[q.a] * sp + gz[q.a] * cp; }
+                if (ib) p1 = ringA[q.b & M]; else { p1.x = gv[q.b]; p1.y = gy[q.b] * sp + gz[q.b] * cp; }
+                if (ic) p2 = ringA[q.c & M]; else { p2.x = gv[q.c]; p2.y = gy[q.c] * sp + gz[q.c] * cp; }
+            }
+            const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
+            const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
+            const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
+            const int v0 = (pa | pb) ? -1 : 1, v1 = (pa | pb | pc) ? -1 : 1, v2 = pc ? -1 : 1;
+            if (ia & ib & ic) {
+                atomicAdd(&ringC[q.a & M], v0); atomicAdd(&ringC[q.b & M], v1); atomicAdd(&ringC[q.c & M], v2);
+            } else {
+                auto vote = [&](bool in, int vtx, int val) {
+                    if (in) { atomicAdd(&ringC[vtx & M], val); return; }
+                    const int e = atomicAdd(n_pendV, 1);
+                    if (e < kPendCap) { int2 p; p.x = vtx; p.y = val; pendV[e] = p; } else overflow = 1;
+                };
+                vote(ia, q.a, v0); vote(ib, q.b, v1); vote(ic, q.c, v2);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) { if (b1 + j * B + rid < e1) vote_row(c1[j]); }
+        for (int t = b1 + kTileRows * B + rid; t < e1; t += B) vote_row(load_tri(rows1, t));
+        MVOSR_TSTAMP(2);
+        // the selection sweep over this tile's rows of tri2 (:225-240)
+        auto select_row = [&](const TriIds q) {
+            if ((q.a | q.b | q.c) < 0 || q.a < lo || q.b < lo || q.c < lo || q.a >= n || q.b >= n || q.c >= n) { bad = 1; return; }
+            const bool ia = (unsigned)(q.a - lo) <= (unsigned)M, ib = (unsigned)(q.b - lo) <= (unsigned)M, ic = (unsigned)(q.c - lo) <= (unsigned)M;
+            const bool all_in = ia & ib & ic;
+            double x0, y0, z0, x1, y1, z1, x2, y2, z2;
+            auto vertex = [&](bool in, int vtx, double &x, double &y, double &z) {
+                if (in) { const double2 pa = ringA[vtx & M], pb = ringB[vtx & M]; x = pb.x; y = pb.y; z = pa.y; }
+                else { const double yy = gy[vtx], zz = gz[vtx]; x = gx[vtx]; y = yy * cp - zz * sp; z = yy * sp + zz * cp; }
+            };
+            if (all_in) {
+                const double2 a0 = ringA[q.a & M], a1 = ringA[q.b & M], a2 = ringA[q.c & M];
+                const double2 g0_ = ringB[q.a & M], g1_ = ringB[q.b & M], g2_ = ringB[q.c & M];
+                x0 = g0_.x; y0 = g0_.y; z0 = a0.y; x1 = g1_.x; y1 = g1_.y; z1 = a1.y; x2 = g2_.x; y2 = g2_.y; z2 = a2.y;
+                used[q.a & M] = 1; used[q.b & M] = 1; used[q.c & M] = 1;        // (every writer stores the same value)
+            } else {
+                vertex(ia, q.a, x0, y0, z0); vertex(ib, q.b, x1, y1, z1); vertex(ic, q.c, x2, y2, z2);
+            }
+            const double h = div3((y0 + y1) + y2);                                               // :238
+            const int r = classify_triangle<false>(x0, y0, z0, x1, y1, z1, x2, y2, z2, h, a.pt, nullptr, nullptr, nullptr, 0);
+            if (r & 4) singular = 1;
+            if (r & 2) { hsum += h; hcnt += 1.0; }                                               // :240
+            const bool flat = (r & 1) != 0;
+            if (flat) ++npitch;
+            const unsigned long long key = (flat && h == h) ? height_key64(h) : 0ull;
+            if (all_in) {
+                if (key) { atomicMax(&ringH[q.a & M], key); atomicMax(&ringH[q.b & M], key); atomicMax(&ringH[q.c & M], key); }
+            } else {
+                auto touch = [&](bool in, int vtx) {
+                    if (in) { used[vtx & M] = 1; if (key) atomicMax(&ringH[vtx & M], key); return; }
+                    const int e = atomicAdd(n_pendH, 1);
+                    if (e < kPendCap) { ulonglong2 p; p.x = (unsigned long long)(unsigned)vtx; p.y = key; pendH[e] = p; } else overflow = 1;
+                };
+                touch(ia, q.a); touch(ib, q.b); touch(ic, q.c);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) { if (b2 + j * B + rid < e2) select_row(c2[j]); }
+        for (int t = b2 + kTileRows * B + rid; t < e2; t += B) select_row(load_tri(rows2, t));
+        MVOSR_TSTAMP(3);
+        __syncthreads();                               // every row that names a vertex of tile k has been processed
+        MVOSR_TSTAMP(4);
+        // tile k leaves the ring: final vote of its vertices (:166), candidates parked, tile k+2 takes the slot
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            if (j * B + tid >= W) continue;
+            const int i = lo + j * B + tid, slot = i & M;
+            bool survivor = false, is_cand = false;
+            double cy = 0.0, ch = 0.0;
+            if (i < n) {
+                survivor = ringC[slot] >= 0;                                           // :166
+                if (used[slot] && !survivor) bad = 1;                                  // tri2 names a feature the vote dropped
+                const unsigned long long hk = ringH[slot];
+                is_cand = hk != 0ull;
+                cy = ringB[slot].y; ch = height_of_key64(hk);                          // y', largest flat height
+            }
+            nvalid += __popcll(__ballot(survivor));
+            const unsigned long long mc = __ballot(is_cand);
+            if (is_cand) { const int at = (i & ~63) + __popcll(mc & ((1ull << lane) - 1ull)); cand_h[at] = ch; cand_y[at] = cy; }
+            if (lane == 0 && (i & ~63) < n) gcount[i >> 6] = (uint8_t)__popcll(mc);
+        }
+        tile_store(k + 2);
+        tile_load(k + 3);
+        MVOSR_TSTAMP(5);
+        __syncthreads();
+        MVOSR_TSTAMP(6);
+    }
+
+    block_sum2<DW>(hsum, hcnt, red + R_SEL_H * 2 * DW);
+    {
+        // flags: one vote per wavefront (<= 16 of them: the three 8-bit fields cannot carry into each other)
+        const int wf = (__ballot(singular != 0) ? 1 : 0) | (__ballot(bad != 0) ? 1 << 8 : 0) | (__ballot(overflow != 0) ? 1 << 16 : 0);
+        int sb = (lane == 0) ? wf : 0;
+        int nv = (lane == 0) ? nvalid : 0;              // (nvalid is wave-uniform: count it once per wave)
+        int z0 = 0;
+        block_sum4i<DW>(npitch, nv, sb, z0, red + R_SEL_CNT * 2 * DW);
+        nvalid = nv; singular = sb & 0xFF; bad = (sb >> 8) & 0xFF; overflow = sb >> 16;
+    }
+    MVOSR_TSTAMP(7);
+    const double hl = hsum / hcnt;                    // np.mean of an empty set -> 0/0 = NaN, like :240
+    const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
+    int status = kStPending;
+    double raw = nan("");
+    int nsel = 0;
+    if (overflow && !bad) {
+        // more far rows than the pending lists hold: not what the tiled layout promises — the two-sweep kernel takes the frame
+        if (tid == 0) { a.redo[1 + atomicAdd(a.redo, 1)] = (int32_t)f; a.o.status[f] = kStRedo; a.nsel[f] = 0; }
+        return;
+    }
+    if (mask_mismatch || bad) {
+        status = MVOSR_ST_ERR_MASK;
+    } else if (singular) {
+        status = MVOSR_ST_ERR_SINGULAR;
+    } else {
+        // a vertex is selected when its largest flat height exceeds the level (:243-247): one comparison per candidate.
+        // A wavefront owns a contiguous range of 64-feature groups.  The candidates' heights and y' were parked in two
+        // planes, so the count reads one and the ordered store the other — every byte once — in batches of kTailBatch
+        // loads in flight (one dependent load per group would put the memory latency on every group).
+        constexpr int kTailBatch = 8;
+        const int ngroups = (n + 63) >> 6, per = (ngroups + DW - 1) / DW;
+        const int g0 = w * per, g1 = min(ngroups, g0 + per);
+        unsigned long long selbits = 0ull;             // bit j: my candidate of group g0 + j is selected (ranges of up to 64 groups)
+        int cnt = 0, near = (hl == hl) ? 0 : 1;
+        for (int gb = g0; gb < g1; gb += kTailBatch) {
+            double hm[kTailBatch];
+#pragma unroll
+            for (int j = 0; j < kTailBatch; ++j) hm[j] = cand_h[(min(gb + j, ngroups - 1) << 6) + lane];
+#pragma unroll
+            for (int j = 0; j < kTailBatch; ++j) {
+                const bool have = gb + j < g1 && lane < (int)gcount[min(gb + j, ngroups - 1)];
+                if (have && fabs(hm[j] - hl) <= kLevelGuard * fabs(hl)) near = 1;
+                const bool sel = have && hm[j] > hl;                                            // :243-244
+                if (sel && gb + j - g0 < 64) selbits |= 1ull << (gb + j - g0);
+                cnt += __popcll(__ballot(sel));
+            }
+        }
+        const int wave_near = __ballot(near != 0) != 0ull;
+        if (lane == 0) { misc[M_WCNT + w] = cnt; misc[M_WCNT + DW + w] = wave_near; }
+        __syncthreads();
+        int base = 0, any_near = 0;
+#pragma unroll
+        for (int i = 0; i < DW; ++i) { const int c = misc[M_WCNT + i]; if (i < w) base += c; nsel += c; any_near |= misc[M_WCNT + DW + i]; }
+        MVOSR_TSTAMP(8);
+        if (any_near || nsel <= kBins) {              // the level's last bits could matter, or the level may be the result: EXACT pass
+            if (tid == 0) { a.redo[1 + atomicAdd(a.redo, 1)] = (int32_t)f; a.o.status[f] = kStRedo; a.nsel[f] = 0; }
+            return;
+        }
+        double *dst = a.ysel + off;
+        for (int gb = g0; gb < g1; gb += kTailBatch) {
+            double yv[kTailBatch], hm[kTailBatch];
+#pragma unroll
+            for (int j = 0; j < kTailBatch; ++j) {
+                const int at = (min(gb + j, ngroups - 1) << 6) + lane;
+                yv[j] = cand_y[at];
+                hm[j] = per > 64 ? cand_h[at] : 0.0;          // (more than 64 groups per wavefront: the bits above do not reach)
+            }
+#pragma unroll
+            for (int j = 0; j < kTailBatch; ++j) {
+                bool sel;
+                if (per > 64) sel = gb + j < g1 && lane < (int)gcount[min(gb + j, ngroups - 1)] && hm[j] > hl;
+                else sel = gb + j < g1 && ((selbits >> (gb + j - g0)) & 1ull);
+                const unsigned long long ms = __ballot(sel);
+                if (sel) dst[base + __popcll(ms & ((1ull << lane) - 1ull))] = yv[j];
+                base += __popcll(ms);
+            }
+        }
+    }
+    MVOSR_TSTAMP(10);
+#ifdef MVOSR_STAMPS
+    if (tid == 0 && a.o.hist) { unsigned long long *d = reinterpret_cast<unsigned long long *>(a.o.hist + f * 2 * kBins); for (int i = 0; i < 12; ++i) d[i] = tacc[i]; }
+#endif
+    if (tid == 0) {
+        a.o.raw_scale[f] = raw;
+        a.o.height[f] = nan("");
+        a.o.height_level[f] = hl;
+        a.o.status[f] = status;
+        a.nsel[f] = nsel;
+        R.n_sel = nsel;
+        write_counts(a, f, nvalid, npitch, -1, R);       // (the number of flat triangles above the level is not formed here)
+        if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = st[1] = st[2] = st[3] = nan(""); }
+    }
+}
+
 template <int DW>
 __global__ __launch_bounds__(DW *kWave) void outlier_vote_dense_kernel(const DenseArgs da) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1654,8 +2047,11 @@ static inline KArgs &kargs_of(DenseArgs &a) { return a.k; }
 
 template <class Args>
 static int launch_modes(mvosr_ctx *ctx, void (*k_hot)(const Args), void (*k_exact)(const Args), void (*k_full)(const Args),
-                        Args args, int64_t nl, int threads, size_t lds, int mode, const char *name) {
+                        Args args, int64_t nl, int threads, size_t lds, int mode, const char *name, size_t lds_hot = 0,
+                        int threads_hot = 0) {
     int rc;
+    if (lds_hot == 0) lds_hot = lds;
+    if (threads_hot == 0) threads_hot = threads;
     kargs_of(args).redo_pass = 0;
     if (mode == MODE_FULL) {
         if ((rc = prepare_kernel(k_full, lds))) return rc;
@@ -1667,10 +2063,10 @@ static int launch_modes(mvosr_ctx *ctx, void (*k_hot)(const Args), void (*k_exac
         hipLaunchKernelGGL(k_exact, dim3((unsigned)nl), dim3(threads), lds, ctx_stream(ctx), args);
         return check_launch(name);
     }
-    if ((rc = prepare_kernel(k_hot, lds))) return rc;
+    if ((rc = prepare_kernel(k_hot, lds_hot))) return rc;
     const hipError_t e = hipMemsetAsync(kargs_of(args).redo, 0, sizeof(int32_t), ctx_stream(ctx));
     if (e != hipSuccess) return set_hip_error("hipMemsetAsync(redo list)", e);
-    hipLaunchKernelGGL(k_hot, dim3((unsigned)nl), dim3(threads), lds, ctx_stream(ctx), args);
+    hipLaunchKernelGGL(k_hot, dim3((unsigned)nl), dim3(threads_hot), lds_hot, ctx_stream(ctx), args);
     if ((rc = check_launch(name))) return rc;
     kargs_of(args).redo_pass = 1;
     const unsigned grid = (unsigned)(nl < (int64_t)kRedoGrid ? nl : (int64_t)kRedoGrid);
@@ -1712,7 +2108,11 @@ static int launch_scale_dense_w(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, int
     da.k = ka;
     da.ws.P2 = nullptr; da.ws.Y2 = nullptr;
     int rc = MVOSR_OK;
-    if (!vote_only && ka.b.tri2_ids != MVOSR_TRI2_FEATURES) {    // neither the vote alone nor feature-numbered rows need the workspace
+    // the tiled variant: feature-numbered rows with the host's tile index, frames small enough for its LDS plan
+    const bool tiled = !vote_only && ka.b.tri2_ids == MVOSR_TRI2_FEATURES && ka.b.tile_w == kTileW && ka.b.tile_base &&
+                       ka.b.tile1_off && ka.b.tile2_off && !(debug_skip_env() & 32) &&
+                       (int64_t)tiled_plan(ka.b.max_feat, kTiledWaves).total <= (int64_t)g_max_dyn_lds;
+    if (!vote_only && (ka.b.tri2_ids != MVOSR_TRI2_FEATURES || tiled)) {    // (the vote alone and the two-sweep feature-numbered variant need no workspace)
         void *p[2];
         if ((rc = ctx_workspace_dense(ctx, ka.b.total_feat, p))) return rc;
         da.ws.P2 = reinterpret_cast<double2 *>(p[0]); da.ws.Y2 = reinterpret_cast<double *>(p[1]);
@@ -1722,6 +2122,10 @@ static int launch_scale_dense_w(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, int
         hipLaunchKernelGGL((outlier_vote_dense_kernel<DW>), dim3((unsigned)nl), dim3(DW * kWave), lds, ctx_stream(ctx), da);
         return check_launch("outlier_vote_dense_kernel");
     }
+    if (tiled)
+        return launch_modes<DenseArgs>(ctx, scale_frames_tiled_kernel<kTiledWaves>, scale_frames_dense_feat_kernel<DW, MODE_EXACT>,
+                                       scale_frames_dense_feat_kernel<DW, MODE_FULL>, da, nl, DW * kWave, lds, mode,
+                                       "scale_frames_tiled_kernel", tiled_plan(ka.b.max_feat, kTiledWaves).total, kTiledWaves * kWave);
     if (ka.b.tri2_ids == MVOSR_TRI2_FEATURES)
         return launch_modes<DenseArgs>(ctx, scale_frames_dense_feat_kernel<DW, MODE_HOT>, scale_frames_dense_feat_kernel<DW, MODE_EXACT>,
                                        scale_frames_dense_feat_kernel<DW, MODE_FULL>, da, nl, DW * kWave, lds, mode,

@@ -54,6 +54,12 @@ class DeviceBatch:
         self.tri2_ids = int(pf.tri2_ids)
         if pf.n2_expected is not None:
             self.bufs["n2_expected"] = self.ctx.to_device(pf.n2_expected, np.int32)
+        self.tile_w = 0
+        if pf.tile_w and pf.tile1_off is not None and pf.tile2_off is not None:
+            self.tile_w = int(pf.tile_w)
+            self.bufs["tile_base"] = self.ctx.to_device(pf.tile_base, np.int64)
+            self.bufs["tile1_off"] = self.ctx.to_device(pf.tile1_off, np.int32)
+            self.bufs["tile2_off"] = self.ctx.to_device(pf.tile2_off, np.int32)
         self.algorithmic_bytes = pf.algorithmic_bytes()
         self._struct = None
 
@@ -62,7 +68,8 @@ class DeviceBatch:
             p = lambda k: (self.bufs[k].ptr if k in self.bufs else None)
             self._struct = _lib.Batch(self.n_frames, p("feat_off"), p("feat_cnt"), p("x"), p("y"), p("z"), p("v"),
                                       p("tri1_off"), p("tri1"), p("tri2_off"), p("tri2"), p("n2_expected"),
-                                      self.max_feat, self.tri2_ids, self.total_padded)
+                                      self.max_feat, self.tri2_ids, self.total_padded,
+                                      getattr(self, "tile_w", 0), 0, p("tile_base"), p("tile1_off"), p("tile2_off"))
         return self._struct
 
     def free(self):

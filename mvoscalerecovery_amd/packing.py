@@ -269,6 +269,10 @@ class PackedFrames:
     n2_expected: np.ndarray = None  # int32 [F]
     max_feat: int = 0
     tri2_ids: int = 0               # 0: tri2 indexes the survivors (SciPy's numbering), 1: the frame's features
+    tile_w: int = 0                 # tile index of dense frames (mvosr_batch.tile_*): 0 = none
+    tile_base: np.ndarray = None    # int64 [F+1]
+    tile1_off: np.ndarray = None    # int32 [tile_base[F]]
+    tile2_off: np.ndarray = None
     extra: dict = field(default_factory=dict)
 
     @property
@@ -410,13 +414,23 @@ def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0, featu
                 m_old = np.empty_like(m_new)
                 m_old[perms[f]] = m_new
                 tri2s[f] = _relabel_tri2(tri2s[f], m_old, perms[f])
+    tiled = feature_ids and pf.extra.get("tile1") is not None
+    tile2 = []
     if feature_ids:
         for f in range(pf.n_frames):
+            n = int(pf.feat_cnt[f])
+            offs = np.zeros((n + TILE_W - 1) // TILE_W + 1, dtype=np.int32)
             if tri2s[f] is not None and tri2s[f].shape[0]:
                 survivors = np.nonzero(np.asarray(valid_masks[f], dtype=bool))[0].astype(np.int32)   # increasing: row order is kept
                 tri2s[f] = survivors[tri2s[f]]
+                if tiled:
+                    tri2s[f], offs = _tile_sort(tri2s[f], n)
+            tile2.append(offs)
     pf.tri2_ids = 1 if feature_ids else 0
     pf.tri2_off, pf.tri2 = _pack_tris(tri2s)
+    if tiled:
+        pf.extra["tile2"] = tile2
+        _finish_tile_index(pf)
     if valid_masks is not None:
         pf.n2_expected = np.array([int(np.count_nonzero(m)) for m in valid_masks], dtype=np.int32)
     return pf
@@ -444,6 +458,12 @@ def tile_frames(pf: PackedFrames, repeats: int) -> PackedFrames:
     if pf.n2_expected is not None:
         out.n2_expected = np.tile(pf.n2_expected, repeats)
     out.tri2_ids = pf.tri2_ids
+    if pf.tile_w and pf.tile1_off is not None and pf.tile2_off is not None:
+        nt = int(pf.tile_base[-1])
+        out.tile_w = pf.tile_w
+        out.tile_base = np.concatenate([pf.tile_base[:-1] + r * nt for r in range(repeats)] + [np.array([repeats * nt], dtype=np.int64)])
+        out.tile1_off = np.tile(pf.tile1_off, repeats)
+        out.tile2_off = np.tile(pf.tile2_off, repeats)
     return out
 
 
@@ -506,6 +526,75 @@ def apply_locality_order(pf: PackedFrames, min_features=0):
                 t = inv[pf.tri1[a:b]].astype(np.int32)
                 pf.tri1[a:b] = t[np.argsort(t.min(axis=1), kind="stable")]
     pf.extra["perm"] = perms
+    return pf
+
+
+TILE_W = 512                    # MVOSR_TILE_W (include/mvosr.h)
+
+
+def _tile_sort(tri, n, tile_w=TILE_W):
+    """Rows (numbered over the frame's packed features) in the order the tiled kernel walks them: sorted by smallest
+    vertex (stable).  Returns ``(rows, offsets)``; ``offsets[k]`` = first row whose smallest vertex lies in tile k or
+    later, ``offsets[ntiles]`` = number of rows."""
+    ntiles = (n + tile_w - 1) // tile_w
+    if tri.shape[0] == 0:
+        return tri, np.zeros(ntiles + 1, dtype=np.int32)
+    lo = tri.min(axis=1)
+    order = np.argsort(lo, kind="stable")
+    rows = np.ascontiguousarray(tri[order])
+    offs = np.searchsorted(lo[order], np.arange(ntiles) * tile_w, side="left")
+    return rows, np.concatenate([offs, [tri.shape[0]]]).astype(np.int32)
+
+
+def _finish_tile_index(pf: PackedFrames):
+    t1, t2 = pf.extra.get("tile1"), pf.extra.get("tile2")
+    if t1 is None or t2 is None or any(t is None for t in t1) or any(t is None for t in t2):
+        return
+    lens = np.array([len(t) for t in t1], dtype=np.int64)
+    pf.tile_base = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pf.tile1_off = np.concatenate(t1).astype(np.int32)
+    pf.tile2_off = np.concatenate(t2).astype(np.int32)
+    pf.tile_w = TILE_W
+
+
+def apply_tile_order(pf: PackedFrames):
+    """Lay every frame of a DENSE batch out for the tiled gather kernel: features sorted along the
+    image axis of larger extent — a Delaunay triangle's three vertices are then a few dozen positions apart (at
+    N = 20000: median 58, 99th percentile 180; along a Z-order curve the 99th percentile is 6700) —, tri1 relabelled
+    and its rows sorted by smallest vertex with the few far rows last, and the tile index built (tri2 follows in
+    :func:`attach_tri2`).  The path's results do not depend on feature or row order (the vote is an integer sum over
+    incident rows, the selection a set, the histogram order-free); the order of the three vertices INSIDE a row, which
+    the vote does depend on (/root/reference/src/scale_calculator.py:113-115), is untouched.  ``pf.extra['perm'][f][k]`` =
+    original packed position of the feature now at k; ``pf.lower_index`` is permuted along."""
+    perms, tiles = [], []
+    for f in range(pf.n_frames):
+        n = int(pf.feat_cnt[f])
+        sl = pf.frame_slice(f)
+        if n == 0:
+            perms.append(None)
+            tiles.append(np.zeros(1, dtype=np.int32))
+            continue
+        u, v = pf.u[sl], pf.v[sl]
+        key = u if (u.max() - u.min()) >= (v.max() - v.min()) else v
+        perm = np.argsort(key, kind="stable")
+        inv = np.empty(n, dtype=np.int64)
+        inv[perm] = np.arange(n)
+        for name in ("x", "y", "z", "v", "u"):
+            plane = getattr(pf, name)
+            plane[sl] = plane[sl][perm]
+        if pf.lower_index[f] is not None:
+            pf.lower_index[f] = np.asarray(pf.lower_index[f])[perm]
+        perms.append(perm)
+        offs = np.zeros((n + TILE_W - 1) // TILE_W + 1, dtype=np.int32)
+        if pf.tri1_off is not None:
+            a, b = int(pf.tri1_off[f]), int(pf.tri1_off[f + 1])
+            if b > a:
+                rows, offs = _tile_sort(inv[pf.tri1[a:b]].astype(np.int32), n)
+                pf.tri1[a:b] = rows
+        tiles.append(offs)
+    pf.extra["perm"] = perms
+    pf.extra["tile1"] = tiles
+    pf.extra["tile2"] = None
     return pf
 
 

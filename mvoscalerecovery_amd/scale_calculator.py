@@ -272,9 +272,9 @@ class ScaleEstimator:
         cap = int(ctx.lib.mvosr_max_lds_features())
         st["dense"] = pf.max_feat > cap
         if st["dense"]:
-            # dense frames gather from global memory: lay them out for locality (results are
+            # dense frames gather from global memory: lay the batch out for the tiled kernel (results are
             # order-independent; vertex order inside triangle rows is untouched)
-            packing.apply_locality_order(pf, min_features=cap + 1)
+            packing.apply_tile_order(pf)
         st["dbatch"] = DeviceBatch(ctx, pf, with_tri2=False)
         if tri2s is None:
             vote_out = DeviceOutputs(ctx, st["dbatch"], counts=True, stage=True)

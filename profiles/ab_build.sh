@@ -1,0 +1,16 @@
+#!/bin/bash
+# A/B builds of libmvosr.so with extra -D flags, for same-box comparisons on the GPU:
+#   profiles/ab_build.sh NAME "-DFOO=1 -DBAR"   ->  gpurun_out/ab/libmvosr_NAME.so   (use with MVOSR_LIB_PATH=...)
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+NAME=$1; shift
+mkdir -p $R/profiles/ab/obj_$NAME
+cd $R/mvoscalerecovery_amd/csrc
+for f in mvosr_kernels mvosr_rescale mvosr_capi; do
+  if [ $f = mvosr_kernels ] || [ ! -f $R/profiles/ab/obj_$NAME/$f.o ]; then
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function $@ -c $f.hip -o $R/profiles/ab/obj_$NAME/$f.o &
+  fi
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $R/profiles/ab/obj_$NAME/*.o -o $R/profiles/ab/libmvosr_$NAME.so
+echo built $R/profiles/ab/libmvosr_$NAME.so

@@ -220,6 +220,89 @@ def test_dense_seeded_batches(gpu, n, count):
         assert np.array_equal(res[k], res3[k], equal_nan=True), k
 
 
+def _pack_tiled(frames, ores):
+    """Dense batch in the layout of packing.apply_tile_order (what ScaleEstimator.scale_calculation_batch builds)."""
+    from mvoscalerecovery_amd import packing
+    pf = packing.pack_features([f[0] for f in frames], [f[1] for f in frames])
+    packing.attach_tri1(pf, [r.tri1 for r in ores])
+    packing.apply_tile_order(pf)
+    masks = [np.asarray(r.valid)[pf.extra["perm"][f]] for f, r in enumerate(ores)]
+    packing.attach_tri2(pf, [r.tri2 for r in ores], masks, feature_ids=True)
+    assert pf.tile_w == 512 and pf.tri2_ids == 1
+    return pf
+
+
+def test_dense_tiled_kernel(gpu):
+    """The traffic-lean dense variant (tile index, two-tile LDS ring, per-vertex flat-height keys instead of a second
+    sweep) against the oracle: statuses and raw scales exact, height_level to rounding (product mode), vote and
+    pitch counts exact; a mixed batch with a small and an LDS-sized frame; results independent of the variant."""
+    from mvoscalerecovery_amd import synth, constants as K
+    from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs, ScaleEngine
+    so = _oracle()
+    sizes = (20000, 7000, 300, 2500, 21000, 9000)
+    frames = [synth.synth_frame(i, n, base_seed=4242, upper_fraction=0.05 * (i % 2)) for i, n in enumerate(sizes)]
+    ores = _oracle_frames(frames)
+    pf = _pack_tiled(frames, ores)
+    eng = ScaleEngine(1.75, ctx=gpu)
+    db = DeviceBatch(gpu, pf)
+    out = DeviceOutputs(gpu, db, counts=True)
+    eng.scale_batch(db, out)
+    gpu.sync()
+    res = {k: out.get(k) for k in out.bufs}
+    out.free()
+    for f, r in enumerate(ores):
+        assert res["status"][f] == r.status, (f, res["status"][f], r.status)
+        assert res["raw_scale"][f] == r.raw_scale and res["height"][f] == r.height, f
+        assert abs(res["height_level"][f] - r.height_level) <= 1e-13 * abs(r.height_level), f
+        assert res["counts"][f, K.CNT_VALID] == int(r.valid.sum())
+        assert res["counts"][f, K.CNT_TRI_PITCH] == int(r.sel.valid_pitch.sum())
+        assert res["counts"][f, K.CNT_SELECTED] == len(r.sel.selected_ids)
+        assert res["counts"][f, K.CNT_KEPT] == r.road.n_kept and res["counts"][f, K.CNT_MODES] == r.road.n_modes
+    # stage outputs select the two-sweep kernel in EXACT mode on the same layout: identical results (the level is
+    # then NumPy's pairwise sum over the rows in the LAYOUT's order, which the host permuted: equal to rounding)
+    out2 = DeviceOutputs(gpu, db, counts=True, stage=True)
+    eng.scale_batch(db, out2)
+    gpu.sync()
+    res2 = {k: out2.get(k) for k in out2.bufs}
+    out2.free()
+    for k in ("raw_scale", "height", "status"):
+        assert np.array_equal(res[k], res2[k], equal_nan=True), k
+    for f, r in enumerate(ores):
+        assert abs(res2["height_level"][f] - r.height_level) <= 1e-14 * abs(r.height_level), f
+    # two launches are bit-identical (fixed summation order, order-free atomics)
+    out3 = DeviceOutputs(gpu, db, counts=True)
+    eng.scale_batch(db, out3)
+    gpu.sync()
+    for k in ("raw_scale", "height", "height_level", "status", "counts"):
+        assert np.array_equal(res[k], out3.get(k), equal_nan=True), k
+    out3.free()
+    db.free()
+
+
+def test_dense_tiled_kernel_refuses_a_bad_index(gpu):
+    """The tile index is input too: a non-monotone index, or one that walks a row after the tile of its smallest vertex
+    has left the ring, gives MVOSR_ST_ERR_MASK for that frame (and only that frame)."""
+    from mvoscalerecovery_amd import synth, constants as K
+    from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs, ScaleEngine
+    frames = [synth.synth_frame(i, 8000, base_seed=777) for i in range(3)]
+    ores = _oracle_frames(frames)
+    eng = ScaleEngine(1.75, ctx=gpu)
+    for kind in ("shift", "order"):
+        pf = _pack_tiled(frames, ores)
+        a = int(pf.tile_base[1])
+        if kind == "shift":
+            pf.tile1_off[a + 3:a + 9] -= 700          # rows walked with a later tile than the one their smallest vertex is in
+        else:
+            pf.tile2_off[a + 5] = pf.tile2_off[a + 4] - 1
+        db = DeviceBatch(gpu, pf)
+        out = DeviceOutputs(gpu, db, counts=True)
+        eng.scale_batch(db, out)
+        gpu.sync()
+        st = out.get("status")
+        out.free(); db.free()
+        assert st[0] == ores[0].status and st[2] == ores[2].status and st[1] == K.ST_ERR_MASK, (kind, st)
+
+
 def test_road_cases_kernel(gpu):
     """K3 alone on the reference's road-model edge cases (tests/golden/road_cases.json)."""
     from mvoscalerecovery_amd import packing
