@@ -130,11 +130,11 @@ typedef struct mvosr_batch {
      * of both triangulations sorted by smallest vertex, the gather variant reads every input byte once: it walks the
      * frame in tiles of MVOSR_TILE_W features with two tiles resident in LDS.  Per frame f the index holds
      * ntiles(f) + 1 = ceil(feat_cnt[f] / MVOSR_TILE_W) + 1 entries starting at tile_base[f]: entry k (k < ntiles) =
-     * index, within the frame's rows, of the first row whose smallest vertex lies in tile k or later (rows sorted by
-     * smallest vertex); entry ntiles = the frame's row count.  Vertices of a row that lie beyond tile k+1 are
-     * fetched from global memory (a few per thousand rows in a Delaunay triangulation laid out this way).  The
-     * kernel checks the index (starts at 0, monotone, ends at the row count) and that no row names a vertex before
-     * its tile; an inconsistent index gives MVOSR_ST_ERR_MASK, never a wrong result. */
+     * index, within the frame's rows, of the first row that is walked with tile k — its vertices all lie in tiles k
+     * and k+1; entry ntiles = where the "far" rows start (rows whose vertices are further apart: they come last, a
+     * few per thousand in a Delaunay triangulation laid out this way, and are gathered from global memory).  The
+     * kernel checks the index (starts at 0, monotone, in range) and every walked row against its tile window; an
+     * inconsistent index gives MVOSR_ST_ERR_MASK, never a wrong result. */
     int32_t tile_w;              /* MVOSR_TILE_W, or 0 */
     int32_t reserved0;
     const int64_t *tile_base;    /* [F+1] */

@@ -1511,7 +1511,15 @@ constexpr int kTileW = 512;                 // features per tile (MVOSR_TILE_W i
 #endif
 constexpr int kTiledWaves = MVOSR_TILED_WAVES;
 constexpr int kPendCap = 1024;              // pending votes / heights for vertices whose tile has not arrived yet
-constexpr int kTileRows = 3;                // rows per thread and triangulation prefetched for the coming step
+#ifndef MVOSR_TILE_ROWS
+#define MVOSR_TILE_ROWS 2
+#endif
+constexpr int kTileRows = MVOSR_TILE_ROWS;  // rows per thread and triangulation prefetched for the coming step
+#ifndef MVOSR_TILED_SUBC
+#define MVOSR_TILED_SUBC 1
+#endif
+constexpr int kSubC = MVOSR_TILED_SUBC;     // vote counters per ring vertex (a lane adds to counter lane % kSubC): rows are sorted by smallest vertex, so the
+                                            // lanes of one LDS atomic name the same vertices again and again, and updates of one word are serialised
 
 struct TiledPlan { uint32_t ringA, ringB, ringH, ringC, used, pendV, pendH, gcount, toff, red, misc, total; };
 __host__ __device__ inline TiledPlan tiled_plan(int n, int waves) {
@@ -1520,8 +1528,8 @@ __host__ __device__ inline TiledPlan tiled_plan(int n, int waves) {
     p.ringA = 0;                                                 // double2 {v, z'}  x 2 tiles
     p.ringB = p.ringA + 16u * 2u * kTileW;                       // double2 {x, y'}  x 2 tiles
     p.ringH = p.ringB + 16u * 2u * kTileW;                       // uint64 key of the largest flat height x 2 tiles
-    p.ringC = p.ringH + 8u * 2u * kTileW;                        // int32 vote counter x 2 tiles
-    p.used = p.ringC + 4u * 2u * kTileW;                         // uint8 "a tri2 row names this vertex" x 2 tiles
+    p.ringC = p.ringH + 8u * 2u * kTileW;                        // int32 vote counters (kSubC per vertex) x 2 tiles
+    p.used = p.ringC + 4u * 2u * kTileW * kSubC;                 // uint8 "a tri2 row names this vertex" x 2 tiles
     p.pendV = align16(p.used + 2u * kTileW);                     // {vertex, +-1}
     p.pendH = p.pendV + 8u * kPendCap;                           // {vertex, -, key64}
     p.gcount = p.pendH + 16u * kPendCap;                         // candidates per group of 64 features (uint8)
@@ -1592,7 +1600,7 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
             const int o1 = bad ? 0 : a.b.tile1_off[tb + k], o2 = bad ? 0 : a.b.tile2_off[tb + k];
             toff1[k] = o1; toff2[k] = o2;
             if (k == 0 && (o1 != 0 || o2 != 0)) bad = 1;
-            if (k == ntiles && (o1 != t1n || o2 != t2n)) bad = 1;
+            if (k == ntiles && (o1 > t1n || o2 > t2n)) bad = 1;
             if (k > 0 && !bad && (o1 < a.b.tile1_off[tb + k - 1] || o2 < a.b.tile2_off[tb + k - 1])) bad = 1;
         }
     }
@@ -1617,7 +1625,8 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
             pa.x = tv[j]; pa.y = ty[j] * sp + tz[j] * cp;          // {v, z'}
             pb.x = tx[j]; pb.y = ty[j] * cp - tz[j] * sp;          // {x, y'}
             if (i < n) { ringA[slot] = pa; ringB[slot] = pb; }
-            ringC[slot] = 1;                                       // np.ones, :153
+#pragma unroll
+            for (int c = 0; c < kSubC; ++c) ringC[slot * kSubC + c] = c == 0 ? 1 : 0;      // np.ones, :153 (the sub-counters add up)
             ringH[slot] = 0ull;
             used[slot] = 0;
         }
@@ -1643,11 +1652,68 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
 
     double hsum = 0.0, hcnt = 0.0;
     int npitch = 0, singular = 0, nvalid = 0, overflow = 0;
-    TriIds n1[kTileRows], n2[kTileRows];              // this thread's first rows of the coming step, in flight
     const int rid = tid;       // (lane l of wavefront w taking row l*DW + w — neighbouring rows, which share vertices, then meet in
                                // different LDS atomic instructions — was measured 16 % slower: the row loads lose their coalescing)
+
+    // ---- far rows first: the few rows (about 2 per thousand) whose vertices are not within two tiles of each other.
+    // All three vertices come from the caller's planes (one batch of gathers per frame instead of a stall in every
+    // step), and what the row contributes to them waits in the pending lists until their tiles are in the ring.
+    const int far1 = toff1[ntiles], far2 = toff2[ntiles];
+    for (int t = far1 + tid; t < t1n; t += B) {
+        const TriIds q = load_tri(rows1, t);
+        if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
+        double2 p0, p1, p2;
+        p0.x = gv[q.a]; p0.y = gy[q.a] * sp + gz[q.a] * cp;
+        p1.x = gv[q.b]; p1.y = gy[q.b] * sp + gz[q.b] * cp;
+        p2.x = gv[q.c]; p2.y = gy[q.c] * sp + gz[q.c] * cp;
+        const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
+        const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
+        const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
+        const int e = atomicAdd(n_pendV, 3);
+        if (e + 3 <= kPendCap) {
+            int2 p;
+            p.x = q.a; p.y = (pa | pb) ? -1 : 1; pendV[e] = p;
+            p.x = q.b; p.y = (pa | pb | pc) ? -1 : 1; pendV[e + 1] = p;
+            p.x = q.c; p.y = pc ? -1 : 1; pendV[e + 2] = p;
+        } else overflow = 1;
+    }
+    for (int t = far2 + tid; t < t2n; t += B) {
+        const TriIds q = load_tri(rows2, t);
+        if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
+        const double ya = gy[q.a], za = gz[q.a], yb = gy[q.b], zb = gz[q.b], yc = gy[q.c], zc = gz[q.c];
+        const double y0 = ya * cp - za * sp, y1 = yb * cp - zb * sp, y2 = yc * cp - zc * sp;
+        const double h = div3((y0 + y1) + y2);                                               // :238
+        const int r = classify_triangle<false>(gx[q.a], y0, ya * sp + za * cp, gx[q.b], y1, yb * sp + zb * cp,
+                                               gx[q.c], y2, yc * sp + zc * cp, h, a.pt, nullptr, nullptr, nullptr, 0);
+        if (r & 4) singular = 1;
+        if (r & 2) { hsum += h; hcnt += 1.0; }                                               // :240
+        if (r & 1) ++npitch;
+        const unsigned long long key = ((r & 1) && h == h) ? height_key64(h) : 0ull;
+        const int e = atomicAdd(n_pendH, 3);
+        if (e + 3 <= kPendCap) {
+            ulonglong2 p; p.y = key;
+            p.x = (unsigned long long)(unsigned)q.a; pendH[e] = p;
+            p.x = (unsigned long long)(unsigned)q.b; pendH[e + 1] = p;
+            p.x = (unsigned long long)(unsigned)q.c; pendH[e + 2] = p;
+        } else overflow = 1;
+    }
+    __syncthreads();
+    // contributions of the far rows to the vertices of a tile (applied once the tile is in the ring)
+    auto apply_pending = [&](int tile) {
+        const int nv = min(n_pendV[0], kPendCap), nh = min(n_pendH[0], kPendCap);
+        for (int e = tid; e < nv; e += B) { const int2 p = pendV[e]; if (p.x / W == tile) atomicAdd(&ringC[(p.x & M) * kSubC], p.y); }
+        for (int e = tid; e < nh; e += B) {
+            const ulonglong2 p = pendH[e];
+            const int vtx = (int)(p.x & 0xFFFFFFFFull);
+            if (vtx / W == tile) { if (p.y) atomicMax(&ringH[vtx & M], p.y); used[vtx & M] = 1; }
+        }
+    };
+    apply_pending(0);
+    MVOSR_TSTAMP(1);
+
     const int32_t *rows1c = t1n > 0 ? rows1 : rows2;   // (an empty first triangulation: any readable row will do for the clamped loads)
     const int last1 = max(t1n, 1) - 1, last2 = t2n - 1;
+    TriIds n1[kTileRows], n2[kTileRows];              // this thread's first rows of the coming step, in flight
     auto prefetch_rows = [&](int k) {
 #pragma unroll
         for (int j = 0; j < kTileRows; ++j) {
@@ -1666,81 +1732,68 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
 #pragma unroll
         for (int j = 0; j < kTileRows; ++j) { c1[j] = n1[j]; c2[j] = n2[j]; }
         prefetch_rows(min(k + 1, ntiles - 1));
-        // contributions that waited for tile k+1 (it entered the ring at the end of the last step)
-        {
-            const int nv = min(n_pendV[0], kPendCap), nh = min(n_pendH[0], kPendCap);
-            for (int e = tid; e < nv; e += B) { const int2 p = pendV[e]; if ((p.x >> 9) == k + 1) atomicAdd(&ringC[p.x & M], p.y); }
-            for (int e = tid; e < nh; e += B) {
-                const ulonglong2 p = pendH[e];
-                const int vtx = (int)(p.x & 0xFFFFFFFFull);
-                if ((vtx >> 9) == k + 1) { if (p.y) atomicMax(&ringH[vtx & M], p.y); used[vtx & M] = 1; }
-            }
-        }
-        // the vote over this tile's rows of tri1 (:151-167): vertices from the ring, 32-bit counters in the ring
+        apply_pending(k + 1);                          // (tile k+1 entered the ring at the end of the last step)
+        // the vote over this tile's rows of tri1 (:151-167): vertices from the ring, 32-bit counters in the ring.
+        // Every row of the walk has its vertices in tiles k and k+1 (checked: anything else is not the promised layout).
+        auto row_ok = [&](const TriIds q) {
+            const unsigned far = max(max((unsigned)(q.a - lo), (unsigned)(q.b - lo)), (unsigned)(q.c - lo));
+            return far <= (unsigned)M && max(max(q.a, q.b), q.c) < n;
+        };
         auto vote_row = [&](const TriIds q) {
-            if ((q.a | q.b | q.c) < 0 || q.a < lo || q.b < lo || q.c < lo || q.a >= n || q.b >= n || q.c >= n) { bad = 1; return; }
-            const bool ia = (unsigned)(q.a - lo) <= (unsigned)M, ib = (unsigned)(q.b - lo) <= (unsigned)M, ic = (unsigned)(q.c - lo) <= (unsigned)M;
-            double2 p0, p1, p2;
-            if (ia & ib & ic) { p0 = ringA[q.a & M]; p1 = ringA[q.b & M]; p2 = ringA[q.c & M]; }      // {v, z'}
-            else {
-                // a far vertex (its tile has not arrived): fetched from the caller's planes
-                if (ia) p0 = ringA[q.a & M]; else { p0.x = gv[q.a]; p0.y = gy[q.a] * sp + gz[q.a] * cp; }
-                if (ib) p1 = ringA[q.b & M]; else { p1.x = gv[q.b]; p1.y = gy[q.b] * sp + gz[q.b] * cp; }
-                if (ic) p2 = ringA[q.c & M]; else { p2.x = gv[q.c]; p2.y = gy[q.c] * sp + gz[q.c] * cp; }
-            }
+            if (!row_ok(q)) { bad = 1; return; }
+            const double2 p0 = ringA[q.a & M], p1 = ringA[q.b & M], p2 = ringA[q.c & M];      // {v, z'}
             const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
             const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
             const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
-            const int v0 = (pa | pb) ? -1 : 1, v1 = (pa | pb | pc) ? -1 : 1, v2 = pc ? -1 : 1;
-            if (ia & ib & ic) {
-                atomicAdd(&ringC[q.a & M], v0); atomicAdd(&ringC[q.b & M], v1); atomicAdd(&ringC[q.c & M], v2);
-            } else {
-                auto vote = [&](bool in, int vtx, int val) {
-                    if (in) { atomicAdd(&ringC[vtx & M], val); return; }
-                    const int e = atomicAdd(n_pendV, 1);
-                    if (e < kPendCap) { int2 p; p.x = vtx; p.y = val; pendV[e] = p; } else overflow = 1;
-                };
-                vote(ia, q.a, v0); vote(ib, q.b, v1); vote(ic, q.c, v2);
-            }
+            atomicAdd(&ringC[(q.a & M) * kSubC], (pa | pb) ? -1 : 1);
+            atomicAdd(&ringC[(q.b & M) * kSubC], (pa | pb | pc) ? -1 : 1);
+            atomicAdd(&ringC[(q.c & M) * kSubC], pc ? -1 : 1);
         };
+        {
+            // the prefetched rows: every ring read first (the compiler cannot move the reads of one row across the LDS
+            // atomics of another, and issued together their latencies overlap), then the tests and the atomics
+            double2 vp[kTileRows][3];
+            bool ok[kTileRows];
 #pragma unroll
-        for (int j = 0; j < kTileRows; ++j) { if (b1 + j * B + rid < e1) vote_row(c1[j]); }
+            for (int j = 0; j < kTileRows; ++j) {
+                const TriIds q = c1[j];
+                const bool live = b1 + j * B + rid < e1;
+                ok[j] = live && row_ok(q);
+                if (live && !ok[j]) bad = 1;
+                if (ok[j]) { vp[j][0] = ringA[q.a & M]; vp[j][1] = ringA[q.b & M]; vp[j][2] = ringA[q.c & M]; }      // {v, z'}
+            }
+#pragma unroll
+            for (int j = 0; j < kTileRows; ++j) {
+                if (!ok[j]) continue;
+                const TriIds q = c1[j];
+                const double2 p0 = vp[j][0], p1 = vp[j][1], p2 = vp[j][2];
+                const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
+                const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
+                const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
+                atomicAdd(&ringC[(q.a & M) * kSubC], (pa | pb) ? -1 : 1);
+                atomicAdd(&ringC[(q.b & M) * kSubC], (pa | pb | pc) ? -1 : 1);
+                atomicAdd(&ringC[(q.c & M) * kSubC], pc ? -1 : 1);
+            }
+        }
         for (int t = b1 + kTileRows * B + rid; t < e1; t += B) vote_row(load_tri(rows1, t));
         MVOSR_TSTAMP(2);
         // the selection sweep over this tile's rows of tri2 (:225-240)
         auto select_row = [&](const TriIds q) {
-            if ((q.a | q.b | q.c) < 0 || q.a < lo || q.b < lo || q.c < lo || q.a >= n || q.b >= n || q.c >= n) { bad = 1; return; }
-            const bool ia = (unsigned)(q.a - lo) <= (unsigned)M, ib = (unsigned)(q.b - lo) <= (unsigned)M, ic = (unsigned)(q.c - lo) <= (unsigned)M;
-            const bool all_in = ia & ib & ic;
-            double x0, y0, z0, x1, y1, z1, x2, y2, z2;
-            auto vertex = [&](bool in, int vtx, double &x, double &y, double &z) {
-                if (in) { const double2 pa = ringA[vtx & M], pb = ringB[vtx & M]; x = pb.x; y = pb.y; z = pa.y; }
-                else { const double yy = gy[vtx], zz = gz[vtx]; x = gx[vtx]; y = yy * cp - zz * sp; z = yy * sp + zz * cp; }
-            };
-            if (all_in) {
-                const double2 a0 = ringA[q.a & M], a1 = ringA[q.b & M], a2 = ringA[q.c & M];
-                const double2 g0_ = ringB[q.a & M], g1_ = ringB[q.b & M], g2_ = ringB[q.c & M];
-                x0 = g0_.x; y0 = g0_.y; z0 = a0.y; x1 = g1_.x; y1 = g1_.y; z1 = a1.y; x2 = g2_.x; y2 = g2_.y; z2 = a2.y;
-                used[q.a & M] = 1; used[q.b & M] = 1; used[q.c & M] = 1;        // (every writer stores the same value)
-            } else {
-                vertex(ia, q.a, x0, y0, z0); vertex(ib, q.b, x1, y1, z1); vertex(ic, q.c, x2, y2, z2);
-            }
-            const double h = div3((y0 + y1) + y2);                                               // :238
-            const int r = classify_triangle<false>(x0, y0, z0, x1, y1, z1, x2, y2, z2, h, a.pt, nullptr, nullptr, nullptr, 0);
+            if (!row_ok(q)) { bad = 1; return; }
+            const double2 a0 = ringA[q.a & M], a1 = ringA[q.b & M], a2 = ringA[q.c & M];
+            const double2 g0_ = ringB[q.a & M], g1_ = ringB[q.b & M], g2_ = ringB[q.c & M];
+            used[q.a & M] = 1; used[q.b & M] = 1; used[q.c & M] = 1;        // (every writer stores the same value)
+            const double h = div3((g0_.y + g1_.y) + g2_.y);                                      // :238
+            const int r = classify_triangle<false>(g0_.x, g0_.y, a0.y, g1_.x, g1_.y, a1.y, g2_.x, g2_.y, a2.y, h, a.pt,
+                                                   nullptr, nullptr, nullptr, 0);
             if (r & 4) singular = 1;
             if (r & 2) { hsum += h; hcnt += 1.0; }                                               // :240
-            const bool flat = (r & 1) != 0;
-            if (flat) ++npitch;
-            const unsigned long long key = (flat && h == h) ? height_key64(h) : 0ull;
-            if (all_in) {
-                if (key) { atomicMax(&ringH[q.a & M], key); atomicMax(&ringH[q.b & M], key); atomicMax(&ringH[q.c & M], key); }
-            } else {
-                auto touch = [&](bool in, int vtx) {
-                    if (in) { used[vtx & M] = 1; if (key) atomicMax(&ringH[vtx & M], key); return; }
-                    const int e = atomicAdd(n_pendH, 1);
-                    if (e < kPendCap) { ulonglong2 p; p.x = (unsigned long long)(unsigned)vtx; p.y = key; pendH[e] = p; } else overflow = 1;
-                };
-                touch(ia, q.a); touch(ib, q.b); touch(ic, q.c);
+            if (r & 1) {
+                ++npitch;
+                if (h == h) {
+                    const unsigned long long key = height_key64(h);
+                    atomicMax(&ringH[q.a & M], key); atomicMax(&ringH[q.b & M], key); atomicMax(&ringH[q.c & M], key);
+                }
             }
         };
 #pragma unroll
@@ -1757,7 +1810,10 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
             bool survivor = false, is_cand = false;
             double cy = 0.0, ch = 0.0;
             if (i < n) {
-                survivor = ringC[slot] >= 0;                                           // :166
+                int csum = 0;
+#pragma unroll
+                for (int c = 0; c < kSubC; ++c) csum += ringC[slot * kSubC + c];
+                survivor = csum >= 0;                                                  // :166
                 if (used[slot] && !survivor) bad = 1;                                  // tri2 names a feature the vote dropped
                 const unsigned long long hk = ringH[slot];
                 is_cand = hk != 0ull;

@@ -533,17 +533,19 @@ TILE_W = 512                    # MVOSR_TILE_W (include/mvosr.h)
 
 
 def _tile_sort(tri, n, tile_w=TILE_W):
-    """Rows (numbered over the frame's packed features) in the order the tiled kernel walks them: sorted by smallest
-    vertex (stable).  Returns ``(rows, offsets)``; ``offsets[k]`` = first row whose smallest vertex lies in tile k or
-    later, ``offsets[ntiles]`` = number of rows."""
+    """Rows (numbered over the frame's packed features) in the order the tiled kernel walks them: rows whose vertices
+    all lie in the tile of their smallest vertex or the next one, sorted by that smallest vertex, then the "far" rows.
+    Returns ``(rows, offsets)``; ``offsets[k]`` = first row of tile k for k < ntiles, ``offsets[ntiles]`` = first far row."""
     ntiles = (n + tile_w - 1) // tile_w
     if tri.shape[0] == 0:
         return tri, np.zeros(ntiles + 1, dtype=np.int32)
-    lo = tri.min(axis=1)
-    order = np.argsort(lo, kind="stable")
+    lo, hi = tri.min(axis=1), tri.max(axis=1)
+    far = hi >= (lo // tile_w + 2) * tile_w
+    order = np.lexsort((lo, far))                       # near rows first, by smallest vertex (stable)
     rows = np.ascontiguousarray(tri[order])
-    offs = np.searchsorted(lo[order], np.arange(ntiles) * tile_w, side="left")
-    return rows, np.concatenate([offs, [tri.shape[0]]]).astype(np.int32)
+    n_near = int(np.count_nonzero(~far))
+    offs = np.searchsorted(lo[order][:n_near], np.arange(ntiles) * tile_w, side="left")
+    return rows, np.concatenate([offs, [n_near]]).astype(np.int32)
 
 
 def _finish_tile_index(pf: PackedFrames):
