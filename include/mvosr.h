@@ -305,6 +305,17 @@ int mvosr_ransac_plane_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pt
                              int32_t *used);
 
 /*
+ * The 2-D line variant, get_pitch_line_ransac (/root/reference/src/estimate_road_norm.py:60-64) with estimate_line /
+ * is_inlier_line (:39-49): same kernel and replay rule; samples are pairs, stored like triples
+ * (pairs[f][h][0..1] used, [2] ignored), points are (px, py); model [F][4] = unit (a, b, 0, c) of the best line
+ * a x + b y + c = 0 with b >= 0 (the reference's SVD null vector has an arbitrary sign).
+ */
+int mvosr_ransac_line_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                            const double *px, const double *py, const int32_t *pairs, int n_hyp,
+                            double threshold, double goal_fraction, int32_t *counts, double *model, int32_t *best_ic,
+                            int32_t *used);
+
+/*
  * The legacy per-triangle batch of /root/reference/src/triangle_batch.py:14-68: features are
  * [u, v, depth] (b->x = u, b->v = v, b->z = depth; b->tri1 = Delaunay over (u,v), :23-25).  Per
  * triangle: back-projection with (focus, cx, cy) (:32-33), n = A^-1.1 (:36-37), s = n_y/|n| (:43),

@@ -82,6 +82,8 @@ SYMBOLS = {
                                              C.c_int64]),
     "mvosr_ransac_plane_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int, C.c_double, C.c_double,
                                            _P, _P, _P, _P]),
+    "mvosr_ransac_line_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, C.c_double, C.c_double,
+                                          _P, _P, _P, _P]),
     "mvosr_triangle_batch": (C.c_int, [_P, C.POINTER(Batch), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                        _P, _P, _P]),
     "mvosr_plane_inliers": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_double, _P]),

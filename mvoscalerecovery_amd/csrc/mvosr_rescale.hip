@@ -239,6 +239,8 @@ struct RansacArgs {
     int32_t *counts;                                     // [F][H] inlier counts (or NULL)
     double *model;                                       // [F][4] best model, sign fixed so that n_y >= 0
     int32_t *best_ic, *used;                             // [F]
+    int32_t line;                                        // 1: 2-D line fit (estimate_line / is_inlier_line, estimate_road_norm.py:39-49):
+                                                         // samples are PAIRS (still 3 ints apart), pz is not read, model = (a, b, 0, c)
 };
 constexpr int kMaxHyp = 512;
 
@@ -262,11 +264,19 @@ __global__ __launch_bounds__(kRsBlock) void ransac_plane_kernel(const RansacArgs
     for (int h = tid; h < H; h += kRsBlock) {
         const int32_t *t = a.triples + ((int64_t)f * H + h) * 3;
         const int i0 = t[0], i1 = t[1], i2 = t[2];
-        const double x0 = px[i0], y0 = py[i0], z0 = pz[i0];
-        const double e1x = px[i1] - x0, e1y = py[i1] - y0, e1z = pz[i1] - z0;
-        const double e2x = px[i2] - x0, e2y = py[i2] - y0, e2z = pz[i2] - z0;
-        double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
-        double d = -((nx * x0 + ny * y0) + nz * z0);
+        double nx, ny, nz, d;
+        if (a.line) {
+            // the line a x + b y + c = 0 through two points: the null vector of [x y 1] (estimate_road_norm.py:44-46)
+            const double x0 = px[i0], y0 = py[i0];
+            nx = py[i1] - y0; ny = -(px[i1] - x0); nz = 0.0;
+            d = -(nx * x0 + ny * y0);
+        } else {
+            const double x0 = px[i0], y0 = py[i0], z0 = pz[i0];
+            const double e1x = px[i1] - x0, e1y = py[i1] - y0, e1z = pz[i1] - z0;
+            const double e2x = px[i2] - x0, e2y = py[i2] - y0, e2z = pz[i2] - z0;
+            nx = e1y * e2z - e1z * e2y; ny = e1z * e2x - e1x * e2z; nz = e1x * e2y - e1y * e2x;
+            d = -((nx * x0 + ny * y0) + nz * z0);
+        }
         const double inv = 1.0 / sqrt(((nx * nx + ny * ny) + nz * nz) + d * d);
         double4 m; m.x = nx * inv; m.y = ny * inv; m.z = nz * inv; m.w = d * inv;
         mods[h] = m;
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(kRsBlock) void ransac_plane_kernel(const RansacArgs
         for (int k = 0; k < kRansacPPT; ++k) {
             const int j = c0 + k * kRsBlock + tid;
             const int jc = min(j, M - 1);
-            qx[k] = px[jc]; qy[k] = py[jc]; qz[k] = pz[jc];
+            qx[k] = px[jc]; qy[k] = py[jc]; qz[k] = a.line ? 0.0 : pz[jc];
             if (j >= M) qx[k] = nan("");                         // never an inlier: no masks or branches in the loop below
         }
         const int rows = min(kRansacPPT, (M - c0 + kRsBlock - 1) / kRsBlock);      // workgroup-uniform: rows that hold any point
@@ -469,23 +479,39 @@ int mvosr_flat_selection_batch(mvosr_ctx *ctx, const mvosr_batch *b, double loos
     return check_launch("flat_selection_kernel");
 }
 
-int mvosr_ransac_plane_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
-                             const double *px, const double *py, const double *pz, const int32_t *triples, int n_hyp,
-                             double threshold, double goal_fraction, int32_t *counts, double *model, int32_t *best_ic,
-                             int32_t *used) {
-    if (!ctx || !pts_off || !pts_cnt || !px || !py || !pz || !triples || !model || !best_ic || !used)
-        return set_error(MVOSR_ERR_ARG, "ransac_plane: null argument");
-    if (n_hyp < 1 || n_hyp > kMaxHyp) return set_error(MVOSR_ERR_ARG, "ransac_plane: n_hyp must be in 1..%d", kMaxHyp);
+static int launch_ransac(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                         const double *px, const double *py, const double *pz, const int32_t *samples, int n_hyp,
+                         double threshold, double goal_fraction, int32_t *counts, double *model, int32_t *best_ic,
+                         int32_t *used, int line) {
+    if (!ctx || !pts_off || !pts_cnt || !px || !py || (!pz && !line) || !samples || !model || !best_ic || !used)
+        return set_error(MVOSR_ERR_ARG, "ransac: null argument");
+    if (n_hyp < 1 || n_hyp > kMaxHyp) return set_error(MVOSR_ERR_ARG, "ransac: n_hyp must be in 1..%d", kMaxHyp);
     if (n_frames <= 0) return MVOSR_OK;
     int rc = ctx_activate(ctx);
     if (rc) return rc;
     RansacArgs a;
-    a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.px = px; a.py = py; a.pz = pz; a.triples = triples;
+    a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.px = px; a.py = py; a.pz = pz; a.triples = samples;
     a.n_hyp = n_hyp; a.threshold = threshold; a.goal_fraction = goal_fraction; a.counts = counts; a.model = model;
-    a.best_ic = best_ic; a.used = used;
+    a.best_ic = best_ic; a.used = used; a.line = line;
     const size_t lds = 36u * (size_t)n_hyp + 16;
     hipLaunchKernelGGL(ransac_plane_kernel, dim3((unsigned)n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
     return check_launch("ransac_plane_kernel");
+}
+
+int mvosr_ransac_plane_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                             const double *px, const double *py, const double *pz, const int32_t *triples, int n_hyp,
+                             double threshold, double goal_fraction, int32_t *counts, double *model, int32_t *best_ic,
+                             int32_t *used) {
+    return launch_ransac(ctx, n_frames, pts_off, pts_cnt, px, py, pz, triples, n_hyp, threshold, goal_fraction, counts, model,
+                         best_ic, used, 0);
+}
+
+int mvosr_ransac_line_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                            const double *px, const double *py, const int32_t *pairs, int n_hyp,
+                            double threshold, double goal_fraction, int32_t *counts, double *model, int32_t *best_ic,
+                            int32_t *used) {
+    return launch_ransac(ctx, n_frames, pts_off, pts_cnt, px, py, nullptr, pairs, n_hyp, threshold, goal_fraction, counts, model,
+                         best_ic, used, 1);
 }
 
 int mvosr_triangle_batch(mvosr_ctx *ctx, const mvosr_batch *b, double focus, double cx, double cy, double s_min,

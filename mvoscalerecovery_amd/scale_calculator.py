@@ -202,6 +202,23 @@ class ScaleEstimator:
     def road_model_calculation(self, feature3d):
         return self.road_model_calculation_static(feature3d)                  # :281-282
 
+    def road_model_calculation_ransac(self, feature3d, seed=None, triples=None):
+        """scale_calculator.py:366-384 (not on the path of :281; kept for callers that use it): RANSAC plane through the
+        selected points (30 hypotheses, threshold 0.005; :369), its inliers at 0.01 (:370-371), camera height
+        ``-d/|n|`` and pitch ``asin(-n_y/|n|)`` with the normal's sign fixed so that n_y >= 0 (:372-383).  Returns
+        ``(ransac_camera_height, pitch, inliers)``.  The reference's sampler is unseeded; ``seed`` / ``triples`` make
+        the draw reproducible."""
+        from . import estimate_road_norm as ern
+        pts = np.asarray(feature3d, dtype=np.float64)
+        m, _ = ern.get_pitch_ransac(pts, 30, 0.005, seed=seed, triples=triples, device=self.engine.ctx.device)      # :369
+        inlier_id = ern.get_inliers(m, pts, 0.01, device=self.engine.ctx.device)                                    # :370
+        inliers = pts[inlier_id, :]
+        normal, h_bar = np.array(m[0:-1]), -m[-1]                                                                   # :372-374
+        if normal[1] < 0:                                                                                           # :375-377
+            normal, h_bar = -normal, -h_bar
+        normal_len = np.sqrt(np.sum(normal * normal))
+        return h_bar / normal_len, np.arcsin(-normal[1] / normal_len), inliers                                      # :380-384
+
     def scale_calculation_static(self, point_selected):
         """scale_calculator.py:401-409 (remaps ``point_selected`` in place, like the reference)."""
         self.feature_remap(point_selected)

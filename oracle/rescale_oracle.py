@@ -143,6 +143,40 @@ def run_ransac(pts, triples, threshold=RANSAC_THRESHOLD, goal_fraction=RANSAC_GO
     return best_m, best_ic, used
 
 
+def estimate_line(p2):
+    """estimate_road_norm.py:39-46: unit 3-vector spanning the null space of [x y 1] of 2 points."""
+    a = np.ones((2, 3))
+    a[:, :2] = np.asarray(p2)[:2]
+    return np.linalg.svd(a)[-1][-1, :]
+
+
+def run_ransac_line(pts, pairs, threshold, goal_fraction=RANSAC_GOAL):
+    """get_pitch_line_ransac (estimate_road_norm.py:60-64) with the sample sequence given."""
+    goal = pts.shape[0] * goal_fraction
+    best_ic, best_m, used = 0, None, 0
+    for t in pairs:
+        used += 1
+        m = estimate_line(pts[list(t)])
+        ic = int(np.sum(np.abs(pts @ m[:2] + m[2]) < threshold))              # is_inlier_line, :48-49
+        if ic > best_ic:
+            best_ic, best_m = ic, m
+            if ic > goal:
+                break
+    return best_m, best_ic, used
+
+
+def road_model_ransac(pts, triples):
+    """ScaleEstimator.road_model_calculation_ransac, /root/reference/src/scale_calculator.py:366-384, with the sample
+    triples given: (camera height, pitch, inlier mask)."""
+    m, _, _ = run_ransac(pts, triples, threshold=0.005)
+    inl = np.abs(pts @ m[:3] + m[3]) < 0.01                                   # get_inliers, estimate_road_norm.py:71-78
+    normal, h_bar = np.array(m[:3]), -m[3]
+    if normal[1] < 0:
+        normal, h_bar = -normal, -h_bar
+    ln = np.sqrt(np.sum(normal * normal))
+    return h_bar / ln, np.arcsin(-normal[1] / ln), inl
+
+
 def scale_from_model(m, absolute_reference):
     """rescale.py:156-167: camera height from the plane, sign fixed so that n_y >= 0."""
     norm = np.array(m[:3], dtype=np.float64)

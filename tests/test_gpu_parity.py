@@ -736,6 +736,26 @@ def test_seq200_golden_through_driver(gpu):
     np.testing.assert_array_equal(res1["scales"], z["scales"][:25])
 
 
+def test_main_offline_files_golden(gpu, tmp_path):
+    """What /root/reference/src/main_offline.py itself writes for the synthetic 200-frame dict (scales.txt, path.txt:
+    tests/golden/seq200_main_offline.npz), reproduced by the drop-in estimator behind the build's driver — frame at a
+    time, batched (streaming) and sharded-driver (one rank) — value for value."""
+    import zlib
+    from mvoscalerecovery_amd import offline, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z, meta = load_npz("seq200_main_offline.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    for k, runner in enumerate((offline.run_sequence, offline.run_sequence_batched, offline.run_sequence_sharded)):
+        est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, delaunay_workers=8)
+        est.PIPELINE_CHUNK = 48
+        res = runner(data, est)
+        np.testing.assert_array_equal(res["scales"], z["scales"])
+        base = str(tmp_path) + "/r%d_" % k
+        offline.save_outputs(base, ".golden", res["scales"], data["motions"])
+        np.testing.assert_array_equal(np.loadtxt(base + "path.txt.golden"), z["path"])
+        assert zlib.crc32(open(base + "scales.txt.golden").read().encode()) == int(z["scales_txt_crc"])
+
+
 def test_seq4541_golden_batched(gpu):
     """Config C3: KITTI-00-length (4541 frames) main_offline-shaped replay, ragged N (300-1500),
     not-moving and too-few-feature frames; every filtered scale must equal the reference's
@@ -888,6 +908,34 @@ def test_road_norm_helpers(gpu):
 
 
 # ---------------------------------------------------------------- full-size properties (BASELINE configs[1])
+def test_road_norm_helpers_reference_golden(gpu):
+    """estimate_road_norm.py's helpers and ScaleEstimator.road_model_calculation_ransac against the reference's own
+    outputs (tests/golden/road_norm.json, sample sequences replayed): motion helpers incl. the np.matrix return type,
+    plane RANSAC -> height / pitch / inliers, line RANSAC -> model (up to the SVD's sign) and inlier count."""
+    import json
+    from mvoscalerecovery_amd import estimate_road_norm as ern
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "road_norm.json")))
+    for c in g["motion"]:
+        t = np.array(c["t"])
+        n = ern.get_norm_svd(t)
+        assert type(n).__name__ == c["norm_type"] and list(n.shape) == c["norm_shape"]
+        np.testing.assert_allclose(np.asarray(n).reshape(-1), c["norm"], rtol=0, atol=1e-14)
+        assert abs(ern.get_pitch_svd(t) - c["pitch_svd"]) <= 1e-14
+        assert ern.get_pitch(t) == c["pitch"]
+    est = ScaleEstimator(1.75, window_size=5)
+    for c in g["planes"]:
+        pts = np.array(c["pts"])
+        h, pitch, inl = est.road_model_calculation_ransac(pts, triples=np.array(c["triples"], dtype=np.int32))
+        assert abs(h - c["height"]) <= 1e-9 * abs(c["height"]) and abs(pitch - c["pitch"]) <= 1e-9
+        assert inl.shape[0] == c["n_inliers"] and abs(float(np.sum(inl)) - c["inlier_sum"]) <= 1e-9 * abs(c["inlier_sum"])
+    for c in g["lines"]:
+        m, ic = ern.get_pitch_line_ransac(np.array(c["xy"]), 40, 0.01, pairs=np.array(c["pairs"], dtype=np.int32))
+        ref = np.array(c["model"])
+        assert ic == c["best_ic"]
+        assert min(np.abs(m - ref).max(), np.abs(m + ref).max()) <= 1e-9 and m[1] >= 0
+
+
 def test_full_size_properties(gpu):
     """16 384 frames x 2000 features (the bench workload): results cannot be compared frame by frame
     with the CPU oracle in seconds, so size-independent properties are checked instead:

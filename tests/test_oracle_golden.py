@@ -314,3 +314,21 @@ def test_road_long_lists():
         assert len(y) == c["n"] and float(np.sum(y)) == c["sum"]
         rm = so.road_model(y, 0.7)
         assert rm.height == c["height"] and rm.skew == c["skew"], (k, rm.height, rm.skew)
+
+
+def test_driver_loop_against_the_references_own_main_offline(tmp_path):
+    """tests/golden/seq200_main_offline.npz holds what /root/reference/src/main_offline.py ITSELF wrote (scales.txt,
+    path.txt) for the synthetic 200-frame dict: the build's driver loop (offline.run_sequence + save_outputs) around
+    the oracle estimator must write the same files — gates, repeat-previous-scale, scales[1:], pose integration."""
+    import zlib
+    from mvoscalerecovery_amd import offline, synth
+    z, meta = load_npz("seq200_main_offline.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    res = offline.run_sequence(data, so.OracleScaleEstimator(meta["abs_ref"], window_size=meta["window"]))
+    np.testing.assert_array_equal(res["scales"], z["scales"])
+    poses = offline.save_outputs(str(tmp_path) + "/synth_result_", ".golden", res["scales"], data["motions"])
+    np.testing.assert_array_equal(np.loadtxt(str(tmp_path) + "/synth_result_path.txt.golden"), z["path"])
+    assert zlib.crc32(open(str(tmp_path) + "/synth_result_scales.txt.golden").read().encode()) == int(z["scales_txt_crc"])
+    # the same golden as the spy-based seq200 fixture (which drives the reference estimator through offline.run_sequence)
+    z2, _ = load_npz("seq200.npz")
+    np.testing.assert_array_equal(z["scales"], z2["scales"])

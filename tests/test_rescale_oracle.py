@@ -46,3 +46,25 @@ def test_rescale_sequence_golden():
             assert est.last["best_ic"] == int(z["f%d_best_ic" % i])
             assert est.last["used"] == int(z["f%d_used" % i])
         assert s == float(z["f%d_scale" % i]) and sd == 1, i
+
+
+def test_road_norm_helpers_golden():
+    """Oracle restatements of the RANSAC consumers against what the reference itself returned with the same sample
+    sequence (tests/golden/road_norm.json): road_model_calculation_ransac (scale_calculator.py:366-384) and the 2-D
+    line variant get_pitch_line_ransac (estimate_road_norm.py:39-49,60-64)."""
+    import json
+    import os
+    import numpy as np
+    from oracle import rescale_oracle as ro
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "road_norm.json")))
+    for c in g["planes"]:
+        pts = np.array(c["pts"])
+        h, pitch, inl = ro.road_model_ransac(pts, np.array(c["triples"]))
+        assert abs(h - c["height"]) <= 1e-12 * abs(c["height"]) and abs(pitch - c["pitch"]) <= 1e-12
+        assert int(inl.sum()) == c["n_inliers"]
+    for c in g["lines"]:
+        xy = np.array(c["xy"])
+        m, ic, used = ro.run_ransac_line(xy, np.array(c["pairs"]), 0.01)
+        assert ic == c["best_ic"] and used == c["used"]
+        ref = np.array(c["model"])
+        assert min(np.abs(m - ref).max(), np.abs(m + ref).max()) <= 1e-12          # SVD null vector: sign is arbitrary
