@@ -331,6 +331,28 @@ int mvosr_triangle_batch(mvosr_ctx *ctx, const mvosr_batch *b, double focus, dou
 int mvosr_plane_inliers(mvosr_ctx *ctx, int64_t n, const double *px, const double *py, const double *pz, const double *model4,
                         double threshold, uint8_t *mask);
 
+/* ---- optional device stage for the triangulations themselves -------------------- */
+
+enum mvosr_dt_status {
+    MVOSR_DT_OK = 0,
+    MVOSR_DT_DEGENERATE = 1      /* duplicate / collinear / cocircular points within the guard bands, or a row count that
+                                    is not Euler's 2n - 2 - h: rows are not to be used — triangulate this frame on the host */
+};
+
+/*
+ * Batched 2-D Delaunay triangulation: what scipy.spatial.Delaunay(points).simplices computes at
+ * /root/reference/src/scale_calculator.py:257-258 and :266-267, as a device stage.  For points in general position the
+ * triangle SET is the one Qhull returns; the rows are positively oriented, start with their smallest vertex and are
+ * sorted by it (then counter-clockwise around it).  Qhull's own rotation of each row — which the reference's vote
+ * depends on (:113-115) — is not reproducible from the geometry, so scales computed on these rows are a DELIBERATE
+ * DEVIATION from the reference (selected explicitly by the host with triangulation="gpu"; DESIGN.md gives the measured
+ * agreement).  Frame f's points are (u, v)[pts_off[f] .. +pts_cnt[f]); its rows are written at tri + 3*tri_off[f]
+ * (room for 2*pts_cnt[f] rows), tri_cnt[f] says how many; status[f] is an mvosr_dt_status.  max_pts = max(pts_cnt).
+ */
+int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                         const double *u, const double *v, int max_pts, const int64_t *tri_off, int32_t *tri,
+                         int32_t *tri_cnt, int32_t *status);
+
 /* LDS bytes the fused kernel requests for a frame of n features (host-side planning). */
 size_t mvosr_lds_bytes(int n_features);
 /* Largest frame the LDS-resident variant accepts on this build. */

@@ -87,6 +87,7 @@ SYMBOLS = {
     "mvosr_triangle_batch": (C.c_int, [_P, C.POINTER(Batch), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                        _P, _P, _P]),
     "mvosr_plane_inliers": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_double, _P]),
+    "mvosr_delaunay_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P]),
     "mvosr_lds_bytes": (C.c_size_t, [C.c_int]),
     "mvosr_max_lds_features": (C.c_int, []),
 }

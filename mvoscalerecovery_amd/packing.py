@@ -59,6 +59,59 @@ def _get_pool(workers):
     return _pool
 
 
+def delaunay_gpu(ctx, point_sets):
+    """The device stage for the triangulations (``mvosr_delaunay_batch``): per point set the (T,3) int32
+    rows — the triangle set SciPy returns for points in general position, rows positively oriented with their smallest
+    vertex first — or ``None`` where the kernel declined (duplicate / collinear / cocircular points within its guard
+    bands, fewer than 3 points): those sets are for the host's Qhull.  A DELIBERATE DEVIATION from the reference when
+    used for the vote (Qhull's rotation of each row is not reproducible); never the default."""
+    import ctypes as C
+    from . import _lib
+    F = len(point_sets)
+    if F == 0:
+        return []
+    cnt = np.array([len(p) for p in point_sets], dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(cnt.astype(np.int64))])
+    toff = 2 * off
+    total = max(int(off[-1]), 1)
+    uv = np.zeros((total, 2), dtype=np.float64)
+    for f, p in enumerate(point_sets):
+        if len(p):
+            uv[off[f]:off[f + 1]] = np.asarray(p, dtype=np.float64).reshape(-1, 2)
+    d_u, d_v = ctx.to_device(np.ascontiguousarray(uv[:, 0])), ctx.to_device(np.ascontiguousarray(uv[:, 1]))
+    d_off, d_cnt, d_toff = ctx.to_device(off[:-1].astype(np.int64)), ctx.to_device(cnt), ctx.to_device(toff[:-1].astype(np.int64))
+    d_tri = ctx.empty((2 * total, 3), np.int32)
+    d_tcnt, d_st = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
+    _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, int(cnt.max()), d_toff.ptr,
+                                            d_tri.ptr, d_tcnt.ptr, d_st.ptr), "mvosr_delaunay_batch")
+    ctx.sync()
+    tri, tcnt, st = d_tri.download(), d_tcnt.download(), d_st.download()
+    for b in (d_u, d_v, d_off, d_cnt, d_toff, d_tri, d_tcnt, d_st):
+        b.free()
+    delaunay_gpu.last_status = st                      # (bits 8.. of a declined frame's status say why: mvosr_delaunay.hip)
+    return [np.ascontiguousarray(tri[toff[f]:toff[f] + tcnt[f]]) if st[f] == 0 else None for f in range(F)]
+
+
+DELAUNAY_GPU_MAX_POINTS = 7000          # what the kernel's LDS plan holds (16 B per point + 40 KB)
+
+
+def delaunay_gpu_or_host(ctx, point_sets, workers=0):
+    """``triangulation="gpu"``: :func:`delaunay_gpu` for every point set it accepts, SciPy/Qhull (the reference's call) for
+    the ones it declines — degenerate inputs, sets too large for its LDS plan — and for sets SciPy itself rejects, whose
+    exception is returned in place of the rows (as :func:`delaunay_many` does)."""
+    out = [None] * len(point_sets)
+    small = [f for f, p in enumerate(point_sets) if 3 <= len(p) <= DELAUNAY_GPU_MAX_POINTS]
+    if small:
+        for f, t in zip(small, delaunay_gpu(ctx, [point_sets[f] for f in small])):
+            out[f] = t
+    rest = [f for f, t in enumerate(out) if t is None]
+    if rest:
+        for f, t in zip(rest, delaunay_many([point_sets[f] for f in rest], workers)):
+            out[f] = t
+    delaunay_gpu_or_host.last_host_fraction = len(rest) / max(len(point_sets), 1)
+    return out
+
+
 def start_pool(workers=None):
     """Create the Delaunay worker pool NOW.  The workers are forked, so this belongs before the first GPU call of the
     process (a HIP context, torch.cuda, RCCL all start runtime threads, and a fork taken while one of them holds a
@@ -369,6 +422,23 @@ class _Tri2Handle:
         for f, t in zip(self.todo, self.handle.get()):
             tri2s[f] = t
         return tri2s
+
+
+def survivor_points(pf: PackedFrames, valid_masks):
+    """Per frame the (u, v) of the features the vote kept, in their ORIGINAL order (what the reference's second
+    Delaunay call sees, :264-266), or ``None`` for frames that never make that call (<= 3 features, :263-270)."""
+    perms = pf.extra.get("perm") or [None] * pf.n_frames
+    pts = []
+    for f in range(pf.n_frames):
+        s = pf.frame_slice(f)
+        m = np.asarray(valid_masks[f], dtype=bool)
+        u, v = pf.u[s], pf.v[s]
+        if perms[f] is not None:
+            inv = np.empty(len(perms[f]), dtype=np.int64)
+            inv[perms[f]] = np.arange(len(perms[f]))
+            u, v, m = u[inv], v[inv], m[inv]
+        pts.append(np.stack([u[m], v[m]], axis=1) if len(m) > 3 else None)
+    return pts
 
 
 def submit_tri2(pf: PackedFrames, valid_masks, workers=0, slot=1):

@@ -48,7 +48,7 @@ def raise_for_status(status, frame=None):
 
 class ScaleEstimator:
     def __init__(self, absolute_reference, window_size=6, vanish=K.VANISH, focus=K.FOCUS, device=0,
-                 delaunay_workers=None, verbose=False, mutate_inputs=True):
+                 delaunay_workers=None, verbose=False, mutate_inputs=True, triangulation="scipy"):
         # reference attributes (scale_calculator.py:23-40)
         self.absolute_reference = absolute_reference
         self.camera_pitch = K.CAMERA_PITCH
@@ -72,6 +72,13 @@ class ScaleEstimator:
         self.verbose = verbose
         self.mutate_inputs = mutate_inputs          # the reference remaps the caller's feature3d in place (:414)
         self.delaunay_workers = delaunay_workers
+        # "scipy": both triangulations by scipy.spatial.Delaunay on the host, rows consumed verbatim — the reference's
+        # results bit for bit.  "gpu": the device stage mvosr_delaunay_batch (same triangle set, canonical row form) — a
+        # DELIBERATE DEVIATION: the reference's vote depends on Qhull's rotation of each row (:113-115), which cannot be
+        # reproduced, so some frames' scales differ by a histogram bin (DESIGN.md §3.8 has the measured agreement).
+        if triangulation not in ("scipy", "gpu"):
+            raise ValueError("triangulation must be 'scipy' or 'gpu'")
+        self.triangulation = triangulation
         if delaunay_workers is None or delaunay_workers > 1:
             packing.start_pool(delaunay_workers)    # fork the host stage's workers BEFORE the GPU runtime starts its threads
         self.engine = ScaleEngine(absolute_reference, device=device, camera_pitch=self.camera_pitch)
@@ -279,7 +286,13 @@ class ScaleEstimator:
             for f3 in f3s:
                 if isinstance(f3, np.ndarray) and f3.size:
                     self.feature_remap(f3)                                   # :414
-        h1 = tri1s if tri1s is not None else packing.submit_tri1(pf, self.delaunay_workers, slot=k % 4)
+        if tri1s is not None:
+            h1 = tri1s
+        elif self.triangulation == "gpu":
+            pts = [np.stack([pf.u[pf.frame_slice(f)], pf.v[pf.frame_slice(f)]], axis=1) for f in range(pf.n_frames)]
+            h1 = packing.delaunay_gpu_or_host(self.engine.ctx, pts, self.delaunay_workers)
+        else:
+            h1 = packing.submit_tri1(pf, self.delaunay_workers, slot=k % 4)
         return {"pf": pf, "h1": h1, "n": len(f3s), "out": None, "dbatch": None, "masks": None}
 
     def _chunk_vote(self, st, tri2s, k):
@@ -304,7 +317,15 @@ class ScaleEstimator:
                     print('feature rejected ', int(np.sum(~m)))
                     print('feature left     ', int(np.sum(m)))
             vote_out.free()
-            st["h2"] = packing.submit_tri2(pf, st["masks"], self.delaunay_workers, slot=4 + k % 4)
+            if self.triangulation == "gpu":
+                pts = packing.survivor_points(pf, st["masks"])
+                todo = [f for f, p in enumerate(pts) if p is not None]
+                tri2s = [np.zeros((0, 3), dtype=np.int32)] * pf.n_frames
+                for f, t in zip(todo, packing.delaunay_gpu_or_host(ctx, [pts[f] for f in todo], self.delaunay_workers)):
+                    tri2s[f] = t
+                st["h2"] = tri2s
+            else:
+                st["h2"] = packing.submit_tri2(pf, st["masks"], self.delaunay_workers, slot=4 + k % 4)
         else:
             if any(p is not None for p in (pf.extra.get("perm") or [])):
                 raise ValueError("precomputed tri2s for dense (re-ordered) frames need the vote mask: pass tri1s only")

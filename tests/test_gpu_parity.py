@@ -303,6 +303,64 @@ def test_dense_tiled_kernel_refuses_a_bad_index(gpu):
         assert st[0] == ores[0].status and st[2] == ores[2].status and st[1] == K.ST_ERR_MASK, (kind, st)
 
 
+def test_gpu_delaunay_matches_scipy_triangle_set(gpu):
+    """mvosr_delaunay_batch: for points in general position the triangle SET is SciPy's (Qhull's), every row is
+    positively oriented and starts with its smallest vertex, rows are sorted by that vertex; degenerate inputs
+    (duplicates, a grid, collinear points, fewer than 3 points) are declined, not mis-triangulated."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import packing, synth
+    rng = np.random.default_rng(17)
+    sets = [synth.synth_frame(i, n, base_seed=606)[1] for i, n in enumerate((2000, 1500, 300, 64, 7, 3, 4000, 5500))]
+    sets.append(rng.normal(0.0, 1.0, (900, 2)) * [1.0, 1e-3])                       # a very flat cloud
+    sets.append(np.concatenate([rng.uniform(0, 100, (500, 2)), rng.uniform(40, 41, (500, 2))]))     # a dense cluster in a sparse field
+    got = packing.delaunay_gpu(gpu, sets)
+    for k, (pts, tri) in enumerate(zip(sets, got)):
+        assert tri is not None, k
+        ref = Delaunay(pts).simplices
+        assert tri.shape == ref.shape, (k, tri.shape, ref.shape)
+        assert set(map(tuple, np.sort(tri, axis=1))) == set(map(tuple, np.sort(ref, axis=1))), k
+        a, b, c = pts[tri[:, 0]], pts[tri[:, 1]], pts[tri[:, 2]]
+        assert np.all((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0]) > 0), k     # like SciPy's rows
+        assert np.all(tri[:, 0] < tri[:, 1]) and np.all(tri[:, 0] < tri[:, 2]), k
+        assert np.all(np.diff(tri[:, 0]) >= 0), k
+    # two launches: identical rows (nothing depends on scheduling)
+    again = packing.delaunay_gpu(gpu, sets[:3])
+    for x, y in zip(got[:3], again):
+        assert np.array_equal(x, y)
+    grid = np.stack(np.meshgrid(np.arange(20.0), np.arange(15.0)), axis=-1).reshape(-1, 2)
+    dup = sets[2].copy(); dup[10] = dup[200]
+    line = np.stack([np.arange(50.0), 2.0 * np.arange(50.0)], axis=1)
+    declined = packing.delaunay_gpu(gpu, [grid, dup, line, sets[2][:2]])
+    assert all(t is None for t in declined)
+
+
+def test_triangulation_gpu_option(gpu):
+    """ScaleEstimator(triangulation="gpu"): both triangulations from the device stage.  The pipeline on top of them is
+    still exact — the oracle, GIVEN the same rows, returns the same scales bit for bit — and the deviation from the
+    reference is only what Qhull's row rotation decides in the vote: most frames still agree (measured in
+    profiles/r02_gpu_delaunay.json: 94 % of the raw scales of the 4541-frame sequence)."""
+    from mvoscalerecovery_amd import packing, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    frames = [synth.synth_frame(i, int(n), base_seed=1357, upper_fraction=0.1) for i, n in enumerate(np.random.default_rng(3).integers(200, 2200, 60))]
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    est.PIPELINE_CHUNK = 16
+    scales, stds = est.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames])
+    ref = so.OracleScaleEstimator(1.75, window_size=5)
+    same_as_scipy = 0
+    for i, (f3, f2) in enumerate(frames):
+        low = so.lower_mask(f2)
+        tri1 = packing.delaunay_gpu(gpu, [f2[low]])[0]
+        assert tri1 is not None
+        counters = so.outlier_votes(f2[low][:, 1], so.remap(f3)[low][:, 2], tri1)
+        tri2 = packing.delaunay_gpu(gpu, [f2[low][counters >= 0]])[0]
+        s, sd = ref.scale_calculation(f3, f2, tri1=tri1, tri2=tri2)
+        assert s == scales[i] and sd == stds[i], i
+        r0 = so.frame_raw_scale(f3, f2, 1.75)                        # SciPy's rows, i.e. the reference's result
+        same_as_scipy += int(r0.raw_scale == ref.last.raw_scale)
+    assert same_as_scipy >= 0.8 * len(frames), same_as_scipy
+
+
 def test_road_cases_kernel(gpu):
     """K3 alone on the reference's road-model edge cases (tests/golden/road_cases.json)."""
     from mvoscalerecovery_amd import packing
