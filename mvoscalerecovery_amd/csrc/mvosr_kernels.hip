@@ -699,6 +699,9 @@ struct RoadArgs {
     mvosr_outputs o;
     int64_t first_frame, n_frames;
     int pending_only;            // 1: fused path, only frames the scale kernel left pending
+    int32_t *level_redo;         // fused HOT path: frames that end on the fallback level (:334-335) are not finished but appended
+                                 // here ([0] = count): height_level becomes their result, so it must be NumPy's own double first
+    const int32_t *list;         // process the frames list[1 .. list[0]] (grid-strided) instead of first_frame + index
 };
 
 // bin of y against the workgroup's table edges[k] = {edge k, edge k+1} (same doubles as bin_edge)
@@ -962,7 +965,10 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
 #ifndef MVOSR_ROAD_MINW
 #define MVOSR_ROAD_MINW 1
 #endif
-__global__ __launch_bounds__(kRoadWaves *kWave, MVOSR_ROAD_MINW) void road_model_kernel(const RoadArgs a) {
+// LIST: the frames of a.list, grid-strided (the rare second pass over the frames that ended on the fallback level); otherwise
+// frame first_frame + wavefront index, no loop (a loop around the body costs the product variant 57 VGPRs, i.e. half its occupancy)
+template <bool LIST>
+__global__ __launch_bounds__(kRoadWaves *kWave, (LIST ? 1 : 4)) void road_model_kernel(const RoadArgs a) {
     static_assert(kRoadRC >= 16 && kRoadRC <= kDropStride, "verdict bytes per lane; the keep masks are 32 bits");
     __shared__ int hist_all[kRoadWaves][2][176];
     __shared__ double2 edges[kBins + 1];
@@ -970,8 +976,8 @@ __global__ __launch_bounds__(kRoadWaves *kWave, MVOSR_ROAD_MINW) void road_model
     __shared__ __attribute__((aligned(16))) uint8_t drop_all[kRoadWaves][kDropStride * kWave];
     for (int k = threadIdx.x; k < kBins; k += kRoadWaves * kWave) { double2 e; e.x = bin_edge(k); e.y = bin_edge(k + 1); edges[k] = e; }
     __syncthreads();
-    const int64_t f = a.first_frame + (int64_t)blockIdx.x * kRoadWaves + wave_id();
-    if (f >= a.first_frame + a.n_frames) return;
+    const int64_t slot = (int64_t)blockIdx.x * kRoadWaves + wave_id();
+    auto one_frame = [&](const int64_t f) {
     if (a.pending_only && a.o.status[f] != kStPending) return;
     MVOSR_STAMP_DECL
     MVOSR_RSTAMP(0);
@@ -993,6 +999,11 @@ __global__ __launch_bounds__(kRoadWaves *kWave, MVOSR_ROAD_MINW) void road_model
 #ifdef MVOSR_STAMPS
     if (lane_id() == 0 && a.o.hist) { unsigned long long *d = reinterpret_cast<unsigned long long *>(a.o.hist + f * 2 * kBins) + 16; for (int i = 0; i < 8; ++i) d[i] = stamps[i]; }
 #endif
+    if (R.status == MVOSR_ST_LEVEL && a.level_redo) {
+        // the frame's height IS height_level, which the HOT scale kernel summed in its own order: the EXACT pass redoes it
+        if (lane_id() == 0) { a.level_redo[1 + atomicAdd(a.level_redo, 1)] = (int32_t)f; a.o.status[f] = kStRedo; }
+        return;
+    }
     if (lane_id() == 0) {
         double height = nan(""), raw = nan("");
         if (R.status == MVOSR_ST_NO_FLAT) raw = a.P.absolute_reference / hl;                        // :421
@@ -1006,6 +1017,13 @@ __global__ __launch_bounds__(kRoadWaves *kWave, MVOSR_ROAD_MINW) void road_model
             c[MVOSR_CNT_MODE_LEFT] = R.mode_left; c[MVOSR_CNT_MODE_RIGHT] = R.mode_right;
         }
         if (a.o.stats) { double *st = a.o.stats + 4 * f; st[0] = R.mean; st[1] = R.std; st[2] = R.skew; st[3] = R.median; }
+    }
+    };
+    if constexpr (LIST) {
+        const int64_t n_todo = (int64_t)a.list[0];
+        for (int64_t it = slot; it < n_todo; it += (int64_t)gridDim.x * kRoadWaves) one_frame((int64_t)a.list[1 + it]);
+    } else {
+        if (slot < a.n_frames) one_frame(a.first_frame + slot);
     }
 }
 
@@ -1087,7 +1105,7 @@ __device__ __forceinline__ void frame_tail(const KArgs &a, const Smem &s, int64_
 #pragma unroll
         for (int i = 0; i < BW; ++i) { const int c = s.misc[M_WCNT + i]; if (i < w) base += c; nsel += c; }
         if constexpr (MODE == MODE_HOT) {
-            if (S.near || nsel <= kBins) {
+            if (S.near || nsel == 0) {
                 if (tid == 0) { a.redo[1 + atomicAdd(a.redo, 1)] = (int32_t)f; a.o.status[f] = kStRedo; a.nsel[f] = 0; }
                 return;
             }
@@ -1445,7 +1463,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
 #pragma unroll
         for (int i = 0; i < DW; ++i) { const int c = misc[M_WCNT + i]; if (i < w) { base_s += c; base_v += misc[M_WCNT + DW + i]; } nsel += c; }
         if constexpr (MODE == MODE_HOT) {
-            if (S.near || nsel <= kBins) {       // the level's last bits may matter: leave the frame to the EXACT pass
+            if (S.near || nsel == 0) {           // the level's last bits may matter: leave the frame to the EXACT pass
                 if (tid == 0) { a.redo[1 + atomicAdd(a.redo, 1)] = (int32_t)f; a.o.status[f] = kStRedo; a.nsel[f] = 0; }
                 return;
             }
@@ -1886,7 +1904,7 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
 #pragma unroll
         for (int i = 0; i < DW; ++i) { const int c = misc[M_WCNT + i]; if (i < w) base += c; nsel += c; any_near |= misc[M_WCNT + DW + i]; }
         MVOSR_TSTAMP(8);
-        if (any_near || nsel <= kBins) {              // the level's last bits could matter, or the level may be the result: EXACT pass
+        if (any_near || nsel == 0) {                  // the level's last bits could matter, or the level is the result: EXACT pass
             if (tid == 0) { a.redo[1 + atomicAdd(a.redo, 1)] = (int32_t)f; a.o.status[f] = kStRedo; a.nsel[f] = 0; }
             return;
         }
@@ -2098,6 +2116,7 @@ static int check_fit(const mvosr_batch *b, int waves, int sc, size_t lds) {
 // range in that mode; HOT runs the product variant and then the EXACT variant over the redo list the HOT kernel
 // filled (a short persistent grid: the list's length is only known on the device, and is almost always zero).
 constexpr int kRedoGrid = 512;
+constexpr int kModeExactList = 3;
 static inline KArgs &kargs_of(KArgs &a) { return a; }
 static inline KArgs &kargs_of(DenseArgs &a) { return a.k; }
 
@@ -2115,6 +2134,12 @@ static int launch_modes(mvosr_ctx *ctx, void (*k_hot)(const Args), void (*k_exac
         return check_launch(name);
     }
     if ((rc = prepare_kernel(k_exact, lds))) return rc;
+    if (mode == kModeExactList) {                 // the EXACT variant over the list in args.redo (filled by the road-model kernel)
+        kargs_of(args).redo_pass = 1;
+        const unsigned grid = (unsigned)(nl < (int64_t)kRedoGrid ? nl : (int64_t)kRedoGrid);
+        hipLaunchKernelGGL(k_exact, dim3(grid), dim3(threads), lds, ctx_stream(ctx), args);
+        return check_launch(name);
+    }
     if (mode == MODE_EXACT) {
         hipLaunchKernelGGL(k_exact, dim3((unsigned)nl), dim3(threads), lds, ctx_stream(ctx), args);
         return check_launch(name);
@@ -2198,8 +2223,9 @@ static int launch_scale_dense(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, int m
 // one wavefront per frame, kRoadWaves frames per workgroup
 static int launch_road(mvosr_ctx *ctx, const RoadArgs &ra, hipStream_t stream) {
     if (ra.n_frames <= 0) return MVOSR_OK;
-    const unsigned blocks = (unsigned)((ra.n_frames + kRoadWaves - 1) / kRoadWaves);
-    hipLaunchKernelGGL(road_model_kernel, dim3(blocks), dim3(kRoadWaves * kWave), 0, stream, ra);
+    const unsigned blocks = ra.list ? 64u : (unsigned)((ra.n_frames + kRoadWaves - 1) / kRoadWaves);
+    if (ra.list) hipLaunchKernelGGL(road_model_kernel<true>, dim3(blocks), dim3(kRoadWaves * kWave), 0, stream, ra);
+    else hipLaunchKernelGGL(road_model_kernel<false>, dim3(blocks), dim3(kRoadWaves * kWave), 0, stream, ra);
     return check_launch("road_model_kernel");
 }
 
@@ -2266,6 +2292,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     if (b->n_frames >= ((int64_t)1 << 31) - 1) return set_error(MVOSR_ERR_TOO_LARGE, "scale_batch: more than 2^31-2 frames in one batch");
     if ((rc = ctx_workspace(ctx, b->n_frames, b->total_feat, &ka.ysel, &ka.nsel))) return rc;
     ka.redo = ka.nsel + b->n_frames;            // [1 + n_frames] ints behind the nsel array
+    int32_t *redo2 = ka.redo + b->n_frames + 1; // a second list: frames the road model ends on the fallback level
     // FULL: per-triangle debug outputs; EXACT: stage outputs requested (height_level bit-equal to NumPy's for every
     // frame); HOT: the product path + its exact pass over the frames that need it
     const int mode = (o->tri_normals || o->tri_pitch_deg || o->tri_heights) ? MODE_FULL
@@ -2273,7 +2300,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     const int waves = pick_waves(waves_per_frame, b->max_feat);
     RoadArgs ra;
     ra.P = *p; ra.off = b->feat_off; ra.cnt = ka.nsel; ra.y = ka.ysel; ra.scratch = ka.ysel;
-    ra.height_level = o->height_level; ra.o = *o; ra.pending_only = 1;
+    ra.height_level = o->height_level; ra.o = *o; ra.pending_only = 1; ra.level_redo = nullptr; ra.list = nullptr;
     // The step is two launches on the context's stream: the scale kernel, then the road model (one
     // wavefront per frame) on the dense lists it left in the workspace.  (Splitting the batch into
     // chunks to run the road model of one chunk under the scale kernel of the next was measured
@@ -2291,7 +2318,23 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, mode, false) : dispatch_scale(ctx, ka, waves, n_launch, mode))) return rc;
     if (pev && (ee = hipEventRecord(pev[1], ctx_stream(ctx))) != hipSuccess) return set_hip_error("hipEventRecord(profile)", ee);
     ra.first_frame = first_frame; ra.n_frames = n_launch;
-    if (!(debug_skip_env() & 16)) { if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc; }
+    if (!(debug_skip_env() & 16)) {
+        if (mode == MODE_HOT) {
+            // frames whose road model ends on the fallback level (:334-335; rare) come back on a second list: the EXACT
+            // variant redoes them (height_level in NumPy's order), then the road model runs on that list alone
+            const hipError_t e2 = hipMemsetAsync(redo2, 0, sizeof(int32_t), ctx_stream(ctx));
+            if (e2 != hipSuccess) return set_hip_error("hipMemsetAsync(redo list 2)", e2);
+            ra.level_redo = redo2;
+        }
+        if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc;
+        if (mode == MODE_HOT) {
+            KArgs k2 = ka;
+            k2.redo = redo2;
+            if ((rc = dense ? launch_scale_dense(ctx, k2, n_launch, kModeExactList, false) : dispatch_scale(ctx, k2, waves, n_launch, kModeExactList))) return rc;
+            ra.level_redo = nullptr; ra.list = redo2;
+            if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc;
+        }
+    }
     if (pev) {
         if ((ee = hipEventRecord(pev[2], ctx_stream(ctx))) != hipSuccess) return set_hip_error("hipEventRecord(profile)", ee);
         ctx->prof_calls++;
@@ -2333,7 +2376,7 @@ int mvosr_road_model_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_ba
     if ((rc = ctx_workspace(ctx, b->n_frames, b->total_feat, &scratch, &unused))) return rc;
     ra.P = *p; ra.off = b->feat_off; ra.cnt = b->feat_cnt; ra.y = b->y; ra.scratch = scratch;
     ra.height_level = height_level_in; ra.o = *o;
-    ra.first_frame = 0; ra.n_frames = b->n_frames; ra.pending_only = 0;
+    ra.first_frame = 0; ra.n_frames = b->n_frames; ra.pending_only = 0; ra.level_redo = nullptr; ra.list = nullptr;
     return launch_road(ctx, ra, ctx_stream(ctx));
 }
 

@@ -502,6 +502,32 @@ def test_frame_fuzz_through_drop_in(gpu):
     assert {K.ST_MODE, K.ST_RIGHT, K.ST_MEDIAN, K.ST_NO_FLAT} <= seen
 
 
+def test_frame_fuzz_batched_product_mode(gpu):
+    """The same adversarial frames through the PRODUCT (HOT) kernels in one batch: raw scales bit-equal to the reference's,
+    including the frames whose result is the level itself (nothing selected; road model ending on its fallback level) —
+    those come back through the exact passes — and the statuses the oracle gives."""
+    from mvoscalerecovery_amd import constants as K, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_fuzz.npz"))
+    idx = [i for i in range(len(z["scale"])) if not z["raised"][i]]
+    frames = [synth.fuzz_frame(i, int(z["seed"])) for i in idx]
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=8)
+    est.PIPELINE_CHUNK = 64
+    raw, status, level, errors = est.raw_scale_batch([f[0] for f in frames], [f[1] for f in frames])
+    assert not errors
+    seen = set()
+    for k, i in enumerate(idx):
+        want = z["scale"][i]
+        assert (np.isnan(raw[k]) and np.isnan(want)) or raw[k] == want, (i, raw[k], want, status[k])
+        r = so.frame_raw_scale(frames[k][0], frames[k][1], 1.75)
+        assert status[k] == r.status, (i, status[k], r.status)
+        if status[k] in (K.ST_NO_FLAT, K.ST_LEVEL) and not np.isnan(r.height_level):
+            assert level[k] == r.height_level, i
+        seen.add(int(status[k]))
+    assert {K.ST_MODE, K.ST_RIGHT, K.ST_MEDIAN, K.ST_NO_FLAT} <= seen
+
+
 def test_window_median_kernel(gpu):
     from mvoscalerecovery_amd.engine import ScaleEngine
     so = _oracle()
@@ -876,6 +902,71 @@ def test_rccl_gather_and_gpu_median_world1(gpu, tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733")
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "world1 ok" in p.stdout, p.stdout + p.stderr
+
+
+def test_one_million_frames_two_ranks_gather_and_median(gpu, tmp_path):
+    """Config C4's cross-rank half at full size: 1 000 000 frames, two ranks (both on this GPU: MVOSR_SHARE_GPU, gloo
+    staging through the host), each rank's record all-gathered with ONE collective and the window-median kernel
+    reading the gathered buffer in place; checked against NumPy's sliding median of the whole sequence."""
+    import subprocess
+    import sys
+    import textwrap
+    from conftest import ROOT
+    script = tmp_path / "w2.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        sys.path.insert(0, %r)
+        from mvoscalerecovery_amd import _lib, sharding
+        from mvoscalerecovery_amd.engine import ScaleEngine
+        from oracle import scale_oracle as so
+        rank, local, world = sharding.init_distributed("gloo")
+        assert world == 2
+        n = 1000001                                   # ragged: rank 0 holds one frame more
+        rng = np.random.default_rng(2)
+        raw_all = rng.uniform(0.5, 3.0, n)
+        raw_all[[5, 500000, 999999]] = np.nan
+        st_all = rng.integers(0, 5, n).astype(np.int32)
+        lvl_all = rng.uniform(-1.0, 1.0, n)
+        a, b = sharding.partition(n, world, rank)
+        dev = torch.device("cuda", local)
+        ctx = _lib.Context(local)
+        stream = torch.cuda.Stream(device=local)
+        torch.cuda.set_stream(stream)
+        ctx.set_stream(stream.cuda_stream)
+        eng = ScaleEngine(1.75, ctx=ctx)
+        rec = sharding.RankRecord(max(sharding.shard_sizes(n, world)), dev).fill(raw_all[a:b], st_all[a:b], lvl_all[a:b])
+        c0 = sharding.collectives_issued
+        filt, g = sharding.gather_and_filter(rec, n, 5, sharding.make_gpu_median(eng), queue=[2.0, 1.0])
+        torch.cuda.synchronize()
+        assert sharding.collectives_issued == c0 + 1
+        got = filt.cpu().numpy()
+        head, _ = so.window_median(raw_all[:16], 5, [2.0, 1.0])
+        assert np.array_equal(got[:16], head, equal_nan=True)
+        win = np.lib.stride_tricks.sliding_window_view(raw_all, 5)
+        want = np.median(win, axis=1)                 # (NaN propagates, like np.median of the deque)
+        assert np.array_equal(got[4:], want, equal_nan=True)
+        assert np.array_equal(g.status().cpu().numpy(), st_all) and np.array_equal(g.level().cpu().numpy(), lvl_all)
+        dist.barrier()
+        dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """ % ROOT))
+    port = 29900 + os.getpid() % 90
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MVOSR_SHARE_GPU="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for rank, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        assert p.returncode == 0, out
+        assert "rank %d ok" % rank in out
 
 
 # ---------------------------------------------------------------- the `rescale` variant (f2/f4)
