@@ -293,6 +293,8 @@ def main():
                          offs("tri1_off", pf_pool.tri1_off[:-1], t1p, True), rep("tri1", pf_pool.tri1[:t1p].reshape(-1), np.int32),
                          offs("tri2_off", pf_pool.tri2_off[:-1], t2p, True), rep("tri2", pf_pool.tri2[:t2p].reshape(-1), np.int32),
                          rep("n2", pf_pool.n2_expected, np.int32), pf_pool.max_feat, int(pf_pool.tri2_ids), pool_pad * repeats)
+    cnt_host = np.tile(np.ascontiguousarray(pf_pool.feat_cnt, dtype=np.int32), repeats)
+    _lib.check(ctx.lib.mvosr_batch_size_hint(cnt_host.ctypes.data, F, C.byref(bstruct)), "mvosr_batch_size_hint")
     if pf_pool.tile_w and not args.no_tiles:
         nt = int(pf_pool.tile_base[-1])
         bstruct.tile_w = int(pf_pool.tile_w)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MVOSR_ABI_VERSION 3
+#define MVOSR_ABI_VERSION 4
 
 /* error codes (function return values) */
 enum mvosr_err {
@@ -136,10 +136,17 @@ typedef struct mvosr_batch {
      * kernel checks the index (starts at 0, monotone, in range) and every walked row against its tile window; an
      * inconsistent index gives MVOSR_ST_ERR_MASK, never a wrong result. */
     int32_t tile_w;              /* MVOSR_TILE_W, or 0 */
-    int32_t reserved0;
+    int32_t min_feat;            /* min(feat_cnt), or 0 = not stated.  With waves_per_frame == 0 a batch whose smallest
+                                    and largest frames fall into different variants' ranges (below) is launched per
+                                    size class — each class with the variant and the LDS request of its own largest
+                                    frame; stating min_feat lets a uniform batch skip the classification launch    */
     const int64_t *tile_base;    /* [F+1] */
     const int32_t *tile1_off;    /* [tile_base[F]] index into the frame's tri1 rows */
     const int32_t *tile2_off;    /* [tile_base[F]] index into the frame's tri2 rows */
+    int32_t size_hint[4];        /* opaque, all zero = none.  mvosr_batch_size_hint() fills it from the host's copy of
+                                    feat_cnt (how many frames each size class holds), so that the per-class launches
+                                    of a ragged batch are exactly as long as their lists; without it every class is
+                                    launched over n_launch workgroups, most of which leave at once                  */
 } mvosr_batch;
 
 #define MVOSR_TILE_W 512
@@ -215,7 +222,9 @@ void mvosr_default_params(mvosr_params *p, double absolute_reference);
  * frame, no LDS-resident frame, full occupancy) turns each list into height / scale / status.
  * `waves_per_frame` selects the scale kernel's variant: 0 = choose from max_feat (measured crossovers:
  * 1 up to 384 features, 4 up to 1024, 8 while two workgroups fit a CU's LDS — about 3000 —, 16 above),
- * 1 = one wavefront per frame (<= 512 features), 4/8/16 = one workgroup of that many wavefronts.
+ * 1 = one wavefront per frame (<= 512 features), 4/8/16 = one workgroup of that many wavefronts.  With 0, a batch
+ * of at least 2048 frames whose sizes span more than one of those ranges (b->min_feat) is split on the device into
+ * its size classes, one launch per class over the class's frame list (results do not depend on the variant).
  * Frames that do not fit LDS in fp64 (max_feat > mvosr_max_lds_features(), about 6200) and batches with
  * feature-numbered second triangulations (b->tri2_ids) run the gather variant, which keeps only the vote
  * counters in LDS; with survivor-numbered rows it uses 24 bytes of context workspace per feature.
@@ -224,6 +233,10 @@ void mvosr_default_params(mvosr_params *p, double absolute_reference);
 int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b,
                       const mvosr_outputs *o, int waves_per_frame,
                       int64_t first_frame, int64_t n_launch);
+
+/* Host helper (no GPU work): from the HOST copy of the batch's feat_cnt set b->max_feat, b->min_feat and
+ * b->size_hint.  Optional — see mvosr_batch.size_hint. */
+int mvosr_batch_size_hint(const int32_t *feat_cnt_host, int64_t n_frames, mvosr_batch *b);
 
 /*
  * Stage K1 alone: find_outliers (scale_calculator.py:151-167) for every frame; writes

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 LIB_PATH = os.environ.get("MVOSR_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")   # (override: A/B builds in profiles/)
-ABI_VERSION = 3
+ABI_VERSION = 4
 TRI2_SURVIVORS, TRI2_FEATURES = 0, 1      # mvosr_batch.tri2_ids
 N_COUNTS = 8
 TILE_W = 512                              # MVOSR_TILE_W
@@ -35,8 +35,8 @@ class Batch(C.Structure):
                 ("tri1_off", C.c_void_p), ("tri1", C.c_void_p), ("tri2_off", C.c_void_p), ("tri2", C.c_void_p),
                 ("n2_expected", C.c_void_p), ("max_feat", C.c_int32), ("tri2_ids", C.c_int32),
                 ("total_feat", C.c_int64),
-                ("tile_w", C.c_int32), ("reserved0", C.c_int32), ("tile_base", C.c_void_p),
-                ("tile1_off", C.c_void_p), ("tile2_off", C.c_void_p)]
+                ("tile_w", C.c_int32), ("min_feat", C.c_int32), ("tile_base", C.c_void_p),
+                ("tile1_off", C.c_void_p), ("tile2_off", C.c_void_p), ("size_hint", C.c_int32 * 4)]
 
 
 class Outputs(C.Structure):
@@ -73,6 +73,7 @@ SYMBOLS = {
     "mvosr_default_params": (None, [C.POINTER(Params), C.c_double]),
     "mvosr_scale_batch": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Batch), C.POINTER(Outputs), C.c_int,
                                     C.c_int64, C.c_int64]),
+    "mvosr_batch_size_hint": (C.c_int, [_P, C.c_int64, C.POINTER(Batch)]),
     "mvosr_outlier_vote_batch": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Batch), C.POINTER(Outputs), C.c_int]),
     "mvosr_road_model_batch": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Batch), _P, C.POINTER(Outputs), C.c_int]),
     "mvosr_window_median": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, _P]),

@@ -45,7 +45,7 @@ int ctx_workspace(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat, double *
     }
     if ((size_t)n_frames > ctx->ws_nsel_len) {
         if (ctx->ws_nsel) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->ws_nsel); ctx->ws_nsel = nullptr; ctx->ws_nsel_len = 0; }
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->ws_nsel), ((size_t)n_frames * 3 + 4) * sizeof(int32_t));   // counts + the two redo lists
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->ws_nsel), ((size_t)n_frames * 6 + 12) * sizeof(int32_t));   // counts + the two redo lists + the size classes' header and lists
         if (e != hipSuccess) return set_hip_error("hipMalloc(workspace: selected counts)", e);
         ctx->ws_nsel_len = (size_t)n_frames;
     }

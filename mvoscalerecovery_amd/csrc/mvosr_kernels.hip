@@ -1042,6 +1042,9 @@ struct KArgs {
     int redo_pass;           // EXACT kernels: 1 = process the redo list (grid-strided), 0 = frame first_frame + blockIdx.x
     double *ysel;            // workspace plane (laid out like x): the selected y' of every frame, dense
     int32_t *nsel;           // workspace [F]: how many
+    // size-class launches of a ragged batch (LIST kernels): the class's frame list and its length
+    const int32_t *cls_list;
+    const int32_t *cls_cnt;
 };
 
 __device__ __forceinline__ void write_counts(const KArgs &a, int64_t f, int nvalid, int npitch, int ntv, const RoadResult &R) {
@@ -1133,8 +1136,11 @@ __device__ __forceinline__ void frame_tail(const KArgs &a, const Smem &s, int64_
 }
 
 // The frames of a launch: frame first_frame + blockIdx.x — or, in the EXACT pass over the redo list, the list's entries
-// strided over the grid (the list is short or empty; its length is only known on the device).
-template <int MODE, class Body>
+// strided over the grid (the list is short or empty; its length is only known on the device) — or, in a size-class
+// launch (LIST), entry blockIdx.x of the class's list (the grid covers the longest possible list; workgroups beyond the
+// list's end leave at once.  A grid of resident workgroups looping over the list was tried first: the loop makes the
+// compiler keep the kernel arguments live in registers — 69 -> 109 VGPRs for the 4-wavefront variant).
+template <int MODE, bool LIST, class Body>
 __device__ __forceinline__ void for_frames(const KArgs &a, Body body) {
     if constexpr (MODE == MODE_EXACT) {
         if (a.redo_pass) {
@@ -1146,6 +1152,10 @@ __device__ __forceinline__ void for_frames(const KArgs &a, Body body) {
             return;
         }
     }
+    if constexpr (LIST) {
+        if ((int)blockIdx.x < *a.cls_cnt) body((int64_t)a.cls_list[blockIdx.x]);
+        return;
+    }
     body(a.first_frame + blockIdx.x);
 }
 
@@ -1153,10 +1163,10 @@ __device__ __forceinline__ void for_frames(const KArgs &a, Body body) {
 #define MVOSR_MINW 1
 #endif
 // (the 8-wavefront product variants must stay within 80 VGPRs: three workgroups per CU are six wavefronts per SIMD)
-template <int WAVES, int SC, int MODE>
+template <int WAVES, int SC, int MODE, bool LIST = false>
 __global__ __launch_bounds__(WAVES *kWave, (WAVES == 8 && MODE == MODE_HOT ? 6 : MVOSR_MINW)) void scale_frames_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    for_frames<MODE>(a, [&](const int64_t f) {
+    for_frames<MODE, LIST>(a, [&](const int64_t f) {
     constexpr int B = WAVES * kWave;
     const int n = a.b.feat_cnt[f];
     const int64_t off = a.b.feat_off[f];
@@ -1295,7 +1305,7 @@ template <int DW, int MODE>
 __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const DenseArgs da) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KArgs &a = da.k;
-    for_frames<MODE>(a, [&](const int64_t f) {
+    for_frames<MODE, false>(a, [&](const int64_t f) {
     constexpr int B = DW * kWave;
     const int tid = threadIdx.x;
     const int n = a.b.feat_cnt[f];
@@ -1347,7 +1357,7 @@ template <int DW, int MODE>
 __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(const DenseArgs da) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KArgs &a = da.k;
-    for_frames<MODE>(a, [&](const int64_t f) {
+    for_frames<MODE, false>(a, [&](const int64_t f) {
     constexpr int B = DW * kWave;
     constexpr bool FULL = MODE == MODE_FULL;
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
@@ -2070,6 +2080,55 @@ static int debug_skip_env() {
     return v;
 }
 
+// Size classes of a ragged batch (the crossovers of pick_waves): the frames of a launch are split into up to three
+// lists, and every list is launched with the variant and the LDS request of its own largest possible frame.
+constexpr int kClassHeader = 4;                // cnt[3] | pad
+constexpr int kClassThr0 = 384, kClassThr1 = 1024;
+constexpr int64_t kClassMinFrames = 2048;      // below: one launch (three short grids would cost more than they save)
+constexpr int32_t kClassHintMagic = 0x4d56;    // mvosr_batch.size_hint[3] when mvosr_batch_size_hint filled it
+constexpr int kClassifyWaves = 16;
+struct ClassArgs {
+    const int32_t *feat_cnt;
+    int64_t first_frame, n_frames;
+    int32_t *hdr;                              // kClassHeader ints, zeroed before the launch
+    int32_t *lists;                            // 3 x stride entries
+    int64_t stride;
+    int32_t *redo;                             // the (zeroed) redo list
+    int grid[3];                               // workgroups of each class's launch
+};
+
+__host__ __device__ inline int size_class_of(int n) { return n <= kClassThr0 ? 0 : (n <= kClassThr1 ? 1 : 2); }
+
+// One atomic per workgroup and class; the order inside a list is free.  A frame that does not fit its class's launch
+// (a size hint that understates the class) goes to the redo list: the EXACT pass walks that list whatever its length.
+__global__ __launch_bounds__(kClassifyWaves *kWave) void classify_frames_kernel(const ClassArgs c) {
+    __shared__ int wcnt[kClassifyWaves][3];
+    __shared__ int bbase[3];
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    int cls = -1;
+    int32_t f = 0;
+    if (i < c.n_frames) {
+        f = (int32_t)(c.first_frame + i);
+        cls = size_class_of(c.feat_cnt[f]);
+    }
+    const uint64_t m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+    if (lane == 0) { wcnt[w][0] = __popcll(m0); wcnt[w][1] = __popcll(m1); wcnt[w][2] = __popcll(m2); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int tot = 0;
+        for (int ww = 0; ww < kClassifyWaves; ++ww) tot += wcnt[ww][threadIdx.x];
+        bbase[threadIdx.x] = tot ? atomicAdd(c.hdr + threadIdx.x, tot) : 0;
+    }
+    __syncthreads();
+    if (cls < 0) return;
+    const uint64_t m = cls == 0 ? m0 : (cls == 1 ? m1 : m2);
+    int pos = bbase[cls] + __popcll(m & ((1ull << lane) - 1ull));
+    for (int ww = 0; ww < w; ++ww) pos += wcnt[ww][cls];
+    if (pos < c.grid[cls]) c.lists[cls * c.stride + pos] = f;
+    else c.redo[1 + atomicAdd(c.redo, 1)] = f;
+}
+
 // Variants: (wavefronts per frame, 64-feature sub-chunks each wave compacts).  Capacity of a variant
 // is WAVES*SC*64 features; 16-bit vote counters and the 64-bit per-thread triangle flags are wider
 // than any frame that fits LDS.
@@ -2244,6 +2303,64 @@ static int launch_road(mvosr_ctx *ctx, const RoadArgs &ra, hipStream_t stream) {
 static int dispatch_scale(mvosr_ctx *ctx, const KArgs &ka, int waves, int64_t nl, int mode) { MVOSR_DISPATCH(launch_scale, ctx, ka, nl, mode); }
 static int dispatch_vote(mvosr_ctx *ctx, const KArgs &ka, int waves, int64_t nl) { MVOSR_DISPATCH(launch_vote, ctx, ka, nl); }
 
+// the HOT list variant of (waves, sub-chunks)
+typedef void (*scale_kernel_fn)(const KArgs);
+static scale_kernel_fn hot_list_kernel(int waves, int n) {
+    switch (waves) {
+        case 1: return scale_frames_kernel<1, 8, MODE_HOT, true>;
+        case 4: return (n <= variant_capacity(4, 4)) ? scale_frames_kernel<4, 4, MODE_HOT, true> : scale_frames_kernel<4, 8, MODE_HOT, true>;
+        case 16: return (n <= variant_capacity(16, 4)) ? scale_frames_kernel<16, 4, MODE_HOT, true> : scale_frames_kernel<16, 8, MODE_HOT, true>;
+        default: return (n <= variant_capacity(8, 4)) ? scale_frames_kernel<8, 4, MODE_HOT, true> : scale_frames_kernel<8, 8, MODE_HOT, true>;
+    }
+}
+
+// HOT pass of a ragged batch: classify, then one launch per size class over the class's list.  The frames every class leaves for the EXACT pass land on the one redo
+// list; the caller runs that pass (kModeExactList) with the batch-wide variant.
+static int launch_scale_classes(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
+    int rc;
+    hipError_t e;
+    int32_t *hdr = ka.nsel + 3 * ka.b.n_frames + 4;
+    ClassArgs ca;
+    ca.feat_cnt = ka.b.feat_cnt; ca.first_frame = ka.first_frame; ca.n_frames = nl;
+    ca.hdr = hdr; ca.lists = hdr + kClassHeader; ca.stride = ka.b.n_frames; ca.redo = ka.redo;
+    const bool hinted = ka.b.size_hint[3] == kClassHintMagic;
+    const int thr[3] = {kClassThr0, kClassThr1, ka.b.max_feat};
+    scale_kernel_fn fn[3];
+    int waves[3];
+    size_t lds[3];
+    KArgs kc[3];
+    for (int c = 0; c < 3; ++c) {
+        kc[c] = ka;
+        kc[c].b.max_feat = thr[c] < ka.b.max_feat ? thr[c] : ka.b.max_feat;
+        const int n = kc[c].b.max_feat;
+        waves[c] = pick_waves(0, n);
+        lds[c] = lds_plan(n, waves[c]).total;
+        fn[c] = hot_list_kernel(waves[c], n);
+        const int sc = (n <= variant_capacity(waves[c], 4) && waves[c] != 1) ? 4 : 8;
+        if ((rc = check_fit(&kc[c].b, waves[c], sc, lds[c]))) return rc;
+        if ((rc = prepare_kernel(fn[c], lds[c]))) return rc;
+        const int64_t bound = hinted && (int64_t)ka.b.size_hint[c] < nl ? (int64_t)ka.b.size_hint[c] : nl;
+        ca.grid[c] = (int)(bound < 0 ? 0 : bound);
+        kc[c].cls_list = ca.lists + c * ca.stride;
+        kc[c].cls_cnt = hdr + c;
+        kc[c].redo_pass = 0;
+    }
+    if ((e = hipMemsetAsync(hdr, 0, kClassHeader * sizeof(int32_t), ctx_stream(ctx))) != hipSuccess)
+        return set_hip_error("hipMemsetAsync(class lists)", e);
+    if ((e = hipMemsetAsync(ka.redo, 0, sizeof(int32_t), ctx_stream(ctx))) != hipSuccess)
+        return set_hip_error("hipMemsetAsync(redo list)", e);
+    const int cb = kClassifyWaves * kWave;
+    hipLaunchKernelGGL(classify_frames_kernel, dim3((unsigned)((nl + cb - 1) / cb)), dim3(cb), 0, ctx_stream(ctx), ca);
+    if ((rc = check_launch("classify_frames_kernel"))) return rc;
+    for (int c = 2; c >= 0; --c) {              // largest frames first
+        if (c > 0 && thr[c - 1] >= ka.b.max_feat) continue;             // no frame of the batch is that large
+        if (ka.b.min_feat > thr[c] || ca.grid[c] == 0) continue;         // ... or that small
+        hipLaunchKernelGGL(fn[c], dim3((unsigned)ca.grid[c]), dim3(waves[c] * kWave), lds[c], ctx_stream(ctx), kc[c]);
+        if ((rc = check_launch("scale_frames_kernel (size class)"))) return rc;
+    }
+    return MVOSR_OK;
+}
+
 void set_max_dynamic_lds(int bytes) { g_max_dyn_lds = bytes; }
 
 }  // namespace mvosr
@@ -2287,7 +2404,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     KArgs ka;
     ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
     ka.first_frame = first_frame; ka.height_level_in = nullptr; ka.debug_skip = debug_skip_env();
-    ka.redo_pass = 0;
+    ka.redo_pass = 0; ka.cls_list = nullptr; ka.cls_cnt = nullptr;
     if (b->total_feat <= 0) return set_error(MVOSR_ERR_ARG, "scale_batch: batch.total_feat (length of the feature planes) not set");
     if (b->n_frames >= ((int64_t)1 << 31) - 1) return set_error(MVOSR_ERR_TOO_LARGE, "scale_batch: more than 2^31-2 frames in one batch");
     if ((rc = ctx_workspace(ctx, b->n_frames, b->total_feat, &ka.ysel, &ka.nsel))) return rc;
@@ -2315,7 +2432,15 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     hipEvent_t *pev = (ctx->prof_on && ctx->prof_calls < kProfRing) ? ctx->prof_ev[ctx->prof_calls] : nullptr;
     hipError_t ee = hipSuccess;
     if (pev && (ee = hipEventRecord(pev[0], ctx_stream(ctx))) != hipSuccess) return set_hip_error("hipEventRecord(profile)", ee);
-    if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, mode, false) : dispatch_scale(ctx, ka, waves, n_launch, mode))) return rc;
+    // ragged batch: the HOT pass per size class (each class with its own variant and LDS request), then the EXACT pass
+    // over the redo list as usual
+    const bool by_class = mode == MODE_HOT && !dense && waves_per_frame == 0 && n_launch >= kClassMinFrames &&
+                          b->max_feat > kClassThr0 && !(debug_skip_env() & 64) &&
+                          (b->min_feat <= 0 || pick_waves(0, b->min_feat) != waves);
+    if (by_class) {
+        if ((rc = launch_scale_classes(ctx, ka, n_launch))) return rc;
+        if ((rc = dispatch_scale(ctx, ka, waves, n_launch, kModeExactList))) return rc;
+    } else if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, mode, false) : dispatch_scale(ctx, ka, waves, n_launch, mode))) return rc;
     if (pev && (ee = hipEventRecord(pev[1], ctx_stream(ctx))) != hipSuccess) return set_hip_error("hipEventRecord(profile)", ee);
     ra.first_frame = first_frame; ra.n_frames = n_launch;
     if (!(debug_skip_env() & 16)) {
@@ -2342,6 +2467,24 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     return MVOSR_OK;
 }
 
+int mvosr_batch_size_hint(const int32_t *feat_cnt_host, int64_t n_frames, mvosr_batch *b) {
+    if (!b || n_frames < 0 || (n_frames > 0 && !feat_cnt_host)) return set_error(MVOSR_ERR_ARG, "batch_size_hint: null argument");
+    int64_t cnt[3] = {0, 0, 0};
+    int32_t lo = 0, hi = 0;
+    for (int64_t f = 0; f < n_frames; ++f) {
+        const int32_t n = feat_cnt_host[f];
+        if (n < 0) return set_error(MVOSR_ERR_ARG, "batch_size_hint: negative feature count");
+        if (f == 0 || n < lo) lo = n;
+        if (f == 0 || n > hi) hi = n;
+        ++cnt[size_class_of(n)];
+    }
+    b->max_feat = hi;
+    b->min_feat = lo;            // (0 reads as "not stated": a batch with an empty frame is treated as ragged)
+    for (int c = 0; c < 3; ++c) b->size_hint[c] = (int32_t)(cnt[c] > 0x7fffffff ? 0x7fffffff : cnt[c]);
+    b->size_hint[3] = kClassHintMagic;
+    return MVOSR_OK;
+}
+
 int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b, const mvosr_outputs *o,
                              int waves_per_frame) {
     int rc = check_common(ctx, p, b, o);
@@ -2353,6 +2496,7 @@ int mvosr_outlier_vote_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_
     KArgs ka;
     ka.P = *p; ka.b = *b; ka.o = *o; ka.pt = make_pitch_test(p->pitch_threshold_deg);
     ka.first_frame = 0; ka.height_level_in = nullptr; ka.debug_skip = 0; ka.ysel = nullptr; ka.nsel = nullptr; ka.redo = nullptr; ka.redo_pass = 0;
+    ka.cls_list = nullptr; ka.cls_cnt = nullptr;
     if ((waves_per_frame == 0 || waves_per_frame == 16) && b->max_feat > lds_capacity_features()) {
         if (b->total_feat <= 0) return set_error(MVOSR_ERR_ARG, "outlier_vote: batch.total_feat not set");
         return launch_scale_dense(ctx, ka, b->n_frames, MODE_HOT, true);

@@ -29,6 +29,7 @@ class DeviceBatch:
         self.ctx = ctx
         self.n_frames = pf.n_frames
         self.max_feat = pf.max_feat
+        self._feat_cnt_host = np.ascontiguousarray(pf.feat_cnt, dtype=np.int32)
         self.total_padded = pf.total_padded
         self.n_tri1 = int(pf.tri1_off[-1]) if pf.tri1_off is not None else 0
         self.n_tri2 = int(pf.tri2_off[-1]) if (with_tri2 and pf.tri2_off is not None) else 0
@@ -70,6 +71,11 @@ class DeviceBatch:
                                       p("tri1_off"), p("tri1"), p("tri2_off"), p("tri2"), p("n2_expected"),
                                       self.max_feat, self.tri2_ids, self.total_padded,
                                       getattr(self, "tile_w", 0), 0, p("tile_base"), p("tile1_off"), p("tile2_off"))
+            if self.n_frames:               # min_feat + the size classes' counts (ragged batches launch per class)
+                mf = self._struct.max_feat
+                _lib.check(self.ctx.lib.mvosr_batch_size_hint(self._feat_cnt_host.ctypes.data, self.n_frames,
+                                                              C.byref(self._struct)), "mvosr_batch_size_hint")
+                self._struct.max_feat = max(mf, self._struct.max_feat)
         return self._struct
 
     def free(self):

@@ -580,6 +580,73 @@ def test_ragged_batch_and_determinism(gpu):
         assert np.array_equal(res[k], res_b[k], equal_nan=True), k
 
 
+def test_size_class_dispatch(gpu):
+    """A ragged batch of >= 2048 frames in product mode is launched per size class (1 / 4 / 8 wavefronts per frame,
+    each class with its own LDS request): every frame equals the oracle, the whole result equals the single-variant
+    launch bit for bit, frames that need the EXACT pass (nothing selected) and frames the kernel never sweeps
+    (no features) included; a sub-range launch (first_frame / n_launch) classifies only its own frames."""
+    from mvoscalerecovery_amd import packing, synth, constants as K
+    from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs, ScaleEngine
+    rng = np.random.default_rng(5)
+    sizes = [int(v) for v in rng.integers(60, 1500, 44)] + [384, 385, 1024, 1025]
+    frames = [synth.synth_frame(i, n, base_seed=777, upper_fraction=0.05 * (i % 3)) for i, n in enumerate(sizes)]
+    cases = load_json("frame_cases.json")
+    for name in ("wall_none_selected", "all_flat_nan_level", "five_points"):
+        if name in cases:
+            frames.append((np.array(cases[name]["f3"]), np.array(cases[name]["f2"])))
+    ores = _oracle_frames(frames)
+    pool = len(frames)
+    pf_pool = _pack(frames, [r.tri1 for r in ores], [r.tri2 for r in ores], [r.valid for r in ores])
+    repeats = 48
+    pf = packing.tile_frames(pf_pool, repeats)
+    assert pf.n_frames >= 2048 and pf.max_feat > 1024 and int(pf.feat_cnt.min()) <= 384
+    eng = ScaleEngine(1.75, ctx=gpu)
+    db = DeviceBatch(gpu, pf)
+
+    def run(waves, first=0, n=0):
+        out = DeviceOutputs(gpu, db, counts=True)
+        for k in ("raw_scale", "height", "height_level"):
+            out.bufs[k].upload(np.full(pf.n_frames, -7.0))
+        eng.scale_batch(db, out, waves=waves, first=first, count=n)
+        gpu.sync()
+        r = {k: out.get(k) for k in ("raw_scale", "height", "height_level", "status", "counts")}
+        out.free()
+        return r
+
+    by_class = run(0)
+    single = run(8)
+    for k in ("raw_scale", "height", "status", "counts"):
+        assert np.array_equal(by_class[k], single[k], equal_nan=True), k
+    # (product mode: the level is each variant's own fixed-order sum unless it is the result — then it is exact)
+    np.testing.assert_allclose(by_class["height_level"], single["height_level"], rtol=1e-13, equal_nan=True)
+    for f in range(pool):
+        for r in (0, repeats - 1):
+            g = r * pool + f
+            assert by_class["status"][g] == ores[f].status, (f, r)
+            if ores[f].status not in K.ERROR_STATUSES:
+                assert by_class["raw_scale"][g] == ores[f].raw_scale or (np.isnan(by_class["raw_scale"][g]) and np.isnan(ores[f].raw_scale)), (f, r)
+    # the class counts are a hint: without it (every class launched over the whole range) and with one that
+    # understates every class (the overflow goes through the EXACT pass) the results are the same
+    st = db.struct()
+    hint = list(st.size_hint)
+    assert hint[3] != 0 and sum(hint[:3]) == pf.n_frames and int(st.min_feat) == int(pf.feat_cnt.min())
+    for variant in ((0, 0, 0, 0), (hint[0] // 2, hint[1] // 3, 7, hint[3])):
+        for k in range(4):
+            st.size_hint[k] = variant[k]
+        other = run(0)
+        for k in ("raw_scale", "height", "status", "counts"):
+            assert np.array_equal(by_class[k], other[k], equal_nan=True), (variant, k)
+    for k in range(4):
+        st.size_hint[k] = hint[k]
+    # a sub-range: frames outside it keep the sentinel
+    first, n = 3 * pool + 5, 2100
+    part = run(0, first, n)
+    assert np.array_equal(part["raw_scale"][first:first + n], by_class["raw_scale"][first:first + n], equal_nan=True)
+    assert np.array_equal(part["status"][first:first + n], by_class["status"][first:first + n])
+    assert np.all(part["raw_scale"][:first] == -7.0) and np.all(part["raw_scale"][first + n:] == -7.0)
+    db.free()
+
+
 def test_frame_edge_cases(gpu):
     """Frame-level goldens of the reference: nothing selected (std 100), NaN height_level,
     duplicate pixels, five points, mostly-upper frame."""
