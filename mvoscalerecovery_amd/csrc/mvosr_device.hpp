@@ -185,7 +185,12 @@ __device__ __forceinline__ double div3(double x) {
     const double q = x * c;
     const double r = __builtin_fma(-3.0, q, x);
     double res = __builtin_fma(r, c, q);
-    if (!((ax > 0x1p-900) & (ax < 0x1p900))) res = x / 3.0;      // rare: one skipped region, no else-part
+    if (!((ax > 0x1p-900) & (ax < 0x1p900))) {
+        // rare, and it has to stay a skipped region: without the asm the compiler evaluates the division for every
+        // triangle and selects (some 17 instructions more per row, one of them a quarter-rate v_rcp_f64)
+        asm volatile("" : "+v"(x));
+        res = x / 3.0;
+    }
     return res;
 }
 
