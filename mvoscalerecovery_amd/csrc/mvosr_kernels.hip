@@ -573,7 +573,10 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     const double2 p0 = s.P[q.a], p1 = s.P[q.b], p2 = s.P[q.c];      // {x, z'}
     const double y0 = s.Y[q.a], y1 = s.Y[q.b], y2 = s.Y[q.c];
     const double x0 = p0.x, z0 = p0.y, x1 = p1.x, z1 = p1.y, x2 = p2.x, z2 = p2.y;
-    const double h = div3((y0 + y1) + y2);                                               // :238
+    // :238.  The product path works on 3h = (y0+y1)+y2: its level is only trusted outside the guard band anyway (a frame
+    // with a flat triangle inside it is redone in the EXACT variant), which is ~10^4 roundings wide — so the division
+    // by 3 per triangle, and its rounding, are left out of both sweeps.
+    const double h = MODE == MODE_HOT ? (y0 + y1) + y2 : div3((y0 + y1) + y2);
     const int r = classify_triangle<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, h, pt, g_normals, g_pitch, g_heights, t2_begin + t);
     const bool is_flat = r & 1, is_steep = r & 2;
     if (r & 4) singular = 1;
@@ -605,7 +608,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     block_sum2<WAVES>(hsum, hcnt, s.red + R_SEL_H * 2 * WAVES);
     MVOSR_STAMP(4);
     SelectResult r;
-    double hl = hsum / hcnt;                      // np.mean of an empty set -> 0/0 = NaN, like :240
+    double hl = hsum / hcnt;                      // np.mean of an empty set -> 0/0 = NaN, like :240.  (HOT: the mean of 3h)
     if constexpr (MODE != MODE_HOT)
         hl = exact_height_level<FULL>(tri2 + 3 * t2_begin, t2_count, (int)hcnt, pt, LdsFetch{s.P, s.Y, n_valid});
     int ntv = 0, near = 0;
@@ -613,7 +616,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
         const unsigned long long fw = (FW == 1 || kk < 64) ? flat : flat_hi;
         if (!((fw >> (kk & 63)) & 1ull)) return;
         const double y0 = s.Y[qa], y1 = s.Y[qb], y2 = s.Y[qc];
-        const double h = div3((y0 + y1) + y2);
+        const double h = MODE == MODE_HOT ? (y0 + y1) + y2 : div3((y0 + y1) + y2);           // HOT: 3h against 3 * level
         if constexpr (MODE == MODE_HOT) { if (fabs(h - hl) <= kLevelGuard * fabs(hl)) near = 1; }
         if (h > hl) {                                                                        // :243-244
             ++ntv;
@@ -637,7 +640,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     singular = sn & 0xFFFF;
     r.near = sn >> 16;
     MVOSR_STAMP(5);
-    r.height_level = hl;
+    r.height_level = MODE == MODE_HOT ? hl / 3.0 : hl;
     r.n_steep = (int)hcnt;
     r.n_pitch = npitch; r.n_tri_valid = ntv; r.singular = singular; r.bad = bad;
     return r;
