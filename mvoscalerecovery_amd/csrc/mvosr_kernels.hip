@@ -1713,7 +1713,7 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
         if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
         const double ya = gy[q.a], za = gz[q.a], yb = gy[q.b], zb = gz[q.b], yc = gy[q.c], zc = gz[q.c];
         const double y0 = ya * cp - za * sp, y1 = yb * cp - zb * sp, y2 = yc * cp - zc * sp;
-        const double h = div3((y0 + y1) + y2);                                               // :238
+        const double h = (y0 + y1) + y2;                                                     // :238 — 3h, like every height of this kernel
         const int r = classify_triangle<false>(gx[q.a], y0, ya * sp + za * cp, gx[q.b], y1, yb * sp + zb * cp,
                                                gx[q.c], y2, yc * sp + zc * cp, h, a.pt, nullptr, nullptr, nullptr, 0);
         if (r & 4) singular = 1;
@@ -1814,7 +1814,9 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
             const double2 a0 = ringA[q.a & M], a1 = ringA[q.b & M], a2 = ringA[q.c & M];
             const double2 g0_ = ringB[q.a & M], g1_ = ringB[q.b & M], g2_ = ringB[q.c & M];
             used[q.a & M] = 1; used[q.b & M] = 1; used[q.c & M] = 1;        // (every writer stores the same value)
-            const double h = div3((g0_.y + g1_.y) + g2_.y);                                      // :238
+            // :238.  3h instead of h: the keys, their maxima and the level all scale by three, the comparisons of the tail are
+            // the same outside the guard band (as in the LDS-resident product kernel), and no triangle pays the division
+            const double h = (g0_.y + g1_.y) + g2_.y;
             const int r = classify_triangle<false>(g0_.x, g0_.y, a0.y, g1_.x, g1_.y, a1.y, g2_.x, g2_.y, a2.y, h, a.pt,
                                                    nullptr, nullptr, nullptr, 0);
             if (r & 4) singular = 1;
@@ -1873,7 +1875,7 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
         nvalid = nv; singular = sb & 0xFF; bad = (sb >> 8) & 0xFF; overflow = sb >> 16;
     }
     MVOSR_TSTAMP(7);
-    const double hl = hsum / hcnt;                    // np.mean of an empty set -> 0/0 = NaN, like :240
+    const double hl = hsum / hcnt;                    // np.mean of an empty set -> 0/0 = NaN, like :240  (three times the level)
     const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
     int status = kStPending;
     double raw = nan("");
@@ -1948,7 +1950,7 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
     if (tid == 0) {
         a.o.raw_scale[f] = raw;
         a.o.height[f] = nan("");
-        a.o.height_level[f] = hl;
+        a.o.height_level[f] = hl / 3.0;
         a.o.status[f] = status;
         a.nsel[f] = nsel;
         R.n_sel = nsel;
