@@ -362,6 +362,8 @@ def main():
     gpu_raw = rec.raw[:pool_n].cpu().numpy()
     gpu_status = rec.status[:pool_n].cpu().numpy()
     st_all = rec.status.cpu().numpy()
+    import zlib
+    raw_crc = zlib.crc32(rec.raw.cpu().numpy().tobytes())       # same workload => same number, whatever the build
 
     if rank == 0:
         value = total_frames * args.steps / elapsed
@@ -406,6 +408,7 @@ def main():
                          "road_model_kernel_ms_avg": road_ms_avg, "step_kernels_ms_avg": step_ms_avg,
                          "step_achieved": bytes_per_launch / (step_ms_avg * 1e-3) / 1e9,
                          "step_frac": bytes_per_launch / (step_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "raw_scale_crc32": raw_crc,
             "status_histogram": {str(k): int(v) for k, v in zip(*np.unique(st_all, return_counts=True))},
             "host_delaunay_cpu_ms_per_frame": delaunay_cpu_s * 1e3,
         }

@@ -188,6 +188,15 @@ def _shm_attach(path, keep):
 def shutdown_pool():
     global _pool, _pool_size
     if _pool is not None:
+        # let the workers leave by themselves (close = "no more jobs"): a SIGTERM is caught by signal handlers a
+        # preloaded tool may have installed in the forked workers (rocprofv3 then "finalizes" in a process that never
+        # touched the GPU and can hang); terminate() only for workers still there after a grace period
+        try:
+            _pool.close()
+            for p in list(getattr(_pool, "_pool", [])):
+                p.join(2.0)
+        except Exception:
+            pass
         _pool.terminate()
         _pool, _pool_size = None, 0
     for role in list(_shm):

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 cd /tmp
 OUT=$R/gpurun_out
 mkdir -p $OUT
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o bench -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e "$@" > $OUT/${TAG}_stats.log 2>&1
+timeout 90 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o bench -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e "$@" > $OUT/${TAG}_stats.log 2>&1
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" \
            "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B" \
@@ -22,7 +22,7 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAVES" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/${TAG}_pmc$i -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e "$@" > $OUT/${TAG}_pmc$i.log 2>&1
+  timeout 90 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/${TAG}_pmc$i -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e "$@" > $OUT/${TAG}_pmc$i.log 2>&1
 done
 grep -h '^{' $OUT/${TAG}_stats.log > $OUT/${TAG}_bench_under_rocprof.json
 ls $OUT

@@ -4,6 +4,10 @@ summaries: profiles/<tag>_kernel_stats.csv (verbatim --stats table), profiles/<t
 and profiles/traffic.json (HBM bytes per frame of the fused kernel, read by bench.py).
 
     python profiles/summarize.py r01 [--kernel scale_frames_kernel] [--frames 16384] [--features 2000]
+
+--kernel takes a ";"-separated list of name fragments: the dominant stage of a ragged batch is three launches (one per
+size class); their averages and per-dispatch counter medians are added up.  --entry NAME merges the traffic figure into
+profiles/traffic.json's "entries" under that key (what bench.py looks up) instead of writing a one-entry file.
 """
 import argparse
 import csv
@@ -24,12 +28,14 @@ def main():
     ap.add_argument("--frames", type=int, default=16384)
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--traffic-name", default="traffic.json")
+    ap.add_argument("--entry", default="")
     a = ap.parse_args()
+    kernels = [k for k in a.kernel.split(";") if k]
     out = os.path.join(ROOT, "gpurun_out")
     stats = os.path.join(out, a.tag + "_stats", "bench_kernel_stats.csv")
     shutil.copy(stats, os.path.join(HERE, a.tag + "_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
-    krow = [r for r in rows if a.kernel in r["Name"]][0]
+    krows = [[r for r in rows if k in r["Name"]][0] for k in kernels]
     bench = json.loads(open(os.path.join(out, a.tag + "_bench_under_rocprof.json")).read().strip().splitlines()[-1])
     counters, road = {}, {}
     for d in sorted(glob.glob(os.path.join(out, a.tag + "_pmc*"))):
@@ -37,11 +43,12 @@ def main():
         if not os.path.isfile(f):
             continue
         for r in csv.DictReader(open(f)):
-            if a.kernel in r["Kernel_Name"]:
-                counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for k in kernels:
+                if k in r["Kernel_Name"]:
+                    counters.setdefault(r["Counter_Name"], {}).setdefault(k, []).append(float(r["Counter_Value"]))
             if "road_model_kernel" in r["Kernel_Name"]:
                 road.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    med = {k: statistics.median(v) for k, v in counters.items()}
+    med = {c: sum(statistics.median(v) for v in per.values()) for c, per in counters.items()}
     road = {k: statistics.median(v) for k, v in road.items()}
     F = int(bench.get("config", {}).get("frames_per_step_per_gpu", a.frames))
     lines = ["# rocprofv3 summary %s — `python bench.py` (N=1, %d frames x %d features per launch)" % (a.tag, F, a.features), ""]
@@ -49,7 +56,7 @@ def main():
               "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
     for r in rows:
         lines.append("| `%s` | %s | %.0f | %s | %s | %s |" % (r["Name"], r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"], r["Percentage"]))
-    avg_ms = float(krow["AverageNs"]) / 1e6
+    avg_ms = sum(float(r["AverageNs"]) for r in krows) / 1e6
     lines += ["", "bench.py in the same run (HIP events on the launch stream): kernel_ms_avg = %.4f ms; rocprof average = %.4f ms."
               % (bench["roofline"]["kernel_ms_avg"], avg_ms),
               "roofline: achieved %.1f GB/s algorithmic = %.3f of the 8 TB/s HBM peak; %.2f M frames/s."
@@ -89,7 +96,15 @@ def main():
                   % (med.get("SQ_ACTIVE_INST_ANY", 0) / wc, med.get("SQ_WAIT_ANY", 0) / wc, med.get("SQ_WAIT_INST_ANY", 0) / wc,
                      med.get("SQ_ACTIVE_INST_VALU", 0) / wc, med.get("SQ_ACTIVE_INST_LDS", 0) / wc)]
     open(os.path.join(HERE, a.tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
-    if traffic is not None:
+    if traffic is not None and a.entry:
+        path = os.path.join(HERE, a.traffic_name)
+        doc = json.load(open(path)) if os.path.isfile(path) else {}
+        doc.setdefault("entries", {})[a.entry] = {
+            "tag": a.tag, "frames": F, "features": a.features, "hbm_bytes_per_launch": traffic, "hbm_bytes_per_frame": traffic / F,
+            "fetch_size_kib": med["FETCH_SIZE"], "write_size_kib": med["WRITE_SIZE"], "kernels": kernels,
+            "method": "2*FETCH_SIZE+WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section), separate --pmc passes"}
+        json.dump(doc, open(path, "w"), indent=1)
+    elif traffic is not None:
         json.dump({"tag": a.tag, "frames": F, "features": a.features, "hbm_bytes_per_launch": traffic,
                    "hbm_bytes_per_frame": traffic / F, "fetch_size_kib": med["FETCH_SIZE"], "write_size_kib": med["WRITE_SIZE"],
                    "method": "2*FETCH_SIZE+WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section), separate --pmc passes"},
