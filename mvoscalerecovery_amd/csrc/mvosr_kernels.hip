@@ -1065,12 +1065,14 @@ __device__ __forceinline__ void write_counts(const KArgs &a, int64_t f, int nval
 // quantity, resolved by the host's push step from the MVOSR_ST_TOO_FEW status.
 __device__ __forceinline__ bool early_frame_exit(const KArgs &a, int64_t f, int n, int t2n) {
     const bool too_few = n >= 1 && n <= 3;
-    if (!(n <= 0 || too_few || t2n <= 0)) return false;
+    // a frame larger than the batch header says (max_feat sized this launch's LDS and variant): refused, not processed
+    const bool oversize = n > a.b.max_feat;
+    if (!(n <= 0 || too_few || t2n <= 0 || oversize)) return false;
     if (threadIdx.x == 0) {
         RoadResult R;
         R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
         a.o.raw_scale[f] = nan(""); a.o.height[f] = nan(""); a.o.height_level[f] = nan("");
-        a.o.status[f] = too_few ? MVOSR_ST_TOO_FEW : MVOSR_ST_ERR_EMPTY;
+        a.o.status[f] = oversize ? MVOSR_ST_ERR_MASK : (too_few ? MVOSR_ST_TOO_FEW : MVOSR_ST_ERR_EMPTY);
         a.nsel[f] = 0;
         write_counts(a, f, too_few ? n : 0, 0, 0, R);
     }

@@ -749,6 +749,31 @@ def test_row_count_guards(gpu):
         assert st[0] == base[0] and st[1] == K.ST_ERR_MASK and st[2] == K.ST_ERR_MASK, (stage, st)
 
 
+def test_frame_larger_than_batch_header(gpu):
+    """mvosr_batch.max_feat sizes the launch's LDS and picks its variant: a frame with more features than it states
+    (possible only through the C ABI, where the counts live in device memory) is refused with MVOSR_ST_ERR_MASK —
+    the frames around it are processed as usual."""
+    from mvoscalerecovery_amd import synth, constants as K
+    from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs, ScaleEngine
+    frames = [synth.synth_frame(i, n, base_seed=99) for i, n in enumerate((300, 700, 350))]
+    ores = _oracle_frames(frames)
+    pf = _pack(frames, [r.tri1 for r in ores], [r.tri2 for r in ores], [r.valid for r in ores])
+    eng = ScaleEngine(1.75, ctx=gpu)
+    db = DeviceBatch(gpu, pf)
+    st = db.struct()
+    st.max_feat = 400
+    for k in range(4):
+        st.size_hint[k] = 0
+    out = DeviceOutputs(gpu, db, counts=True)
+    eng.scale_batch(db, out)
+    gpu.sync()
+    status, raw = out.get("status"), out.get("raw_scale")
+    out.free(); db.free()
+    assert status[1] == K.ST_ERR_MASK and np.isnan(raw[1])
+    for f in (0, 2):
+        assert status[f] == ores[f].status and raw[f] == ores[f].raw_scale, f
+
+
 def test_dense_fan_vote_counter_range(gpu):
     """A fan: one centre vertex in every row.  With 30000 rows its 16-bit counter holds the exact vote; with 40000 it
     would wrap into the neighbouring feature's half — the dense vote sees the update that crosses the end and flags
