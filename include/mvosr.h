@@ -117,7 +117,8 @@ typedef struct mvosr_batch {
                                     ids index the features that survive the vote, in order     */
     const int32_t *n2_expected;  /* [F] or NULL: number of points tri2 was built on; a frame whose
                                     vote keeps a different number gets MVOSR_ST_ERR_MASK        */
-    int32_t max_feat;            /* max(feat_cnt) — sizes the LDS request                      */
+    int32_t max_feat;            /* max(feat_cnt) — sizes the LDS request; a frame with more
+                                    features than this gets MVOSR_ST_ERR_MASK                  */
     int32_t tri2_ids;            /* MVOSR_TRI2_SURVIVORS (0): tri2 as SciPy returns it, ids index the survivors;
                                     MVOSR_TRI2_FEATURES (1): the same rows relabelled to index the frame's features
                                     (every vertex a survivor, else MVOSR_ST_ERR_MASK) — the frames then run the
@@ -221,7 +222,7 @@ void mvosr_default_params(mvosr_params *p, double absolute_reference);
  * y' as a dense list in the context's workspace, and the road-model kernel (one WAVEFRONT per
  * frame, no LDS-resident frame, full occupancy) turns each list into height / scale / status.
  * `waves_per_frame` selects the scale kernel's variant: 0 = choose from max_feat (measured crossovers:
- * 1 up to 384 features, 4 up to 1024, 8 while two workgroups fit a CU's LDS — about 3000 —, 16 above),
+ * 1 up to 320 features, 4 up to 1152, 8 while two workgroups fit a CU's LDS — about 3000 —, 16 above),
  * 1 = one wavefront per frame (<= 512 features), 4/8/16 = one workgroup of that many wavefronts.  With 0, a batch
  * of at least 2048 frames whose sizes span more than one of those ranges (b->min_feat) is split on the device into
  * its size classes, one launch per class over the class's frame list (results do not depend on the variant).

@@ -2090,7 +2090,8 @@ static int debug_skip_env() {
 // Size classes of a ragged batch (the crossovers of pick_waves): the frames of a launch are split into up to three
 // lists, and every list is launched with the variant and the LDS request of its own largest possible frame.
 constexpr int kClassHeader = 4;                // cnt[3] | pad
-constexpr int kClassThr0 = 384, kClassThr1 = 1024;
+constexpr int kWaves1Max = 320, kWaves4Max = 1152;      // pick_waves' crossovers
+constexpr int kClassThr0 = kWaves1Max, kClassThr1 = 1024;   // (the 4-wavefront class stops where its SC = 4 instantiation does)
 constexpr int64_t kClassMinFrames = 2048;      // below: one launch (three short grids would cost more than they save)
 constexpr int32_t kClassHintMagic = 0x4d56;    // mvosr_batch.size_hint[3] when mvosr_batch_size_hint filled it
 constexpr int kClassifyWaves = 16;
@@ -2141,10 +2142,12 @@ __global__ __launch_bounds__(kClassifyWaves *kWave) void classify_frames_kernel(
 // than any frame that fits LDS.
 static int pick_waves(int requested, int max_feat) {
     if (requested == 1 || requested == 4 || requested == 8 || requested == 16) return requested;
-    // measured crossovers (frames/s at 256 ... 4096 features per frame): 1 wave up to 384, 4 up to 1024, 8 as
-    // long as two workgroups fit a CU's LDS (about 3000 features: 0.49 of the HBM peak against 0.37 with 16), 16 above
-    if (max_feat <= 384) return 1;
-    if (max_feat <= 1024) return 4;
+    // measured crossovers (frames/s at 256 ... 4096 features per frame, re-measured after the round-2 kernel changes):
+    // 1 wave up to 320 (256: 0.51 of the HBM peak against 0.44 with 4; 384: 0.46 against 0.50), 4 up to 1152 (1024: 0.57
+    // against 0.51 with 8; 1280: 0.50 against 0.52), 8 as long as two workgroups fit a CU's LDS (about 3000 features:
+    // 0.49 against 0.37 with 16), 16 above
+    if (max_feat <= kWaves1Max) return 1;
+    if (max_feat <= kWaves4Max) return 4;
     if (max_feat <= 2048 || 2 * (int64_t)lds_plan(max_feat, 8).total <= (int64_t)g_max_dyn_lds) return 8;
     return 16;
 }

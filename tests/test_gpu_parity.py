@@ -588,7 +588,7 @@ def test_size_class_dispatch(gpu):
     from mvoscalerecovery_amd import packing, synth, constants as K
     from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs, ScaleEngine
     rng = np.random.default_rng(5)
-    sizes = [int(v) for v in rng.integers(60, 1500, 44)] + [384, 385, 1024, 1025]
+    sizes = [int(v) for v in rng.integers(60, 1500, 44)] + [320, 321, 1024, 1025]
     frames = [synth.synth_frame(i, n, base_seed=777, upper_fraction=0.05 * (i % 3)) for i, n in enumerate(sizes)]
     cases = load_json("frame_cases.json")
     for name in ("wall_none_selected", "all_flat_nan_level", "five_points"):
@@ -599,7 +599,7 @@ def test_size_class_dispatch(gpu):
     pf_pool = _pack(frames, [r.tri1 for r in ores], [r.tri2 for r in ores], [r.valid for r in ores])
     repeats = 48
     pf = packing.tile_frames(pf_pool, repeats)
-    assert pf.n_frames >= 2048 and pf.max_feat > 1024 and int(pf.feat_cnt.min()) <= 384
+    assert pf.n_frames >= 2048 and pf.max_feat > 1024 and int(pf.feat_cnt.min()) <= 320
     eng = ScaleEngine(1.75, ctx=gpu)
     db = DeviceBatch(gpu, pf)
 
