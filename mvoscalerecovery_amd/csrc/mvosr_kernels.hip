@@ -1167,9 +1167,12 @@ __device__ __forceinline__ void for_frames(const KArgs &a, Body body) {
 #ifndef MVOSR_MINW
 #define MVOSR_MINW 1
 #endif
+#ifndef MVOSR_HOTW
+#define MVOSR_HOTW 6
+#endif
 // (the 8-wavefront product variants must stay within 80 VGPRs: three workgroups per CU are six wavefronts per SIMD)
 template <int WAVES, int SC, int MODE, bool LIST = false>
-__global__ __launch_bounds__(WAVES *kWave, (WAVES == 8 && MODE == MODE_HOT ? 6 : MVOSR_MINW)) void scale_frames_kernel(const KArgs a) {
+__global__ __launch_bounds__(WAVES *kWave, (WAVES == 8 && MODE == MODE_HOT ? MVOSR_HOTW : MVOSR_MINW)) void scale_frames_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     for_frames<MODE, LIST>(a, [&](const int64_t f) {
     constexpr int B = WAVES * kWave;
