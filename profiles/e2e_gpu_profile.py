@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Where the host time of the drop-in batch call goes with triangulation="gpu" (cProfile, cumulative):
+    python profiles/e2e_gpu_profile.py [frames] [features]"""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvoscalerecovery_amd import synth
+from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+frames = [synth.synth_frame(i, N, base_seed=2024) for i in range(F)]
+f3, f2 = [f[0] for f in frames], [f[1] for f in frames]
+est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+est.scale_calculation_batch(f3[:64], f2[:64])
+t0 = time.perf_counter()
+pr = cProfile.Profile()
+pr.enable()
+s, e = est.scale_calculation_batch(f3, f2)
+pr.disable()
+dt = time.perf_counter() - t0
+print("triangulation=gpu N=%d frames=%d: %.0f frames/s (%.3f ms/frame)" % (N, F, F / dt, 1e3 * dt / F))
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
