@@ -128,7 +128,7 @@ def build_pool(ctx, engine, sizes, seed):
     t0 = time.perf_counter()
     packing.attach_tri2(pf, None, masks, None, feature_ids=dense)    # dense: rows numbered over the features (no compaction)
     t_del2 = time.perf_counter() - t0
-    workers = packing.resolve_workers(None)
+    workers = max(1, packing.resolve_workers(None))
     return frames, pf, masks, (t_del1 + t_del2) * workers / pool       # CPU-seconds of Delaunay per frame
 
 
@@ -220,6 +220,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="dry run: more ranks than GPUs (gloo, devices shared round-robin)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tiles", action="store_true", help="diagnostic: dense frames without the tile index (the two-sweep gather kernel)")
+    ap.add_argument("--no-far-table", action="store_true", help="diagnostic: dense frames without the far rows' vertex table (the kernel gathers)")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--alias-pool", action="store_true",
                     help="diagnostic: every tile reads the feature planes of the SAME pool frames (cache-resident: 41 %% "
@@ -301,6 +302,10 @@ def main():
         bstruct.tile_base = offs("tile_base", pf_pool.tile_base[:-1], nt, True)
         bstruct.tile1_off = rep("tile1_off", pf_pool.tile1_off, np.int32)
         bstruct.tile2_off = rep("tile2_off", pf_pool.tile2_off, np.int32)
+        if pf_pool.tile_far is not None and not args.no_far_table:
+            nf = int(pf_pool.tile_far_off[-1])
+            bstruct.tile_far = rep("tile_far", pf_pool.tile_far[:max(nf, 1)], np.float64)
+            bstruct.tile_far_off = offs("tile_far_off", pf_pool.tile_far_off[:-1], nf, True)
     bytes_per_launch = pf_pool.algorithmic_bytes() * repeats
     n_mean = float(pf_pool.feat_cnt.mean())
     t1_mean = float(pf_pool.tri1_off[-1]) / pool_n

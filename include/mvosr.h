@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MVOSR_ABI_VERSION 4
+#define MVOSR_ABI_VERSION 5
 
 /* error codes (function return values) */
 enum mvosr_err {
@@ -148,6 +148,15 @@ typedef struct mvosr_batch {
                                     feat_cnt (how many frames each size class holds), so that the per-class launches
                                     of a ragged batch are exactly as long as their lists; without it every class is
                                     launched over n_launch workgroups, most of which leave at once                  */
+    /* Optional companion of the tile index (NULL: the kernel gathers instead): the far rows' vertices, copied out of
+     * the planes by the packer so that the kernel reads them as one contiguous block per frame instead of a 128-byte
+     * line per 8-byte element.  Per frame f, tile_far_off[f+1] - tile_far_off[f] = 9 * (far rows of tri1 + far rows of
+     * tri2) doubles starting at tile_far[tile_far_off[f]]: first every far row of tri1 in row order as (y, z, v) of
+     * its three vertices, then every far row of tri2 as (x, y, z) of its three vertices — the values of the planes,
+     * verbatim (raw, before the remap).  A block of the wrong length gives MVOSR_ST_ERR_MASK; the VALUES cannot be
+     * checked by the kernel: they are the caller's copy of its own planes. */
+    const double *tile_far;
+    const int64_t *tile_far_off; /* [F+1] */
 } mvosr_batch;
 
 #define MVOSR_TILE_W 512

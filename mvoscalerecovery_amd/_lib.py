@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 LIB_PATH = os.environ.get("MVOSR_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")   # (override: A/B builds in profiles/)
-ABI_VERSION = 4
+ABI_VERSION = 5
 TRI2_SURVIVORS, TRI2_FEATURES = 0, 1      # mvosr_batch.tri2_ids
 N_COUNTS = 8
 TILE_W = 512                              # MVOSR_TILE_W
@@ -36,7 +36,8 @@ class Batch(C.Structure):
                 ("n2_expected", C.c_void_p), ("max_feat", C.c_int32), ("tri2_ids", C.c_int32),
                 ("total_feat", C.c_int64),
                 ("tile_w", C.c_int32), ("min_feat", C.c_int32), ("tile_base", C.c_void_p),
-                ("tile1_off", C.c_void_p), ("tile2_off", C.c_void_p), ("size_hint", C.c_int32 * 4)]
+                ("tile1_off", C.c_void_p), ("tile2_off", C.c_void_p), ("size_hint", C.c_int32 * 4),
+                ("tile_far", C.c_void_p), ("tile_far_off", C.c_void_p)]
 
 
 class Outputs(C.Structure):

@@ -1557,7 +1557,7 @@ constexpr int kTileRows = MVOSR_TILE_ROWS;  // rows per thread and triangulation
 constexpr int kSubC = MVOSR_TILED_SUBC;     // vote counters per ring vertex (a lane adds to counter lane % kSubC): rows are sorted by smallest vertex, so the
                                             // lanes of one LDS atomic name the same vertices again and again, and updates of one word are serialised
 
-struct TiledPlan { uint32_t ringA, ringB, ringH, ringC, used, pendV, pendH, gcount, toff, red, misc, total; };
+struct TiledPlan { uint32_t ringA, ringB, ringH, ringC, used, pendV, pendH, toff, red, misc, total; };
 __host__ __device__ inline TiledPlan tiled_plan(int n, int waves) {
     TiledPlan p;
     const uint32_t ntiles = (uint32_t)((n + kTileW - 1) / kTileW);
@@ -1568,8 +1568,7 @@ __host__ __device__ inline TiledPlan tiled_plan(int n, int waves) {
     p.used = p.ringC + 4u * 2u * kTileW * kSubC;                 // uint8 "a tri2 row names this vertex" x 2 tiles
     p.pendV = align16(p.used + 2u * kTileW);                     // {vertex, +-1}
     p.pendH = p.pendV + 8u * kPendCap;                           // {vertex, -, key64}
-    p.gcount = p.pendH + 16u * kPendCap;                         // candidates per group of 64 features (uint8)
-    p.toff = align16(p.gcount + (uint32_t)((n + 63) / 64) + 16u); // the frame's tile index: 2 x (ntiles + 1) ints
+    p.toff = align16(p.pendH + 16u * kPendCap);                   // the frame's tile index: 2 x (ntiles + 1) ints
     p.red = align16(p.toff + 8u * (ntiles + 2u));
     p.misc = p.red + 8u * (uint32_t)(kRedSlots * 2 * waves);
     p.total = p.misc + 4u * 64u;
@@ -1610,7 +1609,6 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
     uint8_t *used = reinterpret_cast<uint8_t *>(smem + pl.used);
     int2 *pendV = reinterpret_cast<int2 *>(smem + pl.pendV);
     ulonglong2 *pendH = reinterpret_cast<ulonglong2 *>(smem + pl.pendH);
-    uint8_t *gcount = reinterpret_cast<uint8_t *>(smem + pl.gcount);
     int *toff1 = reinterpret_cast<int *>(smem + pl.toff);
     double *red = reinterpret_cast<double *>(smem + pl.red);
     int *misc = reinterpret_cast<int *>(smem + pl.misc);
@@ -1694,14 +1692,29 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
     // ---- far rows first: the few rows (about 2 per thousand) whose vertices are not within two tiles of each other.
     // All three vertices come from the caller's planes (one batch of gathers per frame instead of a stall in every
     // step), and what the row contributes to them waits in the pending lists until their tiles are in the ring.
+    // With the packer's far table (mvosr_batch.tile_far) the vertices are one contiguous block per frame, 72 bytes per
+    // row; without it they are gathered from the planes (a 128-byte line per element).
     const int far1 = toff1[ntiles], far2 = toff2[ntiles];
+    const double *fart = nullptr;
+    if (a.b.tile_far && a.b.tile_far_off) {
+        const int64_t fb = a.b.tile_far_off[f];
+        if (a.b.tile_far_off[f + 1] - fb != 9 * ((int64_t)(t1n - far1) + (int64_t)(t2n - far2))) bad = 1;     // (uniform: all threads see it)
+        else fart = a.b.tile_far + fb;
+    }
     for (int t = far1 + tid; t < t1n; t += B) {
         const TriIds q = load_tri(rows1, t);
         if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
         double2 p0, p1, p2;
-        p0.x = gv[q.a]; p0.y = gy[q.a] * sp + gz[q.a] * cp;
-        p1.x = gv[q.b]; p1.y = gy[q.b] * sp + gz[q.b] * cp;
-        p2.x = gv[q.c]; p2.y = gy[q.c] * sp + gz[q.c] * cp;
+        if (fart) {
+            const double *r = fart + 9 * (t - far1);                 // (y, z, v) x 3
+            p0.x = r[2]; p0.y = r[0] * sp + r[1] * cp;
+            p1.x = r[5]; p1.y = r[3] * sp + r[4] * cp;
+            p2.x = r[8]; p2.y = r[6] * sp + r[7] * cp;
+        } else {
+            p0.x = gv[q.a]; p0.y = gy[q.a] * sp + gz[q.a] * cp;
+            p1.x = gv[q.b]; p1.y = gy[q.b] * sp + gz[q.b] * cp;
+            p2.x = gv[q.c]; p2.y = gy[q.c] * sp + gz[q.c] * cp;
+        }
         const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
         const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
         const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
@@ -1716,11 +1729,17 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
     for (int t = far2 + tid; t < t2n; t += B) {
         const TriIds q = load_tri(rows2, t);
         if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) { bad = 1; continue; }
-        const double ya = gy[q.a], za = gz[q.a], yb = gy[q.b], zb = gz[q.b], yc = gy[q.c], zc = gz[q.c];
+        double xa, ya, za, xb, yb, zb, xc, yc, zc;
+        if (fart) {
+            const double *r = fart + 9 * ((t1n - far1) + (t - far2));    // (x, y, z) x 3
+            xa = r[0]; ya = r[1]; za = r[2]; xb = r[3]; yb = r[4]; zb = r[5]; xc = r[6]; yc = r[7]; zc = r[8];
+        } else {
+            xa = gx[q.a]; ya = gy[q.a]; za = gz[q.a]; xb = gx[q.b]; yb = gy[q.b]; zb = gz[q.b]; xc = gx[q.c]; yc = gy[q.c]; zc = gz[q.c];
+        }
         const double y0 = ya * cp - za * sp, y1 = yb * cp - zb * sp, y2 = yc * cp - zc * sp;
         const double h = (y0 + y1) + y2;                                                     // :238 — 3h, like every height of this kernel
-        const int r = classify_triangle<false>(gx[q.a], y0, ya * sp + za * cp, gx[q.b], y1, yb * sp + zb * cp,
-                                               gx[q.c], y2, yc * sp + zc * cp, h, a.pt, nullptr, nullptr, nullptr, 0);
+        const int r = classify_triangle<false>(xa, y0, ya * sp + za * cp, xb, y1, yb * sp + zb * cp,
+                                               xc, y2, yc * sp + zc * cp, h, a.pt, nullptr, nullptr, nullptr, 0);
         if (r & 4) singular = 1;
         if (r & 2) { hsum += h; hcnt += 1.0; }                                               // :240
         if (r & 1) ++npitch;
@@ -1748,9 +1767,11 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
     MVOSR_TSTAMP(1);
 
     const int32_t *rows1c = t1n > 0 ? rows1 : rows2;   // (an empty first triangulation: any readable row will do for the clamped loads)
-    const int last1 = max(t1n, 1) - 1, last2 = t2n - 1;
     TriIds n1[kTileRows], n2[kTileRows];              // this thread's first rows of the coming step, in flight
+    // (clamped to the tile's OWN last row: a slot beyond it re-reads that row's line instead of pulling in rows of the
+    // next tile, which the next step would fetch a second time — tri2 has ~830 rows per tile against 1024 slots)
     auto prefetch_rows = [&](int k) {
+        const int last1 = max(min(toff1[k + 1], max(t1n, 1)) - 1, 0), last2 = max(min(toff2[k + 1], t2n) - 1, 0);
 #pragma unroll
         for (int j = 0; j < kTileRows; ++j) {
             n1[j] = load_tri(rows1c, min(toff1[k] + j * B + rid, last1));
@@ -1758,7 +1779,17 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
         }
     };
     prefetch_rows(0);
-    double *cand_h = reinterpret_cast<double *>(da.ws.P2 + off), *cand_y = cand_h + ((n + 1) & ~1);     // candidates' largest flat height / y'
+    // Candidates' largest flat height / y': two planes of n doubles in the workspace.  Wavefront w retires the 64-feature
+    // groups g = w (mod DW) of every tile and APPENDS their candidates to its own dense list (capacity = the features it
+    // retires, so the lists tile the planes exactly): the tail then reads candidates only, not group slots — the planes
+    // were read in full before, 320 KB per 20000-feature frame for the third of the slots that held something.
+    double *cand_h = reinterpret_cast<double *>(da.ws.P2 + off), *cand_y = cand_h + ((n + 1) & ~1);
+    int cand_base = 0, cand_cnt = 0;                   // my wavefront's list: where it starts, how many entries (wave-uniform)
+    {
+        const int nfull = n >> 6, rem = n & 63;
+        for (int ww = 0; ww < w; ++ww)
+            cand_base += 64 * (nfull > ww ? (nfull - 1 - ww) / DW + 1 : 0) + ((rem && (nfull % DW) == ww) ? rem : 0);
+    }
 
     // ---- the walk over the tiles
     for (int k = 0; k < ntiles; ++k) {
@@ -1859,8 +1890,8 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
             }
             nvalid += __popcll(__ballot(survivor));
             const unsigned long long mc = __ballot(is_cand);
-            if (is_cand) { const int at = (i & ~63) + __popcll(mc & ((1ull << lane) - 1ull)); cand_h[at] = ch; cand_y[at] = cy; }
-            if (lane == 0 && (i & ~63) < n) gcount[i >> 6] = (uint8_t)__popcll(mc);
+            if (is_cand) { const int at = cand_base + cand_cnt + __popcll(mc & ((1ull << lane) - 1ull)); cand_h[at] = ch; cand_y[at] = cy; }
+            cand_cnt += __popcll(mc);
         }
         tile_store(k + 2);
         tile_load(k + 3);
@@ -1900,20 +1931,20 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
         // planes, so the count reads one and the ordered store the other — every byte once — in batches of kTailBatch
         // loads in flight (one dependent load per group would put the memory latency on every group).
         constexpr int kTailBatch = 8;
-        const int ngroups = (n + 63) >> 6, per = (ngroups + DW - 1) / DW;
-        const int g0 = w * per, g1 = min(ngroups, g0 + per);
-        unsigned long long selbits = 0ull;             // bit j: my candidate of group g0 + j is selected (ranges of up to 64 groups)
+        const int nchunks = (cand_cnt + 63) >> 6;      // 64 entries of my list per chunk
+        const double *my_h = cand_h + cand_base, *my_y = cand_y + cand_base;
+        unsigned long long selbits = 0ull;             // bit c: my entry of chunk c is selected (lists of up to 64 chunks)
         int cnt = 0, near = (hl == hl) ? 0 : 1;
-        for (int gb = g0; gb < g1; gb += kTailBatch) {
+        for (int cb = 0; cb < nchunks; cb += kTailBatch) {
             double hm[kTailBatch];
 #pragma unroll
-            for (int j = 0; j < kTailBatch; ++j) hm[j] = cand_h[(min(gb + j, ngroups - 1) << 6) + lane];
+            for (int j = 0; j < kTailBatch; ++j) hm[j] = my_h[min(((cb + j) << 6) + lane, max(cand_cnt, 1) - 1)];
 #pragma unroll
             for (int j = 0; j < kTailBatch; ++j) {
-                const bool have = gb + j < g1 && lane < (int)gcount[min(gb + j, ngroups - 1)];
+                const bool have = ((cb + j) << 6) + lane < cand_cnt;
                 if (have && fabs(hm[j] - hl) <= kLevelGuard * fabs(hl)) near = 1;
                 const bool sel = have && hm[j] > hl;                                            // :243-244
-                if (sel && gb + j - g0 < 64) selbits |= 1ull << (gb + j - g0);
+                if (sel && cb + j < 64) selbits |= 1ull << (cb + j);
                 cnt += __popcll(__ballot(sel));
             }
         }
@@ -1929,19 +1960,19 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
             return;
         }
         double *dst = a.ysel + off;
-        for (int gb = g0; gb < g1; gb += kTailBatch) {
+        for (int cb = 0; cb < nchunks; cb += kTailBatch) {
             double yv[kTailBatch], hm[kTailBatch];
 #pragma unroll
             for (int j = 0; j < kTailBatch; ++j) {
-                const int at = (min(gb + j, ngroups - 1) << 6) + lane;
-                yv[j] = cand_y[at];
-                hm[j] = per > 64 ? cand_h[at] : 0.0;          // (more than 64 groups per wavefront: the bits above do not reach)
+                const int at = min(((cb + j) << 6) + lane, max(cand_cnt, 1) - 1);
+                yv[j] = my_y[at];
+                hm[j] = nchunks > 64 ? my_h[at] : 0.0;        // (more than 64 chunks in my list: the bits above do not reach)
             }
 #pragma unroll
             for (int j = 0; j < kTailBatch; ++j) {
                 bool sel;
-                if (per > 64) sel = gb + j < g1 && lane < (int)gcount[min(gb + j, ngroups - 1)] && hm[j] > hl;
-                else sel = gb + j < g1 && ((selbits >> (gb + j - g0)) & 1ull);
+                if (nchunks > 64) sel = ((cb + j) << 6) + lane < cand_cnt && hm[j] > hl;
+                else sel = cb + j < 64 && ((selbits >> (cb + j)) & 1ull) && ((cb + j) << 6) + lane < cand_cnt;
                 const unsigned long long ms = __ballot(sel);
                 if (sel) dst[base + __popcll(ms & ((1ull << lane) - 1ull))] = yv[j];
                 base += __popcll(ms);

@@ -61,6 +61,9 @@ class DeviceBatch:
             self.bufs["tile_base"] = self.ctx.to_device(pf.tile_base, np.int64)
             self.bufs["tile1_off"] = self.ctx.to_device(pf.tile1_off, np.int32)
             self.bufs["tile2_off"] = self.ctx.to_device(pf.tile2_off, np.int32)
+            if pf.tile_far is not None:
+                self.bufs["tile_far"] = self.ctx.to_device(pf.tile_far, np.float64)
+                self.bufs["tile_far_off"] = self.ctx.to_device(pf.tile_far_off, np.int64)
         self.algorithmic_bytes = pf.algorithmic_bytes()
         self._struct = None
 
@@ -71,6 +74,8 @@ class DeviceBatch:
                                       p("tri1_off"), p("tri1"), p("tri2_off"), p("tri2"), p("n2_expected"),
                                       self.max_feat, self.tri2_ids, self.total_padded,
                                       getattr(self, "tile_w", 0), 0, p("tile_base"), p("tile1_off"), p("tile2_off"))
+            self._struct.tile_far = p("tile_far")
+            self._struct.tile_far_off = p("tile_far_off")
             if self.n_frames:               # min_feat + the size classes' counts (ragged batches launch per class)
                 mf = self._struct.max_feat
                 _lib.check(self.ctx.lib.mvosr_batch_size_hint(self._feat_cnt_host.ctypes.data, self.n_frames,

@@ -250,11 +250,14 @@ def available_cpus():
 
 
 def resolve_workers(workers):
-    """``None`` -> one worker per available CPU (batch paths), shared evenly between the ranks of a node
-    (``LOCAL_WORLD_SIZE`` of torch.distributed.run), anything else as given."""
+    """``None`` -> ``MVOSR_DELAUNAY_WORKERS`` if set, else one worker per available CPU (batch paths), shared evenly
+    between the ranks of a node (``LOCAL_WORLD_SIZE`` of torch.distributed.run); anything else as given."""
     if workers is not None:
         return int(workers)
     import os
+    env = os.environ.get("MVOSR_DELAUNAY_WORKERS")                      # e.g. 0 under a profiler: no forked workers at all
+    if env is not None and env.strip().lstrip("-").isdigit():
+        return max(0, int(env))
     try:
         ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     except ValueError:
@@ -335,6 +338,8 @@ class PackedFrames:
     tile_base: np.ndarray = None    # int64 [F+1]
     tile1_off: np.ndarray = None    # int32 [tile_base[F]]
     tile2_off: np.ndarray = None
+    tile_far: np.ndarray = None     # float64: the far rows' vertices, copied out of the planes (mvosr_batch.tile_far)
+    tile_far_off: np.ndarray = None # int64 [F+1], in doubles
     extra: dict = field(default_factory=dict)
 
     @property
@@ -353,6 +358,9 @@ class PackedFrames:
         return 8 * 4 * n + 12 * (t1 + t2) + 12 * self.n_frames
 
 
+FRAME_ALIGN = 16           # doubles
+
+
 def pack_features(feature3ds, feature2ds, vanish=VANISH):
     """Apply the vanishing-row filter and lay the survivors out as planes."""
     F = len(feature3ds)
@@ -363,7 +371,10 @@ def pack_features(feature3ds, feature2ds, vanish=VANISH):
         idx = np.nonzero(f2[:, 1] > vanish)[0] if f2.size else np.zeros(0, dtype=np.int64)   # :252
         lower_index.append(idx)
         cnt[f] = idx.shape[0]
-    padded = (cnt.astype(np.int64) + 1) & ~np.int64(1)
+    # every frame's segment starts on a 128-byte line of the planes (16 doubles): a frame's loads then never share a
+    # line with its neighbour's, and the 4 KB tile blocks of the dense kernel are line-aligned (the C ABI asks for
+    # even offsets only)
+    padded = (cnt.astype(np.int64) + (FRAME_ALIGN - 1)) & ~np.int64(FRAME_ALIGN - 1)
     off = np.zeros(F, dtype=np.int64)
     if F:
         off[1:] = np.cumsum(padded)[:-1]
@@ -543,6 +554,11 @@ def tile_frames(pf: PackedFrames, repeats: int) -> PackedFrames:
         out.tile_base = np.concatenate([pf.tile_base[:-1] + r * nt for r in range(repeats)] + [np.array([repeats * nt], dtype=np.int64)])
         out.tile1_off = np.tile(pf.tile1_off, repeats)
         out.tile2_off = np.tile(pf.tile2_off, repeats)
+        if pf.tile_far is not None:
+            nf = int(pf.tile_far_off[-1])
+            out.tile_far = np.tile(pf.tile_far[:max(nf, 1)], repeats)
+            out.tile_far_off = np.concatenate([pf.tile_far_off[:-1] + r * nf for r in range(repeats)]
+                                              + [np.array([repeats * nf], dtype=np.int64)])
     return out
 
 
@@ -636,6 +652,28 @@ def _finish_tile_index(pf: PackedFrames):
     pf.tile1_off = np.concatenate(t1).astype(np.int32)
     pf.tile2_off = np.concatenate(t2).astype(np.int32)
     pf.tile_w = TILE_W
+    # the far rows' vertices as one contiguous block per frame: (y, z, v) x 3 per far row of tri1, then (x, y, z) x 3
+    # per far row of tri2 — plain copies of the planes' values
+    blocks, lens = [], []
+    for f in range(pf.n_frames):
+        sl = pf.frame_slice(f)
+        x, y, z, v = pf.x[sl], pf.y[sl], pf.z[sl], pf.v[sl]
+        parts = []
+        a, b = int(pf.tri1_off[f]), int(pf.tri1_off[f + 1])
+        far = pf.tri1[a + int(t1[f][-1]):b]
+        if len(far):
+            parts.append(np.stack([y[far], z[far], v[far]], axis=2).reshape(-1))
+        a, b = int(pf.tri2_off[f]), int(pf.tri2_off[f + 1])
+        far = pf.tri2[a + int(t2[f][-1]):b]
+        if len(far):
+            parts.append(np.stack([x[far], y[far], z[far]], axis=2).reshape(-1))
+        blk = np.concatenate(parts) if parts else np.zeros(0)
+        blocks.append(blk)
+        lens.append(len(blk))
+    pf.tile_far = np.ascontiguousarray(np.concatenate(blocks) if blocks else np.zeros(0), dtype=np.float64)
+    if pf.tile_far.size == 0:
+        pf.tile_far = np.zeros(1)                                  # (a valid device pointer even when no frame has far rows)
+    pf.tile_far_off = np.concatenate([[0], np.cumsum(np.array(lens, dtype=np.int64))]).astype(np.int64)
 
 
 def apply_tile_order(pf: PackedFrames):

@@ -9,6 +9,8 @@
 TAG=${1:-r01}; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export TMPDIR=/tmp
+# no forked Delaunay workers under the profiler: its preloaded library lives in them too and has hung their exit
+export MVOSR_DELAUNAY_WORKERS=0
 cd /tmp
 OUT=$R/gpurun_out
 mkdir -p $OUT

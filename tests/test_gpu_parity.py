@@ -276,6 +276,28 @@ def test_dense_tiled_kernel(gpu):
     for k in ("raw_scale", "height", "height_level", "status", "counts"):
         assert np.array_equal(res[k], out3.get(k), equal_nan=True), k
     out3.free()
+    # the far rows' vertices come from the packer's table (mvosr_batch.tile_far); without it the kernel gathers them
+    # from the planes: the same results.  A table of the wrong length for a frame refuses that frame.
+    assert pf.tile_far is not None and int(pf.tile_far_off[-1]) > 0 and int(pf.tile_far_off[-1]) % 9 == 0
+    st = db.struct()
+    far_ptr, far_off = st.tile_far, st.tile_far_off
+    st.tile_far, st.tile_far_off = None, None
+    out4 = DeviceOutputs(gpu, db, counts=True)
+    eng.scale_batch(db, out4)
+    gpu.sync()
+    for k in ("raw_scale", "height", "height_level", "status", "counts"):
+        assert np.array_equal(res[k], out4.get(k), equal_nan=True), k
+    out4.free()
+    bad_off = pf.tile_far_off.copy()
+    bad_off[-1] += 9                                    # the last frame seems to have one far row more than its index says
+    buf = gpu.to_device(bad_off, np.int64)
+    st.tile_far, st.tile_far_off = far_ptr, buf.ptr
+    out5 = DeviceOutputs(gpu, db, counts=True)
+    eng.scale_batch(db, out5)
+    gpu.sync()
+    st5 = out5.get("status")
+    out5.free(); buf.free()
+    assert st5[-1] == K.ST_ERR_MASK and all(st5[f] == ores[f].status for f in range(len(ores) - 1))
     db.free()
 
 
