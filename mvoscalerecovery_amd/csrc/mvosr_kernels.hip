@@ -754,9 +754,18 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
         atomicAdd(&hist[bin], 1);
         binc[k] = bin;
     }
-    for (int i = RC * kWave + lane; i < M; i += kWave) {
-        const int bin = bin_of_table(yv[i], edges);
-        if (bin >= 0) atomicAdd(&hist[bin], 1);
+    // (lists longer than the register cache — dense frames: four loads in flight per trip instead of one dependent
+    // round trip per value; the same in the two passes further down)
+    constexpr int kLongUnroll = 8;
+    for (int i0 = RC * kWave + lane; i0 < M; i0 += kLongUnroll * kWave) {
+        double yl[kLongUnroll];
+#pragma unroll
+        for (int j = 0; j < kLongUnroll; ++j) yl[j] = yv[min(i0 + j * kWave, M - 1)];
+#pragma unroll
+        for (int j = 0; j < kLongUnroll; ++j) {
+            const int bin = (i0 + j * kWave < M) ? bin_of_table(yl[j], edges) : -1;
+            if (bin >= 0) atomicAdd(&hist[bin], 1);
+        }
     }
     MVOSR_RSTAMP(2);
     // (one wave: its LDS operations execute in order, the reads below see the atomics above)
@@ -831,11 +840,18 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
 #pragma unroll
     for (int k = 0; k < RC; ++k) sum += ((kept >> k) & 1u) ? yc[k] : 0.0;
     double cntd = (double)__popc(kept);
-    for (int i = RC * kWave + lane; i < M; i += kWave) {              // lists longer than the register cache
-        const double y = yv[i];
-        const int bin = bin_of_table(y, edges);
-        if (bin >= 0 && nearflag[bin] && dropped_by_single(y, bin, single, first_single)) continue;
-        sum += y; cntd += 1.0;
+    for (int i0 = RC * kWave + lane; i0 < M; i0 += kLongUnroll * kWave) {   // lists longer than the register cache
+        double yl[kLongUnroll];
+#pragma unroll
+        for (int j = 0; j < kLongUnroll; ++j) yl[j] = yv[min(i0 + j * kWave, M - 1)];
+#pragma unroll
+        for (int j = 0; j < kLongUnroll; ++j) {
+            if (i0 + j * kWave >= M) continue;
+            const double y = yl[j];
+            const int bin = bin_of_table(y, edges);
+            if (bin >= 0 && nearflag[bin] && dropped_by_single(y, bin, single, first_single)) continue;
+            sum += y; cntd += 1.0;
+        }
     }
     sum = wave_sum(sum);
     cntd = wave_sum(cntd);
@@ -899,12 +915,19 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
         const double d = ((kept >> k) & 1u) ? yc[k] - mean : 0.0;
         ss += d * d;
     }
-    for (int i = RC * kWave + lane; i < M; i += kWave) {
-        const double y = yv[i];
-        const int bin = bin_of_table(y, edges);
-        if (bin >= 0 && nearflag[bin] && dropped_by_single(y, bin, single, first_single)) continue;
-        const double d = y - mean;
-        ss += d * d;
+    for (int i0 = RC * kWave + lane; i0 < M; i0 += kLongUnroll * kWave) {
+        double yl[kLongUnroll];
+#pragma unroll
+        for (int j = 0; j < kLongUnroll; ++j) yl[j] = yv[min(i0 + j * kWave, M - 1)];
+#pragma unroll
+        for (int j = 0; j < kLongUnroll; ++j) {
+            if (i0 + j * kWave >= M) continue;
+            const double y = yl[j];
+            const int bin = bin_of_table(y, edges);
+            if (bin >= 0 && nearflag[bin] && dropped_by_single(y, bin, single, first_single)) continue;
+            const double d = y - mean;
+            ss += d * d;
+        }
     }
     ss = wave_sum(ss);
     MVOSR_RSTAMP(5);
