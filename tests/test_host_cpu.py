@@ -38,6 +38,52 @@ def test_lds_plan_three_frames_per_cu():
     assert lib.mvosr_lds_bytes(300) < 10 * 1024
 
 
+def test_batch_size_hint_is_host_only():
+    """mvosr_batch_size_hint needs no GPU: min / max / class counts of a batch from the host's copy of feat_cnt
+    (classes: one wavefront per frame up to 320 features, four up to 1024, eight or sixteen above)."""
+    import ctypes as C
+    from mvoscalerecovery_amd import _lib
+    lib = _lib.load()
+    cnt = np.array([0, 5, 320, 321, 1024, 1025, 1500, 300, 2000], dtype=np.int32)
+    b = _lib.Batch()
+    assert lib.mvosr_batch_size_hint(cnt.ctypes.data, len(cnt), C.byref(b)) == 0
+    assert (b.min_feat, b.max_feat) == (0, 2000)
+    assert list(b.size_hint)[:3] == [4, 2, 3] and b.size_hint[3] != 0
+    assert lib.mvosr_batch_size_hint(None, 3, C.byref(b)) != 0                     # null counts: refused, error text set
+    assert b"batch_size_hint" in lib.mvosr_last_error()
+    bad = np.array([3, -1], dtype=np.int32)
+    assert lib.mvosr_batch_size_hint(bad.ctypes.data, 2, C.byref(b)) != 0
+
+
+def test_tile_layout_far_table_is_a_copy_of_the_planes():
+    """packing.apply_tile_order + attach_tri2(feature_ids=True): the far rows' vertex table holds, per far row, the
+    planes' own values of its three vertices — (y, z, v) for tri1, (x, y, z) for tri2 — and every frame starts on a
+    128-byte line of the planes."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import packing, synth
+    frames = [synth.synth_frame(i, n, base_seed=5) for i, n in enumerate((3000, 700, 2500))]
+    pf = packing.pack_features([f[0] for f in frames], [f[1] for f in frames])
+    assert all(int(o) % 16 == 0 for o in pf.feat_off)
+    packing.attach_tri1(pf, None)
+    packing.apply_tile_order(pf)
+    masks = [np.ones(int(n), dtype=bool) for n in pf.feat_cnt]
+    tri2 = [Delaunay(np.stack([pf.u[pf.frame_slice(f)], pf.v[pf.frame_slice(f)]], axis=1)).simplices.astype(np.int32) for f in range(3)]
+    packing.attach_tri2(pf, tri2, masks, feature_ids=True)
+    assert pf.tile_far is not None and len(pf.tile_far_off) == 4
+    for f in range(3):
+        sl = pf.frame_slice(f)
+        x, y, z, v = pf.x[sl], pf.y[sl], pf.z[sl], pf.v[sl]
+        nt = len(pf.tile1_off[int(pf.tile_base[f]):int(pf.tile_base[f + 1])]) - 1
+        far1 = pf.tri1[int(pf.tri1_off[f]) + int(pf.tile1_off[int(pf.tile_base[f]) + nt]):int(pf.tri1_off[f + 1])]
+        far2 = pf.tri2[int(pf.tri2_off[f]) + int(pf.tile2_off[int(pf.tile_base[f]) + nt]):int(pf.tri2_off[f + 1])]
+        blk = pf.tile_far[int(pf.tile_far_off[f]):int(pf.tile_far_off[f + 1])]
+        assert len(blk) == 9 * (len(far1) + len(far2))
+        want = np.concatenate([np.stack([y[far1], z[far1], v[far1]], axis=2).reshape(-1),
+                               np.stack([x[far2], y[far2], z[far2]], axis=2).reshape(-1)]) if len(blk) else np.zeros(0)
+        assert np.array_equal(blk, want)
+    assert int(pf.tile_far_off[-1]) > 0                     # (the 3000-feature frame has hull slivers across tiles)
+
+
 def test_product_fails_loudly_without_gpu():
     """No CPU fallback: constructing the estimator without a device raises."""
     import torch
