@@ -705,6 +705,7 @@ struct RoadArgs {
     int32_t *level_redo;         // fused HOT path: frames that end on the fallback level (:334-335) are not finished but appended
                                  // here ([0] = count): height_level becomes their result, so it must be NumPy's own double first
     const int32_t *list;         // process the frames list[1 .. list[0]] (grid-strided) instead of first_frame + index
+    int wide;                    // one WORKGROUP per frame (dense batches: long lists, few frames)
 };
 
 // bin of y against the workgroup's table edges[k] = {edge k, edge k+1} (same doubles as bin_edge)
@@ -717,17 +718,29 @@ __device__ __forceinline__ int bin_of_table(double y, const double2 *edges) {
     return k;
 }
 
-template <int RC>
+// WW = 1: the whole list in one wavefront.  WW = kRoadWaves (dense frames, lists of thousands of values, too few
+// frames to fill the GPU with one wavefront each): the workgroup's wavefronts share the frame — each takes a
+// contiguous part `[lo, hi)` of the list through the per-value passes (histogram into the SHARED `hist`, suspects,
+// sums; partial sums meet in `part`, added in wavefront order), every wavefront evaluates the histogram logic
+// redundantly (same inputs, same result), and wavefront 0 alone finishes the frame (modes, the decision, the cold
+// exact branches over the whole list).  `Mall` is the whole list's length; `yv` its first value.
+template <int RC, int WW = 1>
 __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16_t *slots, uint8_t *dropb, const double2 *edges,
-                                                const double *yv, double *scratch,
-                                                int M, double height_level, const mvosr_params &P, int32_t *g_hist, bool exact_stats MVOSR_STAMP_ARG) {
+                                                const double *yv_all, double *scratch,
+                                                int Mall, double height_level, const mvosr_params &P, int32_t *g_hist, bool exact_stats,
+                                                int part_lo, int part_hi, double *part MVOSR_STAMP_ARG) {
     const int lane = lane_id();
     RoadResult R;
-    R.height = nan(""); R.status = MVOSR_ST_MODE; R.n_sel = M; R.n_kept = 0; R.n_modes = 0; R.mode_left = -1; R.mode_right = -1;
+    R.height = nan(""); R.status = MVOSR_ST_MODE; R.n_sel = Mall; R.n_kept = 0; R.n_modes = 0; R.mode_left = -1; R.mode_right = -1;
     R.mean = R.std = R.skew = R.median = nan("");
-    if (M == 0) { R.status = MVOSR_ST_NO_FLAT; return R; }
+    if (Mall == 0) { R.status = MVOSR_ST_NO_FLAT; return R; }
+    const double *yv = yv_all + part_lo;                // my part of the list (WW == 1: all of it)
+    const int M = part_hi - part_lo;                    // (may be 0 for the last wavefronts of a short list)
+    if (WW == 1 || wave_id() == 0) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { const int b = lane + 64 * c; if (b < 176) hist[b] = 0; }
+        for (int c = 0; c < 3; ++c) { const int b = lane + 64 * c; if (b < 176) hist[b] = 0; }
+    }
+    if constexpr (WW > 1) __syncthreads();
 
     // histogram (np.histogram, :326); the first RC values of every lane stay in registers
     double yc[RC];
@@ -740,7 +753,7 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
                                               : (((1u << nfull) - 1u) | ((lane < M - nfull * kWave ? 1u : 0u) << nfull));
 #pragma unroll
     for (int k = 0; k < RC; ++k) {
-        const int i = min(k * kWave + lane, M - 1);                                       // clamped: always a legal address
+        const int i = max(min(k * kWave + lane, M - 1), 0);                               // clamped: always a legal address
         yc[k] = yv[i];
     }
 #pragma unroll
@@ -760,7 +773,7 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     for (int i0 = RC * kWave + lane; i0 < M; i0 += kLongUnroll * kWave) {
         double yl[kLongUnroll];
 #pragma unroll
-        for (int j = 0; j < kLongUnroll; ++j) yl[j] = yv[min(i0 + j * kWave, M - 1)];
+        for (int j = 0; j < kLongUnroll; ++j) yl[j] = yv[max(min(i0 + j * kWave, M - 1), 0)];
 #pragma unroll
         for (int j = 0; j < kLongUnroll; ++j) {
             const int bin = (i0 + j * kWave < M) ? bin_of_table(yl[j], edges) : -1;
@@ -768,6 +781,7 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
         }
     }
     MVOSR_RSTAMP(2);
+    if constexpr (WW > 1) __syncthreads();              // every part's values are in the shared histogram
     // (one wave: its LDS operations execute in order, the reads below see the atomics above)
     int hraw[3], hz[3];
     Bits192 single, modes, mins;
@@ -783,7 +797,7 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     }
     mx = wave_max(mx);
     mn = wave_min(mn);
-    if (g_hist) {
+    if (g_hist && (WW == 1 || wave_id() == 0)) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) { const int b = lane + 64 * c; if (b < kBins) { g_hist[b] = hraw[c]; g_hist[kBins + b] = hz[c]; } }
     }
@@ -843,7 +857,7 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     for (int i0 = RC * kWave + lane; i0 < M; i0 += kLongUnroll * kWave) {   // lists longer than the register cache
         double yl[kLongUnroll];
 #pragma unroll
-        for (int j = 0; j < kLongUnroll; ++j) yl[j] = yv[min(i0 + j * kWave, M - 1)];
+        for (int j = 0; j < kLongUnroll; ++j) yl[j] = yv[max(min(i0 + j * kWave, M - 1), 0)];
 #pragma unroll
         for (int j = 0; j < kLongUnroll; ++j) {
             if (i0 + j * kWave >= M) continue;
@@ -855,6 +869,14 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     }
     sum = wave_sum(sum);
     cntd = wave_sum(cntd);
+    if constexpr (WW > 1) {
+        if (lane == 0) { part[2 * wave_id()] = sum; part[2 * wave_id() + 1] = cntd; }
+        __syncthreads();
+        sum = 0.0; cntd = 0.0;
+#pragma unroll
+        for (int i = 0; i < WW; ++i) { sum += part[2 * i]; cntd += part[2 * i + 1]; }
+        __syncthreads();                                // (the slots are used again for the squares)
+    }
     MVOSR_RSTAMP(4);
     const int nkept = (int)cntd;
     R.n_kept = nkept;
@@ -863,12 +885,12 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     auto pack_kept = [&]() {
         int nlist = 0;
 #pragma unroll 1
-        for (int i0 = 0; i0 < M; i0 += kWave) {
+        for (int i0 = 0; i0 < Mall; i0 += kWave) {
             const int i = i0 + lane;
             bool keep = false;
             double y = 0.0;
-            if (i < M) {
-                y = yv[i];
+            if (i < Mall) {
+                y = yv_all[i];
                 const int bin = bin_of_table(y, edges);
                 keep = !(bin >= 0 && nearflag[bin] && dropped_by_single(y, bin, single, first_single));
             }
@@ -880,6 +902,7 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     };
 
     if (!have_modes) {
+        if constexpr (WW > 1) { if (wave_id() != 0) return R; }                             // (no barrier lies ahead on this branch)
         if (nkept == 0) { R.height = height_level; R.status = MVOSR_ST_LEVEL; return R; }   // :334-335
         // np.median (:333): pack the kept values into `scratch` (index <= source index, so in place
         // is safe when scratch == yv), then rank counting: the two middle order statistics
@@ -918,7 +941,7 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     for (int i0 = RC * kWave + lane; i0 < M; i0 += kLongUnroll * kWave) {
         double yl[kLongUnroll];
 #pragma unroll
-        for (int j = 0; j < kLongUnroll; ++j) yl[j] = yv[min(i0 + j * kWave, M - 1)];
+        for (int j = 0; j < kLongUnroll; ++j) yl[j] = yv[max(min(i0 + j * kWave, M - 1), 0)];
 #pragma unroll
         for (int j = 0; j < kLongUnroll; ++j) {
             if (i0 + j * kWave >= M) continue;
@@ -930,6 +953,14 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
         }
     }
     ss = wave_sum(ss);
+    if constexpr (WW > 1) {
+        if (lane == 0) part[wave_id()] = ss;
+        __syncthreads();
+        if (wave_id() != 0) return R;                   // wavefront 0 finishes the frame
+        ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < WW; ++i) ss += part[i];
+    }
     MVOSR_RSTAMP(5);
 
 #pragma unroll
@@ -993,38 +1024,50 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
 #endif
 // LIST: the frames of a.list, grid-strided (the rare second pass over the frames that ended on the fallback level); otherwise
 // frame first_frame + wavefront index, no loop (a loop around the body costs the product variant 57 VGPRs, i.e. half its occupancy)
-template <bool LIST>
+template <bool LIST, int WW = 1>
 __global__ __launch_bounds__(kRoadWaves *kWave, (LIST ? 1 : 4)) void road_model_kernel(const RoadArgs a) {
     static_assert(kRoadRC >= 16 && kRoadRC <= kDropStride, "verdict bytes per lane; the keep masks are 32 bits");
+    static_assert(WW == 1 || (WW == kRoadWaves && !LIST), "wide variant: the whole workgroup on one frame");
     __shared__ int hist_all[kRoadWaves][2][176];
     __shared__ double2 edges[kBins + 1];
     __shared__ uint16_t slots_all[kRoadWaves][kRoadRC * kWave];
     __shared__ __attribute__((aligned(16))) uint8_t drop_all[kRoadWaves][kDropStride * kWave];
+    __shared__ double part[2 * kRoadWaves];
     for (int k = threadIdx.x; k < kBins; k += kRoadWaves * kWave) { double2 e; e.x = bin_edge(k); e.y = bin_edge(k + 1); edges[k] = e; }
     __syncthreads();
-    const int64_t slot = (int64_t)blockIdx.x * kRoadWaves + wave_id();
+    const int64_t slot = WW > 1 ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * kRoadWaves + wave_id();
     auto one_frame = [&](const int64_t f) {
-    if (a.pending_only && a.o.status[f] != kStPending) return;
+    if (a.pending_only && a.o.status[f] != kStPending) return;          // (wide: the same answer in every wavefront)
     MVOSR_STAMP_DECL
     MVOSR_RSTAMP(0);
     const int M = a.cnt[f];
     const int64_t off = a.off[f];
     const double hl = a.height_level ? a.height_level[f] : nan("");
     MVOSR_RSTAMP(1);
-    // values per lane kept in registers: as few as the list needs (the passes over them are branch-free, so
-    // a short list would otherwise pay for sixteen rows of padding)
-    int *h0 = hist_all[wave_id()][0], *h1 = hist_all[wave_id()][1];
+    // values per lane kept in registers: as few as the list (wide: this wavefront's part of it) needs (the passes over
+    // them are branch-free, so a short list would otherwise pay for sixteen rows of padding)
+    int *h0 = hist_all[WW > 1 ? 0 : wave_id()][0], *h1 = hist_all[wave_id()][1];
     int32_t *gh = a.o.hist ? a.o.hist + f * 2 * kBins : nullptr;
     const bool ex = a.o.stats != nullptr;
-    const RoadResult R = (M <= 4 * kWave) ? road_wave<4>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
-                       : (M <= 8 * kWave) ? road_wave<8>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
-                       : (M <= 12 * kWave) ? road_wave<12>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
-                       : (kRoadRC == 16 || M <= 16 * kWave) ? road_wave<16>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS)
-                                          : road_wave<kRoadRC>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex MVOSR_STAMP_PASS);
+    int lo = 0, hi = M;
+    if constexpr (WW > 1) {
+        const int q = ((M + WW * kWave - 1) / (WW * kWave)) * kWave;     // values per wavefront, whole rows of 64
+        lo = min(M, wave_id() * q);
+        hi = min(M, lo + q);
+    }
+    const int Mp = hi - lo;
+#define MVOSR_ROAD_CALL(RC_) road_wave<RC_, WW>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex, lo, hi, part MVOSR_STAMP_PASS)
+    const RoadResult R = (Mp <= 4 * kWave) ? MVOSR_ROAD_CALL(4)
+                       : (Mp <= 8 * kWave) ? MVOSR_ROAD_CALL(8)
+                       : (Mp <= 12 * kWave) ? MVOSR_ROAD_CALL(12)
+                       : (kRoadRC == 16 || Mp <= 16 * kWave) ? MVOSR_ROAD_CALL(16)
+                                          : MVOSR_ROAD_CALL(kRoadRC);
+#undef MVOSR_ROAD_CALL
     MVOSR_RSTAMP(6);
 #ifdef MVOSR_STAMPS
     if (lane_id() == 0 && a.o.hist) { unsigned long long *d = reinterpret_cast<unsigned long long *>(a.o.hist + f * 2 * kBins) + 16; for (int i = 0; i < 8; ++i) d[i] = stamps[i]; }
 #endif
+    if (WW > 1 && wave_id() != 0) return;                               // wavefront 0 holds the frame's result
     if (R.status == MVOSR_ST_LEVEL && a.level_redo) {
         // the frame's height IS height_level, which the HOT scale kernel summed in its own order: the EXACT pass redoes it
         if (lane_id() == 0) { a.level_redo[1 + atomicAdd(a.level_redo, 1)] = (int32_t)f; a.o.status[f] = kStRedo; }
@@ -2349,6 +2392,10 @@ static int launch_scale_dense(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, int m
 // one wavefront per frame, kRoadWaves frames per workgroup
 static int launch_road(mvosr_ctx *ctx, const RoadArgs &ra, hipStream_t stream) {
     if (ra.n_frames <= 0) return MVOSR_OK;
+    if (ra.wide && !ra.list) {
+        hipLaunchKernelGGL((road_model_kernel<false, kRoadWaves>), dim3((unsigned)ra.n_frames), dim3(kRoadWaves * kWave), 0, stream, ra);
+        return check_launch("road_model_kernel (wide)");
+    }
     const unsigned blocks = ra.list ? 64u : (unsigned)((ra.n_frames + kRoadWaves - 1) / kRoadWaves);
     if (ra.list) hipLaunchKernelGGL(road_model_kernel<true>, dim3(blocks), dim3(kRoadWaves * kWave), 0, stream, ra);
     else hipLaunchKernelGGL(road_model_kernel<false>, dim3(blocks), dim3(kRoadWaves * kWave), 0, stream, ra);
@@ -2484,7 +2531,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     const int waves = pick_waves(waves_per_frame, b->max_feat);
     RoadArgs ra;
     ra.P = *p; ra.off = b->feat_off; ra.cnt = ka.nsel; ra.y = ka.ysel; ra.scratch = ka.ysel;
-    ra.height_level = o->height_level; ra.o = *o; ra.pending_only = 1; ra.level_redo = nullptr; ra.list = nullptr;
+    ra.height_level = o->height_level; ra.o = *o; ra.pending_only = 1; ra.level_redo = nullptr; ra.list = nullptr; ra.wide = 0;
     // The step is two launches on the context's stream: the scale kernel, then the road model (one
     // wavefront per frame) on the dense lists it left in the workspace.  (Splitting the batch into
     // chunks to run the road model of one chunk under the scale kernel of the next was measured
@@ -2510,6 +2557,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     } else if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, mode, false) : dispatch_scale(ctx, ka, waves, n_launch, mode))) return rc;
     if (pev && (ee = hipEventRecord(pev[1], ctx_stream(ctx))) != hipSuccess) return set_hip_error("hipEventRecord(profile)", ee);
     ra.first_frame = first_frame; ra.n_frames = n_launch;
+    ra.wide = (dense && !(debug_skip_env() & 256)) ? 1 : 0;     // dense batches: thousands of values per list, few frames
     if (!(debug_skip_env() & 16)) {
         if (mode == MODE_HOT) {
             // frames whose road model ends on the fallback level (:334-335; rare) come back on a second list: the EXACT
@@ -2588,6 +2636,7 @@ int mvosr_road_model_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_ba
     ra.P = *p; ra.off = b->feat_off; ra.cnt = b->feat_cnt; ra.y = b->y; ra.scratch = scratch;
     ra.height_level = height_level_in; ra.o = *o;
     ra.first_frame = 0; ra.n_frames = b->n_frames; ra.pending_only = 0; ra.level_redo = nullptr; ra.list = nullptr;
+    ra.wide = b->max_feat > 4 * kRoadRC * kWave ? 1 : 0;        // lists beyond four wavefronts' register caches
     return launch_road(ctx, ra, ctx_stream(ctx));
 }
 
