@@ -2181,6 +2181,11 @@ static PitchTest make_pitch_test(double thr_deg) {
     return pt;
 }
 
+// Ablation / A-B switches of profiling runs (env MVOSR_DEBUG_SKIP, a bit mask; 0 in production — results with any bit
+// of 1..16 set are NOT the path's results): 1 / 2 / 4 skip the vote sweep / first / second selection sweep, 8 forces the
+// refused-frame tail, 16 skips the road-model launches, 32 ignores a batch's tile index (two-sweep dense kernel),
+// 64 launches a ragged batch with one variant instead of per size class, 256 keeps the one-wavefront road model for
+// dense batches.
 static int debug_skip_env() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("MVOSR_DEBUG_SKIP"); v = e ? atoi(e) : 0; }
