@@ -23,7 +23,17 @@ if __name__ == "__main__":
                                         upper_fraction=float(rng.choice([0.0, 0.1, 0.4]))))
     est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False)
     t0 = time.perf_counter()
-    raw, status, level, errs = est.raw_scale_batch([f[0] for f in frames], [f[1] for f in frames])
+    if os.environ.get("SOAK_ONE_LAUNCH"):
+        # triangulations from the oracle, every frame in ONE launch: a ragged batch of >= 2048 frames is then launched
+        # per size class (the streaming path works in chunks of 512, which never are)
+        pre = [so.frame_raw_scale(f3.copy(), f2, 1.75) for f3, f2 in frames]
+        ok = [i for i, r in enumerate(pre) if r.tri1 is not None and r.tri2 is not None and len(r.tri2)]
+        frames = [frames[i] for i in ok]
+        F = len(frames)
+        raw, status, level, errs = est.raw_scale_batch([f[0] for f in frames], [f[1] for f in frames],
+                                                       [pre[i].tri1 for i in ok], [pre[i].tri2 for i in ok])
+    else:
+        raw, status, level, errs = est.raw_scale_batch([f[0] for f in frames], [f[1] for f in frames])
     t_gpu = time.perf_counter() - t0
     counts = est.last_counts
     bad = 0
