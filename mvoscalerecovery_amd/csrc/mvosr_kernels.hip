@@ -2458,7 +2458,10 @@ static int launch_scale_classes(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
         const int sc = (n <= variant_capacity(waves[c], 4) && waves[c] != 1) ? 4 : 8;
         if ((rc = check_fit(&kc[c].b, waves[c], sc, lds[c]))) return rc;
         if ((rc = prepare_kernel(fn[c], lds[c]))) return rc;
-        const int64_t bound = hinted && (int64_t)ka.b.size_hint[c] < nl ? (int64_t)ka.b.size_hint[c] : nl;
+        int64_t bound = hinted && (int64_t)ka.b.size_hint[c] < nl ? (int64_t)ka.b.size_hint[c] : nl;
+        // a class the batch header rules out (no frame that large / that small) is not launched: its grid is 0, so a
+        // frame that lands in it after all — a header that understates the batch — goes to the redo list like any overflow
+        if ((c > 0 && thr[c - 1] >= ka.b.max_feat) || ka.b.min_feat > thr[c]) bound = 0;
         ca.grid[c] = (int)(bound < 0 ? 0 : bound);
         kc[c].cls_list = ca.lists + c * ca.stride;
         kc[c].cls_cnt = hdr + c;
@@ -2472,8 +2475,7 @@ static int launch_scale_classes(mvosr_ctx *ctx, const KArgs &ka, int64_t nl) {
     hipLaunchKernelGGL(classify_frames_kernel, dim3((unsigned)((nl + cb - 1) / cb)), dim3(cb), 0, ctx_stream(ctx), ca);
     if ((rc = check_launch("classify_frames_kernel"))) return rc;
     for (int c = 2; c >= 0; --c) {              // largest frames first
-        if (c > 0 && thr[c - 1] >= ka.b.max_feat) continue;             // no frame of the batch is that large
-        if (ka.b.min_feat > thr[c] || ca.grid[c] == 0) continue;         // ... or that small
+        if (ca.grid[c] == 0) continue;
         hipLaunchKernelGGL(fn[c], dim3((unsigned)ca.grid[c]), dim3(waves[c] * kWave), lds[c], ctx_stream(ctx), kc[c]);
         if ((rc = check_launch("scale_frames_kernel (size class)"))) return rc;
     }

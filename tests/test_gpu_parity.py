@@ -660,6 +660,14 @@ def test_size_class_dispatch(gpu):
             assert np.array_equal(by_class[k], other[k], equal_nan=True), (variant, k)
     for k in range(4):
         st.size_hint[k] = hint[k]
+    # ... and so is min_feat: a header that overstates the smallest frame (the smallest class is then not launched)
+    # loses no frame — the classification sends them through the EXACT pass
+    true_min = int(st.min_feat)
+    st.min_feat = 700
+    other = run(0)
+    for k in ("raw_scale", "height", "status", "counts"):
+        assert np.array_equal(by_class[k], other[k], equal_nan=True), ("min_feat", k)
+    st.min_feat = true_min
     # a sub-range: frames outside it keep the sentinel
     first, n = 3 * pool + 5, 2100
     part = run(0, first, n)
