@@ -734,7 +734,7 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
     R.height = nan(""); R.status = MVOSR_ST_MODE; R.n_sel = Mall; R.n_kept = 0; R.n_modes = 0; R.mode_left = -1; R.mode_right = -1;
     R.mean = R.std = R.skew = R.median = nan("");
     if (Mall == 0) { R.status = MVOSR_ST_NO_FLAT; return R; }
-    const double *yv = yv_all + part_lo;                // my part of the list (WW == 1: all of it)
+    const double *yv = yv_all + (part_hi > part_lo ? part_lo : 0);     // my part of the list (WW == 1: all of it; an empty part: any legal address)
     const int M = part_hi - part_lo;                    // (may be 0 for the last wavefronts of a short list)
     if (WW == 1 || wave_id() == 0) {
 #pragma unroll
