@@ -38,6 +38,31 @@ def test_lds_plan_three_frames_per_cu():
     assert lib.mvosr_lds_bytes(300) < 10 * 1024
 
 
+def test_ctypes_structs_match_the_header(tmp_path):
+    """The ctypes mirrors of mvosr_params / mvosr_batch / mvosr_outputs have the header's size and field offsets
+    (checked with the C compiler: the structs grew twice in round 2)."""
+    import ctypes as C
+    from mvoscalerecovery_amd import _lib
+    fields = {"mvosr_params": [n for n, _ in _lib.Params._fields_], "mvosr_batch": [n for n, _ in _lib.Batch._fields_],
+              "mvosr_outputs": [n for n, _ in _lib.Outputs._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "mvosr.h"', 'int main(void) {']
+    for st, names in fields.items():
+        src.append('printf("%s %%zu\\n", sizeof(%s));' % (st, st))
+        for n in names:
+            src.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (st, n, st, n))
+    src += ['printf("abi %d\\n", MVOSR_ABI_VERSION);', 'return 0; }']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert int(got["abi"]) == _lib.ABI_VERSION
+    for st, cls in (("mvosr_params", _lib.Params), ("mvosr_batch", _lib.Batch), ("mvosr_outputs", _lib.Outputs)):
+        assert int(got[st]) == C.sizeof(cls), st
+        for n, _ in cls._fields_:
+            assert int(got["%s.%s" % (st, n)]) == getattr(cls, n).offset, (st, n)
+
+
 def test_batch_size_hint_is_host_only():
     """mvosr_batch_size_hint needs no GPU: min / max / class counts of a batch from the host's copy of feat_cnt
     (classes: one wavefront per frame up to 320 features, four up to 1024, eight or sixteen above)."""
