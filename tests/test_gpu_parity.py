@@ -1380,3 +1380,44 @@ def test_sharded_sequence_driver_two_ranks_one_gpu(gpu, tmp_path):
             out, _ = p.communicate()
         assert p.returncode == 0, out
         assert "rank %d ok" % rank in out
+
+
+def test_bench_line_contract(gpu):
+    """bench.py prints ONE JSON line with the driver's keys, a roofline block whose numbers are consistent with each
+    other, and a cpu_baseline block; a second run with --gpus 2 on this 1-GPU box refuses loudly (no silent single rank)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--frames", "8192", "--pool", "64", "--steps", "3", "--warmup", "1",
+                        "--no-e2e"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "frames/s" and d["dtype"] == "f64"
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert 0.05 < r["frac"] < 1.0 and r["kernel_ms_avg"] < d["ms_per_step"] * 1.05
+    assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "frames/s"
+    if _device_count() == 1:
+        p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--frames", "4096", "--pool", "32", "--steps", "1",
+                             "--warmup", "1", "--no-e2e", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+        assert p2.returncode != 0 and not [ln for ln in p2.stdout.splitlines() if ln.startswith("{")]
+
+
+def _device_count():
+    from mvoscalerecovery_amd import _lib
+    return int(_lib.load().mvosr_device_count())
+
