@@ -94,6 +94,9 @@ def launch_ranks(args, argv):
 # ---------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------
+TILE_ABOVE = [1 << 30]
+
+
 def frame_sizes(args, pool):
     if args.workload == "kitti":
         # configs[2]: per-frame feature counts after the VO's masks, a few hundred to ~1500 (C3)
@@ -113,7 +116,7 @@ def build_pool(ctx, engine, sizes, seed):
     t0 = time.perf_counter()
     packing.attach_tri1(pf, None, None)
     t_del1 = time.perf_counter() - t0
-    cap = int(ctx.lib.mvosr_max_lds_features())
+    cap = min(int(ctx.lib.mvosr_max_lds_features()), TILE_ABOVE[0])
     dense = pf.max_feat > cap
     if dense:            # dense frames: the tiled layout (what ScaleEstimator.scale_calculation_batch does)
         packing.apply_tile_order(pf)
@@ -219,6 +222,8 @@ def main():
     ap.add_argument("--waves", type=int, default=0, help="wavefronts per frame (0 = auto)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: more ranks than GPUs (gloo, devices shared round-robin)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile-above", type=int, default=0,
+                    help="diagnostic: frames with more features than this take the tiled layout / kernel (0: only frames beyond the LDS capacity)")
     ap.add_argument("--no-tiles", action="store_true", help="diagnostic: dense frames without the tile index (the two-sweep gather kernel)")
     ap.add_argument("--no-far-table", action="store_true", help="diagnostic: dense frames without the far rows' vertex table (the kernel gathers)")
     ap.add_argument("--no-e2e", action="store_true")
@@ -226,6 +231,8 @@ def main():
                     help="diagnostic: every tile reads the feature planes of the SAME pool frames (cache-resident: 41 %% "
                          "less HBM traffic); the JSON line is marked and is not a benchmark result")
     args = ap.parse_args()
+    if args.tile_above > 0:
+        TILE_ABOVE[0] = args.tile_above
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
@@ -268,7 +275,7 @@ def main():
     repeats = max(1, frames_req // pool_n)
     F = pool_n * repeats
     frames, pf_pool, masks, delaunay_cpu_s = build_pool(ctx, engine, sizes, seed=2024)
-    dense = pf_pool.max_feat > int(ctx.lib.mvosr_max_lds_features())
+    dense = pf_pool.max_feat > min(int(ctx.lib.mvosr_max_lds_features()), TILE_ABOVE[0])
     # The pool is uploaded once and replicated in HBM on the device (torch.repeat): F frames at distinct
     # addresses (F * 156 KB >> the 256 MB Infinity Cache) without building them on the host.
     dev = torch.device("cuda", local)
