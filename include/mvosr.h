@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MVOSR_ABI_VERSION 5
+#define MVOSR_ABI_VERSION 6
 
 /* error codes (function return values) */
 enum mvosr_err {
@@ -59,8 +59,9 @@ enum mvosr_status {
     MVOSR_ST_ERR_SINGULAR = 7,  /* LinAlgError at scale_calculator.py:229 */
     MVOSR_ST_ERR_MASK = 8,      /* tri2 inconsistent with the vote computed on the GPU, or a
                                    vertex id out of range (build-side check, no reference analogue) */
-    MVOSR_ST_ERR_EMPTY = 9,     /* frame without features/triangles (build-side check) */
-    MVOSR_ST_TOO_FEW = 10       /* 1..3 features below the vanishing row: the reference skips the second
+    MVOSR_ST_ERR_EMPTY = 9,     /* frame without triangles, or with fewer than 3 features below the vanishing row (where the
+                                   reference's first Delaunay call raises QhullError, :257: the caller must raise) */
+    MVOSR_ST_TOO_FEW = 10       /* exactly 3 features below the vanishing row: the reference skips the second
                                    triangulation (:263-270) and divides by the PREVIOUS frame's height_level
                                    (:420-422, std 100); raw_scale/height_level are NaN here and the host's
                                    cross-frame step supplies that level */
@@ -94,8 +95,16 @@ typedef struct mvosr_params {
     double skew_threshold;       /* 0.3 (:348) */
     double mode_rel;             /* 0.33 (:461) */
     int32_t mode_min;            /* 2 (:451,:462) */
-    int32_t reserved;
+    int32_t vote_mode;           /* MVOSR_VOTE_REFERENCE (0): check_triangle's flag pattern exactly as the reference has it —
+                                    `b > 0` marks vertices 0 and 1 (:113-115), so the vote depends on the order of the
+                                    vertices inside a row and the rows must be SciPy's, verbatim;
+                                    MVOSR_VOTE_FIXED (1): `b > 0` marks vertices 0 and 2 (the evident intent of those lines) —
+                                    a DECLARED DEVIATION from the reference: the vote is then invariant
+                                    under the order of a row's vertices, so any row form of the same triangle set gives
+                                    the same counters (what makes the device triangulation's rows usable) */
 } mvosr_params;
+#define MVOSR_VOTE_REFERENCE 0
+#define MVOSR_VOTE_FIXED 1
 
 /* A packed batch of F frames, resident in HBM.  Features are those that passed the
  * vanishing-row filter (:252-254), stored as planes (structure of arrays) with the frames'
@@ -157,6 +166,12 @@ typedef struct mvosr_batch {
      * checked by the kernel: they are the caller's copy of its own planes. */
     const double *tile_far;
     const int64_t *tile_far_off; /* [F+1] */
+    /* Optional explicit row counts (NULL: frame f has tri*_off[f+1] - tri*_off[f] rows).  With counts, frame f's rows are
+     * the first tri*_cnt[f] rows at tri*_off[f] and the offsets only say where a frame's rows start — the form
+     * mvosr_delaunay_batch writes (a frame's capacity is 2 * points rows; how many it holds is known on the device
+     * only), so that a device-built triangulation goes into the scale kernel without a trip through the host. */
+    const int32_t *tri1_cnt;     /* [F] or NULL */
+    const int32_t *tri2_cnt;     /* [F] or NULL */
 } mvosr_batch;
 
 #define MVOSR_TILE_W 512
@@ -365,16 +380,23 @@ enum mvosr_dt_status {
 /*
  * Batched 2-D Delaunay triangulation: what scipy.spatial.Delaunay(points).simplices computes at
  * /root/reference/src/scale_calculator.py:257-258 and :266-267, as a device stage.  For points in general position the
- * triangle SET is the one Qhull returns; the rows are positively oriented, start with their smallest vertex and are
- * sorted by it (then counter-clockwise around it).  Qhull's own rotation of each row — which the reference's vote
- * depends on (:113-115) — is not reproducible from the geometry, so scales computed on these rows are a DELIBERATE
- * DEVIATION from the reference (selected explicitly by the host with triangulation="gpu"; DESIGN.md gives the measured
- * agreement).  Frame f's points are (u, v)[pts_off[f] .. +pts_cnt[f]); its rows are written at tri + 3*tri_off[f]
- * (room for 2*pts_cnt[f] rows), tri_cnt[f] says how many; status[f] is an mvosr_dt_status.  max_pts = max(pts_cnt).
+ * triangle SET is the one Qhull returns; the rows come in a canonical form — vertex ids ascending inside a row, rows in
+ * lexicographic order — a function of the set alone.  Qhull's own rotation of each row, which the reference's vote
+ * depends on (:113-115), is not reproducible from the geometry: these rows are meant for MVOSR_VOTE_FIXED, under which
+ * they and SciPy's rows give bit-identical results (the host selects both with triangulation="gpu",
+ * check_triangle="fixed"); with MVOSR_VOTE_REFERENCE they are a measured deviation.
+ * Frame f's points are (u, v)[pts_off[f] .. +pts_cnt[f]); with `keep` (laid out like u; e.g. the vote counters of
+ * mvosr_outlier_vote_batch) only the points with keep[i] >= 0 take part and the ids are their ranks among those, in
+ * order — the second triangulation over the survivors of the vote (:264-266) without a compaction pass.  n_used[f]
+ * (optional) = the number of points triangulated (what mvosr_batch.n2_expected wants).  Rows are written at
+ * tri + 3*tri_off[f] (room for 2 * points rows), tri_cnt[f] says how many; status[f] is an mvosr_dt_status (a declined
+ * frame has tri_cnt 0 and the reason in the status' bits 8..).  max_pts = max(pts_cnt) <= mvosr_delaunay_max_points().
  */
 int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
-                         const double *u, const double *v, int max_pts, const int64_t *tri_off, int32_t *tri,
-                         int32_t *tri_cnt, int32_t *status);
+                         const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
+                         int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status);
+/* Largest frame mvosr_delaunay_batch takes (the frame's points, grid and rows live in one workgroup's LDS). */
+int mvosr_delaunay_max_points(void);
 
 /* LDS bytes the fused kernel requests for a frame of n features (host-side planning). */
 size_t mvosr_lds_bytes(int n_features);

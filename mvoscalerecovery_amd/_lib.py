@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 LIB_PATH = os.environ.get("MVOSR_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")   # (override: A/B builds in profiles/)
-ABI_VERSION = 5
+ABI_VERSION = 6
+VOTE_REFERENCE, VOTE_FIXED = 0, 1          # mvosr_params.vote_mode
 TRI2_SURVIVORS, TRI2_FEATURES = 0, 1      # mvosr_batch.tri2_ids
 N_COUNTS = 8
 TILE_W = 512                              # MVOSR_TILE_W
@@ -26,7 +27,7 @@ class MvosrLibraryError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("cos_pitch", C.c_double), ("sin_pitch", C.c_double), ("absolute_reference", C.c_double),
                 ("pitch_threshold_deg", C.c_double), ("skew_threshold", C.c_double), ("mode_rel", C.c_double),
-                ("mode_min", C.c_int32), ("reserved", C.c_int32)]
+                ("mode_min", C.c_int32), ("vote_mode", C.c_int32)]
 
 
 class Batch(C.Structure):
@@ -37,7 +38,8 @@ class Batch(C.Structure):
                 ("total_feat", C.c_int64),
                 ("tile_w", C.c_int32), ("min_feat", C.c_int32), ("tile_base", C.c_void_p),
                 ("tile1_off", C.c_void_p), ("tile2_off", C.c_void_p), ("size_hint", C.c_int32 * 4),
-                ("tile_far", C.c_void_p), ("tile_far_off", C.c_void_p)]
+                ("tile_far", C.c_void_p), ("tile_far_off", C.c_void_p),
+                ("tri1_cnt", C.c_void_p), ("tri2_cnt", C.c_void_p)]
 
 
 class Outputs(C.Structure):
@@ -89,7 +91,8 @@ SYMBOLS = {
     "mvosr_triangle_batch": (C.c_int, [_P, C.POINTER(Batch), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                        _P, _P, _P]),
     "mvosr_plane_inliers": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_double, _P]),
-    "mvosr_delaunay_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "mvosr_delaunay_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
+    "mvosr_delaunay_max_points": (C.c_int, []),
     "mvosr_lds_bytes": (C.c_size_t, [C.c_int]),
     "mvosr_max_lds_features": (C.c_int, []),
 }

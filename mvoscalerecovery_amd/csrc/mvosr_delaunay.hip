@@ -1,29 +1,38 @@
 // mvosr_delaunay.hip — batched 2-D Delaunay triangulation on the GPU: the two
 // scipy.spatial.Delaunay calls of /root/reference/src/scale_calculator.py:257-258,266-267, which cost 3-3.5 ms each
-// on a host core and bound the end-to-end rate of the drop-in path, as an optional device stage.
+// on a host core and bound the end-to-end rate of the drop-in path, as a device stage whose rows stay on the device.
 //
-// This is a DELIBERATE DEVIATION, selected explicitly (triangulation="gpu"), never the default: the reference's
-// depth-order vote depends on the order of the vertices INSIDE a row of Qhull's output (scale_calculator.py:113-115),
-// and that order is a by-product of Qhull's processing order, not a function of the geometry.  For points in general
-// position the triangle SET is unique and this kernel returns exactly that set (tested against SciPy); what it cannot
-// return is Qhull's rotation of each row.  Rows come out positively oriented (like SciPy's) with the smallest vertex
-// first, sorted by that vertex and then counter-clockwise around it — a canonical, documented form.  DESIGN.md reports
-// how often the quantised scales still equal the reference's.
+// What it returns: for points in general position the Delaunay triangle SET is unique, and this kernel returns exactly
+// that set (tested against SciPy) in a CANONICAL row form — vertex ids ascending inside a row, rows in lexicographic
+// order — a function of the set alone.  What it cannot return is Qhull's rotation of each row, a by-product of Qhull's
+// processing order that the reference's depth-order vote depends on (scale_calculator.py:113-115 sets flag[1] where
+// flag[2] is meant).  The rows are therefore meant for the order-invariant vote (check_triangle="fixed",
+// mvosr_params.vote_mode = MVOSR_VOTE_FIXED), with which SciPy's rows and these rows give bit-identical results; with the
+// reference's flag pattern they are a measured deviation.
 //
-// Algorithm: one workgroup per frame, the frame's points in LDS in fp64; every point builds its own Delaunay star,
-// independently of all others (no shared mutable structure, no ordering between stars): one scan of the frame collects
-// the points within a radius R of p (a few average spacings), the nearest of them is a Delaunay neighbour, and from it
-// the star is wrapped counter-clockwise (then clockwise, if p is on the hull): the third vertex of the triangle on the
-// left of the directed edge (p, q) is the point c on that side that sees the edge under the largest angle, i.e. with
-// the smallest cot = (c-p).(c-q) / cross(q-p, c-p).  A completion is final when its circumcircle lies inside the
-// candidates' radius (2r <= R); otherwise, and on the hull, it is redone over all points.  A triangle is written by its
-// smallest vertex, so every triangle appears once.  Points are processed in chunks; a chunk's rows are staged in LDS
-// and written in point order (block prefix sum), so the output does not depend on scheduling.
+// Algorithm (round 3; the round-2 kernel scanned all points of the frame for every point): one workgroup of 8
+// wavefronts per frame, the frame's points in LDS in fp64, counting-sorted into a uniform grid of ~1.5 points per cell
+// (cell id = row-major, so one row of a cell box is one contiguous range of the sorted array).  Every point builds
+// its own Delaunay star, independently of all others (no shared mutable structure, nothing ordered between stars):
+//   phase 1, ONE LANE PER POINT: nearest neighbour within the point's 5x5 cell block (a Delaunay neighbour), then the
+//     star is wrapped counter-clockwise: the apex of the triangle on the left of the directed edge (p, q) is the
+//     candidate c of the block that sees the edge under the largest angle (smallest cot = (c-p).(c-q) / cross(q-p, c-p),
+//     compared by cross-multiplication: no division or square root per candidate).  Lanes of one cell walk the same
+//     candidate list in lockstep (LDS broadcast reads).  A completion whose circumcircle leaves the block is continued
+//     optimistically and queued for verification; a star that is open within its block, or owns more rows than the
+//     lane's register list holds, goes to the hard list;
+//   phase 1b, ONE WAVEFRONT PER QUEUED COMPLETION: the same search over the cell box of the circumcircle; a different
+//     answer sends the point to the hard list;
+//   phase 2, ONE WAVEFRONT PER HARD POINT (hull vertices, points next to long hull slivers: a few per cent): the same
+//     wrap with the lanes striding over the candidates, the search widened to the circumcircle's cell box or to the
+//     whole frame where the block cannot certify the answer, clockwise as well when the star is open (hull).
+// A triangle is written by its smallest vertex, so it appears once; a point's rows are sorted and the points' row counts
+// prefix-summed in point order, so the output does not depend on scheduling.
 //
-// Robustness: plain fp64 predicates with guard bands.  A frame in which a decision is within the guard band — two
+// Robustness: plain fp64 predicates with guard bands.  A frame in which a decision falls inside a band — two
 // candidates with (nearly) the same cot: four cocircular points; a point (nearly) on the line through an edge;
-// duplicate points — or whose row count is not Euler's 2n - 2 - h is flagged MVOSR_DT_DEGENERATE and left to the
-// host's Qhull (SciPy resolves such inputs by its own joggling rules, which are not reproducible here).
+// duplicate points — or whose rows fail Euler's relation (2n - 2 - h rows, 3 star triangles per row) is flagged
+// MVOSR_DT_DEGENERATE and left to the host's Qhull (SciPy resolves such inputs by its own rules).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -36,239 +45,526 @@ namespace mvosr {
 
 constexpr int kDtWaves = 8;
 constexpr int kDtBlock = kDtWaves * kWave;
-constexpr int kDtChunk = 256;            // points per chunk (rows staged in LDS per chunk)
-constexpr int kDtMaxOwn = 32;            // rows a point may own (it owns the triangles in which it is the smallest vertex)
-constexpr int kDtMaxCand = 256;          // candidates within the radius, per point
-constexpr int kDtMaxDeg = 64;
-constexpr double kDtTieTol = 1e-9;       // relative guard band on cot differences / collinearity
+constexpr int kDtR = 2;                  // a point's candidates: the (2R+1)^2 cell block around its cell
+constexpr double kDtPerCell = 1.5;       // target points per cell (measured trade-off: profiles/micro/dt_proto.py)
+constexpr int kDtMaxCells = 4096;
+constexpr int kDtLaneRows = 8;           // rows a point may own on the lane path (more: hard list)
+constexpr int kDtLaneDeg = 24;           // star degree on the lane path
+constexpr int kDtWaveRows = 32;          // rows a point may own at all
+constexpr int kDtWaveDeg = 60;
+constexpr int kDtVq = 1024;              // queued completions
+constexpr int kDtHardCap = 1024;         // hard points
+constexpr int kDtArenaSlack = 512;       // rows of points that are recomputed stay behind in the arena
+constexpr double kDtTieTol = 1e-9;       // relative guard band on cot differences
+constexpr double kDtColTol = 1e-12;      // relative guard band on collinearity (|cross| <= tol |a| |b|)
+
+// why a frame was declined (status bits 8..)
+enum { DT_WHY_DUP = 1, DT_WHY_TIE = 2, DT_WHY_COLLINEAR = 4, DT_WHY_DEGREE = 8, DT_WHY_ROWS = 16, DT_WHY_EULER = 32,
+       DT_WHY_HARD = 64, DT_WHY_SIZE = 128 };
 
 struct DtArgs {
     int64_t n_frames;
     const int64_t *pts_off; const int32_t *pts_cnt;      // [F] the frame's points in u/v
     const double *u, *v;
+    const int32_t *keep;                                 // laid out like u, or null: a point takes part iff keep[i] >= 0
     const int64_t *tri_off;                              // [F] start of the frame's rows in `tri` (capacity 2*n rows)
-    int32_t *tri;                                        // rows (a, b, c)
+    int32_t *tri;                                        // rows (a, b, c), a < b < c
     int32_t *tri_cnt;                                    // [F] rows written
+    int32_t *n_used;                                     // [F] points triangulated (null: not wanted)
     int32_t *status;                                     // [F] MVOSR_DT_*
+    int max_pts;
 };
 
-struct DtBest { double t; int id; int tie; };
+struct DtPlan { uint32_t S, oid, od, astart, cs, arena, vq, hard, wrows, red, misc, total; int max_cells, arena_cap; };
 
-// among the wavefront's lanes: the smallest t, its id, and whether another lane's DIFFERENT point comes within the guard band
-__device__ __forceinline__ DtBest dt_wave_best(double t, int id, double t2nd) {
-    // per-lane (t, id) is that lane's best; t2nd its runner-up (of another point)
-    double m = t;
-    m = fmin(m, dpp_mov<kDppXor1>(m));
-    m = fmin(m, dpp_mov<kDppXor2>(m));
-    m = fmin(m, dpp_mov<kDppHalfMirror>(m));
-    m = fmin(m, dpp_mov<kDppMirror>(m));
-    m = fmin(fmin(readlane_d(m, 0), readlane_d(m, 16)), fmin(readlane_d(m, 32), readlane_d(m, 48)));
-    DtBest r;
-    r.t = m; r.id = -1; r.tie = 0;
+__host__ __device__ inline int dt_cell_cap(int max_pts) {
+    int c = (int)((double)max_pts / kDtPerCell * 1.25) + 64;
+    return c > kDtMaxCells ? kDtMaxCells : c;
+}
+__host__ __device__ inline DtPlan dt_plan(int max_pts) {
+    DtPlan p;
+    const uint32_t npad = (uint32_t)((max_pts + 7) & ~7);
+    p.max_cells = dt_cell_cap(max_pts);
+    p.arena_cap = (int)(2u * npad) + kDtArenaSlack;
+    p.S = 0;                                             // double2 per point (sorted by cell)
+    p.oid = p.S + 16u * npad;                            // u16: sorted index -> id of the point
+    p.od = p.oid + 2u * npad;                            // u16 per id: rows owned | star degree << 6 | listed << 14 | open << 15
+    p.astart = p.od + 2u * npad;                         // u16 per id: the point's rows in the arena
+    p.cs = p.astart + 2u * npad;                         // u32 per cell (+1): end of the cell in the sorted array
+    p.arena = p.cs + 4u * (uint32_t)(p.max_cells + 8);   // u32 rows (b << 16 | c) in the order they were found
+    p.vq = p.arena + 4u * (uint32_t)p.arena_cap;         // uint2 per queued completion
+    p.hard = p.vq + 8u * kDtVq;                          // u16 sorted indices
+    p.wrows = p.hard + 2u * kDtHardCap;                  // u32 [waves][kDtWaveRows]
+    p.red = p.wrows + 4u * kDtWaves * kDtWaveRows;       // doubles: block reductions
+    p.misc = p.red + 8u * 4u * kDtWaves;
+    p.total = p.misc + 4u * 64u;
+    return p;
+}
+
+enum { DM_FLAGS = 0, DM_ARENA = 1, DM_VQ = 2, DM_NHARD = 3, DM_WCNT = 8 /* [8..15] */, DM_WSUM = 16 /* [16..23] */, DM_WSUM2 = 24, DM_WSUM3 = 32 };
+
+struct DtGrid {
+    double lo_u, lo_v, ix, iy;
+    int gx, gy;
+    const uint32_t *cs;
+    __device__ __forceinline__ int cellx(double x) const { return (int)fmin(fmax((x - lo_u) * ix, 0.0), (double)(gx - 1)); }
+    __device__ __forceinline__ int celly(double y) const { return (int)fmin(fmax((y - lo_v) * iy, 0.0), (double)(gy - 1)); }
+    __device__ __forceinline__ int row_begin(int cy, int cxa) const { const int c = cy * gx + cxa; return c ? (int)cs[c - 1] : 0; }
+    __device__ __forceinline__ int row_end(int cy, int cxb) const { return (int)cs[cy * gx + cxb]; }
+};
+
+struct DtBox { int xa, xb, ya, yb; };
+
+// the best and the second best apex seen so far, as fractions num / cr (cr > 0)
+struct DtAcc {
+    double n1, c1, n2, c2;
+    int b1, flag;
+    __device__ __forceinline__ void reset() { n1 = INFINITY; c1 = 1.0; n2 = INFINITY; c2 = 1.0; b1 = -1; flag = 0; }
+};
+
+// candidates S[j0..j1) against the directed edge p -> p + a; sgn = +1: apex on the left, -1: on the right
+template <bool WAVE>
+__device__ __forceinline__ void dt_scan(DtAcc &A, const double2 *S, int j0, int j1, int i, int iq, double px, double py,
+                                        double ax, double ay, double a2col, double sgn) {
+    const int step = WAVE ? kWave : 1;
+    for (int j = j0 + (WAVE ? lane_id() : 0); j < j1; j += step) {
+        if (j == i || j == iq) continue;
+        const double2 c = S[j];
+        const double bx = c.x - px, by = c.y - py;
+        const double cr = sgn * (ax * by - ay * bx);
+        const double b2 = bx * bx + by * by;
+        if (cr * cr <= a2col * b2) {                       // (nearly) on the line through the edge
+            if (bx * ax + by * ay > 0.0 || b2 == 0.0) A.flag = 1;      // ... ahead of p: the sign of cr decides a triangle
+            continue;
+        }
+        if (cr <= 0.0) continue;
+        const double num = bx * (bx - ax) + by * (by - ay);           // (c - p).(c - q)
+        if (num * A.c1 < A.n1 * cr) { A.n2 = A.n1; A.c2 = A.c1; A.n1 = num; A.c1 = cr; A.b1 = j; }
+        else if (num * A.c2 < A.n2 * cr) { A.n2 = num; A.c2 = cr; }
+    }
+}
+
+template <bool WAVE>
+__device__ __forceinline__ void dt_scan_box(DtAcc &A, const double2 *S, const DtGrid &G, const DtBox &B, int i, int iq,
+                                            double px, double py, double ax, double ay, double a2col, double sgn) {
+    for (int y = B.ya; y <= B.yb; ++y)
+        dt_scan<WAVE>(A, S, G.row_begin(y, B.xa), G.row_end(y, B.xb), i, iq, px, py, ax, ay, a2col, sgn);
+}
+
+// runner-up within the guard band of the best: t2 - t1 <= tol (|t1| + 1) with t = n / c
+__device__ __forceinline__ bool dt_acc_tie(const DtAcc &A) {
+    return A.b1 >= 0 && (A.n2 * A.c1 - A.n1 * A.c2) <= kDtTieTol * (fabs(A.n1) + A.c1) * A.c2;
+}
+
+__device__ __forceinline__ double dt_wave_min(double x) {
+    x = fmin(x, dpp_mov<kDppXor1>(x)); x = fmin(x, dpp_mov<kDppXor2>(x)); x = fmin(x, dpp_mov<kDppHalfMirror>(x)); x = fmin(x, dpp_mov<kDppMirror>(x));
+    return fmin(fmin(readlane_d(x, 0), readlane_d(x, 16)), fmin(readlane_d(x, 32), readlane_d(x, 48)));
+}
+
+struct DtPick { int id, tie, flag; };
+// the wavefront's answer from its lanes' accumulators
+__device__ __forceinline__ DtPick dt_wave_pick(const DtAcc &A) {
+    const double t1 = A.b1 >= 0 ? A.n1 / A.c1 : INFINITY;
+    const double t2 = A.n2 / A.c2;
+    const double m = dt_wave_min(t1);
+    DtPick r;
+    r.id = -1; r.tie = 0;
+    r.flag = __ballot(A.flag != 0) != 0ull;
     if (!(m < INFINITY)) return r;
-    const unsigned long long who = __ballot(t == m);
-    const int src = (int)__ffsll((long long)who) - 1;
-    r.id = __builtin_amdgcn_readlane(id, src);
+    const unsigned long long who = __ballot(A.b1 >= 0 && t1 == m);
+    r.id = __builtin_amdgcn_readlane(A.b1, (int)__ffsll((long long)who) - 1);
     const double band = kDtTieTol * (fabs(m) + 1.0);
-    // a tie: another lane's best (a different point) or any lane's runner-up within the band
-    const bool close = (t - m <= band && id != r.id && id >= 0) || (t2nd - m <= band);
+    const bool close = (A.b1 >= 0 && A.b1 != r.id && t1 - m <= band) || (t2 - m <= band);
     r.tie = __ballot(close) != 0ull;
     return r;
+}
+
+// cell box of the circle through p, q, c (any orientation), clamped to the grid
+__device__ __forceinline__ DtBox dt_circle_box(const DtGrid &G, double px, double py, double2 q, double2 c) {
+    const double ax = q.x - px, ay = q.y - py, bx = c.x - px, by = c.y - py;
+    const double cr = ax * by - ay * bx, a2 = ax * ax + ay * ay, b2 = bx * bx + by * by;
+    const double inv = 0.5 / cr;
+    const double ox = (by * a2 - ay * b2) * inv, oy = (ax * b2 - bx * a2) * inv;
+    const double r = sqrt(ox * ox + oy * oy) * (1.0 + 1e-12);
+    DtBox B;
+    B.xa = G.cellx(px + ox - r); B.xb = G.cellx(px + ox + r); B.ya = G.celly(py + oy - r); B.yb = G.celly(py + oy + r);
+    if (!(r < INFINITY)) { B.xa = 0; B.xb = G.gx - 1; B.ya = 0; B.yb = G.gy - 1; }      // (NaN / overflow: everything)
+    return B;
+}
+__device__ __forceinline__ DtBox dt_disc_box(const DtGrid &G, double px, double py, double d2) {
+    const double r = sqrt(d2) * (1.0 + 1e-12);
+    DtBox B;
+    B.xa = G.cellx(px - r); B.xb = G.cellx(px + r); B.ya = G.celly(py - r); B.yb = G.celly(py + r);
+    return B;
+}
+__device__ __forceinline__ bool dt_inside(const DtBox &B, const DtBox &blk) {
+    return B.xa >= blk.xa && B.xb <= blk.xb && B.ya >= blk.ya && B.yb <= blk.yb;
+}
+
+__device__ __forceinline__ int dt_incl_scan(int v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v += o; }
+    return v;
 }
 
 __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = blockIdx.x;
-    const int n = a.pts_cnt[f];
+    const int n_in = a.pts_cnt[f];
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    if (n < 3) {
-        if (tid == 0) { a.tri_cnt[f] = 0; a.status[f] = MVOSR_DT_DEGENERATE; }
-        return;
-    }
-    const int64_t off = a.pts_off[f];
-    const uint32_t npad = (uint32_t)((n + 1) & ~1);
-    double2 *P = reinterpret_cast<double2 *>(smem);                                  // {u, v}
-    int *stage = reinterpret_cast<int *>(smem + 16u * npad);                         // [kDtChunk][kDtMaxOwn] packed rows (b | c << 16)
-    uint8_t *own = reinterpret_cast<uint8_t *>(stage + kDtChunk * kDtMaxOwn);        // [kDtChunk] rows owned
-    uint16_t *cand_all = reinterpret_cast<uint16_t *>(own + kDtChunk);               // [kDtWaves][kDtMaxCand]
-    double *red = reinterpret_cast<double *>(smem + ((16u * npad + 4u * kDtChunk * kDtMaxOwn + kDtChunk + 2u * kDtWaves * kDtMaxCand + 15u) & ~15u));
-    int *misc = reinterpret_cast<int *>(red + 8 * kDtWaves);
-    uint16_t *cand = cand_all + w * kDtMaxCand;
+    const DtPlan L = dt_plan(a.max_pts);
+    double2 *S = reinterpret_cast<double2 *>(smem + L.S);
+    uint16_t *oid = reinterpret_cast<uint16_t *>(smem + L.oid);
+    uint16_t *od = reinterpret_cast<uint16_t *>(smem + L.od);
+    uint16_t *astart = reinterpret_cast<uint16_t *>(smem + L.astart);
+    uint32_t *cs = reinterpret_cast<uint32_t *>(smem + L.cs);
+    uint32_t *arena = reinterpret_cast<uint32_t *>(smem + L.arena);
+    uint2 *vq = reinterpret_cast<uint2 *>(smem + L.vq);
+    uint16_t *hard = reinterpret_cast<uint16_t *>(smem + L.hard);
+    uint32_t *wrows = reinterpret_cast<uint32_t *>(smem + L.wrows) + w * kDtWaveRows;
+    double *red = reinterpret_cast<double *>(smem + L.red);
+    int *misc = reinterpret_cast<int *>(smem + L.misc);
 
-    // points -> LDS, bounding box
+    auto decline = [&](int why, int n_used) {
+        if (tid == 0) { a.tri_cnt[f] = 0; a.status[f] = MVOSR_DT_DEGENERATE | (why << 8); if (a.n_used) a.n_used[f] = n_used; }
+    };
+    if (n_in > a.max_pts || n_in < 0) { decline(DT_WHY_SIZE, 0); return; }
+    const int64_t off = a.pts_off[f];
+    const double *gu = a.u + off, *gv = a.v + off;
+    const int32_t *gk = a.keep ? a.keep + off : nullptr;
+
+    // ---- pass 0: survivors per wavefront slice (ids are ranks among the survivors, in order), bounding box
+    const int per = ((n_in + kDtBlock - 1) / kDtBlock) * kWave;          // slice of a wavefront: a multiple of 64
+    const int s_begin = w * per, s_end = min(n_in, s_begin + per);
     double lo_u = INFINITY, hi_u = -INFINITY, lo_v = INFINITY, hi_v = -INFINITY;
-    for (int i = tid; i < n; i += kDtBlock) {
-        double2 p; p.x = a.u[off + i]; p.y = a.v[off + i];
-        P[i] = p;
-        lo_u = fmin(lo_u, p.x); hi_u = fmax(hi_u, p.x); lo_v = fmin(lo_v, p.y); hi_v = fmax(hi_v, p.y);
+    int wcnt = 0;
+    for (int i0 = s_begin; i0 < s_end; i0 += kWave) {
+        const int i = i0 + lane;
+        bool k = i < s_end;
+        if (k && gk) k = gk[i] >= 0;
+        if (k) {
+            const double pu = gu[i], pv = gv[i];
+            lo_u = fmin(lo_u, pu); hi_u = fmax(hi_u, pu); lo_v = fmin(lo_v, pv); hi_v = fmax(hi_v, pv);
+        }
+        wcnt += __popcll(__ballot(k));
     }
     {
-        // block min/max through LDS (one slot per wave and quantity)
-        auto wave_min_d = [&](double x) {
-            x = fmin(x, dpp_mov<kDppXor1>(x)); x = fmin(x, dpp_mov<kDppXor2>(x)); x = fmin(x, dpp_mov<kDppHalfMirror>(x)); x = fmin(x, dpp_mov<kDppMirror>(x));
-            return fmin(fmin(readlane_d(x, 0), readlane_d(x, 16)), fmin(readlane_d(x, 32), readlane_d(x, 48)));
-        };
-        const double a0 = wave_min_d(lo_u), a1 = wave_min_d(-hi_u), a2 = wave_min_d(lo_v), a3 = wave_min_d(-hi_v);
-        if (lane == 0) { red[4 * w] = a0; red[4 * w + 1] = a1; red[4 * w + 2] = a2; red[4 * w + 3] = a3; }
-        if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0; }      // [0] degenerate flag, [1] rows written so far, [2] hull edges
-        __syncthreads();
-        lo_u = INFINITY; hi_u = INFINITY; lo_v = INFINITY; hi_v = INFINITY;
-        for (int i = 0; i < kDtWaves; ++i) { lo_u = fmin(lo_u, red[4 * i]); hi_u = fmin(hi_u, red[4 * i + 1]); lo_v = fmin(lo_v, red[4 * i + 2]); hi_v = fmin(hi_v, red[4 * i + 3]); }
-        hi_u = -hi_u; hi_v = -hi_v;
+        const double a0 = dt_wave_min(lo_u), a1 = dt_wave_min(-hi_u), a2 = dt_wave_min(lo_v), a3 = dt_wave_min(-hi_v);
+        if (lane == 0) { red[4 * w] = a0; red[4 * w + 1] = a1; red[4 * w + 2] = a2; red[4 * w + 3] = a3; misc[DM_WCNT + w] = wcnt; }
+        if (tid < 8) misc[tid] = 0;
     }
-    const double area = fmax((hi_u - lo_u) * (hi_v - lo_v), 1e-300);
-    const double R0 = 4.0 * sqrt(area / (double)n);              // a few average spacings
-    int degenerate = 0, hull_edges = 0;
-    int32_t *rows = a.tri + 3 * a.tri_off[f];
-
-    // one completion: the point c strictly on the side `sgn` of the directed edge p -> q (relative coordinates
-    // a = q - p) that minimises cot(angle pcq); `list` != nullptr: among the candidates, else among all points
-    auto complete = [&](const double2 p, int ip, int iq, double sgn, const uint16_t *list, int nlist) -> DtBest {
-        const double2 qa = P[iq];
-        const double ax = qa.x - p.x, ay = qa.y - p.y;
-        const double la = sqrt(ax * ax + ay * ay);
-        double bt = INFINITY, bt2 = INFINITY;
-        int bid = -1;
-        int flag = 0;
-        const int count = list ? nlist : n;
-        for (int j = lane; j < count; j += kWave) {
-            const int ic = list ? (int)list[j] : j;
-            if (ic == ip || ic == iq) continue;
-            const double2 c = P[ic];
-            const double bx = c.x - p.x, by = c.y - p.y;
-            const double cr = sgn * (ax * by - ay * bx);
-            const double lb = sqrt(bx * bx + by * by);
-            if (fabs(cr) <= kDtTieTol * 1e-3 * la * lb) { if (bx * ax + by * ay > 0.0 || lb == 0.0) flag = 1; continue; }   // (nearly) on the line, ahead of p
-            if (cr <= 0.0) continue;
-            const double t = (bx * (bx - ax) + by * (by - ay)) / cr;
-            if (t < bt) { bt2 = bt; bt = t; bid = ic; } else if (t < bt2) bt2 = t;
-        }
-        DtBest r = dt_wave_best(bt, bid, bt2);
-        r.tie = (r.tie ? 2 : 0) | (__ballot(flag) != 0ull ? 4 : 0);
-        return r;
-    };
-
-    for (int c0 = 0; c0 < n; c0 += kDtChunk) {
-        const int cn = min(kDtChunk, n - c0);
-        for (int i = tid; i < cn; i += kDtBlock) own[i] = 0;
-        __syncthreads();
-        // ---- stars of the chunk's points, one wavefront per point
-        for (int ip = c0 + w; ip < c0 + cn; ip += kDtWaves) {
-            const double2 p = P[ip];
-            double R = R0, Rlist = R0;           // Rlist: the radius the candidate list was actually collected with
-            int ncand = 0, inear = -1;
-            // candidates within R (grown until there are at least 8), nearest neighbour
-            for (int attempt = 0; attempt < 6; ++attempt) {
-                ncand = 0;
-                Rlist = R;
-                double dn = INFINITY; int in_ = -1;
-                const double R2 = R * R;
-                for (int j0 = 0; j0 < n; j0 += kWave) {
-                    const int j = j0 + lane;
-                    bool in = false;
-                    if (j < n && j != ip) {
-                        const double2 c = P[j];
-                        const double dx = c.x - p.x, dy = c.y - p.y, d2 = dx * dx + dy * dy;
-                        in = d2 <= R2;
-                        if (d2 < dn) { dn = d2; in_ = j; }
-                    }
-                    const unsigned long long m = __ballot(in);
-                    const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
-                    if (in && pos < kDtMaxCand) cand[pos] = (uint16_t)j;
-                    ncand += __popcll(m);
-                }
-                // wave argmin of the nearest neighbour
-                double m = dn;
-                m = fmin(m, dpp_mov<kDppXor1>(m)); m = fmin(m, dpp_mov<kDppXor2>(m)); m = fmin(m, dpp_mov<kDppHalfMirror>(m)); m = fmin(m, dpp_mov<kDppMirror>(m));
-                m = fmin(fmin(readlane_d(m, 0), readlane_d(m, 16)), fmin(readlane_d(m, 32), readlane_d(m, 48)));
-                const unsigned long long who = __ballot(dn == m);
-                inear = __builtin_amdgcn_readlane(in_, (int)__ffsll((long long)who) - 1);
-                if (m == 0.0 || __popcll(who) > 1) degenerate |= 1;      // duplicate point / two equally near neighbours
-                if (ncand > kDtMaxCand) { R *= 0.5; continue; }
-                if (ncand >= 8 || ncand >= n - 1) break;
-                R *= 2.0;
-            }
-            if (ncand > kDtMaxCand) ncand = 0;                           // (give up on the list: every completion scans all points)
-            // wrap the star: counter-clockwise from the nearest neighbour, then clockwise if the star is open
-            int nown = 0, deg = 0;
-            for (int dir = 0; dir < 2; ++dir) {
-                const double sgn = dir == 0 ? 1.0 : -1.0;
-                int iq = inear;
-                bool open = false;
-                while (true) {
-                    DtBest b = complete(p, ip, iq, sgn, cand, ncand);
-                    bool redo = b.id < 0;
-                    if (!redo) {
-                        // the circumcircle of (p, q, c) must lie inside the candidates' radius for the answer to be final
-                        const double2 q = P[iq], c = P[b.id];
-                        const double ax = q.x - p.x, ay = q.y - p.y, bx = c.x - p.x, by = c.y - p.y;
-                        const double cr = ax * by - ay * bx, a2 = ax * ax + ay * ay, b2 = bx * bx + by * by;
-                        const double ox = (by * a2 - ay * b2) / (2.0 * cr), oy = (ax * b2 - bx * a2) / (2.0 * cr);
-                        if (!(4.0 * (ox * ox + oy * oy) <= Rlist * Rlist)) redo = true;
-                    }
-                    if (redo) b = complete(p, ip, iq, sgn, nullptr, 0);
-                    if (b.tie) degenerate |= b.tie;
-                    if (b.id < 0) { open = true; ++hull_edges; break; }          // nothing on that side: a hull edge
-                    if (++deg > kDtMaxDeg) { degenerate |= 8; break; }
-                    // the triangle (p, q, c) [dir 0] / (p, c, q) [dir 1] is positively oriented; p writes it when p is its smallest vertex
-                    if (ip < iq && ip < b.id) {
-                        if (nown < kDtMaxOwn) {
-                            if (lane == 0) stage[(ip - c0) * kDtMaxOwn + nown] = dir == 0 ? (iq | (b.id << 16)) : (b.id | (iq << 16));
-                            ++nown;
-                        } else degenerate |= 16;
-                    }
-                    iq = b.id;
-                    if (iq == inear) break;                                       // closed
-                }
-                if (!open) break;                                                 // interior point: one direction closes the star
-                if (dir == 0 && deg == 0) { /* the first edge is a hull edge on its left: go clockwise from it */ }
-            }
-            if (lane == 0) own[ip - c0] = (uint8_t)nown;
-        }
-        __syncthreads();
-        // ---- the chunk's rows in point order: block prefix over own[], then (smallest, b, c)
-        {
-            int mine = 0;
-            const int per = (cn + kDtBlock - 1) / kDtBlock;
-            const int i0 = tid * per, i1 = min(cn, i0 + per);
-            for (int i = i0; i < i1; ++i) mine += own[i];
-            // exclusive scan of `mine` over the block
-            int incl = mine;
-#pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-            int *wsum = misc + 8;
-            if (lane == kWave - 1) wsum[w] = incl;
-            __syncthreads();
-            int base = misc[1];
-            for (int i = 0; i < w; ++i) base += wsum[i];
-            int at = base + incl - mine;
-            for (int i = i0; i < i1; ++i) {
-                const int k = own[i];
-                for (int j = 0; j < k; ++j) {
-                    const int pk = stage[i * kDtMaxOwn + j];
-                    if (at < 2 * n) { rows[3 * at] = c0 + i; rows[3 * at + 1] = pk & 0xFFFF; rows[3 * at + 2] = (pk >> 16) & 0xFFFF; }
-                    ++at;
-                }
-            }
-            __syncthreads();
-            if (tid == kDtBlock - 1) misc[1] = at;                       // (the last thread's end = the chunk's end)
-            __syncthreads();
-        }
-    }
-    // flags / hull count of all wavefronts, Euler's relation
-    if (lane == 0) { if (degenerate) atomicOr(&misc[0], degenerate); atomicAdd(&misc[2], hull_edges); }
     __syncthreads();
-    if (tid == 0) {
-        const int total = misc[1];
-        const int h = misc[2] / 2;                      // every hull edge is met from both of its end points
-        int st = MVOSR_DT_OK;
-        // (bits 8.. say why, for diagnostics: 1 duplicate / equidistant nearest points, 2 cocircular, 4 collinear, 8 degree cap,
-        //  16 rows-per-point cap, 32 Euler's relation)
-        int why = misc[0];
-        if (total != 2 * n - 2 - h || (misc[2] & 1) || total > 2 * n) why |= 32;
-        if (why) st = MVOSR_DT_DEGENERATE | (why << 8);
-        a.tri_cnt[f] = total > 2 * n ? 0 : total;
-        a.status[f] = st;
+    int n = 0, rank_base = 0;
+    lo_u = INFINITY; hi_u = INFINITY; lo_v = INFINITY; hi_v = INFINITY;
+#pragma unroll
+    for (int i = 0; i < kDtWaves; ++i) {
+        const int c = misc[DM_WCNT + i];
+        if (i < w) rank_base += c;
+        n += c;
+        lo_u = fmin(lo_u, red[4 * i]); hi_u = fmin(hi_u, red[4 * i + 1]); lo_v = fmin(lo_v, red[4 * i + 2]); hi_v = fmin(hi_v, red[4 * i + 3]);
+    }
+    hi_u = -hi_u; hi_v = -hi_v;
+    if (n < 3) { decline(DT_WHY_SIZE, n); return; }
+    const double W = hi_u - lo_u, H = hi_v - lo_v;
+    if (!(W > 0.0 && H > 0.0 && W < INFINITY && H < INFINITY)) { decline(DT_WHY_COLLINEAR, n); return; }   // (also NaN coordinates)
+
+    // ---- the grid
+    DtGrid G;
+    {
+        const double s = sqrt(W * H * kDtPerCell / (double)n);
+        double fx = ceil(W / s), fy = ceil(H / s);
+        fx = fmin(fmax(fx, 1.0), (double)L.max_cells); fy = fmin(fmax(fy, 1.0), (double)L.max_cells);
+        if (fx * fy > (double)L.max_cells) {
+            const double k = sqrt((double)L.max_cells / (fx * fy));
+            fx = fmax(1.0, floor(fx * k)); fy = fmax(1.0, floor(fy * k));
+            while (fx * fy > (double)L.max_cells) { if (fx >= fy) fx -= 1.0; else fy -= 1.0; }
+        }
+        G.gx = (int)fx; G.gy = (int)fy;
+        G.lo_u = lo_u; G.lo_v = lo_v; G.ix = fx / W; G.iy = fy / H; G.cs = cs;
+    }
+    const int ncell = G.gx * G.gy;
+    for (int c = tid; c <= ncell; c += kDtBlock) cs[c] = 0u;
+    for (int i = tid; i < ((n + 1) >> 1); i += kDtBlock) reinterpret_cast<uint32_t *>(od)[i] = 0u;
+    __syncthreads();
+
+    // ---- pass 1: points per cell
+    for (int i0 = s_begin; i0 < s_end; i0 += kWave) {
+        const int i = i0 + lane;
+        bool k = i < s_end;
+        if (k && gk) k = gk[i] >= 0;
+        if (k) atomicAdd(&cs[G.celly(gv[i]) * G.gx + G.cellx(gu[i])], 1u);
+    }
+    __syncthreads();
+    // exclusive scan over the cells (cs[c] = start of cell c; pass 2 advances it to the cell's end)
+    {
+        const int cper = (ncell + kDtBlock - 1) / kDtBlock;
+        const int c0 = tid * cper, c1 = min(ncell, c0 + cper);
+        int mine = 0;
+        for (int c = c0; c < c1; ++c) mine += (int)cs[c];
+        const int incl = dt_incl_scan(mine);
+        if (lane == kWave - 1) misc[DM_WSUM + w] = incl;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < kDtWaves; ++i) if (i < w) base += misc[DM_WSUM + i];
+        int at = base + incl - mine;
+        for (int c = c0; c < c1; ++c) { const int k = (int)cs[c]; cs[c] = (uint32_t)at; at += k; }
+    }
+    __syncthreads();
+    // ---- pass 2: scatter (the order inside a cell is whatever the atomics give: no output depends on it)
+    {
+        int rank = rank_base;
+        for (int i0 = s_begin; i0 < s_end; i0 += kWave) {
+            const int i = i0 + lane;
+            bool k = i < s_end;
+            if (k && gk) k = gk[i] >= 0;
+            const unsigned long long m = __ballot(k);
+            if (k) {
+                double2 p; p.x = gu[i]; p.y = gv[i];
+                const int pos = (int)atomicAdd(&cs[G.celly(p.y) * G.gx + G.cellx(p.x)], 1u);
+                S[pos] = p;
+                oid[pos] = (uint16_t)(rank + __popcll(m & ((1ull << lane) - 1ull)));
+            }
+            rank += __popcll(m);
+        }
+    }
+    __syncthreads();
+
+    int degenerate = 0;
+    // ---- phase 1: one lane per point
+    for (int i0 = 0; i0 < n; i0 += kDtBlock) {
+        const int i = i0 + tid;
+        int nown = 0, deg = 0, state = 0;          // state: 0 ok, 1 hard
+        uint32_t rows[kDtLaneRows];
+#pragma unroll
+        for (int k = 0; k < kDtLaneRows; ++k) rows[k] = 0xFFFFFFFFu;
+        int oi = 0;
+        if (i < n) {
+            const double2 p = S[i];
+            oi = oid[i];
+            const int cx = G.cellx(p.x), cy = G.celly(p.y);
+            DtBox blk;
+            blk.xa = max(cx - kDtR, 0); blk.xb = min(cx + kDtR, G.gx - 1); blk.ya = max(cy - kDtR, 0); blk.yb = min(cy + kDtR, G.gy - 1);
+            // nearest neighbour: a Delaunay neighbour, if its disc lies within the block
+            double bd = INFINITY;
+            int q0 = -1;
+            for (int y = blk.ya; y <= blk.yb; ++y) {
+                const int j1 = G.row_end(y, blk.xb);
+                for (int j = G.row_begin(y, blk.xa); j < j1; ++j) {
+                    const double2 c = S[j];
+                    const double dx = c.x - p.x, dy = c.y - p.y, d2 = dx * dx + dy * dy;
+                    if (j != i && d2 < bd) { bd = d2; q0 = j; }
+                }
+            }
+            if (q0 >= 0 && bd == 0.0) degenerate |= DT_WHY_DUP;
+            if (q0 < 0 || !dt_inside(dt_disc_box(G, p.x, p.y, bd), blk)) state = 1;
+            int iq = q0;
+            while (state == 0) {
+                const double2 q = S[iq];
+                const double ax = q.x - p.x, ay = q.y - p.y;
+                DtAcc A;
+                A.reset();
+                dt_scan_box<false>(A, S, G, blk, i, iq, p.x, p.y, ax, ay, kDtColTol * kDtColTol * (ax * ax + ay * ay), 1.0);
+                if (A.flag) degenerate |= DT_WHY_COLLINEAR;
+                if (A.b1 < 0) { state = 1; break; }                       // open within the block
+                if (dt_acc_tie(A)) degenerate |= DT_WHY_TIE;
+                const int ic = A.b1;
+                if (!dt_inside(dt_circle_box(G, p.x, p.y, q, S[ic]), blk)) {
+                    // the circumcircle leaves the block: go on, a wavefront checks the completion afterwards
+                    const int pos = atomicAdd(&misc[DM_VQ], 1);
+                    if (pos >= kDtVq) { state = 1; break; }
+                    uint2 e; e.x = (uint32_t)i | ((uint32_t)iq << 16); e.y = (uint32_t)ic;
+                    vq[pos] = e;
+                }
+                if (++deg > kDtLaneDeg) { state = 1; break; }
+                const int oq = oid[iq], oc = oid[ic];
+                if (oi < oq && oi < oc) {
+                    if (nown == kDtLaneRows) { state = 1; break; }
+                    uint32_t key = ((uint32_t)min(oq, oc) << 16) | (uint32_t)max(oq, oc);
+#pragma unroll
+                    for (int k = 0; k < kDtLaneRows; ++k) { const uint32_t lo = min(key, rows[k]), hi = max(key, rows[k]); rows[k] = lo; key = hi; }
+                    ++nown;
+                }
+                iq = ic;
+                if (iq == q0) break;
+            }
+            if (state) {
+                nown = 0;
+                const int pos = atomicAdd(&misc[DM_NHARD], 1);
+                if (pos < kDtHardCap) hard[pos] = (uint16_t)i; else degenerate |= DT_WHY_HARD;
+            }
+        }
+        // the wavefront's rows go to the arena together
+        const int incl = dt_incl_scan(nown);
+        int base = 0;
+        if (lane == kWave - 1 && incl > 0) base = atomicAdd(&misc[DM_ARENA], incl);
+        base = __shfl(base, kWave - 1);
+        const int total = __shfl(incl, kWave - 1);
+        if (base + total > L.arena_cap) { degenerate |= DT_WHY_ROWS; }
+        else if (i < n && state == 0) {
+            const int at = base + incl - nown;
+#pragma unroll
+            for (int k = 0; k < kDtLaneRows; ++k) if (k < nown) arena[at + k] = rows[k];
+            od[oi] = (uint16_t)(nown | (deg << 6));
+            astart[oi] = (uint16_t)at;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1b: queued completions, one wavefront each
+    {
+        const int nreq = min(misc[DM_VQ], kDtVq);
+        for (int r = w; r < nreq; r += kDtWaves) {
+            const uint2 e = vq[r];
+            const int i = (int)(e.x & 0xFFFFu), iq = (int)(e.x >> 16), ic = (int)e.y;
+            const double2 p = S[i], q = S[iq];
+            const double ax = q.x - p.x, ay = q.y - p.y;
+            const DtBox B = dt_circle_box(G, p.x, p.y, q, S[ic]);
+            DtAcc A;
+            A.reset();
+            dt_scan_box<true>(A, S, G, B, i, iq, p.x, p.y, ax, ay, kDtColTol * kDtColTol * (ax * ax + ay * ay), 1.0);
+            const DtPick pk = dt_wave_pick(A);
+            if (pk.flag) degenerate |= DT_WHY_COLLINEAR;
+            if (pk.id == ic) { if (pk.tie) degenerate |= DT_WHY_TIE; }
+            else if (lane == 0) {
+                const int oi = oid[i];
+                const uint32_t bit = 0x4000u << ((oi & 1) * 16);
+                const uint32_t old = atomicOr(reinterpret_cast<uint32_t *>(od) + (oi >> 1), bit);
+                if (!(old & bit)) {
+                    const int pos = atomicAdd(&misc[DM_NHARD], 1);
+                    if (pos < kDtHardCap) hard[pos] = (uint16_t)i; else degenerate |= DT_WHY_HARD;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: hard points, one wavefront each
+    {
+        const int nh = min(misc[DM_NHARD], kDtHardCap);
+        const DtBox all = {0, G.gx - 1, 0, G.gy - 1};
+        for (int h = w; h < nh; h += kDtWaves) {
+            const int i = hard[h];
+            const double2 p = S[i];
+            const int oi = oid[i];
+            const int cx = G.cellx(p.x), cy = G.celly(p.y);
+            DtBox blk;
+            blk.xa = max(cx - kDtR, 0); blk.xb = min(cx + kDtR, G.gx - 1); blk.ya = max(cy - kDtR, 0); blk.yb = min(cy + kDtR, G.gy - 1);
+            // nearest neighbour (block, then everything)
+            int q0 = -1;
+            double dmin = INFINITY;
+            for (int pass = 0; pass < 2; ++pass) {
+                const DtBox &B = pass ? all : blk;
+                double bd = INFINITY;
+                int bq = -1;
+                for (int y = B.ya; y <= B.yb; ++y) {
+                    const int j1 = G.row_end(y, B.xb);
+                    for (int j = G.row_begin(y, B.xa) + lane; j < j1; j += kWave) {
+                        const double2 c = S[j];
+                        const double dx = c.x - p.x, dy = c.y - p.y, d2 = dx * dx + dy * dy;
+                        if (j != i && d2 < bd) { bd = d2; bq = j; }
+                    }
+                }
+                dmin = dt_wave_min(bd);
+                q0 = -1;
+                if (dmin < INFINITY) {
+                    const unsigned long long who = __ballot(bq >= 0 && bd == dmin);
+                    q0 = __builtin_amdgcn_readlane(bq, (int)__ffsll((long long)who) - 1);
+                }
+                if (q0 >= 0 && dt_inside(dt_disc_box(G, p.x, p.y, dmin), B)) break;
+            }
+            if (q0 < 0) { degenerate |= DT_WHY_EULER; continue; }
+            if (dmin == 0.0) { degenerate |= DT_WHY_DUP; continue; }
+            int nrows = 0, deg = 0, open = 0, bad = 0;
+            for (int dir = 0; dir < 2 && !bad; ++dir) {
+                const double sgn = dir ? -1.0 : 1.0;
+                int iq = q0;
+                while (true) {
+                    const double2 q = S[iq];
+                    const double ax = q.x - p.x, ay = q.y - p.y;
+                    const double a2col = kDtColTol * kDtColTol * (ax * ax + ay * ay);
+                    DtAcc A;
+                    A.reset();
+                    dt_scan_box<true>(A, S, G, blk, i, iq, p.x, p.y, ax, ay, a2col, sgn);
+                    DtPick pk = dt_wave_pick(A);
+                    if (pk.id < 0 || !dt_inside(dt_circle_box(G, p.x, p.y, q, S[max(pk.id, 0)]), blk)) {
+                        // nothing on that side within the block, or a circumcircle that leaves it: search the circle's
+                        // cell box, or the whole frame
+                        const DtBox B = pk.id < 0 ? all : dt_circle_box(G, p.x, p.y, q, S[pk.id]);
+                        A.reset();
+                        dt_scan_box<true>(A, S, G, B, i, iq, p.x, p.y, ax, ay, a2col, sgn);
+                        pk = dt_wave_pick(A);
+                    }
+                    if (pk.flag) degenerate |= DT_WHY_COLLINEAR;
+                    if (pk.id < 0) { open = 1; break; }                    // a hull edge
+                    if (pk.tie) degenerate |= DT_WHY_TIE;
+                    if (++deg > kDtWaveDeg) { degenerate |= DT_WHY_DEGREE; bad = 1; break; }
+                    const int oq = oid[iq], oc = oid[pk.id];
+                    if (oi < oq && oi < oc) {
+                        if (nrows == kDtWaveRows) { degenerate |= DT_WHY_ROWS; bad = 1; break; }
+                        if (lane == 0) wrows[nrows] = ((uint32_t)min(oq, oc) << 16) | (uint32_t)max(oq, oc);
+                        ++nrows;
+                    }
+                    iq = pk.id;
+                    if (iq == q0) break;                                   // closed
+                }
+                if (!open) break;
+            }
+            if (bad) continue;
+            // the point's rows, sorted (rank by counting), to the arena
+            int base = 0;
+            if (lane == 0 && nrows > 0) base = atomicAdd(&misc[DM_ARENA], nrows);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + nrows > L.arena_cap) { degenerate |= DT_WHY_ROWS; continue; }
+            if (lane < nrows) {
+                const uint32_t key = wrows[lane];
+                int rank = 0;
+                for (int k = 0; k < nrows; ++k) rank += wrows[k] < key ? 1 : 0;
+                arena[base + rank] = key;
+            }
+            if (lane == 0) {
+                od[oi] = (uint16_t)(nrows | (deg << 6) | (open << 15));
+                astart[oi] = (uint16_t)base;
+            }
+        }
+    }
+    if (degenerate) atomicOr(&misc[DM_FLAGS], degenerate);
+    __syncthreads();
+
+    // ---- rows in point order: block prefix over the points' row counts; Euler's relation
+    {
+        const int pper = (n + kDtBlock - 1) / kDtBlock;
+        const int o0 = tid * pper, o1 = min(n, o0 + pper);
+        int mine = 0, sdeg = 0, hull = 0;
+        for (int o = o0; o < o1; ++o) { const int d = od[o]; mine += d & 63; sdeg += (d >> 6) & 63; hull += (d >> 15) & 1; }
+        const int incl = dt_incl_scan(mine);
+        const int wdeg = wave_sum(sdeg), whull = wave_sum(hull);
+        if (lane == kWave - 1) misc[DM_WSUM + w] = incl;
+        if (lane == 0) { misc[DM_WSUM2 + w] = wdeg; misc[DM_WSUM3 + w] = whull; }
+        __syncthreads();
+        int base = 0, total = 0, tdeg = 0, thull = 0;
+#pragma unroll
+        for (int i = 0; i < kDtWaves; ++i) {
+            const int c = misc[DM_WSUM + i];
+            if (i < w) base += c;
+            total += c; tdeg += misc[DM_WSUM2 + i]; thull += misc[DM_WSUM3 + i];
+        }
+        int why = misc[DM_FLAGS];
+        if (total != 2 * n - 2 - thull || tdeg != 3 * total) why |= DT_WHY_EULER;
+        if (why) { decline(why, n); return; }
+        int32_t *rows = a.tri + 3 * a.tri_off[f];
+        int at = base + incl - mine;
+        for (int o = o0; o < o1; ++o) {
+            const int k = od[o] & 63;
+            const uint32_t *src = arena + astart[o];
+            for (int j = 0; j < k; ++j) {
+                const uint32_t key = src[j];
+                rows[3 * at] = o; rows[3 * at + 1] = (int32_t)(key >> 16); rows[3 * at + 2] = (int32_t)(key & 0xFFFFu);
+                ++at;
+            }
+        }
+        if (tid == 0) { a.tri_cnt[f] = total; a.status[f] = MVOSR_DT_OK; if (a.n_used) a.n_used[f] = n; }
     }
 }
 
@@ -276,23 +572,34 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
 
 using namespace mvosr;
 
+extern "C" int mvosr_delaunay_max_points(void) {
+    int lo = 3, hi = 65535;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (dt_plan(mid).total <= 160u * 1024u) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 extern "C" int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
-                                    const double *u, const double *v, int max_pts, const int64_t *tri_off, int32_t *tri,
-                                    int32_t *tri_cnt, int32_t *status) {
+                                    const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
+                                    int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status) {
     if (!ctx || !pts_off || !pts_cnt || !u || !v || !tri_off || !tri || !tri_cnt || !status)
         return set_error(MVOSR_ERR_ARG, "delaunay_batch: null argument");
-    if (max_pts < 0 || max_pts > 65535) return set_error(MVOSR_ERR_TOO_LARGE, "delaunay_batch: at most 65535 points per frame");
+    if (max_pts < 0) return set_error(MVOSR_ERR_ARG, "delaunay_batch: max_pts < 0");
     if (n_frames <= 0) return MVOSR_OK;
     int rc = ctx_activate(ctx);
     if (rc) return rc;
-    const uint32_t npad = (uint32_t)((max_pts + 1) & ~1);
-    const size_t lds = ((16u * npad + 4u * kDtChunk * kDtMaxOwn + kDtChunk + 2u * kDtWaves * kDtMaxCand + 15u) & ~15u) + 8u * 8u * kDtWaves + 4u * 32u;
-    if (lds > 160u * 1024u) return set_error(MVOSR_ERR_TOO_LARGE, "delaunay_batch: %d points need %zu B of LDS", max_pts, lds);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(delaunay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (max_pts < 3) max_pts = 3;
+    const DtPlan L = dt_plan(max_pts);
+    if (max_pts > 65535 || L.total > 160u * 1024u)
+        return set_error(MVOSR_ERR_TOO_LARGE, "delaunay_batch: %d points per frame need %u B of LDS (limit: %d points)", max_pts, L.total,
+                         mvosr_delaunay_max_points());
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(delaunay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
     if (e != hipSuccess) return set_hip_error("hipFuncSetAttribute(delaunay_kernel)", e);
     DtArgs a;
-    a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.tri_off = tri_off; a.tri = tri;
-    a.tri_cnt = tri_cnt; a.status = status;
-    hipLaunchKernelGGL(delaunay_kernel, dim3((unsigned)n_frames), dim3(kDtBlock), lds, ctx_stream(ctx), a);
+    a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
+    a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.max_pts = max_pts;
+    hipLaunchKernelGGL(delaunay_kernel, dim3((unsigned)n_frames), dim3(kDtBlock), L.total, ctx_stream(ctx), a);
     return check_launch("delaunay_kernel");
 }

@@ -96,6 +96,22 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *slot) {
         a = ta; b = tb;
     }
 }
+// three sums at once: (a, b) through `slot`, c through `slot_c` (WAVES doubles, another site's unused scratch)
+template <int WAVES>
+__device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *slot, double *slot_c) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    if constexpr (WAVES > 1) {
+        const int w = wave_id();
+        if (lane_id() == 0) { slot[2 * w] = a; slot[2 * w + 1] = b; slot_c[w] = c; }
+        __syncthreads();
+        double ta = 0.0, tb = 0.0, tc = 0.0;
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) { ta += slot[2 * i]; tb += slot[2 * i + 1]; tc += slot_c[i]; }
+        a = ta; b = tb; c = tc;
+    }
+}
 // four int counters at once (`slot` reinterpreted: 4*WAVES ints = 2*WAVES doubles)
 template <int WAVES>
 __device__ __forceinline__ void block_sum4i(int &a, int &b, int &c, int &d, double *slot_d) {

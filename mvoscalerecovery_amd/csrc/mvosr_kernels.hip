@@ -56,7 +56,7 @@ struct LdsPlan {
 };
 __host__ __device__ inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 constexpr int kRedSlots = 6;                       // one scratch slot per block reduction site
-enum { R_SEL_H = 0, R_SEL_CNT = 1, R_ROAD_N = 2, R_ROAD_SUM = 3, R_ROAD_SS = 4, R_MISC = 5 };
+enum { R_SEL_H = 0, R_SEL_CNT = 1, R_SEL_ABS = 2, R_ROAD_SUM = 3, R_ROAD_SS = 4, R_MISC = 5 };
 __host__ __device__ inline LdsPlan lds_plan(int n, int waves) {
     LdsPlan p;
     const uint32_t npad = (uint32_t)((n + 1) & ~1);
@@ -143,6 +143,22 @@ struct TriChunk {
     }
 };
 
+// The three vertices' flags from check_triangle's three pair tests (:110-118).  fixed == false: the reference's own
+// pattern — the (0,2) test marks vertices 0 and 1 (:113-115); true (mvosr_params.vote_mode == MVOSR_VOTE_FIXED): it marks
+// 0 and 2, so that a vertex is flagged iff one of its two pair tests fails, whatever the order of the row's vertices.
+// `fixed` is uniform: the two extra terms are scalar mask operations.
+struct VoteFlags { bool f0, f1, f2; };
+__device__ __forceinline__ VoteFlags vote_flags(bool pa, bool pb, bool pc, bool fixed) {
+    const bool pb1 = pb & !fixed, pb2 = pb & fixed;
+    VoteFlags r;
+    r.f0 = pa | pb; r.f1 = pa | pb1 | pc; r.f2 = pb2 | pc;
+    return r;
+}
+// rows of frame f in a triangulation given by offsets (+ optional explicit counts: device-built triangulations)
+__device__ __forceinline__ int tri_rows(const int64_t *off, const int32_t *cnt, int64_t f) {
+    return cnt ? cnt[f] : (int)(off[f + 1] - off[f]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Phase A: stage {v, z'}, y' and run the depth-order vote over the first triangulation; then the
 // survivors are moved down in place (order kept) with x taking v's slot, so that the second
@@ -156,7 +172,7 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
                                           const double *gv, const int32_t *tri1, int64_t t1_begin, int t1_count,
                                           double cp, double sp, int32_t *g_counters, int &bad,
                                           const int32_t *tri2, int64_t t2_begin, int t2_count, TriChunk<WAVES * kWave> &next,
-                                          int dbg = 0 MVOSR_STAMP_ARG) {
+                                          bool fixed, int dbg = 0 MVOSR_STAMP_ARG) {
     constexpr int B = WAVES * kWave;
     const int tid = threadIdx.x;
     const int npad2 = (n + 1) >> 1;
@@ -222,9 +238,10 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
             const TriIds q = tc.q[k];
             const double2 p0 = vp[k][0], p1 = vp[k][1], p2 = vp[k][2];
             const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
-            const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
+            const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does — unless `fixed`)
             const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
-            const bool f0 = pa | pb, f1 = pa | pb | pc, f2 = pc;
+            const VoteFlags vf = vote_flags(pa, pb, pc, fixed);
+            const bool f0 = vf.f0, f1 = vf.f1, f2 = vf.f2;
             // one wrap-around add per vertex: +-1 in the vertex's 16-bit half (the halves stay in
             // [1, 0xFFFE], so a -1 never borrows across them)
             // (-1 << 16 = 0xFFFF0000 = -(1 << 16): the sign is chosen first, then shifted into the vertex's half)
@@ -548,9 +565,11 @@ struct LdsFetch {            // rows of tri2 index the compacted survivors in LD
     }
 };
 
-// |h - level| within this relative distance: the comparison h > level (:243) may depend on the summation order behind
-// the level, so the level is recomputed in NumPy's order before it is trusted (the sweep's own sum agrees with NumPy's
-// to ~1e-15 relative)
+// |h - level| within this distance, RELATIVE TO THE MEAN MAGNITUDE OF WHAT WAS SUMMED (sum |h| / count, not |level|: the
+// rounding error of a sum scales with the magnitudes of its terms, and steep triangles above and below the camera can
+// cancel to a level near zero): the comparison h > level (:243) may depend on the summation order behind the level, so
+// the level is recomputed in NumPy's order before it is trusted (the sweep's own sum agrees with NumPy's to ~1e-15 of
+// that magnitude)
 constexpr double kLevelGuard = 1e-12;
 
 template <int WAVES, int MODE, int FW = 1>
@@ -563,7 +582,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     const int tid = threadIdx.x;
     unsigned long long flat = 0ull;          // bit kk: my kk-th triangle has pitch_deg < thr
     unsigned long long flat_hi = 0ull;       // bits 64..127 (FW == 2: dense frames, up to 128 triangles per thread)
-    double hsum = 0.0, hcnt = 0.0;
+    double hsum = 0.0, hcnt = 0.0, habs = 0.0;
     int npitch = 0, singular = 0, bad = 0;
     // more rows than the per-thread flag words can name (not a triangulation of this frame's points): refuse
     if (t2_count > 64 * FW * B) { bad = 1; t2_count = 0; }
@@ -580,7 +599,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     const int r = classify_triangle<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, h, pt, g_normals, g_pitch, g_heights, t2_begin + t);
     const bool is_flat = r & 1, is_steep = r & 2;
     if (r & 4) singular = 1;
-    if (is_steep) { hsum += h; hcnt += 1.0; }                                            // :240
+    if (is_steep) { hsum += h; hcnt += 1.0; if constexpr (MODE == MODE_HOT) habs += fabs(h); }     // :240
     if (is_flat) {
         if (FW == 1 || kk < 64) flat |= 1ull << (kk & 63); else flat_hi |= 1ull << (kk & 63);
         ++npitch;
@@ -605,10 +624,12 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     const int t2d = (dbg & 4) ? 0 : t2_count;
     const bool in_regs = t2_count <= kTC * B;
     if (!in_regs && t2d > 0) tc.template load<true>(tri2, t2_begin, t2_count, 0, tid);
-    block_sum2<WAVES>(hsum, hcnt, s.red + R_SEL_H * 2 * WAVES);
+    if constexpr (MODE == MODE_HOT) block_sum3<WAVES>(hsum, hcnt, habs, s.red + R_SEL_H * 2 * WAVES, s.red + R_SEL_ABS * 2 * WAVES);
+    else block_sum2<WAVES>(hsum, hcnt, s.red + R_SEL_H * 2 * WAVES);
     MVOSR_STAMP(4);
     SelectResult r;
     double hl = hsum / hcnt;                      // np.mean of an empty set -> 0/0 = NaN, like :240.  (HOT: the mean of 3h)
+    const double guard = kLevelGuard * (habs / hcnt);
     if constexpr (MODE != MODE_HOT)
         hl = exact_height_level<FULL>(tri2 + 3 * t2_begin, t2_count, (int)hcnt, pt, LdsFetch{s.P, s.Y, n_valid});
     int ntv = 0, near = 0;
@@ -617,7 +638,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
         if (!((fw >> (kk & 63)) & 1ull)) return;
         const double y0 = s.Y[qa], y1 = s.Y[qb], y2 = s.Y[qc];
         const double h = MODE == MODE_HOT ? (y0 + y1) + y2 : div3((y0 + y1) + y2);           // HOT: 3h against 3 * level
-        if constexpr (MODE == MODE_HOT) { if (fabs(h - hl) <= kLevelGuard * fabs(hl)) near = 1; }
+        if constexpr (MODE == MODE_HOT) { if (fabs(h - hl) <= guard) near = 1; }
         if (h > hl) {                                                                        // :243-244
             ++ntv;
             atomicOr(&s.sel[qa >> 5], 1u << (qa & 31));                                      // :247
@@ -1130,10 +1151,12 @@ __device__ __forceinline__ void write_counts(const KArgs &a, int64_t f, int nval
 // triangulation and the scale comes from the previous frame's height_level (:420-422) — a cross-frame
 // quantity, resolved by the host's push step from the MVOSR_ST_TOO_FEW status.
 __device__ __forceinline__ bool early_frame_exit(const KArgs &a, int64_t f, int n, int t2n) {
-    const bool too_few = n >= 1 && n <= 3;
+    // (exactly 3: with 1 or 2 points the reference's first Delaunay call raises QhullError at :257 — the host path reports
+    // that from its own call; a C-ABI caller gets MVOSR_ST_ERR_EMPTY, never a silent scale)
+    const bool too_few = n == 3;
     // a frame larger than the batch header says (max_feat sized this launch's LDS and variant): refused, not processed
     const bool oversize = n > a.b.max_feat;
-    if (!(n <= 0 || too_few || t2n <= 0 || oversize)) return false;
+    if (!(n <= 2 || too_few || t2n <= 0 || oversize)) return false;
     if (threadIdx.x == 0) {
         RoadResult R;
         R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
@@ -1245,7 +1268,7 @@ __global__ __launch_bounds__(WAVES *kWave, (WAVES == 8 && MODE == MODE_HOT ? MVO
     const int n = a.b.feat_cnt[f];
     const int64_t off = a.b.feat_off[f];
     const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
-    const int t1n = (int)(a.b.tri1_off[f + 1] - t1b), t2n = (int)(a.b.tri2_off[f + 1] - t2b);
+    const int t1n = tri_rows(a.b.tri1_off, a.b.tri1_cnt, f), t2n = tri_rows(a.b.tri2_off, a.b.tri2_cnt, f);
     const Smem s = carve(smem, n, WAVES);
     MVOSR_STAMP_DECL
     MVOSR_STAMP(0);
@@ -1259,7 +1282,7 @@ __global__ __launch_bounds__(WAVES *kWave, (WAVES == 8 && MODE == MODE_HOT ? MVO
     const int nvalid = phase_vote<WAVES, SC>(s, n, a.b.x + off, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
                                              a.P.cos_pitch, a.P.sin_pitch,
                                              a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad,
-                                             a.b.tri2, t2b, t2n, tc2, a.debug_skip MVOSR_STAMP_PASS);
+                                             a.b.tri2, t2b, t2n, tc2, a.P.vote_mode == MVOSR_VOTE_FIXED, a.debug_skip MVOSR_STAMP_PASS);
     const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
 
     SelectResult S;
@@ -1297,7 +1320,7 @@ template <int DW, bool FUSED>
 __device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n, const double *gx, const double *gy, const double *gz,
                                                 const double *gv, const int32_t *tri1, int64_t t1_begin, int t1_count,
                                                 double cp, double sp, int32_t *g_counters, int &bad,
-                                                double2 *P2, double *Y2) {
+                                                double2 *P2, double *Y2, bool fixed) {
     constexpr int B = DW * kWave;
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
     const uint16_t *c16 = reinterpret_cast<const uint16_t *>(c32);
@@ -1318,7 +1341,8 @@ __device__ __forceinline__ int phase_vote_dense(uint32_t *c32, int *misc, int n,
         const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
         const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
         const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
-        const bool f0 = pa | pb, f1 = pa | pb | pc, f2 = pc;
+        const VoteFlags vf = vote_flags(pa, pb, pc, fixed);
+        const bool f0 = vf.f0, f1 = vf.f1, f2 = vf.f2;
         const int s0 = (q.a & 1) * 16, s1 = (q.b & 1) * 16, s2 = (q.c & 1) * 16;
         const uint32_t u0 = 1u << s0, u1 = 1u << s1, u2 = 1u << s2;
         if (!checked) {
@@ -1385,7 +1409,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const Den
     const int n = a.b.feat_cnt[f];
     const int64_t off = a.b.feat_off[f];
     const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
-    const int t1n = (int)(a.b.tri1_off[f + 1] - t1b), t2n = (int)(a.b.tri2_off[f + 1] - t2b);
+    const int t1n = tri_rows(a.b.tri1_off, a.b.tri1_cnt, f), t2n = tri_rows(a.b.tri2_off, a.b.tri2_cnt, f);
     RoadResult R;
     R.height = nan(""); R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
     R.mean = R.std = R.skew = R.median = nan("");
@@ -1404,7 +1428,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const Den
     int bad = 0;
     const int nvalid = phase_vote_dense<DW, true>(s.c32, s.misc, n, a.b.x + off, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
                                               a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad,
-                                              da.ws.P2 + off, da.ws.Y2 + off);
+                                              da.ws.P2 + off, da.ws.Y2 + off, a.P.vote_mode == MVOSR_VOTE_FIXED);
     const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
     SelectResult S;
     S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 1; S.n_steep = 0; S.near = 0;
@@ -1438,7 +1462,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
     const int n = a.b.feat_cnt[f];
     const int64_t off = a.b.feat_off[f];
     const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
-    const int t1n = (int)(a.b.tri1_off[f + 1] - t1b), t2n = (int)(a.b.tri2_off[f + 1] - t2b);
+    const int t1n = tri_rows(a.b.tri1_off, a.b.tri1_cnt, f), t2n = tri_rows(a.b.tri2_off, a.b.tri2_cnt, f);
     RoadResult R;
     R.height = nan(""); R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
     R.mean = R.std = R.skew = R.median = nan("");
@@ -1454,7 +1478,8 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
     for (int i = tid; i < (n + 31) / 32; i += B) sel[i] = 0u;
     int bad = 0;
     const int nvalid = phase_vote_dense<DW, false>(c32, misc, n, nullptr, gy, gz, a.b.v + off, a.b.tri1, t1b, t1n, cp, sp,
-                                                   a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad, nullptr, nullptr);
+                                                   a.o.vote_counters ? a.o.vote_counters + off : nullptr, bad, nullptr, nullptr,
+                                                   a.P.vote_mode == MVOSR_VOTE_FIXED);
     const bool mask_mismatch = a.b.n2_expected && a.b.n2_expected[f] != nvalid;
     SelectResult S;
     S.height_level = nan(""); S.n_pitch = S.n_tri_valid = 0; S.singular = 0; S.bad = 1; S.n_steep = 0; S.near = 0;
@@ -1473,7 +1498,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
     };
     if (!mask_mismatch) {
         unsigned long long flat = 0ull, flat_hi = 0ull;      // bit kk: my kk-th triangle has pitch_deg < thr
-        double hsum = 0.0, hcnt = 0.0;
+        double hsum = 0.0, hcnt = 0.0, habs = 0.0;
         int npitch = 0, singular = 0, ntv = 0, near = 0;
         if (t2n > 128 * B) bad = 1;                          // more rows than the per-thread flag words can name
         const int t2s = bad ? 0 : t2n;
@@ -1489,7 +1514,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
             const int r = classify_triangle<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, h, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
                                                   a.o.tri_heights, t2b + base + tid);
             if (r & 4) singular = 1;
-            if (r & 2) { hsum += h; hcnt += 1.0; }                                               // :240
+            if (r & 2) { hsum += h; hcnt += 1.0; if constexpr (MODE == MODE_HOT) habs += fabs(h); }     // :240
             if (r & 1) {
                 if (kk < 64) flat |= 1ull << (kk & 63); else flat_hi |= 1ull << (kk & 63);
                 ++npitch;
@@ -1497,8 +1522,10 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
         }
         cur = {0, 0, 0};
         if (tid < t2s) cur = load_tri(tri, tid);
-        block_sum2<DW>(hsum, hcnt, red + R_SEL_H * 2 * DW);
+        if constexpr (MODE == MODE_HOT) block_sum3<DW>(hsum, hcnt, habs, red + R_SEL_H * 2 * DW, red + R_SEL_ABS * 2 * DW);
+        else block_sum2<DW>(hsum, hcnt, red + R_SEL_H * 2 * DW);
         double hl = hsum / hcnt;                      // np.mean of an empty set -> 0/0 = NaN, like :240
+        const double guard = kLevelGuard * (habs / hcnt);
         if constexpr (MODE != MODE_HOT) hl = exact_height_level<FULL>(tri, t2s, (int)hcnt, a.pt, fetch);
         for (int base = 0, kk = 0; base < t2s; base += B, ++kk) {
             const TriIds q = cur;
@@ -1507,7 +1534,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
             if (base + tid < t2s && ((fw >> (kk & 63)) & 1ull)) {
                 const double y0 = gy[q.a] * cp - gz[q.a] * sp, y1 = gy[q.b] * cp - gz[q.b] * sp, y2 = gy[q.c] * cp - gz[q.c] * sp;
                 const double h = div3((y0 + y1) + y2);
-                if constexpr (MODE == MODE_HOT) { if (fabs(h - hl) <= kLevelGuard * fabs(hl)) near = 1; }
+                if constexpr (MODE == MODE_HOT) { if (fabs(h - hl) <= guard) near = 1; }
                 if (h > hl) {                                                                    // :243-244
                     ++ntv;
                     atomicOr(&sel[q.a >> 5], 1u << (q.a & 31));                                  // :247
@@ -1655,6 +1682,7 @@ template <int DW>
 __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_tiled_kernel(const DenseArgs da) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KArgs &a = da.k;
+    const bool fixed = a.P.vote_mode == MVOSR_VOTE_FIXED;
     constexpr int B = DW * kWave, W = kTileW, M = 2 * kTileW - 1, VPT = W / B > 0 ? W / B : 1;   // VPT: a tile's vertices per thread
     static_assert(W % B == 0 || B > W, "tile width / block size");
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
@@ -1662,7 +1690,7 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
     const int n = a.b.feat_cnt[f];
     const int64_t off = a.b.feat_off[f];
     const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
-    const int t1n = (int)(a.b.tri1_off[f + 1] - t1b), t2n = (int)(a.b.tri2_off[f + 1] - t2b);
+    const int t1n = tri_rows(a.b.tri1_off, a.b.tri1_cnt, f), t2n = tri_rows(a.b.tri2_off, a.b.tri2_cnt, f);
     RoadResult R;
     R.height = nan(""); R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
     R.mean = R.std = R.skew = R.median = nan("");
@@ -1751,6 +1779,7 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
     MVOSR_TSTAMP(0);
 
     double hsum = 0.0, hcnt = 0.0;
+    bool sneg = false, spos = false, mixed_signs = false;      // steep heights below / above zero
     int npitch = 0, singular = 0, nvalid = 0, overflow = 0;
     const int rid = tid;       // (lane l of wavefront w taking row l*DW + w — neighbouring rows, which share vertices, then meet in
                                // different LDS atomic instructions — was measured 16 % slower: the row loads lose their coalescing)
@@ -1787,9 +1816,10 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
         const int e = atomicAdd(n_pendV, 3);
         if (e + 3 <= kPendCap) {
             int2 p;
-            p.x = q.a; p.y = (pa | pb) ? -1 : 1; pendV[e] = p;
-            p.x = q.b; p.y = (pa | pb | pc) ? -1 : 1; pendV[e + 1] = p;
-            p.x = q.c; p.y = pc ? -1 : 1; pendV[e + 2] = p;
+            const VoteFlags vf = vote_flags(pa, pb, pc, fixed);
+            p.x = q.a; p.y = vf.f0 ? -1 : 1; pendV[e] = p;
+            p.x = q.b; p.y = vf.f1 ? -1 : 1; pendV[e + 1] = p;
+            p.x = q.c; p.y = vf.f2 ? -1 : 1; pendV[e + 2] = p;
         } else overflow = 1;
     }
     for (int t = far2 + tid; t < t2n; t += B) {
@@ -1807,7 +1837,7 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
         const int r = classify_triangle<false>(xa, y0, ya * sp + za * cp, xb, y1, yb * sp + zb * cp,
                                                xc, y2, yc * sp + zc * cp, h, a.pt, nullptr, nullptr, nullptr, 0);
         if (r & 4) singular = 1;
-        if (r & 2) { hsum += h; hcnt += 1.0; }                                               // :240
+        if (r & 2) { hsum += h; hcnt += 1.0; sneg |= h < 0.0; spos |= h > 0.0; }             // :240
         if (r & 1) ++npitch;
         const unsigned long long key = ((r & 1) && h == h) ? height_key64(h) : 0ull;
         const int e = atomicAdd(n_pendH, 3);
@@ -1878,9 +1908,10 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
             const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
             const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
             const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
-            atomicAdd(&ringC[(q.a & M) * kSubC], (pa | pb) ? -1 : 1);
-            atomicAdd(&ringC[(q.b & M) * kSubC], (pa | pb | pc) ? -1 : 1);
-            atomicAdd(&ringC[(q.c & M) * kSubC], pc ? -1 : 1);
+            const VoteFlags vf = vote_flags(pa, pb, pc, fixed);
+            atomicAdd(&ringC[(q.a & M) * kSubC], vf.f0 ? -1 : 1);
+            atomicAdd(&ringC[(q.b & M) * kSubC], vf.f1 ? -1 : 1);
+            atomicAdd(&ringC[(q.c & M) * kSubC], vf.f2 ? -1 : 1);
         };
         {
             // the prefetched rows: every ring read first (the compiler cannot move the reads of one row across the LDS
@@ -1903,9 +1934,10 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
                 const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
                 const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
                 const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
-                atomicAdd(&ringC[(q.a & M) * kSubC], (pa | pb) ? -1 : 1);
-                atomicAdd(&ringC[(q.b & M) * kSubC], (pa | pb | pc) ? -1 : 1);
-                atomicAdd(&ringC[(q.c & M) * kSubC], pc ? -1 : 1);
+                const VoteFlags vf = vote_flags(pa, pb, pc, fixed);
+                atomicAdd(&ringC[(q.a & M) * kSubC], vf.f0 ? -1 : 1);
+                atomicAdd(&ringC[(q.b & M) * kSubC], vf.f1 ? -1 : 1);
+                atomicAdd(&ringC[(q.c & M) * kSubC], vf.f2 ? -1 : 1);
             }
         }
         for (int t = b1 + kTileRows * B + rid; t < e1; t += B) vote_row(load_tri(rows1, t));
@@ -1922,7 +1954,7 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
             const int r = classify_triangle<false>(g0_.x, g0_.y, a0.y, g1_.x, g1_.y, a1.y, g2_.x, g2_.y, a2.y, h, a.pt,
                                                    nullptr, nullptr, nullptr, 0);
             if (r & 4) singular = 1;
-            if (r & 2) { hsum += h; hcnt += 1.0; }                                               // :240
+            if (r & 2) { hsum += h; hcnt += 1.0; sneg |= h < 0.0; spos |= h > 0.0; }             // :240
             if (r & 1) {
                 ++npitch;
                 if (h == h) {
@@ -1972,9 +2004,12 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
         const int wf = (__ballot(singular != 0) ? 1 : 0) | (__ballot(bad != 0) ? 1 << 8 : 0) | (__ballot(overflow != 0) ? 1 << 16 : 0);
         int sb = (lane == 0) ? wf : 0;
         int nv = (lane == 0) ? nvalid : 0;              // (nvalid is wave-uniform: count it once per wave)
-        int z0 = 0;
+        // steep heights of both signs: the level's rounding error is then relative to sum |h| / count, not to |level| (they
+        // may cancel), and the guard band below, which is relative to |level|, is not wide enough — the EXACT pass takes the frame
+        int z0 = (lane == 0) ? ((__ballot(sneg) ? 1 : 0) | (__ballot(spos) ? 1 << 8 : 0)) : 0;
         block_sum4i<DW>(npitch, nv, sb, z0, red + R_SEL_CNT * 2 * DW);
         nvalid = nv; singular = sb & 0xFF; bad = (sb >> 8) & 0xFF; overflow = sb >> 16;
+        mixed_signs = (z0 & 0xFF) && (z0 >> 8);
     }
     MVOSR_TSTAMP(7);
     const double hl = hsum / hcnt;                    // np.mean of an empty set -> 0/0 = NaN, like :240  (three times the level)
@@ -2000,7 +2035,7 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
         const int nchunks = (cand_cnt + 63) >> 6;      // 64 entries of my list per chunk
         const double *my_h = cand_h + cand_base, *my_y = cand_y + cand_base;
         unsigned long long selbits = 0ull;             // bit c: my entry of chunk c is selected (lists of up to 64 chunks)
-        int cnt = 0, near = (hl == hl) ? 0 : 1;
+        int cnt = 0, near = (hl == hl && !mixed_signs) ? 0 : 1;
         for (int cb = 0; cb < nchunks; cb += kTailBatch) {
             double hm[kTailBatch];
 #pragma unroll
@@ -2070,7 +2105,7 @@ __global__ __launch_bounds__(DW *kWave) void outlier_vote_dense_kernel(const Den
     if (n <= 0) { if (threadIdx.x == 0 && a.o.counts) a.o.counts[f * MVOSR_N_COUNTS + MVOSR_CNT_VALID] = 0; return; }
     const int64_t off = a.b.feat_off[f];
     const int64_t t1b = a.b.tri1_off[f];
-    const int t1n = (int)(a.b.tri1_off[f + 1] - t1b);
+    const int t1n = tri_rows(a.b.tri1_off, a.b.tri1_cnt, f);
     const uint32_t npad = (uint32_t)((n + 1) & ~1);
     uint32_t *c32 = reinterpret_cast<uint32_t *>(smem);
     double *red = reinterpret_cast<double *>(smem + align16(2u * npad + 16u) + align16(4u * ((uint32_t)(n + 31) / 32u)));
@@ -2078,7 +2113,7 @@ __global__ __launch_bounds__(DW *kWave) void outlier_vote_dense_kernel(const Den
     int bad = 0;
     const int nvalid = phase_vote_dense<DW, false>(c32, misc, n, nullptr, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
                                                a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters + off, bad,
-                                               nullptr, nullptr);
+                                               nullptr, nullptr, a.P.vote_mode == MVOSR_VOTE_FIXED);
     int b0 = bad, b1 = 0, b2 = 0, b3 = 0;
     block_sum4i<DW>(b0, b1, b2, b3, red + R_MISC * 2 * DW);
     if (threadIdx.x == 0) {
@@ -2096,14 +2131,14 @@ __global__ __launch_bounds__(WAVES *kWave) void outlier_vote_kernel(const KArgs 
     if (n <= 0) { if (threadIdx.x == 0 && a.o.counts) a.o.counts[f * MVOSR_N_COUNTS + MVOSR_CNT_VALID] = 0; return; }
     const int64_t off = a.b.feat_off[f];
     const int64_t t1b = a.b.tri1_off[f];
-    const int t1n = (int)(a.b.tri1_off[f + 1] - t1b);
+    const int t1n = tri_rows(a.b.tri1_off, a.b.tri1_cnt, f);
     const Smem s = carve(smem, n, WAVES);
     int bad = 0;
     MVOSR_STAMP_DECL
     TriChunk<WAVES * kWave> unused;
     const int nvalid = phase_vote<WAVES, SC>(s, n, nullptr, a.b.y + off, a.b.z + off, a.b.v + off, a.b.tri1, t1b, t1n,
                                              a.P.cos_pitch, a.P.sin_pitch, a.o.vote_counters + off, bad, nullptr, 0, 0, unused,
-                                             0 MVOSR_STAMP_PASS);
+                                             a.P.vote_mode == MVOSR_VOTE_FIXED, 0 MVOSR_STAMP_PASS);
     int b0 = bad | (t1n > kMaxVoteRows ? 1 : 0), b1 = 0, b2 = 0, b3 = 0;
     block_sum4i<WAVES>(b0, b1, b2, b3, s.red + R_MISC * 2 * WAVES);
     if (threadIdx.x == 0) {
@@ -2181,15 +2216,19 @@ static PitchTest make_pitch_test(double thr_deg) {
     return pt;
 }
 
-// Ablation / A-B switches of profiling runs (env MVOSR_DEBUG_SKIP, a bit mask; 0 in production — results with any bit
-// of 1..16 set are NOT the path's results): 1 / 2 / 4 skip the vote sweep / first / second selection sweep, 8 forces the
-// refused-frame tail, 16 skips the road-model launches, 32 ignores a batch's tile index (two-sweep dense kernel),
-// 64 launches a ragged batch with one variant instead of per size class, 256 keeps the one-wavefront road model for
-// dense batches.
+// Ablation / A-B switches of profiling runs: ONLY in builds with -DMVOSR_ABLATE (profiles/ab_build.sh); the shipped library
+// ignores the variable (tested).  Env MVOSR_DEBUG_SKIP, a bit mask — results with any bit of 1..16 set are NOT the path's
+// results: 1 / 2 / 4 skip the vote sweep / first / second selection sweep, 8 forces the refused-frame tail, 16 skips the
+// road-model launches, 32 ignores a batch's tile index (two-sweep dense kernel), 64 launches a ragged batch with one
+// variant instead of per size class, 256 keeps the one-wavefront road model for dense batches.
 static int debug_skip_env() {
+#ifdef MVOSR_ABLATE
     static int v = -1;
     if (v < 0) { const char *e = getenv("MVOSR_DEBUG_SKIP"); v = e ? atoi(e) : 0; }
     return v;
+#else
+    return 0;
+#endif
 }
 
 // Size classes of a ragged batch (the crossovers of pick_waves): the frames of a launch are split into up to three
@@ -2500,7 +2539,7 @@ void mvosr_default_params(mvosr_params *p, double absolute_reference) {
     p->skew_threshold = 0.3;
     p->mode_rel = 0.33;
     p->mode_min = 2;
-    p->reserved = 0;
+    p->vote_mode = MVOSR_VOTE_REFERENCE;
 }
 
 size_t mvosr_lds_bytes(int n_features) {

@@ -59,13 +59,23 @@ def _get_pool(workers):
     return _pool
 
 
-def delaunay_gpu(ctx, point_sets):
+def canonical_rows(tri):
+    """Rows of a triangulation in the canonical form of ``check_triangle="fixed"``: vertex ids ascending inside a row,
+    rows in lexicographic order — a function of the triangle SET alone (what ``mvosr_delaunay_batch`` emits, so that
+    SciPy's rows and the device's rows of the same triangulation are the same array)."""
+    t = np.sort(np.asarray(tri, dtype=np.int32).reshape(-1, 3), axis=1)
+    if t.shape[0] == 0:
+        return t
+    return np.ascontiguousarray(t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))])
+
+
+def delaunay_gpu(ctx, point_sets, keeps=None):
     """The device stage for the triangulations (``mvosr_delaunay_batch``): per point set the (T,3) int32
-    rows — the triangle set SciPy returns for points in general position, rows positively oriented with their smallest
-    vertex first — or ``None`` where the kernel declined (duplicate / collinear / cocircular points within its guard
-    bands, fewer than 3 points): those sets are for the host's Qhull.  A DELIBERATE DEVIATION from the reference when
-    used for the vote (Qhull's rotation of each row is not reproducible); never the default."""
-    import ctypes as C
+    rows — the triangle set SciPy returns for points in general position, in canonical form (:func:`canonical_rows`) —
+    or ``None`` where the kernel declined (duplicate / collinear / cocircular points within its guard bands, fewer than
+    3 points): those sets are for the host's Qhull.  ``keeps`` (optional, one int array per set): only the points with
+    ``keep >= 0`` are triangulated, numbered by their rank among those.  This host-array form is what tests and small
+    callers use; the batch path of ``ScaleEstimator`` keeps points, masks and rows on the device."""
     from . import _lib
     F = len(point_sets)
     if F == 0:
@@ -75,39 +85,50 @@ def delaunay_gpu(ctx, point_sets):
     toff = 2 * off
     total = max(int(off[-1]), 1)
     uv = np.zeros((total, 2), dtype=np.float64)
+    kp = np.zeros(total, dtype=np.int32)
     for f, p in enumerate(point_sets):
         if len(p):
             uv[off[f]:off[f + 1]] = np.asarray(p, dtype=np.float64).reshape(-1, 2)
+            if keeps is not None:
+                kp[off[f]:off[f + 1]] = np.asarray(keeps[f], dtype=np.int32)
     d_u, d_v = ctx.to_device(np.ascontiguousarray(uv[:, 0])), ctx.to_device(np.ascontiguousarray(uv[:, 1]))
+    d_keep = ctx.to_device(kp) if keeps is not None else None
     d_off, d_cnt, d_toff = ctx.to_device(off[:-1].astype(np.int64)), ctx.to_device(cnt), ctx.to_device(toff[:-1].astype(np.int64))
     d_tri = ctx.empty((2 * total, 3), np.int32)
-    d_tcnt, d_st = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
-    _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, int(cnt.max()), d_toff.ptr,
-                                            d_tri.ptr, d_tcnt.ptr, d_st.ptr), "mvosr_delaunay_batch")
+    d_tcnt, d_st, d_used = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
+    _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr,
+                                            d_keep.ptr if d_keep is not None else None, int(cnt.max()), d_toff.ptr,
+                                            d_tri.ptr, d_tcnt.ptr, d_used.ptr, d_st.ptr), "mvosr_delaunay_batch")
     ctx.sync()
-    tri, tcnt, st = d_tri.download(), d_tcnt.download(), d_st.download()
-    for b in (d_u, d_v, d_off, d_cnt, d_toff, d_tri, d_tcnt, d_st):
+    tri, tcnt, st, used = d_tri.download(), d_tcnt.download(), d_st.download(), d_used.download()
+    for b in (d_u, d_v, d_off, d_cnt, d_toff, d_tri, d_tcnt, d_st, d_used) + ((d_keep,) if d_keep is not None else ()):
         b.free()
     delaunay_gpu.last_status = st                      # (bits 8.. of a declined frame's status say why: mvosr_delaunay.hip)
+    delaunay_gpu.last_used = used
     return [np.ascontiguousarray(tri[toff[f]:toff[f] + tcnt[f]]) if st[f] == 0 else None for f in range(F)]
 
 
-DELAUNAY_GPU_MAX_POINTS = 7000          # what the kernel's LDS plan holds (16 B per point + 40 KB)
+def delaunay_gpu_max_points():
+    """Largest point set the device stage takes (its points, grid and rows live in one workgroup's LDS)."""
+    from . import _lib
+    return int(_lib.load().mvosr_delaunay_max_points())
 
 
-def delaunay_gpu_or_host(ctx, point_sets, workers=0):
-    """``triangulation="gpu"``: :func:`delaunay_gpu` for every point set it accepts, SciPy/Qhull (the reference's call) for
-    the ones it declines — degenerate inputs, sets too large for its LDS plan — and for sets SciPy itself rejects, whose
-    exception is returned in place of the rows (as :func:`delaunay_many` does)."""
+def delaunay_gpu_or_host(ctx, point_sets, workers=0, canonical=True):
+    """``triangulation="gpu"`` for host-side point sets: :func:`delaunay_gpu` for every set it accepts, SciPy/Qhull (the
+    reference's call) for the ones it declines — degenerate inputs, sets too large for its LDS plan — and for sets SciPy
+    itself rejects, whose exception is returned in place of the rows (as :func:`delaunay_many` does).  ``canonical``:
+    the host's rows are brought to the device stage's row form."""
     out = [None] * len(point_sets)
-    small = [f for f, p in enumerate(point_sets) if 3 <= len(p) <= DELAUNAY_GPU_MAX_POINTS]
+    cap = delaunay_gpu_max_points()
+    small = [f for f, p in enumerate(point_sets) if 3 <= len(p) <= cap]
     if small:
         for f, t in zip(small, delaunay_gpu(ctx, [point_sets[f] for f in small])):
             out[f] = t
     rest = [f for f, t in enumerate(out) if t is None]
     if rest:
         for f, t in zip(rest, delaunay_many([point_sets[f] for f in rest], workers)):
-            out[f] = t
+            out[f] = canonical_rows(t) if (canonical and not isinstance(t, Exception)) else t
     delaunay_gpu_or_host.last_host_fraction = len(rest) / max(len(point_sets), 1)
     return out
 

@@ -72,13 +72,30 @@ def lower_mask(feature2d, vanish=VANISH):
 
 
 # ---- a7: find_outliers / check_triangle ---------------------------------------------------
-def outlier_votes(v, z, tri):
+def canonical_rows(tri):
+    """The row form of the ``check_triangle="fixed"`` mode: vertex ids ascending inside every row, rows in
+    lexicographic order — a function of the triangle SET alone, so SciPy's rows and the device
+    triangulation's rows (mvosr_delaunay_batch emits this form) give the same array."""
+    t = np.sort(np.asarray(tri).reshape(-1, 3), axis=1)
+    if t.shape[0] == 0:
+        return t
+    return t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+
+
+CHECK_TRIANGLE_MODES = ("reference", "fixed")
+
+
+def outlier_votes(v, z, tri, check_triangle="reference"):
     """scale_calculator.py:105-119,151-167.  ``v`` pixel rows, ``z`` depths (remapped), ``tri``
     (T,3) int vertex ids exactly as SciPy emitted them.  Returns the per-feature counters
     (int64, start value 1, +1 per incident triangle that does not flag the vertex, -1 per one
-    that does).  The flag pattern reproduces the reference's quirk: the (0,2) pair test marks
-    vertices 0 and 1 (:113-115), never vertex 2.
+    that does).  ``check_triangle="reference"`` reproduces the reference's quirk: the (0,2) pair test
+    marks vertices 0 and 1 (:113-115), never vertex 2.  ``"fixed"`` is the evident intent of those lines —
+    ``b > 0`` marks vertices 0 and 2 — a DECLARED DEVIATION: every vertex is then flagged
+    iff one of its two pair tests fails, which does not depend on the order of the vertices inside a row.
     """
+    if check_triangle not in CHECK_TRIANGLE_MODES:
+        raise ValueError("check_triangle must be 'reference' or 'fixed'")
     tri = np.asarray(tri)
     n = v.shape[0]
     counters = np.ones(n, dtype=np.int64)
@@ -89,7 +106,10 @@ def outlier_votes(v, z, tri):
     a = (v0 - v1) * (d0 - d1) > 0
     b = (v0 - v2) * (d0 - d2) > 0
     c = (v1 - v2) * (d1 - d2) > 0
-    flag = np.stack([a | b, a | b | c, c], axis=1)          # (T,3) True = vote against
+    if check_triangle == "fixed":
+        flag = np.stack([a | b, a | c, b | c], axis=1)
+    else:
+        flag = np.stack([a | b, a | b | c, c], axis=1)      # (T,3) True = vote against
     votes = np.where(flag, -1, 1).astype(np.int64)
     np.add.at(counters, tri.reshape(-1), votes.reshape(-1))
     return counters
@@ -312,17 +332,22 @@ def delaunay(points2d):
 
 
 def frame_raw_scale(feature3d, feature2d, absolute_reference, tri1=None, tri2=None,
-                    camera_pitch=CAMERA_PITCH, vanish=VANISH, keep=True):
+                    camera_pitch=CAMERA_PITCH, vanish=VANISH, keep=True, check_triangle="reference"):
     """scale_calculator.py:411-422 up to (not including) the window filter.  ``tri1``/``tri2``
     may be supplied (the batch path takes both triangulations as inputs); otherwise they are
-    computed with SciPy exactly where the reference computes them."""
+    computed with SciPy exactly where the reference computes them.  ``check_triangle="fixed"``: the
+    order-invariant vote on rows in canonical form (``canonical_rows``) — both triangulations then enter
+    the stages as functions of their triangle sets only (the declared deviation of row f1)."""
+    fixed = check_triangle == "fixed"
     f3 = remap(np.asarray(feature3d, dtype=np.float64), camera_pitch)
     f2 = np.asarray(feature2d, dtype=np.float64)
     low = lower_mask(f2, vanish)
     f3l, f2l = f3[low], f2[low]
     if tri1 is None:
         tri1 = delaunay(f2l)
-    counters = outlier_votes(f2l[:, 1], f3l[:, 2], tri1)
+    if fixed:
+        tri1 = canonical_rows(tri1)
+    counters = outlier_votes(f2l[:, 1], f3l[:, 2], tri1, check_triangle)
     valid = votes_valid(counters)
     if not valid.shape[0] > 3:                                            # :263 (the LENGTH of the mask, as the reference tests it)
         res = FrameResult(np.nan, np.nan, np.nan, ST_TOO_FEW, 100)        # :268-270 -> None -> :420-422 with the previous level
@@ -332,6 +357,8 @@ def frame_raw_scale(feature3d, feature2d, absolute_reference, tri1=None, tri2=No
     f3v, f2v = f3l[valid], f2l[valid]
     if tri2 is None:
         tri2 = delaunay(f2v)
+    if fixed:
+        tri2 = canonical_rows(tri2)
     sel = tri_select(f3v, tri2)
     res = FrameResult(np.nan, np.nan, sel.height_level, ST_MODE, 1)
     if keep:
@@ -377,7 +404,10 @@ class OracleScaleEstimator:
     the stage functions above.  Used by tests as the comparator for the product's
     ``ScaleEstimator`` and by the driver-loop tests as the injected CPU backend."""
 
-    def __init__(self, absolute_reference, window_size=6, vanish=VANISH, focus=718):
+    def __init__(self, absolute_reference, window_size=6, vanish=VANISH, focus=718, check_triangle="reference"):
+        if check_triangle not in CHECK_TRIANGLE_MODES:
+            raise ValueError("check_triangle must be 'reference' or 'fixed'")
+        self.check_triangle = check_triangle
         self.absolute_reference = absolute_reference
         self.camera_pitch = CAMERA_PITCH
         self.window_size = window_size
@@ -401,7 +431,7 @@ class OracleScaleEstimator:
 
     def scale_calculation(self, feature3d, feature2d, img=None, tri1=None, tri2=None):
         res = frame_raw_scale(feature3d, feature2d, self.absolute_reference, tri1, tri2,
-                              self.camera_pitch, self.vanish)
+                              self.camera_pitch, self.vanish, check_triangle=self.check_triangle)
         self.last = res
         if res.status == ST_TOO_FEW:
             # :420-422 reads self.height_level of an earlier frame (AttributeError if there is none)

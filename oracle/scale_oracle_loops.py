@@ -24,8 +24,9 @@ from . import scale_oracle as so
 warnings.filterwarnings("ignore", category=PendingDeprecationWarning)      # np.matrix, which the reference uses (:228-229)
 
 
-def check_triangle(v, d):
-    """scale_calculator.py:105-119 (the (0,2) pair marks vertices 0 and 1, as the reference does)."""
+def check_triangle(v, d, mode="reference"):
+    """scale_calculator.py:105-119 (the (0,2) pair marks vertices 0 and 1, as the reference does).
+    ``mode="fixed"``: the (0,2) pair marks vertices 0 and 2 — the declared deviation of SURVEY.md §8 f1."""
     flag = [False, False, False]
     a = (v[0] - v[1]) * (d[0] - d[1])
     b = (v[0] - v[2]) * (d[0] - d[2])
@@ -35,20 +36,23 @@ def check_triangle(v, d):
         flag[1] = True
     if b > 0:
         flag[0] = True
-        flag[1] = True
+        if mode == "fixed":
+            flag[2] = True
+        else:
+            flag[1] = True
     if c > 0:
         flag[1] = True
         flag[2] = True
     return np.array(flag)
 
 
-def find_outliers(feature3d, feature2d, triangle_ids):
+def find_outliers(feature3d, feature2d, triangle_ids, mode="reference"):
     """scale_calculator.py:151-167: per-feature counters (start 1), one Python iteration per triangle."""
     outliers = np.ones((feature3d.shape[0]))
     for triangle_id in triangle_ids:
         depths = feature3d[triangle_id, 2]
         pixel_vs = feature2d[triangle_id, 1]
-        flag = check_triangle(pixel_vs, depths)
+        flag = check_triangle(pixel_vs, depths, mode)
         outlier = triangle_id[flag]
         inlier = triangle_id[~flag]
         outliers[outlier] -= np.ones(outliers[outlier].shape[0])
@@ -79,22 +83,28 @@ def feature_selection_by_tri(feature3d, triangle_ids):
 
 
 def frame_raw_scale(feature3d, feature2d, absolute_reference, tri1=None, tri2=None,
-                    camera_pitch=so.CAMERA_PITCH, vanish=so.VANISH):
+                    camera_pitch=so.CAMERA_PITCH, vanish=so.VANISH, check_triangle_mode="reference"):
     """One frame up to the window filter (scale_calculator.py:411-422), reference-shaped loops for the two hot
-    stages.  Returns ``(raw_scale, status, height_level, counters, selected_ids)``."""
+    stages.  Returns ``(raw_scale, status, height_level, counters, selected_ids)``.  ``check_triangle_mode="fixed"``:
+    the order-invariant vote on canonical rows (``scale_oracle.canonical_rows``)."""
+    fixed = check_triangle_mode == "fixed"
     f3 = so.remap(np.asarray(feature3d, dtype=np.float64), camera_pitch)
     f2 = np.asarray(feature2d, dtype=np.float64)
     low = so.lower_mask(f2, vanish)
     f3l, f2l = f3[low], f2[low]
     if tri1 is None:
         tri1 = so.delaunay(f2l)
-    counters = find_outliers(f3l, f2l, np.asarray(tri1))
+    if fixed:
+        tri1 = so.canonical_rows(tri1)
+    counters = find_outliers(f3l, f2l, np.asarray(tri1), check_triangle_mode)
     valid = counters >= 0
     if not valid.shape[0] > 3:
         return np.nan, so.ST_TOO_FEW, np.nan, counters, None
     f3v, f2v = f3l[valid], f2l[valid]
     if tri2 is None:
         tri2 = so.delaunay(f2v)
+    if fixed:
+        tri2 = so.canonical_rows(tri2)
     try:
         selected, height_level = feature_selection_by_tri(f3v, np.asarray(tri2))
     except np.linalg.LinAlgError:
