@@ -69,6 +69,76 @@ int ctx_workspace_dense(mvosr_ctx *ctx, int64_t total_feat, void *planes[2]) {
     return MVOSR_OK;
 }
 
+// ---- caching allocators ---------------------------------------------------------------------------------------
+static size_t round_block(size_t bytes) {
+    if (bytes < 512) return 512;
+    if (bytes <= ((size_t)1 << 20)) { size_t p = 512; while (p < bytes) p <<= 1; return p; }
+    const size_t mb = (size_t)1 << 20;
+    if (bytes <= 64 * mb) return (bytes + mb - 1) / mb * mb;                  // 1 MiB steps
+    return (bytes + 16 * mb - 1) / (16 * mb) * (16 * mb);                     // 16 MiB steps
+}
+
+static void cache_release_all(mvosr_ctx *ctx, mvosr_block_cache &c, bool host) {
+    for (auto &kv : c.free_blocks) {
+        if (kv.second.pending) (void)hipEventSynchronize(kv.second.ev);
+        (void)hipEventDestroy(kv.second.ev);
+        if (host) { (void)hipHostFree(kv.second.ptr); ctx->n_host_free++; } else { (void)hipFree(kv.second.ptr); ctx->n_hip_free++; }
+    }
+    c.free_blocks.clear();
+    c.cached_bytes = 0;
+}
+
+static int cache_alloc(mvosr_ctx *ctx, mvosr_block_cache &c, bool host, size_t bytes, void **out) {
+    const size_t want = round_block(bytes);
+    auto it = c.free_blocks.lower_bound(want);
+    if (it != c.free_blocks.end() && it->first <= want + want / 4) {
+        mvosr_block b = it->second;
+        c.free_blocks.erase(it);
+        c.cached_bytes -= b.bytes;
+        if (b.pending) {
+            const hipError_t e = hipEventSynchronize(b.ev);
+            if (e != hipSuccess) return set_hip_error("hipEventSynchronize(cached block)", e);
+            b.pending = false;
+        }
+        c.live[b.ptr] = b;
+        ctx->n_cache_hits++;
+        *out = b.ptr;
+        return MVOSR_OK;
+    }
+    mvosr_block b;
+    b.bytes = want; b.pending = false; b.ptr = nullptr;
+    hipError_t e = host ? hipHostMalloc(&b.ptr, want, hipHostMallocDefault) : hipMalloc(&b.ptr, want);
+    if (e != hipSuccess) {                       // out of memory: give the cache back and try once more
+        (void)hipGetLastError();
+        cache_release_all(ctx, c, host);
+        e = host ? hipHostMalloc(&b.ptr, want, hipHostMallocDefault) : hipMalloc(&b.ptr, want);
+    }
+    if (e != hipSuccess) return set_hip_error(host ? "hipHostMalloc" : "hipMalloc", e);
+    if (host) ctx->n_host_malloc++; else ctx->n_hip_malloc++;
+    e = hipEventCreateWithFlags(&b.ev, hipEventDisableTiming);
+    if (e != hipSuccess) { if (host) (void)hipHostFree(b.ptr); else (void)hipFree(b.ptr); return set_hip_error("hipEventCreate(block)", e); }
+    c.live[b.ptr] = b;
+    *out = b.ptr;
+    return MVOSR_OK;
+}
+
+static int cache_free(mvosr_ctx *ctx, mvosr_block_cache &c, bool host, void *ptr) {
+    auto it = c.live.find(ptr);
+    if (it == c.live.end()) return set_error(MVOSR_ERR_ARG, "free: pointer %p was not allocated by this context", ptr);
+    mvosr_block b = it->second;
+    c.live.erase(it);
+    // work queued on either stream may still use the block: its next user waits for this point of both streams
+    hipError_t e = hipEventRecord(ctx->upload_ev, ctx->upload_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0);
+    if (e == hipSuccess) e = hipEventRecord(b.ev, ctx->stream);
+    if (e != hipSuccess) return set_hip_error("hipEventRecord(block release)", e);
+    b.pending = true;
+    c.cached_bytes += b.bytes;
+    c.free_blocks.emplace(b.bytes, b);
+    (void)host;
+    return MVOSR_OK;
+}
+
 }  // namespace mvosr
 
 using namespace mvosr;
@@ -113,6 +183,10 @@ int mvosr_ctx_create(int device, mvosr_ctx **out) {
     ctx->ws_dense_len = 0;
     for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) ctx->prof_ev[i][j] = nullptr;
     ctx->ws_ysel = nullptr; ctx->ws_ysel_len = 0; ctx->ws_nsel = nullptr; ctx->ws_nsel_len = 0;
+    ctx->n_hip_malloc = ctx->n_hip_free = ctx->n_host_malloc = ctx->n_host_free = ctx->n_cache_hits = 0;
+    e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming);
+    if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return set_hip_error("upload stream / event", e); }
     ctx->n_cu = prop.multiProcessorCount;
     int optin = 0;
     if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || optin <= 0)
@@ -129,6 +203,13 @@ int mvosr_ctx_destroy(mvosr_ctx *ctx) {
     if (!ctx) return MVOSR_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->upload_stream);
+    cache_release_all(ctx, ctx->dev_cache, false);
+    cache_release_all(ctx, ctx->host_cache, true);
+    for (auto &kv : ctx->dev_cache.live) { (void)hipEventDestroy(kv.second.ev); (void)hipFree(kv.first); }
+    for (auto &kv : ctx->host_cache.live) { (void)hipEventDestroy(kv.second.ev); (void)hipHostFree(kv.first); }
+    (void)hipEventDestroy(ctx->upload_ev);
+    (void)hipStreamDestroy(ctx->upload_stream);
     for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) if (ctx->prof_ev[i][j]) (void)hipEventDestroy(ctx->prof_ev[i][j]);
     for (int i = 0; i < 2; ++i) if (ctx->ws_dense[i]) (void)hipFree(ctx->ws_dense[i]);
     if (ctx->ws_ysel) (void)hipFree(ctx->ws_ysel);
@@ -198,15 +279,67 @@ int mvosr_ctx_reserve(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat) {
 int mvosr_malloc(mvosr_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return set_error(MVOSR_ERR_ARG, "malloc: null argument");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
-    return MVOSR_OK;
+    return cache_alloc(ctx, ctx->dev_cache, false, bytes ? bytes : 16, dptr);
 }
 
 int mvosr_free(mvosr_ctx *ctx, void *dptr) {
     if (!ctx) return set_error(MVOSR_ERR_ARG, "free: null context");
     if (!dptr) return MVOSR_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipFree(dptr));
+    return cache_free(ctx, ctx->dev_cache, false, dptr);
+}
+
+int mvosr_host_alloc(mvosr_ctx *ctx, size_t bytes, void **hptr) {
+    if (!ctx || !hptr) return set_error(MVOSR_ERR_ARG, "host_alloc: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return cache_alloc(ctx, ctx->host_cache, true, bytes ? bytes : 16, hptr);
+}
+
+int mvosr_host_free(mvosr_ctx *ctx, void *hptr) {
+    if (!ctx) return set_error(MVOSR_ERR_ARG, "host_free: null context");
+    if (!hptr) return MVOSR_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return cache_free(ctx, ctx->host_cache, true, hptr);
+}
+
+int mvosr_ctx_trim(mvosr_ctx *ctx) {
+    if (!ctx) return set_error(MVOSR_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    cache_release_all(ctx, ctx->dev_cache, false);
+    cache_release_all(ctx, ctx->host_cache, true);
+    return MVOSR_OK;
+}
+
+int mvosr_ctx_alloc_stats(mvosr_ctx *ctx, int64_t *out, int n_out) {
+    if (!ctx || !out) return set_error(MVOSR_ERR_ARG, "alloc_stats: null argument");
+    const int64_t v[8] = {ctx->n_hip_malloc, ctx->n_hip_free, ctx->n_host_malloc, ctx->n_host_free, ctx->n_cache_hits,
+                          (int64_t)ctx->dev_cache.cached_bytes, (int64_t)ctx->host_cache.cached_bytes,
+                          (int64_t)(ctx->dev_cache.live.size() + ctx->host_cache.live.size())};
+    for (int i = 0; i < n_out && i < 8; ++i) out[i] = v[i];
+    return MVOSR_OK;
+}
+
+int mvosr_memcpy_h2d_async(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return set_error(MVOSR_ERR_ARG, "memcpy_h2d_async: null argument");
+    if (!bytes) return MVOSR_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->upload_stream));
+    return MVOSR_OK;
+}
+
+int mvosr_upload_fence(mvosr_ctx *ctx) {
+    if (!ctx) return set_error(MVOSR_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->upload_ev, ctx->upload_stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
+    return MVOSR_OK;
+}
+
+int mvosr_memcpy_d2h_async(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return set_error(MVOSR_ERR_ARG, "memcpy_d2h_async: null argument");
+    if (!bytes) return MVOSR_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return MVOSR_OK;
 }
 

@@ -45,14 +45,20 @@ namespace mvosr {
 
 constexpr int kDtWaves = 8;
 constexpr int kDtBlock = kDtWaves * kWave;
-constexpr int kDtR = 2;                  // a point's candidates: the (2R+1)^2 cell block around its cell
-constexpr double kDtPerCell = 1.5;       // target points per cell (measured trade-off: profiles/micro/dt_proto.py)
+#ifndef MVOSR_DT_R
+#define MVOSR_DT_R 2
+#endif
+#ifndef MVOSR_DT_PER_CELL
+#define MVOSR_DT_PER_CELL 1.5
+#endif
+constexpr int kDtR = MVOSR_DT_R;         // a point's candidates: the (2R+1)^2 cell block around its cell
+constexpr double kDtPerCell = MVOSR_DT_PER_CELL;   // target points per cell (measured trade-off: profiles/micro/dt_proto.py)
 constexpr int kDtMaxCells = 4096;
 constexpr int kDtLaneRows = 8;           // rows a point may own on the lane path (more: hard list)
 constexpr int kDtLaneDeg = 24;           // star degree on the lane path
 constexpr int kDtWaveRows = 32;          // rows a point may own at all
 constexpr int kDtWaveDeg = 60;
-constexpr int kDtVq = 1024;              // queued completions
+constexpr int kDtVq = 512;               // queued completions (more: the point goes to the hard list)
 constexpr int kDtHardCap = 1024;         // hard points
 constexpr int kDtArenaSlack = 512;       // rows of points that are recomputed stay behind in the arena
 constexpr double kDtTieTol = 1e-9;       // relative guard band on cot differences
@@ -73,7 +79,19 @@ struct DtArgs {
     int32_t *n_used;                                     // [F] points triangulated (null: not wanted)
     int32_t *status;                                     // [F] MVOSR_DT_*
     int max_pts;
+#ifdef MVOSR_STAMPS
+    unsigned long long *stamps;                          // diagnostic builds: 16 values per frame (phase boundaries, list lengths)
+#endif
 };
+
+#ifdef MVOSR_STAMPS
+static unsigned long long *g_dt_stamps = nullptr;
+#define DT_STAMP(i) do { if (tid == 0 && a.stamps) a.stamps[16 * f + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DT_NOTE(i, v) do { if (tid == 0 && a.stamps) a.stamps[16 * f + (i)] = (unsigned long long)(v); } while (0)
+#else
+#define DT_STAMP(i) do {} while (0)
+#define DT_NOTE(i, v) do {} while (0)
+#endif
 
 struct DtPlan { uint32_t S, oid, od, astart, cs, arena, vq, hard, wrows, red, misc, total; int max_cells, arena_cap; };
 
@@ -94,17 +112,17 @@ __host__ __device__ inline DtPlan dt_plan(int max_pts) {
     p.arena = p.cs + 4u * (uint32_t)(p.max_cells + 8);   // u32 rows (b << 16 | c) in the order they were found
     p.vq = p.arena + 4u * (uint32_t)p.arena_cap;         // uint2 per queued completion
     p.hard = p.vq + 8u * kDtVq;                          // u16 sorted indices
-    p.wrows = p.hard + 2u * kDtHardCap;                  // u32 [waves][kDtWaveRows]
-    p.red = p.wrows + 4u * kDtWaves * kDtWaveRows;       // doubles: block reductions
+    p.wrows = p.hard + 2u * kDtHardCap;                  // u32 [groups of 16 lanes][kDtWaveRows]
+    p.red = p.wrows + 4u * (kDtBlock / 16) * kDtWaveRows;    // doubles: block reductions
     p.misc = p.red + 8u * 4u * kDtWaves;
     p.total = p.misc + 4u * 64u;
     return p;
 }
 
-enum { DM_FLAGS = 0, DM_ARENA = 1, DM_VQ = 2, DM_NHARD = 3, DM_WCNT = 8 /* [8..15] */, DM_WSUM = 16 /* [16..23] */, DM_WSUM2 = 24, DM_WSUM3 = 32 };
+enum { DM_FLAGS = 0, DM_ARENA = 1, DM_VQ = 2, DM_NHARD = 3, DM_NEXT = 4, DM_WCNT = 8 /* [8..15] */, DM_WSUM = 16 /* [16..23] */, DM_WSUM2 = 24, DM_WSUM3 = 32 };
 
 struct DtGrid {
-    double lo_u, lo_v, ix, iy;
+    double lo_u, lo_v, ix, iy, sx, sy;
     int gx, gy;
     const uint32_t *cs;
     __device__ __forceinline__ int cellx(double x) const { return (int)fmin(fmax((x - lo_u) * ix, 0.0), (double)(gx - 1)); }
@@ -115,67 +133,121 @@ struct DtGrid {
 
 struct DtBox { int xa, xb, ya, yb; };
 
-// the best and the second best apex seen so far, as fractions num / cr (cr > 0)
-struct DtAcc {
-    double n1, c1, n2, c2;
-    int b1, flag;
-    __device__ __forceinline__ void reset() { n1 = INFINITY; c1 = 1.0; n2 = INFINITY; c2 = 1.0; b1 = -1; flag = 0; }
+// the directed edge p -> q = p + a of a completion.  sgn = +1: the apex is wanted on the left, -1: on the right.
+// (k, side) describe the wanted half-plane per cell row: side = +1: u below px + k (v - py), -1: above, 0: no statement
+struct DtEdge {
+    double px, py, ax, ay, a2col, sgn, k;
+    int i, iq, side;
+    __device__ __forceinline__ void set(double2 p, double2 q, int i_, int iq_, double sgn_) {
+        px = p.x; py = p.y; ax = q.x - p.x; ay = q.y - p.y; i = i_; iq = iq_; sgn = sgn_;
+        a2col = kDtColTol * kDtColTol * (ax * ax + ay * ay);
+        const double A = sgn * ax, B = sgn * ay;
+        side = B > 0.0 ? 1 : (B < 0.0 ? -1 : 0);
+        k = side ? A / B : 0.0;
+    }
 };
 
-// candidates S[j0..j1) against the directed edge p -> p + a; sgn = +1: apex on the left, -1: on the right
-template <bool WAVE>
-__device__ __forceinline__ void dt_scan(DtAcc &A, const double2 *S, int j0, int j1, int i, int iq, double px, double py,
-                                        double ax, double ay, double a2col, double sgn) {
-    const int step = WAVE ? kWave : 1;
-    for (int j = j0 + (WAVE ? lane_id() : 0); j < j1; j += step) {
-        if (j == i || j == iq) continue;
-        const double2 c = S[j];
-        const double bx = c.x - px, by = c.y - py;
-        const double cr = sgn * (ax * by - ay * bx);
-        const double b2 = bx * bx + by * by;
-        if (cr * cr <= a2col * b2) {                       // (nearly) on the line through the edge
-            if (bx * ax + by * ay > 0.0 || b2 == 0.0) A.flag = 1;      // ... ahead of p: the sign of cr decides a triangle
-            continue;
-        }
-        if (cr <= 0.0) continue;
-        const double num = bx * (bx - ax) + by * (by - ay);           // (c - p).(c - q)
-        if (num * A.c1 < A.n1 * cr) { A.n2 = A.n1; A.c2 = A.c1; A.n1 = num; A.c1 = cr; A.b1 = j; }
-        else if (num * A.c2 < A.n2 * cr) { A.n2 = num; A.c2 = cr; }
+// The best apex seen so far as a fraction num / cr (cr > 0): t = cot of the angle under which the candidate sees the
+// edge.  `tie`: a candidate came within the guard band of the best of its time — which covers every candidate within
+// the band of the FINAL best (a better one that arrives later is compared with the best of its own time, itself at
+// least as good as the earlier candidate).
+struct DtAcc {
+    double n1, c1, s1;
+    int b1, flag, tie;
+    __device__ __forceinline__ void reset() { n1 = 1e300; c1 = 1.0; s1 = kDtTieTol * 1e300; b1 = -1; flag = 0; tie = 0; }
+};
+
+constexpr int kDtGroup = 16;            // lanes that share a completion in the group passes: one DPP row
+
+// one candidate of a group pass, branch-free
+__device__ __forceinline__ void dt_step(DtAcc &A, const DtEdge &E, int j, double2 c) {
+    const double bx = c.x - E.px, by = c.y - E.py;
+    const double cr = E.sgn * __builtin_fma(E.ax, by, -(E.ay * bx));
+    const double b2 = __builtin_fma(bx, bx, by * by);
+    const double dot = __builtin_fma(bx, E.ax, by * E.ay);
+    const double num = b2 - dot;                                        // (c - p).(c - q)
+    const bool skip = (j == E.i) | (j == E.iq);
+    const bool col = cr * cr <= E.a2col * b2;                           // (nearly) on the line through the edge ...
+    A.flag |= (!skip & col & ((dot > 0.0) | (b2 == 0.0))) ? 1 : 0;      // ... ahead of p: the sign of cr would decide a triangle
+    const bool ok = !skip & !col & (cr > 0.0);
+    const double d = __builtin_fma(num, A.c1, -(A.n1 * cr));            // num / cr < n1 / c1  <=>  d < 0
+    const bool better = ok & (d < 0.0);
+    A.tie |= (ok & (fabs(d) <= A.s1 * cr)) ? 1 : 0;                     // |t - t1| <= tol (|t1| + 1)
+    const double s_new = kDtTieTol * (fabs(num) + cr);
+    A.n1 = better ? num : A.n1; A.c1 = better ? cr : A.c1; A.s1 = better ? s_new : A.s1; A.b1 = better ? j : A.b1;
+}
+
+// one candidate of the lane pass: m1 = the lane is wrapping its star (as dt_step, apex on the left); otherwise it is
+// looking for its point's nearest neighbour — the same minimisation with num = |c - p|^2, cr = 1
+__device__ __forceinline__ void dt_step_lane(DtAcc &A, const DtEdge &E, bool m1, int j, double2 c) {
+    const double bx = c.x - E.px, by = c.y - E.py;
+    const double cr0 = __builtin_fma(E.ax, by, -(E.ay * bx));
+    const double b2 = __builtin_fma(bx, bx, by * by);
+    const double dot = __builtin_fma(bx, E.ax, by * E.ay);
+    const double cr = m1 ? cr0 : 1.0;
+    const double num = m1 ? b2 - dot : b2;
+    const bool skip = (j == E.i) | (j == E.iq);
+    const bool col = m1 & (cr0 * cr0 <= E.a2col * b2);
+    A.flag |= (!skip & col & ((dot > 0.0) | (b2 == 0.0))) ? 1 : 0;
+    const bool ok = !skip & !col & (cr > 0.0);
+    const double d = __builtin_fma(num, A.c1, -(A.n1 * cr));
+    const bool better = ok & (d < 0.0);
+    A.tie |= (m1 & ok & (fabs(d) <= A.s1 * cr)) ? 1 : 0;
+    const double s_new = kDtTieTol * (fabs(num) + cr);
+    A.n1 = better ? num : A.n1; A.c1 = better ? cr : A.c1; A.s1 = better ? s_new : A.s1; A.b1 = better ? j : A.b1;
+}
+
+// the part of cell row y, columns xa..xb, that can hold points on the wanted side of the edge, as a range of the sorted array
+__device__ __forceinline__ void dt_row_range(const DtGrid &G, const DtEdge &E, int y, int xa, int xb, int &j0, int &j1) {
+    if (E.side) {
+        const double v0 = G.lo_v + ((double)y - 1e-6) * G.sy, v1 = G.lo_v + ((double)(y + 1) + 1e-6) * G.sy;
+        const double t0 = E.k * (v0 - E.py), t1 = E.k * (v1 - E.py);
+        if (E.side > 0) xb = min(xb, G.cellx(E.px + fmax(t0, t1)) + 1);
+        else xa = max(xa, G.cellx(E.px + fmin(t0, t1)) - 1);
+    }
+    j0 = 0; j1 = 0;
+    if (xa <= xb) { j0 = G.row_begin(y, xa); j1 = G.row_end(y, xb); }
+}
+
+// a cell box, GL lanes striding over each row
+template <int GL>
+__device__ __forceinline__ void dt_scan_box(DtAcc &A, const double2 *S, const DtGrid &G, const DtBox &B, const DtEdge &E) {
+    const int gl = lane_id() & (GL - 1);
+    for (int y = B.ya; y <= B.yb; ++y) {
+        int j0, j1;
+        dt_row_range(G, E, y, B.xa, B.xb, j0, j1);
+        for (int j = j0 + gl; j < j1; j += GL) dt_step(A, E, j, S[j]);
     }
 }
 
-template <bool WAVE>
-__device__ __forceinline__ void dt_scan_box(DtAcc &A, const double2 *S, const DtGrid &G, const DtBox &B, int i, int iq,
-                                            double px, double py, double ax, double ay, double a2col, double sgn) {
-    for (int y = B.ya; y <= B.yb; ++y)
-        dt_scan<WAVE>(A, S, G.row_begin(y, B.xa), G.row_end(y, B.xb), i, iq, px, py, ax, ay, a2col, sgn);
-}
+constexpr int kDtRows = 2 * kDtR + 1;
 
-// runner-up within the guard band of the best: t2 - t1 <= tol (|t1| + 1) with t = n / c
-__device__ __forceinline__ bool dt_acc_tie(const DtAcc &A) {
-    return A.b1 >= 0 && (A.n2 * A.c1 - A.n1 * A.c2) <= kDtTieTol * (fabs(A.n1) + A.c1) * A.c2;
+// ---- groups of 16 lanes (one DPP row): min, ballot, broadcast
+__device__ __forceinline__ double dt_group_min(double x) {
+    x = fmin(x, dpp_mov<kDppXor1>(x)); x = fmin(x, dpp_mov<kDppXor2>(x)); x = fmin(x, dpp_mov<kDppHalfMirror>(x)); x = fmin(x, dpp_mov<kDppMirror>(x));
+    return x;
 }
+__device__ __forceinline__ unsigned dt_group_ballot(bool b) { return (unsigned)((__ballot(b) >> (lane_id() & 48)) & 0xFFFFull); }
+__device__ __forceinline__ int dt_group_shfl(int v, int src) { return __shfl(v, (lane_id() & 48) | src); }
 
 __device__ __forceinline__ double dt_wave_min(double x) {
-    x = fmin(x, dpp_mov<kDppXor1>(x)); x = fmin(x, dpp_mov<kDppXor2>(x)); x = fmin(x, dpp_mov<kDppHalfMirror>(x)); x = fmin(x, dpp_mov<kDppMirror>(x));
+    x = dt_group_min(x);
     return fmin(fmin(readlane_d(x, 0), readlane_d(x, 16)), fmin(readlane_d(x, 32), readlane_d(x, 48)));
 }
 
 struct DtPick { int id, tie, flag; };
-// the wavefront's answer from its lanes' accumulators
-__device__ __forceinline__ DtPick dt_wave_pick(const DtAcc &A) {
+// the group's answer from its lanes' accumulators
+__device__ __forceinline__ DtPick dt_group_pick(const DtAcc &A) {
     const double t1 = A.b1 >= 0 ? A.n1 / A.c1 : INFINITY;
-    const double t2 = A.n2 / A.c2;
-    const double m = dt_wave_min(t1);
+    const double m = dt_group_min(t1);
     DtPick r;
-    r.id = -1; r.tie = 0;
-    r.flag = __ballot(A.flag != 0) != 0ull;
-    if (!(m < INFINITY)) return r;
-    const unsigned long long who = __ballot(A.b1 >= 0 && t1 == m);
-    r.id = __builtin_amdgcn_readlane(A.b1, (int)__ffsll((long long)who) - 1);
+    const unsigned who = dt_group_ballot(A.b1 >= 0 && t1 == m);
+    r.id = dt_group_shfl(A.b1, who ? (int)__ffs((int)who) - 1 : 0);
+    if (!who) r.id = -1;
     const double band = kDtTieTol * (fabs(m) + 1.0);
-    const bool close = (A.b1 >= 0 && A.b1 != r.id && t1 - m <= band) || (t2 - m <= band);
-    r.tie = __ballot(close) != 0ull;
+    const bool close = (A.b1 >= 0 && A.b1 != r.id && t1 - m <= band) || A.tie != 0;
+    r.tie = (r.id >= 0) && dt_group_ballot(close) != 0u;
+    r.flag = dt_group_ballot(A.flag != 0) != 0u;
     return r;
 }
 
@@ -208,7 +280,7 @@ __device__ __forceinline__ int dt_incl_scan(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
+__global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = blockIdx.x;
     const int n_in = a.pts_cnt[f];
@@ -222,7 +294,6 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
     uint32_t *arena = reinterpret_cast<uint32_t *>(smem + L.arena);
     uint2 *vq = reinterpret_cast<uint2 *>(smem + L.vq);
     uint16_t *hard = reinterpret_cast<uint16_t *>(smem + L.hard);
-    uint32_t *wrows = reinterpret_cast<uint32_t *>(smem + L.wrows) + w * kDtWaveRows;
     double *red = reinterpret_cast<double *>(smem + L.red);
     int *misc = reinterpret_cast<int *>(smem + L.misc);
 
@@ -230,6 +301,7 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
         if (tid == 0) { a.tri_cnt[f] = 0; a.status[f] = MVOSR_DT_DEGENERATE | (why << 8); if (a.n_used) a.n_used[f] = n_used; }
     };
     if (n_in > a.max_pts || n_in < 0) { decline(DT_WHY_SIZE, 0); return; }
+    DT_STAMP(0);
     const int64_t off = a.pts_off[f];
     const double *gu = a.u + off, *gv = a.v + off;
     const int32_t *gk = a.keep ? a.keep + off : nullptr;
@@ -252,7 +324,7 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
     {
         const double a0 = dt_wave_min(lo_u), a1 = dt_wave_min(-hi_u), a2 = dt_wave_min(lo_v), a3 = dt_wave_min(-hi_v);
         if (lane == 0) { red[4 * w] = a0; red[4 * w + 1] = a1; red[4 * w + 2] = a2; red[4 * w + 3] = a3; misc[DM_WCNT + w] = wcnt; }
-        if (tid < 8) misc[tid] = 0;
+        if (tid < 8) misc[tid] = tid == DM_NEXT ? kDtBlock : 0;
     }
     __syncthreads();
     int n = 0, rank_base = 0;
@@ -281,9 +353,10 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
             while (fx * fy > (double)L.max_cells) { if (fx >= fy) fx -= 1.0; else fy -= 1.0; }
         }
         G.gx = (int)fx; G.gy = (int)fy;
-        G.lo_u = lo_u; G.lo_v = lo_v; G.ix = fx / W; G.iy = fy / H; G.cs = cs;
+        G.lo_u = lo_u; G.lo_v = lo_v; G.ix = fx / W; G.iy = fy / H; G.sx = W / fx; G.sy = H / fy; G.cs = cs;
     }
     const int ncell = G.gx * G.gy;
+    DT_STAMP(1);
     for (int c = tid; c <= ncell; c += kDtBlock) cs[c] = 0u;
     for (int i = tid; i < ((n + 1) >> 1); i += kDtBlock) reinterpret_cast<uint32_t *>(od)[i] = 0u;
     __syncthreads();
@@ -331,103 +404,151 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
     }
     __syncthreads();
 
+    DT_STAMP(2);
     int degenerate = 0;
-    // ---- phase 1: one lane per point
-    for (int i0 = 0; i0 < n; i0 += kDtBlock) {
-        const int i = i0 + tid;
-        int nown = 0, deg = 0, state = 0;          // state: 0 ok, 1 hard
+    // ---- phase 1: one lane per point.  Lanes are persistent: a lane whose star is complete takes the next point (stars
+    // have 3 to 10+ triangles: in rounds of 64 points the wavefront would wait for its largest star), and the nearest-
+    // neighbour search that starts a star is the same candidate loop in another mode, so that lanes in different
+    // stages of their stars share every iteration.
+    {
+        int i = tid < n ? tid : -1;                 // (misc[DM_NEXT] starts at kDtBlock)
+        bool exhausted = tid >= n;
+        int mode = 0, oi = 0, q0 = -1, iq = -1, deg = 0, nown = 0;
+        double2 p;
+        p.x = 0.0; p.y = 0.0;
         uint32_t rows[kDtLaneRows];
 #pragma unroll
         for (int k = 0; k < kDtLaneRows; ++k) rows[k] = 0xFFFFFFFFu;
-        int oi = 0;
-        if (i < n) {
-            const double2 p = S[i];
-            oi = oid[i];
+        if (i >= 0) { p = S[i]; oi = oid[i]; }
+        for (;;) {
+            if (i < 0 && !exhausted) {
+                const int idx = atomicAdd(&misc[DM_NEXT], 1);
+                if (idx < n) {
+                    i = idx; p = S[i]; oi = oid[i]; mode = 0; deg = 0; nown = 0; iq = -1;
+#pragma unroll
+                    for (int k = 0; k < kDtLaneRows; ++k) rows[k] = 0xFFFFFFFFu;
+                } else exhausted = true;
+            }
+            if (__ballot(i >= 0) == 0ull) break;
+            const bool act = i >= 0, m1 = mode == 1;
             const int cx = G.cellx(p.x), cy = G.celly(p.y);
             DtBox blk;
             blk.xa = max(cx - kDtR, 0); blk.xb = min(cx + kDtR, G.gx - 1); blk.ya = max(cy - kDtR, 0); blk.yb = min(cy + kDtR, G.gy - 1);
-            // nearest neighbour: a Delaunay neighbour, if its disc lies within the block
-            double bd = INFINITY;
-            int q0 = -1;
-            for (int y = blk.ya; y <= blk.yb; ++y) {
-                const int j1 = G.row_end(y, blk.xb);
-                for (int j = G.row_begin(y, blk.xa); j < j1; ++j) {
-                    const double2 c = S[j];
-                    const double dx = c.x - p.x, dy = c.y - p.y, d2 = dx * dx + dy * dy;
-                    if (j != i && d2 < bd) { bd = d2; q0 = j; }
-                }
-            }
-            if (q0 >= 0 && bd == 0.0) degenerate |= DT_WHY_DUP;
-            if (q0 < 0 || !dt_inside(dt_disc_box(G, p.x, p.y, bd), blk)) state = 1;
-            int iq = q0;
-            while (state == 0) {
-                const double2 q = S[iq];
-                const double ax = q.x - p.x, ay = q.y - p.y;
-                DtAcc A;
-                A.reset();
-                dt_scan_box<false>(A, S, G, blk, i, iq, p.x, p.y, ax, ay, kDtColTol * kDtColTol * (ax * ax + ay * ay), 1.0);
-                if (A.flag) degenerate |= DT_WHY_COLLINEAR;
-                if (A.b1 < 0) { state = 1; break; }                       // open within the block
-                if (dt_acc_tie(A)) degenerate |= DT_WHY_TIE;
-                const int ic = A.b1;
-                if (!dt_inside(dt_circle_box(G, p.x, p.y, q, S[ic]), blk)) {
-                    // the circumcircle leaves the block: go on, a wavefront checks the completion afterwards
-                    const int pos = atomicAdd(&misc[DM_VQ], 1);
-                    if (pos >= kDtVq) { state = 1; break; }
-                    uint2 e; e.x = (uint32_t)i | ((uint32_t)iq << 16); e.y = (uint32_t)ic;
-                    vq[pos] = e;
-                }
-                if (++deg > kDtLaneDeg) { state = 1; break; }
-                const int oq = oid[iq], oc = oid[ic];
-                if (oi < oq && oi < oc) {
-                    if (nown == kDtLaneRows) { state = 1; break; }
-                    uint32_t key = ((uint32_t)min(oq, oc) << 16) | (uint32_t)max(oq, oc);
+            DtEdge E;
+            E.set(p, S[max(iq, 0)], i, iq, 1.0);
+            if (!m1) E.side = 0;                                     // the nearest-neighbour search takes whole rows
+            // the block's rows as up to five ranges of the sorted array, walked as ONE loop (a loop per row would run
+            // for the longest row of any lane, five times over)
+            int j0[kDtRows], j1[kDtRows];
 #pragma unroll
-                    for (int k = 0; k < kDtLaneRows; ++k) { const uint32_t lo = min(key, rows[k]), hi = max(key, rows[k]); rows[k] = lo; key = hi; }
-                    ++nown;
-                }
-                iq = ic;
-                if (iq == q0) break;
+            for (int r = 0; r < kDtRows; ++r) {
+                const int y = cy - kDtR + r;
+                j0[r] = 0; j1[r] = 0;
+                if (act && y >= blk.ya && y <= blk.yb) dt_row_range(G, E, y, blk.xa, blk.xb, j0[r], j1[r]);
             }
-            if (state) {
-                nown = 0;
+            DtAcc A;
+            A.reset();
+            {
+                int j = j0[0], je = j1[0], seg = 0;
+                auto advance = [&]() {
+                    do {
+                        j = j0[1]; je = j1[1];
+#pragma unroll
+                        for (int r = 1; r < kDtRows - 1; ++r) { j0[r] = j0[r + 1]; j1[r] = j1[r + 1]; }
+                        j0[kDtRows - 1] = 0; j1[kDtRows - 1] = 0;
+                        ++seg;
+                    } while (j >= je && seg < kDtRows - 1);
+                };
+                if (j >= je) advance();
+                while (j < je) {
+                    const double2 c = S[j];
+                    const int jc = j;
+                    ++j;
+                    if (j >= je && seg < kDtRows - 1) advance();
+                    dt_step_lane(A, E, m1, jc, c);
+                }
+            }
+            if (!act) continue;
+            int state = 0;                                           // 1: finished, 2: hard
+            if (!m1) {
+                // the nearest neighbour is a Delaunay neighbour — if its disc lies within the block
+                q0 = A.b1;
+                if (q0 >= 0 && A.n1 == 0.0) degenerate |= DT_WHY_DUP;
+                if (q0 < 0 || !dt_inside(dt_disc_box(G, p.x, p.y, A.n1), blk)) state = 2;
+                iq = q0; mode = 1;
+            } else {
+                if (A.flag) degenerate |= DT_WHY_COLLINEAR;
+                if (A.tie) degenerate |= DT_WHY_TIE;
+                const int ic = A.b1;
+                if (ic < 0) state = 2;                               // open within the block
+                else {
+                    if (!dt_inside(dt_circle_box(G, p.x, p.y, S[iq], S[ic]), blk)) {
+                        // the circumcircle leaves the block: go on, a group of lanes checks the completion afterwards
+                        const int pos = atomicAdd(&misc[DM_VQ], 1);
+                        if (pos >= kDtVq) state = 2;
+                        else { uint2 e; e.x = (uint32_t)i | ((uint32_t)iq << 16); e.y = (uint32_t)ic; vq[pos] = e; }
+                    }
+                    if (++deg > kDtLaneDeg) state = 2;
+                    const int oq = oid[iq], oc = oid[ic];
+                    if (oi < oq && oi < oc) {
+                        if (nown == kDtLaneRows) state = 2;
+                        else {
+                            uint32_t key = ((uint32_t)min(oq, oc) << 16) | (uint32_t)max(oq, oc);
+#pragma unroll
+                            for (int k = 0; k < kDtLaneRows; ++k) { const uint32_t lo = min(key, rows[k]), hi = max(key, rows[k]); rows[k] = lo; key = hi; }
+                            ++nown;
+                        }
+                    }
+                    iq = ic;
+                    if (state == 0 && iq == q0) state = 1;           // closed
+                }
+            }
+            if (state == 1) {
+                const int at = nown ? atomicAdd(&misc[DM_ARENA], nown) : 0;
+                if (at + nown > L.arena_cap) degenerate |= DT_WHY_ROWS;
+                else {
+#pragma unroll
+                    for (int k = 0; k < kDtLaneRows; ++k) if (k < nown) arena[at + k] = rows[k];
+                    od[oi] = (uint16_t)(nown | (deg << 6));
+                    astart[oi] = (uint16_t)at;
+                }
+                i = -1;
+            } else if (state == 2) {
+                od[oi] = 0x4000;                                     // listed (phase 1b does not list it again)
                 const int pos = atomicAdd(&misc[DM_NHARD], 1);
                 if (pos < kDtHardCap) hard[pos] = (uint16_t)i; else degenerate |= DT_WHY_HARD;
+                i = -1;
             }
-        }
-        // the wavefront's rows go to the arena together
-        const int incl = dt_incl_scan(nown);
-        int base = 0;
-        if (lane == kWave - 1 && incl > 0) base = atomicAdd(&misc[DM_ARENA], incl);
-        base = __shfl(base, kWave - 1);
-        const int total = __shfl(incl, kWave - 1);
-        if (base + total > L.arena_cap) { degenerate |= DT_WHY_ROWS; }
-        else if (i < n && state == 0) {
-            const int at = base + incl - nown;
-#pragma unroll
-            for (int k = 0; k < kDtLaneRows; ++k) if (k < nown) arena[at + k] = rows[k];
-            od[oi] = (uint16_t)(nown | (deg << 6));
-            astart[oi] = (uint16_t)at;
         }
     }
     __syncthreads();
+    DT_STAMP(3);
 
-    // ---- phase 1b: queued completions, one wavefront each
+    // The two passes below work in GROUPS of 16 lanes (a DPP row): a completion has a few dozen candidates at most, so
+    // four of them share a wavefront.  Lanes of a group stay together; groups diverge freely.
+    const int gl = lane & (kDtGroup - 1), grp = tid / kDtGroup;
+    constexpr int kGroups = kDtBlock / kDtGroup;
+    // ---- phase 1b: queued completions
     {
         const int nreq = min(misc[DM_VQ], kDtVq);
-        for (int r = w; r < nreq; r += kDtWaves) {
-            const uint2 e = vq[r];
+        for (int r0 = 0; r0 < nreq; r0 += kGroups) {
+            const int r = r0 + grp;
+            const bool have = r < nreq;
+            const uint2 e = vq[have ? r : 0];
             const int i = (int)(e.x & 0xFFFFu), iq = (int)(e.x >> 16), ic = (int)e.y;
             const double2 p = S[i], q = S[iq];
-            const double ax = q.x - p.x, ay = q.y - p.y;
-            const DtBox B = dt_circle_box(G, p.x, p.y, q, S[ic]);
+            DtBox B = dt_circle_box(G, p.x, p.y, q, S[ic]);
+            if (!have) B.yb = B.ya - 1;
+            DtEdge E;
+            E.set(p, q, i, iq, 1.0);
             DtAcc A;
             A.reset();
-            dt_scan_box<true>(A, S, G, B, i, iq, p.x, p.y, ax, ay, kDtColTol * kDtColTol * (ax * ax + ay * ay), 1.0);
-            const DtPick pk = dt_wave_pick(A);
+            dt_scan_box<kDtGroup>(A, S, G, B, E);
+            const DtPick pk = dt_group_pick(A);
+            if (!have) continue;
             if (pk.flag) degenerate |= DT_WHY_COLLINEAR;
             if (pk.id == ic) { if (pk.tie) degenerate |= DT_WHY_TIE; }
-            else if (lane == 0) {
+            else if (gl == 0) {
                 const int oi = oid[i];
                 const uint32_t bit = 0x4000u << ((oi & 1) * 16);
                 const uint32_t old = atomicOr(reinterpret_cast<uint32_t *>(od) + (oi >> 1), bit);
@@ -439,12 +560,15 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
         }
     }
     __syncthreads();
+    DT_STAMP(4);
+    DT_NOTE(8, misc[DM_VQ]);
 
-    // ---- phase 2: hard points, one wavefront each
+    // ---- phase 2: hard points, one group each
     {
         const int nh = min(misc[DM_NHARD], kDtHardCap);
+        uint32_t *grows = reinterpret_cast<uint32_t *>(smem + L.wrows) + grp * kDtWaveRows;
         const DtBox all = {0, G.gx - 1, 0, G.gy - 1};
-        for (int h = w; h < nh; h += kDtWaves) {
+        for (int h = grp; h < nh; h += kGroups) {
             const int i = hard[h];
             const double2 p = S[i];
             const int oi = oid[i];
@@ -460,18 +584,16 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
                 int bq = -1;
                 for (int y = B.ya; y <= B.yb; ++y) {
                     const int j1 = G.row_end(y, B.xb);
-                    for (int j = G.row_begin(y, B.xa) + lane; j < j1; j += kWave) {
+                    for (int j = G.row_begin(y, B.xa) + gl; j < j1; j += kDtGroup) {
                         const double2 c = S[j];
                         const double dx = c.x - p.x, dy = c.y - p.y, d2 = dx * dx + dy * dy;
                         if (j != i && d2 < bd) { bd = d2; bq = j; }
                     }
                 }
-                dmin = dt_wave_min(bd);
-                q0 = -1;
-                if (dmin < INFINITY) {
-                    const unsigned long long who = __ballot(bq >= 0 && bd == dmin);
-                    q0 = __builtin_amdgcn_readlane(bq, (int)__ffsll((long long)who) - 1);
-                }
+                dmin = dt_group_min(bd);
+                const unsigned who = dt_group_ballot(bq >= 0 && bd == dmin);
+                q0 = dt_group_shfl(bq, who ? (int)__ffs((int)who) - 1 : 0);
+                if (!who) q0 = -1;
                 if (q0 >= 0 && dt_inside(dt_disc_box(G, p.x, p.y, dmin), B)) break;
             }
             if (q0 < 0) { degenerate |= DT_WHY_EULER; continue; }
@@ -482,19 +604,19 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
                 int iq = q0;
                 while (true) {
                     const double2 q = S[iq];
-                    const double ax = q.x - p.x, ay = q.y - p.y;
-                    const double a2col = kDtColTol * kDtColTol * (ax * ax + ay * ay);
+                    DtEdge E;
+                    E.set(p, q, i, iq, sgn);
                     DtAcc A;
                     A.reset();
-                    dt_scan_box<true>(A, S, G, blk, i, iq, p.x, p.y, ax, ay, a2col, sgn);
-                    DtPick pk = dt_wave_pick(A);
+                    dt_scan_box<kDtGroup>(A, S, G, blk, E);
+                    DtPick pk = dt_group_pick(A);
                     if (pk.id < 0 || !dt_inside(dt_circle_box(G, p.x, p.y, q, S[max(pk.id, 0)]), blk)) {
                         // nothing on that side within the block, or a circumcircle that leaves it: search the circle's
-                        // cell box, or the whole frame
+                        // cell box, or the whole frame (row by row, each row cut down to the wanted side of the edge)
                         const DtBox B = pk.id < 0 ? all : dt_circle_box(G, p.x, p.y, q, S[pk.id]);
                         A.reset();
-                        dt_scan_box<true>(A, S, G, B, i, iq, p.x, p.y, ax, ay, a2col, sgn);
-                        pk = dt_wave_pick(A);
+                        dt_scan_box<kDtGroup>(A, S, G, B, E);
+                        pk = dt_group_pick(A);
                     }
                     if (pk.flag) degenerate |= DT_WHY_COLLINEAR;
                     if (pk.id < 0) { open = 1; break; }                    // a hull edge
@@ -503,7 +625,7 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
                     const int oq = oid[iq], oc = oid[pk.id];
                     if (oi < oq && oi < oc) {
                         if (nrows == kDtWaveRows) { degenerate |= DT_WHY_ROWS; bad = 1; break; }
-                        if (lane == 0) wrows[nrows] = ((uint32_t)min(oq, oc) << 16) | (uint32_t)max(oq, oc);
+                        if (gl == 0) grows[nrows] = ((uint32_t)min(oq, oc) << 16) | (uint32_t)max(oq, oc);
                         ++nrows;
                     }
                     iq = pk.id;
@@ -514,16 +636,16 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
             if (bad) continue;
             // the point's rows, sorted (rank by counting), to the arena
             int base = 0;
-            if (lane == 0 && nrows > 0) base = atomicAdd(&misc[DM_ARENA], nrows);
-            base = __builtin_amdgcn_readfirstlane(base);
+            if (gl == 0 && nrows > 0) base = atomicAdd(&misc[DM_ARENA], nrows);
+            base = dt_group_shfl(base, 0);
             if (base + nrows > L.arena_cap) { degenerate |= DT_WHY_ROWS; continue; }
-            if (lane < nrows) {
-                const uint32_t key = wrows[lane];
+            for (int k0 = gl; k0 < nrows; k0 += kDtGroup) {
+                const uint32_t key = grows[k0];
                 int rank = 0;
-                for (int k = 0; k < nrows; ++k) rank += wrows[k] < key ? 1 : 0;
+                for (int k = 0; k < nrows; ++k) rank += grows[k] < key ? 1 : 0;
                 arena[base + rank] = key;
             }
-            if (lane == 0) {
+            if (gl == 0) {
                 od[oi] = (uint16_t)(nrows | (deg << 6) | (open << 15));
                 astart[oi] = (uint16_t)base;
             }
@@ -531,6 +653,8 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
     }
     if (degenerate) atomicOr(&misc[DM_FLAGS], degenerate);
     __syncthreads();
+    DT_STAMP(5);
+    DT_NOTE(9, misc[DM_NHARD]);
 
     // ---- rows in point order: block prefix over the points' row counts; Euler's relation
     {
@@ -565,12 +689,17 @@ __global__ __launch_bounds__(kDtBlock) void delaunay_kernel(const DtArgs a) {
             }
         }
         if (tid == 0) { a.tri_cnt[f] = total; a.status[f] = MVOSR_DT_OK; if (a.n_used) a.n_used[f] = n; }
+        DT_STAMP(6);
     }
 }
 
 }  // namespace mvosr
 
 using namespace mvosr;
+
+#ifdef MVOSR_STAMPS
+extern "C" void mvosr_debug_dt_stamps(void *dptr) { g_dt_stamps = reinterpret_cast<unsigned long long *>(dptr); }
+#endif
 
 extern "C" int mvosr_delaunay_max_points(void) {
     int lo = 3, hi = 65535;
@@ -600,6 +729,9 @@ extern "C" int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int6
     DtArgs a;
     a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
     a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.max_pts = max_pts;
+#ifdef MVOSR_STAMPS
+    a.stamps = g_dt_stamps;
+#endif
     hipLaunchKernelGGL(delaunay_kernel, dim3((unsigned)n_frames), dim3(kDtBlock), L.total, ctx_stream(ctx), a);
     return check_launch("delaunay_kernel");
 }

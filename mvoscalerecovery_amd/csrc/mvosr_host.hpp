@@ -4,7 +4,26 @@
 
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <unordered_map>
+
 #include "../../include/mvosr.h"
+
+// A block of the context's caching allocators (device memory / pinned host memory): blocks are handed back to a
+// size-ordered free list instead of hipFree / hipHostFree, so that a steady-state caller allocates nothing.  `ev` is
+// recorded on the compute stream when the block is released and waited for when it is handed out again: work that was
+// still queued on the old contents cannot race with the next user (what hipFree's implicit synchronisation gave).
+struct mvosr_block {
+    void *ptr;
+    size_t bytes;
+    hipEvent_t ev;
+    bool pending;
+};
+struct mvosr_block_cache {
+    std::multimap<size_t, mvosr_block> free_blocks;
+    std::unordered_map<void *, mvosr_block> live;
+    size_t cached_bytes = 0;
+};
 
 struct mvosr_ctx {
     int device;
@@ -25,6 +44,12 @@ struct mvosr_ctx {
     int prof_on;
     int prof_calls;
     hipEvent_t prof_ev[64][3];
+    // host <-> device plumbing: a second stream for uploads (so that the next chunk's inputs travel under the current
+    // chunk's kernels), the caching allocators, and their counters (mvosr_ctx_alloc_stats)
+    hipStream_t upload_stream;
+    hipEvent_t upload_ev;
+    mvosr_block_cache dev_cache, host_cache;
+    int64_t n_hip_malloc, n_hip_free, n_host_malloc, n_host_free, n_cache_hits;
 };
 
 constexpr int kProfRing = 64;

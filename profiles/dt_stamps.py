@@ -1,0 +1,39 @@
+"""Diagnostic: where a workgroup of delaunay_kernel spends its life (in-kernel s_memtime stamps).
+Needs a library built with -DMVOSR_STAMPS:   profiles/ab_build.sh stamps -DMVOSR_STAMPS
+    MVOSR_LIB_PATH=profiles/ab/libmvosr_stamps.so python profiles/dt_stamps.py [n] [sets]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvoscalerecovery_amd import _lib, synth          # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+ctx = _lib.default_context(0)
+pool = [synth.synth_frame(i, n, base_seed=99)[1] for i in range(64)]
+cnt = np.full(F, n, dtype=np.int32)
+off = np.arange(F, dtype=np.int64) * n
+uv = np.concatenate([pool[i % 64] for i in range(F)])
+d_u, d_v = ctx.to_device(np.ascontiguousarray(uv[:, 0])), ctx.to_device(np.ascontiguousarray(uv[:, 1]))
+d_off, d_cnt, d_toff = ctx.to_device(off), ctx.to_device(cnt), ctx.to_device(2 * off)
+d_tri = ctx.empty((2 * F * n, 3), np.int32)
+d_tcnt, d_st, d_used = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
+d_stamps = ctx.zeros((F, 16), np.uint64)
+ctx.lib.mvosr_debug_dt_stamps.argtypes = [C.c_void_p]
+ctx.lib.mvosr_debug_dt_stamps(d_stamps.ptr)
+for _ in range(2):
+    _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n, d_toff.ptr,
+                                            d_tri.ptr, d_tcnt.ptr, d_used.ptr, d_st.ptr), "dt")
+ctx.sync()
+s = d_stamps.download().astype(np.float64)
+d = np.diff(s[:, :7], axis=1)
+tot = s[:, 6] - s[:, 0]
+names = ["load + bbox", "grid dims + zero", "count / scan / scatter", "phase 1 (lanes)", "phase 1b (verify)", "phase 2 (hard points)", "prefix + rows out"]
+print("n=%d sets=%d  declined=%d  workgroup life: median %.0f cycles" % (n, F, int((d_st.download() != 0).sum()), np.median(tot)))
+for k, name in enumerate(names[:6]):
+    print("  %-26s %5.1f %%   (median %.0f cycles)" % (name, 100.0 * np.median(d[:, k] / tot), np.median(d[:, k])))
+print("  queued completions: median %.0f   hard points: median %.0f" % (np.median(s[:, 8]), np.median(s[:, 9])))
