@@ -220,16 +220,50 @@ int mvosr_ctx_profile_read(mvosr_ctx *ctx, int call_index, float *scale_kernel_m
 /* Device facts for the host (name, CU count, LDS per workgroup). */
 int mvosr_ctx_device_info(mvosr_ctx *ctx, char *name, int name_len, int *n_cu, int *lds_per_block);
 
-/* ---- device memory / events (so that a ctypes-only host needs no other GPU library) ------ */
+/* ---- device memory / events (so that a ctypes-only host needs no other GPU library) ------
+ * mvosr_malloc / mvosr_host_alloc are CACHING allocators: a block that is freed goes to a size-ordered free list of the
+ * context instead of hipFree / hipHostFree, and the next request of a similar size takes it from there — a caller in
+ * steady state (a chunk loop, the per-frame drop-in call at /root/reference/src/main.py:110-113) allocates nothing.  A
+ * freed block may still be in use by work queued on the context's streams: its next user waits for that work
+ * (what hipFree's implicit synchronisation gave).  mvosr_ctx_trim returns the cached blocks to the runtime;
+ * mvosr_ctx_alloc_stats reports {hipMalloc calls, hipFree calls, hipHostMalloc calls, hipHostFree calls, cache hits,
+ * cached device bytes, cached host bytes, live blocks} (the first n_out of them). */
 int mvosr_malloc(mvosr_ctx *ctx, size_t bytes, void **dptr);
 int mvosr_free(mvosr_ctx *ctx, void *dptr);
+int mvosr_host_alloc(mvosr_ctx *ctx, size_t bytes, void **hptr);                   /* page-locked host memory (staging) */
+int mvosr_host_free(mvosr_ctx *ctx, void *hptr);
+int mvosr_ctx_trim(mvosr_ctx *ctx);
+int mvosr_ctx_alloc_stats(mvosr_ctx *ctx, int64_t *out, int n_out);
 int mvosr_memcpy_h2d(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);   /* stream-ordered, returns after the copy */
 int mvosr_memcpy_d2h(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);   /* stream-ordered, returns after the copy */
+/* Asynchronous forms.  Uploads run on the context's UPLOAD stream (so that the next chunk's inputs travel under the
+ * current chunk's kernels; `src` should be page-locked — mvosr_host_alloc — or the copy is staged by the runtime) and
+ * mvosr_upload_fence makes the compute stream wait for everything uploaded so far (no host wait).  Downloads are
+ * queued on the compute stream; the data is there after mvosr_ctx_sync. */
+int mvosr_memcpy_h2d_async(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);
+int mvosr_upload_fence(mvosr_ctx *ctx);
+int mvosr_memcpy_d2h_async(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);
 int mvosr_memset(mvosr_ctx *ctx, void *dst, int value, size_t bytes);
 int mvosr_event_create(mvosr_ctx *ctx, void **event);
 int mvosr_event_record(mvosr_ctx *ctx, void *event);          /* on the context's current stream */
 int mvosr_event_elapsed_ms(mvosr_ctx *ctx, void *start, void *stop, float *ms);  /* synchronises on `stop` */
+int mvosr_event_sync(mvosr_ctx *ctx, void *event);             /* host waits for the event (not for later work of the stream) */
 int mvosr_event_destroy(mvosr_ctx *ctx, void *event);
+
+/* ---- host-side packing (no GPU work) ---------------------------------------------------------
+ * The per-frame arrays of the reference's call surface — feature3d (N,3) and feature2d (N,2), C-contiguous float64, as
+ * /root/reference/src/main.py:102-113 hands them to scale_calculation — laid out as the planes of mvosr_batch by
+ * `threads` host threads (<= 0: one per hardware thread, at most 16).  mvosr_pack_count applies the vanishing-row filter
+ * (/root/reference/src/scale_calculator.py:252-254: feature2d[:,1] > vanish) and returns the survivors per frame; the
+ * caller derives feat_off (even, ascending) and sizes the planes — e.g. page-locked staging memory, so that the packed
+ * batch is uploaded without another copy —; mvosr_pack_fill writes x|y|z|u|v at feat_off[f] in the caller's order.
+ * remap_in_place != 0 also applies feature_remap (:390-394) to EVERY row of the caller's feature3d arrays, as the
+ * reference does at :414 (the planes keep the raw values: the kernels remap at load). */
+int mvosr_pack_count(int64_t n_frames, const double *const *feature2d, const int32_t *n_points, double vanish, int32_t *feat_cnt,
+                     int threads);
+int mvosr_pack_fill(int64_t n_frames, double *const *feature3d, const double *const *feature2d, const int32_t *n_points,
+                    double vanish, const int64_t *feat_off, double *x, double *y, double *z, double *u, double *v,
+                    int remap_in_place, double cos_pitch, double sin_pitch, int threads);
 
 /* ---- the hot path ------------------------------------------------------------------------- */
 void mvosr_default_params(mvosr_params *p, double absolute_reference);

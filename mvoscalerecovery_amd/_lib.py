@@ -66,13 +66,23 @@ SYMBOLS = {
     "mvosr_ctx_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mvosr_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "mvosr_free": (C.c_int, [_P, _P]),
+    "mvosr_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "mvosr_host_free": (C.c_int, [_P, _P]),
+    "mvosr_ctx_trim": (C.c_int, [_P]),
+    "mvosr_ctx_alloc_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.c_int]),
+    "mvosr_memcpy_h2d_async": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "mvosr_upload_fence": (C.c_int, [_P]),
+    "mvosr_memcpy_d2h_async": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "mvosr_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "mvosr_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "mvosr_memset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),
     "mvosr_event_create": (C.c_int, [_P, C.POINTER(_P)]),
     "mvosr_event_record": (C.c_int, [_P, _P]),
     "mvosr_event_elapsed_ms": (C.c_int, [_P, _P, _P, C.POINTER(C.c_float)]),
+    "mvosr_event_sync": (C.c_int, [_P, _P]),
     "mvosr_event_destroy": (C.c_int, [_P, _P]),
+    "mvosr_pack_count": (C.c_int, [C.c_int64, _P, _P, C.c_double, _P, C.c_int]),
+    "mvosr_pack_fill": (C.c_int, [C.c_int64, _P, _P, _P, C.c_double, _P, _P, _P, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int]),
     "mvosr_default_params": (None, [C.POINTER(Params), C.c_double]),
     "mvosr_scale_batch": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Batch), C.POINTER(Outputs), C.c_int,
                                     C.c_int64, C.c_int64]),
@@ -171,6 +181,154 @@ class DeviceBuffer:
             pass
 
 
+class PinnedBuffer:
+    """Page-locked host memory from the context's caching allocator (mvosr_host_alloc), seen as NumPy arrays."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(max(nbytes, 16))
+        p = C.c_void_p()
+        check(ctx.lib.mvosr_host_alloc(ctx.handle, self.nbytes, C.byref(p)), "mvosr_host_alloc")
+        self.ptr = p.value
+        self._raw = (C.c_char * self.nbytes).from_address(self.ptr)
+
+    def view(self, offset, shape, dtype):
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape, dtype=np.int64))
+        return np.frombuffer(self._raw, dtype=dtype, count=count, offset=int(offset)).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self._raw = None
+            self.ctx.lib.mvosr_host_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceView:
+    """A typed range of a DeviceBlock (what the C ABI sees as one array)."""
+
+    def __init__(self, block, offset, shape, dtype):
+        self.block, self.offset = block, int(offset)
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.ptr = block.ptr + self.offset
+
+    def download(self):
+        return self.block.read(self)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert arr.nbytes == self.nbytes, (arr.shape, self.shape)
+        check(self.block.ctx.lib.mvosr_memcpy_h2d(self.block.ctx.handle, self.ptr, arr.ctypes.data, self.nbytes), "h2d")
+        self.block.invalidate()
+        return self
+
+    def free(self):                      # the block owns the memory
+        pass
+
+
+class DeviceBlock:
+    """ONE device allocation holding several arrays (256-byte aligned), filled by ONE upload from a page-locked
+    staging buffer and read back by ONE download: the per-frame drop-in call and every chunk of the batch path move
+    their inputs and outputs as a couple of transfers instead of one allocation and one blocking copy per array."""
+
+    ALIGN = 256
+    STAGE_LIMIT = 1 << 28              # larger uploads go array by array (a staging mirror of that size is not worth its memory)
+
+    def __init__(self, ctx, spec):
+        """``spec``: list of (name, shape, dtype)."""
+        self.ctx = ctx
+        self.views = {}
+        size = 0
+        plan = []
+        for name, shape, dtype in spec:
+            size = (size + self.ALIGN - 1) & ~(self.ALIGN - 1)
+            shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+            nb = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+            plan.append((name, size, shape, dtype))
+            size += max(nb, 16)
+        self.nbytes = max(size, 16)
+        p = C.c_void_p()
+        check(ctx.lib.mvosr_malloc(ctx.handle, self.nbytes, C.byref(p)), "mvosr_malloc")
+        self.ptr = p.value
+        for name, off, shape, dtype in plan:
+            self.views[name] = DeviceView(self, off, shape, dtype)
+        self._mirror = None               # host copy of the whole block (outputs), valid until invalidate()
+
+    def __getitem__(self, name):
+        return self.views[name]
+
+    def __contains__(self, name):
+        return name in self.views
+
+    def upload(self, arrays):
+        """``arrays``: name -> NumPy array for (a subset of) the block's views.  One staged asynchronous copy on the upload
+        stream, the compute stream waits for it (no host wait)."""
+        ctx = self.ctx
+        if not arrays:
+            return self
+        if self.nbytes > self.STAGE_LIMIT:
+            for name, arr in arrays.items():
+                v = self.views[name]
+                arr = np.ascontiguousarray(arr, dtype=v.dtype)
+                assert arr.nbytes == v.nbytes, (name, arr.shape, v.shape)
+                check(ctx.lib.mvosr_memcpy_h2d(ctx.handle, v.ptr, arr.ctypes.data, v.nbytes), "h2d")
+            return self
+        lo = min(self.views[n].offset for n in arrays)
+        hi = max(self.views[n].offset + self.views[n].nbytes for n in arrays)
+        stage = PinnedBuffer(ctx, hi - lo)
+        for name, arr in arrays.items():
+            v = self.views[name]
+            dst = stage.view(v.offset - lo, v.shape, v.dtype)
+            np.copyto(dst, np.asarray(arr).reshape(v.shape), casting="same_kind")
+        check(ctx.lib.mvosr_memcpy_h2d_async(ctx.handle, self.ptr + lo, stage.ptr, hi - lo), "h2d_async")
+        check(ctx.lib.mvosr_upload_fence(ctx.handle), "upload_fence")
+        stage.free()                      # (back to the cache; its next user waits for the copy)
+        return self
+
+    def zero(self):
+        check(self.ctx.lib.mvosr_memset(self.ctx.handle, self.ptr, 0, self.nbytes), "memset")
+        return self
+
+    def invalidate(self):
+        self._mirror = None
+
+    def read(self, view):
+        """The view's contents as a NumPy array.  The first read after a launch brings the WHOLE block to the host (one
+        copy + one synchronisation); later reads are served from that copy."""
+        ctx = self.ctx
+        if self.nbytes > self.STAGE_LIMIT:
+            out = np.empty(view.shape, dtype=view.dtype)
+            check(ctx.lib.mvosr_memcpy_d2h(ctx.handle, out.ctypes.data, view.ptr, view.nbytes), "d2h")
+            return out
+        if self._mirror is None:
+            stage = PinnedBuffer(ctx, self.nbytes)
+            check(ctx.lib.mvosr_memcpy_d2h_async(ctx.handle, stage.ptr, self.ptr, self.nbytes), "d2h_async")
+            ctx.sync()
+            self._mirror = np.array(stage.view(0, (self.nbytes,), np.uint8), copy=True)
+            stage.free()
+        return np.array(self._mirror[view.offset:view.offset + view.nbytes].view(view.dtype).reshape(view.shape), copy=True)
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.mvosr_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+        self._mirror = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Context:
     """One device + one HIP stream (mvosr_ctx)."""
 
@@ -194,6 +352,19 @@ class Context:
 
     def zeros(self, shape, dtype):
         return DeviceBuffer(self, shape, dtype).fill(0)
+
+    def block(self, spec):
+        return DeviceBlock(self, spec)
+
+    def alloc_stats(self):
+        """{hip_malloc, hip_free, host_malloc, host_free, cache_hits, cached_device_bytes, cached_host_bytes, live_blocks}"""
+        out = (C.c_int64 * 8)()
+        check(self.lib.mvosr_ctx_alloc_stats(self.handle, out, 8), "mvosr_ctx_alloc_stats")
+        keys = ("hip_malloc", "hip_free", "host_malloc", "host_free", "cache_hits", "cached_device_bytes", "cached_host_bytes", "live_blocks")
+        return dict(zip(keys, (int(v) for v in out)))
+
+    def trim(self):
+        check(self.lib.mvosr_ctx_trim(self.handle), "mvosr_ctx_trim")
 
     def sync(self):
         check(self.lib.mvosr_ctx_sync(self.handle), "mvosr_ctx_sync")

@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <thread>
+#include <vector>
+
 #include "mvosr_host.hpp"
 
 namespace mvosr {
@@ -137,6 +140,26 @@ static int cache_free(mvosr_ctx *ctx, mvosr_block_cache &c, bool host, void *ptr
     c.free_blocks.emplace(b.bytes, b);
     (void)host;
     return MVOSR_OK;
+}
+
+static int pack_threads(int64_t n_frames, int threads) {
+    if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 1; if (threads > 16) threads = 16; }
+    if ((int64_t)threads > n_frames) threads = (int)(n_frames > 0 ? n_frames : 1);
+    return threads;
+}
+
+template <class Fn>
+static void pack_parallel(int64_t n_frames, int threads, Fn fn) {
+    threads = pack_threads(n_frames, threads);
+    if (threads <= 1) { fn(0, n_frames); return; }
+    std::vector<std::thread> pool;
+    const int64_t per = (n_frames + threads - 1) / threads;
+    for (int t = 0; t < threads; ++t) {
+        const int64_t a = t * per, b = a + per < n_frames ? a + per : n_frames;
+        if (a >= b) break;
+        pool.emplace_back([=]() { fn(a, b); });
+    }
+    for (auto &th : pool) th.join();
 }
 
 }  // namespace mvosr
@@ -393,10 +416,64 @@ int mvosr_event_elapsed_ms(mvosr_ctx *ctx, void *start, void *stop, float *ms) {
     return MVOSR_OK;
 }
 
+int mvosr_event_sync(mvosr_ctx *ctx, void *event) {
+    if (!ctx || !event) return set_error(MVOSR_ERR_ARG, "event_sync: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
+    return MVOSR_OK;
+}
+
 int mvosr_event_destroy(mvosr_ctx *ctx, void *event) {
     if (!ctx) return set_error(MVOSR_ERR_ARG, "event_destroy: null context");
     if (!event) return MVOSR_OK;
     HIP_TRY(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+    return MVOSR_OK;
+}
+
+
+// ---- host-side packing (no GPU work): the vanishing-row filter and the plane layout of mvosr_batch ------------------
+// The per-frame arrays of the reference's call surface (feature3d (N,3), feature2d (N,2), row-major float64:
+// /root/reference/src/main.py:102-113) laid out as the planes the kernels read, by a few host threads — a Python loop
+// over the frames costs tens of microseconds per frame, which would bound the end-to-end rate of the batch path.
+int mvosr_pack_count(int64_t n_frames, const double *const *feature2d, const int32_t *n_points, double vanish, int32_t *feat_cnt,
+                     int threads) {
+    if (n_frames < 0 || (n_frames > 0 && (!feature2d || !n_points || !feat_cnt))) return set_error(MVOSR_ERR_ARG, "pack_count: null argument");
+    pack_parallel(n_frames, threads, [=](int64_t a, int64_t b) {
+        for (int64_t f = a; f < b; ++f) {
+            const double *p2 = feature2d[f];
+            const int n = n_points[f];
+            int c = 0;
+            for (int i = 0; i < n; ++i) c += p2[2 * i + 1] > vanish ? 1 : 0;          // scale_calculator.py:252
+            feat_cnt[f] = c;
+        }
+    });
+    return MVOSR_OK;
+}
+
+int mvosr_pack_fill(int64_t n_frames, double *const *feature3d, const double *const *feature2d, const int32_t *n_points,
+                    double vanish, const int64_t *feat_off, double *x, double *y, double *z, double *u, double *v,
+                    int remap_in_place, double cos_pitch, double sin_pitch, int threads) {
+    if (n_frames < 0 || (n_frames > 0 && (!feature3d || !feature2d || !n_points || !feat_off || !x || !y || !z || !u || !v)))
+        return set_error(MVOSR_ERR_ARG, "pack_fill: null argument");
+    pack_parallel(n_frames, threads, [=](int64_t a, int64_t b) {
+        for (int64_t f = a; f < b; ++f) {
+            double *p3 = feature3d[f];
+            const double *p2 = feature2d[f];
+            const int n = n_points[f];
+            int64_t o = feat_off[f];
+            for (int i = 0; i < n; ++i) {
+                const double yy = p3[3 * i + 1], zz = p3[3 * i + 2];
+                if (p2[2 * i + 1] > vanish) {
+                    x[o] = p3[3 * i]; y[o] = yy; z[o] = zz; u[o] = p2[2 * i]; v[o] = p2[2 * i + 1];
+                    ++o;
+                }
+                if (remap_in_place) {                                             // feature_remap on the caller's array (:390-394,:414)
+                    p3[3 * i + 1] = yy * cos_pitch - zz * sin_pitch;
+                    p3[3 * i + 2] = yy * sin_pitch + zz * cos_pitch;
+                }
+            }
+        }
+    });
     return MVOSR_OK;
 }
 

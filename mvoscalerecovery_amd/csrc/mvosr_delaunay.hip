@@ -148,13 +148,14 @@ struct DtEdge {
 };
 
 // The best apex seen so far as a fraction num / cr (cr > 0): t = cot of the angle under which the candidate sees the
-// edge.  `tie`: a candidate came within the guard band of the best of its time — which covers every candidate within
-// the band of the FINAL best (a better one that arrives later is compared with the best of its own time, itself at
-// least as good as the earlier candidate).
+// edge.  Lane pass: `tie` = a candidate came within the guard band of the best OF ITS TIME — which covers every
+// candidate within the band of the FINAL best (a better one that arrives later is compared with the best of its own
+// time, itself at least as good as the earlier candidate) but also chance encounters with an intermediate best, so a
+// set flag is only a reason to look again (dt_confirm_tie).  Group passes keep the runner-up and decide exactly.
 struct DtAcc {
-    double n1, c1, s1;
+    double n1, c1, s1, n2, c2;      // (lane pass: best + `tie`; group passes: best and runner-up)
     int b1, flag, tie;
-    __device__ __forceinline__ void reset() { n1 = 1e300; c1 = 1.0; s1 = kDtTieTol * 1e300; b1 = -1; flag = 0; tie = 0; }
+    __device__ __forceinline__ void reset() { n1 = 1e300; c1 = 1.0; s1 = kDtTieTol * 1e300; n2 = 1e300; c2 = 1.0; b1 = -1; flag = 0; tie = 0; }
 };
 
 constexpr int kDtGroup = 16;            // lanes that share a completion in the group passes: one DPP row
@@ -172,9 +173,9 @@ __device__ __forceinline__ void dt_step(DtAcc &A, const DtEdge &E, int j, double
     const bool ok = !skip & !col & (cr > 0.0);
     const double d = __builtin_fma(num, A.c1, -(A.n1 * cr));            // num / cr < n1 / c1  <=>  d < 0
     const bool better = ok & (d < 0.0);
-    A.tie |= (ok & (fabs(d) <= A.s1 * cr)) ? 1 : 0;                     // |t - t1| <= tol (|t1| + 1)
-    const double s_new = kDtTieTol * (fabs(num) + cr);
-    A.n1 = better ? num : A.n1; A.c1 = better ? cr : A.c1; A.s1 = better ? s_new : A.s1; A.b1 = better ? j : A.b1;
+    const bool second = ok & !better & (__builtin_fma(num, A.c2, -(A.n2 * cr)) < 0.0);
+    A.n2 = better ? A.n1 : (second ? num : A.n2); A.c2 = better ? A.c1 : (second ? cr : A.c2);
+    A.n1 = better ? num : A.n1; A.c1 = better ? cr : A.c1; A.b1 = better ? j : A.b1;
 }
 
 // one candidate of the lane pass: m1 = the lane is wrapping its star (as dt_step, apex on the left); otherwise it is
@@ -207,6 +208,27 @@ __device__ __forceinline__ void dt_row_range(const DtGrid &G, const DtEdge &E, i
     }
     j0 = 0; j1 = 0;
     if (xa <= xb) { j0 = G.row_begin(y, xa); j1 = G.row_end(y, xb); }
+}
+
+// Lane pass, cold: is any candidate of the block other than the winner within the guard band of the winner?
+__device__ __attribute__((noinline)) bool dt_confirm_tie(const double2 *S, const DtGrid &G, const DtBox &blk, const DtEdge &E,
+                                                         int b1, double n1, double c1) {
+    const double s1 = kDtTieTol * (fabs(n1) + c1);
+    bool tie = false;
+    for (int y = blk.ya; y <= blk.yb; ++y) {
+        const int j1 = G.row_end(y, blk.xb);
+        for (int j = G.row_begin(y, blk.xa); j < j1; ++j) {
+            if (j == E.i || j == E.iq || j == b1) continue;
+            const double2 c = S[j];
+            const double bx = c.x - E.px, by = c.y - E.py;
+            const double cr = __builtin_fma(E.ax, by, -(E.ay * bx));
+            const double b2 = __builtin_fma(bx, bx, by * by);
+            if (cr * cr <= E.a2col * b2 || !(cr > 0.0)) continue;
+            const double num = b2 - __builtin_fma(bx, E.ax, by * E.ay);
+            if (fabs(__builtin_fma(num, c1, -(n1 * cr))) <= s1 * cr) tie = true;
+        }
+    }
+    return tie;
 }
 
 // a cell box, GL lanes striding over each row
@@ -245,7 +267,7 @@ __device__ __forceinline__ DtPick dt_group_pick(const DtAcc &A) {
     r.id = dt_group_shfl(A.b1, who ? (int)__ffs((int)who) - 1 : 0);
     if (!who) r.id = -1;
     const double band = kDtTieTol * (fabs(m) + 1.0);
-    const bool close = (A.b1 >= 0 && A.b1 != r.id && t1 - m <= band) || A.tie != 0;
+    const bool close = (A.b1 >= 0 && A.b1 != r.id && t1 - m <= band) || (A.n2 / A.c2 - m <= band);
     r.tie = (r.id >= 0) && dt_group_ballot(close) != 0u;
     r.flag = dt_group_ballot(A.flag != 0) != 0u;
     return r;
@@ -478,7 +500,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                 iq = q0; mode = 1;
             } else {
                 if (A.flag) degenerate |= DT_WHY_COLLINEAR;
-                if (A.tie) degenerate |= DT_WHY_TIE;
+                if (A.tie && dt_confirm_tie(S, G, blk, E, A.b1, A.n1, A.c1)) degenerate |= DT_WHY_TIE;
                 const int ic = A.b1;
                 if (ic < 0) state = 2;                               // open within the block
                 else {

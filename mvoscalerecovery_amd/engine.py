@@ -15,17 +15,22 @@ from .packing import PackedFrames
 
 
 def make_params(absolute_reference, camera_pitch=K.CAMERA_PITCH, pitch_threshold_deg=K.PITCH_THRESHOLD_DEG,
-                skew_threshold=K.SKEW_THRESHOLD, mode_rel=K.MODE_REL, mode_min=K.MODE_MIN):
+                skew_threshold=K.SKEW_THRESHOLD, mode_rel=K.MODE_REL, mode_min=K.MODE_MIN, check_triangle="reference"):
     """cos/sin come from NumPy so the kernels rotate with the very doubles the reference uses
     (/root/reference/src/scale_calculator.py:391-392)."""
     return _lib.Params(float(np.cos(camera_pitch)), float(np.sin(camera_pitch)), float(absolute_reference),
-                       float(pitch_threshold_deg), float(skew_threshold), float(mode_rel), int(mode_min), 0)
+                       float(pitch_threshold_deg), float(skew_threshold), float(mode_rel), int(mode_min),
+                       _lib.VOTE_FIXED if check_triangle == "fixed" else _lib.VOTE_REFERENCE)
 
 
 class DeviceBatch:
-    """HBM-resident image of a packed batch."""
+    """HBM-resident image of a packed batch: ONE device block per upload (features + first triangulation; second
+    triangulation + tile index), each filled by one staged asynchronous copy (``_lib.DeviceBlock``)."""
 
-    def __init__(self, ctx: _lib.Context, pf: PackedFrames, with_tri2=True):
+    def __init__(self, ctx: _lib.Context, pf: PackedFrames, with_tri2=True, device_triangulation=False):
+        """``device_triangulation``: both triangulations will be BUILT on the device (:meth:`triangulate`) — the pixel
+        column ``u`` travels too, and rows, row counts, vote counters and survivor counts get device buffers that the
+        stages hand to each other; nothing of them visits the host."""
         self.ctx = ctx
         self.n_frames = pf.n_frames
         self.max_feat = pf.max_feat
@@ -36,34 +41,78 @@ class DeviceBatch:
         self.algorithmic_bytes = pf.algorithmic_bytes()
         self.tri2_ids = 0
         self.bufs = {}
-        up = self.bufs
-        up["feat_off"] = ctx.to_device(pf.feat_off, np.int64)
-        up["feat_cnt"] = ctx.to_device(pf.feat_cnt, np.int32)
+        self.blocks = []
+        arrays = {"feat_off": (pf.feat_off, np.int64), "feat_cnt": (pf.feat_cnt, np.int32)}
         for name in ("x", "y", "z", "v"):
-            up[name] = ctx.to_device(getattr(pf, name), np.float64)
-        if pf.tri1_off is not None:
-            up["tri1_off"] = ctx.to_device(pf.tri1_off, np.int64)
-            up["tri1"] = ctx.to_device(pf.tri1, np.int32)
-        if with_tri2 and pf.tri2_off is not None:
+            arrays[name] = (getattr(pf, name), np.float64)
+        if pf.tri1_off is not None and not device_triangulation:
+            arrays["tri1_off"] = (pf.tri1_off, np.int64)
+            arrays["tri1"] = (pf.tri1, np.int32)
+        if device_triangulation:
+            arrays["u"] = (pf.u, np.float64)
+            arrays["tri_off"] = (2 * np.asarray(pf.feat_off, dtype=np.int64), np.int64)     # a frame's rows start at twice its feature offset: room for 2n rows
+        self._upload(arrays)
+        self.device_triangulation = bool(device_triangulation)
+        if device_triangulation:
+            F, T = pf.n_frames, 2 * pf.total_padded
+            work = ctx.block([("tri1", (T, 3), np.int32), ("tri2", (T, 3), np.int32), ("vote_counters", pf.total_padded, np.int32)])
+            info = ctx.block([(k, max(F, 1), np.int32) for k in ("tri1_cnt", "tri2_cnt", "dt1_status", "dt2_status", "n2_expected")])
+            self.blocks += [work, info]
+            self.info = info
+            for k in ("tri1", "tri2", "vote_counters"):
+                self.bufs[k] = work[k]
+            for k in info.views:
+                self.bufs[k] = info[k]
+            self.bufs["tri1_off"] = self.bufs["tri2_off"] = self.bufs["tri_off"]
+        elif with_tri2 and pf.tri2_off is not None:
             self.set_tri2(pf)
         self._struct = None
 
+    def triangulate(self, engine):
+        """Delaunay #1 -> depth-order vote -> Delaunay #2 over the survivors (/root/reference/src/scale_calculator.py:
+        257-267), three launches on the context's stream; rows, counters and counts stay in HBM."""
+        ctx, lib, b = self.ctx, self.ctx.lib, self.bufs
+        assert self.device_triangulation
+        self.info.invalidate()
+        _lib.check(lib.mvosr_delaunay_batch(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
+                                            None, int(self.max_feat), b["tri_off"].ptr, b["tri1"].ptr, b["tri1_cnt"].ptr, None,
+                                            b["dt1_status"].ptr), "mvosr_delaunay_batch (first triangulation)")
+        o = _lib.Outputs()
+        o.vote_counters = b["vote_counters"].ptr
+        bs = self.struct()
+        _lib.check(lib.mvosr_outlier_vote_batch(ctx.handle, C.byref(engine.params), C.byref(bs), C.byref(o), 0), "mvosr_outlier_vote_batch")
+        _lib.check(lib.mvosr_delaunay_batch(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
+                                            b["vote_counters"].ptr, int(self.max_feat), b["tri_off"].ptr, b["tri2"].ptr, b["tri2_cnt"].ptr,
+                                            b["n2_expected"].ptr, b["dt2_status"].ptr), "mvosr_delaunay_batch (second triangulation)")
+
+    def triangulation_status(self):
+        """Host copies of (first, second) triangulation status per frame (mvosr_dt_status; non-zero: declined)."""
+        return self.bufs["dt1_status"].download(), self.bufs["dt2_status"].download()
+
+    def _upload(self, arrays):
+        arrays = {k: np.ascontiguousarray(a, dtype=dt) for k, (a, dt) in arrays.items()}
+        blk = self.ctx.block([(k, a.shape, a.dtype) for k, a in arrays.items()])
+        blk.upload(arrays)
+        self.blocks.append(blk)
+        for k in arrays:
+            self.bufs[k] = blk[k]
+
     def set_tri2(self, pf: PackedFrames):
-        self.bufs["tri2_off"] = self.ctx.to_device(pf.tri2_off, np.int64)
-        self.bufs["tri2"] = self.ctx.to_device(pf.tri2, np.int32)
+        arrays = {"tri2_off": (pf.tri2_off, np.int64), "tri2": (pf.tri2, np.int32)}
         self.n_tri2 = int(pf.tri2_off[-1])
         self.tri2_ids = int(pf.tri2_ids)
         if pf.n2_expected is not None:
-            self.bufs["n2_expected"] = self.ctx.to_device(pf.n2_expected, np.int32)
+            arrays["n2_expected"] = (pf.n2_expected, np.int32)
         self.tile_w = 0
         if pf.tile_w and pf.tile1_off is not None and pf.tile2_off is not None:
             self.tile_w = int(pf.tile_w)
-            self.bufs["tile_base"] = self.ctx.to_device(pf.tile_base, np.int64)
-            self.bufs["tile1_off"] = self.ctx.to_device(pf.tile1_off, np.int32)
-            self.bufs["tile2_off"] = self.ctx.to_device(pf.tile2_off, np.int32)
+            arrays["tile_base"] = (pf.tile_base, np.int64)
+            arrays["tile1_off"] = (pf.tile1_off, np.int32)
+            arrays["tile2_off"] = (pf.tile2_off, np.int32)
             if pf.tile_far is not None:
-                self.bufs["tile_far"] = self.ctx.to_device(pf.tile_far, np.float64)
-                self.bufs["tile_far_off"] = self.ctx.to_device(pf.tile_far_off, np.int64)
+                arrays["tile_far"] = (pf.tile_far, np.float64)
+                arrays["tile_far_off"] = (pf.tile_far_off, np.int64)
+        self._upload(arrays)
         self.algorithmic_bytes = pf.algorithmic_bytes()
         self._struct = None
 
@@ -76,6 +125,8 @@ class DeviceBatch:
                                       getattr(self, "tile_w", 0), 0, p("tile_base"), p("tile1_off"), p("tile2_off"))
             self._struct.tile_far = p("tile_far")
             self._struct.tile_far_off = p("tile_far_off")
+            self._struct.tri1_cnt = p("tri1_cnt")
+            self._struct.tri2_cnt = p("tri2_cnt")
             if self.n_frames:               # min_feat + the size classes' counts (ragged batches launch per class)
                 mf = self._struct.max_feat
                 _lib.check(self.ctx.lib.mvosr_batch_size_hint(self._feat_cnt_host.ctypes.data, self.n_frames,
@@ -84,35 +135,45 @@ class DeviceBatch:
         return self._struct
 
     def free(self):
-        for b in self.bufs.values():
+        for b in self.blocks:
             b.free()
+        self.blocks = []
         self.bufs = {}
 
 
 class DeviceOutputs:
-    """Output arrays of a launch; ``stage=True`` adds the per-stage arrays used by parity tests
-    and by the per-frame drop-in call (selected mask, counters, per-triangle values)."""
+    """Output arrays of a launch in ONE device block, read back by one download; ``stage=True`` adds the per-stage
+    arrays used by parity tests and by the per-frame drop-in call (selected mask, counters, per-triangle values).
+    ``share``: another DeviceOutputs whose per-frame arrays (raw_scale ... counts) this one writes into as well."""
 
-    def __init__(self, ctx, batch: DeviceBatch, counts=True, stage=False, per_triangle=False, hist=False):
+    def __init__(self, ctx, batch: DeviceBatch, counts=True, stage=False, per_triangle=False, hist=False, share=None):
         F = batch.n_frames
         self.ctx = ctx
-        self.bufs = {
-            "raw_scale": ctx.empty(F, np.float64), "height": ctx.empty(F, np.float64),
-            "height_level": ctx.empty(F, np.float64), "status": ctx.empty(F, np.int32),
-        }
-        if counts:
-            self.bufs["counts"] = ctx.zeros((F, _lib.N_COUNTS), np.int32)
+        spec, zero = [], False
+        if share is None:
+            spec += [("raw_scale", F, np.float64), ("height", F, np.float64), ("height_level", F, np.float64), ("status", F, np.int32)]
+            if counts:
+                spec.append(("counts", (F, _lib.N_COUNTS), np.int32))
+                zero = True
         if stage:
-            self.bufs["vote_counters"] = ctx.zeros(batch.total_padded, np.int32)
-            self.bufs["selected"] = ctx.zeros(batch.total_padded, np.uint8)
+            spec += [("vote_counters", batch.total_padded, np.int32), ("selected", batch.total_padded, np.uint8)]
+            zero = True
         if per_triangle:
             t2 = max(batch.n_tri2, 1)
-            self.bufs["tri_normals"] = ctx.zeros((t2, 3), np.float64)
-            self.bufs["tri_pitch_deg"] = ctx.zeros(t2, np.float64)
-            self.bufs["tri_heights"] = ctx.zeros(t2, np.float64)
+            spec += [("tri_normals", (t2, 3), np.float64), ("tri_pitch_deg", t2, np.float64), ("tri_heights", t2, np.float64)]
+            zero = True
         if hist:
-            self.bufs["hist"] = ctx.zeros((F, 2, _lib.HIST_BINS), np.int32)
-            self.bufs["stats"] = ctx.zeros((F, 4), np.float64)
+            spec += [("hist", (F, 2, _lib.HIST_BINS), np.int32), ("stats", (F, 4), np.float64)]
+            zero = True
+        self.block = ctx.block(spec) if spec else None
+        self.shared = share
+        self.bufs = dict(self.block.views) if self.block is not None else {}
+        if share is not None:
+            for k in ("raw_scale", "height", "height_level", "status", "counts"):
+                if k in share.bufs:
+                    self.bufs[k] = share.bufs[k]
+        if zero and self.block is not None:
+            self.block.zero()
 
     def struct(self):
         p = lambda k: (self.bufs[k].ptr if k in self.bufs else None)
@@ -120,12 +181,20 @@ class DeviceOutputs:
                             p("vote_counters"), p("selected"), p("tri_normals"), p("tri_pitch_deg"),
                             p("tri_heights"), p("hist"), p("stats"))
 
+    def invalidate(self):
+        """A launch is about to write the arrays: host copies are stale."""
+        if self.block is not None:
+            self.block.invalidate()
+        if self.shared is not None:
+            self.shared.invalidate()
+
     def get(self, name):
         return self.bufs[name].download()
 
     def free(self):
-        for b in self.bufs.values():
-            b.free()
+        if self.block is not None:
+            self.block.free()
+            self.block = None
         self.bufs = {}
 
 
@@ -139,16 +208,19 @@ class ScaleEngine:
 
     def scale_batch(self, batch: DeviceBatch, out: DeviceOutputs, waves=0, first=0, count=0):
         b, o = batch.struct(), out.struct()
+        out.invalidate()
         _lib.check(self.lib.mvosr_scale_batch(self.ctx.handle, C.byref(self.params), C.byref(b), C.byref(o),
                                               int(waves), int(first), int(count)), "mvosr_scale_batch")
 
     def outlier_vote_batch(self, batch: DeviceBatch, out: DeviceOutputs, waves=0):
         b, o = batch.struct(), out.struct()
+        out.invalidate()
         _lib.check(self.lib.mvosr_outlier_vote_batch(self.ctx.handle, C.byref(self.params), C.byref(b), C.byref(o),
                                                      int(waves)), "mvosr_outlier_vote_batch")
 
     def road_model_batch(self, batch: DeviceBatch, out: DeviceOutputs, height_level=None, waves=0):
         b, o = batch.struct(), out.struct()
+        out.invalidate()
         hl = self.ctx.to_device(height_level, np.float64) if height_level is not None else None
         _lib.check(self.lib.mvosr_road_model_batch(self.ctx.handle, C.byref(self.params), C.byref(b),
                                                    hl.ptr if hl is not None else None, C.byref(o), int(waves)),

@@ -450,6 +450,8 @@ def attach_tri1(pf: PackedFrames, tri1s=None, workers=0):
         tri1s = tri1s.get()
     pf.extra["tri1_errors"] = {f: t for f, t in enumerate(tri1s) if isinstance(t, Exception)}
     tri1s = [None if isinstance(t, Exception) else np.ascontiguousarray(t, dtype=np.int32) for t in tri1s]
+    if pf.extra.get("canonical"):               # check_triangle="fixed": rows as a function of the triangle set alone
+        tri1s = [None if t is None else canonical_rows(t) for t in tri1s]
     pf.tri1_off, pf.tri1 = _pack_tris(tri1s)
     return pf
 
@@ -518,6 +520,8 @@ def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0, featu
         tri2s = tri2s.get()
     pf.extra["tri2_errors"] = {f: t for f, t in enumerate(tri2s) if isinstance(t, Exception)}
     tri2s = [None if isinstance(t, Exception) else np.ascontiguousarray(t, dtype=np.int32) for t in tri2s]
+    if pf.extra.get("canonical"):
+        tri2s = [None if t is None else canonical_rows(t) for t in tri2s]
     if valid_masks is not None:
         for f in range(pf.n_frames):
             if perms[f] is not None and tri2s[f] is not None and tri2s[f].shape[0]:

@@ -48,7 +48,7 @@ def raise_for_status(status, frame=None):
 
 class ScaleEstimator:
     def __init__(self, absolute_reference, window_size=6, vanish=K.VANISH, focus=K.FOCUS, device=0,
-                 delaunay_workers=None, verbose=False, mutate_inputs=True, triangulation="scipy"):
+                 delaunay_workers=None, verbose=False, mutate_inputs=True, triangulation="scipy", check_triangle=None):
         # reference attributes (scale_calculator.py:23-40)
         self.absolute_reference = absolute_reference
         self.camera_pitch = K.CAMERA_PITCH
@@ -72,16 +72,28 @@ class ScaleEstimator:
         self.verbose = verbose
         self.mutate_inputs = mutate_inputs          # the reference remaps the caller's feature3d in place (:414)
         self.delaunay_workers = delaunay_workers
-        # "scipy": both triangulations by scipy.spatial.Delaunay on the host, rows consumed verbatim — the reference's
-        # results bit for bit.  "gpu": the device stage mvosr_delaunay_batch (same triangle set, canonical row form) — a
-        # DELIBERATE DEVIATION: the reference's vote depends on Qhull's rotation of each row (:113-115), which cannot be
-        # reproduced, so some frames' scales differ by a histogram bin (DESIGN.md §3.8 has the measured agreement).
+        # triangulation = "scipy": both triangulations by scipy.spatial.Delaunay on the host.  "gpu": the device stage
+        # mvosr_delaunay_batch — same triangle set, canonical row form; rows, vote counters and survivor counts stay in
+        # HBM from the first triangulation to the scale kernel.
+        # check_triangle = "reference": the vote's flag pattern exactly as the reference has it (:113-115 sets flag[1]
+        # where flag[2] is meant), which depends on Qhull's rotation of each row — with SciPy's rows, verbatim, this is
+        # the reference bit for bit (the default).  "fixed": the (0,2) pair marks vertices 0 and 2 — a DECLARED DEVIATION
+        # (DESIGN.md §3.8 has the measured agreement with the reference) under which the vote, and with
+        # rows in canonical form every stage, is a function of the triangle SET alone: "scipy" and "gpu" then give
+        # bit-identical results, pinned by Oracle(check_triangle="fixed").  Default: "reference" with "scipy", "fixed"
+        # with "gpu" ("gpu" with "reference" is accepted but unpinned: Qhull's row rotation cannot be reproduced).
         if triangulation not in ("scipy", "gpu"):
             raise ValueError("triangulation must be 'scipy' or 'gpu'")
+        if check_triangle is None:
+            check_triangle = "fixed" if triangulation == "gpu" else "reference"
+        if check_triangle not in ("reference", "fixed"):
+            raise ValueError("check_triangle must be 'reference' or 'fixed'")
         self.triangulation = triangulation
+        self.check_triangle = check_triangle
         if delaunay_workers is None or delaunay_workers > 1:
             packing.start_pool(delaunay_workers)    # fork the host stage's workers BEFORE the GPU runtime starts its threads
-        self.engine = ScaleEngine(absolute_reference, device=device, camera_pitch=self.camera_pitch)
+        self.engine = ScaleEngine(absolute_reference, device=device, camera_pitch=self.camera_pitch, check_triangle=check_triangle)
+        self.last_declined = 0                      # frames of the last device-triangulation chunk that went to the host's Qhull
         self.last_status = None
         self.last_counts = None
         self.last_raw_scale = None
@@ -123,7 +135,7 @@ class ScaleEstimator:
     # they run on an engine whose remap is the identity.
     def _plain_engine(self):
         if getattr(self, "_plain", None) is None:
-            self._plain = ScaleEngine(self.absolute_reference, ctx=self.engine.ctx, camera_pitch=0.0)
+            self._plain = ScaleEngine(self.absolute_reference, ctx=self.engine.ctx, camera_pitch=0.0, check_triangle=self.check_triangle)
         return self._plain
 
     def _pack_plain(self, feature3d, v_rows):
@@ -258,7 +270,9 @@ class ScaleEstimator:
         if F == 0:
             return np.zeros(0), np.zeros(0)
         stage = bool(_single)
-        if tri1s is None and tri2s is None and not _single and F > self.PIPELINE_CHUNK:
+        if self.triangulation == "gpu" and tri1s is None and tri2s is None:
+            raw, status, level, counts, host_errors, last = self._stream_gpu(feature3ds, feature2ds, stage)
+        elif tri1s is None and tri2s is None and not _single and F > self.PIPELINE_CHUNK:
             raw, status, level, counts, host_errors, last = self._stream_chunks(feature3ds, feature2ds)
         else:
             st = self._chunk_begin(feature3ds, feature2ds, 0, tri1s)
@@ -279,21 +293,29 @@ class ScaleEstimator:
         return filtered, stds
 
     # -- one chunk of frames through the stages; the Delaunay calls are submitted to the pool and collected later
-    def _chunk_begin(self, f3s, f2s, k, tri1s=None):
-        """Vanishing-row filter + packing (:252-254) and the start of the first triangulation (:257)."""
-        pf = packing.pack_features(f3s, f2s, self.vanish)          # raw values, packed BEFORE the in-place remap below
-        if self.mutate_inputs:
+    def _chunk_begin(self, f3s, f2s, k, tri1s=None, _packed=None, _remapped=False):
+        """Vanishing-row filter + packing (:252-254) and the start of the first triangulation (:257), on the host."""
+        if _packed is not None:
+            pf = _packed                                               # (packed — and the caller's arrays remapped — already)
+        elif _remapped:
+            # the caller's arrays were remapped in place by an earlier pass over them (:414): pack them as they are and
+            # run the chunk on the identity-remap engine
+            pf = packing.pack_features(f3s, f2s, self.vanish)
+        else:
+            pf = packing.pack_features(f3s, f2s, self.vanish)      # raw values, packed BEFORE the in-place remap below
+        if self.mutate_inputs and _packed is None and not _remapped:
             for f3 in f3s:
                 if isinstance(f3, np.ndarray) and f3.size:
                     self.feature_remap(f3)                                   # :414
+        pf.extra["canonical"] = self.check_triangle == "fixed"       # rows are brought to canonical form when attached
         if tri1s is not None:
             h1 = tri1s
-        elif self.triangulation == "gpu":
-            pts = [np.stack([pf.u[pf.frame_slice(f)], pf.v[pf.frame_slice(f)]], axis=1) for f in range(pf.n_frames)]
-            h1 = packing.delaunay_gpu_or_host(self.engine.ctx, pts, self.delaunay_workers)
         else:
             h1 = packing.submit_tri1(pf, self.delaunay_workers, slot=k % 4)
-        return {"pf": pf, "h1": h1, "n": len(f3s), "out": None, "dbatch": None, "masks": None}
+        st = {"pf": pf, "h1": h1, "n": len(f3s), "out": None, "dbatch": None, "masks": None}
+        if _remapped:
+            st["eng"] = self._plain_engine()
+        return st
 
     def _chunk_vote(self, st, tri2s, k):
         """First triangulation in, vote on the GPU (:151-167), start of the second triangulation (:266)."""
@@ -317,15 +339,7 @@ class ScaleEstimator:
                     print('feature rejected ', int(np.sum(~m)))
                     print('feature left     ', int(np.sum(m)))
             vote_out.free()
-            if self.triangulation == "gpu":
-                pts = packing.survivor_points(pf, st["masks"])
-                todo = [f for f, p in enumerate(pts) if p is not None]
-                tri2s = [np.zeros((0, 3), dtype=np.int32)] * pf.n_frames
-                for f, t in zip(todo, packing.delaunay_gpu_or_host(ctx, [pts[f] for f in todo], self.delaunay_workers)):
-                    tri2s[f] = t
-                st["h2"] = tri2s
-            else:
-                st["h2"] = packing.submit_tri2(pf, st["masks"], self.delaunay_workers, slot=4 + k % 4)
+            st["h2"] = packing.submit_tri2(pf, st["masks"], self.delaunay_workers, slot=4 + k % 4)
         else:
             if any(p is not None for p in (pf.extra.get("perm") or [])):
                 raise ValueError("precomputed tri2s for dense (re-ordered) frames need the vote mask: pass tri1s only")
@@ -340,38 +354,48 @@ class ScaleEstimator:
         st["dbatch"].set_tri2(pf)
         out = DeviceOutputs(ctx, st["dbatch"], counts=True, stage=stage)
         eng.scale_batch(st["dbatch"], out)
-        if not stage:
-            # A frame with <= 3 features below the vanishing row divides by the height_level its predecessor left
-            # (:263-270,:420-422), so that predecessor's level must be np.mean's own double, not the product kernel's
-            # fixed-order sum: the frames that can be such a predecessor — the one before a too-few frame, and the last
-            # frame of the chunk (what follows is not known here) — run once more, alone, in the exact mode the stage
-            # outputs select.
-            cnt = pf.feat_cnt
-            ok = np.nonzero(cnt > 3)[0]
-            again = set(int(g) for g in ok if g + 1 < len(cnt) and 1 <= cnt[g + 1] <= 3)
-            if len(ok):
-                again.add(int(ok[-1]))
-            if again:
-                ex = DeviceOutputs(ctx, st["dbatch"], counts=False, stage=True)
-                for k in ("raw_scale", "height", "height_level", "status"):
-                    ex.bufs[k].free()
-                    ex.bufs[k] = out.bufs[k]
-                if "counts" in out.bufs:
-                    ex.bufs["counts"] = out.bufs["counts"]
-                for g in sorted(again):
-                    eng.scale_batch(st["dbatch"], ex, first=g, count=1)
-                ctx.sync()
-                for k in ("vote_counters", "selected"):
-                    ex.bufs[k].free()
-                ex.bufs = {}
-        ctx.sync()
-        res = (out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts"))
         host_errors = dict(pf.extra["tri2_errors"])                           # QhullError at :266
         host_errors.update(pf.extra["tri1_errors"])                           # ... or already at :257
+        if not stage:
+            self._exact_rerun(eng, st["dbatch"], out, pf, host_errors)
+        ctx.sync()
+        res = (out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts"))
         st["out"] = out
         if not keep:
             self._chunk_free(st)
         return res + (host_errors,)
+
+    def _exact_rerun(self, eng, db, out, pf, host_errors):
+        """The product (HOT) kernel leaves ``height_level`` as its own fixed-order sum wherever the level decides nothing
+        in the frame itself.  Where a LATER step reads a frame's level, it must be np.mean's own double: the frame before
+        one that takes the "no enough feature for triangulation" branch (3 features below the vanishing row: :263-270
+        divides by the previous level, :420-422), the last frame of the chunk (what follows is not known here), and —
+        since the estimator keeps the level of the last frame that reached :241 when a frame raises — the frame before
+        the chunk's first error and that frame itself when its road model raised (:343-344 come after :241).  Those
+        frames run once more, alone, in the exact mode the stage outputs select."""
+        ctx = self.engine.ctx
+        cnt = pf.feat_cnt
+        ok = np.nonzero(cnt > 3)[0]
+        again = set(int(g) for g in ok if g + 1 < len(cnt) and cnt[g + 1] == 3)
+        if len(ok):
+            again.add(int(ok[-1]))
+        status = out.get("status")
+        bad = np.isin(status, K.ERROR_STATUSES)
+        for f in host_errors:
+            bad[f] = True
+        if bad.any():
+            e = int(np.argmax(bad))
+            if status[e] in (K.ST_ERR_LEFT, K.ST_ERR_RIGHT) and e not in host_errors:
+                again.add(e)
+            prev = [int(g) for g in ok if g < e]
+            if prev:
+                again.add(prev[-1])
+        if again:
+            ex = DeviceOutputs(ctx, db, counts=False, stage=True, share=out)
+            for g in sorted(again):
+                eng.scale_batch(db, ex, first=g, count=1)
+            ctx.sync()
+            ex.free()
 
     @staticmethod
     def _chunk_free(st):
@@ -413,6 +437,92 @@ class ScaleEstimator:
         for (a, _), r in zip(bounds, results):
             host_errors.update({a + f: e for f, e in r[4].items()})
         return raw, status, level, counts, host_errors, S[n - 1]
+
+    GPU_CHUNK = 2048            # frames per chunk of the device-triangulation path
+
+    def _chunk_gpu(self, f3s, f2s, stage):
+        """One chunk with both triangulations built on the device: pack -> ONE upload -> Delaunay #1, vote, Delaunay #2,
+        scale kernel, road model, all queued on the stream; nothing is waited for here (``_chunk_gpu_finish`` does)."""
+        ctx = self.engine.ctx
+        pf = packing.pack_features(f3s, f2s, self.vanish)          # raw values, packed BEFORE the in-place remap below
+        pf.extra["canonical"] = self.check_triangle == "fixed"
+        if self.mutate_inputs:
+            for f3 in f3s:
+                if isinstance(f3, np.ndarray) and f3.size:
+                    self.feature_remap(f3)                                   # :414
+        st = {"pf": pf, "n": len(f3s), "out": None, "dbatch": None, "masks": None, "gpu": True, "stage": stage}
+        if pf.max_feat > packing.delaunay_gpu_max_points() or pf.n_frames == 0:
+            st["gpu"] = False                                                # frames the device stage does not take: the host's path
+            return st
+        db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True)
+        db.triangulate(self.engine)
+        out = DeviceOutputs(ctx, db, counts=True, stage=stage)
+        self.engine.scale_batch(db, out)
+        st["dbatch"], st["out"] = db, out
+        return st
+
+    def _chunk_gpu_finish(self, st, f3s, f2s, keep=False):
+        """Results of a chunk started by ``_chunk_gpu``; frames whose triangulation the device stage declined (degenerate
+        point sets, fewer than 3 points) are redone through the host's path (SciPy's rows, canonical form in "fixed" mode)."""
+        eng, ctx, pf = self.engine, self.engine.ctx, st["pf"]
+        stage = st["stage"]
+        if not st["gpu"]:
+            sub = self._chunk_begin(f3s, f2s, 0, _packed=pf)
+            self._chunk_vote(sub, None, 0)
+            res = self._chunk_scale(sub, None, stage, keep=True)
+            st.update(out=sub["out"], dbatch=sub["dbatch"], masks=sub["masks"], pf=sub["pf"])
+            if not keep:
+                self._chunk_free(st)
+            return res
+        db, out = st["dbatch"], st["out"]
+        if not stage:
+            self._exact_rerun(eng, db, out, pf, {})
+        raw, status, level, counts = out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts")
+        s1, s2 = db.triangulation_status()
+        host_errors = {}
+        redo = np.nonzero((s1 != 0) | (s2 != 0))[0]
+        self.last_declined = len(redo)
+        if len(redo):
+            sub = self._chunk_begin([f3s[f] for f in redo], [f2s[f] for f in redo], 0, _remapped=self.mutate_inputs)
+            self._chunk_vote(sub, None, 0)
+            r_raw, r_status, r_level, r_counts, r_err = self._chunk_scale(sub, None, False)
+            raw[redo], status[redo], level[redo], counts[redo] = r_raw, r_status, r_level, r_counts
+            host_errors = {int(redo[k]): e for k, e in r_err.items()}
+        if stage:
+            c = db.bufs["vote_counters"].download()
+            st["masks"] = [c[pf.frame_slice(f)] >= 0 for f in range(pf.n_frames)]
+            if len(redo):                        # (per-frame call whose triangulation was declined: stage outputs from the host's path)
+                one = self._chunk_begin(f3s, f2s, 0, _remapped=self.mutate_inputs)
+                self._chunk_vote(one, None, 0)
+                self._chunk_scale(one, None, True, keep=True)
+                self._chunk_free(st)
+                st.update(out=one["out"], dbatch=one["dbatch"], masks=one["masks"], pf=one["pf"])
+        if not keep:
+            self._chunk_free(st)
+        return raw, status, level, counts, host_errors
+
+    def _stream_gpu(self, feature3ds, feature2ds, stage):
+        """The batch through the device-triangulation path in chunks: the GPU works on chunk k while this process packs
+        chunk k+1 (every launch and copy of a chunk is asynchronous)."""
+        F, C = len(feature3ds), self.GPU_CHUNK
+        bounds = [(a, min(F, a + C)) for a in range(0, F, C)]
+        results, pending = [], None
+        for k, (a, b) in enumerate(bounds):
+            cur = (self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage), a, b)
+            if pending is not None:
+                ps, pa, pb = pending
+                results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb]))
+            pending = cur
+        ps, pa, pb = pending
+        results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb], keep=True))
+        raw = np.concatenate([r[0] for r in results])
+        status = np.concatenate([r[1] for r in results])
+        level = np.concatenate([r[2] for r in results])
+        counts = np.concatenate([r[3] for r in results])
+        host_errors = {}
+        for (a, _), r in zip(bounds, results):
+            host_errors.update({a + f: e for f, e in r[4].items()})
+        return raw, status, level, counts, host_errors, ps
 
     def _flat_feature_of(self, feature3d, feature2d, st):
         """``self.flat_feature`` / ``flat_feature_2d`` after a batch: the selected points of its last processed frame

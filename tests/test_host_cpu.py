@@ -30,6 +30,30 @@ def test_library_exports_every_declared_symbol():
     assert lib.mvosr_abi_version() == _lib.ABI_VERSION
 
 
+def test_shipped_library_has_no_ablation_switch():
+    """The ablation hook of the profiling builds (env MVOSR_DEBUG_SKIP: bits that switch sweeps off) exists only under
+    -DMVOSR_ABLATE: the product binary does not even contain the variable's name, nor the stamp hooks."""
+    from mvoscalerecovery_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"MVOSR_DEBUG_SKIP" not in blob
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "mvosr_debug" not in nm
+
+
+def test_canonical_rows_and_delaunay_limits():
+    """packing.canonical_rows (the row form of check_triangle="fixed" and of the device triangulation) equals the
+    oracle's; the device stage's size limit is a host-side query."""
+    from mvoscalerecovery_amd import packing
+    from oracle import scale_oracle as so
+    rng = np.random.default_rng(0)
+    t = rng.integers(0, 50, (40, 3)).astype(np.int32)
+    a, b = packing.canonical_rows(t), so.canonical_rows(t)
+    assert np.array_equal(a, b) and a.dtype == np.int32
+    assert np.all(a[:, 0] <= a[:, 1]) and np.all(a[:, 1] <= a[:, 2])
+    assert packing.canonical_rows(np.zeros((0, 3), np.int32)).shape == (0, 3)
+    assert 4000 <= packing.delaunay_gpu_max_points() < 65536
+
+
 def test_lds_plan_three_frames_per_cu():
     from mvoscalerecovery_amd import _lib
     lib = _lib.load()

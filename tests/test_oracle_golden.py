@@ -40,6 +40,43 @@ def test_kat_check_triangle_flags():
         assert flag.tolist() == case["flag"], case
 
 
+def test_fixed_check_triangle_mode_is_order_invariant():
+    """check_triangle="fixed" (the declared deviation of SURVEY.md §8 f1: `b > 0` marks vertices 0 and 2): per pair test
+    the two vertices of the pair are flagged; on the reference's own known-answer cases the fixed pattern differs from
+    the reference's exactly where b > 0; and a frame's result does not change when rows are rotated, reflected or
+    permuted — in both flavours of the oracle — while the reference's pattern does change."""
+    from oracle import scale_oracle_loops as sl
+    from mvoscalerecovery_amd import synth
+    kat = load_json("kat.json")
+    for case in kat["check_triangle"]:
+        v, d = np.array(case["v"], dtype=float), np.array(case["d"], dtype=float)
+        a, b, c = (v[0] - v[1]) * (d[0] - d[1]) > 0, (v[0] - v[2]) * (d[0] - d[2]) > 0, (v[1] - v[2]) * (d[1] - d[2]) > 0
+        want = [a or b, a or c, b or c]
+        assert (so.outlier_votes(v, d, np.array([[0, 1, 2]]), "fixed") == 0).tolist() == want
+        assert sl.check_triangle(v, d, "fixed").tolist() == want
+        if not b:
+            assert want == case["flag"]
+    rng = np.random.default_rng(5)
+    f3, f2 = synth.synth_frame(2, 700, base_seed=77, upper_fraction=0.1)
+    base = so.frame_raw_scale(f3, f2, 1.75, check_triangle="fixed")
+    low = so.lower_mask(f2)
+    t1 = so.delaunay(f2[low])
+    differs = False
+    for trial in range(3):
+        t = np.stack([np.roll(r, rng.integers(3)) if rng.integers(2) else r[::-1] for r in t1])[rng.permutation(len(t1))]
+        r = so.frame_raw_scale(f3, f2, 1.75, tri1=t, check_triangle="fixed")
+        assert np.array_equal(r.counters, base.counters) and r.raw_scale == base.raw_scale and r.height_level == base.height_level
+        assert np.array_equal(r.tri1, base.tri1) and np.array_equal(r.tri2, base.tri2)          # canonical rows
+        differs |= not np.array_equal(so.frame_raw_scale(f3, f2, 1.75, tri1=t).counters, so.frame_raw_scale(f3, f2, 1.75).counters)
+    assert differs                                                    # the reference's pattern IS order-dependent
+    lo = sl.frame_raw_scale(f3, f2, 1.75, check_triangle_mode="fixed")
+    assert lo[0] == base.raw_scale and lo[2] == base.height_level and np.array_equal(lo[3], base.counters)
+    est = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+    assert est.scale_calculation(f3, f2)[0] == base.raw_scale
+    with pytest.raises(ValueError):
+        so.OracleScaleEstimator(1.75, check_triangle="other")
+
+
 def test_kat_three_triangles():
     kat = load_json("kat.json")["three_triangles"]
     sel = so.tri_select(np.array(kat["pts"]), np.array(kat["tri"]))
