@@ -31,7 +31,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                 (per-triangle Python loops, as the reference is written); `cpu_baseline_all_cores` the vectorised one
                 on every CPU the process may use (N = 1 only);
   e2e           frames/s of ScaleEstimator.scale_calculation_batch on a bounded sample, host Delaunay x2, packing and
-                uploads included, with the number of host CPUs it used.
+                uploads included, with the number of host CPUs it used;
+  e2e_gpu_triangulation   the same call with both triangulations built on the device (triangulation="gpu",
+                check_triangle="fixed": a declared deviation, bit-equal to the fixed-mode oracle), plus the Delaunay kernel
+                alone and the allocation counters of the timed call;
+  latency       per-frame latency of the drop-in scale_calculation call in the reference's loop shape.
 """
 from __future__ import annotations
 
@@ -207,6 +211,85 @@ def e2e_leg(args, device, sizes, seed, budget_frames):
     return {"value": n / dt, "unit": "frames/s", "frames": n, "host_cpus": packing.resolve_workers(None),
             "what": "ScaleEstimator.scale_calculation_batch: vanishing-row filter, packing, SciPy Delaunay x2 on the host "
                     "process pool (overlapped with the GPU stages chunk by chunk), uploads, kernels, window median"}
+
+
+def e2e_gpu_leg(args, device, sizes, seed, n_frames):
+    """The batch call end to end with BOTH TRIANGULATIONS BUILT ON THE DEVICE (triangulation="gpu", which selects
+    check_triangle="fixed": DESIGN.md §3.8): C packer -> one upload per chunk -> Delaunay #1 -> vote -> Delaunay #2 ->
+    scale kernel -> road model -> results; rows, masks and counts never leave HBM.  Also: the device triangulation alone
+    (mvosr_delaunay_batch on resident point sets), and the alloc counters of a steady-state call."""
+    from mvoscalerecovery_amd import _lib, packing, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    pool = [synth.synth_frame(200000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(256)]
+    f3s = [pool[i % 256][0] for i in range(n_frames)]
+    f2s = [pool[i % 256][1] for i in range(n_frames)]
+    est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
+    est.scale_calculation_batch(f3s[:4096], f2s[:4096])                       # warm-up: kernels, allocator caches
+    ctx = est.engine.ctx
+    a0 = ctx.alloc_stats()
+    t0 = time.perf_counter()
+    est.scale_calculation_batch(f3s, f2s)
+    dt = time.perf_counter() - t0
+    a1 = ctx.alloc_stats()
+    # the triangulation kernel alone on resident point sets of the workload's size
+    n = int(max(sizes))
+    F = 4096
+    cnt = np.full(F, n, dtype=np.int32)
+    off = np.arange(F, dtype=np.int64) * n
+    uv = np.concatenate([pool[i % 64][1][:n] for i in range(F)])
+    if uv.shape[0] == F * n:
+        d_u, d_v = ctx.to_device(np.ascontiguousarray(uv[:, 0])), ctx.to_device(np.ascontiguousarray(uv[:, 1]))
+        d_off, d_cnt, d_toff = ctx.to_device(off), ctx.to_device(cnt), ctx.to_device(2 * off)
+        d_tri = ctx.empty((2 * F * n, 3), np.int32)
+        d_tcnt, d_st = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
+        launch = lambda: _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n, d_toff.ptr,
+                                                                 d_tri.ptr, d_tcnt.ptr, None, d_st.ptr), "mvosr_delaunay_batch")
+        launch(); ctx.sync()
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.record(e0)
+        for _ in range(3):
+            launch()
+        ctx.record(e1)
+        dt_ms = ctx.elapsed_ms(e0, e1) / 3
+        dt_alone = {"sets_per_s": F / dt_ms * 1e3, "points_per_set": n, "sets": F, "kernel_ms": dt_ms,
+                    "declined": int((d_st.download() != 0).sum())}
+        for b in (d_u, d_v, d_off, d_cnt, d_toff, d_tri, d_tcnt, d_st):
+            b.free()
+    else:
+        dt_alone = None
+    return {"value": n_frames / dt, "unit": "frames/s", "frames": n_frames, "declined_last_chunk": int(est.last_declined),
+            "delaunay_kernel": dt_alone,
+            "hip_malloc_calls_in_timed_call": a1["hip_malloc"] - a0["hip_malloc"], "hip_host_malloc_calls_in_timed_call": a1["host_malloc"] - a0["host_malloc"],
+            "what": "ScaleEstimator(triangulation='gpu').scale_calculation_batch on a list of per-frame arrays: vanishing-row filter + "
+                    "packing by the C packer into page-locked memory, one upload per chunk, Delaunay #1 / vote / Delaunay #2 / scale "
+                    "kernel / road model on the device, window median; a declared deviation from the reference (check_triangle='fixed'), "
+                    "bit-equal to the fixed-mode oracle"}
+
+
+def latency_leg(args, device, sizes, seed, frames=40):
+    """Per-frame latency of the drop-in call in the reference's loop shape (/root/reference/src/main.py:110-113): one
+    scale_calculation per frame — with SciPy's triangulations (the default, bit-exact path) and with the device's."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    fr = [synth.synth_frame(300000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(frames)]
+    out = {}
+    for name, kw in (("scipy", {}), ("gpu", {"triangulation": "gpu"})):
+        est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, delaunay_workers=0, **kw)
+        for f3, f2 in fr[:5]:
+            est.scale_calculation(f3.copy(), f2)
+        a0 = est.engine.ctx.alloc_stats()
+        t = []
+        for f3, f2 in fr:
+            a = f3.copy()
+            t0 = time.perf_counter()
+            est.scale_calculation(a, f2)
+            t.append(time.perf_counter() - t0)
+        a1 = est.engine.ctx.alloc_stats()
+        t = np.array(t) * 1e3
+        out[name] = {"median_ms": float(np.median(t)), "p90_ms": float(np.percentile(t, 90)),
+                     "hip_malloc_calls": a1["hip_malloc"] - a0["hip_malloc"], "hip_host_malloc_calls": a1["host_malloc"] - a0["host_malloc"]}
+    out["what"] = "ScaleEstimator.scale_calculation per frame (stage outputs, flat_feature), %d frames after 5 warm-up calls" % frames
+    return out
 
 
 def main():
@@ -463,6 +546,14 @@ def main():
                 line["e2e"] = e2e_leg(args, local, sizes, 2024, 4096)
             except Exception as exc:                                    # noqa: BLE001
                 line["e2e"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                line["e2e_gpu_triangulation"] = e2e_gpu_leg(args, local, sizes, 2024, 32768)
+            except Exception as exc:                                    # noqa: BLE001
+                line["e2e_gpu_triangulation"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                line["latency"] = latency_leg(args, local, sizes, 2024)
+            except Exception as exc:                                    # noqa: BLE001
+                line["latency"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         print(json.dumps(line))
         sys.stdout.flush()
     if n_gpus > 1:

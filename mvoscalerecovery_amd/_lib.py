@@ -293,12 +293,41 @@ class DeviceBlock:
         stage.free()                      # (back to the cache; its next user waits for the copy)
         return self
 
+    def staging(self):
+        """A page-locked image of the whole block for the caller to fill in place (``stage.view`` at each view's
+        offset); ``commit(stage)`` then uploads it with one asynchronous copy."""
+        return PinnedBuffer(self.ctx, self.nbytes)
+
+    def commit(self, stage):
+        ctx = self.ctx
+        check(ctx.lib.mvosr_memcpy_h2d_async(ctx.handle, self.ptr, stage.ptr, self.nbytes), "h2d_async")
+        check(ctx.lib.mvosr_upload_fence(ctx.handle), "upload_fence")
+        stage.free()
+        return self
+
     def zero(self):
         check(self.ctx.lib.mvosr_memset(self.ctx.handle, self.ptr, 0, self.nbytes), "memset")
         return self
 
+    def prefetch(self):
+        """Queue the download of the whole block behind the work launched so far and mark that point with an event:
+        a later ``read`` waits for the event only — not for work queued after it (the next chunk's kernels)."""
+        ctx = self.ctx
+        if self.nbytes > self.STAGE_LIMIT:
+            return self
+        self._mirror = None
+        self._pf_stage = PinnedBuffer(ctx, self.nbytes)
+        check(ctx.lib.mvosr_memcpy_d2h_async(ctx.handle, self._pf_stage.ptr, self.ptr, self.nbytes), "d2h_async")
+        if getattr(self, "_pf_event", None) is None:
+            self._pf_event = ctx.event()
+        ctx.record(self._pf_event)
+        return self
+
     def invalidate(self):
         self._mirror = None
+        if getattr(self, "_pf_stage", None) is not None:
+            self._pf_stage.free()
+            self._pf_stage = None
 
     def read(self, view):
         """The view's contents as a NumPy array.  The first read after a launch brings the WHOLE block to the host (one
@@ -308,6 +337,11 @@ class DeviceBlock:
             out = np.empty(view.shape, dtype=view.dtype)
             check(ctx.lib.mvosr_memcpy_d2h(ctx.handle, out.ctypes.data, view.ptr, view.nbytes), "d2h")
             return out
+        if self._mirror is None and getattr(self, "_pf_stage", None) is not None:
+            check(ctx.lib.mvosr_event_sync(ctx.handle, self._pf_event), "event_sync")
+            self._mirror = np.array(self._pf_stage.view(0, (self.nbytes,), np.uint8), copy=True)
+            self._pf_stage.free()
+            self._pf_stage = None
         if self._mirror is None:
             stage = PinnedBuffer(ctx, self.nbytes)
             check(ctx.lib.mvosr_memcpy_d2h_async(ctx.handle, stage.ptr, self.ptr, self.nbytes), "d2h_async")
@@ -317,6 +351,12 @@ class DeviceBlock:
         return np.array(self._mirror[view.offset:view.offset + view.nbytes].view(view.dtype).reshape(view.shape), copy=True)
 
     def free(self):
+        if getattr(self, "_pf_stage", None) is not None:
+            self._pf_stage.free()
+            self._pf_stage = None
+        if getattr(self, "_pf_event", None) is not None:
+            self.ctx.lib.mvosr_event_destroy(self.ctx.handle, self._pf_event)
+            self._pf_event = None
         if self.ptr:
             self.ctx.lib.mvosr_free(self.ctx.handle, self.ptr)
             self.ptr = None

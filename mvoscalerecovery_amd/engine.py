@@ -23,11 +23,46 @@ def make_params(absolute_reference, camera_pitch=K.CAMERA_PITCH, pitch_threshold
                        _lib.VOTE_FIXED if check_triangle == "fixed" else _lib.VOTE_REFERENCE)
 
 
+def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=0):
+    """The batch path's front end without a Python loop over the frames' CONTENTS: the C packer (mvosr_pack_count /
+    mvosr_pack_fill, a few host threads) applies the vanishing-row filter (/root/reference/src/scale_calculator.py:252-254)
+    and writes the planes x|y|z|v|u straight into page-locked staging memory, which one asynchronous copy moves into a
+    device block.  ``remap = (cos, sin)``: feature_remap is applied to the caller's arrays in place on the way (:414).
+    Returns ``(PackedFrames without host planes, DeviceBlock)`` for ``DeviceBatch(..., device_triangulation=True,
+    uploaded=block)``."""
+    from . import packing
+    F = len(feature3ds)
+    lib = ctx.lib
+    p3 = np.fromiter((a.__array_interface__["data"][0] for a in feature3ds), dtype=np.uint64, count=F)
+    p2 = np.fromiter((a.__array_interface__["data"][0] for a in feature2ds), dtype=np.uint64, count=F)
+    npts = np.fromiter((a.shape[0] for a in feature3ds), dtype=np.int32, count=F)
+    cnt = np.zeros(F, dtype=np.int32)
+    _lib.check(lib.mvosr_pack_count(F, p2.ctypes.data, npts.ctypes.data, float(vanish), cnt.ctypes.data, int(threads)), "mvosr_pack_count")
+    off, total = packing.pack_layout(cnt)
+    blk = ctx.block([("feat_off", F, np.int64), ("feat_cnt", F, np.int32), ("x", total, np.float64), ("y", total, np.float64),
+                     ("z", total, np.float64), ("v", total, np.float64), ("u", total, np.float64), ("tri_off", F, np.int64)])
+    stage = blk.staging()
+    sv = lambda k: stage.view(blk[k].offset, blk[k].shape, blk[k].dtype)
+    sv("feat_off")[:] = off
+    sv("feat_cnt")[:] = cnt
+    sv("tri_off")[:] = 2 * off
+    base = stage.ptr
+    c, s_ = (remap if remap is not None else (1.0, 0.0))
+    _lib.check(lib.mvosr_pack_fill(F, p3.ctypes.data, p2.ctypes.data, npts.ctypes.data, float(vanish), off.ctypes.data,
+                                   base + blk["x"].offset, base + blk["y"].offset, base + blk["z"].offset, base + blk["u"].offset,
+                                   base + blk["v"].offset, 1 if remap is not None else 0, float(c), float(s_), int(threads)),
+               "mvosr_pack_fill")
+    blk.commit(stage)
+    pf = PackedFrames(F, off, cnt, None, None, None, None, None, [None] * F, max_feat=int(cnt.max()) if F else 0)
+    pf.extra["total_padded"] = total
+    return pf, blk
+
+
 class DeviceBatch:
     """HBM-resident image of a packed batch: ONE device block per upload (features + first triangulation; second
     triangulation + tile index), each filled by one staged asynchronous copy (``_lib.DeviceBlock``)."""
 
-    def __init__(self, ctx: _lib.Context, pf: PackedFrames, with_tri2=True, device_triangulation=False):
+    def __init__(self, ctx: _lib.Context, pf: PackedFrames, with_tri2=True, device_triangulation=False, uploaded=None):
         """``device_triangulation``: both triangulations will be BUILT on the device (:meth:`triangulate`) — the pixel
         column ``u`` travels too, and rows, row counts, vote counters and survivor counts get device buffers that the
         stages hand to each other; nothing of them visits the host."""
@@ -42,16 +77,21 @@ class DeviceBatch:
         self.tri2_ids = 0
         self.bufs = {}
         self.blocks = []
-        arrays = {"feat_off": (pf.feat_off, np.int64), "feat_cnt": (pf.feat_cnt, np.int32)}
-        for name in ("x", "y", "z", "v"):
-            arrays[name] = (getattr(pf, name), np.float64)
-        if pf.tri1_off is not None and not device_triangulation:
-            arrays["tri1_off"] = (pf.tri1_off, np.int64)
-            arrays["tri1"] = (pf.tri1, np.int32)
-        if device_triangulation:
-            arrays["u"] = (pf.u, np.float64)
-            arrays["tri_off"] = (2 * np.asarray(pf.feat_off, dtype=np.int64), np.int64)     # a frame's rows start at twice its feature offset: room for 2n rows
-        self._upload(arrays)
+        if uploaded is not None:                 # (pack_upload_native: the features are on their way already)
+            assert device_triangulation
+            self.blocks.append(uploaded)
+            self.bufs.update(uploaded.views)
+        else:
+            arrays = {"feat_off": (pf.feat_off, np.int64), "feat_cnt": (pf.feat_cnt, np.int32)}
+            for name in ("x", "y", "z", "v"):
+                arrays[name] = (getattr(pf, name), np.float64)
+            if pf.tri1_off is not None and not device_triangulation:
+                arrays["tri1_off"] = (pf.tri1_off, np.int64)
+                arrays["tri1"] = (pf.tri1, np.int32)
+            if device_triangulation:
+                arrays["u"] = (pf.u, np.float64)
+                arrays["tri_off"] = (2 * np.asarray(pf.feat_off, dtype=np.int64), np.int64)     # a frame's rows start at twice its feature offset: room for 2n rows
+            self._upload(arrays)
         self.device_triangulation = bool(device_triangulation)
         if device_triangulation:
             F, T = pf.n_frames, 2 * pf.total_padded
@@ -88,6 +128,9 @@ class DeviceBatch:
     def triangulation_status(self):
         """Host copies of (first, second) triangulation status per frame (mvosr_dt_status; non-zero: declined)."""
         return self.bufs["dt1_status"].download(), self.bufs["dt2_status"].download()
+
+    def prefetch_info(self):
+        self.info.prefetch()
 
     def _upload(self, arrays):
         arrays = {k: np.ascontiguousarray(a, dtype=dt) for k, (a, dt) in arrays.items()}
@@ -180,6 +223,11 @@ class DeviceOutputs:
         return _lib.Outputs(p("raw_scale"), p("height"), p("height_level"), p("status"), p("counts"),
                             p("vote_counters"), p("selected"), p("tri_normals"), p("tri_pitch_deg"),
                             p("tri_heights"), p("hist"), p("stats"))
+
+    def prefetch(self):
+        """Queue the download of the per-frame results behind the launches so far (see DeviceBlock.prefetch)."""
+        if self.block is not None:
+            self.block.prefetch()
 
     def invalidate(self):
         """A launch is about to write the arrays: host copies are stale."""

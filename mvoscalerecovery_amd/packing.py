@@ -365,7 +365,7 @@ class PackedFrames:
 
     @property
     def total_padded(self):
-        return int(self.x.shape[0])
+        return int(self.extra.get("total_padded", self.x.shape[0] if self.x is not None else 0))
 
     def frame_slice(self, f):
         o = int(self.feat_off[f])
@@ -419,6 +419,25 @@ def pack_features(feature3ds, feature2ds, vanish=VANISH):
         u[o:o + n] = f2[idx, 0]
         v[o:o + n] = f2[idx, 1]
     return PackedFrames(F, off, cnt, x, y, z, v, u, lower_index, max_feat=int(cnt.max()) if F else 0)
+
+
+def native_packable(feature3ds, feature2ds):
+    """Can the C packer (mvosr_pack_*) read these frames in place?  C-contiguous float64 (N,3) / (N,2) NumPy arrays."""
+    f64 = np.dtype(np.float64)
+    for a, b in zip(feature3ds, feature2ds):
+        if not (type(a) is np.ndarray and type(b) is np.ndarray and a.dtype == f64 and b.dtype == f64 and a.ndim == 2 and b.ndim == 2
+                and a.flags.c_contiguous and b.flags.c_contiguous and a.shape[1] == 3 and b.shape[1] == 2 and a.shape[0] == b.shape[0]):
+            return False
+    return True
+
+
+def pack_layout(cnt):
+    """Frame offsets (every frame's segment on a 128-byte line of the planes) and the planes' length for per-frame counts."""
+    padded = (cnt.astype(np.int64) + (FRAME_ALIGN - 1)) & ~np.int64(FRAME_ALIGN - 1)
+    off = np.zeros(len(cnt), dtype=np.int64)
+    if len(cnt):
+        off[1:] = np.cumsum(padded)[:-1]
+    return off, max(int(padded.sum()) if len(cnt) else 0, 2)
 
 
 def _pack_tris(tris):

@@ -365,36 +365,41 @@ class ScaleEstimator:
             self._chunk_free(st)
         return res + (host_errors,)
 
-    def _exact_rerun(self, eng, db, out, pf, host_errors):
+    def _exact_rerun(self, eng, db, out, pf, host_errors, errors_only=False):
         """The product (HOT) kernel leaves ``height_level`` as its own fixed-order sum wherever the level decides nothing
         in the frame itself.  Where a LATER step reads a frame's level, it must be np.mean's own double: the frame before
         one that takes the "no enough feature for triangulation" branch (3 features below the vanishing row: :263-270
         divides by the previous level, :420-422), the last frame of the chunk (what follows is not known here), and —
         since the estimator keeps the level of the last frame that reached :241 when a frame raises — the frame before
         the chunk's first error and that frame itself when its road model raised (:343-344 come after :241).  Those
-        frames run once more, alone, in the exact mode the stage outputs select."""
+        frames run once more, alone, in the exact mode the stage outputs select.  ``host_errors is None``: only the
+        frames known before any result is (no wait for the GPU); ``errors_only``: only the error-related ones."""
         ctx = self.engine.ctx
         cnt = pf.feat_cnt
         ok = np.nonzero(cnt > 3)[0]
-        again = set(int(g) for g in ok if g + 1 < len(cnt) and cnt[g + 1] == 3)
-        if len(ok):
-            again.add(int(ok[-1]))
-        status = out.get("status")
-        bad = np.isin(status, K.ERROR_STATUSES)
-        for f in host_errors:
-            bad[f] = True
-        if bad.any():
-            e = int(np.argmax(bad))
-            if status[e] in (K.ST_ERR_LEFT, K.ST_ERR_RIGHT) and e not in host_errors:
-                again.add(e)
-            prev = [int(g) for g in ok if g < e]
-            if prev:
-                again.add(prev[-1])
+        again = set()
+        if not errors_only:
+            again = set(int(g) for g in ok if g + 1 < len(cnt) and cnt[g + 1] == 3)
+            if len(ok):
+                again.add(int(ok[-1]))
+        if host_errors is not None:
+            status = out.get("status")
+            bad = np.isin(status, K.ERROR_STATUSES)
+            for f in host_errors:
+                bad[f] = True
+            if bad.any():
+                e = int(np.argmax(bad))
+                if status[e] in (K.ST_ERR_LEFT, K.ST_ERR_RIGHT) and e not in host_errors:
+                    again.add(e)
+                prev = [int(g) for g in ok if g < e]
+                if prev:
+                    again.add(prev[-1])
         if again:
             ex = DeviceOutputs(ctx, db, counts=False, stage=True, share=out)
             for g in sorted(again):
                 eng.scale_batch(db, ex, first=g, count=1)
-            ctx.sync()
+            if host_errors is not None:
+                ctx.sync()
             ex.free()
 
     @staticmethod
@@ -441,23 +446,38 @@ class ScaleEstimator:
     GPU_CHUNK = 2048            # frames per chunk of the device-triangulation path
 
     def _chunk_gpu(self, f3s, f2s, stage):
-        """One chunk with both triangulations built on the device: pack -> ONE upload -> Delaunay #1, vote, Delaunay #2,
-        scale kernel, road model, all queued on the stream; nothing is waited for here (``_chunk_gpu_finish`` does)."""
+        """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
+        ONE upload -> Delaunay #1, vote, Delaunay #2, scale kernel, road model, the exact re-runs known in advance and
+        the download of the results, all queued; nothing is waited for here (``_chunk_gpu_finish`` does)."""
+        from .engine import pack_upload_native
         ctx = self.engine.ctx
-        pf = packing.pack_features(f3s, f2s, self.vanish)          # raw values, packed BEFORE the in-place remap below
+        native = len(f3s) > 0 and packing.native_packable(f3s, f2s)
+        blk = None
+        if native:
+            remap = (self.engine.params.cos_pitch, self.engine.params.sin_pitch) if self.mutate_inputs else None
+            pf, blk = pack_upload_native(ctx, f3s, f2s, self.vanish, remap)             # (:252-254, and :414 on the caller's arrays)
+        else:
+            pf = packing.pack_features(f3s, f2s, self.vanish)          # raw values, packed BEFORE the in-place remap below
+            if self.mutate_inputs:
+                for f3 in f3s:
+                    if isinstance(f3, np.ndarray) and f3.size:
+                        self.feature_remap(f3)                                   # :414
         pf.extra["canonical"] = self.check_triangle == "fixed"
-        if self.mutate_inputs:
-            for f3 in f3s:
-                if isinstance(f3, np.ndarray) and f3.size:
-                    self.feature_remap(f3)                                   # :414
-        st = {"pf": pf, "n": len(f3s), "out": None, "dbatch": None, "masks": None, "gpu": True, "stage": stage}
+        st = {"pf": pf, "n": len(f3s), "out": None, "dbatch": None, "masks": None, "gpu": True, "stage": stage,
+              "remapped": bool(self.mutate_inputs)}
         if pf.max_feat > packing.delaunay_gpu_max_points() or pf.n_frames == 0:
             st["gpu"] = False                                                # frames the device stage does not take: the host's path
+            if blk is not None:
+                blk.free()
             return st
-        db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True)
+        db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk)
         db.triangulate(self.engine)
         out = DeviceOutputs(ctx, db, counts=True, stage=stage)
         self.engine.scale_batch(db, out)
+        if not stage:
+            self._exact_rerun(self.engine, db, out, pf, None)
+        out.prefetch()
+        db.prefetch_info()
         st["dbatch"], st["out"] = db, out
         return st
 
@@ -467,7 +487,7 @@ class ScaleEstimator:
         eng, ctx, pf = self.engine, self.engine.ctx, st["pf"]
         stage = st["stage"]
         if not st["gpu"]:
-            sub = self._chunk_begin(f3s, f2s, 0, _packed=pf)
+            sub = self._chunk_begin(f3s, f2s, 0, _remapped=st["remapped"])
             self._chunk_vote(sub, None, 0)
             res = self._chunk_scale(sub, None, stage, keep=True)
             st.update(out=sub["out"], dbatch=sub["dbatch"], masks=sub["masks"], pf=sub["pf"])
@@ -475,15 +495,15 @@ class ScaleEstimator:
                 self._chunk_free(st)
             return res
         db, out = st["dbatch"], st["out"]
-        if not stage:
-            self._exact_rerun(eng, db, out, pf, {})
-        raw, status, level, counts = out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts")
         s1, s2 = db.triangulation_status()
-        host_errors = {}
         redo = np.nonzero((s1 != 0) | (s2 != 0))[0]
+        if not stage:
+            self._exact_rerun(eng, db, out, pf, {int(f): True for f in redo}, errors_only=True)
+        raw, status, level, counts = out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts")
+        host_errors = {}
         self.last_declined = len(redo)
         if len(redo):
-            sub = self._chunk_begin([f3s[f] for f in redo], [f2s[f] for f in redo], 0, _remapped=self.mutate_inputs)
+            sub = self._chunk_begin([f3s[f] for f in redo], [f2s[f] for f in redo], 0, _remapped=st["remapped"])
             self._chunk_vote(sub, None, 0)
             r_raw, r_status, r_level, r_counts, r_err = self._chunk_scale(sub, None, False)
             raw[redo], status[redo], level[redo], counts[redo] = r_raw, r_status, r_level, r_counts
@@ -492,7 +512,7 @@ class ScaleEstimator:
             c = db.bufs["vote_counters"].download()
             st["masks"] = [c[pf.frame_slice(f)] >= 0 for f in range(pf.n_frames)]
             if len(redo):                        # (per-frame call whose triangulation was declined: stage outputs from the host's path)
-                one = self._chunk_begin(f3s, f2s, 0, _remapped=self.mutate_inputs)
+                one = self._chunk_begin(f3s, f2s, 0, _remapped=st["remapped"])
                 self._chunk_vote(one, None, 0)
                 self._chunk_scale(one, None, True, keep=True)
                 self._chunk_free(st)
@@ -628,7 +648,10 @@ class ScaleEstimator:
         valid = valid_masks[f]
         nvalid = int(np.count_nonzero(valid))
         picked = np.nonzero(sel[:nvalid])[0]                                   # np.unique order, :247
-        idx = np.sort(pf.lower_index[f][np.nonzero(valid)[0][picked]])                # np.unique order (:247), whatever the packed order
+        lower = pf.lower_index[f]
+        if lower is None:                                                      # (packed by the C packer: recomputed for this one frame)
+            lower = np.nonzero(np.asarray(feature2ds[f], dtype=np.float64)[:, 1] > self.vanish)[0]
+        idx = np.sort(lower[np.nonzero(valid)[0][picked]])                     # np.unique order (:247), whatever the packed order
         f3 = np.asarray(feature3ds[f], dtype=np.float64)
         if not self.mutate_inputs:
             f3 = f3.copy()
