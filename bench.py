@@ -61,10 +61,50 @@ WINDOW = 5                      # main.py:55
 # ---------------------------------------------------------------------------------------------------------------
 # self-launch (no GPU call may precede this: torch.cuda.device_count() does not initialise the runtime)
 # ---------------------------------------------------------------------------------------------------------------
+def gpu_count_without_runtime():
+    """GPUs of this box WITHOUT touching the HIP runtime (the parent of the self-launched ranks must stay GPU-free): the
+    KFD topology's nodes with SIMDs (CPUs are nodes too, with simd_count 0), cut down by a *_VISIBLE_DEVICES list."""
+    import glob
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            with open(path) as fh:
+                for ln in fh:
+                    if ln.startswith("simd_count"):
+                        n += 1 if int(ln.split()[1]) > 0 else 0
+                        break
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def _tail(path, lines=30):
+    try:
+        with open(path, errors="replace") as fh:
+            return "".join(fh.readlines()[-lines:])
+    except OSError:
+        return ""
+
+
 def launch_ranks(args, argv):
+    """Start the N ranks as child processes (each a fresh interpreter: nothing here has touched a GPU), every rank's
+    stdout / stderr in files of a temporary directory; poll them all — a rank that dies before the first collective would
+    otherwise leave rank 0 waiting in the all-gather for ever — and on the first failure (or the timeout) stop the rest and
+    print the tails of what the ranks wrote."""
+    import shutil
     import socket
-    import torch
-    n_dev = torch.cuda.device_count()
+    import tempfile
+    n_dev = gpu_count_without_runtime()
+    if n_dev is None:
+        import torch
+        n_dev = torch.cuda.device_count()          # (does not initialise the runtime on this image)
     if n_dev < args.gpus and not args.share_gpu:
         print("bench.py: --gpus %d but this box has %d GPU(s); refusing to run (use --share-gpu for a dry run of the "
               "%d-rank path on fewer devices)" % (args.gpus, n_dev, args.gpus), file=sys.stderr)
@@ -72,25 +112,64 @@ def launch_ranks(args, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="mvosr_bench_")
+    procs, files = [], []
     for rank in range(args.gpus):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         if args.share_gpu:
             env["MVOSR_SHARE_GPU"] = "1"
             env["MVOSR_DIST_BACKEND"] = "gloo"
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if any(codes):
-        print("bench.py: rank exit codes %s" % codes, file=sys.stderr)
-        sys.stdout.write(out0 or "")
+        fo = open(os.path.join(logdir, "rank%d.out" % rank), "w")
+        fe = open(os.path.join(logdir, "rank%d.err" % rank), "w")
+        files += [fo, fe]
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=fo, stderr=fe))
+    deadline = time.time() + args.launch_timeout
+    codes = [None] * args.gpus
+    failed = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and failed is None:
+                    failed = "rank %d exited with code %s" % (r, codes[r])
+        if failed is None and time.time() > deadline:
+            failed = "timeout after %d s" % args.launch_timeout
+        if failed is not None:
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        codes = [p.poll() for p in procs]
+    for f in files:
+        f.close()
+    out0 = ""
+    try:
+        with open(os.path.join(logdir, "rank0.out")) as fh:
+            out0 = fh.read()
+    except OSError:
+        pass
+    if failed is not None or any(codes):
+        print("bench.py: %s; rank exit codes %s; logs in %s" % (failed or "a rank failed", codes, logdir), file=sys.stderr)
+        for r in range(args.gpus):
+            if codes[r] not in (0,):
+                print("---- rank %d (exit %s) stderr tail\n%s---- rank %d stdout tail\n%s" % (
+                    r, codes[r], _tail(os.path.join(logdir, "rank%d.err" % r)), r, _tail(os.path.join(logdir, "rank%d.out" % r), 10)), file=sys.stderr)
+        sys.stdout.write(out0)
         return 1
-    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
     if len(lines) != 1:
-        print("bench.py: expected one JSON line from rank 0, got %d" % len(lines), file=sys.stderr)
+        print("bench.py: expected one JSON line from rank 0, got %d (logs in %s)" % (len(lines), logdir), file=sys.stderr)
         return 1
+    shutil.rmtree(logdir, ignore_errors=True)
     print(lines[0])
     return 0
 
@@ -310,6 +389,11 @@ def main():
     ap.add_argument("--no-tiles", action="store_true", help="diagnostic: dense frames without the tile index (the two-sweep gather kernel)")
     ap.add_argument("--no-far-table", action="store_true", help="diagnostic: dense frames without the far rows' vertex table (the kernel gathers)")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--c4", action="store_true",
+                    help="BASELINE configs[3] literally: --total-frames (default 1 000 000) frames SPLIT over the ranks in contiguous, "
+                         "possibly ragged blocks (strong scaling) instead of --frames per rank (weak scaling)")
+    ap.add_argument("--total-frames", type=int, default=0, help="with --c4: frames of the whole job (0: 1 000 000)")
+    ap.add_argument("--launch-timeout", type=int, default=3600, help="seconds the self-launched ranks may take")
     ap.add_argument("--alias-pool", action="store_true",
                     help="diagnostic: every tile reads the feature planes of the SAME pool frames (cache-resident: 41 %% "
                          "less HBM traffic); the JSON line is marked and is not a benchmark result")
@@ -346,6 +430,8 @@ def main():
 
     rank, local, world = sharding.init_distributed()
     n_gpus = world
+    if os.environ.get("MVOSR_BENCH_FAIL_RANK") == str(rank) and world > 1:      # (test hook of the launcher's failure handling)
+        raise RuntimeError("injected failure on rank %d" % rank)
     if os.environ.get("MVOSR_SHARE_GPU") == "1":
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -355,8 +441,15 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     engine = ScaleEngine(ABS_REF, ctx=ctx)
 
-    repeats = max(1, frames_req // pool_n)
-    F = pool_n * repeats
+    c4_total = (args.total_frames or 1000000) if args.c4 else 0
+    if args.c4:
+        a_, b_ = sharding.partition(c4_total, world, rank)
+        frames_req = b_ - a_                                       # this rank's block of the job (ragged: the first total % world ranks hold one more)
+        repeats = max(1, -(-frames_req // pool_n))
+        F = frames_req
+    else:
+        repeats = max(1, frames_req // pool_n)
+        F = pool_n * repeats
     frames, pf_pool, masks, delaunay_cpu_s = build_pool(ctx, engine, sizes, seed=2024)
     dense = pf_pool.max_feat > min(int(ctx.lib.mvosr_max_lds_features()), TILE_ABOVE[0])
     # The pool is uploaded once and replicated in HBM on the device (torch.repeat): F frames at distinct
@@ -384,7 +477,28 @@ def main():
                          offs("tri1_off", pf_pool.tri1_off[:-1], t1p, True), rep("tri1", pf_pool.tri1[:t1p].reshape(-1), np.int32),
                          offs("tri2_off", pf_pool.tri2_off[:-1], t2p, True), rep("tri2", pf_pool.tri2[:t2p].reshape(-1), np.int32),
                          rep("n2", pf_pool.n2_expected, np.int32), pf_pool.max_feat, int(pf_pool.tri2_ids), pool_pad * repeats)
-    cnt_host = np.tile(np.ascontiguousarray(pf_pool.feat_cnt, dtype=np.int32), repeats)
+    cnt_host = np.tile(np.ascontiguousarray(pf_pool.feat_cnt, dtype=np.int32), repeats)[:F]
+    if args.c4:
+        # the job's frame g is pool frame g % pool_n, whichever rank holds it: this rank's frame k is the job's frame
+        # a_ + k.  Per-frame metadata is laid out accordingly (explicit row counts: the offsets are no CSR array then)
+        if dense:
+            print("bench.py: --c4 is configs[3] (LDS-resident frames); dense frames run with --features 20000 --gpus N", file=sys.stderr)
+            sys.exit(2)
+        k_ = np.arange(repeats * pool_n, dtype=np.int64)
+        src, copy = (k_ + a_) % pool_n, k_ // pool_n
+
+        def up(name, arr, dtype):
+            keep[name] = torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).to(dev)
+            return keep[name].data_ptr()
+        t1o, t2o = np.asarray(pf_pool.tri1_off, dtype=np.int64), np.asarray(pf_pool.tri2_off, dtype=np.int64)
+        bstruct.feat_off = up("c4_feat_off", np.asarray(pf_pool.feat_off, dtype=np.int64)[src] + copy * pool_pad, np.int64)
+        bstruct.feat_cnt = up("c4_feat_cnt", np.asarray(pf_pool.feat_cnt)[src], np.int32)
+        bstruct.tri1_off = up("c4_tri1_off", t1o[src] + copy * t1p, np.int64)
+        bstruct.tri2_off = up("c4_tri2_off", t2o[src] + copy * t2p, np.int64)
+        bstruct.tri1_cnt = up("c4_tri1_cnt", (t1o[1:] - t1o[:-1])[src], np.int32)
+        bstruct.tri2_cnt = up("c4_tri2_cnt", (t2o[1:] - t2o[:-1])[src], np.int32)
+        bstruct.n2_expected = up("c4_n2", np.asarray(pf_pool.n2_expected)[src], np.int32)
+        cnt_host = np.ascontiguousarray(np.asarray(pf_pool.feat_cnt, dtype=np.int32)[src][:F])
     _lib.check(ctx.lib.mvosr_batch_size_hint(cnt_host.ctypes.data, F, C.byref(bstruct)), "mvosr_batch_size_hint")
     if pf_pool.tile_w and not args.no_tiles:
         nt = int(pf_pool.tile_base[-1])
@@ -396,14 +510,14 @@ def main():
             nf = int(pf_pool.tile_far_off[-1])
             bstruct.tile_far = rep("tile_far", pf_pool.tile_far[:max(nf, 1)], np.float64)
             bstruct.tile_far_off = offs("tile_far_off", pf_pool.tile_far_off[:-1], nf, True)
-    bytes_per_launch = pf_pool.algorithmic_bytes() * repeats
+    bytes_per_launch = pf_pool.algorithmic_bytes() * repeats if not args.c4 else int(pf_pool.algorithmic_bytes() * (F / pool_n))
     n_mean = float(pf_pool.feat_cnt.mean())
     t1_mean = float(pf_pool.tri1_off[-1]) / pool_n
     t2_mean = float(pf_pool.tri2_off[-1]) / pool_n
 
     # the kernels write this rank's outputs straight into its record; the N-rank step all-gathers the record
-    total_frames = F * n_gpus
-    rec = sharding.RankRecord(F, dev)
+    total_frames = c4_total if args.c4 else F * n_gpus
+    rec = sharding.RankRecord(max(sharding.shard_sizes(total_frames, n_gpus)) if args.c4 else F, dev)
     height = torch.empty(F, dtype=torch.float64, device=dev)
     outs = _lib.Outputs(rec.raw.data_ptr(), height.data_ptr(), rec.level.data_ptr(), rec.status.data_ptr(),
                         None, None, None, None, None, None, None, None)
@@ -411,6 +525,8 @@ def main():
     median = sharding.make_gpu_median(engine)
     force_gather = bool(os.environ.get("MVOSR_BENCH_FORCE_GATHER")) and dist.is_initialized()   # diagnostic: the N>1 step on one rank
     gathered = n_gpus > 1 or force_gather
+
+    last_gather = [None]
 
     def step(ev_pair=None):
         if ev_pair is not None:
@@ -420,7 +536,7 @@ def main():
         if ev_pair is not None:
             ctx.record(ev_pair[1])
         if gathered:
-            filtered, _ = sharding.gather_and_filter(rec, total_frames, WINDOW, median)
+            filtered, last_gather[0] = sharding.gather_and_filter(rec, total_frames, WINDOW, median)
         else:
             filtered = median(rec.raw, WINDOW)
         return filtered
@@ -459,6 +575,11 @@ def main():
     st_all = rec.status.cpu().numpy()
     import zlib
     raw_crc = zlib.crc32(rec.raw.cpu().numpy().tobytes())       # same workload => same number, whatever the build
+    if args.c4:                                                   # ... and, for the split job, however it is split: the whole sequence
+        whole_raw = last_gather[0].raw() if last_gather[0] is not None else rec.raw[:F]
+        whole_st = last_gather[0].status() if last_gather[0] is not None else rec.status[:F]
+        raw_crc = zlib.crc32(whole_raw.cpu().numpy().tobytes())
+        st_all = whole_st.cpu().numpy()
 
     if rank == 0:
         value = total_frames * args.steps / elapsed
@@ -484,11 +605,14 @@ def main():
         line = {
             "metric": "frames/sec scale-recovery, KITTI-00 flow (~2k feats/frame), 1/2/4/8 GPU",
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.c4 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl + ", %d frames per step per GPU (pool of %d unique frames tiled in HBM), GPU stages only: "
                                      "both Delaunay triangulations precomputed on the host (see e2e), single stream" % (F, pool_n),
-                       "frames_per_step_per_gpu": F, "features_per_frame": n_mean, "tri1_per_frame": t1_mean,
+                       "frames_per_step_per_gpu": F, "frames_per_step_total": total_frames,
+                       "split": ("configs[3]: %d frames split over %d rank(s) in contiguous blocks (rank 0 holds %d)" % (total_frames, n_gpus, F)
+                                 if args.c4 else "weak scaling: every rank owns its own frames"),
+                       "features_per_frame": n_mean, "tri1_per_frame": t1_mean,
                        "tri2_per_frame": t2_mean, "window": WINDOW, "parallelism": "frames sharded x%d" % n_gpus,
                        "waves_per_frame": args.waves if args.waves else "auto"},
             "world_size": dist.get_world_size() if dist.is_initialized() else 1,

@@ -14,18 +14,18 @@
 // wavefronts per frame, the frame's points in LDS in fp64, counting-sorted into a uniform grid of ~1.5 points per cell
 // (cell id = row-major, so one row of a cell box is one contiguous range of the sorted array).  Every point builds
 // its own Delaunay star, independently of all others (no shared mutable structure, nothing ordered between stars):
-//   phase 1, ONE LANE PER POINT: nearest neighbour within the point's 5x5 cell block (a Delaunay neighbour), then the
-//     star is wrapped counter-clockwise: the apex of the triangle on the left of the directed edge (p, q) is the
-//     candidate c of the block that sees the edge under the largest angle (smallest cot = (c-p).(c-q) / cross(q-p, c-p),
-//     compared by cross-multiplication: no division or square root per candidate).  Lanes of one cell walk the same
-//     candidate list in lockstep (LDS broadcast reads).  A completion whose circumcircle leaves the block is continued
-//     optimistically and queued for verification; a star that is open within its block, or owns more rows than the
-//     lane's register list holds, goes to the hard list;
-//   phase 1b, ONE WAVEFRONT PER QUEUED COMPLETION: the same search over the cell box of the circumcircle; a different
-//     answer sends the point to the hard list;
-//   phase 2, ONE WAVEFRONT PER HARD POINT (hull vertices, points next to long hull slivers: a few per cent): the same
-//     wrap with the lanes striding over the candidates, the search widened to the circumcircle's cell box or to the
-//     whole frame where the block cannot certify the answer, clockwise as well when the star is open (hull).
+//   ONE LANE PER POINT, the lanes persistent (a lane whose star is complete takes the next point).  A star starts at
+//     the point's nearest neighbour within its 5x5 cell block (a Delaunay neighbour) and is wrapped counter-clockwise:
+//     the apex of the triangle on the left of the directed edge (p, q) is the candidate c that sees the edge under the
+//     largest angle (smallest cot = (c-p).(c-q) / cross(q-p, c-p), compared by cross-multiplication: no division or
+//     square root per candidate; one branch-free step per candidate).  Every iteration of the loop is one scan step
+//     per lane — up to five cell rows, cut down to the wanted side of the edge, and 32 candidates — so lanes in
+//     different stages of different stars share every iteration.  A completion whose circumcircle lies within the
+//     block is final; otherwise the search goes on over the circle's cell box, and where the block holds nothing on
+//     the wanted side over the whole frame (hull vertices, points next to long hull slivers: the star is then wrapped
+//     clockwise from its first neighbour as well);
+//   a GROUP OF 16 LANES (one DPP row) per point for the few points that own more rows or have a larger star than a
+//     lane keeps in registers.
 // A triangle is written by its smallest vertex, so it appears once; a point's rows are sorted and the points' row counts
 // prefix-summed in point order, so the output does not depend on scheduling.
 //
@@ -56,11 +56,11 @@ constexpr double kDtPerCell = MVOSR_DT_PER_CELL;   // target points per cell (me
 constexpr int kDtMaxCells = 4096;
 constexpr int kDtLaneRows = 8;           // rows a point may own on the lane path (more: hard list)
 constexpr int kDtLaneDeg = 24;           // star degree on the lane path
+constexpr int kDtBudget = 32;            // candidates per lane and scan step
 constexpr int kDtWaveRows = 32;          // rows a point may own at all
 constexpr int kDtWaveDeg = 60;
-constexpr int kDtVq = 512;               // queued completions (more: the point goes to the hard list)
-constexpr int kDtHardCap = 1024;         // hard points
-constexpr int kDtArenaSlack = 512;       // rows of points that are recomputed stay behind in the arena
+constexpr int kDtHardCap = 256;          // points left to the group pass
+constexpr int kDtArenaSlack = 64;
 constexpr double kDtTieTol = 1e-9;       // relative guard band on cot differences
 constexpr double kDtColTol = 1e-12;      // relative guard band on collinearity (|cross| <= tol |a| |b|)
 
@@ -93,7 +93,7 @@ static unsigned long long *g_dt_stamps = nullptr;
 #define DT_NOTE(i, v) do {} while (0)
 #endif
 
-struct DtPlan { uint32_t S, oid, od, astart, cs, arena, vq, hard, wrows, red, misc, total; int max_cells, arena_cap; };
+struct DtPlan { uint32_t S, oid, od, astart, cs, arena, hard, wrows, red, misc, total; int max_cells, arena_cap; };
 
 __host__ __device__ inline int dt_cell_cap(int max_pts) {
     int c = (int)((double)max_pts / kDtPerCell * 1.25) + 64;
@@ -110,8 +110,7 @@ __host__ __device__ inline DtPlan dt_plan(int max_pts) {
     p.astart = p.od + 2u * npad;                         // u16 per id: the point's rows in the arena
     p.cs = p.astart + 2u * npad;                         // u32 per cell (+1): end of the cell in the sorted array
     p.arena = p.cs + 4u * (uint32_t)(p.max_cells + 8);   // u32 rows (b << 16 | c) in the order they were found
-    p.vq = p.arena + 4u * (uint32_t)p.arena_cap;         // uint2 per queued completion
-    p.hard = p.vq + 8u * kDtVq;                          // u16 sorted indices
+    p.hard = p.arena + 4u * (uint32_t)p.arena_cap;       // u16 sorted indices
     p.wrows = p.hard + 2u * kDtHardCap;                  // u32 [groups of 16 lanes][kDtWaveRows]
     p.red = p.wrows + 4u * (kDtBlock / 16) * kDtWaveRows;    // doubles: block reductions
     p.misc = p.red + 8u * 4u * kDtWaves;
@@ -314,7 +313,6 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     uint16_t *astart = reinterpret_cast<uint16_t *>(smem + L.astart);
     uint32_t *cs = reinterpret_cast<uint32_t *>(smem + L.cs);
     uint32_t *arena = reinterpret_cast<uint32_t *>(smem + L.arena);
-    uint2 *vq = reinterpret_cast<uint2 *>(smem + L.vq);
     uint16_t *hard = reinterpret_cast<uint16_t *>(smem + L.hard);
     double *red = reinterpret_cast<double *>(smem + L.red);
     int *misc = reinterpret_cast<int *>(smem + L.misc);
@@ -429,49 +427,62 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     DT_STAMP(2);
     int degenerate = 0;
     // ---- phase 1: one lane per point.  Lanes are persistent: a lane whose star is complete takes the next point (stars
-    // have 3 to 10+ triangles: in rounds of 64 points the wavefront would wait for its largest star), and the nearest-
-    // neighbour search that starts a star is the same candidate loop in another mode, so that lanes in different
-    // stages of their stars share every iteration.
+    // have 3 to 10+ triangles: in rounds of 64 points the wavefront would wait for its largest star).  Every iteration of
+    // the loop is ONE SCAN STEP per lane — up to five cell rows and kDtBudget candidates of the lane's current search:
+    // the nearest-neighbour search that starts a star (the same minimisation in another mode), a completion within the
+    // point's block, or the continuation of a WIDE search (the cell box of a circumcircle that leaves the block, or the
+    // whole frame cut down to the wanted side of the edge, when the block holds nothing on that side: hull vertices and
+    // their neighbours).  Lanes in different stages of different stars share every iteration; none waits for another.
     {
         int i = tid < n ? tid : -1;                 // (misc[DM_NEXT] starts at kDtBlock)
         bool exhausted = tid >= n;
-        int mode = 0, oi = 0, q0 = -1, iq = -1, deg = 0, nown = 0;
+        int mode = 0, oi = 0, q0 = -1, iq = -1, deg = 0, nown = 0, open = 0;
+        int wide = 0, y_next = 0, j_resume = 0;     // the current search: box rows from y_next on, the first of them from j_resume
+        double sgn = 1.0;
+        DtBox box = {0, 0, 0, -1};
+        DtAcc A;
+        A.reset();
         double2 p;
         p.x = 0.0; p.y = 0.0;
         uint32_t rows[kDtLaneRows];
 #pragma unroll
         for (int k = 0; k < kDtLaneRows; ++k) rows[k] = 0xFFFFFFFFu;
-        if (i >= 0) { p = S[i]; oi = oid[i]; }
+        auto block_of = [&](double2 pt) {
+            const int cx = G.cellx(pt.x), cy = G.celly(pt.y);
+            DtBox b_;
+            b_.xa = max(cx - kDtR, 0); b_.xb = min(cx + kDtR, G.gx - 1); b_.ya = max(cy - kDtR, 0); b_.yb = min(cy + kDtR, G.gy - 1);
+            return b_;
+        };
+        auto begin_search = [&](const DtBox &b_, int w_) { box = b_; wide = w_; y_next = b_.ya; j_resume = 0; A.reset(); };
+        if (i >= 0) { p = S[i]; oi = oid[i]; begin_search(block_of(p), 0); }
         for (;;) {
             if (i < 0 && !exhausted) {
                 const int idx = atomicAdd(&misc[DM_NEXT], 1);
                 if (idx < n) {
-                    i = idx; p = S[i]; oi = oid[i]; mode = 0; deg = 0; nown = 0; iq = -1;
+                    i = idx; p = S[i]; oi = oid[i]; mode = 0; deg = 0; nown = 0; iq = -1; open = 0; sgn = 1.0;
 #pragma unroll
                     for (int k = 0; k < kDtLaneRows; ++k) rows[k] = 0xFFFFFFFFu;
+                    begin_search(block_of(p), 0);
                 } else exhausted = true;
             }
             if (__ballot(i >= 0) == 0ull) break;
             const bool act = i >= 0, m1 = mode == 1;
-            const int cx = G.cellx(p.x), cy = G.celly(p.y);
-            DtBox blk;
-            blk.xa = max(cx - kDtR, 0); blk.xb = min(cx + kDtR, G.gx - 1); blk.ya = max(cy - kDtR, 0); blk.yb = min(cy + kDtR, G.gy - 1);
             DtEdge E;
-            E.set(p, S[max(iq, 0)], i, iq, 1.0);
+            E.set(p, S[max(iq, 0)], i, iq, sgn);
             if (!m1) E.side = 0;                                     // the nearest-neighbour search takes whole rows
-            // the block's rows as up to five ranges of the sorted array, walked as ONE loop (a loop per row would run
-            // for the longest row of any lane, five times over)
+            // up to five rows of the search's box as ranges of the sorted array, walked as ONE loop (a loop per row would
+            // run for the longest row of any lane, five times over)
             int j0[kDtRows], j1[kDtRows];
 #pragma unroll
             for (int r = 0; r < kDtRows; ++r) {
-                const int y = cy - kDtR + r;
+                const int y = y_next + r;
                 j0[r] = 0; j1[r] = 0;
-                if (act && y >= blk.ya && y <= blk.yb) dt_row_range(G, E, y, blk.xa, blk.xb, j0[r], j1[r]);
+                if (act && y <= box.yb) dt_row_range(G, E, y, box.xa, box.xb, j0[r], j1[r]);
             }
-            DtAcc A;
-            A.reset();
+            j0[0] = max(j0[0], j_resume);
+            int seg = 0, budget = kDtBudget;
             {
-                int j = j0[0], je = j1[0], seg = 0;
+                int j = j0[0], je = j1[0];
                 auto advance = [&]() {
                     do {
                         j = j0[1]; je = j1[1];
@@ -482,36 +493,54 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                     } while (j >= je && seg < kDtRows - 1);
                 };
                 if (j >= je) advance();
-                while (j < je) {
+                while (j < je && budget > 0) {
                     const double2 c = S[j];
                     const int jc = j;
-                    ++j;
+                    ++j; --budget;
                     if (j >= je && seg < kDtRows - 1) advance();
                     dt_step_lane(A, E, m1, jc, c);
                 }
+                if (j < je) { y_next += seg; j_resume = j; }        // out of budget: go on from here in the next iteration
+                else { y_next += kDtRows; j_resume = 0; }
             }
-            if (!act) continue;
+            if (!act || y_next <= box.yb) continue;                  // (the search is not finished)
+            // ---- the search is complete
+            const DtBox blk = block_of(p);
             int state = 0;                                           // 1: finished, 2: hard
+            int accept = -1;
             if (!m1) {
-                // the nearest neighbour is a Delaunay neighbour — if its disc lies within the block
+                // the nearest neighbour is a Delaunay neighbour — certified when its disc lies within what was searched
                 q0 = A.b1;
                 if (q0 >= 0 && A.n1 == 0.0) degenerate |= DT_WHY_DUP;
-                if (q0 < 0 || !dt_inside(dt_disc_box(G, p.x, p.y, A.n1), blk)) state = 2;
-                iq = q0; mode = 1;
+                if (q0 >= 0 && (wide || dt_inside(dt_disc_box(G, p.x, p.y, A.n1), blk))) {
+                    iq = q0; mode = 1;
+                    begin_search(blk, 0);
+                } else if (!wide) {
+                    const DtBox all = {0, G.gx - 1, 0, G.gy - 1};
+                    begin_search(all, 1);
+                } else state = 2;                                    // (a frame of one point: cannot happen, n >= 3)
             } else {
                 if (A.flag) degenerate |= DT_WHY_COLLINEAR;
-                if (A.tie && dt_confirm_tie(S, G, blk, E, A.b1, A.n1, A.c1)) degenerate |= DT_WHY_TIE;
                 const int ic = A.b1;
-                if (ic < 0) state = 2;                               // open within the block
-                else {
-                    if (!dt_inside(dt_circle_box(G, p.x, p.y, S[iq], S[ic]), blk)) {
-                        // the circumcircle leaves the block: go on, a group of lanes checks the completion afterwards
-                        const int pos = atomicAdd(&misc[DM_VQ], 1);
-                        if (pos >= kDtVq) state = 2;
-                        else { uint2 e; e.x = (uint32_t)i | ((uint32_t)iq << 16); e.y = (uint32_t)ic; vq[pos] = e; }
+                if (!wide) {
+                    if (ic >= 0 && dt_inside(dt_circle_box(G, p.x, p.y, S[iq], S[ic]), blk)) accept = ic;
+                    else {
+                        // nothing on that side within the block, or a circumcircle that leaves it: the search goes on over
+                        // the circle's cell box, or over the whole frame (each row cut down to the wanted side of the edge)
+                        const DtBox all = {0, G.gx - 1, 0, G.gy - 1};
+                        begin_search(ic < 0 ? all : dt_circle_box(G, p.x, p.y, S[iq], S[ic]), 1);
                     }
+                } else if (ic >= 0) accept = ic;
+                else {
+                    // a hull edge: the star is open.  Counter-clockwise done: clockwise from the first neighbour
+                    open = 1;
+                    if (sgn > 0.0) { sgn = -1.0; iq = q0; begin_search(blk, 0); }
+                    else state = 1;
+                }
+                if (accept >= 0) {
+                    if (A.tie && dt_confirm_tie(S, G, box, E, A.b1, A.n1, A.c1)) degenerate |= DT_WHY_TIE;
                     if (++deg > kDtLaneDeg) state = 2;
-                    const int oq = oid[iq], oc = oid[ic];
+                    const int oq = oid[iq], oc = oid[accept];
                     if (oi < oq && oi < oc) {
                         if (nown == kDtLaneRows) state = 2;
                         else {
@@ -521,8 +550,11 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                             ++nown;
                         }
                     }
-                    iq = ic;
-                    if (state == 0 && iq == q0) state = 1;           // closed
+                    iq = accept;
+                    if (state == 0) {
+                        if (sgn > 0.0 && iq == q0) state = 1;        // closed
+                        else begin_search(blk, 0);
+                    }
                 }
             }
             if (state == 1) {
@@ -531,12 +563,13 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                 else {
 #pragma unroll
                     for (int k = 0; k < kDtLaneRows; ++k) if (k < nown) arena[at + k] = rows[k];
-                    od[oi] = (uint16_t)(nown | (deg << 6));
+                    od[oi] = (uint16_t)(nown | (deg << 6) | (open << 15));
                     astart[oi] = (uint16_t)at;
                 }
                 i = -1;
             } else if (state == 2) {
-                od[oi] = 0x4000;                                     // listed (phase 1b does not list it again)
+                // more rows / a larger star than a lane keeps: the group pass below takes the point
+                od[oi] = 0x4000;
                 const int pos = atomicAdd(&misc[DM_NHARD], 1);
                 if (pos < kDtHardCap) hard[pos] = (uint16_t)i; else degenerate |= DT_WHY_HARD;
                 i = -1;
@@ -550,40 +583,8 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     // four of them share a wavefront.  Lanes of a group stay together; groups diverge freely.
     const int gl = lane & (kDtGroup - 1), grp = tid / kDtGroup;
     constexpr int kGroups = kDtBlock / kDtGroup;
-    // ---- phase 1b: queued completions
-    {
-        const int nreq = min(misc[DM_VQ], kDtVq);
-        for (int r0 = 0; r0 < nreq; r0 += kGroups) {
-            const int r = r0 + grp;
-            const bool have = r < nreq;
-            const uint2 e = vq[have ? r : 0];
-            const int i = (int)(e.x & 0xFFFFu), iq = (int)(e.x >> 16), ic = (int)e.y;
-            const double2 p = S[i], q = S[iq];
-            DtBox B = dt_circle_box(G, p.x, p.y, q, S[ic]);
-            if (!have) B.yb = B.ya - 1;
-            DtEdge E;
-            E.set(p, q, i, iq, 1.0);
-            DtAcc A;
-            A.reset();
-            dt_scan_box<kDtGroup>(A, S, G, B, E);
-            const DtPick pk = dt_group_pick(A);
-            if (!have) continue;
-            if (pk.flag) degenerate |= DT_WHY_COLLINEAR;
-            if (pk.id == ic) { if (pk.tie) degenerate |= DT_WHY_TIE; }
-            else if (gl == 0) {
-                const int oi = oid[i];
-                const uint32_t bit = 0x4000u << ((oi & 1) * 16);
-                const uint32_t old = atomicOr(reinterpret_cast<uint32_t *>(od) + (oi >> 1), bit);
-                if (!(old & bit)) {
-                    const int pos = atomicAdd(&misc[DM_NHARD], 1);
-                    if (pos < kDtHardCap) hard[pos] = (uint16_t)i; else degenerate |= DT_WHY_HARD;
-                }
-            }
-        }
-    }
     __syncthreads();
     DT_STAMP(4);
-    DT_NOTE(8, misc[DM_VQ]);
 
     // ---- phase 2: hard points, one group each
     {

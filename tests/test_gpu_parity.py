@@ -1530,6 +1530,42 @@ def test_bench_line_contract(gpu):
         assert p2.returncode != 0 and not [ln for ln in p2.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_bench_multi_rank_dry_runs(gpu):
+    """The N-rank paths of bench.py as dry runs on this box (--share-gpu: gloo, ranks share the device): BASELINE
+    configs[3] literally (--c4: a fixed number of frames SPLIT over the ranks, ragged blocks, one collective per step,
+    "strong"), configs[4]'s dense frames on two ranks, and a rank that fails: the launcher reports it and exits non-zero
+    instead of leaving rank 0 in the all-gather."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--share-gpu", "--steps", "2", "--warmup", "1", "--no-e2e", "--no-cpu-baseline"]
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--c4", "--total-frames", "10001", "--pool", "64"] + common,
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 3 and d["world_size"] == 3 and d["collectives_per_step"] == 1.0
+    assert d["config"]["frames_per_step_total"] == 10001 and d["config"]["frames_per_step_per_gpu"] == 3334
+    assert abs(d["value"] - 10001 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--c4", "--total-frames", "10001", "--pool", "64",
+                             "--steps", "2", "--warmup", "1", "--no-e2e", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert single.returncode == 0, single.stderr[-3000:]
+    d1 = json.loads([ln for ln in single.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["raw_scale_crc32"] == d["raw_scale_crc32"] and d1["status_histogram"] == d["status_histogram"]     # the same job, however it is split
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--features", "20000", "--frames", "16", "--pool", "4"] + common,
+                       capture_output=True, text=True, env=env, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["collectives_per_step"] == 1.0 and "tiled" in d["roofline"]["kernel"]
+    env_bad = dict(env, MVOSR_BENCH_FAIL_RANK="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--frames", "2048", "--pool", "32", "--launch-timeout", "300"] + common,
+                       capture_output=True, text=True, env=env_bad, timeout=900)
+    assert p.returncode != 0 and "rank 1" in p.stderr and "injected failure" in p.stderr, p.stderr[-2000:]
+
+
 def _device_count():
     from mvoscalerecovery_amd import _lib
     return int(_lib.load().mvosr_device_count())
