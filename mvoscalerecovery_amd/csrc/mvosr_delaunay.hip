@@ -54,9 +54,19 @@ constexpr int kDtBlock = kDtWaves * kWave;
 constexpr int kDtR = MVOSR_DT_R;         // a point's candidates: the (2R+1)^2 cell block around its cell
 constexpr double kDtPerCell = MVOSR_DT_PER_CELL;   // target points per cell (measured trade-off: profiles/micro/dt_proto.py)
 constexpr int kDtMaxCells = 4096;
-constexpr int kDtLaneRows = 8;           // rows a point may own on the lane path (more: hard list)
+#ifndef MVOSR_DT_LANE_ROWS
+#define MVOSR_DT_LANE_ROWS 12
+#endif
+constexpr int kDtLaneRows = MVOSR_DT_LANE_ROWS;   // rows a point may own on the lane path (more: the group pass)
 constexpr int kDtLaneDeg = 24;           // star degree on the lane path
-constexpr int kDtBudget = 32;            // candidates per lane and scan step
+#ifndef MVOSR_DT_BUDGET
+#define MVOSR_DT_BUDGET 32
+#endif
+#ifndef MVOSR_DT_RWIDE
+#define MVOSR_DT_RWIDE 8
+#endif
+constexpr int kDtBudget = MVOSR_DT_BUDGET;   // candidates per lane and scan step
+constexpr int kDtRWide = MVOSR_DT_RWIDE;              // the block a search is widened to before it takes the whole frame
 constexpr int kDtWaveRows = 32;          // rows a point may own at all
 constexpr int kDtWaveDeg = 60;
 constexpr int kDtHardCap = 256;          // points left to the group pass
@@ -181,7 +191,7 @@ __device__ __forceinline__ void dt_step(DtAcc &A, const DtEdge &E, int j, double
 // looking for its point's nearest neighbour — the same minimisation with num = |c - p|^2, cr = 1
 __device__ __forceinline__ void dt_step_lane(DtAcc &A, const DtEdge &E, bool m1, int j, double2 c) {
     const double bx = c.x - E.px, by = c.y - E.py;
-    const double cr0 = __builtin_fma(E.ax, by, -(E.ay * bx));
+    const double cr0 = E.sgn * __builtin_fma(E.ax, by, -(E.ay * bx));
     const double b2 = __builtin_fma(bx, bx, by * by);
     const double dot = __builtin_fma(bx, E.ax, by * E.ay);
     const double cr = m1 ? cr0 : 1.0;
@@ -220,7 +230,7 @@ __device__ __attribute__((noinline)) bool dt_confirm_tie(const double2 *S, const
             if (j == E.i || j == E.iq || j == b1) continue;
             const double2 c = S[j];
             const double bx = c.x - E.px, by = c.y - E.py;
-            const double cr = __builtin_fma(E.ax, by, -(E.ay * bx));
+            const double cr = E.sgn * __builtin_fma(E.ax, by, -(E.ay * bx));
             const double b2 = __builtin_fma(bx, bx, by * by);
             if (cr * cr <= E.a2col * b2 || !(cr > 0.0)) continue;
             const double num = b2 - __builtin_fma(bx, E.ax, by * E.ay);
@@ -434,8 +444,13 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     // whole frame cut down to the wanted side of the edge, when the block holds nothing on that side: hull vertices and
     // their neighbours).  Lanes in different stages of different stars share every iteration; none waits for another.
     {
-        int i = tid < n ? tid : -1;                 // (misc[DM_NEXT] starts at kDtBlock)
+        // Points are taken from both ends of the sorted array towards its middle: the first and the last cell rows hold
+        // the hull and the points next to it, whose stars need wide searches — the long tasks start first, the short
+        // ones fill the tail.
+        auto point_of = [&](int idx) { return (idx & 1) ? n - 1 - (idx >> 1) : (idx >> 1); };
+        int i = tid < n ? point_of(tid) : -1;       // (misc[DM_NEXT] starts at kDtBlock)
         bool exhausted = tid >= n;
+        int nn_level = 0;                           // nearest-neighbour search: 3x3 block, then 5x5, then the frame
         int mode = 0, oi = 0, q0 = -1, iq = -1, deg = 0, nown = 0, open = 0;
         int wide = 0, y_next = 0, j_resume = 0;     // the current search: box rows from y_next on, the first of them from j_resume
         double sgn = 1.0;
@@ -447,22 +462,23 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
         uint32_t rows[kDtLaneRows];
 #pragma unroll
         for (int k = 0; k < kDtLaneRows; ++k) rows[k] = 0xFFFFFFFFu;
-        auto block_of = [&](double2 pt) {
+        auto block_r = [&](double2 pt, int R) {
             const int cx = G.cellx(pt.x), cy = G.celly(pt.y);
             DtBox b_;
-            b_.xa = max(cx - kDtR, 0); b_.xb = min(cx + kDtR, G.gx - 1); b_.ya = max(cy - kDtR, 0); b_.yb = min(cy + kDtR, G.gy - 1);
+            b_.xa = max(cx - R, 0); b_.xb = min(cx + R, G.gx - 1); b_.ya = max(cy - R, 0); b_.yb = min(cy + R, G.gy - 1);
             return b_;
         };
+        auto block_of = [&](double2 pt) { return block_r(pt, kDtR); };
         auto begin_search = [&](const DtBox &b_, int w_) { box = b_; wide = w_; y_next = b_.ya; j_resume = 0; A.reset(); };
-        if (i >= 0) { p = S[i]; oi = oid[i]; begin_search(block_of(p), 0); }
+        if (i >= 0) { p = S[i]; oi = oid[i]; begin_search(block_r(p, 1), 0); }
         for (;;) {
             if (i < 0 && !exhausted) {
                 const int idx = atomicAdd(&misc[DM_NEXT], 1);
                 if (idx < n) {
-                    i = idx; p = S[i]; oi = oid[i]; mode = 0; deg = 0; nown = 0; iq = -1; open = 0; sgn = 1.0;
+                    i = point_of(idx); p = S[i]; oi = oid[i]; mode = 0; deg = 0; nown = 0; iq = -1; open = 0; sgn = 1.0; nn_level = 0;
 #pragma unroll
                     for (int k = 0; k < kDtLaneRows; ++k) rows[k] = 0xFFFFFFFFu;
-                    begin_search(block_of(p), 0);
+                    begin_search(block_r(p, 1), 0);
                 } else exhausted = true;
             }
             if (__ballot(i >= 0) == 0ull) break;
@@ -504,39 +520,44 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                 else { y_next += kDtRows; j_resume = 0; }
             }
             if (!act || y_next <= box.yb) continue;                  // (the search is not finished)
-            // ---- the search is complete
+            // ---- the search is complete.  A search that does not certify its answer is widened: the point's 3x3 block
+            // (nearest neighbour only), its 5x5 block, an 11x11 block, then — final by construction — the cell box of the
+            // answer's circumcircle, or the whole frame when there is no answer yet.
             const DtBox blk = block_of(p);
+            const DtBox all = {0, G.gx - 1, 0, G.gy - 1};
             int state = 0;                                           // 1: finished, 2: hard
             int accept = -1;
             if (!m1) {
                 // the nearest neighbour is a Delaunay neighbour — certified when its disc lies within what was searched
                 q0 = A.b1;
                 if (q0 >= 0 && A.n1 == 0.0) degenerate |= DT_WHY_DUP;
-                if (q0 >= 0 && (wide || dt_inside(dt_disc_box(G, p.x, p.y, A.n1), blk))) {
-                    iq = q0; mode = 1;
+                if (q0 >= 0 && (wide || dt_inside(dt_disc_box(G, p.x, p.y, A.n1), box))) {
+                    iq = q0; mode = 1; nn_level = 0;
                     begin_search(blk, 0);
-                } else if (!wide) {
-                    const DtBox all = {0, G.gx - 1, 0, G.gy - 1};
-                    begin_search(all, 1);
-                } else state = 2;                                    // (a frame of one point: cannot happen, n >= 3)
+                } else if (wide) state = 2;                          // (a frame of one point: cannot happen, n >= 3)
+                else {
+                    ++nn_level;
+                    if (nn_level == 1) begin_search(blk, 0);
+                    else if (nn_level == 2) begin_search(block_r(p, kDtRWide), 0);
+                    else begin_search(all, 1);
+                }
             } else {
                 if (A.flag) degenerate |= DT_WHY_COLLINEAR;
                 const int ic = A.b1;
-                if (!wide) {
-                    if (ic >= 0 && dt_inside(dt_circle_box(G, p.x, p.y, S[iq], S[ic]), blk)) accept = ic;
+                if (wide) {
+                    if (ic >= 0) accept = ic;
                     else {
-                        // nothing on that side within the block, or a circumcircle that leaves it: the search goes on over
-                        // the circle's cell box, or over the whole frame (each row cut down to the wanted side of the edge)
-                        const DtBox all = {0, G.gx - 1, 0, G.gy - 1};
-                        begin_search(ic < 0 ? all : dt_circle_box(G, p.x, p.y, S[iq], S[ic]), 1);
+                        // a hull edge: the star is open.  Counter-clockwise done: clockwise from the first neighbour
+                        open = 1;
+                        if (sgn > 0.0) { sgn = -1.0; iq = q0; nn_level = 0; begin_search(blk, 0); }
+                        else state = 1;
                     }
-                } else if (ic >= 0) accept = ic;
-                else {
-                    // a hull edge: the star is open.  Counter-clockwise done: clockwise from the first neighbour
-                    open = 1;
-                    if (sgn > 0.0) { sgn = -1.0; iq = q0; begin_search(blk, 0); }
-                    else state = 1;
-                }
+                } else if (ic >= 0) {
+                    const DtBox cb = dt_circle_box(G, p.x, p.y, S[iq], S[ic]);
+                    if (dt_inside(cb, box)) accept = ic;
+                    else begin_search(cb, 1);                        // the circumcircle leaves what was searched: its cell box decides
+                } else if (nn_level == 0) { nn_level = 1; begin_search(block_r(p, kDtRWide), 0); }     // nothing on that side within the block
+                else begin_search(all, 1);
                 if (accept >= 0) {
                     if (A.tie && dt_confirm_tie(S, G, box, E, A.b1, A.n1, A.c1)) degenerate |= DT_WHY_TIE;
                     if (++deg > kDtLaneDeg) state = 2;
@@ -551,6 +572,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                         }
                     }
                     iq = accept;
+                    nn_level = 0;
                     if (state == 0) {
                         if (sgn > 0.0 && iq == q0) state = 1;        // closed
                         else begin_search(blk, 0);

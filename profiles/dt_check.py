@@ -35,7 +35,8 @@ for k, (pts, tri) in enumerate(zip(sets, got)):
     ok = tri is not None and tri.shape == ref.shape and np.array_equal(tri, ref)
     if not ok:
         bad.append({"set": k, "n": len(pts), "status": int(st[k]), "why": int(st[k]) >> 8, "rows": None if tri is None else int(tri.shape[0]), "ref_rows": int(ref.shape[0])})
-out["mismatch"] = bad
+out["mismatch"] = bad[:6]
+out["mismatch_count"] = len(bad)
 # keep mask
 pts = sets[0]
 keep = np.where(rng.uniform(size=len(pts)) < 0.9, 1, -1).astype(np.int32)

@@ -16,4 +16,4 @@ for rep in range(6):
     for k, (t, r) in enumerate(zip(g, refs)):
         if t is None or not np.array_equal(t, r):
             out.append({"rep": rep, "frame": k, "n": len(frames[k]), "why": int(st[k]) >> 8, "none": t is None})
-print(json.dumps(out))
+print(json.dumps({"bad": len(out), "first": out[:5]}))
