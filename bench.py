@@ -201,8 +201,11 @@ def build_pool(ctx, engine, sizes, seed):
     t_del1 = time.perf_counter() - t0
     cap = min(int(ctx.lib.mvosr_max_lds_features()), TILE_ABOVE[0])
     dense = pf.max_feat > cap
+    t_tile = 0.0
     if dense:            # dense frames: the tiled layout (what ScaleEstimator.scale_calculation_batch does)
+        t0 = time.perf_counter()
         packing.apply_tile_order(pf)
+        t_tile = time.perf_counter() - t0
     db = DeviceBatch(ctx, pf, with_tri2=False)
     out = DeviceOutputs(ctx, db, counts=True, stage=True)
     engine.outlier_vote_batch(db, out)
@@ -213,6 +216,7 @@ def build_pool(ctx, engine, sizes, seed):
     db.free()
     t0 = time.perf_counter()
     packing.attach_tri2(pf, None, masks, None, feature_ids=dense)    # dense: rows numbered over the features (no compaction)
+    build_pool.host_layout_ms_per_frame = t_tile * 1e3 / pool        # (sort, relabel, tile index of the dense layout: one host thread)
     t_del2 = time.perf_counter() - t0
     workers = max(1, packing.resolve_workers(None))
     return frames, pf, masks, (t_del1 + t_del2) * workers / pool       # CPU-seconds of Delaunay per frame
@@ -283,7 +287,8 @@ def e2e_leg(args, device, sizes, seed, budget_frames):
     n = min(budget_frames, 4096)
     frames = [synth.synth_frame(100000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(n)]
     est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False)
-    est.scale_calculation_batch([f[0] for f in frames[:64]], [f[1] for f in frames[:64]])         # warm-up (pool, workspaces)
+    nw = min(64, max(8, n // 8))
+    est.scale_calculation_batch([f[0] for f in frames[:nw]], [f[1] for f in frames[:nw]])         # warm-up (pool, workspaces)
     t0 = time.perf_counter()
     est.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames])
     dt = time.perf_counter() - t0
@@ -665,6 +670,14 @@ def main():
                                                             "may use: affinity and cgroup quota), triangulations supplied" % (alln, cpu_workers)}
             except Exception as exc:                                    # noqa: BLE001
                 line["cpu_baseline_all_cores"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if dense:
+            line["host_tile_layout_ms_per_frame"] = getattr(build_pool, "host_layout_ms_per_frame", None)
+        if n_gpus == 1 and not args.no_e2e and dense:
+            # dense frames end to end: host Qhull (~140 CPU-ms per call and frame) bounds it; the tile layout is included
+            try:
+                line["e2e"] = e2e_leg(args, local, sizes, 2024, 96)
+            except Exception as exc:                                    # noqa: BLE001
+                line["e2e"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if n_gpus == 1 and not args.no_e2e and not dense:
             try:
                 line["e2e"] = e2e_leg(args, local, sizes, 2024, 4096)

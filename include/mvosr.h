@@ -172,6 +172,12 @@ typedef struct mvosr_batch {
      * only), so that a device-built triangulation goes into the scale kernel without a trip through the host. */
     const int32_t *tri1_cnt;     /* [F] or NULL */
     const int32_t *tri2_cnt;     /* [F] or NULL */
+    /* Optional, for layouts that PERMUTE the rows of tri2 (the dense tile layout sorts them by smallest vertex): laid out
+     * like tri2's rows, tri2_order[tri2_off[f] + k] = index, within frame f's rows as stored, of the k-th row of the
+     * caller's original order (SciPy's).  height_level is np.mean over the steep triangles' heights IN ROW ORDER
+     * (/root/reference/src/scale_calculator.py:239-240): with the table the exact pass sums in the original order and
+     * the level is the reference's double to the last bit; without it (NULL) in the stored order (equal to rounding). */
+    const int32_t *tri2_order;
 } mvosr_batch;
 
 #define MVOSR_TILE_W 512

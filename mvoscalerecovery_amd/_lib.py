@@ -39,7 +39,7 @@ class Batch(C.Structure):
                 ("tile_w", C.c_int32), ("min_feat", C.c_int32), ("tile_base", C.c_void_p),
                 ("tile1_off", C.c_void_p), ("tile2_off", C.c_void_p), ("size_hint", C.c_int32 * 4),
                 ("tile_far", C.c_void_p), ("tile_far_off", C.c_void_p),
-                ("tri1_cnt", C.c_void_p), ("tri2_cnt", C.c_void_p)]
+                ("tri1_cnt", C.c_void_p), ("tri2_cnt", C.c_void_p), ("tri2_order", C.c_void_p)]
 
 
 class Outputs(C.Structure):

@@ -511,6 +511,7 @@ __device__ __forceinline__ int classify_triangle(double x0, double y0, double z0
 template <bool FULL, class Fetch>
 struct SteepStream {
     const int32_t *tri;           // the frame's first row
+    const int32_t *order;         // null, or: the k-th row of the caller's ORIGINAL order is row order[k] here (mvosr_batch.tri2_order)
     int t2n;
     const PitchTest &pt;
     Fetch fetch;
@@ -522,7 +523,8 @@ struct SteepStream {
         bool steep = false;
         h = 0.0;
         if (t < t2n) {
-            const TriIds q = load_tri(tri, t);
+            const int row = order ? min(max(order[t], 0), t2n - 1) : t;      // (clamped: a bad table cannot index outside the frame's rows)
+            const TriIds q = load_tri(tri, row);
             double x0, y0, z0, x1, y1, z1, x2, y2, z2;
             if (fetch(q, x0, y0, z0, x1, y1, z1, x2, y2, z2)) {
                 h = div3((y0 + y1) + y2);
@@ -547,9 +549,10 @@ struct SteepStream {
 // in row order, divided by the count.  `n_steep` is the count the sweep found.  Every wavefront that calls it
 // computes the same value (no barrier, nothing written).  Only the EXACT / FULL kernel variants contain it.
 template <bool FULL, class Fetch>
-__device__ __forceinline__ double exact_height_level(const int32_t *tri, int t2n, int n_steep, const PitchTest &pt, Fetch fetch) {
+__device__ __forceinline__ double exact_height_level(const int32_t *tri, int t2n, int n_steep, const PitchTest &pt, Fetch fetch,
+                                                     const int32_t *order = nullptr) {
     if (n_steep <= 0) return nan("");                           // np.mean of an empty slice
-    SteepStream<FULL, Fetch> st{tri, t2n, pt, fetch, 0, 0ull, 0.0};
+    SteepStream<FULL, Fetch> st{tri, order, t2n, pt, fetch, 0, 0ull, 0.0};
     return (0.0 + np_pairwise_stream(st, n_steep)) / (double)n_steep;
 }
 
@@ -1526,7 +1529,8 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
         else block_sum2<DW>(hsum, hcnt, red + R_SEL_H * 2 * DW);
         double hl = hsum / hcnt;                      // np.mean of an empty set -> 0/0 = NaN, like :240
         const double guard = kLevelGuard * (habs / hcnt);
-        if constexpr (MODE != MODE_HOT) hl = exact_height_level<FULL>(tri, t2s, (int)hcnt, a.pt, fetch);
+        if constexpr (MODE != MODE_HOT)
+            hl = exact_height_level<FULL>(tri, t2s, (int)hcnt, a.pt, fetch, a.b.tri2_order ? a.b.tri2_order + t2b : nullptr);
         for (int base = 0, kk = 0; base < t2s; base += B, ++kk) {
             const TriIds q = cur;
             if (base + B + tid < t2s) cur = load_tri(tri, base + B + tid);

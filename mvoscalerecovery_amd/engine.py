@@ -146,6 +146,8 @@ class DeviceBatch:
         self.tri2_ids = int(pf.tri2_ids)
         if pf.n2_expected is not None:
             arrays["n2_expected"] = (pf.n2_expected, np.int32)
+        if getattr(pf, "tri2_order", None) is not None:
+            arrays["tri2_order"] = (pf.tri2_order if pf.tri2_order.size else np.zeros(1, np.int32), np.int32)
         self.tile_w = 0
         if pf.tile_w and pf.tile1_off is not None and pf.tile2_off is not None:
             self.tile_w = int(pf.tile_w)
@@ -170,6 +172,7 @@ class DeviceBatch:
             self._struct.tile_far_off = p("tile_far_off")
             self._struct.tri1_cnt = p("tri1_cnt")
             self._struct.tri2_cnt = p("tri2_cnt")
+            self._struct.tri2_order = p("tri2_order")
             if self.n_frames:               # min_feat + the size classes' counts (ragged batches launch per class)
                 mf = self._struct.max_feat
                 _lib.check(self.ctx.lib.mvosr_batch_size_hint(self._feat_cnt_host.ctypes.data, self.n_frames,

@@ -355,6 +355,7 @@ class PackedFrames:
     n2_expected: np.ndarray = None  # int32 [F]
     max_feat: int = 0
     tri2_ids: int = 0               # 0: tri2 indexes the survivors (SciPy's numbering), 1: the frame's features
+    tri2_order: np.ndarray = None   # int32 [T2]: where the k-th ORIGINAL row of a frame went (layouts that permute tri2's rows)
     tile_w: int = 0                 # tile index of dense frames (mvosr_batch.tile_*): 0 = none
     tile_base: np.ndarray = None    # int64 [F+1]
     tile1_off: np.ndarray = None    # int32 [tile_base[F]]
@@ -541,27 +542,42 @@ def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0, featu
     tri2s = [None if isinstance(t, Exception) else np.ascontiguousarray(t, dtype=np.int32) for t in tri2s]
     if pf.extra.get("canonical"):
         tri2s = [None if t is None else canonical_rows(t) for t in tri2s]
+    row_src = [None] * pf.n_frames          # row_src[f][i] = index, in the caller's original order, of the row now stored at i
     if valid_masks is not None:
         for f in range(pf.n_frames):
             if perms[f] is not None and tri2s[f] is not None and tri2s[f].shape[0]:
                 m_new = np.asarray(valid_masks[f], dtype=bool)
                 m_old = np.empty_like(m_new)
                 m_old[perms[f]] = m_new
-                tri2s[f] = _relabel_tri2(tri2s[f], m_old, perms[f])
+                tri2s[f], row_src[f] = _relabel_tri2(tri2s[f], m_old, perms[f], return_order=True)
     tiled = feature_ids and pf.extra.get("tile1") is not None
     tile2 = []
+    orders = None
     if feature_ids:
+        orders = []
         for f in range(pf.n_frames):
             n = int(pf.feat_cnt[f])
             offs = np.zeros((n + TILE_W - 1) // TILE_W + 1, dtype=np.int32)
+            inv = np.zeros(0, dtype=np.int32)
             if tri2s[f] is not None and tri2s[f].shape[0]:
                 survivors = np.nonzero(np.asarray(valid_masks[f], dtype=bool))[0].astype(np.int32)   # increasing: row order is kept
                 tri2s[f] = survivors[tri2s[f]]
+                t = tri2s[f].shape[0]
+                src = row_src[f] if row_src[f] is not None else np.arange(t)
                 if tiled:
                     tri2s[f], offs = _tile_sort(tri2s[f], n)
+                    src = src[_tile_sort.last_order]
+                inv = np.empty(t, dtype=np.int32)
+                inv[src] = np.arange(t, dtype=np.int32)                                           # original row k is stored at inv[k]
             tile2.append(offs)
+            orders.append(inv)
     pf.tri2_ids = 1 if feature_ids else 0
     pf.tri2_off, pf.tri2 = _pack_tris(tri2s)
+    pf.tri2_order = None
+    if orders is not None:
+        pf.tri2_order = np.ascontiguousarray(np.concatenate(orders) if len(orders) else np.zeros(0, np.int32), dtype=np.int32)
+        if pf.tri2_order.shape[0] != int(pf.tri2_off[-1]):
+            pf.tri2_order = None
     if tiled:
         pf.extra["tile2"] = tile2
         _finish_tile_index(pf)
@@ -592,6 +608,8 @@ def tile_frames(pf: PackedFrames, repeats: int) -> PackedFrames:
     if pf.n2_expected is not None:
         out.n2_expected = np.tile(pf.n2_expected, repeats)
     out.tri2_ids = pf.tri2_ids
+    if pf.tri2_order is not None:
+        out.tri2_order = np.tile(pf.tri2_order[:max(int(pf.tri2_off[-1]), 0)], repeats)
     if pf.tile_w and pf.tile1_off is not None and pf.tile2_off is not None:
         nt = int(pf.tile_base[-1])
         out.tile_w = pf.tile_w
@@ -684,6 +702,7 @@ def _tile_sort(tri, n, tile_w=TILE_W):
     rows = np.ascontiguousarray(tri[order])
     n_near = int(np.count_nonzero(~far))
     offs = np.searchsorted(lo[order][:n_near], np.arange(ntiles) * tile_w, side="left")
+    _tile_sort.last_order = order                       # stored row i = original row order[i]
     return rows, np.concatenate([offs, [n_near]]).astype(np.int32)
 
 
@@ -761,9 +780,10 @@ def apply_tile_order(pf: PackedFrames):
     return pf
 
 
-def _relabel_tri2(tri_old, m_old, perm):
+def _relabel_tri2(tri_old, m_old, perm, return_order=False):
     """Second-triangulation rows numbered over the survivors in ORIGINAL order -> over the survivors
-    in the permuted order; rows sorted by their smallest vertex."""
+    in the permuted order; rows sorted by their smallest vertex (``return_order``: also the original index of every
+    stored row)."""
     m_new = m_old[perm]
     c_old = np.cumsum(m_old) - 1
     c_new = np.cumsum(m_new) - 1
@@ -771,4 +791,5 @@ def _relabel_tri2(tri_old, m_old, perm):
     keep_new = np.nonzero(m_new)[0]
     remap[c_old[perm[keep_new]]] = c_new[keep_new]
     t = remap[tri_old].astype(np.int32)
-    return t[np.argsort(t.min(axis=1), kind="stable")]
+    order = np.argsort(t.min(axis=1), kind="stable")
+    return (t[order], order) if return_order else t[order]

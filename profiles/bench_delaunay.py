@@ -1,0 +1,46 @@
+"""mvosr_delaunay_batch alone on resident point sets (the workload profiles/collect_delaunay.sh runs under rocprofv3):
+    python profiles/bench_delaunay.py [--points 2000] [--sets 4096] [--steps 5]
+Prints one JSON line: sets/s from HIP events around the launches, declines, and the size of the problem."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvoscalerecovery_amd import _lib, synth      # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--points", type=int, default=2000)
+ap.add_argument("--sets", type=int, default=4096)
+ap.add_argument("--steps", type=int, default=5)
+args = ap.parse_args()
+n, F = args.points, args.sets
+ctx = _lib.default_context(0)
+pool = [synth.synth_frame(i, n, base_seed=99)[1] for i in range(64)]
+cnt = np.full(F, n, dtype=np.int32)
+off = np.arange(F, dtype=np.int64) * n
+uv = np.concatenate([pool[i % 64] for i in range(F)])
+d_u, d_v = ctx.to_device(np.ascontiguousarray(uv[:, 0])), ctx.to_device(np.ascontiguousarray(uv[:, 1]))
+d_off, d_cnt, d_toff = ctx.to_device(off), ctx.to_device(cnt), ctx.to_device(2 * off)
+d_tri = ctx.empty((2 * F * n, 3), np.int32)
+d_tcnt, d_st = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
+
+
+def launch():
+    _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n, d_toff.ptr,
+                                            d_tri.ptr, d_tcnt.ptr, None, d_st.ptr), "mvosr_delaunay_batch")
+
+
+launch()
+ctx.sync()
+e0, e1 = ctx.event(), ctx.event()
+ctx.record(e0)
+for _ in range(args.steps):
+    launch()
+ctx.record(e1)
+ms = ctx.elapsed_ms(e0, e1) / args.steps
+rows = d_tcnt.download()
+print(json.dumps({"points_per_set": n, "sets": F, "steps": args.steps, "kernel_ms": ms, "sets_per_s": F / ms * 1e3,
+                  "points_per_s": F * n / ms * 1e3, "rows_per_set": float(rows.mean()), "declined": int((d_st.download() != 0).sum())}))
