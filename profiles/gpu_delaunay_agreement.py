@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""How often the scales computed on the GPU triangulations (triangulation="gpu": same triangle set, canonical row
-rotation instead of Qhull's) equal the reference's — the measured size of that deliberate deviation —
-and what the device stage buys end to end.
+"""How often the scales of the DECLARED DEVIATION — triangulation="gpu", check_triangle="fixed": the order-invariant vote
+on the device's triangulations — equal the reference's own, and what the device stage buys end to end.
+(Against its own oracle, Oracle(check_triangle="fixed"), that mode is bit-equal on every frame: tests/test_gpu_parity.py.)
+Also: the same fixed vote on SciPy's triangulations (identical to "gpu" by construction), and "gpu" with the reference's
+flag pattern (unpinned: Qhull's row rotation is not reproducible).
 
-    python profiles/gpu_delaunay_agreement.py  >  profiles/r02_gpu_delaunay.json
+    python profiles/gpu_delaunay_agreement.py  >  profiles/r03_gpu_delaunay.json
 
 Sequences: the 4541-frame main_offline-shaped golden (tests/golden/seq4541.npz: the reference's raw and filtered scales)
 and the 400 adversarial frames of tests/golden/frame_fuzz.npz."""
@@ -20,8 +22,10 @@ packing.start_pool(None)
 out = {}
 z, meta = load_npz("seq4541.npz")
 data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
-for mode in ("scipy", "gpu"):
-    est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, triangulation=mode)
+for mode, kw in (("scipy", {}), ("gpu", {"triangulation": "gpu"}), ("scipy_fixed", {"check_triangle": "fixed"}),
+                 ("gpu_reference_pattern", {"triangulation": "gpu", "check_triangle": "reference"})):
+    est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, **kw)
+    offline.run_sequence_batched(data, ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, **kw))     # warm-up
     t0 = time.perf_counter()
     res = offline.run_sequence_batched(data, est)
     dt = time.perf_counter() - t0
@@ -35,7 +39,8 @@ for mode in ("scipy", "gpu"):
         "raw_scale_rel_diff_median_of_differing": float(np.median(rel[~same_raw])) if (~same_raw).any() else 0.0,
         "raw_scale_rel_diff_max": float(np.nanmax(rel)), "raw_scale_within_1e-4_fraction": float(np.mean(rel <= 1e-4)),
         "status_equal_fraction": None, "seconds": dt, "frames_per_s_end_to_end": float(len(raw) / dt),
-        "host_fallback_fraction_last_chunk": getattr(packing.delaunay_gpu_or_host, "last_host_fraction", None) if mode == "gpu" else None}
+        "check_triangle": est.check_triangle, "triangulation": est.triangulation,
+        "declined_by_the_device_stage_last_chunk": int(est.last_declined)}
 zf = np.load(os.path.join(ROOT, "tests", "golden", "frame_fuzz.npz"))
 names = list(zf["exception_names"])
 agree = tot = exc_agree = 0
