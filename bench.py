@@ -304,11 +304,12 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames):
     (mvosr_delaunay_batch on resident point sets), and the alloc counters of a steady-state call."""
     from mvoscalerecovery_amd import _lib, packing, synth
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
-    pool = [synth.synth_frame(200000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(256)]
-    f3s = [pool[i % 256][0] for i in range(n_frames)]
-    f2s = [pool[i % 256][1] for i in range(n_frames)]
+    npool = 256 if max(sizes) <= 6000 else 16
+    pool = [synth.synth_frame(200000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(npool)]
+    f3s = [pool[i % npool][0] for i in range(n_frames)]
+    f2s = [pool[i % npool][1] for i in range(n_frames)]
     est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
-    est.scale_calculation_batch(f3s[:4096], f2s[:4096])                       # warm-up: kernels, allocator caches
+    est.scale_calculation_batch(f3s, f2s)                                     # warm-up: kernels, allocator caches (same sizes as the timed call)
     ctx = est.engine.ctx
     a0 = ctx.alloc_stats()
     t0 = time.perf_counter()
@@ -317,10 +318,10 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames):
     a1 = ctx.alloc_stats()
     # the triangulation kernel alone on resident point sets of the workload's size
     n = int(max(sizes))
-    F = 4096
+    F = 4096 if n <= 6000 else 256
     cnt = np.full(F, n, dtype=np.int32)
     off = np.arange(F, dtype=np.int64) * n
-    uv = np.concatenate([pool[i % 64][1][:n] for i in range(F)])
+    uv = np.concatenate([pool[i % min(64, npool)][1][:n] for i in range(F)])
     if uv.shape[0] == F * n:
         d_u, d_v = ctx.to_device(np.ascontiguousarray(uv[:, 0])), ctx.to_device(np.ascontiguousarray(uv[:, 1]))
         d_off, d_cnt, d_toff = ctx.to_device(off), ctx.to_device(cnt), ctx.to_device(2 * off)
@@ -678,6 +679,10 @@ def main():
                 line["e2e"] = e2e_leg(args, local, sizes, 2024, 96)
             except Exception as exc:                                    # noqa: BLE001
                 line["e2e"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                line["e2e_gpu_triangulation"] = e2e_gpu_leg(args, local, sizes, 2024, 1024)
+            except Exception as exc:                                    # noqa: BLE001
+                line["e2e_gpu_triangulation"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if n_gpus == 1 and not args.no_e2e and not dense:
             try:
                 line["e2e"] = e2e_leg(args, local, sizes, 2024, 4096)

@@ -430,13 +430,18 @@ enum mvosr_dt_status {
  * order — the second triangulation over the survivors of the vote (:264-266) without a compaction pass.  n_used[f]
  * (optional) = the number of points triangulated (what mvosr_batch.n2_expected wants).  Rows are written at
  * tri + 3*tri_off[f] (room for 2 * points rows), tri_cnt[f] says how many; status[f] is an mvosr_dt_status (a declined
- * frame has tri_cnt 0 and the reason in the status' bits 8..).  max_pts = max(pts_cnt) <= mvosr_delaunay_max_points().
+ * frame has tri_cnt 0 and the reason in the status' bits 8..).  max_pts = max(pts_cnt) <= mvosr_delaunay_max_points();
+ * above mvosr_delaunay_lds_points() the context's workspace grows by ~33 bytes per point of the launch (hipMalloc).
  */
 int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
                          const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
                          int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status);
-/* Largest frame mvosr_delaunay_batch takes (the frame's points, grid and rows live in one workgroup's LDS). */
+/* Largest frame mvosr_delaunay_batch takes (32 000 points: ids and row indices are 16-bit), and the largest frame whose
+ * points, grid and rows fit one workgroup's LDS (about 4 700): a launch whose max_pts is larger runs the kernel's
+ * global-memory variant — the same algorithm with the per-frame arrays in a slice of the context's workspace, read
+ * through L1/L2 (dense frames, BASELINE configs[4]); slower per point, same rows. */
 int mvosr_delaunay_max_points(void);
+int mvosr_delaunay_lds_points(void);
 
 /* LDS bytes the fused kernel requests for a frame of n features (host-side planning). */
 size_t mvosr_lds_bytes(int n_features);

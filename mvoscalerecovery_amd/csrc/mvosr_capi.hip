@@ -57,6 +57,20 @@ int ctx_workspace(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat, double *
     return MVOSR_OK;
 }
 
+int ctx_workspace_bytes(mvosr_ctx *ctx, size_t bytes, void **ptr) {
+    if (bytes > ctx->ws_bytes_len) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->ws_bytes) (void)hipFree(ctx->ws_bytes);
+        ctx->ws_bytes = nullptr; ctx->ws_bytes_len = 0;
+        const size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&ctx->ws_bytes, want);
+        if (e != hipSuccess) return set_hip_error("hipMalloc(workspace: per-frame arrays of large triangulations)", e);
+        ctx->ws_bytes_len = want;
+    }
+    *ptr = ctx->ws_bytes;
+    return MVOSR_OK;
+}
+
 int ctx_workspace_dense(mvosr_ctx *ctx, int64_t total_feat, void *planes[2]) {
     if ((size_t)total_feat > ctx->ws_dense_len) {
         (void)hipStreamSynchronize(ctx->stream);
@@ -204,6 +218,7 @@ int mvosr_ctx_create(int device, mvosr_ctx **out) {
     ctx->prof_on = 0; ctx->prof_calls = 0;
     for (int i = 0; i < 2; ++i) ctx->ws_dense[i] = nullptr;
     ctx->ws_dense_len = 0;
+    ctx->ws_bytes = nullptr; ctx->ws_bytes_len = 0;
     for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) ctx->prof_ev[i][j] = nullptr;
     ctx->ws_ysel = nullptr; ctx->ws_ysel_len = 0; ctx->ws_nsel = nullptr; ctx->ws_nsel_len = 0;
     ctx->n_hip_malloc = ctx->n_hip_free = ctx->n_host_malloc = ctx->n_host_free = ctx->n_cache_hits = 0;
@@ -237,6 +252,7 @@ int mvosr_ctx_destroy(mvosr_ctx *ctx) {
     for (int i = 0; i < 2; ++i) if (ctx->ws_dense[i]) (void)hipFree(ctx->ws_dense[i]);
     if (ctx->ws_ysel) (void)hipFree(ctx->ws_ysel);
     if (ctx->ws_nsel) (void)hipFree(ctx->ws_nsel);
+    if (ctx->ws_bytes) (void)hipFree(ctx->ws_bytes);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MVOSR_OK;

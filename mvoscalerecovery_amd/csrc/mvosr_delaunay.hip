@@ -89,6 +89,7 @@ struct DtArgs {
     int32_t *n_used;                                     // [F] points triangulated (null: not wanted)
     int32_t *status;                                     // [F] MVOSR_DT_*
     int max_pts;
+    char *ws;                                            // GLOBAL variant: a slice of dt_plan().big bytes per frame
 #ifdef MVOSR_STAMPS
     unsigned long long *stamps;                          // diagnostic builds: 16 values per frame (phase boundaries, list lengths)
 #endif
@@ -103,16 +104,22 @@ static unsigned long long *g_dt_stamps = nullptr;
 #define DT_NOTE(i, v) do {} while (0)
 #endif
 
-struct DtPlan { uint32_t S, oid, od, astart, cs, arena, hard, wrows, red, misc, total; int max_cells, arena_cap; };
+// The per-frame arrays: the BIG part (points, ids, per-point row bookkeeping, cell index, row arena: ~33 B per point)
+// lives in the workgroup's LDS for frames up to ~4700 points, and in a per-frame slice of the context's workspace (read
+// through L1/L2) for larger ones (the GLOBAL kernel variant: dense frames, config C5); the small part always in LDS.
+struct DtPlan { uint32_t S, oid, od, astart, cs, arena, big, hard, wrows, red, misc, total; int max_cells, arena_cap; };
+constexpr int kDtMaxCellsGlobal = 32768;
+constexpr int kDtMaxPointsGlobal = 32000;      // (row arena indices and point ids are 16-bit)
 
-__host__ __device__ inline int dt_cell_cap(int max_pts) {
+__host__ __device__ inline int dt_cell_cap(int max_pts, bool global) {
     int c = (int)((double)max_pts / kDtPerCell * 1.25) + 64;
-    return c > kDtMaxCells ? kDtMaxCells : c;
+    const int cap = global ? kDtMaxCellsGlobal : kDtMaxCells;
+    return c > cap ? cap : c;
 }
-__host__ __device__ inline DtPlan dt_plan(int max_pts) {
+__host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false) {
     DtPlan p;
     const uint32_t npad = (uint32_t)((max_pts + 7) & ~7);
-    p.max_cells = dt_cell_cap(max_pts);
+    p.max_cells = dt_cell_cap(max_pts, global);
     p.arena_cap = (int)(2u * npad) + kDtArenaSlack;
     p.S = 0;                                             // double2 per point (sorted by cell)
     p.oid = p.S + 16u * npad;                            // u16: sorted index -> id of the point
@@ -120,7 +127,8 @@ __host__ __device__ inline DtPlan dt_plan(int max_pts) {
     p.astart = p.od + 2u * npad;                         // u16 per id: the point's rows in the arena
     p.cs = p.astart + 2u * npad;                         // u32 per cell (+1): end of the cell in the sorted array
     p.arena = p.cs + 4u * (uint32_t)(p.max_cells + 8);   // u32 rows (b << 16 | c) in the order they were found
-    p.hard = p.arena + 4u * (uint32_t)p.arena_cap;       // u16 sorted indices
+    p.big = (p.arena + 4u * (uint32_t)p.arena_cap + 255u) & ~255u;
+    p.hard = p.big;                                      // u16 sorted indices
     p.wrows = p.hard + 2u * kDtHardCap;                  // u32 [groups of 16 lanes][kDtWaveRows]
     p.red = p.wrows + 4u * (kDtBlock / 16) * kDtWaveRows;    // doubles: block reductions
     p.misc = p.red + 8u * 4u * kDtWaves;
@@ -311,21 +319,24 @@ __device__ __forceinline__ int dt_incl_scan(int v) {
     return v;
 }
 
+template <bool GLOBAL>
 __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = blockIdx.x;
     const int n_in = a.pts_cnt[f];
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    const DtPlan L = dt_plan(a.max_pts);
-    double2 *S = reinterpret_cast<double2 *>(smem + L.S);
-    uint16_t *oid = reinterpret_cast<uint16_t *>(smem + L.oid);
-    uint16_t *od = reinterpret_cast<uint16_t *>(smem + L.od);
-    uint16_t *astart = reinterpret_cast<uint16_t *>(smem + L.astart);
-    uint32_t *cs = reinterpret_cast<uint32_t *>(smem + L.cs);
-    uint32_t *arena = reinterpret_cast<uint32_t *>(smem + L.arena);
-    uint16_t *hard = reinterpret_cast<uint16_t *>(smem + L.hard);
-    double *red = reinterpret_cast<double *>(smem + L.red);
-    int *misc = reinterpret_cast<int *>(smem + L.misc);
+    const DtPlan L = dt_plan(a.max_pts, GLOBAL);
+    char *big = GLOBAL ? a.ws + (size_t)f * L.big : smem;                  // the frame's big arrays
+    char *small = GLOBAL ? smem - L.big : smem;                            // (the plan's offsets of the small ones start at L.big)
+    double2 *S = reinterpret_cast<double2 *>(big + L.S);
+    uint16_t *oid = reinterpret_cast<uint16_t *>(big + L.oid);
+    uint16_t *od = reinterpret_cast<uint16_t *>(big + L.od);
+    uint16_t *astart = reinterpret_cast<uint16_t *>(big + L.astart);
+    uint32_t *cs = reinterpret_cast<uint32_t *>(big + L.cs);
+    uint32_t *arena = reinterpret_cast<uint32_t *>(big + L.arena);
+    uint16_t *hard = reinterpret_cast<uint16_t *>(small + L.hard);
+    double *red = reinterpret_cast<double *>(small + L.red);
+    int *misc = reinterpret_cast<int *>(small + L.misc);
 
     auto decline = [&](int why, int n_used) {
         if (tid == 0) { a.tri_cnt[f] = 0; a.status[f] = MVOSR_DT_DEGENERATE | (why << 8); if (a.n_used) a.n_used[f] = n_used; }
@@ -433,6 +444,9 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
         }
     }
     __syncthreads();
+    // GLOBAL: the cell index was read (the scan) and then rewritten by other wavefronts' stores and atomics — this CU's L1
+    // may hold the old lines
+    if constexpr (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
     DT_STAMP(2);
     int degenerate = 0;
@@ -611,7 +625,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     // ---- phase 2: hard points, one group each
     {
         const int nh = min(misc[DM_NHARD], kDtHardCap);
-        uint32_t *grows = reinterpret_cast<uint32_t *>(smem + L.wrows) + grp * kDtWaveRows;
+        uint32_t *grows = reinterpret_cast<uint32_t *>(small + L.wrows) + grp * kDtWaveRows;
         const DtBox all = {0, G.gx - 1, 0, G.gy - 1};
         for (int h = grp; h < nh; h += kGroups) {
             const int i = hard[h];
@@ -746,7 +760,7 @@ using namespace mvosr;
 extern "C" void mvosr_debug_dt_stamps(void *dptr) { g_dt_stamps = reinterpret_cast<unsigned long long *>(dptr); }
 #endif
 
-extern "C" int mvosr_delaunay_max_points(void) {
+static int dt_lds_points() {
     int lo = 3, hi = 65535;
     while (lo < hi) {
         const int mid = (lo + hi + 1) / 2;
@@ -754,6 +768,9 @@ extern "C" int mvosr_delaunay_max_points(void) {
     }
     return lo;
 }
+
+extern "C" int mvosr_delaunay_max_points(void) { return kDtMaxPointsGlobal; }
+extern "C" int mvosr_delaunay_lds_points(void) { return dt_lds_points(); }
 
 extern "C" int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
                                     const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
@@ -765,18 +782,30 @@ extern "C" int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int6
     int rc = ctx_activate(ctx);
     if (rc) return rc;
     if (max_pts < 3) max_pts = 3;
-    const DtPlan L = dt_plan(max_pts);
-    if (max_pts > 65535 || L.total > 160u * 1024u)
-        return set_error(MVOSR_ERR_TOO_LARGE, "delaunay_batch: %d points per frame need %u B of LDS (limit: %d points)", max_pts, L.total,
-                         mvosr_delaunay_max_points());
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(delaunay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
-    if (e != hipSuccess) return set_hip_error("hipFuncSetAttribute(delaunay_kernel)", e);
+    if (max_pts > kDtMaxPointsGlobal)
+        return set_error(MVOSR_ERR_TOO_LARGE, "delaunay_batch: %d points per frame (limit: %d)", max_pts, kDtMaxPointsGlobal);
+    const bool global = max_pts > dt_lds_points();
+    const DtPlan L = dt_plan(max_pts, global);
     DtArgs a;
     a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
-    a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.max_pts = max_pts;
+    a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.max_pts = max_pts; a.ws = nullptr;
 #ifdef MVOSR_STAMPS
     a.stamps = g_dt_stamps;
 #endif
-    hipLaunchKernelGGL(delaunay_kernel, dim3((unsigned)n_frames), dim3(kDtBlock), L.total, ctx_stream(ctx), a);
+    size_t lds = L.total;
+    if (global) {
+        // frames beyond the LDS capacity: the big arrays in the context's workspace, one slice per frame
+        void *ws = nullptr;
+        if ((rc = ctx_workspace_bytes(ctx, (size_t)n_frames * L.big, &ws))) return rc;
+        a.ws = reinterpret_cast<char *>(ws);
+        lds = L.total - L.big;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(delaunay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return set_hip_error("hipFuncSetAttribute(delaunay_kernel)", e);
+        hipLaunchKernelGGL(delaunay_kernel<true>, dim3((unsigned)n_frames), dim3(kDtBlock), lds, ctx_stream(ctx), a);
+        return check_launch("delaunay_kernel (global-memory variant)");
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(delaunay_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_hip_error("hipFuncSetAttribute(delaunay_kernel)", e);
+    hipLaunchKernelGGL(delaunay_kernel<false>, dim3((unsigned)n_frames), dim3(kDtBlock), lds, ctx_stream(ctx), a);
     return check_launch("delaunay_kernel");
 }

@@ -40,6 +40,8 @@ struct mvosr_ctx {
     // dense-frame variant: remapped planes {v|x,z'} x2 and y' x2 (48 B per feature), grow-only
     void *ws_dense[2];            // {x, z'} (16 B) and y' (8 B) per surviving feature of a dense batch
     size_t ws_dense_len;
+    void *ws_bytes;               // generic grow-only scratch (the Delaunay kernel's per-frame arrays beyond the LDS capacity)
+    size_t ws_bytes_len;
     // optional per-call kernel timing (mvosr_ctx_profile): start / between the two kernels / end
     int prof_on;
     int prof_calls;
@@ -65,5 +67,6 @@ void set_max_dynamic_lds(int bytes);
 // Make the context's workspace at least (n_frames, total_feat) large; hipMalloc only when it grows.
 int ctx_workspace(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat, double **ysel, int32_t **nsel);
 int ctx_workspace_dense(mvosr_ctx *ctx, int64_t total_feat, void *planes[2]);   // P2 (16 B/feature), Y2 (8 B/feature)
+int ctx_workspace_bytes(mvosr_ctx *ctx, size_t bytes, void **ptr);               // generic grow-only scratch
 
 }  // namespace mvosr

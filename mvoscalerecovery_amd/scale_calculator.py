@@ -444,6 +444,7 @@ class ScaleEstimator:
         return raw, status, level, counts, host_errors, S[n - 1]
 
     GPU_CHUNK = 2048            # frames per chunk of the device-triangulation path
+    GPU_CHUNK_POINTS = 5000000  # ... and features per chunk (40 B each in staging memory, ~100 B each on the device)
 
     def _chunk_gpu(self, f3s, f2s, stage):
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
@@ -525,7 +526,17 @@ class ScaleEstimator:
         """The batch through the device-triangulation path in chunks: the GPU works on chunk k while this process packs
         chunk k+1 (every launch and copy of a chunk is asynchronous)."""
         F, C = len(feature3ds), self.GPU_CHUNK
-        bounds = [(a, min(F, a + C)) for a in range(0, F, C)]
+        # chunks of at most GPU_CHUNK frames and GPU_CHUNK_POINTS features (a chunk's planes, rows and staging memory
+        # scale with its points: dense frames travel in smaller chunks)
+        npts = np.fromiter((len(a) for a in feature3ds), dtype=np.int64, count=F)
+        bounds, a = [], 0
+        while a < F:
+            b = min(F, a + C)
+            tot = np.cumsum(npts[a:b])
+            over = int(np.searchsorted(tot, self.GPU_CHUNK_POINTS, side="right"))
+            b = min(b, a + max(over, 1))
+            bounds.append((a, b))
+            a = b
         results, pending = [], None
         for k, (a, b) in enumerate(bounds):
             cur = (self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage), a, b)

@@ -456,6 +456,29 @@ def test_triangulation_gpu_fixed_is_bit_equal_to_oracle(gpu):
             assert np.array_equal(one.flat_feature, ref.flat_feature), i
 
 
+def test_triangulation_gpu_dense_frames(gpu):
+    """Frames beyond the LDS capacity (config C5's sizes) through the device-triangulation path: the Delaunay kernel's
+    global-memory variant (per-frame arrays in the context's workspace) gives SciPy's rows exactly, and the estimator —
+    device triangulations, dense gather kernels, nothing of a frame on the host between upload and result — is bit-equal
+    to the fixed-mode oracle."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import packing, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    assert packing.delaunay_gpu_max_points() >= 20000 > int(gpu.lib.mvosr_delaunay_lds_points())
+    sets = [synth.synth_frame(i, n, base_seed=77)[1] for i, n in enumerate((5000, 20000))]
+    for pts, tri in zip(sets, packing.delaunay_gpu(gpu, sets)):
+        assert tri is not None and np.array_equal(tri, packing.canonical_rows(Delaunay(pts).simplices))
+    frames = [synth.synth_frame(i, n, base_seed=909, upper_fraction=0.05) for i, n in enumerate((8000, 20000, 1200, 7000))]
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    scales, stds = est.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames])
+    assert est.last_declined == 0
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+    for i, (f3, f2) in enumerate(frames):
+        s, sd = ref.scale_calculation(f3, f2)
+        assert s == scales[i] and sd == stds[i], (i, s, scales[i])
+
+
 def test_triangulation_gpu_fixed_seq4541_and_fuzz(gpu):
     """The same bar on config C3's 4541-frame sequence (every raw and filtered scale of its processed frames) and on the
     adversarial frames of frame_fuzz.npz — including the ones whose point sets the device stage declines (duplicates,
