@@ -154,13 +154,20 @@ struct DtBox { int xa, xb, ya, yb; };
 // (k, side) describe the wanted half-plane per cell row: side = +1: u below px + k (v - py), -1: above, 0: no statement
 struct DtEdge {
     double px, py, ax, ay, a2col, sgn, k;
+    double sax, say, cr_add;       // lane pass: sgn * a, and what is added to the cross product (0; 1 in the nearest-neighbour mode)
     int i, iq, side;
     __device__ __forceinline__ void set(double2 p, double2 q, int i_, int iq_, double sgn_) {
         px = p.x; py = p.y; ax = q.x - p.x; ay = q.y - p.y; i = i_; iq = iq_; sgn = sgn_;
         a2col = kDtColTol * kDtColTol * (ax * ax + ay * ay);
-        const double A = sgn * ax, B = sgn * ay;
-        side = B > 0.0 ? 1 : (B < 0.0 ? -1 : 0);
-        k = side ? A / B : 0.0;
+        sax = sgn * ax; say = sgn * ay; cr_add = 0.0;
+        side = say > 0.0 ? 1 : (say < 0.0 ? -1 : 0);
+        k = side ? sax / say : 0.0;
+    }
+    // the nearest-neighbour search as the same minimisation: with a = 0 the step's numerator is |c - p|^2, its cross
+    // product 0 + 1, nothing is "on the line" (a2col < 0) and no row is cut
+    __device__ __forceinline__ void set_nn(double2 p, int i_) {
+        px = p.x; py = p.y; ax = 0.0; ay = 0.0; sax = 0.0; say = 0.0; cr_add = 1.0; a2col = -1.0; sgn = 1.0; k = 0.0;
+        i = i_; iq = -1; side = 0;
     }
 };
 
@@ -195,24 +202,22 @@ __device__ __forceinline__ void dt_step(DtAcc &A, const DtEdge &E, int j, double
     A.n1 = better ? num : A.n1; A.c1 = better ? cr : A.c1; A.b1 = better ? j : A.b1;
 }
 
-// one candidate of the lane pass: m1 = the lane is wrapping its star (as dt_step, apex on the left); otherwise it is
-// looking for its point's nearest neighbour — the same minimisation with num = |c - p|^2, cr = 1
+// one candidate of the lane pass (as dt_step; best + `tie` only).  m1 = the lane is wrapping its star; otherwise it is
+// looking for its point's nearest neighbour, which the edge's set_nn() turns into the same arithmetic.
 __device__ __forceinline__ void dt_step_lane(DtAcc &A, const DtEdge &E, bool m1, int j, double2 c) {
     const double bx = c.x - E.px, by = c.y - E.py;
-    const double cr0 = E.sgn * __builtin_fma(E.ax, by, -(E.ay * bx));
+    const double cr = __builtin_fma(E.sax, by, __builtin_fma(-E.say, bx, E.cr_add));
     const double b2 = __builtin_fma(bx, bx, by * by);
     const double dot = __builtin_fma(bx, E.ax, by * E.ay);
-    const double cr = m1 ? cr0 : 1.0;
-    const double num = m1 ? b2 - dot : b2;
+    const double num = b2 - dot;                                        // (c - p).(c - q)
     const bool skip = (j == E.i) | (j == E.iq);
-    const bool col = m1 & (cr0 * cr0 <= E.a2col * b2);
+    const bool col = cr * cr <= E.a2col * b2;
     A.flag |= (!skip & col & ((dot > 0.0) | (b2 == 0.0))) ? 1 : 0;
     const bool ok = !skip & !col & (cr > 0.0);
     const double d = __builtin_fma(num, A.c1, -(A.n1 * cr));
     const bool better = ok & (d < 0.0);
-    A.tie |= (m1 & ok & (fabs(d) <= A.s1 * cr)) ? 1 : 0;
-    const double s_new = kDtTieTol * (fabs(num) + cr);
-    A.n1 = better ? num : A.n1; A.c1 = better ? cr : A.c1; A.s1 = better ? s_new : A.s1; A.b1 = better ? j : A.b1;
+    A.tie |= (m1 & ok & (fabs(d) <= (kDtTieTol * (fabs(A.n1) + A.c1)) * cr)) ? 1 : 0;
+    A.n1 = better ? num : A.n1; A.c1 = better ? cr : A.c1; A.b1 = better ? j : A.b1;
 }
 
 // the part of cell row y, columns xa..xb, that can hold points on the wanted side of the edge, as a range of the sorted array
@@ -498,8 +503,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
             if (__ballot(i >= 0) == 0ull) break;
             const bool act = i >= 0, m1 = mode == 1;
             DtEdge E;
-            E.set(p, S[max(iq, 0)], i, iq, sgn);
-            if (!m1) E.side = 0;                                     // the nearest-neighbour search takes whole rows
+            if (m1) E.set(p, S[max(iq, 0)], i, iq, sgn); else E.set_nn(p, i);
             // up to five rows of the search's box as ranges of the sorted array, walked as ONE loop (a loop per row would
             // run for the longest row of any lane, five times over)
             int j0[kDtRows], j1[kDtRows];
