@@ -239,6 +239,16 @@ int mvosr_free(mvosr_ctx *ctx, void *dptr);
 int mvosr_host_alloc(mvosr_ctx *ctx, size_t bytes, void **hptr);                   /* page-locked host memory (staging) */
 int mvosr_host_free(mvosr_ctx *ctx, void *hptr);
 int mvosr_ctx_trim(mvosr_ctx *ctx);
+/* A cached block's release normally marks "everything queued so far" as its last use — in a chunk loop that includes the
+ * NEXT chunk's kernels, and the block's next user would wait for them.  mvosr_block_mark(ctx, ptr, 1) records the last use
+ * NOW (call it right after the last launch that touches the block) and a later mvosr_free keeps that mark;
+ * MVOSR_MARK_UPLOAD: the block (a staging buffer) is used by the upload stream only — its last use is what that stream
+ * has queued so far; MVOSR_MARK_IDLE: the caller knows that nothing queued uses the block (a download target whose copy
+ * it has waited for); 0 withdraws a mark (the block is used again). */
+#define MVOSR_MARK_NOW 1
+#define MVOSR_MARK_IDLE 2
+#define MVOSR_MARK_UPLOAD 3
+int mvosr_block_mark(mvosr_ctx *ctx, void *ptr, int marked);
 int mvosr_ctx_alloc_stats(mvosr_ctx *ctx, int64_t *out, int n_out);
 int mvosr_memcpy_h2d(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);   /* stream-ordered, returns after the copy */
 int mvosr_memcpy_d2h(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);   /* stream-ordered, returns after the copy */
@@ -262,14 +272,16 @@ int mvosr_event_destroy(mvosr_ctx *ctx, void *event);
  * `threads` host threads (<= 0: one per hardware thread, at most 16).  mvosr_pack_count applies the vanishing-row filter
  * (/root/reference/src/scale_calculator.py:252-254: feature2d[:,1] > vanish) and returns the survivors per frame; the
  * caller derives feat_off (even, ascending) and sizes the planes — e.g. page-locked staging memory, so that the packed
- * batch is uploaded without another copy —; mvosr_pack_fill writes x|y|z|u|v at feat_off[f] in the caller's order.
+ * batch is uploaded without another copy —; mvosr_pack_fill writes x|y|z|u|v at feat_off[f] in the caller's order and,
+ * when feat_cnt_out is given, the number of features it kept per frame — so a caller that lays the frames out by their
+ * UNFILTERED sizes (feat_off from n_points: a few per cent of slack) needs no counting pass at all.
  * remap_in_place != 0 also applies feature_remap (:390-394) to EVERY row of the caller's feature3d arrays, as the
  * reference does at :414 (the planes keep the raw values: the kernels remap at load). */
 int mvosr_pack_count(int64_t n_frames, const double *const *feature2d, const int32_t *n_points, double vanish, int32_t *feat_cnt,
                      int threads);
 int mvosr_pack_fill(int64_t n_frames, double *const *feature3d, const double *const *feature2d, const int32_t *n_points,
                     double vanish, const int64_t *feat_off, double *x, double *y, double *z, double *u, double *v,
-                    int remap_in_place, double cos_pitch, double sin_pitch, int threads);
+                    int remap_in_place, double cos_pitch, double sin_pitch, int threads, int32_t *feat_cnt_out);
 
 /* ---- the hot path ------------------------------------------------------------------------- */
 void mvosr_default_params(mvosr_params *p, double absolute_reference);
@@ -294,7 +306,11 @@ void mvosr_default_params(mvosr_params *p, double absolute_reference);
  * feature-numbered second triangulations (b->tri2_ids) run the gather variant, which keeps only the vote
  * counters in LDS; with survivor-numbered rows it uses 24 bytes of context workspace per feature.
  * `first_frame`/`n_launch` restrict the launch to a sub-range of the batch (n_launch <= 0: all).
+ * MVOSR_WAVES_EXACT or-ed into `waves_per_frame` runs the frames in the exact mode — height_level summed in NumPy's
+ * order for every frame, what the stage outputs select implicitly — without asking for stage outputs (the host re-runs
+ * single frames this way when a later step will read their level).
  */
+#define MVOSR_WAVES_EXACT 0x100
 int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b,
                       const mvosr_outputs *o, int waves_per_frame,
                       int64_t first_frame, int64_t n_launch);

@@ -14,6 +14,8 @@ import numpy as np
 LIB_PATH = os.environ.get("MVOSR_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")   # (override: A/B builds in profiles/)
 ABI_VERSION = 6
 VOTE_REFERENCE, VOTE_FIXED = 0, 1          # mvosr_params.vote_mode
+WAVES_EXACT = 0x100                        # MVOSR_WAVES_EXACT, or-ed into waves_per_frame
+MARK_NOW, MARK_IDLE, MARK_UPLOAD = 1, 2, 3 # mvosr_block_mark
 TRI2_SURVIVORS, TRI2_FEATURES = 0, 1      # mvosr_batch.tri2_ids
 N_COUNTS = 8
 TILE_W = 512                              # MVOSR_TILE_W
@@ -82,7 +84,8 @@ SYMBOLS = {
     "mvosr_event_sync": (C.c_int, [_P, _P]),
     "mvosr_event_destroy": (C.c_int, [_P, _P]),
     "mvosr_pack_count": (C.c_int, [C.c_int64, _P, _P, C.c_double, _P, C.c_int]),
-    "mvosr_pack_fill": (C.c_int, [C.c_int64, _P, _P, _P, C.c_double, _P, _P, _P, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int]),
+    "mvosr_pack_fill": (C.c_int, [C.c_int64, _P, _P, _P, C.c_double, _P, _P, _P, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int, _P]),
+    "mvosr_block_mark": (C.c_int, [_P, _P, C.c_int]),
     "mvosr_default_params": (None, [C.POINTER(Params), C.c_double]),
     "mvosr_scale_batch": (C.c_int, [_P, C.POINTER(Params), C.POINTER(Batch), C.POINTER(Outputs), C.c_int,
                                     C.c_int64, C.c_int64]),
@@ -109,6 +112,23 @@ SYMBOLS = {
 }
 
 _lib = None
+_pyhelper = False
+
+
+def pyhelper():
+    """libmvosr_py.so (csrc/mvosr_pyhelper.c): pointer / size tables of a list of per-frame arrays through the buffer
+    protocol in C.  Plumbing only; ``None`` when it is not built (the caller then asks the arrays one by one in Python)."""
+    global _pyhelper
+    if _pyhelper is False:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr_py.so")
+        try:
+            h = C.PyDLL(path)
+            h.mvosr_py_frame_pointers.restype = C.c_long
+            h.mvosr_py_frame_pointers.argtypes = [C.py_object, C.py_object, C.c_void_p, C.c_void_p, C.c_void_p]
+            _pyhelper = h
+        except (OSError, AttributeError):
+            _pyhelper = None
+    return _pyhelper
 
 
 def load():
@@ -198,9 +218,13 @@ class PinnedBuffer:
         count = int(np.prod(shape, dtype=np.int64))
         return np.frombuffer(self._raw, dtype=dtype, count=count, offset=int(offset)).reshape(shape)
 
-    def free(self):
+    def free(self, mark=0):
+        """``mark``: MARK_UPLOAD — the buffer was the source of uploads only; MARK_IDLE — nothing queued uses it (its
+        download has been waited for).  Without one, its next user waits for everything queued so far."""
         if self.ptr:
             self._raw = None
+            if mark:
+                self.ctx.lib.mvosr_block_mark(self.ctx.handle, self.ptr, int(mark))
             self.ctx.lib.mvosr_host_free(self.ctx.handle, self.ptr)
             self.ptr = None
 
@@ -291,7 +315,7 @@ class DeviceBlock:
             np.copyto(dst, np.asarray(arr).reshape(v.shape), casting="same_kind")
         check(ctx.lib.mvosr_memcpy_h2d_async(ctx.handle, self.ptr + lo, stage.ptr, hi - lo), "h2d_async")
         check(ctx.lib.mvosr_upload_fence(ctx.handle), "upload_fence")
-        stage.free()                      # (back to the cache; its next user waits for the copy)
+        stage.free(MARK_UPLOAD)           # (back to the cache; its next user waits for the copy)
         return self
 
     def staging(self):
@@ -303,11 +327,18 @@ class DeviceBlock:
         ctx = self.ctx
         check(ctx.lib.mvosr_memcpy_h2d_async(ctx.handle, self.ptr, stage.ptr, self.nbytes), "h2d_async")
         check(ctx.lib.mvosr_upload_fence(ctx.handle), "upload_fence")
-        stage.free()
+        stage.free(MARK_UPLOAD)
         return self
 
     def zero(self):
         check(self.ctx.lib.mvosr_memset(self.ctx.handle, self.ptr, 0, self.nbytes), "memset")
+        return self
+
+    def mark(self, marked=True):
+        """The block's last use is what has been queued SO FAR (mvosr_block_mark): a later ``free`` does not make its next
+        user wait for work queued after this point.  ``mark(False)``: the block is used again."""
+        if self.ptr:
+            check(self.ctx.lib.mvosr_block_mark(self.ctx.handle, self.ptr, 1 if marked else 0), "mvosr_block_mark")
         return self
 
     def prefetch(self):
@@ -341,14 +372,14 @@ class DeviceBlock:
         if self._mirror is None and getattr(self, "_pf_stage", None) is not None:
             check(ctx.lib.mvosr_event_sync(ctx.handle, self._pf_event), "event_sync")
             self._mirror = np.array(self._pf_stage.view(0, (self.nbytes,), np.uint8), copy=True)
-            self._pf_stage.free()
+            self._pf_stage.free(MARK_IDLE)
             self._pf_stage = None
         if self._mirror is None:
             stage = PinnedBuffer(ctx, self.nbytes)
             check(ctx.lib.mvosr_memcpy_d2h_async(ctx.handle, stage.ptr, self.ptr, self.nbytes), "d2h_async")
             ctx.sync()
             self._mirror = np.array(stage.view(0, (self.nbytes,), np.uint8), copy=True)
-            stage.free()
+            stage.free(MARK_IDLE)
         return np.array(self._mirror[view.offset:view.offset + view.nbytes].view(view.dtype).reshape(view.shape), copy=True)
 
     def free(self):

@@ -108,6 +108,11 @@ static void cache_release_all(mvosr_ctx *ctx, mvosr_block_cache &c, bool host) {
 static int cache_alloc(mvosr_ctx *ctx, mvosr_block_cache &c, bool host, size_t bytes, void **out) {
     const size_t want = round_block(bytes);
     auto it = c.free_blocks.lower_bound(want);
+    // among the cached blocks of a fitting size prefer one whose last use has completed (a chunk loop keeps two
+    // generations of blocks: the one the GPU still works on and the one being filled)
+    for (auto jt = it; jt != c.free_blocks.end() && jt->first <= want + want / 4; ++jt) {
+        if (!jt->second.pending || hipEventQuery(jt->second.ev) == hipSuccess) { it = jt; break; }
+    }
     if (it != c.free_blocks.end() && it->first <= want + want / 4) {
         mvosr_block b = it->second;
         c.free_blocks.erase(it);
@@ -117,13 +122,15 @@ static int cache_alloc(mvosr_ctx *ctx, mvosr_block_cache &c, bool host, size_t b
             if (e != hipSuccess) return set_hip_error("hipEventSynchronize(cached block)", e);
             b.pending = false;
         }
+        b.marked = false;
+        b.idle = false;
         c.live[b.ptr] = b;
         ctx->n_cache_hits++;
         *out = b.ptr;
         return MVOSR_OK;
     }
     mvosr_block b;
-    b.bytes = want; b.pending = false; b.ptr = nullptr;
+    b.bytes = want; b.pending = false; b.marked = false; b.idle = false; b.ptr = nullptr;
     hipError_t e = host ? hipHostMalloc(&b.ptr, want, hipHostMallocDefault) : hipMalloc(&b.ptr, want);
     if (e != hipSuccess) {                       // out of memory: give the cache back and try once more
         (void)hipGetLastError();
@@ -144,12 +151,16 @@ static int cache_free(mvosr_ctx *ctx, mvosr_block_cache &c, bool host, void *ptr
     if (it == c.live.end()) return set_error(MVOSR_ERR_ARG, "free: pointer %p was not allocated by this context", ptr);
     mvosr_block b = it->second;
     c.live.erase(it);
-    // work queued on either stream may still use the block: its next user waits for this point of both streams
-    hipError_t e = hipEventRecord(ctx->upload_ev, ctx->upload_stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0);
-    if (e == hipSuccess) e = hipEventRecord(b.ev, ctx->stream);
-    if (e != hipSuccess) return set_hip_error("hipEventRecord(block release)", e);
-    b.pending = true;
+    if (!b.marked) {
+        // work queued on either stream may still use the block: its next user waits for this point of both streams
+        hipError_t e = hipEventRecord(ctx->upload_ev, ctx->upload_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0);
+        if (e == hipSuccess) e = hipEventRecord(b.ev, ctx->stream);
+        if (e != hipSuccess) return set_hip_error("hipEventRecord(block release)", e);
+    }
+    b.pending = !b.idle;
+    b.marked = false;
+    b.idle = false;
     c.cached_bytes += b.bytes;
     c.free_blocks.emplace(b.bytes, b);
     (void)host;
@@ -341,6 +352,30 @@ int mvosr_host_free(mvosr_ctx *ctx, void *hptr) {
     return cache_free(ctx, ctx->host_cache, true, hptr);
 }
 
+int mvosr_block_mark(mvosr_ctx *ctx, void *ptr, int marked) {
+    if (!ctx || !ptr) return set_error(MVOSR_ERR_ARG, "block_mark: null argument");
+    mvosr_block_cache *c = &ctx->dev_cache;
+    auto it = c->live.find(ptr);
+    if (it == c->live.end()) { c = &ctx->host_cache; it = c->live.find(ptr); }
+    if (it == c->live.end()) return set_error(MVOSR_ERR_ARG, "block_mark: pointer %p was not allocated by this context", ptr);
+    if (marked == MVOSR_MARK_NOW) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipEventRecord(ctx->upload_ev, ctx->upload_stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
+        HIP_TRY(hipEventRecord(it->second.ev, ctx->stream));
+    } else if (marked == MVOSR_MARK_UPLOAD) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipEventRecord(it->second.ev, ctx->upload_stream));
+    } else if (marked == MVOSR_MARK_IDLE) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipEventRecord(it->second.ev, ctx->upload_stream));      // (an event that is complete at once when the stream is idle; never waited for long)
+        it->second.idle = true;
+    } else if (marked != 0) return set_error(MVOSR_ERR_ARG, "block_mark: unknown mark %d", marked);
+    if (marked != MVOSR_MARK_IDLE) it->second.idle = false;
+    it->second.marked = marked != 0;
+    return MVOSR_OK;
+}
+
 int mvosr_ctx_trim(mvosr_ctx *ctx) {
     if (!ctx) return set_error(MVOSR_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -468,7 +503,7 @@ int mvosr_pack_count(int64_t n_frames, const double *const *feature2d, const int
 
 int mvosr_pack_fill(int64_t n_frames, double *const *feature3d, const double *const *feature2d, const int32_t *n_points,
                     double vanish, const int64_t *feat_off, double *x, double *y, double *z, double *u, double *v,
-                    int remap_in_place, double cos_pitch, double sin_pitch, int threads) {
+                    int remap_in_place, double cos_pitch, double sin_pitch, int threads, int32_t *feat_cnt_out) {
     if (n_frames < 0 || (n_frames > 0 && (!feature3d || !feature2d || !n_points || !feat_off || !x || !y || !z || !u || !v)))
         return set_error(MVOSR_ERR_ARG, "pack_fill: null argument");
     pack_parallel(n_frames, threads, [=](int64_t a, int64_t b) {
@@ -488,6 +523,7 @@ int mvosr_pack_fill(int64_t n_frames, double *const *feature3d, const double *co
                     p3[3 * i + 2] = yy * sin_pitch + zz * cos_pitch;
                 }
             }
+            if (feat_cnt_out) feat_cnt_out[f] = (int32_t)(o - feat_off[f]);
         }
     });
     return MVOSR_OK;

@@ -18,6 +18,8 @@ struct mvosr_block {
     size_t bytes;
     hipEvent_t ev;
     bool pending;
+    bool marked;       // `ev` already marks the block's last use (mvosr_block_mark): releasing it records nothing later
+    bool idle;         // marked MVOSR_MARK_IDLE: nothing queued uses the block any more
 };
 struct mvosr_block_cache {
     std::multimap<size_t, mvosr_block> free_blocks;

@@ -2557,6 +2557,8 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
                       int waves_per_frame, int64_t first_frame, int64_t n_launch) {
     int rc = check_common(ctx, p, b, o);
     if (rc) return rc;
+    const bool want_exact = (waves_per_frame & MVOSR_WAVES_EXACT) != 0;
+    waves_per_frame &= ~MVOSR_WAVES_EXACT;
     if (!b->x || !b->y || !b->z || !b->v || !b->tri1_off || !b->tri2_off || !b->tri2)
         return set_error(MVOSR_ERR_ARG, "scale_batch: missing input plane / triangulation");
     if (!o->raw_scale || !o->height || !o->height_level || !o->status)
@@ -2577,7 +2579,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     // FULL: per-triangle debug outputs; EXACT: stage outputs requested (height_level bit-equal to NumPy's for every
     // frame); HOT: the product path + its exact pass over the frames that need it
     const int mode = (o->tri_normals || o->tri_pitch_deg || o->tri_heights) ? MODE_FULL
-                     : ((o->selected || o->vote_counters) ? MODE_EXACT : MODE_HOT);
+                     : ((o->selected || o->vote_counters || want_exact) ? MODE_EXACT : MODE_HOT);
     const int waves = pick_waves(waves_per_frame, b->max_feat);
     RoadArgs ra;
     ra.P = *p; ra.off = b->feat_off; ra.cnt = ka.nsel; ra.y = ka.ysel; ra.scratch = ka.ysel;

@@ -23,7 +23,25 @@ def make_params(absolute_reference, camera_pitch=K.CAMERA_PITCH, pitch_threshold
                        _lib.VOTE_FIXED if check_triangle == "fixed" else _lib.VOTE_REFERENCE)
 
 
-def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=0):
+def frame_tables(feature3ds, feature2ds):
+    """(data pointers of feature3ds, of feature2ds, rows per frame) as uint64 / uint64 / int32 arrays when every frame is
+    a C-contiguous float64 (n,3) / (n,2) pair the C packer can read in place, else ``None``.  Through libmvosr_py.so
+    (one C loop over the lists) when it is there."""
+    from . import packing
+    F = len(feature3ds)
+    h = _lib.pyhelper()
+    if h is not None and type(feature3ds) is list and type(feature2ds) is list:
+        p3, p2, npts = np.empty(F, np.uint64), np.empty(F, np.uint64), np.empty(F, np.int32)
+        r = h.mvosr_py_frame_pointers(feature3ds, feature2ds, p3.ctypes.data, p2.ctypes.data, npts.ctypes.data)
+        return (p3, p2, npts) if r == F else None
+    if not packing.native_packable(feature3ds, feature2ds):
+        return None
+    return None if F == 0 else (np.fromiter((a.__array_interface__["data"][0] for a in feature3ds), dtype=np.uint64, count=F),
+                                np.fromiter((a.__array_interface__["data"][0] for a in feature2ds), dtype=np.uint64, count=F),
+                                np.fromiter((a.shape[0] for a in feature3ds), dtype=np.int32, count=F))
+
+
+def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=0, tables=None):
     """The batch path's front end without a Python loop over the frames' CONTENTS: the C packer (mvosr_pack_count /
     mvosr_pack_fill, a few host threads) applies the vanishing-row filter (/root/reference/src/scale_calculator.py:252-254)
     and writes the planes x|y|z|v|u straight into page-locked staging memory, which one asynchronous copy moves into a
@@ -33,25 +51,30 @@ def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=
     from . import packing
     F = len(feature3ds)
     lib = ctx.lib
-    p3 = np.fromiter((a.__array_interface__["data"][0] for a in feature3ds), dtype=np.uint64, count=F)
-    p2 = np.fromiter((a.__array_interface__["data"][0] for a in feature2ds), dtype=np.uint64, count=F)
-    npts = np.fromiter((a.shape[0] for a in feature3ds), dtype=np.int32, count=F)
-    cnt = np.zeros(F, dtype=np.int32)
-    _lib.check(lib.mvosr_pack_count(F, p2.ctypes.data, npts.ctypes.data, float(vanish), cnt.ctypes.data, int(threads)), "mvosr_pack_count")
-    off, total = packing.pack_layout(cnt)
+    if tables is not None:
+        p3, p2, npts = tables
+    else:
+        p3 = np.fromiter((a.__array_interface__["data"][0] for a in feature3ds), dtype=np.uint64, count=F)
+        p2 = np.fromiter((a.__array_interface__["data"][0] for a in feature2ds), dtype=np.uint64, count=F)
+        npts = np.fromiter((a.shape[0] for a in feature3ds), dtype=np.int32, count=F)
+    # ONE pass over the frames: they are laid out by their unfiltered sizes (a few per cent of slack where features lie
+    # above the vanishing row) and the packer reports how many it kept
+    off, total = packing.pack_layout(npts)
     blk = ctx.block([("feat_off", F, np.int64), ("feat_cnt", F, np.int32), ("x", total, np.float64), ("y", total, np.float64),
                      ("z", total, np.float64), ("v", total, np.float64), ("u", total, np.float64), ("tri_off", F, np.int64)])
     stage = blk.staging()
     sv = lambda k: stage.view(blk[k].offset, blk[k].shape, blk[k].dtype)
     sv("feat_off")[:] = off
-    sv("feat_cnt")[:] = cnt
     sv("tri_off")[:] = 2 * off
+    cnt_view = sv("feat_cnt")
     base = stage.ptr
     c, s_ = (remap if remap is not None else (1.0, 0.0))
     _lib.check(lib.mvosr_pack_fill(F, p3.ctypes.data, p2.ctypes.data, npts.ctypes.data, float(vanish), off.ctypes.data,
                                    base + blk["x"].offset, base + blk["y"].offset, base + blk["z"].offset, base + blk["u"].offset,
-                                   base + blk["v"].offset, 1 if remap is not None else 0, float(c), float(s_), int(threads)),
+                                   base + blk["v"].offset, 1 if remap is not None else 0, float(c), float(s_), int(threads),
+                                   cnt_view.ctypes.data),
                "mvosr_pack_fill")
+    cnt = np.array(cnt_view, dtype=np.int32, copy=True)
     blk.commit(stage)
     pf = PackedFrames(F, off, cnt, None, None, None, None, None, [None] * F, max_feat=int(cnt.max()) if F else 0)
     pf.extra["total_padded"] = total
@@ -131,6 +154,12 @@ class DeviceBatch:
 
     def prefetch_info(self):
         self.info.prefetch()
+
+    def mark(self, marked=True):
+        """See DeviceBlock.mark: call after the last launch of a chunk; engine launches on the batch withdraw it."""
+        for b in self.blocks:
+            b.mark(marked)
+        self._marked = bool(marked)
 
     def _upload(self, arrays):
         arrays = {k: np.ascontiguousarray(a, dtype=dt) for k, (a, dt) in arrays.items()}
@@ -231,11 +260,13 @@ class DeviceOutputs:
         """Queue the download of the per-frame results behind the launches so far (see DeviceBlock.prefetch)."""
         if self.block is not None:
             self.block.prefetch()
+            self.block.mark(True)
 
     def invalidate(self):
         """A launch is about to write the arrays: host copies are stale."""
         if self.block is not None:
             self.block.invalidate()
+            self.block.mark(False)
         if self.shared is not None:
             self.shared.invalidate()
 
@@ -257,11 +288,13 @@ class ScaleEngine:
         self.lib = self.ctx.lib
         self.params = make_params(absolute_reference, **param_kw)
 
-    def scale_batch(self, batch: DeviceBatch, out: DeviceOutputs, waves=0, first=0, count=0):
+    def scale_batch(self, batch: DeviceBatch, out: DeviceOutputs, waves=0, first=0, count=0, exact=False):
         b, o = batch.struct(), out.struct()
         out.invalidate()
+        if getattr(batch, "_marked", False):
+            batch.mark(False)
         _lib.check(self.lib.mvosr_scale_batch(self.ctx.handle, C.byref(self.params), C.byref(b), C.byref(o),
-                                              int(waves), int(first), int(count)), "mvosr_scale_batch")
+                                              int(waves) | (_lib.WAVES_EXACT if exact else 0), int(first), int(count)), "mvosr_scale_batch")
 
     def outlier_vote_batch(self, batch: DeviceBatch, out: DeviceOutputs, waves=0):
         b, o = batch.struct(), out.struct()

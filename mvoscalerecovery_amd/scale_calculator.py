@@ -394,13 +394,10 @@ class ScaleEstimator:
                 prev = [int(g) for g in ok if g < e]
                 if prev:
                     again.add(prev[-1])
-        if again:
-            ex = DeviceOutputs(ctx, db, counts=False, stage=True, share=out)
-            for g in sorted(again):
-                eng.scale_batch(db, ex, first=g, count=1)
-            if host_errors is not None:
-                ctx.sync()
-            ex.free()
+        for g in sorted(again):
+            eng.scale_batch(db, out, first=g, count=1, exact=True)
+        if again and host_errors is not None:
+            ctx.sync()
 
     @staticmethod
     def _chunk_free(st):
@@ -450,13 +447,14 @@ class ScaleEstimator:
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
         ONE upload -> Delaunay #1, vote, Delaunay #2, scale kernel, road model, the exact re-runs known in advance and
         the download of the results, all queued; nothing is waited for here (``_chunk_gpu_finish`` does)."""
-        from .engine import pack_upload_native
+        from .engine import frame_tables, pack_upload_native
         ctx = self.engine.ctx
-        native = len(f3s) > 0 and packing.native_packable(f3s, f2s)
+        tables = frame_tables(f3s, f2s) if len(f3s) > 0 else None
+        native = tables is not None
         blk = None
         if native:
             remap = (self.engine.params.cos_pitch, self.engine.params.sin_pitch) if self.mutate_inputs else None
-            pf, blk = pack_upload_native(ctx, f3s, f2s, self.vanish, remap)             # (:252-254, and :414 on the caller's arrays)
+            pf, blk = pack_upload_native(ctx, f3s, f2s, self.vanish, remap, tables=tables)     # (:252-254, and :414 on the caller's arrays)
         else:
             pf = packing.pack_features(f3s, f2s, self.vanish)          # raw values, packed BEFORE the in-place remap below
             if self.mutate_inputs:
@@ -479,6 +477,7 @@ class ScaleEstimator:
             self._exact_rerun(self.engine, db, out, pf, None)
         out.prefetch()
         db.prefetch_info()
+        db.mark()                     # the chunk's last launch is queued: its blocks' next users need not wait for later chunks
         st["dbatch"], st["out"] = db, out
         return st
 

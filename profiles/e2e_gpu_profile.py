@@ -13,10 +13,10 @@ from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-frames = [synth.synth_frame(i, N, base_seed=2024) for i in range(F)]
-f3, f2 = [f[0] for f in frames], [f[1] for f in frames]
-est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
-est.scale_calculation_batch(f3[:64], f2[:64])
+pool = [synth.synth_frame(i, N, base_seed=2024) for i in range(256)]
+f3, f2 = [pool[i % 256][0] for i in range(F)], [pool[i % 256][1] for i in range(F)]
+est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
+est.scale_calculation_batch(f3, f2)
 t0 = time.perf_counter()
 pr = cProfile.Profile()
 pr.enable()
