@@ -177,6 +177,9 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
     const int tid = threadIdx.x;
     const int npad2 = (n + 1) >> 1;
     TriChunk<B> tc;
+#ifdef MVOSR_PRIO_LOAD
+    __builtin_amdgcn_s_setprio(MVOSR_PRIO_LOAD);                       // (experiment: the streaming phase ahead of other workgroups' sweeps)
+#endif
     tc.template load<true>(tri1, t1_begin, t1_count, 0, tid);          // in flight while the features stream in
     // planes are 16-byte aligned per frame: two features per lane and load, two loads per plane in flight
     const double2 *gy2 = reinterpret_cast<const double2 *>(gy);
@@ -202,6 +205,9 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
             sY2[i1] = yr; s.P[2 * i1] = p0; s.P[2 * i1 + 1] = p1; s.c32[i1] = ones;
         }
     }
+#ifdef MVOSR_PRIO_LOAD
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();
     MVOSR_STAMP(1);
 

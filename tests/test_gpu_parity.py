@@ -1553,6 +1553,40 @@ def test_bench_line_contract(gpu):
         assert p2.returncode != 0 and not [ln for ln in p2.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_steady_state_allocates_nothing(gpu):
+    """The caching allocators (mvosr_malloc / mvosr_host_alloc): after warm-up neither the per-frame drop-in call (the
+    reference's loop shape, /root/reference/src/main.py:110-113) nor a repeated batch call reaches hipMalloc / hipHostMalloc
+    — counted by the context (mvosr_ctx_alloc_stats) — with SciPy's and with the device's triangulations; a released block
+    is handed out again (cache hits), and mvosr_ctx_trim gives the cache back."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    frames = [synth.synth_frame(i, 900, base_seed=31, upper_fraction=0.1) for i in range(24)]
+    for kw in ({"delaunay_workers": 0}, {"triangulation": "gpu", "delaunay_workers": 0}):
+        est = ScaleEstimator(1.75, window_size=5, device=gpu.device, **kw)
+        ctx = est.engine.ctx
+        for f3, f2 in frames[:6]:
+            est.scale_calculation(f3.copy(), f2)
+        a0 = ctx.alloc_stats()
+        for f3, f2 in frames[6:]:
+            est.scale_calculation(f3.copy(), f2)
+        a1 = ctx.alloc_stats()
+        assert a1["hip_malloc"] == a0["hip_malloc"] and a1["host_malloc"] == a0["host_malloc"], (kw, a0, a1)
+        assert a1["cache_hits"] > a0["cache_hits"]
+        f3s, f2s = [f[0].copy() for f in frames], [f[1] for f in frames]
+        est2 = ScaleEstimator(1.75, window_size=5, device=gpu.device, mutate_inputs=False, **kw)
+        est2.scale_calculation_batch(f3s, f2s)
+        est2.scale_calculation_batch(f3s, f2s)
+        b0 = ctx.alloc_stats()
+        est2.scale_calculation_batch(f3s, f2s)
+        b1 = ctx.alloc_stats()
+        assert b1["hip_malloc"] == b0["hip_malloc"] and b1["host_malloc"] == b0["host_malloc"], (kw, b0, b1)
+    cached = gpu.alloc_stats()
+    assert cached["cached_device_bytes"] > 0
+    gpu.trim()
+    after = gpu.alloc_stats()
+    assert after["cached_device_bytes"] == 0 and after["cached_host_bytes"] == 0 and after["hip_free"] > cached["hip_free"]
+
+
 def test_bench_multi_rank_dry_runs(gpu):
     """The N-rank paths of bench.py as dry runs on this box (--share-gpu: gloo, ranks share the device): BASELINE
     configs[3] literally (--c4: a fixed number of frames SPLIT over the ranks, ragged blocks, one collective per step,
