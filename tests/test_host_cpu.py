@@ -54,6 +54,47 @@ def test_canonical_rows_and_delaunay_limits():
     assert 4000 <= packing.delaunay_gpu_max_points() < 65536
 
 
+def test_c_packer_equals_python_packer():
+    """mvosr_pack_count / mvosr_pack_fill (host threads, no GPU): the vanishing-row filter, the plane layout and the
+    in-place feature_remap of /root/reference/src/scale_calculator.py:252-254,390-394,414 — against packing.pack_features
+    and the oracle's remap, bit for bit; the CPython helper's pointer tables; frames it must refuse."""
+    import ctypes as C
+    from mvoscalerecovery_amd import _lib, engine, packing, synth
+    from oracle import scale_oracle as so
+    lib = _lib.load()
+    frames = [synth.synth_frame(i, n, base_seed=12, upper_fraction=0.3) for i, n in enumerate((500, 3, 0, 1200, 77))]
+    frames[2] = (np.zeros((0, 3)), np.zeros((0, 2)))
+    f3s, f2s = [f[0].copy() for f in frames], [f[1].copy() for f in frames]
+    tb = engine.frame_tables(f3s, f2s)
+    assert tb is not None
+    p3, p2, npts = tb
+    assert npts.tolist() == [len(a) for a in f3s]
+    assert all(int(p3[i]) == f3s[i].ctypes.data and int(p2[i]) == f2s[i].ctypes.data for i in range(len(f3s)) if len(f3s[i]))
+    F = len(f3s)
+    cnt = np.zeros(F, np.int32)
+    assert lib.mvosr_pack_count(F, p2.ctypes.data, npts.ctypes.data, 185.0, cnt.ctypes.data, 3) == 0
+    ref = packing.pack_features(f3s, f2s, 185)
+    assert np.array_equal(cnt, ref.feat_cnt)
+    off, total = packing.pack_layout(npts)                  # (laid out by unfiltered sizes, as the batch path does)
+    planes = {k: np.full(total, np.nan) for k in "xyzuv"}
+    cnt2 = np.zeros(F, np.int32)
+    c, s_ = float(np.cos(so.CAMERA_PITCH)), float(np.sin(so.CAMERA_PITCH))
+    want_remapped = [so.remap(a) for a in f3s]
+    assert lib.mvosr_pack_fill(F, p3.ctypes.data, p2.ctypes.data, npts.ctypes.data, 185.0, off.ctypes.data,
+                               planes["x"].ctypes.data, planes["y"].ctypes.data, planes["z"].ctypes.data, planes["u"].ctypes.data,
+                               planes["v"].ctypes.data, 1, c, s_, 2, cnt2.ctypes.data) == 0
+    assert np.array_equal(cnt2, ref.feat_cnt)
+    for f in range(F):
+        n, a, b = int(cnt[f]), int(off[f]), ref.frame_slice(f)
+        for k in "xyzuv":
+            assert np.array_equal(planes[k][a:a + n], getattr(ref, k)[b]), (f, k)        # raw values: the kernels remap at load
+        assert np.array_equal(f3s[f], want_remapped[f]), f                                  # the caller's arrays: remapped in place (:414)
+    # what the C packer cannot read in place is refused (the batch path then packs in Python)
+    assert engine.frame_tables([f3s[0].astype(np.float32)], [f2s[0]]) is None
+    assert engine.frame_tables([f3s[0][::2]], [f2s[0][::2]]) is None
+    assert engine.frame_tables([f3s[0]], [f2s[3]]) is None
+
+
 def test_lds_plan_three_frames_per_cu():
     from mvoscalerecovery_amd import _lib
     lib = _lib.load()
