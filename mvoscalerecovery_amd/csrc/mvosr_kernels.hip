@@ -51,6 +51,43 @@ namespace mvosr {
 // ---------------------------------------------------------------------------------------------
 // LDS carve-up (byte offsets, all multiples of 16)
 // ---------------------------------------------------------------------------------------------
+// Experiment (review item 4 ii): an XOR swizzle of the vertex records' slots.  -DMVOSR_PSWZ=k permutes the slots inside
+// aligned groups of 8 by bits k.. of the index.  The gathers address the records through triangle rows, i.e. at random
+// with respect to the banks, so no fixed permutation changes how many of a ds_read_b128's 16 lanes collide
+// (measured: profiles/r03_ab_swizzle.txt); the product build has no swizzle.
+// -DMVOSR_PSPLIT keeps the records as two 8-byte planes an odd number of doubles apart instead (LDS-resident variants
+// only: an experiment build, not a product one).
+#if defined(MVOSR_PSWZ)
+#define PSW(i) ((i) ^ ((((unsigned)(i)) >> MVOSR_PSWZ) & 7u))
+#define MVOSR_NPAD(n) ((uint32_t)(((n) + 7) & ~7))
+#elif defined(MVOSR_PSPLIT)
+#define PSW(i) (i)
+#define MVOSR_NPAD(n) ((uint32_t)(((n) + 3) & ~1))
+#else
+#define PSW(i) (i)
+#define MVOSR_NPAD(n) ((uint32_t)(((n) + 1) & ~1))
+#endif
+#ifdef MVOSR_PSPLIT
+__device__ __forceinline__ int p_stride(const double2 *P, const double *Y) {
+    return (int)((Y - reinterpret_cast<const double *>(P)) >> 1) - 1;      // npad - 1: odd
+}
+__device__ __forceinline__ double2 p_ld(const double2 *P, const double *Y, int i) {
+    const double *d = reinterpret_cast<const double *>(P);
+    double2 r; r.x = d[i]; r.y = d[p_stride(P, Y) + i]; return r;
+}
+__device__ __forceinline__ double p_ldy(const double2 *P, const double *Y, int i) {
+    return reinterpret_cast<const double *>(P)[p_stride(P, Y) + i];
+}
+__device__ __forceinline__ void p_st(double2 *P, const double *Y, int i, double2 v) {
+    double *d = reinterpret_cast<double *>(P);
+    d[i] = v.x; d[p_stride(P, Y) + i] = v.y;
+}
+#else
+__device__ __forceinline__ double2 p_ld(const double2 *P, const double *, int i) { return P[PSW(i)]; }
+__device__ __forceinline__ double p_ldy(const double2 *P, const double *, int i) { return P[PSW(i)].y; }
+__device__ __forceinline__ void p_st(double2 *P, const double *, int i, double2 v) { P[PSW(i)] = v; }
+#endif
+
 struct LdsPlan {
     uint32_t p, y, c, hist, red, misc, total;
 };
@@ -59,7 +96,7 @@ constexpr int kRedSlots = 6;                       // one scratch slot per block
 enum { R_SEL_H = 0, R_SEL_CNT = 1, R_SEL_ABS = 2, R_ROAD_SUM = 3, R_ROAD_SS = 4, R_MISC = 5 };
 __host__ __device__ inline LdsPlan lds_plan(int n, int waves) {
     LdsPlan p;
-    const uint32_t npad = (uint32_t)((n + 1) & ~1);
+    const uint32_t npad = MVOSR_NPAD(n);
     p.p = 0;                                      // double2 {v|x, z'} per feature
     p.y = p.p + 16u * npad;                       // y' per feature
     p.c = p.y + 8u * npad;                        // 16-bit vote counter per feature; later the selected bit-set
@@ -197,12 +234,12 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
         yr.x = ya.x * cp - za.x * sp;  yr.y = ya.y * cp - za.y * sp;      // :391
         p0.x = va.x; p0.y = ya.x * sp + za.x * cp;                        // :392
         p1.x = va.y; p1.y = ya.y * sp + za.y * cp;
-        sY2[i0] = yr; s.P[2 * i0] = p0; s.P[2 * i0 + 1] = p1; s.c32[i0] = ones;
+        sY2[i0] = yr; p_st(s.P, s.Y, 2 * i0, p0); p_st(s.P, s.Y, 2 * i0 + 1, p1); s.c32[i0] = ones;
         if (two) {
             yr.x = yb.x * cp - zb.x * sp;  yr.y = yb.y * cp - zb.y * sp;
             p0.x = vb.x; p0.y = yb.x * sp + zb.x * cp;
             p1.x = vb.y; p1.y = yb.y * sp + zb.y * cp;
-            sY2[i1] = yr; s.P[2 * i1] = p0; s.P[2 * i1 + 1] = p1; s.c32[i1] = ones;
+            sY2[i1] = yr; p_st(s.P, s.Y, 2 * i1, p0); p_st(s.P, s.Y, 2 * i1 + 1, p1); s.c32[i1] = ones;
         }
     }
 #ifdef MVOSR_PRIO_LOAD
@@ -236,7 +273,7 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
             const TriIds q = tc.q[k];
             vok[k] = base + k * B + tid < t1_count;
             if (vok[k] && ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n)) { bad = 1; vok[k] = false; }
-            if (vok[k]) { vp[k][0] = s.P[q.a]; vp[k][1] = s.P[q.b]; vp[k][2] = s.P[q.c]; }      // {v, z'}
+            if (vok[k]) { vp[k][0] = p_ld(s.P, s.Y, q.a); vp[k][1] = p_ld(s.P, s.Y, q.b); vp[k][2] = p_ld(s.P, s.Y, q.c); }      // {v, z'}
         }
 #pragma unroll
         for (int k = 0; k < kTC; ++k) {
@@ -275,7 +312,7 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
             keep = c >= 0;                                                    // :166
             if (g_counters) g_counters[i] = c;
             yk[k] = s.Y[i];
-            zk[k] = s.P[i].y;
+            zk[k] = p_ldy(s.P, s.Y, i);
         }
         if (keep) keepmask |= 1u << k;
         cnt += __popcll(__ballot(keep));
@@ -293,7 +330,7 @@ __device__ __forceinline__ int phase_vote(const Smem &s, int n, const double *gx
         if (keep) {
             const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
             double2 pv; pv.x = xs[k]; pv.y = zk[k];
-            s.P[pos] = pv;
+            p_st(s.P, s.Y, pos, pv);
             s.Y[pos] = yk[k];
         }
         base += __popcll(m);
@@ -567,7 +604,7 @@ struct LdsFetch {            // rows of tri2 index the compacted survivors in LD
     __device__ __forceinline__ bool operator()(const TriIds q, double &x0, double &y0, double &z0, double &x1, double &y1, double &z1,
                                                double &x2, double &y2, double &z2) const {
         if ((unsigned)q.a >= (unsigned)n_valid || (unsigned)q.b >= (unsigned)n_valid || (unsigned)q.c >= (unsigned)n_valid) return false;
-        const double2 p0 = P[q.a], p1 = P[q.b], p2 = P[q.c];
+        const double2 p0 = p_ld(P, Y, q.a), p1 = p_ld(P, Y, q.b), p2 = p_ld(P, Y, q.c);
         x0 = p0.x; z0 = p0.y; x1 = p1.x; z1 = p1.y; x2 = p2.x; z2 = p2.y;
         y0 = Y[q.a]; y1 = Y[q.b]; y2 = Y[q.c];
         return true;
@@ -598,7 +635,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     // One triangle of the first sweep (:229-240).
     auto test_triangle = [&](int t, int kk, const TriIds q) {
     if ((unsigned)q.a >= (unsigned)n_valid || (unsigned)q.b >= (unsigned)n_valid || (unsigned)q.c >= (unsigned)n_valid) { bad = 1; return; }
-    const double2 p0 = s.P[q.a], p1 = s.P[q.b], p2 = s.P[q.c];      // {x, z'}
+    const double2 p0 = p_ld(s.P, s.Y, q.a), p1 = p_ld(s.P, s.Y, q.b), p2 = p_ld(s.P, s.Y, q.c);      // {x, z'}
     const double y0 = s.Y[q.a], y1 = s.Y[q.b], y2 = s.Y[q.c];
     const double x0 = p0.x, z0 = p0.y, x1 = p1.x, z1 = p1.y, x2 = p2.x, z2 = p2.y;
     // :238.  The product path works on 3h = (y0+y1)+y2: its level is only trusted outside the guard band anyway (a frame
@@ -2241,6 +2278,18 @@ static int debug_skip_env() {
 #endif
 }
 
+// MVOSR_LDS_PAD (same builds only): bytes added to the LDS request of scale_frames_kernel so that fewer workgroups fit a CU
+// — the kernel lays its arrays out from the frame size, the padding is never touched (profiles/ab_occupancy.sh).
+static size_t lds_pad_env() {
+#ifdef MVOSR_ABLATE
+    static long v = -1;
+    if (v < 0) { const char *e = getenv("MVOSR_LDS_PAD"); v = e ? atol(e) : 0; }
+    return (size_t)v;
+#else
+    return 0;
+#endif
+}
+
 // Size classes of a ragged batch (the crossovers of pick_waves): the frames of a launch are split into up to three
 // lists, and every list is launched with the variant and the LDS request of its own largest possible frame.
 constexpr int kClassHeader = 4;                // cnt[3] | pad
@@ -2380,7 +2429,7 @@ static int launch_modes(mvosr_ctx *ctx, void (*k_hot)(const Args), void (*k_exac
 
 template <int WAVES, int SC>
 static int launch_scale(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, int mode) {
-    const size_t lds = lds_plan(ka.b.max_feat, WAVES).total;
+    const size_t lds = lds_plan(ka.b.max_feat, WAVES).total + lds_pad_env();
     int rc = check_fit(&ka.b, WAVES, SC, lds);
     if (rc) return rc;
     return launch_modes<KArgs>(ctx, scale_frames_kernel<WAVES, SC, MODE_HOT>, scale_frames_kernel<WAVES, SC, MODE_EXACT>,

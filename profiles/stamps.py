@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase timeline of the fused kernel from in-kernel s_memtime stamps.
 Needs a library built with -DMVOSR_STAMPS (never the shipped build):
-    make -C mvoscalerecovery_amd/csrc clean; make -C mvoscalerecovery_amd/csrc EXTRA=-DMVOSR_STAMPS
-    python profiles/stamps.py [frames] [features]
+    bash profiles/ab_build.sh stamps "-DMVOSR_STAMPS -DMVOSR_ABLATE"
+    MVOSR_DEBUG_SKIP=16 MVOSR_LIB_PATH=profiles/ab/libmvosr_stamps.so python profiles/stamps.py [frames] [features]
+(MVOSR_DEBUG_SKIP=16: no road-model launch — its histogram output shares the buffer the stamps are written to.)
 Reports SHARES of a workgroup's life per phase (not absolute run time: stamps perturb it)."""
 import os, sys
 import numpy as np
