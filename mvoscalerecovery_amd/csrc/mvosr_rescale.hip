@@ -8,7 +8,7 @@
 //                                                           /root/reference/src/estimate_road_norm.py:8-18,66-70
 //
 // Same conventions as mvosr_kernels.hip: one frame per workgroup, fp64, planes staged in LDS,
-// compiled with -ffp-contract=off.  These are "next" rows: built for parity first, not tuned.
+// compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -84,8 +84,10 @@ __global__ __launch_bounds__(kRsBlock) void graph_inliers_kernel(const GraphArgs
 // ---------------------------------------------------------------------------------------------
 // flat_selection: per triangle n = A^-1 . 1 (LU, like np.matrix.I), heights = 1/|n|,
 // pitch = asin(-n_y/|n|) deg; level = 0.9 * median(heights[pitch < -80]); a triangle is kept when
-// pitch < -85 and heights > level.  The median is the mean of the two middle order statistics,
-// found by radix selection over the list of loose heights in LDS.
+// pitch < -85 and heights > level.  The median is the mean of the two middle order statistics; every triangle's height
+// and flags stay in LDS by row (no compacted list, no append counter), and the order statistic is found on the heights'
+// bit patterns by a 2048-bin histogram over [smallest, largest] loose height — narrowed to the bin that holds the rank
+// and repeated if needed — with wavefront 0 ranking the last <= 64 candidates directly.
 // ---------------------------------------------------------------------------------------------
 struct FlatArgs {
     int64_t n_frames;
@@ -100,6 +102,13 @@ struct FlatArgs {
     int32_t *n_kept;               // [F]
 };
 
+constexpr int kFlatBins = 2048;         // one histogram pass resolves 11 bits of the candidates' range
+constexpr int kFlatRows = 4;            // triangle rows a thread keeps in flight
+constexpr int kFlatDirect = 64;         // that few candidates left: wavefront 0 ranks them directly
+// misc[] slots of flat_selection_kernel
+enum { FM_K = 0, FM_SINGULAR = 1, FM_BADID = 2, FM_KEPT = 3, FM_BIN = 4, FM_RANK = 5, FM_BINCNT = 6, FM_LE = 7, FM_LIST = 8,
+       FM_WSUM = 16 /* [8] per-wave bin totals */, FM_N = 32 };
+
 __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = blockIdx.x;
@@ -107,117 +116,206 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
     const int64_t off = a.feat_off[f];
     const int64_t tb = a.tri_off[f];
     const int tn = (int)(a.tri_off[f + 1] - tb);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     if (n <= 0 || tn <= 0) {
         if (tid == 0) { a.status[f] = MVOSR_ST_ERR_EMPTY; a.height_level[f] = nan(""); a.n_kept[f] = 0; }
         return;
     }
+    // LDS: heights and flags of every triangle by row, the scalars, then the vertex planes — which are dead once the
+    // normals are done: the histogram of the median search takes their place
     const uint32_t npad = (uint32_t)((n + 1) & ~1);
-    double *X = reinterpret_cast<double *>(smem);
+    double *Hh = reinterpret_cast<double *>(smem);               // every triangle's height, by row
+    unsigned long long *U = reinterpret_cast<unsigned long long *>(Hh);   // (heights are >= 0: the bit patterns order like the values)
+    unsigned long long *ext = U + tn;                            // [2] smallest / largest loose height (bits), [2] scratch
+    int *misc = reinterpret_cast<int *>(ext + 4);                // FM_N scalars
+    double *X = reinterpret_cast<double *>(misc + FM_N);
     double *Y = X + npad;
     double *Z = Y + npad;
-    double *L = Z + npad;                                        // loose heights, up to tn
-    int *misc = reinterpret_cast<int *>(L + tn);                 // 16 scalars + 256 histogram bins
-    double *med = reinterpret_cast<double *>(misc + 16 + 256);
-    if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0; misc[3] = 0; }
+    int *hist = reinterpret_cast<int *>(X);                      // kFlatBins bins; later the short candidate list (64-bit)
+    const uint32_t planes = 24u * npad > 4u * kFlatBins ? 24u * npad : 4u * kFlatBins;
+    uint8_t *Fl = reinterpret_cast<uint8_t *>(X) + planes;       // every triangle's flags, by row
+#ifdef MVOSR_FS_STAMPS
+    unsigned long long st[6];
+#define FS_STAMP(i) st[i] = __builtin_amdgcn_s_memtime()
+#else
+#define FS_STAMP(i) do {} while (0)
+#endif
+    FS_STAMP(0);
+    if (tid < FM_N) misc[tid] = 0;
+    if (tid == 0) { ext[0] = ~0ull; ext[1] = 0ull; ext[2] = ~0ull; }
+    // a thread's next kFlatRows triangle rows are in flight while it works on the current ones (and the first ones while
+    // the vertex planes stream in): a row is a dependent global load in front of nine LDS gathers and the LU chain
+    TriIds rows[kFlatRows];
+    auto load_rows = [&](int t0) {
+#pragma unroll
+        for (int j = 0; j < kFlatRows; ++j) rows[j] = load_tri(a.tri + 3 * tb, min(t0 + j * kRsBlock, tn - 1));
+    };
+    load_rows(tid);
+#pragma unroll 4
     for (int i = tid; i < n; i += kRsBlock) { X[i] = a.x[off + i]; Y[i] = a.y[off + i]; Z[i] = a.z[off + i]; }
     const double s_loose = sin(a.loose_deg * 3.141592653589793 / 180.0), s_tight = sin(a.tight_deg * 3.141592653589793 / 180.0);
     __syncthreads();
-    for (int t = tid; t < tn; t += kRsBlock) {
-        const TriIds q = load_tri(a.tri + 3 * tb, t);
-        if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) {
-            misc[2] = 1; a.tri_flags[tb + t] = 0; a.tri_height[tb + t] = nan(""); continue;
+    FS_STAMP(1);
+    // phase 1: every triangle's height and flags into LDS (and the height to the output), the loose ones counted and bounded
+    {
+        int k_mine = 0;
+        unsigned long long umin = ~0ull, umax = 0ull;
+        auto one_row = [&](const TriIds q, const int t) {
+            if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) {
+                misc[FM_BADID] = 1; Fl[t] = 0; Hh[t] = nan(""); a.tri_height[tb + t] = nan(""); return;
+            }
+            double nx, ny, nz;
+            if (!plane_normal(X[q.a], Y[q.a], Z[q.a], X[q.b], Y[q.b], Z[q.b], X[q.c], Y[q.c], Z[q.c], nx, ny, nz)) misc[FM_SINGULAR] = 1;   // rescale.py:79-80
+            const double len = sqrt((nx * nx + ny * ny) + nz * nz);                          // :81
+            const double mu = -(ny / len);                                                   // :82
+            const double h = 1.0 / len;                                                      // :89
+            // pitch = asin(mu) * 180/pi (:83) is increasing in mu: away from the two thresholds the comparison is
+            // made on mu itself, within 1e-12 of one (or for NaN) on the reference's own expression
+            bool loose, tight;
+            if (fabs(mu - s_loose) > 1e-12 && fabs(mu - s_tight) > 1e-12) { loose = mu < s_loose; tight = mu < s_tight; }
+            else {
+                const double pitch = asin(mu) * 180.0 / 3.141592653589793;
+                loose = pitch < a.loose_deg; tight = pitch < a.tight_deg;
+            }
+            Hh[t] = h;
+            Fl[t] = (uint8_t)((loose ? 1 : 0) | (tight ? 2 : 0));                            // :85-86
+            a.tri_height[tb + t] = h;
+            if (loose) {
+                const unsigned long long u = (unsigned long long)__double_as_longlong(h);
+                ++k_mine; umin = u < umin ? u : umin; umax = u > umax ? u : umax;
+            }
+        };
+        for (int t0 = tid; t0 < tn; t0 += kFlatRows * kRsBlock) {
+            TriIds cur[kFlatRows];
+#pragma unroll
+            for (int j = 0; j < kFlatRows; ++j) cur[j] = rows[j];
+            if (t0 + kFlatRows * kRsBlock < tn) load_rows(t0 + kFlatRows * kRsBlock);
+#pragma unroll
+            for (int j = 0; j < kFlatRows; ++j) if (t0 + j * kRsBlock < tn) one_row(cur[j], t0 + j * kRsBlock);
         }
-        double nx, ny, nz;
-        if (!plane_normal(X[q.a], Y[q.a], Z[q.a], X[q.b], Y[q.b], Z[q.b], X[q.c], Y[q.c], Z[q.c], nx, ny, nz)) misc[1] = 1;   // rescale.py:79-80
-        const double len = sqrt((nx * nx + ny * ny) + nz * nz);                          // :81
-        const double mu = -(ny / len);                                                   // :82
-        const double h = 1.0 / len;                                                      // :89
-        // pitch = asin(mu) * 180/pi (:83) is increasing in mu: away from the two thresholds the comparison is
-        // made on mu itself, within 1e-12 of one (or for NaN) on the reference's own expression
-        bool loose, tight;
-        if (fabs(mu - s_loose) > 1e-12 && fabs(mu - s_tight) > 1e-12) { loose = mu < s_loose; tight = mu < s_tight; }
-        else {
-            const double pitch = asin(mu) * 180.0 / 3.141592653589793;
-            loose = pitch < a.loose_deg; tight = pitch < a.tight_deg;
+        k_mine = wave_sum(k_mine);
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const unsigned long long lo = __shfl_xor(umin, o), hi = __shfl_xor(umax, o);
+            umin = lo < umin ? lo : umin; umax = hi > umax ? hi : umax;
         }
-        uint8_t fl = 0;
-        if (loose) { fl |= 1; L[atomicAdd(&misc[0], 1)] = h; }                            // :85
-        if (tight) fl |= 2;                                                              // :86
-        a.tri_flags[tb + t] = fl;
-        a.tri_height[tb + t] = h;
+        if (lane == 0 && k_mine) { atomicAdd(&misc[FM_K], k_mine); atomicMin(&ext[0], umin); atomicMax(&ext[1], umax); }
     }
     __syncthreads();
-    const int k = misc[0];
+    FS_STAMP(2);
+    const int k = misc[FM_K];
     double level = nan("");                                      // median of an empty set is nan (nothing passes)
     if (k > 0) {                                                                         // np.median, :91
-        // the two middle order statistics by radix selection on the bit patterns (heights are >= 0, so the
-        // patterns order like the values): eight passes of a 256-bin histogram over the candidates that
-        // still share the prefix found so far
+        // The lower middle order statistic (rank klo): histogram the candidates' bit patterns over [lo, hi] with bins of
+        // 2^shift patterns (<= 2048 bins), find the bin that holds the rank, narrow [lo, hi] to it, repeat — until a bin is a
+        // single pattern, or holds few enough candidates for wavefront 0 to rank them directly.  Real frames take one
+        // pass: their heights spread over a few thousand distinct patterns per bin at most.
         const int klo = (k - 1) >> 1, khi = k >> 1;
-        const unsigned long long *LU = reinterpret_cast<const unsigned long long *>(L);
-        int *hist = misc + 16;                                   // 256 bins
-        unsigned long long prefix = 0ull;
-        int rank = klo;                                          // rank of the wanted value among the candidates
-        for (int shift = 56; shift >= 0; shift -= 8) {
-            if (tid < 256) hist[tid] = 0;
+        unsigned long long lo = ext[0], hi = ext[1];
+        int rank = klo;
+        unsigned long long vlo_bits = lo;
+        for (;;) {
+            const unsigned long long range = hi - lo;
+            if (range == 0ull) { vlo_bits = lo; break; }
+            const int bits = 64 - __clzll((long long)range);                             // range < 2^bits
+            const int shift = bits > 11 ? bits - 11 : 0;
+            for (int b = tid; b < kFlatBins; b += kRsBlock) hist[b] = 0;
             __syncthreads();
-            for (int i = tid; i < k; i += kRsBlock) {
-                const unsigned long long u = LU[i];
-                if (shift == 56 || (u >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(int)((u >> shift) & 255ull)], 1);
+            #pragma unroll 4
+            for (int t = tid; t < tn; t += kRsBlock) {
+                if (!(Fl[t] & 1)) continue;
+                const unsigned long long u = U[t];
+                if (u >= lo && u <= hi) atomicAdd(&hist[(int)((u - lo) >> shift)], 1);
             }
             __syncthreads();
-            if (tid < kWave) {                                   // wave 0: digit whose cumulative count passes the rank
+            {   // the bin whose cumulative count passes the rank: four bins per thread, wave scan, wave totals through LDS
                 const int b0 = hist[4 * tid], b1 = hist[4 * tid + 1], b2 = hist[4 * tid + 2], b3 = hist[4 * tid + 3];
-                int incl = (b0 + b1) + (b2 + b3);
+                const int mine = (b0 + b1) + (b2 + b3);
+                int incl = mine;
 #pragma unroll
-                for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (tid >= o) incl += up; }
-                const int excl = incl - ((b0 + b1) + (b2 + b3));
-                if (rank >= excl && rank < incl) {               // exactly one lane
-                    int r = rank - excl, dgt = 4 * tid;
-                    if (r >= b0) { r -= b0; ++dgt; if (r >= b1) { r -= b1; ++dgt; if (r >= b2) { r -= b2; ++dgt; } } }
-                    misc[4] = dgt; misc[5] = r;
+                for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+                if (lane == kWave - 1) misc[FM_WSUM + wave] = incl;
+                __syncthreads();
+                int before = 0;
+#pragma unroll
+                for (int w = 0; w < kRsWaves; ++w) if (w < wave) before += misc[FM_WSUM + w];
+                incl += before;
+                const int excl = incl - mine;
+                if (rank >= excl && rank < incl) {               // exactly one thread
+                    int r = rank - excl, bin = 4 * tid, c = b0;
+                    if (r >= b0) { r -= b0; ++bin; c = b1; if (r >= b1) { r -= b1; ++bin; c = b2; if (r >= b2) { r -= b2; ++bin; c = b3; } } }
+                    misc[FM_BIN] = bin; misc[FM_RANK] = r; misc[FM_BINCNT] = c;
                 }
+                __syncthreads();
             }
-            __syncthreads();
-            prefix |= (unsigned long long)misc[4] << shift;
-            rank = misc[5];
-            __syncthreads();
+            const int bin = misc[FM_BIN], c = misc[FM_BINCNT];
+            rank = misc[FM_RANK];
+            lo += (unsigned long long)bin << shift;
+            { const unsigned long long top = lo + ((1ull << shift) - 1ull); hi = top < hi ? top : hi; }
+            if (shift == 0) { vlo_bits = lo; break; }            // the bin is one pattern
+            if (c <= kFlatDirect) {
+                unsigned long long *list = reinterpret_cast<unsigned long long *>(hist);
+                __syncthreads();                                 // every thread has read misc / hist
+                #pragma unroll 4
+                for (int t = tid; t < tn; t += kRsBlock) {
+                    if (!(Fl[t] & 1)) continue;
+                    const unsigned long long u = U[t];
+                    if (u >= lo && u <= hi) list[atomicAdd(&misc[FM_LIST], 1)] = u;
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const unsigned long long mine = lane < c ? list[lane] : ~0ull;
+                    int below = 0;
+                    for (int j = 0; j < c; ++j) { const unsigned long long v = list[j]; below += (v < mine || (v == mine && j < lane)) ? 1 : 0; }
+                    if (lane < c && below == rank) ext[3] = mine;
+                }
+                __syncthreads();
+                vlo_bits = ext[3];
+                break;
+            }
+            __syncthreads();                                     // hist is zeroed again at the top
         }
-        const double vlo = __longlong_as_double((long long)prefix);
+        const double vlo = __longlong_as_double((long long)vlo_bits);
         double vhi = vlo;
         if (khi != klo) {
             // the next order statistic: vlo again if it occurs often enough, else the smallest value above it
-            unsigned long long *mn = reinterpret_cast<unsigned long long *>(med);
-            if (tid == 0) { misc[6] = 0; *mn = ~0ull; }
-            __syncthreads();
             int le = 0;
             unsigned long long above = ~0ull;
-            for (int i = tid; i < k; i += kRsBlock) {
-                const unsigned long long u = LU[i];
-                if (u <= prefix) ++le; else above = u < above ? u : above;
+            #pragma unroll 4
+            for (int t = tid; t < tn; t += kRsBlock) {
+                if (!(Fl[t] & 1)) continue;
+                const unsigned long long u = U[t];
+                if (u <= vlo_bits) ++le; else above = u < above ? u : above;
             }
             le = wave_sum(le);
-            if (lane_id() == 0) atomicAdd(&misc[6], le);
-            atomicMin(mn, above);
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) { const unsigned long long other = __shfl_xor(above, o); above = other < above ? other : above; }
+            if (lane == 0) { atomicAdd(&misc[FM_LE], le); atomicMin(&ext[2], above); }
             __syncthreads();
-            if (misc[6] < khi + 1) vhi = __longlong_as_double((long long)*mn);
+            if (misc[FM_LE] < khi + 1) vhi = __longlong_as_double((long long)ext[2]);
         }
         level = a.height_factor * ((klo == khi) ? vlo : (vlo + vhi) / 2.0);
     }
+    FS_STAMP(3);
     int kept = 0;
+    #pragma unroll 4
     for (int t = tid; t < tn; t += kRsBlock) {
-        const uint8_t fl = a.tri_flags[tb + t];
-        if ((fl & 2) && a.tri_height[tb + t] > level) { a.tri_flags[tb + t] = fl | 4; ++kept; }   // :94-96
+        uint8_t fl = Fl[t];
+        if ((fl & 2) && Hh[t] > level) { fl |= 4; ++kept; }                                 // :94-96
+        a.tri_flags[tb + t] = fl;
     }
     kept = wave_sum(kept);
-    if (lane_id() == 0) atomicAdd(&misc[3], kept);
+    if (lane == 0 && kept) atomicAdd(&misc[FM_KEPT], kept);
     __syncthreads();
     if (tid == 0) {
         a.height_level[f] = level;
-        a.n_kept[f] = misc[3];
-        a.status[f] = misc[2] ? MVOSR_ST_ERR_MASK : (misc[1] ? MVOSR_ST_ERR_SINGULAR : 0);
+        a.n_kept[f] = misc[FM_KEPT];
+        a.status[f] = misc[FM_BADID] ? MVOSR_ST_ERR_MASK : (misc[FM_SINGULAR] ? MVOSR_ST_ERR_SINGULAR : 0);
     }
+#ifdef MVOSR_FS_STAMPS
+    FS_STAMP(4);                                                 // (diagnostic build: the stamps overwrite the frame's first heights)
+    if (tid == 0 && tn >= 5) for (int i = 0; i < 5; ++i) a.tri_height[tb + i] = (double)(st[i] - st[0]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -473,7 +571,9 @@ int mvosr_flat_selection_batch(mvosr_ctx *ctx, const mvosr_batch *b, double loos
     a.tri_off = b->tri2_off; a.tri = b->tri2; a.loose_deg = loose_deg; a.tight_deg = tight_deg; a.height_factor = height_factor;
     a.tri_height = tri_height; a.tri_flags = tri_flags; a.height_level = height_level; a.status = status; a.n_kept = n_kept;
     if (max_tri <= 0) max_tri = 2 * (int64_t)b->max_feat;
-    const size_t lds = 24u * (size_t)((b->max_feat + 1) & ~1) + 8u * (size_t)max_tri + 4u * (16 + 256) + 16;
+    size_t lds = 24u * (size_t)((b->max_feat + 1) & ~1);
+    if (lds < 4u * 2048) lds = 4u * 2048;                        // (the histogram of the median search reuses the vertex planes)
+    lds += 9u * (size_t)max_tri + 32 + 4u * 32 + 16;
     if ((rc = rs_prepare(flat_selection_kernel, lds))) return rc;
     hipLaunchKernelGGL(flat_selection_kernel, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
     return check_launch("flat_selection_kernel");

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--pool", type=int, default=64)
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--hyp-sweep", action="store_true", help="diagnostic: RANSAC kernel time against the number of hypotheses")
     ap.add_argument("--cpu-sample", type=int, default=8, help="frames of the pool timed through the NumPy oracle")
     args = ap.parse_args()
 
@@ -103,6 +104,17 @@ def main():
         _lib.check(lib.mvosr_ransac_plane_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d_tri.ptr, H,
                                                 rescale.RANSAC_THRESHOLD, rescale.RANSAC_GOAL, None, model.ptr, best.ptr, used.ptr),
                    "ransac")
+
+    if args.hyp_sweep:
+        for h2 in (1, 8, 25, 50, 100):
+            if h2 > H:
+                break
+            d_tri2 = ctx.to_device(np.tile(np.stack([t[:h2] for t in triples]), (repeats, 1, 1)), np.int32)
+
+            def ransac_h():
+                _lib.check(lib.mvosr_ransac_plane_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d[0].ptr, d[1].ptr, d[2].ptr, d_tri2.ptr, h2,
+                                                        rescale.RANSAC_THRESHOLD, 2.0, None, model.ptr, best.ptr, used.ptr), "ransac")
+            print("ransac_plane_kernel, %3d hypotheses: %.4f ms per %d frames" % (h2, timed(ctx, ransac_h, args.steps), F), file=sys.stderr)
 
     # row a12 (triangle_batch.py): same frames read as [u, v, depth] + the first triangulation
     tb_h = ctx.zeros(F, np.float64)
