@@ -365,11 +365,12 @@ class ScaleEstimator:
             self._chunk_free(st)
         return res + (host_errors,)
 
-    def _exact_rerun(self, eng, db, out, pf, host_errors, errors_only=False):
+    def _exact_rerun(self, eng, db, out, pf, host_errors, errors_only=False, last=True):
         """The product (HOT) kernel leaves ``height_level`` as its own fixed-order sum wherever the level decides nothing
         in the frame itself.  Where a LATER step reads a frame's level, it must be np.mean's own double: the frame before
         one that takes the "no enough feature for triangulation" branch (3 features below the vanishing row: :263-270
-        divides by the previous level, :420-422), the last frame of the chunk (what follows is not known here), and —
+        divides by the previous level, :420-422), the last frame of the chunk (``last``: unless the caller knows that the
+        next chunk does not start with such a frame), and —
         since the estimator keeps the level of the last frame that reached :241 when a frame raises — the frame before
         the chunk's first error and that frame itself when its road model raised (:343-344 come after :241).  Those
         frames run once more, alone, in the exact mode the stage outputs select.  ``host_errors is None``: only the
@@ -380,7 +381,7 @@ class ScaleEstimator:
         again = set()
         if not errors_only:
             again = set(int(g) for g in ok if g + 1 < len(cnt) and cnt[g + 1] == 3)
-            if len(ok):
+            if len(ok) and last:
                 again.add(int(ok[-1]))
         if host_errors is not None:
             status = out.get("status")
@@ -443,7 +444,7 @@ class ScaleEstimator:
     GPU_CHUNK = 2048            # frames per chunk of the device-triangulation path
     GPU_CHUNK_POINTS = 5000000  # ... and features per chunk (40 B each in staging memory, ~100 B each on the device)
 
-    def _chunk_gpu(self, f3s, f2s, stage):
+    def _chunk_gpu(self, f3s, f2s, stage, last=True):
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
         ONE upload -> Delaunay #1, vote, Delaunay #2, scale kernel, road model, the exact re-runs known in advance and
         the download of the results, all queued; nothing is waited for here (``_chunk_gpu_finish`` does)."""
@@ -474,7 +475,7 @@ class ScaleEstimator:
         out = DeviceOutputs(ctx, db, counts=True, stage=stage)
         self.engine.scale_batch(db, out)
         if not stage:
-            self._exact_rerun(self.engine, db, out, pf, None)
+            self._exact_rerun(self.engine, db, out, pf, None, last=last)
         out.prefetch()
         db.prefetch_info()
         db.mark()                     # the chunk's last launch is queued: its blocks' next users need not wait for later chunks
@@ -536,9 +537,17 @@ class ScaleEstimator:
             b = min(b, a + max(over, 1))
             bounds.append((a, b))
             a = b
-        results, pending = [], None
+        results, pending, reran_last = [], None, []
         for k, (a, b) in enumerate(bounds):
-            cur = (self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage), a, b)
+            # the chunk's last level is read later only by the batch's caller (last chunk) or by a frame with exactly three
+            # features below the vanishing row at the head of the next chunk (:263-270): one exact single-frame run less
+            # per chunk otherwise (a serial ~0.3 ms each)
+            last = k + 1 == len(bounds)
+            if not last:
+                nxt = np.asarray(feature2ds[b])
+                last = nxt.ndim != 2 or nxt.shape[0] == 0 or int(np.count_nonzero(nxt[:, 1] > self.vanish)) <= 3
+            reran_last.append(last)
+            cur = (self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage, last=last), a, b)
             if pending is not None:
                 ps, pa, pb = pending
                 results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb]))
@@ -552,6 +561,23 @@ class ScaleEstimator:
         host_errors = {}
         for (a, _), r in zip(bounds, results):
             host_errors.update({a + f: e for f, e in r[4].items()})
+        # A frame that raises leaves the level of the last frame that reached :241 on the estimator.  Inside a chunk that
+        # frame was run in the exact mode (_exact_rerun); when it is the tail of an EARLIER chunk whose last frame was not
+        # (see above), it is run once more now, alone, through the host's path with the stage outputs.
+        bad = np.isin(status, K.ERROR_STATUSES)
+        for f in host_errors:
+            bad[f] = True
+        if bad.any() and not stage:
+            e = int(np.argmax(bad))
+            setters = np.nonzero(status[:e] != K.ST_TOO_FEW)[0]
+            if len(setters):
+                g = int(setters[-1])
+                k = next(i for i, (a, b) in enumerate(bounds) if a <= g < b)
+                if e >= bounds[k][1] and not reran_last[k]:
+                    one = self._chunk_begin([feature3ds[g]], [feature2ds[g]], 0, _remapped=bool(self.mutate_inputs))
+                    self._chunk_vote(one, None, 0)
+                    r = self._chunk_scale(one, None, True)
+                    level[g] = r[2][0]
         return raw, status, level, counts, host_errors, ps
 
     def _flat_feature_of(self, feature3d, feature2d, st):

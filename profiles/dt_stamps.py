@@ -1,5 +1,5 @@
 """Diagnostic: where a workgroup of delaunay_kernel spends its life (in-kernel s_memtime stamps).
-Needs a library built with -DMVOSR_STAMPS:   profiles/ab_build.sh stamps -DMVOSR_STAMPS
+Needs a library built with -DMVOSR_STAMPS:   profiles/ab_build.sh stamps -DMVOSR_STAMPS   (ONLY=mvosr_delaunay to rebuild that file alone)
     MVOSR_LIB_PATH=profiles/ab/libmvosr_stamps.so python profiles/dt_stamps.py [n] [sets]
 """
 import ctypes as C
@@ -32,7 +32,7 @@ ctx.sync()
 s = d_stamps.download().astype(np.float64)
 d = np.diff(s[:, :7], axis=1)
 tot = s[:, 6] - s[:, 0]
-names = ["load + bbox", "grid dims + zero", "count / scan / scatter", "phase 1 (lanes)", "phase 1b (verify)", "phase 2 (hard points)", "prefix + rows out"]
+names = ["load + bbox + grid dims", "zero + count / scan / scatter", "phase 1 (one lane per point)", "(barrier)", "phase 2 (hard points, groups)", "prefix + Euler + rows out"]
 print("n=%d sets=%d  declined=%d  workgroup life: median %.0f cycles" % (n, F, int((d_st.download() != 0).sum()), np.median(tot)))
 for k, name in enumerate(names[:6]):
     print("  %-26s %5.1f %%   (median %.0f cycles)" % (name, 100.0 * np.median(d[:, k] / tot), np.median(d[:, k])))

@@ -456,6 +456,33 @@ def test_triangulation_gpu_fixed_is_bit_equal_to_oracle(gpu):
             assert np.array_equal(one.flat_feature, ref.flat_feature), i
 
 
+def test_triangulation_gpu_error_at_a_chunk_head_leaves_the_exact_level(gpu):
+    """A frame that raises leaves the level of the last frame that reached :241 on the estimator.  When the raising frame
+    heads a chunk, that frame is the tail of the chunk before — which the streaming path no longer re-runs in the exact
+    mode unless something reads its level: here something does (the single-frame exact run after the fact)."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    frames = [synth.synth_frame(i, 700, base_seed=4711) for i in range(40)]
+    f3s, f2s = [f[0].copy() for f in frames], [f[1].copy() for f in frames]
+    f2s[32][:, 0] = f2s[32][:, 1]                               # collinear image points: the triangulation raises (QhullError)
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    est.GPU_CHUNK = 32
+    exact_runs = []
+    inner = est._chunk_scale
+    est._chunk_scale = lambda st, tri2s, stage, keep=False: (exact_runs.append(stage), inner(st, tri2s, stage, keep=keep))[1]
+    with pytest.raises(Exception) as got:
+        est.scale_calculation_batch(f3s, f2s)
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+    with pytest.raises(Exception) as want:
+        for f3, f2 in zip(f3s, f2s):
+            ref.scale_calculation(f3.copy(), f2.copy())
+    assert type(got.value).__name__ == type(want.value).__name__
+    assert est.height_level == ref.height_level
+    assert list(est.scale_queue) == list(ref.scale_queue)
+    assert True in exact_runs                                   # frame 31 was run again on its own, stage outputs on
+
+
 def test_triangulation_gpu_dense_frames(gpu):
     """Frames beyond the LDS capacity (config C5's sizes) through the device-triangulation path: the Delaunay kernel's
     global-memory variant (per-frame arrays in the context's workspace) gives SciPy's rows exactly, and the estimator —
