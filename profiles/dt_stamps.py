@@ -22,7 +22,7 @@ d_u, d_v = ctx.to_device(np.ascontiguousarray(uv[:, 0])), ctx.to_device(np.ascon
 d_off, d_cnt, d_toff = ctx.to_device(off), ctx.to_device(cnt), ctx.to_device(2 * off)
 d_tri = ctx.empty((2 * F * n, 3), np.int32)
 d_tcnt, d_st, d_used = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
-d_stamps = ctx.zeros((F, 16), np.uint64)
+d_stamps = ctx.zeros((F, 32), np.uint64)
 ctx.lib.mvosr_debug_dt_stamps.argtypes = [C.c_void_p]
 ctx.lib.mvosr_debug_dt_stamps(d_stamps.ptr)
 for _ in range(2):
@@ -36,4 +36,7 @@ names = ["load + bbox + grid dims", "zero + count / scan / scatter", "phase 1 (o
 print("n=%d sets=%d  declined=%d  workgroup life: median %.0f cycles" % (n, F, int((d_st.download() != 0).sum()), np.median(tot)))
 for k, name in enumerate(names[:6]):
     print("  %-26s %5.1f %%   (median %.0f cycles)" % (name, 100.0 * np.median(d[:, k] / tot), np.median(d[:, k])))
-print("  queued completions: median %.0f   hard points: median %.0f" % (np.median(s[:, 8]), np.median(s[:, 9])))
+print("  hard points: median %.0f   triangles taken after a search: %.0f per set, from a hint: %.0f per set" % (np.median(s[:, 9]), np.mean(s[:, 10]), np.mean(s[:, 11])))
+print("  steps per point: max %.0f (mean over sets); points with <=6 / <=10 / <=16 / <=28 / more steps: %s" % (np.mean(s[:, 16]), " / ".join("%.0f" % np.mean(s[:, 17 + k]) for k in range(5))))
+print("  open stars (hull vertices): %.0f per set, %.1f steps each; closed stars: %.1f steps each" % (np.mean(s[:, 24]), np.mean(s[:, 22]) / max(np.mean(s[:, 24]), 1), np.mean(s[:, 23]) / max(n - np.mean(s[:, 24]), 1)))
+print("  scan steps per lane: %.1f   lanes with a point in a step: %.1f %%" % (np.mean(s[:, 12]) / 512.0, 100.0 * np.mean(s[:, 13]) / max(np.mean(s[:, 12]), 1)))
