@@ -309,7 +309,8 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames):
     f3s = [pool[i % npool][0] for i in range(n_frames)]
     f2s = [pool[i % npool][1] for i in range(n_frames)]
     est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
-    est.scale_calculation_batch(f3s, f2s)                                     # warm-up: kernels, allocator caches (same sizes as the timed call)
+    for _ in range(2):                                                        # warm-up: kernels, allocator caches (same sizes as the timed call)
+        est.scale_calculation_batch(f3s, f2s)
     ctx = est.engine.ctx
     a0 = ctx.alloc_stats()
     t0 = time.perf_counter()
@@ -673,6 +674,14 @@ def main():
                 line["cpu_baseline_all_cores"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if dense:
             line["host_tile_layout_ms_per_frame"] = getattr(build_pool, "host_layout_ms_per_frame", None)
+        if n_gpus == 1 and not args.no_e2e:
+            # The secondary legs run in their own context.  This one's two streams go first: with torch's two and the legs'
+            # two the process would own six — more than ROCm's four hardware queues per process (GPU_MAX_HW_QUEUES), and
+            # streams that share a queue serialise: the end-to-end leg's upload stream stopped overlapping its kernels
+            # (measured: 172 k instead of 240 k frames/s with a second, idle context alive).
+            torch.cuda.synchronize()
+            keep.clear()
+            ctx.close()
         if n_gpus == 1 and not args.no_e2e and dense:
             # dense frames end to end: host Qhull (~140 CPU-ms per call and frame) bounds it; the tile layout is included
             try:

@@ -146,6 +146,14 @@ static int cache_alloc(mvosr_ctx *ctx, mvosr_block_cache &c, bool host, size_t b
     return MVOSR_OK;
 }
 
+// The upload stream exists from the first upload on: a context that never uploads through the library (a caller that hands
+// over device pointers of its own) does not take one of the process's few hardware queues (ROCm: four per process by
+// default — GPU_MAX_HW_QUEUES; streams beyond that share queues and serialise).
+static hipError_t ensure_upload_stream(mvosr_ctx *ctx) {
+    if (ctx->upload_stream) return hipSuccess;
+    return hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
+}
+
 static int cache_free(mvosr_ctx *ctx, mvosr_block_cache &c, bool host, void *ptr) {
     auto it = c.live.find(ptr);
     if (it == c.live.end()) return set_error(MVOSR_ERR_ARG, "free: pointer %p was not allocated by this context", ptr);
@@ -153,8 +161,11 @@ static int cache_free(mvosr_ctx *ctx, mvosr_block_cache &c, bool host, void *ptr
     c.live.erase(it);
     if (!b.marked) {
         // work queued on either stream may still use the block: its next user waits for this point of both streams
-        hipError_t e = hipEventRecord(ctx->upload_ev, ctx->upload_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0);
+        hipError_t e = hipSuccess;
+        if (ctx->upload_stream) {                                // (no upload stream yet: nothing was ever queued on it)
+            e = hipEventRecord(ctx->upload_ev, ctx->upload_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0);
+        }
         if (e == hipSuccess) e = hipEventRecord(b.ev, ctx->stream);
         if (e != hipSuccess) return set_hip_error("hipEventRecord(block release)", e);
     }
@@ -233,8 +244,8 @@ int mvosr_ctx_create(int device, mvosr_ctx **out) {
     for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) ctx->prof_ev[i][j] = nullptr;
     ctx->ws_ysel = nullptr; ctx->ws_ysel_len = 0; ctx->ws_nsel = nullptr; ctx->ws_nsel_len = 0;
     ctx->n_hip_malloc = ctx->n_hip_free = ctx->n_host_malloc = ctx->n_host_free = ctx->n_cache_hits = 0;
-    e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming);
+    ctx->upload_stream = nullptr;
+    e = hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return set_hip_error("upload stream / event", e); }
     ctx->n_cu = prop.multiProcessorCount;
     int optin = 0;
@@ -252,26 +263,34 @@ int mvosr_ctx_destroy(mvosr_ctx *ctx) {
     if (!ctx) return MVOSR_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->upload_stream);
+    if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);
     cache_release_all(ctx, ctx->dev_cache, false);
     cache_release_all(ctx, ctx->host_cache, true);
     for (auto &kv : ctx->dev_cache.live) { (void)hipEventDestroy(kv.second.ev); (void)hipFree(kv.first); }
     for (auto &kv : ctx->host_cache.live) { (void)hipEventDestroy(kv.second.ev); (void)hipHostFree(kv.first); }
     (void)hipEventDestroy(ctx->upload_ev);
-    (void)hipStreamDestroy(ctx->upload_stream);
+    if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
     for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) if (ctx->prof_ev[i][j]) (void)hipEventDestroy(ctx->prof_ev[i][j]);
     for (int i = 0; i < 2; ++i) if (ctx->ws_dense[i]) (void)hipFree(ctx->ws_dense[i]);
     if (ctx->ws_ysel) (void)hipFree(ctx->ws_ysel);
     if (ctx->ws_nsel) (void)hipFree(ctx->ws_nsel);
     if (ctx->ws_bytes) (void)hipFree(ctx->ws_bytes);
-    (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MVOSR_OK;
 }
 
 int mvosr_ctx_set_stream(mvosr_ctx *ctx, void *hip_stream) {
     if (!ctx) return set_error(MVOSR_ERR_ARG, "null context");
-    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (hip_stream) {
+        // the context's own stream is given back while the caller's is in use (one hardware queue less, see above)
+        if (ctx->own_stream) { HIP_TRY(hipStreamSynchronize(ctx->own_stream)); HIP_TRY(hipStreamDestroy(ctx->own_stream)); ctx->own_stream = nullptr; }
+        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    } else {
+        if (!ctx->own_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+        ctx->stream = ctx->own_stream;
+    }
     return MVOSR_OK;
 }
 
@@ -360,14 +379,18 @@ int mvosr_block_mark(mvosr_ctx *ctx, void *ptr, int marked) {
     if (it == c->live.end()) return set_error(MVOSR_ERR_ARG, "block_mark: pointer %p was not allocated by this context", ptr);
     if (marked == MVOSR_MARK_NOW) {
         HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipEventRecord(ctx->upload_ev, ctx->upload_stream));
-        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
+        if (ctx->upload_stream) {
+            HIP_TRY(hipEventRecord(ctx->upload_ev, ctx->upload_stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
+        }
         HIP_TRY(hipEventRecord(it->second.ev, ctx->stream));
     } else if (marked == MVOSR_MARK_UPLOAD) {
         HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(ensure_upload_stream(ctx));
         HIP_TRY(hipEventRecord(it->second.ev, ctx->upload_stream));
     } else if (marked == MVOSR_MARK_IDLE) {
         HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(ensure_upload_stream(ctx));
         HIP_TRY(hipEventRecord(it->second.ev, ctx->upload_stream));      // (an event that is complete at once when the stream is idle; never waited for long)
         it->second.idle = true;
     } else if (marked != 0) return set_error(MVOSR_ERR_ARG, "block_mark: unknown mark %d", marked);
@@ -397,6 +420,7 @@ int mvosr_memcpy_h2d_async(mvosr_ctx *ctx, void *dst, const void *src, size_t by
     if (!ctx || (bytes && (!dst || !src))) return set_error(MVOSR_ERR_ARG, "memcpy_h2d_async: null argument");
     if (!bytes) return MVOSR_OK;
     HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ensure_upload_stream(ctx));
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->upload_stream));
     return MVOSR_OK;
 }
@@ -404,6 +428,7 @@ int mvosr_memcpy_h2d_async(mvosr_ctx *ctx, void *dst, const void *src, size_t by
 int mvosr_upload_fence(mvosr_ctx *ctx) {
     if (!ctx) return set_error(MVOSR_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->upload_stream) return MVOSR_OK;                    // nothing was uploaded yet
     HIP_TRY(hipEventRecord(ctx->upload_ev, ctx->upload_stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
     return MVOSR_OK;
