@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Diagnostic: what made the end-to-end leg 30 % slower inside bench.py than in a process of its own — the batch call of
+ScaleEstimator(triangulation="gpu") five times in a row after a setup step:
+    python profiles/stream_count_bisect.py plain | torchmem | ctx2 | fork | spawnpool | tm_ctx | tm_ctx_noadopt | tm_fork | ctx_fork | all
+Result (profiles/r03_stream_count.txt): torch's streams AND a second mvosr context together — more than ROCm's four hardware
+queues per process; either alone is harmless."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 mode = sys.argv[1]
