@@ -371,10 +371,14 @@ __device__ double np_leaf_sum(const double *a, int n, double shift, bool sq) {
     for (; i < n; ++i) res += np_term(a, i, shift, sq);
     return res;
 }
-__device__ __attribute__((noinline)) double np_pairwise_chunk_cold(const double *a, int n, double shift, int sq) {
-    constexpr int kDepth = 32;                               // > log2 of any list length
-    int lo_s[kDepth], n_s[kDepth], stage_s[kDepth];
-    double val[kDepth];
+// The recursion's stack lives in LDS (kNpStackInts ints per wavefront, 8-byte aligned; every lane of the wavefront walks
+// the same list and writes the same values): as private arrays it was 688 B of scratch memory per lane of every wavefront
+// of road_model_kernel, for a branch one list in thousands takes.
+constexpr int kNpDepth = 8;                                  // a chunk has <= 8192 elements, a leaf <= 128: at most 7 levels
+constexpr int kNpStackInts = 3 * kNpDepth + 2 * kNpDepth;
+__device__ __attribute__((noinline)) double np_pairwise_chunk_cold(const double *a, int n, double shift, int sq, int *stk) {
+    int *lo_s = stk, *n_s = stk + kNpDepth, *stage_s = stk + 2 * kNpDepth;
+    double *val = reinterpret_cast<double *>(stk + 3 * kNpDepth);
     int sp = 0, vp = 0;
     lo_s[0] = 0; n_s[0] = n; stage_s[0] = 0; sp = 1;
     while (sp > 0) {
@@ -393,9 +397,9 @@ __device__ __attribute__((noinline)) double np_pairwise_chunk_cold(const double 
 // chunks' pairwise sums up from left to right (checked against NumPy 2.2 for lists of 10^4 - 2*10^5 elements: a single
 // pairwise recursion over the whole list differs in the last bits from 10291 elements on).
 constexpr int kNpBufSize = 8192;
-__device__ __forceinline__ double np_pairwise_sum_cold(const double *a, int n, double shift, int sq) {
-    double res = np_pairwise_chunk_cold(a, min(n, kNpBufSize), shift, sq);
-    for (int lo = kNpBufSize; lo < n; lo += kNpBufSize) res += np_pairwise_chunk_cold(a + lo, min(kNpBufSize, n - lo), shift, sq);
+__device__ __forceinline__ double np_pairwise_sum_cold(const double *a, int n, double shift, int sq, int *stk) {
+    double res = np_pairwise_chunk_cold(a, min(n, kNpBufSize), shift, sq, stk);
+    for (int lo = kNpBufSize; lo < n; lo += kNpBufSize) res += np_pairwise_chunk_cold(a + lo, min(kNpBufSize, n - lo), shift, sq, stk);
     return res;
 }
 // The same summation over a STREAM of values (next() hands out the list's elements in order; all lanes of
@@ -795,7 +799,7 @@ template <int RC, int WW = 1>
 __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16_t *slots, uint8_t *dropb, const double2 *edges,
                                                 const double *yv_all, double *scratch,
                                                 int Mall, double height_level, const mvosr_params &P, int32_t *g_hist, bool exact_stats,
-                                                int part_lo, int part_hi, double *part MVOSR_STAMP_ARG) {
+                                                int part_lo, int part_hi, double *part, int *np_stack MVOSR_STAMP_ARG) {
     const int lane = lane_id();
     RoadResult R;
     R.height = nan(""); R.status = MVOSR_ST_MODE; R.n_sel = Mall; R.n_kept = 0; R.n_modes = 0; R.mode_left = -1; R.mode_right = -1;
@@ -1075,8 +1079,8 @@ __device__ __forceinline__ RoadResult road_wave(int *hist, int *nearflag, uint16
         if (!(margin > bound) || exact_stats) {
             const int nl = pack_kept();
             __threadfence_block();               // the wave's own stores, visible to all its lanes
-            mean_o = np_pairwise_sum_cold(scratch, nl, 0.0, 0) / (double)nl;    // np.mean
-            sd = sqrt(np_pairwise_sum_cold(scratch, nl, mean_o, 1) / (double)nl);
+            mean_o = np_pairwise_sum_cold(scratch, nl, 0.0, 0, np_stack) / (double)nl;    // np.mean
+            sd = sqrt(np_pairwise_sum_cold(scratch, nl, mean_o, 1, np_stack) / (double)nl);
         }
     }
     const double skew = (mean_o - mode / 10.0) / sd;                            // :496
@@ -1100,6 +1104,7 @@ __global__ __launch_bounds__(kRoadWaves *kWave, (LIST ? 1 : 4)) void road_model_
     __shared__ uint16_t slots_all[kRoadWaves][kRoadRC * kWave];
     __shared__ __attribute__((aligned(16))) uint8_t drop_all[kRoadWaves][kDropStride * kWave];
     __shared__ double part[2 * kRoadWaves];
+    __shared__ __attribute__((aligned(8))) int np_stack_all[kRoadWaves][kNpStackInts];
     for (int k = threadIdx.x; k < kBins; k += kRoadWaves * kWave) { double2 e; e.x = bin_edge(k); e.y = bin_edge(k + 1); edges[k] = e; }
     __syncthreads();
     const int64_t slot = WW > 1 ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * kRoadWaves + wave_id();
@@ -1123,7 +1128,7 @@ __global__ __launch_bounds__(kRoadWaves *kWave, (LIST ? 1 : 4)) void road_model_
         hi = min(M, lo + q);
     }
     const int Mp = hi - lo;
-#define MVOSR_ROAD_CALL(RC_) road_wave<RC_, WW>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex, lo, hi, part MVOSR_STAMP_PASS)
+#define MVOSR_ROAD_CALL(RC_) road_wave<RC_, WW>(h0, h1, slots_all[wave_id()], drop_all[wave_id()], edges, a.y + off, a.scratch + off, M, hl, a.P, gh, ex, lo, hi, part, np_stack_all[wave_id()] MVOSR_STAMP_PASS)
     const RoadResult R = (Mp <= 4 * kWave) ? MVOSR_ROAD_CALL(4)
                        : (Mp <= 8 * kWave) ? MVOSR_ROAD_CALL(8)
                        : (Mp <= 12 * kWave) ? MVOSR_ROAD_CALL(12)
