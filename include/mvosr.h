@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MVOSR_ABI_VERSION 6
+#define MVOSR_ABI_VERSION 7
 
 /* error codes (function return values) */
 enum mvosr_err {
@@ -452,6 +452,16 @@ enum mvosr_dt_status {
 int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
                          const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
                          int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status);
+/* The same with SEEDS: rows (seed_tri + 3*seed_off[f], seed_cnt[f] of them) of a triangulation of ALL the frame's points,
+ * ids = positions in (u, v) — what a call without `keep` wrote for the same frames.  A triangle of that triangulation whose
+ * three vertices are kept is a triangle of this one (its circumcircle was empty among more points), so it is not searched
+ * for again: the second triangulation of a frame (:264-266, over the ~85 % of the points the vote keeps) starts from the
+ * ~60 % of the first one's triangles that survive.  Same rows as without seeds; frames beyond mvosr_delaunay_lds_points()
+ * ignore them.  Seeds that are not a Delaunay triangulation of the frame's points give undefined rows. */
+int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                                const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
+                                int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status,
+                                const int64_t *seed_off, const int32_t *seed_tri, const int32_t *seed_cnt);
 /* Largest frame mvosr_delaunay_batch takes (32 000 points: ids and row indices are 16-bit), and the largest frame whose
  * points, grid and rows fit one workgroup's LDS (about 4 700): a launch whose max_pts is larger runs the kernel's
  * global-memory variant — the same algorithm with the per-frame arrays in a slice of the context's workspace, read

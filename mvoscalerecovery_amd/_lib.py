@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 LIB_PATH = os.environ.get("MVOSR_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")   # (override: A/B builds in profiles/)
-ABI_VERSION = 6
+ABI_VERSION = 7
 VOTE_REFERENCE, VOTE_FIXED = 0, 1          # mvosr_params.vote_mode
 WAVES_EXACT = 0x100                        # MVOSR_WAVES_EXACT, or-ed into waves_per_frame
 MARK_NOW, MARK_IDLE, MARK_UPLOAD = 1, 2, 3 # mvosr_block_mark
@@ -105,6 +105,7 @@ SYMBOLS = {
                                        _P, _P, _P]),
     "mvosr_plane_inliers": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_double, _P]),
     "mvosr_delaunay_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
+    "mvosr_delaunay_batch_seeded": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mvosr_delaunay_max_points": (C.c_int, []),
     "mvosr_delaunay_lds_points": (C.c_int, []),
     "mvosr_lds_bytes": (C.c_size_t, [C.c_int]),

@@ -90,7 +90,11 @@ struct DtArgs {
     int32_t *status;                                     // [F] MVOSR_DT_*
     int max_pts;
     char *ws;                                            // GLOBAL variant: a slice of dt_plan().big bytes per frame
-    uint32_t *hints;                                     // LDS variant: kDtHintK words per point and frame (all ones = empty), or null
+    uint32_t *hints;                                     // LDS variant: kDtHintK (+1: see seeds) words per point and frame (all ones = empty), or null
+    // seeds (mvosr_delaunay_batch_seeded): rows of a triangulation of ALL the frame's points (ids = positions in u/v).  A
+    // triangle of it whose three vertices are kept is a triangle of this one — its circumcircle was empty among more
+    // points — so its three corners go into the hint caches before the first star is started.
+    const int64_t *seed_off; const int32_t *seed_tri; const int32_t *seed_cnt;
 #ifdef MVOSR_STAMPS
     unsigned long long *stamps;                          // diagnostic builds: 16 values per frame (phase boundaries, list lengths)
 #endif
@@ -117,11 +121,11 @@ static unsigned long long *g_dt_stamps = nullptr;
 // a hint that is not visible yet is a search done twice, nothing else.  Measured at 2000 points: 43 % of the 11 936
 // triangle corners of a set are taken from a hint, 5.7 busy scan steps per point instead of 9.0.
 #ifndef MVOSR_DT_HINTS
-#define MVOSR_DT_HINTS 8
+#define MVOSR_DT_HINTS 16
 #endif
 constexpr int kDtHintK = MVOSR_DT_HINTS;       // 0: no hints
 #ifndef MVOSR_DT_CHAIN
-#define MVOSR_DT_CHAIN 3
+#define MVOSR_DT_CHAIN 8
 #endif
 #ifndef MVOSR_DT_COOP
 #define MVOSR_DT_COOP 1
@@ -378,7 +382,17 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     uint16_t *hard = reinterpret_cast<uint16_t *>(small + L.hard);
     double *red = reinterpret_cast<double *>(small + L.red);
     int *misc = reinterpret_cast<int *>(small + L.misc);
-    uint32_t *hints = (!GLOBAL && kDtHintK > 0 && a.hints) ? a.hints + (size_t)f * ((size_t)kDtHintK * (size_t)((a.max_pts + 7) & ~7)) : nullptr;
+    const size_t hint_pts = (size_t)((a.max_pts + 7) & ~7);
+    uint32_t *hints = (!GLOBAL && kDtHintK > 0 && a.hints) ? a.hints + (size_t)f * ((size_t)(kDtHintK + 1) * hint_pts) : nullptr;
+    uint32_t *inv = (hints && a.seed_tri) ? hints + (size_t)kDtHintK * hint_pts : nullptr;       // position in u/v -> sorted index (seeds only)
+    if (hints) {
+        // all ones = empty.  (One hipMemsetAsync over the launch's caches instead held the HOST for the GPU's queue above
+        // 256 MB: the chunk loop around this kernel ran at 146 k instead of 228 k frames/s.)
+        const int n_words = kDtHintK * min(n_in, (int)hint_pts);
+        uint4 ones; ones.x = ones.y = ones.z = ones.w = 0xFFFFFFFFu;
+        for (int k = tid; k < (n_words + 3) / 4; k += kDtBlock) reinterpret_cast<uint4 *>(hints)[k] = ones;
+        if (inv) for (int k = tid; k < min(n_in, (int)hint_pts); k += kDtBlock) inv[k] = 0xFFFFFFFFu;
+    }
 
     auto decline = [&](int why, int n_used) {
         if (tid == 0) { a.tri_cnt[f] = 0; a.status[f] = MVOSR_DT_DEGENERATE | (why << 8); if (a.n_used) a.n_used[f] = n_used; }
@@ -484,11 +498,34 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                 const int pos = (int)atomicAdd(&cs[G.celly(p.y) * G.gx + G.cellx(p.x)], 1u);
                 S[pos] = p;
                 oid[pos] = (uint16_t)(rank + __popcll(m & ((1ull << lane) - 1ull)));
+                if (inv) __hip_atomic_store(inv + i, (uint32_t)pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             rank += __popcll(m);
         }
     }
     __syncthreads();
+    if (inv) {
+        // the seeds' corners into the hint caches (orientation from the points: the rows are in canonical, not in
+        // counter-clockwise order)
+        const int32_t *st = a.seed_tri + 3 * a.seed_off[f];
+        const int ns = a.seed_cnt[f];
+        for (int r = tid; r < ns; r += kDtBlock) {
+            const int ra = st[3 * r], rb = st[3 * r + 1], rc = st[3 * r + 2];
+            if ((unsigned)ra >= (unsigned)n_in || (unsigned)rb >= (unsigned)n_in || (unsigned)rc >= (unsigned)n_in) continue;
+            const uint32_t pa = __hip_atomic_load(inv + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t pb = __hip_atomic_load(inv + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t pc = __hip_atomic_load(inv + rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pa >= (uint32_t)n || pb >= (uint32_t)n || pc >= (uint32_t)n) continue;          // a vertex that is not kept (all ones)
+            const double2 A_ = S[pa], B_ = S[pb], C_ = S[pc];
+            const double cr = (B_.x - A_.x) * (C_.y - A_.y) - (B_.y - A_.y) * (C_.x - A_.x);
+            if (!(cr != 0.0)) continue;
+            if (cr < 0.0) { const uint32_t t = pb; pb = pc; pc = t; }                            // (pa, pb, pc) counter-clockwise now
+            __hip_atomic_store(hints + (size_t)pa * kDtHintK + (pb % kDtHintK), (pb << 16) | pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(hints + (size_t)pb * kDtHintK + (pc % kDtHintK), (pc << 16) | pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(hints + (size_t)pc * kDtHintK + (pa % kDtHintK), (pa << 16) | pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
     // GLOBAL: the cell index was read (the scan) and then rewritten by other wavefronts' stores and atomics — this CU's L1
     // may hold the old lines
     if constexpr (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -907,8 +944,19 @@ extern "C" int mvosr_delaunay_lds_points(void) { return dt_lds_points(); }
 extern "C" int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
                                     const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
                                     int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status) {
+    return mvosr_delaunay_batch_seeded(ctx, n_frames, pts_off, pts_cnt, u, v, keep, max_pts, tri_off, tri, tri_cnt, n_used, status,
+                                       nullptr, nullptr, nullptr);
+}
+
+extern "C" int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                                           const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
+                                           int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status,
+                                           const int64_t *seed_off, const int32_t *seed_tri, const int32_t *seed_cnt) {
     if (!ctx || !pts_off || !pts_cnt || !u || !v || !tri_off || !tri || !tri_cnt || !status)
         return set_error(MVOSR_ERR_ARG, "delaunay_batch: null argument");
+    if ((seed_off || seed_tri || seed_cnt) && !(seed_off && seed_tri && seed_cnt))
+        return set_error(MVOSR_ERR_ARG, "delaunay_batch_seeded: seed_off, seed_tri and seed_cnt go together");
+    if (seed_tri == tri) return set_error(MVOSR_ERR_ARG, "delaunay_batch_seeded: the seeds' rows and the output rows are the same array");
     if (max_pts < 0) return set_error(MVOSR_ERR_ARG, "delaunay_batch: max_pts < 0");
     if (n_frames <= 0) return MVOSR_OK;
     int rc = ctx_activate(ctx);
@@ -921,6 +969,7 @@ extern "C" int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int6
     DtArgs a;
     a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
     a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.max_pts = max_pts; a.ws = nullptr; a.hints = nullptr;
+    a.seed_off = seed_off; a.seed_tri = seed_tri; a.seed_cnt = seed_cnt;
 #ifdef MVOSR_STAMPS
     a.stamps = g_dt_stamps;
 #endif
@@ -939,12 +988,11 @@ extern "C" int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int6
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(delaunay_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_hip_error("hipFuncSetAttribute(delaunay_kernel)", e);
     if (kDtHintK > 0) {
-        // the stars' hint caches (see kDtHintK): 4 * kDtHintK bytes per point, emptied before every launch
+        // the stars' hint caches (see kDtHintK): 4 * (kDtHintK + 1) bytes per point
         void *ws = nullptr;
-        const size_t bytes = (size_t)n_frames * (size_t)kDtHintK * (size_t)((max_pts + 7) & ~7) * sizeof(uint32_t);
+        const size_t bytes = (size_t)n_frames * (size_t)(kDtHintK + 1) * (size_t)((max_pts + 7) & ~7) * sizeof(uint32_t);
         if ((rc = ctx_workspace_bytes(ctx, bytes, &ws))) return rc;
-        if ((e = hipMemsetAsync(ws, 0xFF, bytes, ctx_stream(ctx))) != hipSuccess) return set_hip_error("hipMemsetAsync(Delaunay hint caches)", e);
-        a.hints = reinterpret_cast<uint32_t *>(ws);
+        a.hints = reinterpret_cast<uint32_t *>(ws);              // (every workgroup empties its own frame's caches: no memset of the whole block)
     }
     hipLaunchKernelGGL(delaunay_kernel<false>, dim3((unsigned)n_frames), dim3(kDtBlock), lds, ctx_stream(ctx), a);
     return check_launch("delaunay_kernel");

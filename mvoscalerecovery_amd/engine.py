@@ -144,9 +144,12 @@ class DeviceBatch:
         o.vote_counters = b["vote_counters"].ptr
         bs = self.struct()
         _lib.check(lib.mvosr_outlier_vote_batch(ctx.handle, C.byref(engine.params), C.byref(bs), C.byref(o), 0), "mvosr_outlier_vote_batch")
-        _lib.check(lib.mvosr_delaunay_batch(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
-                                            b["vote_counters"].ptr, int(self.max_feat), b["tri_off"].ptr, b["tri2"].ptr, b["tri2_cnt"].ptr,
-                                            b["n2_expected"].ptr, b["dt2_status"].ptr), "mvosr_delaunay_batch (second triangulation)")
+        # (seeded with the first triangulation: its triangles among the survivors are triangles of the second)
+        _lib.check(lib.mvosr_delaunay_batch_seeded(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
+                                                   b["vote_counters"].ptr, int(self.max_feat), b["tri_off"].ptr, b["tri2"].ptr,
+                                                   b["tri2_cnt"].ptr, b["n2_expected"].ptr, b["dt2_status"].ptr,
+                                                   b["tri_off"].ptr, b["tri1"].ptr, b["tri1_cnt"].ptr),
+                   "mvosr_delaunay_batch_seeded (second triangulation)")
 
     def triangulation_status(self):
         """Host copies of (first, second) triangulation status per frame (mvosr_dt_status; non-zero: declined)."""

@@ -29,6 +29,20 @@ for _ in range(2):
     _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n, d_toff.ptr,
                                             d_tri.ptr, d_tcnt.ptr, d_used.ptr, d_st.ptr), "dt")
 ctx.sync()
+if os.environ.get("DT_SEEDED"):
+    # the second triangulation's shape: 85 % of the points kept, seeded with the rows just computed
+    rng = np.random.default_rng(5)
+    keep = np.where(rng.uniform(size=F * n) < 0.85, 1, -1).astype(np.int32)
+    d_keep = ctx.to_device(keep)
+    d_tri2 = ctx.empty((2 * F * n, 3), np.int32)
+    d_tcnt2 = ctx.zeros(F, np.int32)
+    seeded = os.environ["DT_SEEDED"] == "1"
+    for _ in range(2):
+        _lib.check(ctx.lib.mvosr_delaunay_batch_seeded(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n, d_toff.ptr,
+                                                       d_tri2.ptr, d_tcnt2.ptr, d_used.ptr, d_st.ptr,
+                                                       d_toff.ptr if seeded else None, d_tri.ptr if seeded else None, d_tcnt.ptr if seeded else None), "dt2")
+    ctx.sync()
+    print("second triangulation over 85 %% of the points, %s:" % ("seeded" if seeded else "not seeded"))
 s = d_stamps.download().astype(np.float64)
 d = np.diff(s[:, :7], axis=1)
 tot = s[:, 6] - s[:, 0]
