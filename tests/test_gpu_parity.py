@@ -373,6 +373,57 @@ def test_gpu_delaunay_matches_scipy_triangle_set(gpu):
     assert d_tc.download()[0] == 0 and (d_st.download()[0] & 0xFF) == 1
 
 
+def test_seeded_second_triangulation_equals_scipy_on_the_survivors(gpu):
+    """mvosr_delaunay_batch_seeded: the second triangulation (over the points a mask keeps) seeded with the rows of the first
+    (over all points) gives the rows SciPy gives for the survivors — with masks that keep 30 to 97 % of the points, with a
+    first triangulation that was declined (no seeds), with survivors below three, and identically to the unseeded call."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import _lib, packing, synth
+    rng = np.random.default_rng(77)
+    sets = [synth.synth_frame(i, int(m), base_seed=1234)[1] for i, m in enumerate((2000, 1500, 700, 300, 90, 12, 5, 4000, 2300, 1000))]
+    sets.append(rng.uniform(0, 1, (1800, 2)) * [1241.0, 376.0])
+    dup = sets[3].copy(); dup[7] = dup[100]                      # first triangulation declined (duplicate), survivors fine
+    sets.append(dup)
+    F = len(sets)
+    cnt = np.array([len(p) for p in sets], dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+    uv = np.concatenate(sets)
+    keep_frac = [0.85, 0.6, 0.97, 0.4, 0.8, 0.5, 0.3, 0.85, 0.9, 0.75, 0.85, 0.85]
+    keep = np.concatenate([np.where(rng.uniform(size=n) < f, 3, -2) for n, f in zip(cnt, keep_frac)]).astype(np.int32)
+    keep[off[11] + 7] = -1                                       # the duplicate is voted out: the second triangulation exists
+    d_u, d_v = gpu.to_device(np.ascontiguousarray(uv[:, 0])), gpu.to_device(np.ascontiguousarray(uv[:, 1]))
+    d_off, d_cnt, d_toff, d_keep = gpu.to_device(off), gpu.to_device(cnt), gpu.to_device(2 * off), gpu.to_device(keep)
+    rows = int(2 * cnt.sum())
+    tri1, tri2, tri3 = (gpu.empty((rows, 3), np.int32) for _ in range(3))
+    c1, c2, c3 = (gpu.zeros(F, np.int32) for _ in range(3))
+    s1, s2, s3, used = (gpu.zeros(F, np.int32) for _ in range(4))
+    lib, n_max = gpu.lib, int(cnt.max())
+    _lib.check(lib.mvosr_delaunay_batch(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n_max, d_toff.ptr,
+                                        tri1.ptr, c1.ptr, None, s1.ptr), "first")
+    _lib.check(lib.mvosr_delaunay_batch_seeded(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr,
+                                               tri2.ptr, c2.ptr, used.ptr, s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr), "seeded")
+    _lib.check(lib.mvosr_delaunay_batch(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr,
+                                        tri3.ptr, c3.ptr, None, s3.ptr), "unseeded")
+    h1, h2, h3 = s1.download(), s2.download(), s3.download()
+    t2, t3, n2, n3, nu = tri2.download(), tri3.download(), c2.download(), c3.download(), used.download()
+    assert h1[11] != 0 and (h1[:5] == 0).all()                   # the duplicate's first triangulation was declined, the others not
+    for f in range(F):
+        kept = keep[off[f]:off[f] + cnt[f]] >= 0
+        pts = sets[f][kept]
+        assert nu[f] == kept.sum()
+        assert h2[f] == h3[f] and n2[f] == n3[f], f
+        a = int(2 * off[f])
+        assert np.array_equal(t2[a:a + n2[f]], t3[a:a + n3[f]]), f
+        if len(pts) < 3:
+            assert h2[f] != 0 and n2[f] == 0
+            continue
+        assert h2[f] == 0, (f, h2[f] >> 8)
+        assert np.array_equal(t2[a:a + n2[f]], packing.canonical_rows(Delaunay(pts).simplices)), f
+    # the seeds' rows and the output rows must not be one array
+    assert lib.mvosr_delaunay_batch_seeded(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr,
+                                           tri1.ptr, c2.ptr, None, s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr) != 0
+
+
 def test_fixed_vote_mode_kernels_equal_oracle(gpu):
     """check_triangle="fixed" (mvosr_params.vote_mode = MVOSR_VOTE_FIXED): the order-invariant vote through every kernel
     family (1/4/8/16 wavefronts per frame, the dense two-sweep and tiled kernels) against the oracle's fixed mode — and
