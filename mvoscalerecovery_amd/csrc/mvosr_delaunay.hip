@@ -127,6 +127,9 @@ constexpr int kDtHintK = MVOSR_DT_HINTS;       // 0: no hints
 #ifndef MVOSR_DT_CHAIN
 #define MVOSR_DT_CHAIN 8
 #endif
+#ifndef MVOSR_DT_HINT_START
+#define MVOSR_DT_HINT_START 1
+#endif
 #ifndef MVOSR_DT_COOP
 #define MVOSR_DT_COOP 1
 #endif
@@ -383,7 +386,8 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     double *red = reinterpret_cast<double *>(small + L.red);
     int *misc = reinterpret_cast<int *>(small + L.misc);
     const size_t hint_pts = (size_t)((a.max_pts + 7) & ~7);
-    uint32_t *hints = (!GLOBAL && kDtHintK > 0 && a.hints) ? a.hints + (size_t)f * ((size_t)(kDtHintK + 1) * hint_pts) : nullptr;
+    uint32_t *hints = (!GLOBAL && kDtHintK > 0 && a.hints) ? a.hints + (size_t)f * ((size_t)(kDtHintK + 2) * hint_pts) : nullptr;
+    uint32_t *start = hints ? hints + (size_t)(kDtHintK + 1) * hint_pts : nullptr;               // one known triangle per point: its star starts there
     uint32_t *inv = (hints && a.seed_tri) ? hints + (size_t)kDtHintK * hint_pts : nullptr;       // position in u/v -> sorted index (seeds only)
     if (hints) {
         // all ones = empty.  (One hipMemsetAsync over the launch's caches instead held the HOST for the GPU's queue above
@@ -392,6 +396,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
         uint4 ones; ones.x = ones.y = ones.z = ones.w = 0xFFFFFFFFu;
         for (int k = tid; k < (n_words + 3) / 4; k += kDtBlock) reinterpret_cast<uint4 *>(hints)[k] = ones;
         if (inv) for (int k = tid; k < min(n_in, (int)hint_pts); k += kDtBlock) inv[k] = 0xFFFFFFFFu;
+        for (int k = tid; k < min(n_in, (int)hint_pts); k += kDtBlock) start[k] = 0xFFFFFFFFu;
     }
 
     auto decline = [&](int why, int n_used) {
@@ -523,6 +528,9 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
             __hip_atomic_store(hints + (size_t)pa * kDtHintK + (pb % kDtHintK), (pb << 16) | pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(hints + (size_t)pb * kDtHintK + (pc % kDtHintK), (pc << 16) | pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(hints + (size_t)pc * kDtHintK + (pa % kDtHintK), (pa << 16) | pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(start + pa, (pb << 16) | pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(start + pb, (pc << 16) | pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(start + pc, (pa << 16) | pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
@@ -542,7 +550,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     {
         // Points are taken from both ends of the sorted array towards its middle: the first and the last cell rows hold
         // the hull and the points next to it, whose stars need wide searches — the long tasks start first, the short
-        // ones fill the tail.
+        // ones fill the tail.  (All boundary cells' points first — an order array built per frame — measured the same.)
         auto point_of = [&](int idx) { return (idx & 1) ? n - 1 - (idx >> 1) : (idx >> 1); };
         int i = tid < n ? point_of(tid) : -1;       // (misc[DM_NEXT] starts at kDtBlock)
         bool exhausted = tid >= n;
@@ -575,29 +583,34 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
             box = b_; wide = w_; y_next = b_.ya; j_resume = 0; A.reset();
             coop = (kDtCoop<GLOBAL> && mode == 1 && (c_ < 0 ? w_ : c_)) ? 1 : 0;
         };
-        if (i >= 0) { p = S[i]; oi = oid[i]; begin_search(block_r(p, 1), 0); }
-        for (;;) {
-            if (i < 0 && !exhausted) {
-                const int idx = atomicAdd(&misc[DM_NEXT], 1);
-                if (idx < n) {
-                    i = point_of(idx); p = S[i]; oi = oid[i]; mode = 0; deg = 0; nown = 0; iq = -1; open = 0; sgn = 1.0; nn_level = 0;
-#pragma unroll
-                    for (int k = 0; k < kDtLaneRows; ++k) rows[k] = 0xFFFFFFFFu;
-                    begin_search(block_r(p, 1), 0);
-                } else exhausted = true;
+        // A point that already holds a triangle of its star — "after `from` comes `to`" (a seed, or a neighbour's find) — starts
+        // there: both are Delaunay neighbours, the nearest-neighbour search (a scan step or two) is not needed.  The state is
+        // that of a finished final search whose answer is `to`: the completion code takes it from there.
+        auto start_from_hint = [&]() {
+#if MVOSR_DT_HINT_START
+            if constexpr (!GLOBAL && kDtHintK > 0) {
+                if (hints && i >= 0) {
+                    const uint32_t h = __hip_atomic_load(start + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int from = (int)(h >> 16), to = (int)(h & 0xFFFFu);
+                    if (h != 0xFFFFFFFFu && from < n && to < n && from != to && from != i && to != i) {
+                        mode = 1; q0 = from; iq = from; nn_level = 0;
+                        box.xa = 0; box.xb = 0; box.ya = 0; box.yb = -1; wide = 1; coop = 0; y_next = 0; j_resume = 0;
+                        A.reset(); A.b1 = to;
+                    }
+                }
             }
-            if (__ballot(i >= 0) == 0ull) break;
-            const bool act = i >= 0, m1 = mode == 1;
-#ifdef MVOSR_STAMPS
-            ++n_iter; n_busy += act ? 1 : 0; steps_pt += act ? 1 : 0;
 #endif
+        };
+        if (i >= 0) { p = S[i]; oi = oid[i]; begin_search(block_r(p, 1), 0); start_from_hint(); }
+        // A WIDE search of a star (the cell box of a circumcircle that leaves the point's block, the frame's half beside
+        // a hull edge: hundreds of candidates) is not walked by its lane — 32 candidates per scan step, with 63 lanes
+        // waiting on it at the end of the frame: the hull vertices' stars took 36 steps each against 5.4 for an
+        // interior point and set the workgroup's critical path — but scanned by the whole wavefront at once, one
+        // such search after the other, each lane taking every 64th candidate of a cell row.
+        auto serve_wide = [&]() -> bool {
+            bool any = false;
             if constexpr (kDtCoop<GLOBAL>) {
-            // A WIDE search of a star (the cell box of a circumcircle that leaves the point's block, the frame's half beside
-            // a hull edge: hundreds of candidates) is not walked by its lane — 32 candidates per scan step, with 63 lanes
-            // waiting on it at the end of the frame: the hull vertices' stars took 36 steps each against 5.4 for an
-            // interior point and set the workgroup's critical path — but scanned by the whole wavefront at once, one
-            // such search after the other, each lane taking every 64th candidate of a cell row.
-            for (unsigned long long todo = __ballot(act && m1 && coop); todo; todo &= todo - 1ull) {
+            for (unsigned long long todo = __ballot(i >= 0 && mode == 1 && coop); todo; todo &= todo - 1ull) {
                 const int src = (int)__ffsll((long long)todo) - 1;
                 const int bi = __builtin_amdgcn_readlane(i, src), biq = __builtin_amdgcn_readlane(iq, src);
                 const int bneg = __builtin_amdgcn_readlane(sgn < 0.0 ? 1 : 0, src);
@@ -616,9 +629,29 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                 const DtPick pk = dt_wave_pick(A2);
                 if (pk.flag) degenerate |= DT_WHY_COLLINEAR;
                 if (pk.tie) degenerate |= DT_WHY_TIE;
+                any = true;
                 if (lane == src) { A.reset(); A.b1 = pk.id; y_next = box.yb + 1; j_resume = 0; coop = 0; }
             }
             }
+            return any;
+        };
+        for (;;) {
+            if (i < 0 && !exhausted) {
+                const int idx = atomicAdd(&misc[DM_NEXT], 1);
+                if (idx < n) {
+                    i = point_of(idx); p = S[i]; oi = oid[i]; mode = 0; deg = 0; nown = 0; iq = -1; open = 0; sgn = 1.0; nn_level = 0;
+#pragma unroll
+                    for (int k = 0; k < kDtLaneRows; ++k) rows[k] = 0xFFFFFFFFu;
+                    begin_search(block_r(p, 1), 0);
+                    start_from_hint();
+                } else exhausted = true;
+            }
+            if (__ballot(i >= 0) == 0ull) break;
+            const bool act = i >= 0, m1 = mode == 1;
+#ifdef MVOSR_STAMPS
+            ++n_iter; n_busy += act ? 1 : 0; steps_pt += act ? 1 : 0;
+#endif
+            serve_wide();
             DtEdge E;
             if (m1) E.set(p, S[max(iq, 0)], i, iq, sgn); else E.set_nn(p, i);
             // up to five rows of the search's box as ranges of the sorted array, walked as ONE loop (a loop per row would
@@ -654,7 +687,9 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                 if (j < je) { y_next += seg; j_resume = j; }        // out of budget: go on from here in the next iteration
                 else { y_next += kDtRows; j_resume = 0; }
             }
-            if (!act || y_next <= box.yb) continue;                  // (the search is not finished)
+            // (twice: a wide search the first pass raises is scanned by the wavefront at once and completed in the same step)
+            for (int rep = 0; rep < 2; ++rep) {
+            if (i >= 0 && y_next > box.yb) {                         // the search is finished
             // ---- the search is complete.  A search that does not certify its answer is widened: the point's 3x3 block
             // (nearest neighbour only), its 5x5 block, an 11x11 block, then — final by construction — the cell box of the
             // answer's circumcircle, or the whole frame when there is no answer yet.
@@ -707,6 +742,10 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // in a's star: after c comes p
                             __hip_atomic_store(hints + (size_t)c_ * kDtHintK + ((uint32_t)i % kDtHintK), ((uint32_t)i << 16) | a_,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // in c's star: after p comes a
+#if MVOSR_DT_HINT_START
+                            __hip_atomic_store(start + a_, (c_ << 16) | (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(start + c_, ((uint32_t)i << 16) | a_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                         }
                     }
                     int chain = 0;
@@ -771,6 +810,9 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                 const int pos = atomicAdd(&misc[DM_NHARD], 1);
                 if (pos < kDtHardCap) hard[pos] = (uint16_t)i; else degenerate |= DT_WHY_HARD;
                 i = -1;
+            }
+            }
+            if (rep == 1 || !serve_wide()) break;
             }
         }
 #ifdef MVOSR_STAMPS
@@ -990,7 +1032,7 @@ extern "C" int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, con
     if (kDtHintK > 0) {
         // the stars' hint caches (see kDtHintK): 4 * (kDtHintK + 1) bytes per point
         void *ws = nullptr;
-        const size_t bytes = (size_t)n_frames * (size_t)(kDtHintK + 1) * (size_t)((max_pts + 7) & ~7) * sizeof(uint32_t);
+        const size_t bytes = (size_t)n_frames * (size_t)(kDtHintK + 2) * (size_t)((max_pts + 7) & ~7) * sizeof(uint32_t);
         if ((rc = ctx_workspace_bytes(ctx, bytes, &ws))) return rc;
         a.hints = reinterpret_cast<uint32_t *>(ws);              // (every workgroup empties its own frame's caches: no memset of the whole block)
     }
