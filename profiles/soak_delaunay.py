@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Soak of mvosr_delaunay_batch / _seeded against scipy.spatial.Delaunay (canonical rows): random point sets of several
+distributions and sizes, plus a second triangulation over a random 40-97 % of each set seeded with the first.
+    python profiles/soak_delaunay.py [rounds]      (160 sets per round)"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvoscalerecovery_amd import _lib, packing
+from scipy.spatial import Delaunay
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+ctx = _lib.default_context(0)
+lib = ctx.lib
+rng = np.random.default_rng(31337)
+total = bad = declined = bad2 = declined2 = 0
+for rnd in range(rounds):
+    sets = []
+    for k in range(160):
+        n = int(rng.integers(4, 4700))
+        kind = k % 6
+        if kind == 0: p = rng.uniform(0, 1, (n, 2)) * [1241.0, 376.0]
+        elif kind == 1: p = rng.normal(0, 1, (n, 2)) * [300.0, 40.0] + [600, 200]
+        elif kind == 2:
+            c = rng.uniform(0, 1000, (8, 2)); p = c[rng.integers(0, 8, n)] + rng.normal(0, 15, (n, 2))
+        elif kind == 3:
+            t = rng.uniform(0, 2 * np.pi, n); r = rng.uniform(0.2, 1.0, n) ** 0.3; p = np.stack([r * np.cos(t) * 500, r * np.sin(t) * 100], 1)
+        elif kind == 4:
+            p = np.concatenate([rng.uniform(0, 100, (n // 2, 2)), rng.uniform(900, 1000, (n - n // 2, 2)) * [1, 0.1]])
+        else:
+            p = rng.uniform(0, 1, (n, 2)) ** 3 * [2000.0, 500.0]           # strongly non-uniform density
+        sets.append(np.ascontiguousarray(p))
+    F = len(sets)
+    cnt = np.array([len(p) for p in sets], dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+    uv = np.concatenate(sets)
+    keep = np.concatenate([np.where(rng.uniform(size=n) < rng.uniform(0.4, 0.97), 1, -1) for n in cnt]).astype(np.int32)
+    d_u, d_v = ctx.to_device(np.ascontiguousarray(uv[:, 0])), ctx.to_device(np.ascontiguousarray(uv[:, 1]))
+    d_off, d_cnt, d_toff, d_keep = ctx.to_device(off), ctx.to_device(cnt), ctx.to_device(2 * off), ctx.to_device(keep)
+    rows = int(2 * cnt.sum())
+    tri1, tri2 = ctx.empty((rows, 3), np.int32), ctx.empty((rows, 3), np.int32)
+    c1, c2, s1, s2 = (ctx.zeros(F, np.int32) for _ in range(4))
+    nmax = int(cnt.max())
+    _lib.check(lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, nmax, d_toff.ptr, tri1.ptr, c1.ptr, None, s1.ptr), "dt1")
+    _lib.check(lib.mvosr_delaunay_batch_seeded(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, nmax, d_toff.ptr, tri2.ptr, c2.ptr, None,
+                                               s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr), "dt2")
+    t1, t2, n1, n2, h1, h2 = tri1.download(), tri2.download(), c1.download(), c2.download(), s1.download(), s2.download()
+    for f, p in enumerate(sets):
+        a = int(2 * off[f])
+        total += 1
+        if h1[f] != 0:
+            declined += 1
+        elif not np.array_equal(t1[a:a + n1[f]], packing.canonical_rows(Delaunay(p).simplices)):
+            bad += 1
+            ref = packing.canonical_rows(Delaunay(p).simplices)
+            got = t1[a:a + n1[f]]
+            gs, rs = set(map(tuple, got.tolist())), set(map(tuple, ref.tolist()))
+            print("MISMATCH first n=%d kind=%d rows %d vs %d; only GPU %d, only SciPy %d" % (len(p), f % 6, len(got), len(ref), len(gs - rs), len(rs - gs)))
+            os.makedirs("gpurun_out", exist_ok=True)
+            np.savez("gpurun_out/dt_mismatch_%d.npz" % bad, pts=p, gpu=got, ref=ref)
+        q = p[keep[off[f]:off[f] + cnt[f]] >= 0]
+        if h2[f] != 0:
+            declined2 += 1
+        elif len(q) >= 3 and not np.array_equal(t2[a:a + n2[f]], packing.canonical_rows(Delaunay(q).simplices)):
+            bad2 += 1
+            print("MISMATCH second n=%d kept=%d kind=%d" % (len(p), len(q), f % 6))
+    for b in (d_u, d_v, d_off, d_cnt, d_toff, d_keep, tri1, tri2, c1, c2, s1, s2):
+        b.free()
+print("sets %d: first triangulation declined %d, mismatches %d; seeded second declined %d, mismatches %d" % (total, declined, bad, declined2, bad2))
