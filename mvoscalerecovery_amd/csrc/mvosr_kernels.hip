@@ -603,6 +603,87 @@ __device__ __forceinline__ double exact_height_level(const int32_t *tri, int t2n
     return (0.0 + np_pairwise_stream(st, n_steep)) / (double)n_steep;
 }
 
+// The same double, computed by the whole workgroup.  The streamed version above is one dependent chain per steep triangle
+// (≈0.3 ms for a 2000-feature frame: a quarter of the per-frame call's GPU time); here the steep heights are first packed
+// into `hs` in row order (ballots + a running count: two barriers per WAVES*64 rows), then NumPy's pairwise tree is
+// evaluated with one thread per LEAF (<= 128 elements, the eight-accumulator loop of np_leaf_sum) and the leaves' sums
+// are added up in the recursion's own order by one thread — the same additions in the same order, hence the same bits.
+// `hs`: global scratch of the frame (capacity `cap` doubles; the caller falls back to the streamed version when
+// n_steep + kNpMaxLeaves does not fit).  `wcnt`: WAVES ints of LDS.  `slot`: one double of LDS.  Workgroup-uniform call.
+constexpr int kNpMaxLeaves = kNpBufSize / 64;      // a leaf has more than 64 elements unless the chunk itself is one
+template <class Visit>
+__device__ __forceinline__ void np_pairwise_leaves(int n, Visit visit) {      // visit(lo, len, is_leaf) in post-order; false = an inner node
+    int lo_s[kNpDepth], n_s[kNpDepth], stage_s[kNpDepth];
+    int sp = 1;
+    lo_s[0] = 0; n_s[0] = n; stage_s[0] = 0;
+    while (sp > 0) {
+        const int lo = lo_s[sp - 1], m = n_s[sp - 1], stage = stage_s[sp - 1];
+        if (m <= 128) { visit(lo, m, true); --sp; continue; }
+        int m2 = m / 2;
+        m2 -= m2 % 8;
+        if (stage == 0) { stage_s[sp - 1] = 1; lo_s[sp] = lo; n_s[sp] = m2; stage_s[sp] = 0; ++sp; }
+        else if (stage == 1) { stage_s[sp - 1] = 2; lo_s[sp] = lo + m2; n_s[sp] = m - m2; stage_s[sp] = 0; ++sp; }
+        else { visit(lo, m, false); --sp; }
+    }
+}
+template <int WAVES, bool FULL, class Fetch>
+__device__ __forceinline__ double exact_height_level_block(const int32_t *tri, int t2n, int n_steep, const PitchTest &pt, Fetch fetch,
+                                                           const int32_t *order, double *hs, int *wcnt, double *slot) {
+    constexpr int B = WAVES * kWave;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    if (n_steep <= 0) return nan("");                           // np.mean of an empty slice
+    int packed = 0;
+    for (int r0 = 0; r0 < t2n; r0 += B) {
+        const int t = r0 + tid;
+        bool steep = false;
+        double h = 0.0;
+        if (t < t2n) {
+            const int row = order ? min(max(order[t], 0), t2n - 1) : t;
+            const TriIds q = load_tri(tri, row);
+            double x0, y0, z0, x1, y1, z1, x2, y2, z2;
+            if (fetch(q, x0, y0, z0, x1, y1, z1, x2, y2, z2)) {
+                h = div3((y0 + y1) + y2);
+                steep = classify_triangle<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, h, pt, nullptr, nullptr, nullptr, 0) & 2;
+            }
+        }
+        const unsigned long long m = __ballot(steep);
+        if (lane == 0) wcnt[w] = __popcll(m);
+        __syncthreads();
+        int before = packed, total = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) { const int c = wcnt[i]; if (i < w) before += c; total += c; }
+        if (steep) { const int pos = before + __popcll(m & ((1ull << lane) - 1ull)); if (pos < n_steep) hs[pos] = h; }
+        packed += total;
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    double *leaf = hs + n_steep;                                 // the leaves' sums of the current chunk
+    double res = 0.0;
+    for (int c0 = 0; c0 < n_steep; c0 += kNpBufSize) {
+        const int m = min(kNpBufSize, n_steep - c0);
+        int k = 0;
+        np_pairwise_leaves(m, [&](int lo, int len, bool is_leaf) {
+            if (is_leaf) { if (k % B == tid) leaf[k] = np_leaf_sum(hs + c0 + lo, len, 0.0, false); ++k; }
+        });
+        __threadfence_block();
+        __syncthreads();
+        if (tid == 0) {
+            double val[kNpDepth + 1];
+            int vp = 0, kk = 0;
+            np_pairwise_leaves(m, [&](int, int, bool is_leaf) {
+                if (is_leaf) val[vp++] = leaf[kk++];
+                else { const double r = val[--vp], l = val[--vp]; val[vp++] = l + r; }
+            });
+            *slot = c0 == 0 ? val[0] : *slot + val[0];
+        }
+        __syncthreads();
+    }
+    res = *slot;
+    __syncthreads();
+    return (0.0 + res) / (double)n_steep;
+}
+
 struct LdsFetch {            // rows of tri2 index the compacted survivors in LDS
     const double2 *P; const double *Y; int n_valid;
     __device__ __forceinline__ bool operator()(const TriIds q, double &x0, double &y0, double &z0, double &x1, double &y1, double &z1,
@@ -626,7 +707,7 @@ template <int WAVES, int MODE, int FW = 1>
 __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid, const int32_t *tri2, int64_t t2_begin,
                                                      int t2_count, TriChunk<WAVES * kWave> &tc, PitchTest pt,
                                                      double *g_normals, double *g_pitch, double *g_heights, int bad_in,
-                                                     int dbg = 0 MVOSR_STAMP_ARG) {
+                                                     double *scratch, int scratch_cap, int dbg = 0 MVOSR_STAMP_ARG) {
     constexpr int B = WAVES * kWave;
     constexpr bool FULL = MODE == MODE_FULL;
     const int tid = threadIdx.x;
@@ -680,8 +761,14 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     SelectResult r;
     double hl = hsum / hcnt;                      // np.mean of an empty set -> 0/0 = NaN, like :240.  (HOT: the mean of 3h)
     const double guard = kLevelGuard * (habs / hcnt);
-    if constexpr (MODE != MODE_HOT)
-        hl = exact_height_level<FULL>(tri2 + 3 * t2_begin, t2_count, (int)hcnt, pt, LdsFetch{s.P, s.Y, n_valid});
+    if constexpr (MODE != MODE_HOT) {
+        // (workgroup-uniform condition: hcnt is the block sum)
+        if (scratch && (int)hcnt + kNpMaxLeaves <= scratch_cap)
+            hl = exact_height_level_block<WAVES, FULL>(tri2 + 3 * t2_begin, t2_count, (int)hcnt, pt, LdsFetch{s.P, s.Y, n_valid}, nullptr,
+                                                       scratch, s.misc + M_WCNT, s.red + R_MISC * 2 * WAVES);
+        else
+            hl = exact_height_level<FULL>(tri2 + 3 * t2_begin, t2_count, (int)hcnt, pt, LdsFetch{s.P, s.Y, n_valid});
+    }
     int ntv = 0, near = 0;
     auto mark_triangle = [&](int kk, int qa, int qb, int qc) {
         const unsigned long long fw = (FW == 1 || kk < 64) ? flat : flat_hi;
@@ -1342,7 +1429,7 @@ __global__ __launch_bounds__(WAVES *kWave, (WAVES == 8 && MODE == MODE_HOT ? MVO
     const bool too_many_rows = t1n > kMaxVoteRows;
     if (!mask_mismatch && !too_many_rows)
         S = phase_select<WAVES, MODE>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
-                                      a.o.tri_heights, bad, a.debug_skip MVOSR_STAMP_PASS);
+                                      a.o.tri_heights, bad, a.ysel ? a.ysel + off : nullptr, n, a.debug_skip MVOSR_STAMP_PASS);
     if (a.debug_skip & 8) S.bad = 1;
     frame_tail<WAVES, MODE>(a, s, f, off, nvalid, mask_mismatch || too_many_rows, S, R);
     MVOSR_STAMP(9);
@@ -1487,7 +1574,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_kernel(const Den
         TriChunk<B> tc2;
         tc2.load(a.b.tri2, t2b, t2n, 0, tid);
         S = phase_select<DW, MODE, 2>(s, nvalid, a.b.tri2, t2b, t2n, tc2, a.pt, a.o.tri_normals, a.o.tri_pitch_deg,
-                                      a.o.tri_heights, bad, 0);
+                                      a.o.tri_heights, bad, nullptr, 0, 0);
     }
     frame_tail<DW, MODE>(a, s, f, off, nvalid, mask_mismatch, S, R);
     });
