@@ -380,7 +380,8 @@ class ScaleEstimator:
         ok = np.nonzero(cnt > 3)[0]
         again = set()
         if not errors_only:
-            again = set(int(g) for g in ok if g + 1 < len(cnt) and cnt[g + 1] == 3)
+            nxt = ok[ok + 1 < len(cnt)]
+            again = set(int(g) for g in nxt[cnt[nxt + 1] == 3])
             if len(ok) and last:
                 again.add(int(ok[-1]))
         if host_errors is not None:
@@ -441,6 +442,7 @@ class ScaleEstimator:
             host_errors.update({a + f: e for f, e in r[4].items()})
         return raw, status, level, counts, host_errors, S[n - 1]
 
+    GPU_PIPELINE = 1                # chunks queued on the device behind the one being collected (2 and 3 measured: the same rate)
     GPU_CHUNK = 2048            # frames per chunk of the device-triangulation path
     GPU_CHUNK_POINTS = 5000000  # ... and features per chunk (40 B each in staging memory, ~100 B each on the device)
 
@@ -537,7 +539,7 @@ class ScaleEstimator:
             b = min(b, a + max(over, 1))
             bounds.append((a, b))
             a = b
-        results, pending, reran_last = [], None, []
+        results, queue, reran_last = [], [], []
         for k, (a, b) in enumerate(bounds):
             # the chunk's last level is read later only by the batch's caller (last chunk) or by a frame with exactly three
             # features below the vanishing row at the head of the next chunk (:263-270): one exact single-frame run less
@@ -547,13 +549,16 @@ class ScaleEstimator:
                 nxt = np.asarray(feature2ds[b])
                 last = nxt.ndim != 2 or nxt.shape[0] == 0 or int(np.count_nonzero(nxt[:, 1] > self.vanish)) <= 3
             reran_last.append(last)
-            cur = (self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage, last=last), a, b)
-            if pending is not None:
-                ps, pa, pb = pending
+            queue.append((self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage, last=last), a, b))
+            # GPU_PIPELINE chunks stay queued behind the one whose results are collected: this process packs and uploads
+            # the next chunk meanwhile (the kernel timeline shows the GPU 98 % busy between a call's first and last chunk
+            # with one: what a call pays beyond its kernels is its first chunk's pack + upload and the host's epilogue)
+            while len(queue) > self.GPU_PIPELINE:
+                ps, pa, pb = queue.pop(0)
                 results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb]))
-            pending = cur
-        ps, pa, pb = pending
-        results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb], keep=True))
+        while queue:
+            ps, pa, pb = queue.pop(0)
+            results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb], keep=not queue))
         raw = np.concatenate([r[0] for r in results])
         status = np.concatenate([r[1] for r in results])
         level = np.concatenate([r[2] for r in results])
@@ -591,6 +596,14 @@ class ScaleEstimator:
         f2 = np.asarray(feature2d, dtype=np.float64)
         mutate, self.mutate_inputs = self.mutate_inputs, False
         try:
+            if self.triangulation == "gpu" and not mutate:
+                # (the device's triangulations for this one frame as well: two host Delaunay calls are 5 ms, the whole
+                # per-frame device path 1.5)
+                one = self._chunk_gpu([f3], [f2], True)
+                _, status, _, _, _ = self._chunk_gpu_finish(one, [f3], [f2], keep=True)
+                self._store_flat_feature(one["pf"], one["out"], [f3], [f2], one["masks"], 0, status[0])
+                self._chunk_free(one)
+                return
             one = self._chunk_begin([f3], [f2], 0)
             one["eng"] = self._plain_engine() if mutate else self.engine
             self._chunk_vote(one, None, 0)
@@ -635,10 +648,10 @@ class ScaleEstimator:
         n_ok = err_at
         stds = np.where((status[:n_ok] == K.ST_NO_FLAT) | (status[:n_ok] == K.ST_TOO_FEW), 100, 1).astype(np.float64)   # :413,:333-354
         filtered = self.engine.window_median_host(raw[:n_ok], self.window_size, list(self.scale_queue))   # :396-400
-        for s in raw[:n_ok]:
-            self.scale_queue.append(s)
-            if len(self.scale_queue) > self.window_size:
-                self.scale_queue.popleft()
+        # (the deque after n_ok appends with popleft beyond window_size: its last window_size entries — no loop over the run)
+        tail = list(self.scale_queue) + [s for s in raw[max(0, n_ok - self.window_size):n_ok]]
+        self.scale_queue.clear()
+        self.scale_queue.extend(tail[-self.window_size:])
         if n_ok and cur_level is not None:
             self.height_level = cur_level
             if self.verbose:
