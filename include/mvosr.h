@@ -456,8 +456,8 @@ int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_of
  * ids = positions in (u, v) — what a call without `keep` wrote for the same frames.  A triangle of that triangulation whose
  * three vertices are kept is a triangle of this one (its circumcircle was empty among more points), so it is not searched
  * for again: the second triangulation of a frame (:264-266, over the ~85 % of the points the vote keeps) starts from the
- * ~60 % of the first one's triangles that survive.  Same rows as without seeds; frames beyond mvosr_delaunay_lds_points()
- * ignore them.  Seeds that are not a Delaunay triangulation of the frame's points give undefined rows. */
+ * ~60 % of the first one's triangles that survive.  Same rows as without seeds.  Seeds that are not a Delaunay triangulation
+ * of the frame's points give undefined rows. */
 int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
                                 const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
                                 int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status,

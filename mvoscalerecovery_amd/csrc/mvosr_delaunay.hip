@@ -134,7 +134,14 @@ constexpr int kDtHintK = MVOSR_DT_HINTS;       // 0: no hints
 #define MVOSR_DT_COOP 1
 #endif
 constexpr int kDtHintChain = MVOSR_DT_CHAIN;
-template <bool GLOBAL> constexpr bool kDtCoop = MVOSR_DT_COOP && !GLOBAL;    // (frames in global memory: 26 k -> 19 k sets/s with it at 20 000 points)   // hinted triangles taken in a row before the lane goes back to searching
+#ifndef MVOSR_DT_GLOBAL_HINTS
+#define MVOSR_DT_GLOBAL_HINTS 1
+#endif
+template <bool GLOBAL> constexpr bool kDtHintsOn = kDtHintK > 0 && (!GLOBAL || MVOSR_DT_GLOBAL_HINTS);
+#ifndef MVOSR_DT_GLOBAL_COOP
+#define MVOSR_DT_GLOBAL_COOP 0
+#endif
+template <bool GLOBAL> constexpr bool kDtCoop = MVOSR_DT_COOP && (!GLOBAL || MVOSR_DT_GLOBAL_COOP);    // (frames in global memory: 26 k -> 19 k sets/s with it at 20 000 points)   // hinted triangles taken in a row before the lane goes back to searching
 
 struct DtPlan { uint32_t S, oid, od, astart, cs, arena, big, hard, wrows, red, misc, total; int max_cells, arena_cap; };
 constexpr int kDtMaxCellsGlobal = 32768;
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     double *red = reinterpret_cast<double *>(small + L.red);
     int *misc = reinterpret_cast<int *>(small + L.misc);
     const size_t hint_pts = (size_t)((a.max_pts + 7) & ~7);
-    uint32_t *hints = (!GLOBAL && kDtHintK > 0 && a.hints) ? a.hints + (size_t)f * ((size_t)(kDtHintK + 2) * hint_pts) : nullptr;
+    uint32_t *hints = (kDtHintsOn<GLOBAL> && a.hints) ? a.hints + (size_t)f * ((size_t)(kDtHintK + 2) * hint_pts) : nullptr;
     uint32_t *start = hints ? hints + (size_t)(kDtHintK + 1) * hint_pts : nullptr;               // one known triangle per point: its star starts there
     uint32_t *inv = (hints && a.seed_tri) ? hints + (size_t)kDtHintK * hint_pts : nullptr;       // position in u/v -> sorted index (seeds only)
     if (hints) {
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
         // that of a finished final search whose answer is `to`: the completion code takes it from there.
         auto start_from_hint = [&]() {
 #if MVOSR_DT_HINT_START
-            if constexpr (!GLOBAL && kDtHintK > 0) {
+            if constexpr (kDtHintsOn<GLOBAL>) {
                 if (hints && i >= 0) {
                     const uint32_t h = __hip_atomic_load(start + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int from = (int)(h >> 16), to = (int)(h & 0xFFFFu);
@@ -734,7 +741,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                 else begin_search(all, 1);
                 if (accept >= 0) {
                     if (A.tie && dt_confirm_tie(S, G, box, E, A.b1, A.n1, A.c1)) degenerate |= DT_WHY_TIE;
-                    if constexpr (!GLOBAL && kDtHintK > 0) {
+                    if constexpr (kDtHintsOn<GLOBAL>) {
                         if (hints) {
                             // counter-clockwise walk: (p, iq, accept) is the triangle; clockwise: (p, accept, iq)
                             const uint32_t a_ = (uint32_t)(sgn > 0.0 ? iq : accept), c_ = (uint32_t)(sgn > 0.0 ? accept : iq);
@@ -770,7 +777,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                         if (sgn > 0.0 && iq == q0) { state = 1; break; }      // closed
                         // the next edge of the star: already known from a neighbour's star?
                         accept = -1;
-                        if constexpr (!GLOBAL && kDtHintK > 0) {
+                        if constexpr (kDtHintsOn<GLOBAL>) {
                             if (hints && sgn > 0.0 && chain < kDtHintChain) {
                                 const uint32_t h = __hip_atomic_load(hints + (size_t)i * kDtHintK + ((uint32_t)iq % kDtHintK),
                                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1019,8 +1026,11 @@ extern "C" int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, con
     if (global) {
         // frames beyond the LDS capacity: the big arrays in the context's workspace, one slice per frame
         void *ws = nullptr;
-        if ((rc = ctx_workspace_bytes(ctx, (size_t)n_frames * L.big, &ws))) return rc;
+        const size_t big_bytes = ((size_t)n_frames * L.big + 255) & ~(size_t)255;
+        const size_t hint_bytes = kDtHintsOn<true> ? (size_t)n_frames * (size_t)(kDtHintK + 2) * (size_t)((max_pts + 7) & ~7) * sizeof(uint32_t) : 0;
+        if ((rc = ctx_workspace_bytes(ctx, big_bytes + hint_bytes, &ws))) return rc;
         a.ws = reinterpret_cast<char *>(ws);
+        if (hint_bytes) a.hints = reinterpret_cast<uint32_t *>(a.ws + big_bytes);
         lds = L.total - L.big;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(delaunay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return set_hip_error("hipFuncSetAttribute(delaunay_kernel)", e);
