@@ -1,0 +1,50 @@
+"""Soak of the device-resident path: batches of random frames through ScaleEstimator(triangulation="gpu") (Delaunay #1 -> vote
+-> seeded Delaunay #2 -> scale kernel -> road model, in chunks) against ScaleEstimator(triangulation="scipy",
+check_triangle="fixed") on the same frames (host Qhull rows, the same kernels) — scales and stds must be identical arrays —
+and against the loop-faithful NumPy oracle on a sample.
+    python profiles/soak_gpu_path.py [seconds]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+from mvoscalerecovery_amd import synth
+from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+import scale_oracle as so
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(777)
+t_end = time.time() + budget
+batches = frames = bad = oracle_checked = oracle_bad = declined = 0
+while time.time() < t_end:
+    F = int(rng.integers(40, 400))
+    sizes = rng.integers(150, 2600, F)
+    seed = int(rng.integers(1 << 30))
+    fr = [synth.synth_frame(i, int(n), base_seed=seed, upper_fraction=float(rng.uniform(0.0, 0.3))) for i, n in enumerate(sizes)]
+    f3, f2 = [f[0] for f in fr], [f[1] for f in fr]
+    g = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    g.GPU_CHUNK = int(rng.integers(16, 256))
+    h = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="scipy", check_triangle="fixed", delaunay_workers=8)
+    try:
+        sg = g.scale_calculation_batch(f3, f2); eg = None
+    except Exception as exc:          # noqa: BLE001
+        sg, eg = None, type(exc).__name__
+    try:
+        sh = h.scale_calculation_batch(f3, f2); eh = None
+    except Exception as exc:          # noqa: BLE001
+        sh, eh = None, type(exc).__name__
+    ok = eg == eh and (sg is None or (np.array_equal(sg[0], sh[0], equal_nan=True) and np.array_equal(sg[1], sh[1])))
+    ok = ok and np.array_equal(np.asarray(g.last_raw_scale), np.asarray(h.last_raw_scale), equal_nan=True)
+    bad += 0 if ok else 1
+    if not ok:
+        print("MISMATCH batch seed=%d F=%d chunk=%d: %s / %s" % (seed, F, g.GPU_CHUNK, eg, eh))
+    declined += int(g.last_declined)
+    if batches % 10 == 0 and sg is not None:                  # the oracle on the first frames of every tenth batch
+        o = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+        for i in range(min(12, F)):
+            s, sd = o.scale_calculation(f3[i].copy(), f2[i].copy())
+            oracle_checked += 1
+            if s != sg[0][i] or sd != sg[1][i]:
+                oracle_bad += 1
+    batches += 1; frames += F
+print("batches %d, frames %d: %d batches differ from the host-triangulated run; oracle sample %d frames, %d differ; declined in last chunks %d"
+      % (batches, frames, bad, oracle_checked, oracle_bad, declined))
