@@ -130,6 +130,10 @@ constexpr int kDtHintK = MVOSR_DT_HINTS;       // 0: no hints
 #ifndef MVOSR_DT_HINT_START
 #define MVOSR_DT_HINT_START 1
 #endif
+#ifndef MVOSR_DT_SERVE_ROWS
+#define MVOSR_DT_SERVE_ROWS 4
+#endif
+constexpr int kDtServeRows = MVOSR_DT_SERVE_ROWS;      // (a power of two)
 #ifndef MVOSR_DT_COOP
 #define MVOSR_DT_COOP 1
 #endif
@@ -628,10 +632,15 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                 E2.set(S[bi], S[biq], bi, biq, bneg ? -1.0 : 1.0);
                 DtAcc A2;
                 A2.reset();
-                for (int y = bb.ya; y <= bb.yb; ++y) {
-                    int j0, j1;
-                    dt_row_range(G, E2, y, bb.xa, bb.xb, j0, j1);
-                    for (int j = j0 + lane; j < j1; j += kWave) dt_step(A2, E2, j, S[j]);
+                // kDtServeRows cell rows at a time, 64 / kDtServeRows lanes each: a wide box is many rows of a dozen candidates,
+                // and a row's range costs as much as its candidates (one row at a time with all 64 lanes: 648 k sets/s at
+                // 2000 points; four: 741 k)
+                constexpr int kLanesPerRow = kWave / kDtServeRows;
+                for (int y0 = bb.ya; y0 <= bb.yb; y0 += kDtServeRows) {
+                    const int y = y0 + lane / kLanesPerRow;
+                    int j0 = 0, j1 = 0;
+                    if (y <= bb.yb) dt_row_range(G, E2, y, bb.xa, bb.xb, j0, j1);
+                    for (int j = j0 + (lane & (kLanesPerRow - 1)); j < j1; j += kLanesPerRow) dt_step(A2, E2, j, S[j]);
                 }
                 const DtPick pk = dt_wave_pick(A2);
                 if (pk.flag) degenerate |= DT_WHY_COLLINEAR;
