@@ -1756,7 +1756,7 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
 // ~0.2 % of the rows (hull slivers), whose far vertices are fetched from global memory and whose contributions
 // to those vertices wait in a short pending list until their tile arrives.
 //
-// One workgroup walks the tiles with a ring of TWO tiles in LDS: per vertex {v, z'}, {x, y'} (fed by coalesced
+// One workgroup walks the tiles with a ring of kRing (three) tiles in LDS: per vertex {v, z'}, {x, y'} (fed by coalesced
 // loads of the caller's planes, remap fused, the tile after next in flight in registers), a 32-bit vote counter,
 // the largest height of its flat triangles as an order-preserving 64-bit key (LDS atomic max) and a "named by
 // tri2" flag.  The vote and the selection sweep of a tile's rows run in the same step; nothing is compacted or
@@ -1764,7 +1764,8 @@ __global__ __launch_bounds__(DW *kWave) void scale_frames_dense_feat_kernel(cons
 // survivors only is checked, and the vertices with a flat triangle ("candidates", about a third) park {y', largest
 // flat height} in a scratch plane.  "Some flat triangle at this vertex is higher than the level" (:243-247) — the
 // reference's second pass over the triangles — is then one comparison per candidate once height_level is known.
-// LDS: 62 KB whatever the frame size, two workgroups per CU.
+// LDS: 80 KB whatever the frame size, two workgroups per CU.  With three slots a step has ONE barrier: tile k-1 retires and tile
+// k+2 is stored into its slot while the rows of tile k (vertices in tiles k and k+1) are walked.
 //
 // HBM traffic per frame: planes 32 B x N + rows 12 B x (T1 + T2), each once, + 32 B per candidate: about 1.2 x the
 // algorithmic bytes (the two-sweep gather variant: 2.2 x).
@@ -1778,7 +1779,13 @@ constexpr int kTileW = 512;                 // features per tile (MVOSR_TILE_W i
 #define MVOSR_TILED_WAVES 8
 #endif
 constexpr int kTiledWaves = MVOSR_TILED_WAVES;
-constexpr int kPendCap = 1024;              // pending votes / heights for vertices whose tile has not arrived yet
+#ifndef MVOSR_TILED_RING
+#define MVOSR_TILED_RING 3
+#endif
+constexpr int kRing = MVOSR_TILED_RING;     // tiles in the LDS ring: 2 = two barriers per tile (a tile retires and its successor is stored between them),
+                                            // 3 = one (tile k-1 retires and tile k+2 takes its slot while the rows of tile k are still being walked)
+constexpr int kPendCap = 1024;              // pending votes for vertices whose tile has not arrived yet (4 B each) ...
+constexpr int kPendCapH = kRing == 3 ? 576 : 1024;      // ... and pending heights (12 B each): what fits two workgroups per CU
 #ifndef MVOSR_TILE_ROWS
 #define MVOSR_TILE_ROWS 2
 #endif
@@ -1793,14 +1800,15 @@ struct TiledPlan { uint32_t ringA, ringB, ringH, ringC, used, pendV, pendH, toff
 __host__ __device__ inline TiledPlan tiled_plan(int n, int waves) {
     TiledPlan p;
     const uint32_t ntiles = (uint32_t)((n + kTileW - 1) / kTileW);
-    p.ringA = 0;                                                 // double2 {v, z'}  x 2 tiles
-    p.ringB = p.ringA + 16u * 2u * kTileW;                       // double2 {x, y'}  x 2 tiles
-    p.ringH = p.ringB + 16u * 2u * kTileW;                       // uint64 key of the largest flat height x 2 tiles
-    p.ringC = p.ringH + 8u * 2u * kTileW;                        // int32 vote counters (kSubC per vertex) x 2 tiles
-    p.used = p.ringC + 4u * 2u * kTileW * kSubC;                 // uint8 "a tri2 row names this vertex" x 2 tiles
-    p.pendV = align16(p.used + 2u * kTileW);                     // {vertex, +-1}
-    p.pendH = p.pendV + 8u * kPendCap;                           // {vertex, -, key64}
-    p.toff = align16(p.pendH + 16u * kPendCap);                   // the frame's tile index: 2 x (ntiles + 1) ints
+    constexpr uint32_t RW = (uint32_t)kRing * kTileW;            // vertices in the ring
+    p.ringA = 0;                                                 // double2 {v, z'}
+    p.ringB = p.ringA + 16u * RW;                                // double2 {x, y'}
+    p.ringH = p.ringB + 16u * RW;                                // uint64 key of the largest flat height
+    p.ringC = p.ringH + 8u * RW;                                 // int32 vote counters (kSubC per vertex)
+    p.used = p.ringC + 4u * RW * kSubC;                          // uint8 "a tri2 row names this vertex"
+    p.pendV = align16(p.used + RW);                              // vertex << 1 | (vote is -1)
+    p.pendH = p.pendV + 4u * kPendCap;                           // key64 x kPendCapH, then vertex x kPendCapH
+    p.toff = align16(p.pendH + 12u * kPendCapH);                 // the frame's tile index: 2 x (ntiles + 1) ints
     p.red = align16(p.toff + 8u * (ntiles + 2u));
     p.misc = p.red + 8u * (uint32_t)(kRedSlots * 2 * waves);
     p.total = p.misc + 4u * 64u;
@@ -1840,8 +1848,9 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
     unsigned long long *ringH = reinterpret_cast<unsigned long long *>(smem + pl.ringH);
     int *ringC = reinterpret_cast<int *>(smem + pl.ringC);
     uint8_t *used = reinterpret_cast<uint8_t *>(smem + pl.used);
-    int2 *pendV = reinterpret_cast<int2 *>(smem + pl.pendV);
-    ulonglong2 *pendH = reinterpret_cast<ulonglong2 *>(smem + pl.pendH);
+    int *pendV = reinterpret_cast<int *>(smem + pl.pendV);
+    unsigned long long *pendH = reinterpret_cast<unsigned long long *>(smem + pl.pendH);
+    int *pendHv = reinterpret_cast<int *>(pendH + kPendCapH);
     int *toff1 = reinterpret_cast<int *>(smem + pl.toff);
     double *red = reinterpret_cast<double *>(smem + pl.red);
     int *misc = reinterpret_cast<int *>(smem + pl.misc);
@@ -1883,11 +1892,19 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
             tv[j] = stream_load(gv + i); tx[j] = stream_load(gx + i); ty[j] = stream_load(gy + i); tz[j] = stream_load(gz + i);
         }
     };
+    // ring slots.  Two tiles: feature i sits at i mod 2W.  Three: at i mod 3W — for a feature at distance d <= 2W - 1 from the
+    // start of a tile whose slot begins at sb that is sb + d, wrapped once.
+    auto tile_slot = [&](int t) { return kRing == 2 ? (t & 1) * W : (t % 3) * W; };
+    auto slot_at = [&](int sb, int d) {
+        if constexpr (kRing == 2) return (sb + d) & M;
+        else { const int s_ = sb + d; return s_ >= 3 * W ? s_ - 3 * W : s_; }
+    };
     auto tile_store = [&](int t) {
+        const int sb = tile_slot(t);
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
             if (j * B + tid >= W) continue;
-            const int i = t * W + j * B + tid, slot = i & M;
+            const int i = t * W + j * B + tid, slot = sb + j * B + tid;
             double2 pa, pb;
             pa.x = tv[j]; pa.y = ty[j] * sp + tz[j] * cp;          // {v, z'}
             pb.x = tx[j]; pb.y = ty[j] * cp - tz[j] * sp;          // {x, y'}
@@ -1900,7 +1917,7 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
     };
     tile_load(0); tile_store(0);
     tile_load(1); tile_store(1);
-    tile_load(2);
+    tile_load(2);       // (stored at the end of step 0: into tile 0's slot when that tile has retired, or into the third slot)
     // the block agrees on the index before anyone walks it
     {
         int b0 = bad, b1 = 0, b2 = 0, b3 = 0;
@@ -1954,11 +1971,10 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
         const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
         const int e = atomicAdd(n_pendV, 3);
         if (e + 3 <= kPendCap) {
-            int2 p;
             const VoteFlags vf = vote_flags(pa, pb, pc, fixed);
-            p.x = q.a; p.y = vf.f0 ? -1 : 1; pendV[e] = p;
-            p.x = q.b; p.y = vf.f1 ? -1 : 1; pendV[e + 1] = p;
-            p.x = q.c; p.y = vf.f2 ? -1 : 1; pendV[e + 2] = p;
+            pendV[e] = q.a << 1 | (vf.f0 ? 1 : 0);
+            pendV[e + 1] = q.b << 1 | (vf.f1 ? 1 : 0);
+            pendV[e + 2] = q.c << 1 | (vf.f2 ? 1 : 0);
         } else overflow = 1;
     }
     for (int t = far2 + tid; t < t2n; t += B) {
@@ -1980,22 +1996,22 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
         if (r & 1) ++npitch;
         const unsigned long long key = ((r & 1) && h == h) ? height_key64(h) : 0ull;
         const int e = atomicAdd(n_pendH, 3);
-        if (e + 3 <= kPendCap) {
-            ulonglong2 p; p.y = key;
-            p.x = (unsigned long long)(unsigned)q.a; pendH[e] = p;
-            p.x = (unsigned long long)(unsigned)q.b; pendH[e + 1] = p;
-            p.x = (unsigned long long)(unsigned)q.c; pendH[e + 2] = p;
+        if (e + 3 <= kPendCapH) {
+            pendH[e] = key; pendH[e + 1] = key; pendH[e + 2] = key;
+            pendHv[e] = q.a; pendHv[e + 1] = q.b; pendHv[e + 2] = q.c;
         } else overflow = 1;
     }
     __syncthreads();
     // contributions of the far rows to the vertices of a tile (applied once the tile is in the ring)
     auto apply_pending = [&](int tile) {
-        const int nv = min(n_pendV[0], kPendCap), nh = min(n_pendH[0], kPendCap);
-        for (int e = tid; e < nv; e += B) { const int2 p = pendV[e]; if (p.x / W == tile) atomicAdd(&ringC[(p.x & M) * kSubC], p.y); }
+        const int nv = min(n_pendV[0], kPendCap), nh = min(n_pendH[0], kPendCapH), sb = tile_slot(tile);
+        for (int e = tid; e < nv; e += B) {
+            const int p = pendV[e], vtx = p >> 1;
+            if (vtx / W == tile) atomicAdd(&ringC[(sb + vtx - tile * W) * kSubC], (p & 1) ? -1 : 1);
+        }
         for (int e = tid; e < nh; e += B) {
-            const ulonglong2 p = pendH[e];
-            const int vtx = (int)(p.x & 0xFFFFFFFFull);
-            if (vtx / W == tile) { if (p.y) atomicMax(&ringH[vtx & M], p.y); used[vtx & M] = 1; }
+            const int vtx = pendHv[e];
+            if (vtx / W == tile) { const unsigned long long key = pendH[e]; if (key) atomicMax(&ringH[sb + vtx - tile * W], key); used[sb + vtx - tile * W] = 1; }
         }
     };
     apply_pending(0);
@@ -2026,93 +2042,13 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
             cand_base += 64 * (nfull > ww ? (nfull - 1 - ww) / DW + 1 : 0) + ((rem && (nfull % DW) == ww) ? rem : 0);
     }
 
-    // ---- the walk over the tiles
-    for (int k = 0; k < ntiles; ++k) {
-        const int lo = k * W;
-        const int b1 = toff1[k], e1 = toff1[k + 1], b2 = toff2[k], e2 = toff2[k + 1];
-        TriIds c1[kTileRows], c2[kTileRows];
-#pragma unroll
-        for (int j = 0; j < kTileRows; ++j) { c1[j] = n1[j]; c2[j] = n2[j]; }
-        prefetch_rows(min(k + 1, ntiles - 1));
-        apply_pending(k + 1);                          // (tile k+1 entered the ring at the end of the last step)
-        // the vote over this tile's rows of tri1 (:151-167): vertices from the ring, 32-bit counters in the ring.
-        // Every row of the walk has its vertices in tiles k and k+1 (checked: anything else is not the promised layout).
-        auto row_ok = [&](const TriIds q) {
-            const unsigned far = max(max((unsigned)(q.a - lo), (unsigned)(q.b - lo)), (unsigned)(q.c - lo));
-            return far <= (unsigned)M && max(max(q.a, q.b), q.c) < n;
-        };
-        auto vote_row = [&](const TriIds q) {
-            if (!row_ok(q)) { bad = 1; return; }
-            const double2 p0 = ringA[q.a & M], p1 = ringA[q.b & M], p2 = ringA[q.c & M];      // {v, z'}
-            const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
-            const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
-            const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
-            const VoteFlags vf = vote_flags(pa, pb, pc, fixed);
-            atomicAdd(&ringC[(q.a & M) * kSubC], vf.f0 ? -1 : 1);
-            atomicAdd(&ringC[(q.b & M) * kSubC], vf.f1 ? -1 : 1);
-            atomicAdd(&ringC[(q.c & M) * kSubC], vf.f2 ? -1 : 1);
-        };
-        {
-            // the prefetched rows: every ring read first (the compiler cannot move the reads of one row across the LDS
-            // atomics of another, and issued together their latencies overlap), then the tests and the atomics
-            double2 vp[kTileRows][3];
-            bool ok[kTileRows];
-#pragma unroll
-            for (int j = 0; j < kTileRows; ++j) {
-                const TriIds q = c1[j];
-                const bool live = b1 + j * B + rid < e1;
-                ok[j] = live && row_ok(q);
-                if (live && !ok[j]) bad = 1;
-                if (ok[j]) { vp[j][0] = ringA[q.a & M]; vp[j][1] = ringA[q.b & M]; vp[j][2] = ringA[q.c & M]; }      // {v, z'}
-            }
-#pragma unroll
-            for (int j = 0; j < kTileRows; ++j) {
-                if (!ok[j]) continue;
-                const TriIds q = c1[j];
-                const double2 p0 = vp[j][0], p1 = vp[j][1], p2 = vp[j][2];
-                const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
-                const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
-                const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
-                const VoteFlags vf = vote_flags(pa, pb, pc, fixed);
-                atomicAdd(&ringC[(q.a & M) * kSubC], vf.f0 ? -1 : 1);
-                atomicAdd(&ringC[(q.b & M) * kSubC], vf.f1 ? -1 : 1);
-                atomicAdd(&ringC[(q.c & M) * kSubC], vf.f2 ? -1 : 1);
-            }
-        }
-        for (int t = b1 + kTileRows * B + rid; t < e1; t += B) vote_row(load_tri(rows1, t));
-        MVOSR_TSTAMP(2);
-        // the selection sweep over this tile's rows of tri2 (:225-240)
-        auto select_row = [&](const TriIds q) {
-            if (!row_ok(q)) { bad = 1; return; }
-            const double2 a0 = ringA[q.a & M], a1 = ringA[q.b & M], a2 = ringA[q.c & M];
-            const double2 g0_ = ringB[q.a & M], g1_ = ringB[q.b & M], g2_ = ringB[q.c & M];
-            used[q.a & M] = 1; used[q.b & M] = 1; used[q.c & M] = 1;        // (every writer stores the same value)
-            // :238.  3h instead of h: the keys, their maxima and the level all scale by three, the comparisons of the tail are
-            // the same outside the guard band (as in the LDS-resident product kernel), and no triangle pays the division
-            const double h = (g0_.y + g1_.y) + g2_.y;
-            const int r = classify_triangle<false>(g0_.x, g0_.y, a0.y, g1_.x, g1_.y, a1.y, g2_.x, g2_.y, a2.y, h, a.pt,
-                                                   nullptr, nullptr, nullptr, 0);
-            if (r & 4) singular = 1;
-            if (r & 2) { hsum += h; hcnt += 1.0; sneg |= h < 0.0; spos |= h > 0.0; }             // :240
-            if (r & 1) {
-                ++npitch;
-                if (h == h) {
-                    const unsigned long long key = height_key64(h);
-                    atomicMax(&ringH[q.a & M], key); atomicMax(&ringH[q.b & M], key); atomicMax(&ringH[q.c & M], key);
-                }
-            }
-        };
-#pragma unroll
-        for (int j = 0; j < kTileRows; ++j) { if (b2 + j * B + rid < e2) select_row(c2[j]); }
-        for (int t = b2 + kTileRows * B + rid; t < e2; t += B) select_row(load_tri(rows2, t));
-        MVOSR_TSTAMP(3);
-        __syncthreads();                               // every row that names a vertex of tile k has been processed
-        MVOSR_TSTAMP(4);
-        // tile k leaves the ring: final vote of its vertices (:166), candidates parked, tile k+2 takes the slot
+    // a tile leaves the ring: final vote of its vertices (:166), candidates parked
+    auto retire = [&](int t) {
+        const int sb = tile_slot(t);
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
             if (j * B + tid >= W) continue;
-            const int i = lo + j * B + tid, slot = i & M;
+            const int i = t * W + j * B + tid, slot = sb + j * B + tid;
             bool survivor = false, is_cand = false;
             double cy = 0.0, ch = 0.0;
             if (i < n) {
@@ -2130,12 +2066,101 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
             if (is_cand) { const int at = cand_base + cand_cnt + __popcll(mc & ((1ull << lane) - 1ull)); cand_h[at] = ch; cand_y[at] = cy; }
             cand_cnt += __popcll(mc);
         }
+    };
+    // ---- the walk over the tiles
+    for (int k = 0; k < ntiles; ++k) {
+        const int lo = k * W;
+        const int b1 = toff1[k], e1 = toff1[k + 1], b2 = toff2[k], e2 = toff2[k + 1];
+        const int sbk = tile_slot(k);
+        auto S = [&](int v) { return slot_at(sbk, v - lo); };            // (a checked row: 0 <= v - lo <= 2W - 1)
+        TriIds c1[kTileRows], c2[kTileRows];
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) { c1[j] = n1[j]; c2[j] = n2[j]; }
+        prefetch_rows(min(k + 1, ntiles - 1));
+        apply_pending(k + 1);                          // (tile k+1 entered the ring at the end of the last step)
+        // the vote over this tile's rows of tri1 (:151-167): vertices from the ring, 32-bit counters in the ring.
+        // Every row of the walk has its vertices in tiles k and k+1 (checked: anything else is not the promised layout).
+        auto row_ok = [&](const TriIds q) {
+            const unsigned far = max(max((unsigned)(q.a - lo), (unsigned)(q.b - lo)), (unsigned)(q.c - lo));
+            return far <= (unsigned)M && max(max(q.a, q.b), q.c) < n;
+        };
+        auto vote_row = [&](const TriIds q) {
+            if (!row_ok(q)) { bad = 1; return; }
+            const double2 p0 = ringA[S(q.a)], p1 = ringA[S(q.b)], p2 = ringA[S(q.c)];      // {v, z'}
+            const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
+            const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
+            const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
+            const VoteFlags vf = vote_flags(pa, pb, pc, fixed);
+            atomicAdd(&ringC[(S(q.a)) * kSubC], vf.f0 ? -1 : 1);
+            atomicAdd(&ringC[(S(q.b)) * kSubC], vf.f1 ? -1 : 1);
+            atomicAdd(&ringC[(S(q.c)) * kSubC], vf.f2 ? -1 : 1);
+        };
+        {
+            // the prefetched rows: every ring read first (the compiler cannot move the reads of one row across the LDS
+            // atomics of another, and issued together their latencies overlap), then the tests and the atomics
+            double2 vp[kTileRows][3];
+            bool ok[kTileRows];
+#pragma unroll
+            for (int j = 0; j < kTileRows; ++j) {
+                const TriIds q = c1[j];
+                const bool live = b1 + j * B + rid < e1;
+                ok[j] = live && row_ok(q);
+                if (live && !ok[j]) bad = 1;
+                if (ok[j]) { vp[j][0] = ringA[S(q.a)]; vp[j][1] = ringA[S(q.b)]; vp[j][2] = ringA[S(q.c)]; }      // {v, z'}
+            }
+#pragma unroll
+            for (int j = 0; j < kTileRows; ++j) {
+                if (!ok[j]) continue;
+                const TriIds q = c1[j];
+                const double2 p0 = vp[j][0], p1 = vp[j][1], p2 = vp[j][2];
+                const bool pa = (p0.x - p1.x) * (p0.y - p1.y) > 0.0;       // :107,:110
+                const bool pb = (p0.x - p2.x) * (p0.y - p2.y) > 0.0;       // :108,:113  (marks vertices 0 and 1, as the reference does)
+                const bool pc = (p1.x - p2.x) * (p1.y - p2.y) > 0.0;       // :109,:116
+                const VoteFlags vf = vote_flags(pa, pb, pc, fixed);
+                atomicAdd(&ringC[(S(q.a)) * kSubC], vf.f0 ? -1 : 1);
+                atomicAdd(&ringC[(S(q.b)) * kSubC], vf.f1 ? -1 : 1);
+                atomicAdd(&ringC[(S(q.c)) * kSubC], vf.f2 ? -1 : 1);
+            }
+        }
+        for (int t = b1 + kTileRows * B + rid; t < e1; t += B) vote_row(load_tri(rows1, t));
+        MVOSR_TSTAMP(2);
+        // the selection sweep over this tile's rows of tri2 (:225-240)
+        auto select_row = [&](const TriIds q) {
+            if (!row_ok(q)) { bad = 1; return; }
+            const double2 a0 = ringA[S(q.a)], a1 = ringA[S(q.b)], a2 = ringA[S(q.c)];
+            const double2 g0_ = ringB[S(q.a)], g1_ = ringB[S(q.b)], g2_ = ringB[S(q.c)];
+            used[S(q.a)] = 1; used[S(q.b)] = 1; used[S(q.c)] = 1;        // (every writer stores the same value)
+            // :238.  3h instead of h: the keys, their maxima and the level all scale by three, the comparisons of the tail are
+            // the same outside the guard band (as in the LDS-resident product kernel), and no triangle pays the division
+            const double h = (g0_.y + g1_.y) + g2_.y;
+            const int r = classify_triangle<false>(g0_.x, g0_.y, a0.y, g1_.x, g1_.y, a1.y, g2_.x, g2_.y, a2.y, h, a.pt,
+                                                   nullptr, nullptr, nullptr, 0);
+            if (r & 4) singular = 1;
+            if (r & 2) { hsum += h; hcnt += 1.0; sneg |= h < 0.0; spos |= h > 0.0; }             // :240
+            if (r & 1) {
+                ++npitch;
+                if (h == h) {
+                    const unsigned long long key = height_key64(h);
+                    atomicMax(&ringH[S(q.a)], key); atomicMax(&ringH[S(q.b)], key); atomicMax(&ringH[S(q.c)], key);
+                }
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) { if (b2 + j * B + rid < e2) select_row(c2[j]); }
+        for (int t = b2 + kTileRows * B + rid; t < e2; t += B) select_row(load_tri(rows2, t));
+        MVOSR_TSTAMP(3);
+        if constexpr (kRing == 2) {
+            __syncthreads();                           // every row that names a vertex of tile k has been processed
+            MVOSR_TSTAMP(4);
+            retire(k);                                 // tile k+2 takes the slot
+        } else if (k > 0) retire(k - 1);               // (final since the barrier that ended the last step; tile k+2 takes ITS slot)
         tile_store(k + 2);
         tile_load(k + 3);
         MVOSR_TSTAMP(5);
         __syncthreads();
         MVOSR_TSTAMP(6);
     }
+    if constexpr (kRing == 3) retire(ntiles - 1);
 
     block_sum2<DW>(hsum, hcnt, red + R_SEL_H * 2 * DW);
     {
