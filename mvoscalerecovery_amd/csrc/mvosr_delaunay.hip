@@ -52,6 +52,10 @@ constexpr int kDtBlock = kDtWaves * kWave;
 #define MVOSR_DT_PER_CELL 1.5
 #endif
 constexpr int kDtR = MVOSR_DT_R;         // a point's candidates: the (2R+1)^2 cell block around its cell
+#ifndef MVOSR_DT_COLOUR
+#define MVOSR_DT_COLOUR 1
+#endif
+constexpr bool kDtColour = MVOSR_DT_COLOUR != 0;    // points taken colour by colour of their cells ((x & 1, y & 1)): see the kernel
 constexpr double kDtPerCell = MVOSR_DT_PER_CELL;   // target points per cell (measured trade-off: profiles/micro/dt_proto.py)
 constexpr int kDtMaxCells = 4096;
 #ifndef MVOSR_DT_LANE_ROWS
@@ -397,9 +401,10 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     double *red = reinterpret_cast<double *>(small + L.red);
     int *misc = reinterpret_cast<int *>(small + L.misc);
     const size_t hint_pts = (size_t)((a.max_pts + 7) & ~7);
-    uint32_t *hints = (kDtHintsOn<GLOBAL> && a.hints) ? a.hints + (size_t)f * ((size_t)(kDtHintK + 2) * hint_pts) : nullptr;
+    uint32_t *hints = (kDtHintsOn<GLOBAL> && a.hints) ? a.hints + (size_t)f * ((size_t)(kDtHintK + 3) * hint_pts) : nullptr;
     uint32_t *start = hints ? hints + (size_t)(kDtHintK + 1) * hint_pts : nullptr;               // one known triangle per point: its star starts there
     uint32_t *inv = (hints && a.seed_tri) ? hints + (size_t)kDtHintK * hint_pts : nullptr;       // position in u/v -> sorted index (seeds only)
+    uint32_t *order = (hints && kDtColour && !GLOBAL) ? hints + (size_t)(kDtHintK + 2) * hint_pts : nullptr; // the order in which the points are taken
     if (hints) {
         // all ones = empty.  (One hipMemsetAsync over the launch's caches instead held the HOST for the GPU's queue above
         // 256 MB: the chunk loop around this kernel ran at 146 k instead of 228 k frames/s.)
@@ -520,6 +525,38 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
         }
     }
     __syncthreads();
+    if (order) {
+        // The points are taken cell colour by cell colour — (x & 1, y & 1): all even/even cells first, and so on.  In the
+        // sorted order 512 consecutive points are in flight at once, a band of five or six cell rows in which every point's
+        // neighbours are being worked on at the same moment: the triangle one of them finds cannot be handed to the others
+        // in time (1.67 searches per triangle).  Cells of one colour do not touch: most of a point's neighbours are either
+        // done — their triangles wait in its hint cache — or not started.  +5.5 % at 2000 points, nothing at 600-1200; not in the
+        // global-memory variant, whose point reads want the sorted order's locality (20 000 points: 26.6 k -> 16.7 k sets/s).
+        // (and the points of one cell — neighbours, as a rule — in different rounds: class = 4 * min(position in the cell, 3) + colour)
+        int *ccnt = reinterpret_cast<int *>(red);            // 16 counters (the reductions' scratch is free here)
+        if (tid < 16) ccnt[tid] = 0;
+        __syncthreads();
+        for (int c = tid; c < ncell; c += kDtBlock) {
+            const int cx = c % G.gx, cy = c / G.gx, col = (cx & 1) | ((cy & 1) << 1);
+            const int k = (int)cs[c] - (c ? (int)cs[c - 1] : 0);
+            for (int r = 0; r < min(k, 4); ++r) atomicAdd(&ccnt[4 * r + col], r < 3 ? 1 : k - 3);
+        }
+        __syncthreads();
+        int mine = tid < 16 ? ccnt[tid] : 0, base = 0;
+        __syncthreads();
+        for (int q = 0; q < 16; ++q) { const int v = __shfl(mine, q); if (q < tid) base += v; }
+        if (tid < 16) ccnt[tid] = base;
+        __syncthreads();
+        for (int c = tid; c < ncell; c += kDtBlock) {
+            const int cx = c % G.gx, cy = c / G.gx, col = (cx & 1) | ((cy & 1) << 1);
+            const int b = c ? (int)cs[c - 1] : 0, e = (int)cs[c];
+            for (int j = b; j < e; ++j) {
+                const int at = atomicAdd(&ccnt[4 * min(j - b, 3) + col], 1);
+                __hip_atomic_store(order + at, (uint32_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
     if (inv) {
         // the seeds' corners into the hint caches (orientation from the points: the rows are in canonical, not in
         // counter-clockwise order)
@@ -562,7 +599,10 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
         // Points are taken from both ends of the sorted array towards its middle: the first and the last cell rows hold
         // the hull and the points next to it, whose stars need wide searches — the long tasks start first, the short
         // ones fill the tail.  (All boundary cells' points first — an order array built per frame — measured the same.)
-        auto point_of = [&](int idx) { return (idx & 1) ? n - 1 - (idx >> 1) : (idx >> 1); };
+        auto point_of = [&](int idx) {
+            if (order) return (int)__hip_atomic_load(order + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return (idx & 1) ? n - 1 - (idx >> 1) : (idx >> 1);
+        };
         int i = tid < n ? point_of(tid) : -1;       // (misc[DM_NEXT] starts at kDtBlock)
         bool exhausted = tid >= n;
         int nn_level = 0;                           // nearest-neighbour search: 3x3 block, then 5x5, then the frame
@@ -716,6 +756,9 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
             if (!m1) {
                 // the nearest neighbour is a Delaunay neighbour — certified when its disc lies within what was searched
                 q0 = A.b1;
+#ifdef MVOSR_STAMPS
+                atomicAdd(&misc[63], 1);            // a nearest-neighbour search completed (one widening level)
+#endif
                 if (q0 >= 0 && A.n1 == 0.0) degenerate |= DT_WHY_DUP;
                 if (q0 >= 0 && (wide || dt_inside(dt_disc_box(G, p.x, p.y, A.n1), box))) {
                     iq = q0; mode = 1; nn_level = 0;
@@ -767,6 +810,11 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
                     int chain = 0;
 #ifdef MVOSR_STAMPS
                     ++n_by_search;
+                    if (hints && sgn > 0.0) {       // did the hint arrive while the search ran?
+                        const uint32_t h_ = __hip_atomic_load(hints + (size_t)i * kDtHintK + ((uint32_t)iq % kDtHintK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((h_ >> 16) == (uint32_t)iq) atomicAdd(&misc[61], 1);
+                        else if (h_ != 0xFFFFFFFFu) atomicAdd(&misc[62], 1);      // the slot holds another neighbour's hint
+                    }
 #endif
                     for (;;) {
                         if (++deg > kDtLaneDeg) state = 2;
@@ -839,6 +887,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     DT_STAMP(3);
 #ifdef MVOSR_STAMPS
     DT_NOTE(10, misc[48]); DT_NOTE(11, misc[49]); DT_NOTE(12, misc[50]); DT_NOTE(13, misc[51]);
+    DT_NOTE(26, misc[61]); DT_NOTE(27, misc[62]); DT_NOTE(28, misc[63]);
     if (tid == 0 && a.stamps) for (int k = 52; k < 61; ++k) a.stamps[32 * f + 16 + (k - 52)] = (unsigned long long)misc[k];
 #endif
 
@@ -1036,7 +1085,7 @@ extern "C" int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, con
         // frames beyond the LDS capacity: the big arrays in the context's workspace, one slice per frame
         void *ws = nullptr;
         const size_t big_bytes = ((size_t)n_frames * L.big + 255) & ~(size_t)255;
-        const size_t hint_bytes = kDtHintsOn<true> ? (size_t)n_frames * (size_t)(kDtHintK + 2) * (size_t)((max_pts + 7) & ~7) * sizeof(uint32_t) : 0;
+        const size_t hint_bytes = kDtHintsOn<true> ? (size_t)n_frames * (size_t)(kDtHintK + 3) * (size_t)((max_pts + 7) & ~7) * sizeof(uint32_t) : 0;
         if ((rc = ctx_workspace_bytes(ctx, big_bytes + hint_bytes, &ws))) return rc;
         a.ws = reinterpret_cast<char *>(ws);
         if (hint_bytes) a.hints = reinterpret_cast<uint32_t *>(a.ws + big_bytes);
@@ -1051,7 +1100,7 @@ extern "C" int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, con
     if (kDtHintK > 0) {
         // the stars' hint caches (see kDtHintK): 4 * (kDtHintK + 1) bytes per point
         void *ws = nullptr;
-        const size_t bytes = (size_t)n_frames * (size_t)(kDtHintK + 2) * (size_t)((max_pts + 7) & ~7) * sizeof(uint32_t);
+        const size_t bytes = (size_t)n_frames * (size_t)(kDtHintK + 3) * (size_t)((max_pts + 7) & ~7) * sizeof(uint32_t);
         if ((rc = ctx_workspace_bytes(ctx, bytes, &ws))) return rc;
         a.hints = reinterpret_cast<uint32_t *>(ws);              // (every workgroup empties its own frame's caches: no memset of the whole block)
     }

@@ -54,3 +54,4 @@ print("  hard points: median %.0f   triangles taken after a search: %.0f per set
 print("  steps per point: max %.0f (mean over sets); points with <=6 / <=10 / <=16 / <=28 / more steps: %s" % (np.mean(s[:, 16]), " / ".join("%.0f" % np.mean(s[:, 17 + k]) for k in range(5))))
 print("  open stars (hull vertices): %.0f per set, %.1f steps each; closed stars: %.1f steps each" % (np.mean(s[:, 24]), np.mean(s[:, 22]) / max(np.mean(s[:, 24]), 1), np.mean(s[:, 23]) / max(n - np.mean(s[:, 24]), 1)))
 print("  scan steps per lane: %.1f   lanes with a point in a step: %.1f %%" % (np.mean(s[:, 12]) / 512.0, 100.0 * np.mean(s[:, 13]) / max(np.mean(s[:, 12]), 1)))
+print("  searches whose hint had arrived by the time they finished: %.0f per set; whose slot held another neighbour's hint: %.0f; nearest-neighbour searches completed: %.0f" % (np.mean(s[:, 26]), np.mean(s[:, 27]), np.mean(s[:, 28])))

@@ -8,11 +8,34 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvoscalerecovery_amd import _lib, packing
 from scipy.spatial import Delaunay
 
+from fractions import Fraction as Fr
+
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+
+
+def empty_circle_violations(p, tris, verts):
+    """Exact rational arithmetic: how many of `tris` have one of `verts` strictly inside their circumcircle."""
+    bad_ = 0
+    for t in tris:
+        a_, b_, c_ = ([Fr(float(p[i][0])), Fr(float(p[i][1]))] for i in t)
+        if (b_[0] - a_[0]) * (c_[1] - a_[1]) - (b_[1] - a_[1]) * (c_[0] - a_[0]) < 0:
+            a_, b_ = b_, a_
+        for v in verts:
+            if v in t:
+                continue
+            d = [Fr(float(p[v][0])), Fr(float(p[v][1]))]
+            ax, ay, bx, by, cx, cy = a_[0] - d[0], a_[1] - d[1], b_[0] - d[0], b_[1] - d[1], c_[0] - d[0], c_[1] - d[1]
+            det = (ax * ax + ay * ay) * (bx * cy - cx * by) - (bx * bx + by * by) * (ax * cy - cx * ay) + (cx * cx + cy * cy) * (ax * by - bx * ay)
+            if det > 0:
+                bad_ += 1
+                break
+    return bad_
+
+
 ctx = _lib.default_context(0)
 lib = ctx.lib
 rng = np.random.default_rng(31337)
-total = bad = declined = bad2 = declined2 = 0
+total = bad = declined = bad2 = declined2 = qhull_inexact = device_wrong = qhull_inexact2 = device_wrong2 = 0
 for rnd in range(rounds):
     sets = []
     for k in range(160):
@@ -54,7 +77,16 @@ for rnd in range(rounds):
             ref = packing.canonical_rows(Delaunay(p).simplices)
             got = t1[a:a + n1[f]]
             gs, rs = set(map(tuple, got.tolist())), set(map(tuple, ref.tolist()))
-            print("MISMATCH first n=%d kind=%d rows %d vs %d; only GPU %d, only SciPy %d" % (len(p), f % 6, len(got), len(ref), len(gs - rs), len(rs - gs)))
+            # who is right?  the rows only one side has, against the vertices they involve, in exact arithmetic
+            og, orf = sorted(gs - rs), sorted(rs - gs)
+            verts = sorted(set(v for t in og + orf for v in t))
+            vg, vr = empty_circle_violations(p, og, verts), empty_circle_violations(p, orf, verts)
+            if vg == 0 and vr > 0:
+                qhull_inexact += 1
+            else:
+                device_wrong += 1
+            print("MISMATCH first n=%d kind=%d rows %d vs %d; only GPU %d (violating the empty circle, exactly: %d), only SciPy %d (%d)"
+                  % (len(p), f % 6, len(got), len(ref), len(og), vg, len(orf), vr))
             os.makedirs("gpurun_out", exist_ok=True)
             np.savez("gpurun_out/dt_mismatch_%d.npz" % bad, pts=p, gpu=got, ref=ref)
         q = p[keep[off[f]:off[f] + cnt[f]] >= 0]
@@ -62,7 +94,20 @@ for rnd in range(rounds):
             declined2 += 1
         elif len(q) >= 3 and not np.array_equal(t2[a:a + n2[f]], packing.canonical_rows(Delaunay(q).simplices)):
             bad2 += 1
-            print("MISMATCH second n=%d kept=%d kind=%d" % (len(p), len(q), f % 6))
+            ref = packing.canonical_rows(Delaunay(q).simplices)
+            idx = np.flatnonzero(keep[off[f]:off[f] + cnt[f]] >= 0)              # the kernel's rows name the points of the full set
+            rank = np.full(len(p), -1); rank[idx] = np.arange(len(idx))
+            got = rank[t2[a:a + n2[f]]] if t2[a:a + n2[f]].max(initial=0) >= len(q) else t2[a:a + n2[f]]
+            gs, rs = set(map(tuple, np.sort(got, 1).tolist())), set(map(tuple, np.sort(ref, 1).tolist()))
+            og, orf = sorted(gs - rs), sorted(rs - gs)
+            verts = sorted(set(v for t in og + orf for v in t))
+            vg, vr = empty_circle_violations(q, og, verts), empty_circle_violations(q, orf, verts)
+            if vg == 0 and vr > 0:
+                qhull_inexact2 += 1
+            else:
+                device_wrong2 += 1
+            print("MISMATCH second n=%d kept=%d kind=%d; only GPU %d (violating, exactly: %d), only SciPy %d (%d)" % (len(p), len(q), f % 6, len(og), vg, len(orf), vr))
     for b in (d_u, d_v, d_off, d_cnt, d_toff, d_keep, tri1, tri2, c1, c2, s1, s2):
         b.free()
-print("sets %d: first triangulation declined %d, mismatches %d; seeded second declined %d, mismatches %d" % (total, declined, bad, declined2, bad2))
+print("sets %d: first triangulation declined %d, mismatches %d (SciPy's rows violate the empty circle in exact arithmetic, the device's do not: %d; otherwise: %d); "
+      "seeded second declined %d, mismatches %d (%d; %d)" % (total, declined, bad, qhull_inexact, device_wrong, declined2, bad2, qhull_inexact2, device_wrong2))
