@@ -447,8 +447,8 @@ enum mvosr_dt_status {
  * (optional) = the number of points triangulated (what mvosr_batch.n2_expected wants).  Rows are written at
  * tri + 3*tri_off[f] (room for 2 * points rows), tri_cnt[f] says how many; status[f] is an mvosr_dt_status (a declined
  * frame has tri_cnt 0 and the reason in the status' bits 8..).  max_pts = max(pts_cnt) <= mvosr_delaunay_max_points();
- * The context's workspace (grow-only, hipMalloc when it grows) holds 72 bytes per point of the LAUNCH — n_frames * max_pts
- * points: the stars' hint caches — and ~33 more above mvosr_delaunay_lds_points(): callers with very many
+ * The context's workspace (grow-only, hipMalloc when it grows) holds 76 bytes per point of the LAUNCH — n_frames * max_pts
+ * points: the stars' hint caches and the order the points are taken in — and ~33 more above mvosr_delaunay_lds_points(): callers with very many
  * frames launch in chunks (the host class uses 2048 frames).
  */
 int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
