@@ -4,7 +4,7 @@
 #   AB_LIBS="col0 nn0" bash profiles/ab_dt_order.sh
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
-for a in "--points 2000" "--points 600 --sets 8192" "--points 1200 --sets 4096"; do
+for a in "--points 2000" "--points 2000 --seeded" "--points 600 --sets 8192" "--points 600 --sets 8192 --seeded"; do
   echo "$a"
   for rep in 1 2; do
     for l in prod ${AB_LIBS:-col0}; do
