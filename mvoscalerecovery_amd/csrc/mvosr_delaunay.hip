@@ -45,6 +45,10 @@ namespace mvosr {
 
 constexpr int kDtWaves = 8;
 constexpr int kDtBlock = kDtWaves * kWave;
+#ifndef MVOSR_DT_SMALL_LADDER
+#define MVOSR_DT_SMALL_LADDER 1
+#endif
+constexpr bool kDtSmallLadder = MVOSR_DT_SMALL_LADDER != 0;   // 2- and 4-wavefront instantiations for small frames (see the launcher)
 #ifndef MVOSR_DT_R
 #define MVOSR_DT_R 2
 #endif
@@ -160,7 +164,7 @@ __host__ __device__ inline int dt_cell_cap(int max_pts, bool global) {
     const int cap = global ? kDtMaxCellsGlobal : kDtMaxCells;
     return c > cap ? cap : c;
 }
-__host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false) {
+__host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false, int waves = kDtWaves) {
     DtPlan p;
     const uint32_t npad = (uint32_t)((max_pts + 7) & ~7);
     p.max_cells = dt_cell_cap(max_pts, global);
@@ -174,8 +178,8 @@ __host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false) {
     p.big = (p.arena + 4u * (uint32_t)p.arena_cap + 255u) & ~255u;
     p.hard = p.big;                                      // u16 sorted indices
     p.wrows = p.hard + 2u * kDtHardCap;                  // u32 [groups of 16 lanes][kDtWaveRows]
-    p.red = p.wrows + 4u * (kDtBlock / 16) * kDtWaveRows;    // doubles: block reductions
-    p.misc = p.red + 8u * 4u * kDtWaves;
+    p.red = p.wrows + 4u * (uint32_t)(waves * kWave / 16) * kDtWaveRows;    // doubles: block reductions
+    p.misc = p.red + 8u * 4u * (uint32_t)waves;
     p.total = p.misc + 4u * 64u;
     return p;
 }
@@ -382,13 +386,14 @@ __device__ __forceinline__ int dt_incl_scan(int v) {
     return v;
 }
 
-template <bool GLOBAL>
-__global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
+template <bool GLOBAL, int WAVES = kDtWaves>
+__global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs a) {
+    constexpr int BLOCK = WAVES * kWave;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = blockIdx.x;
     const int n_in = a.pts_cnt[f];
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    const DtPlan L = dt_plan(a.max_pts, GLOBAL);
+    const DtPlan L = dt_plan(a.max_pts, GLOBAL, WAVES);
     char *big = GLOBAL ? a.ws + (size_t)f * L.big : smem;                  // the frame's big arrays
     char *small = GLOBAL ? smem - L.big : smem;                            // (the plan's offsets of the small ones start at L.big)
     double2 *S = reinterpret_cast<double2 *>(big + L.S);
@@ -410,9 +415,9 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
         // 256 MB: the chunk loop around this kernel ran at 146 k instead of 228 k frames/s.)
         const int n_words = kDtHintK * min(n_in, (int)hint_pts);
         uint4 ones; ones.x = ones.y = ones.z = ones.w = 0xFFFFFFFFu;
-        for (int k = tid; k < (n_words + 3) / 4; k += kDtBlock) reinterpret_cast<uint4 *>(hints)[k] = ones;
-        if (inv) for (int k = tid; k < min(n_in, (int)hint_pts); k += kDtBlock) inv[k] = 0xFFFFFFFFu;
-        for (int k = tid; k < min(n_in, (int)hint_pts); k += kDtBlock) start[k] = 0xFFFFFFFFu;
+        for (int k = tid; k < (n_words + 3) / 4; k += BLOCK) reinterpret_cast<uint4 *>(hints)[k] = ones;
+        if (inv) for (int k = tid; k < min(n_in, (int)hint_pts); k += BLOCK) inv[k] = 0xFFFFFFFFu;
+        for (int k = tid; k < min(n_in, (int)hint_pts); k += BLOCK) start[k] = 0xFFFFFFFFu;
     }
 
     auto decline = [&](int why, int n_used) {
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     const int32_t *gk = a.keep ? a.keep + off : nullptr;
 
     // ---- pass 0: survivors per wavefront slice (ids are ranks among the survivors, in order), bounding box
-    const int per = ((n_in + kDtBlock - 1) / kDtBlock) * kWave;          // slice of a wavefront: a multiple of 64
+    const int per = ((n_in + BLOCK - 1) / BLOCK) * kWave;          // slice of a wavefront: a multiple of 64
     const int s_begin = w * per, s_end = min(n_in, s_begin + per);
     double lo_u = INFINITY, hi_u = -INFINITY, lo_v = INFINITY, hi_v = -INFINITY;
     int wcnt = 0;
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     {
         const double a0 = dt_wave_min(lo_u), a1 = dt_wave_min(-hi_u), a2 = dt_wave_min(lo_v), a3 = dt_wave_min(-hi_v);
         if (lane == 0) { red[4 * w] = a0; red[4 * w + 1] = a1; red[4 * w + 2] = a2; red[4 * w + 3] = a3; misc[DM_WCNT + w] = wcnt; }
-        if (tid < 8) misc[tid] = tid == DM_NEXT ? kDtBlock : 0;
+        if (tid < 8) misc[tid] = tid == DM_NEXT ? BLOCK : 0;
 #ifdef MVOSR_STAMPS
         if (tid >= 48 && tid < 64) misc[tid] = 0;
 #endif
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     int n = 0, rank_base = 0;
     lo_u = INFINITY; hi_u = INFINITY; lo_v = INFINITY; hi_v = INFINITY;
 #pragma unroll
-    for (int i = 0; i < kDtWaves; ++i) {
+    for (int i = 0; i < WAVES; ++i) {
         const int c = misc[DM_WCNT + i];
         if (i < w) rank_base += c;
         n += c;
@@ -478,8 +483,8 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     }
     const int ncell = G.gx * G.gy;
     DT_STAMP(1);
-    for (int c = tid; c <= ncell; c += kDtBlock) cs[c] = 0u;
-    for (int i = tid; i < ((n + 1) >> 1); i += kDtBlock) reinterpret_cast<uint32_t *>(od)[i] = 0u;
+    for (int c = tid; c <= ncell; c += BLOCK) cs[c] = 0u;
+    for (int i = tid; i < ((n + 1) >> 1); i += BLOCK) reinterpret_cast<uint32_t *>(od)[i] = 0u;
     __syncthreads();
 
     // ---- pass 1: points per cell
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     __syncthreads();
     // exclusive scan over the cells (cs[c] = start of cell c; pass 2 advances it to the cell's end)
     {
-        const int cper = (ncell + kDtBlock - 1) / kDtBlock;
+        const int cper = (ncell + BLOCK - 1) / BLOCK;
         const int c0 = tid * cper, c1 = min(ncell, c0 + cper);
         int mine = 0;
         for (int c = c0; c < c1; ++c) mine += (int)cs[c];
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
         __syncthreads();
         int base = 0;
 #pragma unroll
-        for (int i = 0; i < kDtWaves; ++i) if (i < w) base += misc[DM_WSUM + i];
+        for (int i = 0; i < WAVES; ++i) if (i < w) base += misc[DM_WSUM + i];
         int at = base + incl - mine;
         for (int c = c0; c < c1; ++c) { const int k = (int)cs[c]; cs[c] = (uint32_t)at; at += k; }
     }
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
         int *ccnt = reinterpret_cast<int *>(red);            // 16 counters (the reductions' scratch is free here)
         if (tid < 16) ccnt[tid] = 0;
         __syncthreads();
-        for (int c = tid; c < ncell; c += kDtBlock) {
+        for (int c = tid; c < ncell; c += BLOCK) {
             const int cx = c % G.gx, cy = c / G.gx, col = (cx & 1) | ((cy & 1) << 1);
             const int k = (int)cs[c] - (c ? (int)cs[c - 1] : 0);
             for (int r = 0; r < min(k, 4); ++r) atomicAdd(&ccnt[4 * r + col], r < 3 ? 1 : k - 3);
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
         for (int q = 0; q < 16; ++q) { const int v = __shfl(mine, q); if (q < tid) base += v; }
         if (tid < 16) ccnt[tid] = base;
         __syncthreads();
-        for (int c = tid; c < ncell; c += kDtBlock) {
+        for (int c = tid; c < ncell; c += BLOCK) {
             const int cx = c % G.gx, cy = c / G.gx, col = (cx & 1) | ((cy & 1) << 1);
             const int b = c ? (int)cs[c - 1] : 0, e = (int)cs[c];
             for (int j = b; j < e; ++j) {
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
         // counter-clockwise order)
         const int32_t *st = a.seed_tri + 3 * a.seed_off[f];
         const int ns = a.seed_cnt[f];
-        for (int r = tid; r < ns; r += kDtBlock) {
+        for (int r = tid; r < ns; r += BLOCK) {
             const int ra = st[3 * r], rb = st[3 * r + 1], rc = st[3 * r + 2];
             if ((unsigned)ra >= (unsigned)n_in || (unsigned)rb >= (unsigned)n_in || (unsigned)rc >= (unsigned)n_in) continue;
             const uint32_t pa = __hip_atomic_load(inv + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
             if (order) return (int)__hip_atomic_load(order + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return (idx & 1) ? n - 1 - (idx >> 1) : (idx >> 1);
         };
-        int i = tid < n ? point_of(tid) : -1;       // (misc[DM_NEXT] starts at kDtBlock)
+        int i = tid < n ? point_of(tid) : -1;       // (misc[DM_NEXT] starts at BLOCK)
         bool exhausted = tid >= n;
         int nn_level = 0;                           // nearest-neighbour search: 3x3 block, then 5x5, then the frame
         int mode = 0, oi = 0, q0 = -1, iq = -1, deg = 0, nown = 0, open = 0;
@@ -894,7 +899,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
     // The two passes below work in GROUPS of 16 lanes (a DPP row): a completion has a few dozen candidates at most, so
     // four of them share a wavefront.  Lanes of a group stay together; groups diverge freely.
     const int gl = lane & (kDtGroup - 1), grp = tid / kDtGroup;
-    constexpr int kGroups = kDtBlock / kDtGroup;
+    constexpr int kGroups = BLOCK / kDtGroup;
     __syncthreads();
     DT_STAMP(4);
 
@@ -993,7 +998,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
 
     // ---- rows in point order: block prefix over the points' row counts; Euler's relation
     {
-        const int pper = (n + kDtBlock - 1) / kDtBlock;
+        const int pper = (n + BLOCK - 1) / BLOCK;
         const int o0 = tid * pper, o1 = min(n, o0 + pper);
         int mine = 0, sdeg = 0, hull = 0;
         for (int o = o0; o < o1; ++o) { const int d = od[o]; mine += d & 63; sdeg += (d >> 6) & 63; hull += (d >> 15) & 1; }
@@ -1004,7 +1009,7 @@ __global__ __launch_bounds__(kDtBlock, 4) void delaunay_kernel(const DtArgs a) {
         __syncthreads();
         int base = 0, total = 0, tdeg = 0, thull = 0;
 #pragma unroll
-        for (int i = 0; i < kDtWaves; ++i) {
+        for (int i = 0; i < WAVES; ++i) {
             const int c = misc[DM_WSUM + i];
             if (i < w) base += c;
             total += c; tdeg += misc[DM_WSUM2 + i]; thull += misc[DM_WSUM3 + i];
@@ -1095,7 +1100,20 @@ extern "C" int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, con
         hipLaunchKernelGGL(delaunay_kernel<true>, dim3((unsigned)n_frames), dim3(kDtBlock), lds, ctx_stream(ctx), a);
         return check_launch("delaunay_kernel (global-memory variant)");
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(delaunay_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // Small frames: fewer wavefronts per frame and more frames per CU.  A 600-point set gives 512 lanes little more than one
+    // point each and its length is that of its longest stars (the hull's); with 256 lanes the same critical path carries
+    // twice the points per lane.  Four wavefronts while THREE frames' arrays fit a CU's LDS (12 wavefronts per CU instead of
+    // 16: equal at 1500 points, +4 % at 1200, +20-50 % below 1000 — and a ragged batch is sized by its largest frame), two
+    // while eight fit (up to ~500 points: +20-50 % over four).
+    int waves = kDtWaves;
+    if (kDtSmallLadder) {
+        if (8u * dt_plan(max_pts, false, 2).total <= 160u * 1024u) waves = 2;
+        else if (3u * dt_plan(max_pts, false, 4).total <= 160u * 1024u) waves = 4;
+    }
+    lds = dt_plan(max_pts, false, waves).total;
+    const void *kfn = waves == 2 ? reinterpret_cast<const void *>(delaunay_kernel<false, 2>)
+                    : waves == 4 ? reinterpret_cast<const void *>(delaunay_kernel<false, 4>) : reinterpret_cast<const void *>(delaunay_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_hip_error("hipFuncSetAttribute(delaunay_kernel)", e);
     if (kDtHintK > 0) {
         // the stars' hint caches (see kDtHintK): 4 * (kDtHintK + 1) bytes per point
@@ -1104,6 +1122,8 @@ extern "C" int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, con
         if ((rc = ctx_workspace_bytes(ctx, bytes, &ws))) return rc;
         a.hints = reinterpret_cast<uint32_t *>(ws);              // (every workgroup empties its own frame's caches: no memset of the whole block)
     }
-    hipLaunchKernelGGL(delaunay_kernel<false>, dim3((unsigned)n_frames), dim3(kDtBlock), lds, ctx_stream(ctx), a);
+    if (waves == 2) hipLaunchKernelGGL((delaunay_kernel<false, 2>), dim3((unsigned)n_frames), dim3(2 * kWave), lds, ctx_stream(ctx), a);
+    else if (waves == 4) hipLaunchKernelGGL((delaunay_kernel<false, 4>), dim3((unsigned)n_frames), dim3(4 * kWave), lds, ctx_stream(ctx), a);
+    else hipLaunchKernelGGL(delaunay_kernel<false>, dim3((unsigned)n_frames), dim3(kDtBlock), lds, ctx_stream(ctx), a);
     return check_launch("delaunay_kernel");
 }

@@ -1,16 +1,19 @@
 #!/bin/bash
 # Same-box A/B of delaunay_kernel variants: the product library against libraries under profiles/ab
 # (profiles/ab_build.sh <tag> <flags>, ONLY=mvosr_delaunay), two alternating passes per size.
-#   AB_LIBS="col0 nn0" bash profiles/ab_dt_order.sh
+#   AB_LIBS="col0 nn0" [AB_SIZES="2000:4096 600:8192"] bash profiles/ab_dt_order.sh
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
-for a in "--points 2000" "--points 2000 --seeded" "--points 600 --sets 8192" "--points 600 --sets 8192 --seeded"; do
-  echo "$a"
-  for rep in 1 2; do
-    for l in prod ${AB_LIBS:-col0}; do
-      if [ $l = prod ]; then r=$(python profiles/bench_delaunay.py $a 2>&1 | tail -1)
-      else r=$(MVOSR_LIB_PATH=$R/profiles/ab/libmvosr_$l.so python profiles/bench_delaunay.py $a 2>&1 | tail -1); fi
-      echo "$l $(echo $r | python -c "import sys,json; print('%.0f' % json.loads(sys.stdin.read())['sets_per_s'])")"
+for sz in ${AB_SIZES:-2000:4096 600:8192}; do
+  for mode in "" "--seeded"; do
+    a="--points ${sz%%:*} --sets ${sz##*:} $mode"
+    echo "$a"
+    for rep in 1 2; do
+      for l in prod ${AB_LIBS:-col0}; do
+        if [ $l = prod ]; then r=$(python profiles/bench_delaunay.py $a 2>&1 | tail -1)
+        else r=$(MVOSR_LIB_PATH=$R/profiles/ab/libmvosr_$l.so python profiles/bench_delaunay.py $a 2>&1 | tail -1); fi
+        echo "$l $(echo $r | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f sets/s, declined %d' % (d['sets_per_s'], d['declined']))")"
+      done
     done
   done
 done

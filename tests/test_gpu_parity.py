@@ -424,6 +424,55 @@ def test_seeded_second_triangulation_equals_scipy_on_the_survivors(gpu):
                                            tri1.ptr, c2.ptr, None, s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr) != 0
 
 
+@pytest.mark.parametrize("n_max", [40, 470, 520, 1100, 1500, 1700])
+def test_delaunay_small_frame_variants(gpu, n_max):
+    """The launcher gives small frames fewer wavefronts (two while eight frames' arrays fit a CU's LDS — up to ~500 points —,
+    four while three fit — ~1550 —, eight above): ragged batches sized on either side of both limits, tiny and degenerate
+    frames among them, first and seeded second triangulation against SciPy."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import _lib, packing, synth
+    rng = np.random.default_rng(1000 + n_max)
+    sizes = [n_max] + [int(x) for x in rng.integers(3, n_max + 1, 37)] + [3, 4, 5, 2]
+    sets = [synth.synth_frame(i, m, base_seed=4321 + n_max)[1] for i, m in enumerate(sizes)]
+    sets.append(np.stack([np.arange(30.0), 3.0 * np.arange(30.0)], axis=1))              # collinear: declined
+    dup = sets[1].copy()
+    if len(dup) > 2:
+        dup[0] = dup[-1]
+    sets.append(dup)                                                                     # a duplicate point: declined
+    F = len(sets)
+    cnt = np.array([len(q) for q in sets], dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+    uv = np.concatenate(sets)
+    keep = np.where(rng.uniform(size=len(uv)) < 0.85, 1, -1).astype(np.int32)
+    d_u, d_v = gpu.to_device(np.ascontiguousarray(uv[:, 0])), gpu.to_device(np.ascontiguousarray(uv[:, 1]))
+    d_off, d_cnt, d_toff, d_keep = gpu.to_device(off), gpu.to_device(cnt), gpu.to_device(2 * off), gpu.to_device(keep)
+    rows = int(2 * cnt.sum())
+    tri1, tri2 = gpu.empty((rows, 3), np.int32), gpu.empty((rows, 3), np.int32)
+    c1, c2, s1, s2 = (gpu.zeros(F, np.int32) for _ in range(4))
+    m = int(cnt.max())
+    _lib.check(gpu.lib.mvosr_delaunay_batch(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, m, d_toff.ptr, tri1.ptr, c1.ptr, None, s1.ptr), "first")
+    _lib.check(gpu.lib.mvosr_delaunay_batch_seeded(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, m, d_toff.ptr, tri2.ptr, c2.ptr, None,
+                                                   s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr), "second")
+    t1, t2, n1, n2, h1, h2 = tri1.download(), tri2.download(), c1.download(), c2.download(), s1.download(), s2.download()
+    assert h1[F - 2] != 0 and h1[F - 1] != 0 and h1[F - 3] != 0            # collinear, duplicate, two points
+    ok = 0
+    for f, q in enumerate(sets[:F - 2]):
+        a = int(2 * off[f])
+        if len(q) >= 3 and h1[f] == 0:
+            assert np.array_equal(t1[a:a + n1[f]], packing.canonical_rows(Delaunay(q).simplices)), (n_max, f, len(q))
+            ok += 1
+        kq = q[keep[off[f]:off[f] + cnt[f]] >= 0]
+        if len(kq) >= 3 and h2[f] == 0:
+            try:
+                ref = packing.canonical_rows(Delaunay(kq).simplices)
+            except Exception:          # noqa: BLE001  (Qhull refuses a handful of collinear survivors)
+                continue
+            assert np.array_equal(t2[a:a + n2[f]], ref), (n_max, f, len(kq))
+    assert ok >= 30
+    for b in (d_u, d_v, d_off, d_cnt, d_toff, d_keep, tri1, tri2, c1, c2, s1, s2):
+        b.free()
+
+
 def test_fixed_vote_mode_kernels_equal_oracle(gpu):
     """check_triangle="fixed" (mvosr_params.vote_mode = MVOSR_VOTE_FIXED): the order-invariant vote through every kernel
     family (1/4/8/16 wavefronts per frame, the dense two-sweep and tiled kernels) against the oracle's fixed mode — and
