@@ -48,6 +48,7 @@ constexpr int kDtBlock = kDtWaves * kWave;
 #ifndef MVOSR_DT_SMALL_LADDER
 #define MVOSR_DT_SMALL_LADDER 1
 #endif
+constexpr int kDtLadderMinFrames = 512;      // two eight-wavefront frames on each of 256 CUs
 constexpr bool kDtSmallLadder = MVOSR_DT_SMALL_LADDER != 0;   // 2- and 4-wavefront instantiations for small frames (see the launcher)
 #ifndef MVOSR_DT_R
 #define MVOSR_DT_R 2
@@ -1105,8 +1106,10 @@ extern "C" int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, con
     // twice the points per lane.  Four wavefronts while THREE frames' arrays fit a CU's LDS (12 wavefronts per CU instead of
     // 16: equal at 1500 points, +4 % at 1200, +20-50 % below 1000 — and a ragged batch is sized by its largest frame), two
     // while eight fit (up to ~500 points: +20-50 % over four).
+    // A launch that cannot fill the GPU with eight-wavefront frames (a per-frame call: ONE frame) keeps all eight: there the
+    // lanes per frame are what shortens the call (900 points: 0.96 against 1.26 ms per frame call).
     int waves = kDtWaves;
-    if (kDtSmallLadder) {
+    if (kDtSmallLadder && n_frames >= kDtLadderMinFrames) {
         if (8u * dt_plan(max_pts, false, 2).total <= 160u * 1024u) waves = 2;
         else if (3u * dt_plan(max_pts, false, 4).total <= 160u * 1024u) waves = 4;
     }

@@ -15,17 +15,26 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--points", type=int, default=2000)
 ap.add_argument("--sets", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--ragged", default="", help="lo:hi — sets of lo..hi points (uniform), the launch sized by the largest: the shape of a chunk of KITTI-sized frames")
 ap.add_argument("--seeded", action="store_true", help="time the SECOND triangulation: 85 %% of the points kept, seeded with the first one's rows")
 args = ap.parse_args()
 n, F = args.points, args.sets
 ctx = _lib.default_context(0)
 pool = [synth.synth_frame(i, n, base_seed=99)[1] for i in range(64)]
-cnt = np.full(F, n, dtype=np.int32)
-off = np.arange(F, dtype=np.int64) * n
-uv = np.concatenate([pool[i % 64] for i in range(F)])
+if args.ragged:
+    lo_, hi_ = (int(x) for x in args.ragged.split(":"))
+    cnt = np.random.default_rng(3).integers(lo_, hi_ + 1, F).astype(np.int32)
+    n = int(cnt.max())
+    pool = [synth.synth_frame(i, n, base_seed=99)[1] for i in range(64)]
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+    uv = np.concatenate([pool[i % 64][:cnt[i]] for i in range(F)])
+else:
+    cnt = np.full(F, n, dtype=np.int32)
+    off = np.arange(F, dtype=np.int64) * n
+    uv = np.concatenate([pool[i % 64] for i in range(F)])
 d_u, d_v = ctx.to_device(np.ascontiguousarray(uv[:, 0])), ctx.to_device(np.ascontiguousarray(uv[:, 1]))
 d_off, d_cnt, d_toff = ctx.to_device(off), ctx.to_device(cnt), ctx.to_device(2 * off)
-d_tri = ctx.empty((2 * F * n, 3), np.int32)
+d_tri = ctx.empty((2 * int(cnt.sum()), 3), np.int32)
 d_tcnt, d_st = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
 
 
@@ -37,9 +46,9 @@ def launch():
 launch()
 ctx.sync()
 if args.seeded:
-    keep = np.where(np.random.default_rng(5).uniform(size=F * n) < 0.85, 1, -1).astype(np.int32)
+    keep = np.where(np.random.default_rng(5).uniform(size=int(cnt.sum())) < 0.85, 1, -1).astype(np.int32)
     d_keep = ctx.to_device(keep)
-    d_tri2 = ctx.empty((2 * F * n, 3), np.int32)
+    d_tri2 = ctx.empty((2 * int(cnt.sum()), 3), np.int32)
     d_tcnt2 = ctx.zeros(F, np.int32)
     d_tcnt1, d_tcnt = d_tcnt, d_tcnt2
 
@@ -58,4 +67,4 @@ ctx.record(e1)
 ms = ctx.elapsed_ms(e0, e1) / args.steps
 rows = d_tcnt.download()
 print(json.dumps({"what": "seeded second triangulation over 85 % of the points" if args.seeded else "first triangulation", "points_per_set": n, "sets": F, "steps": args.steps, "kernel_ms": ms, "sets_per_s": F / ms * 1e3,
-                  "points_per_s": F * n / ms * 1e3, "rows_per_set": float(rows.mean()), "declined": int((d_st.download() != 0).sum())}))
+                  "points_per_s": float(cnt.sum()) / ms * 1e3, "rows_per_set": float(rows.mean()), "declined": int((d_st.download() != 0).sum())}))

@@ -432,7 +432,7 @@ def test_delaunay_small_frame_variants(gpu, n_max):
     from scipy.spatial import Delaunay
     from mvoscalerecovery_amd import _lib, packing, synth
     rng = np.random.default_rng(1000 + n_max)
-    sizes = [n_max] + [int(x) for x in rng.integers(3, n_max + 1, 37)] + [3, 4, 5, 2]
+    sizes = [n_max] + [int(x) for x in rng.integers(3, n_max + 1, 517)] + [3, 4, 5, 2]       # (512 frames and more: below that the launcher keeps eight wavefronts)
     sets = [synth.synth_frame(i, m, base_seed=4321 + n_max)[1] for i, m in enumerate(sizes)]
     sets.append(np.stack([np.arange(30.0), 3.0 * np.arange(30.0)], axis=1))              # collinear: declined
     dup = sets[1].copy()
@@ -457,6 +457,8 @@ def test_delaunay_small_frame_variants(gpu, n_max):
     assert h1[F - 2] != 0 and h1[F - 1] != 0 and h1[F - 3] != 0            # collinear, duplicate, two points
     ok = 0
     for f, q in enumerate(sets[:F - 2]):
+        if f % 6 and f < F - 8:
+            continue                                              # (SciPy on every sixth frame and on the small ones at the end)
         a = int(2 * off[f])
         if len(q) >= 3 and h1[f] == 0:
             assert np.array_equal(t1[a:a + n1[f]], packing.canonical_rows(Delaunay(q).simplices)), (n_max, f, len(q))
