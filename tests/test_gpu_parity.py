@@ -608,6 +608,29 @@ def test_triangulation_gpu_dense_frames(gpu):
         assert s == scales[i] and sd == stds[i], (i, s, scales[i])
 
 
+def test_triangulation_gpu_small_frames_fill_the_gpu(gpu):
+    """A chunk of 512 frames and more whose largest frame has a few hundred features runs the Delaunay kernel's
+    two-wavefront instantiation (eight frames per CU): the estimator on 640 such frames, device triangulations against host
+    triangulations of the same frames (the same kernels downstream) — identical scales and stds — and a sample of them
+    against the fixed-mode oracle."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    rng = np.random.default_rng(99)
+    sizes = rng.integers(60, 470, 640)
+    frames = [synth.synth_frame(i, int(n), base_seed=515, upper_fraction=0.1) for i, n in enumerate(sizes)]
+    f3, f2 = [f[0] for f in frames], [f[1] for f in frames]
+    g = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    h = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="scipy", check_triangle="fixed", delaunay_workers=4)
+    sg, eg = g.scale_calculation_batch(f3, f2)
+    sh, eh = h.scale_calculation_batch(f3, f2)
+    assert np.array_equal(np.asarray(sg), np.asarray(sh)) and np.array_equal(np.asarray(eg), np.asarray(eh))
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+    for i in range(48):
+        s, sd = ref.scale_calculation(f3[i], f2[i])
+        assert s == sg[i] and sd == eg[i], (i, s, sg[i])
+
+
 def test_triangulation_gpu_fixed_seq4541_and_fuzz(gpu):
     """The same bar on config C3's 4541-frame sequence (every raw and filtered scale of its processed frames) and on the
     adversarial frames of frame_fuzz.npz — including the ones whose point sets the device stage declines (duplicates,
