@@ -16,13 +16,18 @@ rng = np.random.default_rng(777)
 t_end = time.time() + budget
 batches = frames = bad = oracle_checked = oracle_bad = declined = 0
 while time.time() < t_end:
-    F = int(rng.integers(40, 400))
-    sizes = rng.integers(150, 2600, F)
+    big = rng.uniform() < 0.35          # a chunk that fills the GPU: the Delaunay kernel's two- / four-wavefront instantiations
+    if big:
+        F = int(rng.integers(520, 1400))
+        sizes = rng.integers(60, int(rng.choice([450, 1100, 1500])), F)
+    else:
+        F = int(rng.integers(40, 400))
+        sizes = rng.integers(150, 2600, F)
     seed = int(rng.integers(1 << 30))
     fr = [synth.synth_frame(i, int(n), base_seed=seed, upper_fraction=float(rng.uniform(0.0, 0.3))) for i, n in enumerate(sizes)]
     f3, f2 = [f[0] for f in fr], [f[1] for f in fr]
     g = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
-    g.GPU_CHUNK = int(rng.integers(16, 256))
+    g.GPU_CHUNK = 2048 if big else int(rng.integers(16, 256))
     h = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="scipy", check_triangle="fixed", delaunay_workers=8)
     try:
         sg = g.scale_calculation_batch(f3, f2); eg = None
