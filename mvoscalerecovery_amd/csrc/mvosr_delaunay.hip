@@ -69,7 +69,7 @@ constexpr int kDtMaxCells = 4096;
 constexpr int kDtLaneRows = MVOSR_DT_LANE_ROWS;   // rows a point may own on the lane path (more: the group pass)
 constexpr int kDtLaneDeg = 24;           // star degree on the lane path
 #ifndef MVOSR_DT_BUDGET
-#define MVOSR_DT_BUDGET 32
+#define MVOSR_DT_BUDGET 48
 #endif
 #ifndef MVOSR_DT_RWIDE
 #define MVOSR_DT_RWIDE 8
