@@ -7,6 +7,7 @@ point raises :class:`MvosrLibraryError`.  The library is built in-tree by
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -171,7 +172,7 @@ class DeviceBuffer:
         self.ctx = ctx
         self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         self.dtype = np.dtype(dtype)
-        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.nbytes = math.prod(self.shape) * self.dtype.itemsize
         p = C.c_void_p()
         check(ctx.lib.mvosr_malloc(ctx.handle, max(self.nbytes, 16), C.byref(p)), "mvosr_malloc")
         self.ptr = p.value
@@ -216,7 +217,7 @@ class PinnedBuffer:
 
     def view(self, offset, shape, dtype):
         dtype = np.dtype(dtype)
-        count = int(np.prod(shape, dtype=np.int64))
+        count = math.prod(shape) if isinstance(shape, (tuple, list)) else int(shape)
         return np.frombuffer(self._raw, dtype=dtype, count=count, offset=int(offset)).reshape(shape)
 
     def free(self, mark=0):
@@ -243,7 +244,7 @@ class DeviceView:
         self.block, self.offset = block, int(offset)
         self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         self.dtype = np.dtype(dtype)
-        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.nbytes = math.prod(self.shape) * self.dtype.itemsize
         self.ptr = block.ptr + self.offset
 
     def download(self):
@@ -277,7 +278,7 @@ class DeviceBlock:
         for name, shape, dtype in spec:
             size = (size + self.ALIGN - 1) & ~(self.ALIGN - 1)
             shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
-            nb = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+            nb = math.prod(shape) * np.dtype(dtype).itemsize
             plan.append((name, size, shape, dtype))
             size += max(nb, 16)
         self.nbytes = max(size, 16)
