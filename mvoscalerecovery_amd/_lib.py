@@ -165,6 +165,12 @@ def check(rc, what=""):
         raise MvosrLibraryError("%s failed (%d): %s" % (what or "libmvosr call", rc, (msg or b"").decode()))
 
 
+def addr(arr):
+    """The address of a NumPy array's data (what ``arr.ctypes.data`` returns, without building the ctypes helper object:
+    15 us each, a dozen per per-frame call)."""
+    return arr.__array_interface__["data"][0]
+
+
 class DeviceBuffer:
     """A hipMalloc'ed array with NumPy dtype/shape metadata."""
 
@@ -180,12 +186,12 @@ class DeviceBuffer:
     def upload(self, arr):
         arr = np.ascontiguousarray(arr, dtype=self.dtype)
         assert arr.nbytes == self.nbytes, (arr.shape, self.shape)
-        check(self.ctx.lib.mvosr_memcpy_h2d(self.ctx.handle, self.ptr, arr.ctypes.data, self.nbytes), "h2d")
+        check(self.ctx.lib.mvosr_memcpy_h2d(self.ctx.handle, self.ptr, addr(arr), self.nbytes), "h2d")
         return self
 
     def download(self):
         out = np.empty(self.shape, dtype=self.dtype)
-        check(self.ctx.lib.mvosr_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes), "d2h")
+        check(self.ctx.lib.mvosr_memcpy_d2h(self.ctx.handle, addr(out), self.ptr, self.nbytes), "d2h")
         return out
 
     def fill(self, byte=0):
@@ -253,7 +259,7 @@ class DeviceView:
     def upload(self, arr):
         arr = np.ascontiguousarray(arr, dtype=self.dtype)
         assert arr.nbytes == self.nbytes, (arr.shape, self.shape)
-        check(self.block.ctx.lib.mvosr_memcpy_h2d(self.block.ctx.handle, self.ptr, arr.ctypes.data, self.nbytes), "h2d")
+        check(self.block.ctx.lib.mvosr_memcpy_h2d(self.block.ctx.handle, self.ptr, addr(arr), self.nbytes), "h2d")
         self.block.invalidate()
         return self
 
@@ -266,6 +272,7 @@ class DeviceBlock:
     staging buffer and read back by ONE download: the per-frame drop-in call and every chunk of the batch path move
     their inputs and outputs as a couple of transfers instead of one allocation and one blocking copy per array."""
 
+    _PLANS = {}
     ALIGN = 256
     STAGE_LIMIT = 1 << 28              # larger uploads go array by array (a staging mirror of that size is not worth its memory)
 
@@ -273,15 +280,28 @@ class DeviceBlock:
         """``spec``: list of (name, shape, dtype)."""
         self.ctx = ctx
         self.views = {}
-        size = 0
-        plan = []
-        for name, shape, dtype in spec:
-            size = (size + self.ALIGN - 1) & ~(self.ALIGN - 1)
-            shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
-            nb = math.prod(shape) * np.dtype(dtype).itemsize
-            plan.append((name, size, shape, dtype))
-            size += max(nb, 16)
-        self.nbytes = max(size, 16)
+        # (the per-frame call builds the same few blocks for every frame of a size: the layout is remembered per spec)
+        try:
+            key = tuple((n_, tuple(sh) if isinstance(sh, (tuple, list)) else sh, dt) for n_, sh, dt in spec)
+            cached = self._PLANS.get(key)
+        except TypeError:                  # an unhashable dtype spelling: no cache
+            key, cached = None, None
+        if cached is None:
+            size = 0
+            plan = []
+            for name, shape, dtype in spec:
+                size = (size + self.ALIGN - 1) & ~(self.ALIGN - 1)
+                shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+                dtype = np.dtype(dtype)
+                nb = math.prod(shape) * dtype.itemsize
+                plan.append((name, size, shape, dtype))
+                size += max(nb, 16)
+            cached = (plan, max(size, 16))
+            if key is not None:
+                if len(self._PLANS) > 256:
+                    self._PLANS.clear()
+                self._PLANS[key] = cached
+        plan, self.nbytes = cached
         p = C.c_void_p()
         check(ctx.lib.mvosr_malloc(ctx.handle, self.nbytes, C.byref(p)), "mvosr_malloc")
         self.ptr = p.value
@@ -306,7 +326,7 @@ class DeviceBlock:
                 v = self.views[name]
                 arr = np.ascontiguousarray(arr, dtype=v.dtype)
                 assert arr.nbytes == v.nbytes, (name, arr.shape, v.shape)
-                check(ctx.lib.mvosr_memcpy_h2d(ctx.handle, v.ptr, arr.ctypes.data, v.nbytes), "h2d")
+                check(ctx.lib.mvosr_memcpy_h2d(ctx.handle, v.ptr, addr(arr), v.nbytes), "h2d")
             return self
         lo = min(self.views[n].offset for n in arrays)
         hi = max(self.views[n].offset + self.views[n].nbytes for n in arrays)
@@ -369,7 +389,7 @@ class DeviceBlock:
         ctx = self.ctx
         if self.nbytes > self.STAGE_LIMIT:
             out = np.empty(view.shape, dtype=view.dtype)
-            check(ctx.lib.mvosr_memcpy_d2h(ctx.handle, out.ctypes.data, view.ptr, view.nbytes), "d2h")
+            check(ctx.lib.mvosr_memcpy_d2h(ctx.handle, addr(out), view.ptr, view.nbytes), "d2h")
             return out
         if self._mirror is None and getattr(self, "_pf_stage", None) is not None:
             check(ctx.lib.mvosr_event_sync(ctx.handle, self._pf_event), "event_sync")

@@ -32,7 +32,7 @@ def frame_tables(feature3ds, feature2ds):
     h = _lib.pyhelper()
     if h is not None and type(feature3ds) is list and type(feature2ds) is list:
         p3, p2, npts = np.empty(F, np.uint64), np.empty(F, np.uint64), np.empty(F, np.int32)
-        r = h.mvosr_py_frame_pointers(feature3ds, feature2ds, p3.ctypes.data, p2.ctypes.data, npts.ctypes.data)
+        r = h.mvosr_py_frame_pointers(feature3ds, feature2ds, _lib.addr(p3), _lib.addr(p2), _lib.addr(npts))
         return (p3, p2, npts) if r == F else None
     if not packing.native_packable(feature3ds, feature2ds):
         return None
@@ -69,10 +69,10 @@ def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=
     cnt_view = sv("feat_cnt")
     base = stage.ptr
     c, s_ = (remap if remap is not None else (1.0, 0.0))
-    _lib.check(lib.mvosr_pack_fill(F, p3.ctypes.data, p2.ctypes.data, npts.ctypes.data, float(vanish), off.ctypes.data,
+    _lib.check(lib.mvosr_pack_fill(F, _lib.addr(p3), _lib.addr(p2), _lib.addr(npts), float(vanish), _lib.addr(off),
                                    base + blk["x"].offset, base + blk["y"].offset, base + blk["z"].offset, base + blk["u"].offset,
                                    base + blk["v"].offset, 1 if remap is not None else 0, float(c), float(s_), int(threads),
-                                   cnt_view.ctypes.data),
+                                   _lib.addr(cnt_view)),
                "mvosr_pack_fill")
     cnt = np.array(cnt_view, dtype=np.int32, copy=True)
     blk.commit(stage)
@@ -207,7 +207,7 @@ class DeviceBatch:
             self._struct.tri2_order = p("tri2_order")
             if self.n_frames:               # min_feat + the size classes' counts (ragged batches launch per class)
                 mf = self._struct.max_feat
-                _lib.check(self.ctx.lib.mvosr_batch_size_hint(self._feat_cnt_host.ctypes.data, self.n_frames,
+                _lib.check(self.ctx.lib.mvosr_batch_size_hint(_lib.addr(self._feat_cnt_host), self.n_frames,
                                                               C.byref(self._struct)), "mvosr_batch_size_hint")
                 self._struct.max_feat = max(mf, self._struct.max_feat)
         return self._struct
@@ -319,14 +319,14 @@ class ScaleEngine:
     def window_median(self, raw_dev_ptr, n, window, queue=(), out_dev_ptr=None):
         q = np.ascontiguousarray(np.asarray(list(queue), dtype=np.float64))
         _lib.check(self.lib.mvosr_window_median(self.ctx.handle, raw_dev_ptr, int(n), int(window),
-                                                q.ctypes.data if q.size else None, int(q.size), out_dev_ptr),
+                                                _lib.addr(q) if q.size else None, int(q.size), out_dev_ptr),
                    "mvosr_window_median")
 
     def window_median_blocked(self, blocks_dev_ptr, n, n_blocks, block_stride, window, queue=(), out_dev_ptr=None):
         """The window median over an all-gathered sequence read in place (sharding.GatheredFrames)."""
         q = np.ascontiguousarray(np.asarray(list(queue), dtype=np.float64))
         _lib.check(self.lib.mvosr_window_median_blocked(self.ctx.handle, blocks_dev_ptr, int(n), int(n_blocks), int(block_stride),
-                                                        int(window), q.ctypes.data if q.size else None, int(q.size), out_dev_ptr),
+                                                        int(window), _lib.addr(q) if q.size else None, int(q.size), out_dev_ptr),
                    "mvosr_window_median_blocked")
 
     def window_median_host(self, raw, window, queue=()):

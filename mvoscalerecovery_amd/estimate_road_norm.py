@@ -74,7 +74,7 @@ def get_inliers(parameter, data, threshold, device=0):
     par = np.ascontiguousarray(np.asarray(parameter, dtype=np.float64).reshape(-1)[:4])
     d = [ctx.to_device(np.ascontiguousarray(pts[:, i])) for i in range(3)]
     mask = ctx.zeros(pts.shape[0], np.uint8)
-    _lib.check(ctx.lib.mvosr_plane_inliers(ctx.handle, pts.shape[0], d[0].ptr, d[1].ptr, d[2].ptr, par.ctypes.data,
+    _lib.check(ctx.lib.mvosr_plane_inliers(ctx.handle, pts.shape[0], d[0].ptr, d[1].ptr, d[2].ptr, _lib.addr(par),
                                            float(threshold), mask.ptr), "mvosr_plane_inliers")
     ctx.sync()
     out = mask.download().astype(bool)
