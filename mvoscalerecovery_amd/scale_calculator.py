@@ -443,8 +443,8 @@ class ScaleEstimator:
         return raw, status, level, counts, host_errors, S[n - 1]
 
     GPU_PIPELINE = 1                # chunks queued on the device behind the one being collected (2 and 3 measured: the same rate)
-    GPU_CHUNK = 2048            # frames per chunk of the device-triangulation path
-    GPU_CHUNK_POINTS = 5000000  # ... and features per chunk (40 B each in staging memory, ~100 B each on the device)
+    GPU_CHUNK = 4096            # frames per chunk of the device-triangulation path, at most (a call of F frames uses chunks of F/4, 512 at least: the pipeline needs a few)
+    GPU_CHUNK_POINTS = 10000000 # ... and features per chunk (40 B each in staging memory, ~180 B each on the device)
 
     def _chunk_gpu(self, f3s, f2s, stage, last=True):
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
@@ -527,7 +527,11 @@ class ScaleEstimator:
     def _stream_gpu(self, feature3ds, feature2ds, stage):
         """The batch through the device-triangulation path in chunks: the GPU works on chunk k while this process packs
         chunk k+1 (every launch and copy of a chunk is asynchronous)."""
-        F, C = len(feature3ds), self.GPU_CHUNK
+        F = len(feature3ds)
+        # Larger chunks leave fewer launch tails (32 768 frames of 2000 features: 347 k frames/s in chunks of 2048, 356 k in
+        # chunks of 4096; 900 features: 710 k / 756 k — profiles/e2e_chunk_sweep.py), but a call that is ONE chunk packs,
+        # uploads and computes one after the other: at least four chunks per call, of 512 frames or more
+        C = int(min(self.GPU_CHUNK, max(512, -(-F // 4))))
         # chunks of at most GPU_CHUNK frames and GPU_CHUNK_POINTS features (a chunk's planes, rows and staging memory
         # scale with its points: dense frames travel in smaller chunks)
         npts = np.fromiter((len(a) for a in feature3ds), dtype=np.int64, count=F)
