@@ -631,6 +631,32 @@ def test_triangulation_gpu_small_frames_fill_the_gpu(gpu):
         assert s == sg[i] and sd == eg[i], (i, s, sg[i])
 
 
+def test_triangulation_gpu_short_first_chunks(gpu):
+    """A call of three full chunks and more starts with short ones (C/8, C/4, C/2: the GPU starts sooner) and keeps two
+    chunks queued: the same scales and stds as with equal chunks and one queued, and a sample equal to the fixed-mode oracle."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    rng = np.random.default_rng(4096)
+    F = 3 * 4096 + 700
+    sizes = rng.integers(40, 180, F)
+    pool = [synth.synth_frame(i, 200, base_seed=31, upper_fraction=0.1) for i in range(64)]
+    f3 = [pool[i % 64][0][:sizes[i]] for i in range(F)]
+    f2 = [pool[i % 64][1][:sizes[i]] for i in range(F)]
+    a = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    b = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    b.GPU_RAMP, b.GPU_PIPELINE = False, 1
+    assert a.GPU_RAMP and a.GPU_CHUNK == 4096
+    sa, ea = a.scale_calculation_batch(f3, f2)
+    sb, eb = b.scale_calculation_batch(f3, f2)
+    assert np.array_equal(np.asarray(sa), np.asarray(sb), equal_nan=True) and np.array_equal(np.asarray(ea), np.asarray(eb), equal_nan=True)
+    assert a.height_level == b.height_level or (a.height_level != a.height_level and b.height_level != b.height_level)
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+    for i in range(600):
+        s, sd = ref.scale_calculation(f3[i], f2[i])
+        assert s == sa[i] and sd == ea[i], (i, s, sa[i])
+
+
 def test_triangulation_gpu_fixed_seq4541_and_fuzz(gpu):
     """The same bar on config C3's 4541-frame sequence (every raw and filtered scale of its processed frames) and on the
     adversarial frames of frame_fuzz.npz — including the ones whose point sets the device stage declines (duplicates,
