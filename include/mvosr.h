@@ -449,7 +449,7 @@ enum mvosr_dt_status {
  * frame has tri_cnt 0 and the reason in the status' bits 8..).  max_pts = max(pts_cnt) <= mvosr_delaunay_max_points();
  * The context's workspace (grow-only, hipMalloc when it grows) holds 76 bytes per point of the LAUNCH — n_frames * max_pts
  * points: the stars' hint caches and the order the points are taken in — and ~33 more above mvosr_delaunay_lds_points(): callers with very many
- * frames launch in chunks (the host class uses up to 4096 frames).
+ * frames launch in chunks (the host class uses up to 8192 frames or 10 M points).
  */
 int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
                          const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,

@@ -444,7 +444,7 @@ class ScaleEstimator:
 
     GPU_RAMP = True                 # short first chunks (see _stream_gpu)
     GPU_PIPELINE = 2                # chunks queued on the device behind the one being collected (with the short first chunks 1 -> 2 is +3 % at 32 768 frames, +6 % at 16 384; 3: the same)
-    GPU_CHUNK = 4096            # frames per chunk of the device-triangulation path, at most (a call of F frames uses chunks of F/4, 512 at least: the pipeline needs a few)
+    GPU_CHUNK = 8192            # frames per chunk of the device-triangulation path, at most (a call of F frames uses chunks of F/4, 512 at least: the pipeline needs a few)
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk (40 B each in staging memory, ~180 B each on the device)
 
     def _chunk_gpu(self, f3s, f2s, stage, last=True):
@@ -530,7 +530,8 @@ class ScaleEstimator:
         chunk k+1 (every launch and copy of a chunk is asynchronous)."""
         F = len(feature3ds)
         # Larger chunks leave fewer launch tails (32 768 frames of 2000 features: 347 k frames/s in chunks of 2048, 356 k in
-        # chunks of 4096; 900 features: 710 k / 756 k — profiles/e2e_chunk_sweep.py), but a call that is ONE chunk packs,
+        # chunks of 4096; 900 features: 710 k / 756 k, and with the short first chunks 764 k / 807 k in chunks of 4096 / 8192 —
+        # profiles/e2e_chunk_sweep.py; the points cap keeps 2000-feature frames at 5000 per chunk), but a call that is ONE chunk packs,
         # uploads and computes one after the other: at least four chunks per call, of 512 frames or more
         C = int(min(self.GPU_CHUNK, max(512, -(-F // 4))))
         # chunks of at most GPU_CHUNK frames and GPU_CHUNK_POINTS features (a chunk's planes, rows and staging memory

@@ -646,7 +646,7 @@ def test_triangulation_gpu_short_first_chunks(gpu):
     a = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
     b = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
     b.GPU_RAMP, b.GPU_PIPELINE = False, 1
-    assert a.GPU_RAMP and a.GPU_CHUNK == 4096
+    assert a.GPU_RAMP and a.GPU_CHUNK >= 4096          # (this call: chunks of a quarter of its frames, 3247, after 405 + 811 + 1623)
     sa, ea = a.scale_calculation_batch(f3, f2)
     sb, eb = b.scale_calculation_batch(f3, f2)
     assert np.array_equal(np.asarray(sa), np.asarray(sb), equal_nan=True) and np.array_equal(np.asarray(ea), np.asarray(eb), equal_nan=True)
