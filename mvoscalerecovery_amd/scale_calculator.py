@@ -536,24 +536,30 @@ class ScaleEstimator:
         C = int(min(self.GPU_CHUNK, max(512, -(-F // 4))))
         # chunks of at most GPU_CHUNK frames and GPU_CHUNK_POINTS features (a chunk's planes, rows and staging memory
         # scale with its points: dense frames travel in smaller chunks)
-        npts = np.fromiter((len(a) for a in feature3ds), dtype=np.int64, count=F)
-        bounds, a = [], 0
         # the first chunks are short (C/8, C/4, C/2): the GPU starts after the pack + upload of 1/8 chunk instead of a whole
         # one, and the host, which prepares a frame in less time than the GPU spends on it, is ahead from then on
         ramp = [C // 8, C // 4, C // 2] if (self.GPU_RAMP and C >= 2048 and F >= 3 * C) else []
-        while a < F:
-            b = min(F, a + (ramp[len(bounds)] if len(bounds) < len(ramp) else C))
-            tot = np.cumsum(npts[a:b])
-            over = int(np.searchsorted(tot, self.GPU_CHUNK_POINTS, side="right"))
-            b = min(b, a + max(over, 1))
-            bounds.append((a, b))
-            a = b
+
+        def chunk_bounds():
+            # (a chunk's sizes are looked at when its turn comes — one pass over the whole call's frames before the first
+            # chunk was 5 ms at 32 768 frames, with an idle GPU)
+            a_, k_ = 0, 0
+            while a_ < F:
+                b_ = min(F, a_ + (ramp[k_] if k_ < len(ramp) else C))
+                tot = np.cumsum(np.fromiter((len(x) for x in feature3ds[a_:b_]), dtype=np.int64, count=b_ - a_))
+                over = int(np.searchsorted(tot, self.GPU_CHUNK_POINTS, side="right"))
+                b_ = min(b_, a_ + max(over, 1))
+                yield a_, b_
+                a_, k_ = b_, k_ + 1
+
+        bounds = []
         results, queue, reran_last = [], [], []
-        for k, (a, b) in enumerate(bounds):
+        for k, (a, b) in enumerate(chunk_bounds()):
+            bounds.append((a, b))
             # the chunk's last level is read later only by the batch's caller (last chunk) or by a frame with exactly three
             # features below the vanishing row at the head of the next chunk (:263-270): one exact single-frame run less
             # per chunk otherwise (a serial ~0.3 ms each)
-            last = k + 1 == len(bounds)
+            last = b == F
             if not last:
                 nxt = np.asarray(feature2ds[b])
                 last = nxt.ndim != 2 or nxt.shape[0] == 0 or int(np.count_nonzero(nxt[:, 1] > self.vanish)) <= 3
