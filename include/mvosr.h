@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MVOSR_ABI_VERSION 7
+#define MVOSR_ABI_VERSION 8
 
 /* error codes (function return values) */
 enum mvosr_err {
@@ -61,10 +61,12 @@ enum mvosr_status {
                                    vertex id out of range (build-side check, no reference analogue) */
     MVOSR_ST_ERR_EMPTY = 9,     /* frame without triangles, or with fewer than 3 features below the vanishing row (where the
                                    reference's first Delaunay call raises QhullError, :257: the caller must raise) */
-    MVOSR_ST_TOO_FEW = 10       /* exactly 3 features below the vanishing row: the reference skips the second
+    MVOSR_ST_TOO_FEW = 10,      /* exactly 3 features below the vanishing row: the reference skips the second
                                    triangulation (:263-270) and divides by the PREVIOUS frame's height_level
                                    (:420-422, std 100); raw_scale/height_level are NaN here and the host's
                                    cross-frame step supplies that level */
+    MVOSR_ST_RS_FEW = 11        /* rescale variant: fewer than 12 selected points — no RANSAC, the previous scale is pushed
+                                   again (/root/reference/src/rescale.py:152,175); raw_scale is NaN */
 };
 
 /* number of int32 per frame in mvosr_outputs.counts */
@@ -408,6 +410,81 @@ int mvosr_ransac_line_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts
                             const double *px, const double *py, const int32_t *pairs, int n_hyp,
                             double threshold, double goal_fraction, int32_t *counts, double *model, int32_t *best_ic,
                             int32_t *used);
+
+/* ---- the `rescale` variant, device-resident (triangulations built by mvosr_delaunay_batch, nothing visits the host) ---- */
+
+typedef struct mvosr_rescale_params {
+    uint32_t good_bits;          /* as mvosr_graph_inliers_batch */
+    int32_t min_valid;           /* 10: the vote's survivors are re-triangulated only when more than this many are left
+                                    (/root/reference/src/rescale.py:133); otherwise every feature stays               */
+    double loose_deg, tight_deg; /* -80, -85 (rescale.py:85-86) */
+    double height_factor;        /* 0.9 (rescale.py:91) */
+    int32_t ransac_min_points;   /* 12 (rescale.py:152) */
+    int32_t n_hyp;               /* 100 (rescale.py:155); <= 512 */
+    double threshold;            /* 0.005 (rescale.py:155) */
+    double goal_fraction;        /* 0.8 (/root/reference/src/estimate_road_norm.py:68) */
+    double absolute_reference;   /* real camera height (rescale.py:167) */
+    uint64_t seed;               /* key of the sample sequence (below) */
+    int64_t frame_base;          /* counter of frame 0 of the batch in the sample sequence (frame f: frame_base + f) */
+} mvosr_rescale_params;
+
+/*
+ * GraphChecker.find_inliers (/root/reference/src/graph.py:18-36) with the decision made on the device:
+ * keep[i] (laid out like z) = 1 where good/total > 0.5 (graph.py:34-35: 2*good > total in integers, 0/0 dropped),
+ * -1 where not — unless min_valid or fewer features pass, in which case the reference keeps the frame as it is
+ * (/root/reference/src/rescale.py:133-137) and the failed ones get 0: `keep >= 0` is the set the second triangulation is
+ * built on (what mvosr_delaunay_batch's `keep` wants), `keep > 0` the vote itself.  n_valid[f] (optional) = features that
+ * passed the vote.  Rows: b->tri1 at b->tri1_off[f], b->tri1_cnt[f] of them when tri1_cnt is given (the form
+ * mvosr_delaunay_batch writes), else tri1_off[f+1] - tri1_off[f].  A frame whose first triangulation was declined
+ * (dt_status[f] != 0, optional) is skipped.
+ */
+int mvosr_graph_keep_batch(mvosr_ctx *ctx, const mvosr_batch *b, uint32_t good_bits, int32_t min_valid, const int32_t *dt_status,
+                           int32_t *keep, int32_t *n_valid, int32_t *status);
+
+/* per-frame outputs of mvosr_flat_ransac_batch (device pointers; the optional ones may be NULL) */
+typedef struct mvosr_rescale_outputs {
+    double *raw_scale;           /* [F] absolute_reference / camera height of the RANSAC plane (rescale.py:156-167); NaN when
+                                    status != 0 */
+    double *height_level;        /* [F] 0.9 * median(heights[pitch < -80]) (rescale.py:91-92) */
+    double *model;               /* [F][4] unit (n, d) of the best plane, n_y >= 0 (rescale.py:159-161) */
+    int32_t *best_ic, *used;     /* [F] inlier count of the best hypothesis, hypotheses consumed (ransac.py:9-22) */
+    int32_t *n_kept;             /* [F] kept triangles (rescale.py:96); the point list has 3 * n_kept entries (:101) */
+    int32_t *status;             /* [F] 0, MVOSR_ST_RS_FEW, MVOSR_ST_ERR_SINGULAR (rescale.py:79 raises), _MASK, _EMPTY */
+    double *tri_height;          /* optional [rows of tri2, laid out like tri2] 1/|n| (rescale.py:89) */
+    uint8_t *tri_flags;          /* optional [like tri_height] bit0 pitch < loose, bit1 pitch < tight, bit2 kept */
+    int32_t *hyp_counts;         /* optional [F][n_hyp] inlier count of every hypothesis */
+} mvosr_rescale_outputs;
+
+/*
+ * flat_selection (rescale.py:75-102) + scale_calculation_ransac's plane fit (rescale.py:151-167) in ONE kernel per
+ * frame: the features with keep[i] >= 0 (keep == NULL: all) are compacted, in order, into LDS at load; b->tri2 (rows
+ * numbered over those survivors; b->tri2_cnt[f] rows at b->tri2_off[f], or the offsets' difference) gives heights,
+ * flags, the median level and the kept rows as mvosr_flat_selection_batch does; the kept rows' vertices, in row order
+ * with repeats (rescale.py:101), are the RANSAC's point list, which never leaves LDS.  The reference draws its sample
+ * triples from OS entropy (/root/reference/src/thirdparty/Ransac/ransac.py:6,10), so any uniform draw of three distinct
+ * list positions per hypothesis is a realisation of it; here hypothesis h of frame f takes
+ *     r_k = mix(mix(seed ^ (frame_base + f) * 0xD1B54A32D192ED03) + 4 h + k),  k = 0, 1, 2      (mix = splitmix64's finaliser)
+ *     i0 = mulhi(r_0, M), i1 = mulhi(r_1, M - 1) skipping i0, i2 = mulhi(r_2, M - 2) skipping both
+ * — a counter-based sequence that depends on (seed, frame counter, hypothesis) only, so a batch, its chunks and
+ * per-frame calls draw the same triples (oracle/rescale_oracle.py restates it).  `id_triples` (optional, [F][n_hyp][3]
+ * survivor-numbered VERTEX ids) replaces the draw: a recorded sample sequence of the reference mapped to point ids
+ * replays its run whatever the row order.  `frame_ids` (optional, [F]) replaces frame_base + f (re-runs of single frames).
+ * The replay rule is mvosr_ransac_plane_batch's.  max_tri: largest row count of a frame (<= 0: 2 * b->max_feat).
+ */
+int mvosr_flat_ransac_batch(mvosr_ctx *ctx, const mvosr_batch *b, const int32_t *keep, const mvosr_rescale_params *rp,
+                            const int32_t *id_triples, const int64_t *frame_ids, const int32_t *dt_status,
+                            const mvosr_rescale_outputs *o, int64_t max_tri);
+
+/*
+ * The cross-frame tail of scale_calculation_ransac (rescale.py:169-178) over a run of frames, on the device: the slew
+ * limiter — a frame with apply[i] != 0 moves the running scale towards raw[i] by at most `slew` (0.3), any other frame
+ * leaves it — followed by the window median of the pushed values (np.median(self.scale_queue)).  raw/apply/pushed/
+ * filtered are device arrays of n; scale_in and queue_in[0..n_queue) (HOST pointer) are the estimator's state before the
+ * run.  apply: int32, non-zero where the frame has a RANSAC model (status 0).  One wavefront walks the sequence (the
+ * limiter is a sequential recurrence of rounded additions), the median is mvosr_window_median's kernel.
+ */
+int mvosr_slew_median(mvosr_ctx *ctx, const double *raw, const int32_t *apply, int64_t n, double slew, double scale_in,
+                      int window, const double *queue_in, int n_queue, double *pushed, double *filtered);
 
 /*
  * The legacy per-triangle batch of /root/reference/src/triangle_batch.py:14-68: features are

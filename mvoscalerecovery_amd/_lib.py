@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 LIB_PATH = os.environ.get("MVOSR_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")   # (override: A/B builds in profiles/)
-ABI_VERSION = 7
+ABI_VERSION = 8
 VOTE_REFERENCE, VOTE_FIXED = 0, 1          # mvosr_params.vote_mode
 WAVES_EXACT = 0x100                        # MVOSR_WAVES_EXACT, or-ed into waves_per_frame
 MARK_NOW, MARK_IDLE, MARK_UPLOAD = 1, 2, 3 # mvosr_block_mark
@@ -50,6 +50,21 @@ class Outputs(C.Structure):
                 ("status", C.c_void_p), ("counts", C.c_void_p), ("vote_counters", C.c_void_p),
                 ("selected", C.c_void_p), ("tri_normals", C.c_void_p), ("tri_pitch_deg", C.c_void_p),
                 ("tri_heights", C.c_void_p), ("hist", C.c_void_p), ("stats", C.c_void_p)]
+
+
+class RescaleParams(C.Structure):
+    """mvosr_rescale_params"""
+    _fields_ = [("good_bits", C.c_uint32), ("min_valid", C.c_int32), ("loose_deg", C.c_double), ("tight_deg", C.c_double),
+                ("height_factor", C.c_double), ("ransac_min_points", C.c_int32), ("n_hyp", C.c_int32),
+                ("threshold", C.c_double), ("goal_fraction", C.c_double), ("absolute_reference", C.c_double),
+                ("seed", C.c_uint64), ("frame_base", C.c_int64)]
+
+
+class RescaleOutputs(C.Structure):
+    """mvosr_rescale_outputs"""
+    _fields_ = [("raw_scale", C.c_void_p), ("height_level", C.c_void_p), ("model", C.c_void_p), ("best_ic", C.c_void_p),
+                ("used", C.c_void_p), ("n_kept", C.c_void_p), ("status", C.c_void_p), ("tri_height", C.c_void_p),
+                ("tri_flags", C.c_void_p), ("hyp_counts", C.c_void_p)]
 
 
 # every symbol include/mvosr.h declares: name -> (restype, argtypes)
@@ -98,6 +113,10 @@ SYMBOLS = {
     "mvosr_graph_inliers_batch": (C.c_int, [_P, C.POINTER(Batch), C.c_uint32, _P, _P, _P]),
     "mvosr_flat_selection_batch": (C.c_int, [_P, C.POINTER(Batch), C.c_double, C.c_double, C.c_double, _P, _P, _P, _P, _P,
                                              C.c_int64]),
+    "mvosr_graph_keep_batch": (C.c_int, [_P, C.POINTER(Batch), C.c_uint32, C.c_int32, _P, _P, _P, _P]),
+    "mvosr_flat_ransac_batch": (C.c_int, [_P, C.POINTER(Batch), _P, C.POINTER(RescaleParams), _P, _P, _P, C.POINTER(RescaleOutputs),
+                                          C.c_int64]),
+    "mvosr_slew_median": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_int, _P, C.c_int, _P, _P]),
     "mvosr_ransac_plane_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int, C.c_double, C.c_double,
                                            _P, _P, _P, _P]),
     "mvosr_ransac_line_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, C.c_double, C.c_double,

@@ -23,6 +23,7 @@ ST_ERR_SINGULAR = 7
 ST_ERR_MASK = 8
 ST_ERR_EMPTY = 9
 ST_TOO_FEW = 10
+ST_RS_FEW = 11                         # rescale variant: fewer than 12 selected points, the previous scale is pushed (rescale.py:152,175)
 
 STATUS_NAMES = {ST_MODE: "mode", ST_RIGHT: "right-edge (skew)", ST_MEDIAN: "median (no modes)",
                 ST_LEVEL: "height_level (no points left)", ST_NO_FLAT: "no flat feature",

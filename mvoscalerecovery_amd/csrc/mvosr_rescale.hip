@@ -37,21 +37,29 @@ struct GraphArgs {
     uint32_t good_bits;            // bit 3*code+k: vertex k of a triangle with this code has marginal > 0.6
     int32_t *total, *good;         // [like z] outputs
     int32_t *status;               // [F] 0 ok / MVOSR_ST_ERR_MASK on a bad vertex id
+    // the device-resident form (graph_inliers_kernel<true>, mvosr_graph_keep_batch): the decision itself
+    const int32_t *tri_cnt;        // [F] rows of the frame (null: tri_off[f+1] - tri_off[f])
+    const int32_t *dt_status;      // [F] non-zero: the frame's triangulation was declined — nothing to do (null: none)
+    int32_t min_valid;             // rescale.py:133
+    int32_t *keep;                 // [like z] 1 passed / 0 failed but the frame stays whole / -1 dropped
+    int32_t *n_valid;              // [F] features that passed (null: not wanted)
 };
 
+template <bool KEEP>
 __global__ __launch_bounds__(kRsBlock) void graph_inliers_kernel(const GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = blockIdx.x;
     const int n = a.feat_cnt[f];
-    if (n <= 0) { if (threadIdx.x == 0 && a.status) a.status[f] = MVOSR_ST_ERR_EMPTY; return; }
+    if (n <= 0) { if (threadIdx.x == 0) { if (a.status) a.status[f] = MVOSR_ST_ERR_EMPTY; if (KEEP && a.n_valid) a.n_valid[f] = 0; } return; }
+    if (KEEP && a.dt_status && a.dt_status[f] != 0) { if (threadIdx.x == 0) { if (a.status) a.status[f] = MVOSR_ST_ERR_EMPTY; if (a.n_valid) a.n_valid[f] = 0; } return; }
     const int64_t off = a.feat_off[f];
     const int64_t tb = a.tri_off[f];
-    const int tn = (int)(a.tri_off[f + 1] - tb);
+    const int tn = a.tri_cnt ? a.tri_cnt[f] : (int)(a.tri_off[f + 1] - tb);
     double2 *P = reinterpret_cast<double2 *>(smem);                       // {v, z}
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + 16u * (uint32_t)((n + 1) & ~1));
-    int *flag = reinterpret_cast<int *>(cnt + n + 4);
+    int *flag = reinterpret_cast<int *>(cnt + n + 4);                     // [0] bad vertex id, [1] features that passed
     const int tid = threadIdx.x;
-    if (tid == 0) *flag = 0;
+    if (tid < 2) flag[tid] = 0;
     for (int i = tid; i < n; i += kRsBlock) {
         double2 p; p.x = a.v[off + i]; p.y = a.z[off + i];               // rescale.py:25: camera_pitch = 0, no remap
         P[i] = p;
@@ -71,14 +79,28 @@ __global__ __launch_bounds__(kRsBlock) void graph_inliers_kernel(const GraphArgs
         atomicAdd(&cnt[q.b], 1u + (((g >> 1) & 1u) << 16));
         atomicAdd(&cnt[q.c], 1u + (((g >> 2) & 1u) << 16));
     }
-    if (bad) *flag = 1;
+    if (bad) flag[0] = 1;
     __syncthreads();
-    for (int i = tid; i < n; i += kRsBlock) {
-        const uint32_t c = cnt[i];
-        a.total[off + i] = (int32_t)(c & 0xFFFFu);
-        a.good[off + i] = (int32_t)(c >> 16);
+    if constexpr (!KEEP) {
+        for (int i = tid; i < n; i += kRsBlock) {
+            const uint32_t c = cnt[i];
+            a.total[off + i] = (int32_t)(c & 0xFFFFu);
+            a.good[off + i] = (int32_t)(c >> 16);
+        }
+    } else {
+        // good/total > 0.5 (graph.py:34-35,131-132): the quotient of two integers below 2^16 is above one half exactly when
+        // 2*good > total (the nearest quotient below is 1/2 - 1/(2 total), far from a rounding); 0/0 is nan: dropped
+        int mine = 0;
+        for (int i = tid; i < n; i += kRsBlock) { const uint32_t c = cnt[i]; mine += (2u * (c >> 16) > (c & 0xFFFFu)) ? 1 : 0; }
+        mine = wave_sum(mine);
+        if (lane_id() == 0 && mine) atomicAdd(&flag[1], mine);
+        __syncthreads();
+        const int nv = flag[1];
+        const int fail = nv > a.min_valid ? -1 : 0;                       // rescale.py:133-137: ten or fewer left — the frame stays whole
+        for (int i = tid; i < n; i += kRsBlock) { const uint32_t c = cnt[i]; a.keep[off + i] = (2u * (c >> 16) > (c & 0xFFFFu)) ? 1 : fail; }
+        if (tid == 0 && a.n_valid) a.n_valid[f] = nv;
     }
-    if (tid == 0 && a.status) a.status[f] = *flag ? MVOSR_ST_ERR_MASK : 0;
+    if (tid == 0 && a.status) a.status[f] = flag[0] ? MVOSR_ST_ERR_MASK : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -100,30 +122,72 @@ struct FlatArgs {
     double *height_level;          // [F]
     int32_t *status;               // [F] 0 / MVOSR_ST_ERR_SINGULAR / MVOSR_ST_ERR_MASK / MVOSR_ST_ERR_EMPTY
     int32_t *n_kept;               // [F]
+    // the device-resident form (flat_selection_kernel<true>, mvosr_flat_ransac_batch): survivors compacted at load, explicit
+    // row counts, and the RANSAC plane fit over the kept rows' vertices as the kernel's tail (tri_height / tri_flags optional)
+    const int32_t *tri_cnt;        // [F] rows of the frame (null: tri_off[f+1] - tri_off[f])
+    const int32_t *keep;           // [like x] a feature takes part iff keep[i] >= 0 (null: all)
+    const int32_t *dt_status;      // [F] non-zero: declined triangulation, frame skipped (null: none)
+    const int32_t *id_triples;     // [F][H][3] survivor-numbered vertex ids replacing the draw (null: draw)
+    const int64_t *frame_ids;      // [F] sample-sequence counter of the frame (null: frame_base + f)
+    int32_t n_hyp, ransac_min_points, max_tri;
+    double threshold, goal_fraction, absolute_reference;
+    uint64_t seed; int64_t frame_base;
+    double *raw_scale, *model;     // [F], [F][4]
+    int32_t *best_ic, *used, *hyp_counts;
 };
 
 constexpr int kFlatBins = 2048;         // one histogram pass resolves 11 bits of the candidates' range
 constexpr int kFlatRows = 4;            // triangle rows a thread keeps in flight
 constexpr int kFlatDirect = 64;         // that few candidates left: wavefront 0 ranks them directly
-// misc[] slots of flat_selection_kernel
+constexpr int kMaxHyp = 512;
+constexpr int kRansacPPT = 8;           // points per thread per chunk (chunks of 4096 points)
+// misc[] slots of flat_selection_kernel (slots below FM_WSUM are zeroed at the start)
 enum { FM_K = 0, FM_SINGULAR = 1, FM_BADID = 2, FM_KEPT = 3, FM_BIN = 4, FM_RANK = 5, FM_BINCNT = 6, FM_LE = 7, FM_LIST = 8,
-       FM_WSUM = 16 /* [8] per-wave bin totals */, FM_N = 32 };
+       FM_WSUM = 16 /* [8] per-wave bin totals */, FM_CW = 24 /* [8] per-wave counts of the ordered compactions */, FM_N = 32 };
 
+// The sample sequence of the device-resident RANSAC (include/mvosr.h, mvosr_flat_ransac_batch): splitmix64's finaliser as a
+// counter-based generator.  oracle/rescale_oracle.py restates it.
+__host__ __device__ __forceinline__ uint64_t rs_mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ void rs_draw3(uint64_t key, int h, int M, int &i0, int &i1, int &i2) {
+    const uint64_t r0 = rs_mix64(key + (uint64_t)(4 * h)), r1 = rs_mix64(key + (uint64_t)(4 * h + 1)), r2 = rs_mix64(key + (uint64_t)(4 * h + 2));
+    i0 = (int)__umul64hi(r0, (uint64_t)M);                                  // uniform on [0, M) up to M / 2^64
+    i1 = (int)__umul64hi(r1, (uint64_t)(M - 1)); if (i1 >= i0) ++i1;         // ... on the M - 1 other positions
+    i2 = (int)__umul64hi(r2, (uint64_t)(M - 2));
+    const int lo = min(i0, i1), hi = max(i0, i1);
+    if (i2 >= lo) ++i2;
+    if (i2 >= hi) ++i2;
+}
+
+template <bool DEV>
 __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = blockIdx.x;
-    const int n = a.feat_cnt[f];
+    const int n_all = a.feat_cnt[f];
     const int64_t off = a.feat_off[f];
     const int64_t tb = a.tri_off[f];
-    const int tn = (int)(a.tri_off[f + 1] - tb);
+    const int tn = a.tri_cnt ? a.tri_cnt[f] : (int)(a.tri_off[f + 1] - tb);
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-    if (n <= 0 || tn <= 0) {
-        if (tid == 0) { a.status[f] = MVOSR_ST_ERR_EMPTY; a.height_level[f] = nan(""); a.n_kept[f] = 0; }
+    const bool skip = DEV && a.dt_status && a.dt_status[f] != 0;
+    if (n_all <= 0 || tn <= 0 || skip || (DEV && tn > a.max_tri)) {
+        if (tid == 0) {
+            a.status[f] = (DEV && !skip && tn > a.max_tri && n_all > 0) ? MVOSR_ST_ERR_MASK : MVOSR_ST_ERR_EMPTY;
+            a.height_level[f] = nan(""); a.n_kept[f] = 0;
+            if constexpr (DEV) {
+                a.raw_scale[f] = nan(""); a.best_ic[f] = 0; a.used[f] = 0;
+                for (int k = 0; k < 4; ++k) a.model[4 * f + k] = nan("");
+            }
+        }
         return;
     }
-    // LDS: heights and flags of every triangle by row, the scalars, then the vertex planes — which are dead once the
-    // normals are done: the histogram of the median search takes their place
-    const uint32_t npad = (uint32_t)((n + 1) & ~1);
+    // LDS: heights and flags of every triangle by row, the scalars, then the vertex planes.  Stage form: the planes are dead
+    // once the normals are done and the histogram of the median search takes their place.  Device-resident form: the planes
+    // live on for the RANSAC, the histogram has its own room, and the heights' room is reused by the point list.
+    const uint32_t npad = (uint32_t)((n_all + 1) & ~1);
     double *Hh = reinterpret_cast<double *>(smem);               // every triangle's height, by row
     unsigned long long *U = reinterpret_cast<unsigned long long *>(Hh);   // (heights are >= 0: the bit patterns order like the values)
     unsigned long long *ext = U + tn;                            // [2] smallest / largest loose height (bits), [2] scratch
@@ -131,8 +195,8 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
     double *X = reinterpret_cast<double *>(misc + FM_N);
     double *Y = X + npad;
     double *Z = Y + npad;
-    int *hist = reinterpret_cast<int *>(X);                      // kFlatBins bins; later the short candidate list (64-bit)
-    const uint32_t planes = 24u * npad > 4u * kFlatBins ? 24u * npad : 4u * kFlatBins;
+    int *hist = DEV ? reinterpret_cast<int *>(Z + npad) : reinterpret_cast<int *>(X);   // kFlatBins bins; later the short candidate list (64-bit)
+    const uint32_t planes = DEV ? 24u * npad + 4u * kFlatBins : (24u * npad > 4u * kFlatBins ? 24u * npad : 4u * kFlatBins);
     uint8_t *Fl = reinterpret_cast<uint8_t *>(X) + planes;       // every triangle's flags, by row
 #ifdef MVOSR_FS_STAMPS
     unsigned long long st[6];
@@ -141,7 +205,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
 #define FS_STAMP(i) do {} while (0)
 #endif
     FS_STAMP(0);
-    if (tid < FM_N) misc[tid] = 0;
+    if (tid < FM_WSUM) misc[tid] = 0;
     if (tid == 0) { ext[0] = ~0ull; ext[1] = 0ull; ext[2] = ~0ull; }
     // a thread's next kFlatRows triangle rows are in flight while it works on the current ones (and the first ones while
     // the vertex planes stream in): a row is a dependent global load in front of nine LDS gathers and the LU chain
@@ -151,8 +215,37 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
         for (int j = 0; j < kFlatRows; ++j) rows[j] = load_tri(a.tri + 3 * tb, min(t0 + j * kRsBlock, tn - 1));
     };
     load_rows(tid);
+    int n = n_all;                                               // features in LDS (the survivors)
+    if (DEV && a.keep) {
+        // ordered compaction at load (rescale.py:134-135: feature3d[valid_id]): every wavefront owns a contiguous segment of
+        // the frame, counts its survivors, and after one barrier knows where its segment starts in LDS
+        const int seg = ((n_all + kRsBlock - 1) / kRsBlock) * kWave;
+        const int s0 = wave * seg, s1 = min(n_all, s0 + seg);
+        int c = 0;
+        for (int i0 = s0; i0 < s1; i0 += kWave) {
+            const int i = i0 + lane;
+            c += __popcll(__ballot(i < s1 && a.keep[off + i] >= 0));
+        }
+        if (lane == 0) misc[FM_CW + wave] = c;
+        __syncthreads();
+        int base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kRsWaves; ++w) { const int cw = misc[FM_CW + w]; total += cw; if (w < wave) base += cw; }
+        n = total;
+        for (int i0 = s0; i0 < s1; i0 += kWave) {
+            const int i = i0 + lane;
+            const bool k = i < s1 && a.keep[off + i] >= 0;
+            const unsigned long long m = __ballot(k);
+            if (k) {
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                X[pos] = a.x[off + i]; Y[pos] = a.y[off + i]; Z[pos] = a.z[off + i];
+            }
+            base += __popcll(m);
+        }
+    } else {
 #pragma unroll 4
-    for (int i = tid; i < n; i += kRsBlock) { X[i] = a.x[off + i]; Y[i] = a.y[off + i]; Z[i] = a.z[off + i]; }
+        for (int i = tid; i < n_all; i += kRsBlock) { X[i] = a.x[off + i]; Y[i] = a.y[off + i]; Z[i] = a.z[off + i]; }
+    }
     const double s_loose = sin(a.loose_deg * 3.141592653589793 / 180.0), s_tight = sin(a.tight_deg * 3.141592653589793 / 180.0);
     __syncthreads();
     FS_STAMP(1);
@@ -162,7 +255,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
         unsigned long long umin = ~0ull, umax = 0ull;
         auto one_row = [&](const TriIds q, const int t) {
             if ((unsigned)q.a >= (unsigned)n || (unsigned)q.b >= (unsigned)n || (unsigned)q.c >= (unsigned)n) {
-                misc[FM_BADID] = 1; Fl[t] = 0; Hh[t] = nan(""); a.tri_height[tb + t] = nan(""); return;
+                misc[FM_BADID] = 1; Fl[t] = 0; Hh[t] = nan(""); if (!DEV || a.tri_height) a.tri_height[tb + t] = nan(""); return;
             }
             double nx, ny, nz;
             if (!plane_normal(X[q.a], Y[q.a], Z[q.a], X[q.b], Y[q.b], Z[q.b], X[q.c], Y[q.c], Z[q.c], nx, ny, nz)) misc[FM_SINGULAR] = 1;   // rescale.py:79-80
@@ -179,7 +272,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
             }
             Hh[t] = h;
             Fl[t] = (uint8_t)((loose ? 1 : 0) | (tight ? 2 : 0));                            // :85-86
-            a.tri_height[tb + t] = h;
+            if (!DEV || a.tri_height) a.tri_height[tb + t] = h;
             if (loose) {
                 const unsigned long long u = (unsigned long long)__double_as_longlong(h);
                 ++k_mine; umin = u < umin ? u : umin; umax = u > umax ? u : umax;
@@ -297,25 +390,149 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
         level = a.height_factor * ((klo == khi) ? vlo : (vlo + vhi) / 2.0);
     }
     FS_STAMP(3);
-    int kept = 0;
-    #pragma unroll 4
-    for (int t = tid; t < tn; t += kRsBlock) {
-        uint8_t fl = Fl[t];
-        if ((fl & 2) && Hh[t] > level) { fl |= 4; ++kept; }                                 // :94-96
-        a.tri_flags[tb + t] = fl;
-    }
-    kept = wave_sum(kept);
-    if (lane == 0 && kept) atomicAdd(&misc[FM_KEPT], kept);
-    __syncthreads();
-    if (tid == 0) {
-        a.height_level[f] = level;
-        a.n_kept[f] = misc[FM_KEPT];
-        a.status[f] = misc[FM_BADID] ? MVOSR_ST_ERR_MASK : (misc[FM_SINGULAR] ? MVOSR_ST_ERR_SINGULAR : 0);
-    }
+    if constexpr (!DEV) {
+        int kept = 0;
+        #pragma unroll 4
+        for (int t = tid; t < tn; t += kRsBlock) {
+            uint8_t fl = Fl[t];
+            if ((fl & 2) && Hh[t] > level) { fl |= 4; ++kept; }                                 // :94-96
+            a.tri_flags[tb + t] = fl;
+        }
+        kept = wave_sum(kept);
+        if (lane == 0 && kept) atomicAdd(&misc[FM_KEPT], kept);
+        __syncthreads();
+        if (tid == 0) {
+            a.height_level[f] = level;
+            a.n_kept[f] = misc[FM_KEPT];
+            a.status[f] = misc[FM_BADID] ? MVOSR_ST_ERR_MASK : (misc[FM_SINGULAR] ? MVOSR_ST_ERR_SINGULAR : 0);
+        }
 #ifdef MVOSR_FS_STAMPS
-    FS_STAMP(4);                                                 // (diagnostic build: the stamps overwrite the frame's first heights)
-    if (tid == 0 && tn >= 5) for (int i = 0; i < 5; ++i) a.tri_height[tb + i] = (double)(st[i] - st[0]);
+        FS_STAMP(4);                                                 // (diagnostic build: the stamps overwrite the frame's first heights)
+        if (tid == 0 && tn >= 5) for (int i = 0; i < 5; ++i) a.tri_height[tb + i] = (double)(st[i] - st[0]);
 #endif
+    } else {
+        // ---- the kept rows (:94-96), wavefront by wavefront over contiguous row segments so that the point list —
+        // triangle_ids[valid_id].reshape(-1), :101 — comes out in row order without a sort
+        const int seg = ((tn + kRsBlock - 1) / kRsBlock) * kWave;
+        const int s0 = wave * seg, s1 = min(tn, s0 + seg);
+        int c = 0;
+        for (int t0 = s0; t0 < s1; t0 += kWave) {
+            const int t = t0 + lane;
+            bool kp = false;
+            if (t < s1) {
+                uint8_t fl = Fl[t];
+                kp = (fl & 2) && Hh[t] > level;
+                if (kp) { fl |= 4; Fl[t] = fl; }
+                if (a.tri_flags) a.tri_flags[tb + t] = fl;
+            }
+            c += __popcll(__ballot(kp));
+        }
+        if (lane == 0) misc[FM_CW + wave] = c;
+        __syncthreads();                                         // (every height has been compared: their room is the list's now)
+        int base = 0, K = 0;
+#pragma unroll
+        for (int w = 0; w < kRsWaves; ++w) { const int cw = misc[FM_CW + w]; K += cw; if (w < wave) base += cw; }
+        const int M = 3 * K;                                     // len(point_selected), :140
+        uint16_t *L = reinterpret_cast<uint16_t *>(Hh);          // the point list as vertex ids
+        const int H = a.n_hyp;
+        double2 *mods = reinterpret_cast<double2 *>(smem + (((uint32_t)(Fl - reinterpret_cast<uint8_t *>(smem)) + (uint32_t)tn + 15u) & ~15u));   // [H][2] unit (n, d) as (nx, ny), (nz, d)
+        int *cnts = reinterpret_cast<int *>(mods + 2 * H);       // [H] inlier counts
+        const bool bad = misc[FM_BADID] || misc[FM_SINGULAR];
+        const bool fit = !bad && M >= a.ransac_min_points;       // :152
+        if (fit) {
+            for (int t0 = s0; t0 < s1; t0 += kWave) {
+                const int t = t0 + lane;
+                const bool kp = t < s1 && (Fl[t] & 4);
+                const unsigned long long m = __ballot(kp);
+                if (kp) {
+                    const TriIds q = load_tri(a.tri + 3 * tb, t);
+                    const int pos = 3 * (base + __popcll(m & ((1ull << lane) - 1ull)));
+                    L[pos] = (uint16_t)q.a; L[pos + 1] = (uint16_t)q.b; L[pos + 2] = (uint16_t)q.c;
+                }
+                base += __popcll(m);
+            }
+            __syncthreads();
+            // the hypotheses' planes, one thread each (ransac.py:10-11, estimate_road_norm.py:13-15)
+            const uint64_t fc = (uint64_t)(a.frame_ids ? a.frame_ids[f] : a.frame_base + f);
+            const uint64_t key = rs_mix64(a.seed ^ (fc * 0xD1B54A32D192ED03ull));
+            for (int h = tid; h < H; h += kRsBlock) {
+                int v0, v1, v2;
+                if (a.id_triples) {
+                    const int32_t *t = a.id_triples + ((int64_t)f * H + h) * 3;
+                    v0 = min(max(t[0], 0), n - 1); v1 = min(max(t[1], 0), n - 1); v2 = min(max(t[2], 0), n - 1);
+                } else {
+                    int i0, i1, i2;
+                    rs_draw3(key, h, M, i0, i1, i2);
+                    v0 = L[i0]; v1 = L[i1]; v2 = L[i2];
+                }
+                const double x0 = X[v0], y0 = Y[v0], z0 = Z[v0];
+                const double e1x = X[v1] - x0, e1y = Y[v1] - y0, e1z = Z[v1] - z0;
+                const double e2x = X[v2] - x0, e2y = Y[v2] - y0, e2z = Z[v2] - z0;
+                const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+                const double d = -((nx * x0 + ny * y0) + nz * z0);
+                const double inv = 1.0 / sqrt(((nx * nx + ny * ny) + nz * nz) + d * d);
+                double2 m0, m1; m0.x = nx * inv; m0.y = ny * inv; m1.x = nz * inv; m1.y = d * inv;
+                mods[2 * h] = m0; mods[2 * h + 1] = m1;
+                cnts[h] = 0;
+            }
+            __syncthreads();
+            // inlier counts (estimate_road_norm.py:17-18 over every list entry, repeats included): a thread's points in
+            // registers, gathered from the LDS planes once, the hypotheses streamed past them
+            for (int c0 = 0; c0 < M; c0 += kRsBlock * kRansacPPT) {
+                double qx[kRansacPPT], qy[kRansacPPT], qz[kRansacPPT];
+#pragma unroll
+                for (int kk = 0; kk < kRansacPPT; ++kk) {
+                    const int j = c0 + kk * kRsBlock + tid;
+                    const int id = L[min(j, M - 1)];
+                    qx[kk] = X[id]; qy[kk] = Y[id]; qz[kk] = Z[id];
+                    if (j >= M) qx[kk] = nan("");                    // never an inlier
+                }
+                const int rws = min(kRansacPPT, (M - c0 + kRsBlock - 1) / kRsBlock);
+#pragma unroll 2
+                for (int h = 0; h < H; ++h) {
+                    const double2 m0 = mods[2 * h], m1 = mods[2 * h + 1];
+                    int ic = 0;
+#pragma unroll
+                    for (int kk = 0; kk < kRansacPPT; ++kk)
+                        if (kk < rws) ic += __popcll(__ballot(fabs(((qx[kk] * m0.x + qy[kk] * m0.y) + qz[kk] * m1.x) + m1.y) < a.threshold));
+                    if (lane == 0 && ic) atomicAdd(&cnts[h], ic);
+                }
+            }
+            __syncthreads();
+            if (a.hyp_counts) for (int h = tid; h < H; h += kRsBlock) a.hyp_counts[(int64_t)f * H + h] = cnts[h];
+        }
+        if (tid == 0) {
+            int status = misc[FM_BADID] ? MVOSR_ST_ERR_MASK : (misc[FM_SINGULAR] ? MVOSR_ST_ERR_SINGULAR : (fit ? 0 : MVOSR_ST_RS_FEW));
+            int best = -1, best_ic = 0, used = 0;
+            double m[4] = {nan(""), nan(""), nan(""), nan("")};
+            double raw = nan("");
+            if (fit) {
+                const double goal = (double)M * a.goal_fraction;                  // estimate_road_norm.py:68
+                for (int h = 0; h < H; ++h) {                                     // ransac.py:9-22
+                    used = h + 1;
+                    if (cnts[h] > best_ic) {
+                        best_ic = cnts[h]; best = h;
+                        if ((double)best_ic > goal) break;
+                    }
+                }
+                if (best >= 0) {
+                    const double2 b0 = mods[2 * best], b1 = mods[2 * best + 1];
+                    const double sgn = (b0.y < 0.0) ? -1.0 : 1.0;                 // rescale.py:159-161
+                    m[0] = sgn * b0.x; m[1] = sgn * b0.y; m[2] = sgn * b1.x; m[3] = sgn * b1.y;
+                    const double h_bar = -m[3];                                    // :158
+                    const double norm_norm = sqrt((m[0] * m[0] + m[1] * m[1]) + m[2] * m[2]) / h_bar;   // :162-163
+                    const double cam_h = 1.0 / norm_norm;                          // :165
+                    raw = a.absolute_reference / cam_h;                            // :167
+                } else status = MVOSR_ST_RS_FEW;                                   // (no hypothesis with an inlier: NaN planes only)
+            }
+            a.height_level[f] = level;
+            a.n_kept[f] = K;
+            a.status[f] = status;
+            a.raw_scale[f] = raw;
+            a.best_ic[f] = best_ic; a.used[f] = used;
+            for (int kk = 0; kk < 4; ++kk) a.model[4 * f + kk] = m[kk];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -340,10 +557,6 @@ struct RansacArgs {
     int32_t line;                                        // 1: 2-D line fit (estimate_line / is_inlier_line, estimate_road_norm.py:39-49):
                                                          // samples are PAIRS (still 3 ints apart), pz is not read, model = (a, b, 0, c)
 };
-constexpr int kMaxHyp = 512;
-
-constexpr int kRansacPPT = 8;           // points per thread per chunk (chunks of 4096 points)
-
 __global__ __launch_bounds__(kRsBlock) void ransac_plane_kernel(const RansacArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = blockIdx.x;
@@ -516,6 +729,33 @@ __global__ __launch_bounds__(kRsBlock) void triangle_batch_kernel(const TriBatch
     }
 }
 
+// The slew limiter of scale_calculation_ransac (/root/reference/src/rescale.py:169-177) over a run of frames: a sequential
+// recurrence of rounded additions, walked by ONE wavefront — 64 frames are loaded at a time, their values broadcast lane by
+// lane (v_readlane), the running scale identical in every lane; lane j keeps the value pushed at its frame.
+__global__ __launch_bounds__(kWave) void slew_kernel(const double *raw, const int32_t *apply, int64_t n, double slew, double s_in,
+                                                     double *pushed) {
+    const int lane = lane_id();
+    double s = s_in;
+    for (int64_t i0 = 0; i0 < n; i0 += kWave) {
+        const int64_t i = i0 + lane;
+        const double r = i < n ? raw[i] : 0.0;
+        const unsigned long long am = __ballot(i < n && apply[i] != 0);
+        const int cnt = (int)((n - i0) < (int64_t)kWave ? (n - i0) : (int64_t)kWave);
+        double out = 0.0;
+        for (int j = 0; j < cnt; ++j) {
+            if ((am >> j) & 1ull) {                                          // :152 — the frame has a RANSAC plane
+                const double rj = readlane_d(r, j);
+                const double d = rj - s;
+                if (d > slew) s += slew;                                     // :169-170
+                else if (d < -slew) s -= slew;                               // :171-172
+                else s = rj;                                                 // :173-174
+            }
+            if (lane == j) out = s;                                          // :175 scale_queue.append(self.scale)
+        }
+        if (i < n) pushed[i] = out;
+    }
+}
+
 // get_inliers, /root/reference/src/estimate_road_norm.py:71-78: |n.p + d| < threshold per point
 __global__ __launch_bounds__(256) void plane_inliers_kernel(int64_t n, const double *px, const double *py, const double *pz,
                                                             double m0, double m1, double m2, double m3, double threshold,
@@ -540,21 +780,39 @@ using namespace mvosr;
 
 extern "C" {
 
-int mvosr_graph_inliers_batch(mvosr_ctx *ctx, const mvosr_batch *b, uint32_t good_bits, int32_t *total, int32_t *good,
-                              int32_t *status) {
-    if (!ctx || !b || !total || !good) return set_error(MVOSR_ERR_ARG, "graph_inliers: null argument");
+static int launch_graph(mvosr_ctx *ctx, const mvosr_batch *b, GraphArgs &a, bool keep) {
     if (!b->feat_off || !b->feat_cnt || !b->z || !b->v || !b->tri1_off || !b->tri1) return set_error(MVOSR_ERR_ARG, "graph_inliers: missing z/v/tri1");
     if (b->n_frames <= 0) return MVOSR_OK;
     int rc = ctx_activate(ctx);
     if (rc) return rc;
     g_rs_max_lds = ctx->max_lds_per_block;
-    GraphArgs a;
     a.n_frames = b->n_frames; a.feat_off = b->feat_off; a.feat_cnt = b->feat_cnt; a.z = b->z; a.v = b->v;
-    a.tri_off = b->tri1_off; a.tri = b->tri1; a.good_bits = good_bits; a.total = total; a.good = good; a.status = status;
+    a.tri_off = b->tri1_off; a.tri = b->tri1; a.tri_cnt = b->tri1_cnt;
     const size_t lds = 16u * (size_t)((b->max_feat + 1) & ~1) + 4u * ((size_t)b->max_feat + 4) + 16;
-    if ((rc = rs_prepare(graph_inliers_kernel, lds))) return rc;
-    hipLaunchKernelGGL(graph_inliers_kernel, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
+    if (keep) {
+        if ((rc = rs_prepare(graph_inliers_kernel<true>, lds))) return rc;
+        hipLaunchKernelGGL(graph_inliers_kernel<true>, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
+    } else {
+        if ((rc = rs_prepare(graph_inliers_kernel<false>, lds))) return rc;
+        hipLaunchKernelGGL(graph_inliers_kernel<false>, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
+    }
     return check_launch("graph_inliers_kernel");
+}
+
+int mvosr_graph_inliers_batch(mvosr_ctx *ctx, const mvosr_batch *b, uint32_t good_bits, int32_t *total, int32_t *good,
+                              int32_t *status) {
+    if (!ctx || !b || !total || !good) return set_error(MVOSR_ERR_ARG, "graph_inliers: null argument");
+    GraphArgs a = {};
+    a.good_bits = good_bits; a.total = total; a.good = good; a.status = status;
+    return launch_graph(ctx, b, a, false);
+}
+
+int mvosr_graph_keep_batch(mvosr_ctx *ctx, const mvosr_batch *b, uint32_t good_bits, int32_t min_valid, const int32_t *dt_status,
+                           int32_t *keep, int32_t *n_valid, int32_t *status) {
+    if (!ctx || !b || !keep) return set_error(MVOSR_ERR_ARG, "graph_keep: null argument");
+    GraphArgs a = {};
+    a.good_bits = good_bits; a.status = status; a.dt_status = dt_status; a.min_valid = min_valid; a.keep = keep; a.n_valid = n_valid;
+    return launch_graph(ctx, b, a, true);
 }
 
 int mvosr_flat_selection_batch(mvosr_ctx *ctx, const mvosr_batch *b, double loose_deg, double tight_deg, double height_factor,
@@ -566,17 +824,61 @@ int mvosr_flat_selection_batch(mvosr_ctx *ctx, const mvosr_batch *b, double loos
     int rc = ctx_activate(ctx);
     if (rc) return rc;
     g_rs_max_lds = ctx->max_lds_per_block;
-    FlatArgs a;
+    FlatArgs a = {};
     a.n_frames = b->n_frames; a.feat_off = b->feat_off; a.feat_cnt = b->feat_cnt; a.x = b->x; a.y = b->y; a.z = b->z;
-    a.tri_off = b->tri2_off; a.tri = b->tri2; a.loose_deg = loose_deg; a.tight_deg = tight_deg; a.height_factor = height_factor;
+    a.tri_off = b->tri2_off; a.tri = b->tri2; a.tri_cnt = b->tri2_cnt; a.loose_deg = loose_deg; a.tight_deg = tight_deg; a.height_factor = height_factor;
     a.tri_height = tri_height; a.tri_flags = tri_flags; a.height_level = height_level; a.status = status; a.n_kept = n_kept;
     if (max_tri <= 0) max_tri = 2 * (int64_t)b->max_feat;
     size_t lds = 24u * (size_t)((b->max_feat + 1) & ~1);
     if (lds < 4u * 2048) lds = 4u * 2048;                        // (the histogram of the median search reuses the vertex planes)
     lds += 9u * (size_t)max_tri + 32 + 4u * 32 + 16;
-    if ((rc = rs_prepare(flat_selection_kernel, lds))) return rc;
-    hipLaunchKernelGGL(flat_selection_kernel, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
+    if ((rc = rs_prepare(flat_selection_kernel<false>, lds))) return rc;
+    hipLaunchKernelGGL(flat_selection_kernel<false>, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
     return check_launch("flat_selection_kernel");
+}
+
+int mvosr_flat_ransac_batch(mvosr_ctx *ctx, const mvosr_batch *b, const int32_t *keep, const mvosr_rescale_params *rp,
+                            const int32_t *id_triples, const int64_t *frame_ids, const int32_t *dt_status,
+                            const mvosr_rescale_outputs *o, int64_t max_tri) {
+    if (!ctx || !b || !rp || !o) return set_error(MVOSR_ERR_ARG, "flat_ransac: null argument");
+    if (!o->raw_scale || !o->height_level || !o->model || !o->best_ic || !o->used || !o->n_kept || !o->status)
+        return set_error(MVOSR_ERR_ARG, "flat_ransac: a required output is null");
+    if (!b->feat_off || !b->feat_cnt || !b->x || !b->y || !b->z || !b->tri2_off || !b->tri2) return set_error(MVOSR_ERR_ARG, "flat_ransac: missing x/y/z/tri2");
+    if (rp->n_hyp < 1 || rp->n_hyp > kMaxHyp) return set_error(MVOSR_ERR_ARG, "flat_ransac: n_hyp must be in 1..%d", kMaxHyp);
+    if (rp->ransac_min_points < 3) return set_error(MVOSR_ERR_ARG, "flat_ransac: ransac_min_points < 3");
+    if (b->max_feat > 65535) return set_error(MVOSR_ERR_TOO_LARGE, "flat_ransac: vertex ids are 16-bit in the point list");
+    if (b->n_frames <= 0) return MVOSR_OK;
+    int rc = ctx_activate(ctx);
+    if (rc) return rc;
+    g_rs_max_lds = ctx->max_lds_per_block;
+    if (max_tri <= 0) max_tri = 2 * (int64_t)b->max_feat;
+    FlatArgs a = {};
+    a.n_frames = b->n_frames; a.feat_off = b->feat_off; a.feat_cnt = b->feat_cnt; a.x = b->x; a.y = b->y; a.z = b->z;
+    a.tri_off = b->tri2_off; a.tri = b->tri2; a.tri_cnt = b->tri2_cnt;
+    a.loose_deg = rp->loose_deg; a.tight_deg = rp->tight_deg; a.height_factor = rp->height_factor;
+    a.tri_height = o->tri_height; a.tri_flags = o->tri_flags; a.height_level = o->height_level; a.status = o->status; a.n_kept = o->n_kept;
+    a.keep = keep; a.dt_status = dt_status; a.id_triples = id_triples; a.frame_ids = frame_ids;
+    a.n_hyp = rp->n_hyp; a.ransac_min_points = rp->ransac_min_points; a.max_tri = (int32_t)max_tri;
+    a.threshold = rp->threshold; a.goal_fraction = rp->goal_fraction; a.absolute_reference = rp->absolute_reference;
+    a.seed = rp->seed; a.frame_base = rp->frame_base;
+    a.raw_scale = o->raw_scale; a.model = o->model; a.best_ic = o->best_ic; a.used = o->used; a.hyp_counts = o->hyp_counts;
+    // heights (reused by the 16-bit point list: 6 B per row <= 8), scalars, planes, histogram, flags, hypotheses
+    const size_t lds = 8u * (size_t)max_tri + 32 + 4u * 32 + 24u * (size_t)((b->max_feat + 1) & ~1) + 4u * 2048 + (size_t)max_tri + 32
+                       + 36u * (size_t)rp->n_hyp + 16;
+    if ((rc = rs_prepare(flat_selection_kernel<true>, lds))) return rc;
+    hipLaunchKernelGGL(flat_selection_kernel<true>, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
+    return check_launch("flat_selection_kernel<device>");
+}
+
+int mvosr_slew_median(mvosr_ctx *ctx, const double *raw, const int32_t *apply, int64_t n, double slew, double scale_in,
+                      int window, const double *queue_in, int n_queue, double *pushed, double *filtered) {
+    if (!ctx || (n > 0 && (!raw || !apply || !pushed || !filtered))) return set_error(MVOSR_ERR_ARG, "slew_median: null argument");
+    if (n <= 0) return MVOSR_OK;
+    int rc = ctx_activate(ctx);
+    if (rc) return rc;
+    hipLaunchKernelGGL(slew_kernel, dim3(1), dim3(kWave), 0, ctx_stream(ctx), raw, apply, n, slew, scale_in, pushed);
+    if ((rc = check_launch("slew_kernel"))) return rc;
+    return mvosr_window_median(ctx, pushed, n, window, queue_in, n_queue, filtered);    // np.median(self.scale_queue), rescale.py:178
 }
 
 static int launch_ransac(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,

@@ -19,24 +19,38 @@ deterministic function of the sample triples.  Here the triples are drawn on the
 reference's behaviour) or supplied by ``sampler(M) -> (H,3)`` — and the GPU evaluates all hypotheses
 and replays the reference's sequential best/stop rule.  With the same triples the results equal the
 reference's (tests/golden/rescale.npz); without, agreement is statistical only.
+
+``triangulation="gpu"`` is the device-resident path: C packer -> ONE upload -> Delaunay #1 (mvosr_delaunay_batch) ->
+GraphChecker vote with the decision made on the device (mvosr_graph_keep_batch) -> Delaunay #2 over the survivors, seeded
+-> flat_selection + RANSAC plane in one kernel per frame (mvosr_flat_ransac_batch) -> after the last chunk the slew
+limiter and the window median on the device (mvosr_slew_median).  No host step between the stages and NO DECLARED
+DEVIATION: the vote's edge potential is symmetric, so its mask is a function of the triangle SET (graph.py:18-36,124-145);
+flat_selection keeps a set of triangles (rescale.py:75-96); only the order of its point list (:101) follows the rows,
+and the RANSAC draws list positions uniformly (ransac.py:10) — here from a counter-based sequence keyed by
+``ransac_seed`` (None: OS entropy, the reference's behaviour).  ``triangulation="scipy", sampling="device"`` runs the
+same kernels on SciPy's triangulations brought to the same row form, with bit-identical results.
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 import random
 from collections import deque
 
 import numpy as np
 
 from . import _lib
+from . import constants as K
 from . import packing
-from .engine import DeviceBatch, ScaleEngine
+from .engine import DeviceBatch, ScaleEngine, frame_tables, pack_upload_native
 
 EDGE_POTENTIAL = [[3, 1], [2, 2], [2, 2], [0, 4]]     # rescale.py:32
 VANISH = 185                                          # rescale.py:30
 RANSAC_ITERATIONS = 100                               # rescale.py:155
 RANSAC_THRESHOLD = 0.005                              # rescale.py:155
 RANSAC_GOAL = 0.8                                     # estimate_road_norm.py:68
+RANSAC_MIN_POINTS = 12                                # rescale.py:152
+MIN_VALID_FOR_RETRI = 10                              # rescale.py:133
 SLEW = 0.3                                            # rescale.py:169-172
 
 
@@ -66,7 +80,7 @@ def good_bits(edge_potential=EDGE_POTENTIAL, prob_threshold=0.6):
 
 class ScaleEstimator:
     def __init__(self, absolute_reference, window_size=6, device=0, ransac_seed=None, sampler=None,
-                 delaunay_workers=None, verbose=False):
+                 delaunay_workers=None, verbose=False, triangulation="scipy", sampling=None):
         # reference attributes (rescale.py:24-35)
         self.absolute_reference = absolute_reference
         self.camera_pitch = 0
@@ -78,6 +92,8 @@ class ScaleEstimator:
         # build-side state
         self.verbose = verbose
         self.delaunay_workers = delaunay_workers
+        if delaunay_workers is None or delaunay_workers > 1:
+            packing.start_pool(delaunay_workers)     # fork the host stage's workers BEFORE the GPU runtime starts its threads
         self.engine = ScaleEngine(absolute_reference, device=device, camera_pitch=0.0)
         self.ctx = self.engine.ctx
         self._good_bits = good_bits()
@@ -85,6 +101,25 @@ class ScaleEstimator:
         self._sampler = sampler
         self.height_level = None
         self.last = {}
+        # triangulation "scipy": both Delaunay calls on the host, as the reference; "gpu": mvosr_delaunay_batch, everything
+        # device-resident.  sampling "host": the triples are drawn here with Python's random, by LIST POSITION in SciPy's row
+        # order (replays a recorded reference run); "device": the kernel's counter-based sequence over rows in canonical
+        # form (the default — and the only choice — with "gpu").
+        if triangulation not in ("scipy", "gpu"):
+            raise ValueError("triangulation must be 'scipy' or 'gpu'")
+        if sampling is None:
+            sampling = "device" if triangulation == "gpu" else "host"
+        if sampling not in ("host", "device"):
+            raise ValueError("sampling must be 'host' or 'device'")
+        if triangulation == "gpu" and sampling == "host":
+            raise ValueError("triangulation='gpu' draws its samples on the device (the point list never visits the host)")
+        if sampling == "device" and sampler is not None:
+            raise ValueError("a host sampler needs sampling='host'; the device path takes id_triples per call")
+        self.triangulation, self.sampling = triangulation, sampling
+        self._seed = int.from_bytes(os.urandom(8), "little") if ransac_seed is None else int(ransac_seed) & ((1 << 64) - 1)
+        self._frame_counter = 0                     # frames this estimator has processed: the sample sequence's counter
+        self.stage_outputs = False                  # device path, per-frame calls: keep masks / rows / flags in self.last
+        self.last_declined = 0
 
     def initial_estimation(self, motion_matrix):
         return 0                                                   # rescale.py:36-38
@@ -258,10 +293,276 @@ class ScaleEstimator:
 
     def scale_calculation(self, feature3d, feature2d, img=None):
         """rescale.py:191-193."""
-        s, e = self.scale_calculation_batch([feature3d], [feature2d])
+        s, e = self.scale_calculation_batch([feature3d], [feature2d], stage=self.stage_outputs)
         return s[0], 1
 
-    def scale_calculation_batch(self, feature3ds, feature2ds):
-        """Equivalent to scale_calculation per frame, in order, with one launch per GPU stage."""
+    def scale_calculation_batch(self, feature3ds, feature2ds, id_triples=None, stage=False):
+        """Equivalent to scale_calculation per frame, in order.  sampling="host": one launch per GPU stage with host
+        steps between them.  sampling="device": the batch streams through the device-resident stages in chunks
+        (``id_triples``: per frame an (H,3) array of survivor-numbered vertex ids replacing the draw — a recorded
+        reference run mapped to point ids; ``stage``: keep the per-frame stage outputs in ``self.last``)."""
+        if self.sampling == "device":
+            return self._stream_device(feature3ds, feature2ds, id_triples, stage)
+        if id_triples is not None:
+            raise ValueError("id_triples belong to sampling='device'")
         sel = self.feature_selection_batch(feature3ds, feature2ds)
         return self.scale_calculation_ransac_batch([s[0] for s in sel])
+
+    # ---- the device-resident path ------------------------------------------------------------------------------
+    GPU_CHUNK = 8192            # frames per chunk, at most (a call of F frames uses chunks of F/4, 512 at least)
+    GPU_CHUNK_POINTS = 10000000 # ... and features per chunk
+    GPU_PIPELINE = 2            # chunks queued on the device behind the one being collected
+    N_HYP = RANSAC_ITERATIONS
+
+    def _rescale_params(self, frame_base):
+        return _lib.RescaleParams(self._good_bits, MIN_VALID_FOR_RETRI, -80.0, -85.0, 0.9, RANSAC_MIN_POINTS, self.N_HYP,
+                                  RANSAC_THRESHOLD, RANSAC_GOAL, float(self.absolute_reference), self._seed, int(frame_base))
+
+    def _launch_flat_ransac(self, db, keep_ptr, dt2_ptr, frame_base, frame_ids, id_triples, stage, max_tri):
+        """mvosr_flat_ransac_batch over a DeviceBatch; returns the outputs' block (download queued)."""
+        ctx, F, H = self.ctx, db.n_frames, self.N_HYP
+        spec = [("raw_scale", F, np.float64), ("height_level", F, np.float64), ("model", (F, 4), np.float64),
+                ("best_ic", F, np.int32), ("used", F, np.int32), ("n_kept", F, np.int32), ("status", F, np.int32)]
+        out = ctx.block(spec)
+        side = []
+        o = _lib.RescaleOutputs(out["raw_scale"].ptr, out["height_level"].ptr, out["model"].ptr, out["best_ic"].ptr,
+                                out["used"].ptr, out["n_kept"].ptr, out["status"].ptr, None, None, None)
+        flags = None
+        if stage:
+            flags = ctx.block([("tri_flags", max(db.n_rows2, 1), np.uint8)])
+            o.tri_flags = flags["tri_flags"].ptr
+        d_ids = d_tr = None
+        if frame_ids is not None:
+            d_ids = ctx.block([("frame_ids", F, np.int64)])
+            d_ids.upload({"frame_ids": np.asarray(frame_ids, dtype=np.int64)})
+            side.append(d_ids)
+        if id_triples is not None:
+            t = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.int32).reshape(H, 3) for x in id_triples]))
+            d_tr = ctx.block([("id_triples", (F, H, 3), np.int32)])
+            d_tr.upload({"id_triples": t})
+            side.append(d_tr)
+        rp = self._rescale_params(frame_base)
+        b = db.struct()
+        _lib.check(ctx.lib.mvosr_flat_ransac_batch(ctx.handle, C.byref(b), keep_ptr, C.byref(rp),
+                                                   d_tr["id_triples"].ptr if d_tr is not None else None,
+                                                   d_ids["frame_ids"].ptr if d_ids is not None else None, dt2_ptr,
+                                                   C.byref(o), int(max_tri)), "mvosr_flat_ransac_batch")
+        out.prefetch()
+        out.mark(True)
+        for blk in side:
+            blk.mark(True)
+        return out, flags, side
+
+    def _chunk_dev_gpu(self, f3s, f2s, frame_base, id_triples, stage):
+        """One chunk, both triangulations on the device: pack (C packer into page-locked memory) -> ONE upload -> every
+        launch and the download of the results queued; nothing is waited for here."""
+        ctx, lib = self.ctx, self.ctx.lib
+        tables = frame_tables(f3s, f2s) if len(f3s) else None
+        if tables is not None:
+            pf, blk = pack_upload_native(ctx, f3s, f2s, self.vanish, None, tables=tables)             # rescale.py:115-117
+            too_large = pf.max_feat > self._max_points()
+            if too_large:
+                blk.free()
+                return {"gpu": False}
+            db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk)
+        else:
+            pf = packing.pack_features(f3s, f2s, self.vanish)
+            if pf.max_feat > self._max_points() or pf.n_frames == 0:
+                return {"gpu": False}
+            db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True)
+        bufs = db.bufs
+        db.info.invalidate()
+        _lib.check(lib.mvosr_delaunay_batch(ctx.handle, db.n_frames, bufs["feat_off"].ptr, bufs["feat_cnt"].ptr, bufs["u"].ptr,
+                                            bufs["v"].ptr, None, int(db.max_feat), bufs["tri_off"].ptr, bufs["tri1"].ptr,
+                                            bufs["tri1_cnt"].ptr, None, bufs["dt1_status"].ptr), "mvosr_delaunay_batch (first triangulation)")
+        bs = db.struct()
+        keep = bufs["vote_counters"]                                        # (the block's per-feature int32 plane: here the keep flags)
+        _lib.check(lib.mvosr_graph_keep_batch(ctx.handle, C.byref(bs), C.c_uint32(self._good_bits), MIN_VALID_FOR_RETRI,
+                                              bufs["dt1_status"].ptr, keep.ptr, None, None), "mvosr_graph_keep_batch")   # graph.py:18-36, rescale.py:133
+        _lib.check(lib.mvosr_delaunay_batch_seeded(ctx.handle, db.n_frames, bufs["feat_off"].ptr, bufs["feat_cnt"].ptr, bufs["u"].ptr,
+                                                   bufs["v"].ptr, keep.ptr, int(db.max_feat), bufs["tri_off"].ptr, bufs["tri2"].ptr,
+                                                   bufs["tri2_cnt"].ptr, bufs["n2_expected"].ptr, bufs["dt2_status"].ptr,
+                                                   bufs["tri_off"].ptr, bufs["tri1"].ptr, bufs["tri1_cnt"].ptr),
+                   "mvosr_delaunay_batch_seeded (second triangulation)")       # rescale.py:134-137
+        db.n_rows2 = 2 * pf.total_padded
+        out, flags, side = self._launch_flat_ransac(db, keep.ptr, bufs["dt2_status"].ptr, frame_base, None, id_triples, stage,
+                                                    2 * int(db.max_feat))
+        db.prefetch_info()
+        db.mark()
+        return {"gpu": True, "pf": pf, "db": db, "out": out, "flags": flags, "side": side}
+
+    def _max_points(self):
+        """Largest frame the device-resident kernels take (flat_selection + RANSAC hold a frame's survivors, rows'
+        heights and flags in one workgroup's LDS: 42 B per feature + 12 KB)."""
+        return min(packing.delaunay_gpu_max_points(), int(self.ctx.lib.mvosr_delaunay_lds_points()),
+                   (self.ctx.lds_per_block - 14000 - 36 * self.N_HYP) // 43)
+
+    def _chunk_dev_host(self, f3s, f2s, frame_base, frame_ids, id_triples, stage):
+        """The same kernels on the host's triangulations (SciPy's rows in canonical form): triangulation="scipy" with
+        sampling="device", and the frames the device triangulation declined.  Synchronous."""
+        ctx, lib = self.ctx, self.ctx.lib
+        pf = packing.pack_features(f3s, f2s, self.vanish)                                   # rescale.py:115-117
+        pf.extra["canonical"] = True
+        packing.attach_tri1(pf, None, self.delaunay_workers)                                # :124
+        db = DeviceBatch(ctx, pf, with_tri2=False)
+        F = pf.n_frames
+        aux = ctx.block([("keep", max(pf.total_padded, 1), np.int32)])
+        bs = db.struct()
+        _lib.check(lib.mvosr_graph_keep_batch(ctx.handle, C.byref(bs), C.c_uint32(self._good_bits), MIN_VALID_FOR_RETRI, None,
+                                              aux["keep"].ptr, None, None), "mvosr_graph_keep_batch")
+        keep = aux["keep"].download()
+        masks = [keep[pf.frame_slice(f)] >= 0 for f in range(F)]
+        packing.attach_tri2(pf, None, masks, self.delaunay_workers)                         # :134-137
+        db.set_tri2(pf)
+        db.n_rows2 = int(pf.tri2_off[-1])
+        max_tri = int(np.max(np.diff(pf.tri2_off))) if F else 0
+        out, flags, side = self._launch_flat_ransac(db, aux["keep"].ptr, None, frame_base, frame_ids, id_triples, stage, max(max_tri, 1))
+        host_errors = dict(pf.extra["tri2_errors"])
+        host_errors.update(pf.extra["tri1_errors"])
+        res = self._collect(out, F)
+        st = {"pf": pf, "db": db, "out": out, "flags": flags, "side": side + [aux], "host_errors": host_errors, "keep": keep}
+        if stage:
+            res["stage"] = self._stage_outputs(st, host=True)
+        self._free_chunk(st)
+        res["host_errors"] = host_errors
+        return res
+
+    @staticmethod
+    def _collect(out, F):
+        return {k: out[k].download() for k in ("raw_scale", "height_level", "model", "best_ic", "used", "n_kept", "status")}
+
+    def _stage_outputs(self, st, host=False):
+        """Per frame: the vote's mask (graph.py:35), the second triangulation's rows and flat_selection's flags."""
+        pf, db = st["pf"], st["db"]
+        F = pf.n_frames
+        fl = st["flags"]["tri_flags"].download()
+        if host:
+            keep = st["keep"]
+            rows = [pf.tri2[pf.tri2_off[f]:pf.tri2_off[f + 1]] for f in range(F)]
+            flags = [fl[pf.tri2_off[f]:pf.tri2_off[f + 1]] for f in range(F)]
+        else:
+            keep = db.bufs["vote_counters"].download()
+            tri2, cnt2 = db.bufs["tri2"].download(), db.bufs["tri2_cnt"].download()
+            toff = 2 * np.asarray(pf.feat_off, dtype=np.int64)
+            rows = [tri2[toff[f]:toff[f] + cnt2[f]] for f in range(F)]
+            flags = [fl[toff[f]:toff[f] + cnt2[f]] for f in range(F)]
+        return {"valid": [keep[pf.frame_slice(f)] > 0 for f in range(F)], "tris2": rows, "tri_flags": flags}
+
+    @staticmethod
+    def _free_chunk(st):
+        for k in ("out", "flags"):
+            if st.get(k) is not None:
+                st[k].free()
+        for blk in st.get("side") or []:
+            blk.free()
+        if st.get("db") is not None:
+            st["db"].free()
+
+    def _chunk_dev_finish(self, st, f3s, f2s, frame_base, id_triples, stage):
+        """Results of a chunk started by ``_chunk_dev_gpu``; frames whose triangulation the device declined (degenerate point
+        sets, fewer than 3 points) are redone on the host's triangulations with their own sample counters."""
+        F = len(f3s)
+        if not st["gpu"]:
+            return self._chunk_dev_host(f3s, f2s, frame_base, None, id_triples, stage)
+        db = st["db"]
+        res = self._collect(st["out"], F)
+        s1, s2 = db.triangulation_status()
+        redo = np.nonzero((s1 != 0) | (s2 != 0))[0]
+        self.last_declined += len(redo)
+        if stage:
+            res["stage"] = self._stage_outputs(st)
+        self._free_chunk(st)
+        res["host_errors"] = {}
+        if len(redo):
+            sub = self._chunk_dev_host([f3s[f] for f in redo], [f2s[f] for f in redo], 0, frame_base + redo,
+                                       None if id_triples is None else [id_triples[f] for f in redo], stage)
+            for k in ("raw_scale", "height_level", "model", "best_ic", "used", "n_kept", "status"):
+                res[k][redo] = sub[k]
+            res["host_errors"] = {int(redo[j]): e for j, e in sub["host_errors"].items()}
+            if stage:
+                for k in ("valid", "tris2", "tri_flags"):
+                    for j, f in enumerate(redo):
+                        res["stage"][k][f] = sub["stage"][k][j]
+        return res
+
+    def _stream_device(self, feature3ds, feature2ds, id_triples, stage):
+        F = len(feature3ds)
+        if F == 0:
+            return np.zeros(0), np.zeros(0)
+        base = self._frame_counter
+        self.last_declined = 0
+        results, bounds = [], []
+        if self.triangulation == "gpu":
+            C_ = int(min(self.GPU_CHUNK, max(512, -(-F // 4))))
+            queue, a = [], 0
+            while a < F:
+                b = min(F, a + C_)
+                tot = np.cumsum(np.fromiter((len(x) for x in feature3ds[a:b]), dtype=np.int64, count=b - a))
+                b = min(b, a + max(int(np.searchsorted(tot, self.GPU_CHUNK_POINTS, side="right")), 1))
+                tr = None if id_triples is None else id_triples[a:b]
+                queue.append((self._chunk_dev_gpu(feature3ds[a:b], feature2ds[a:b], base + a, tr, stage), a, b))
+                bounds.append((a, b))
+                while len(queue) > self.GPU_PIPELINE:
+                    st, pa, pb = queue.pop(0)
+                    results.append(self._chunk_dev_finish(st, feature3ds[pa:pb], feature2ds[pa:pb], base + pa,
+                                                          None if id_triples is None else id_triples[pa:pb], stage))
+                a = b
+            while queue:
+                st, pa, pb = queue.pop(0)
+                results.append(self._chunk_dev_finish(st, feature3ds[pa:pb], feature2ds[pa:pb], base + pa,
+                                                      None if id_triples is None else id_triples[pa:pb], stage))
+        else:
+            C_ = 2048
+            for a in range(0, F, C_):
+                b = min(F, a + C_)
+                bounds.append((a, b))
+                results.append(self._chunk_dev_host(feature3ds[a:b], feature2ds[a:b], base + a, None,
+                                                    None if id_triples is None else id_triples[a:b], stage))
+        cat = lambda k: np.concatenate([r[k] for r in results])
+        raw, status, level = cat("raw_scale"), cat("status"), cat("height_level")
+        host_errors = {}
+        for (a, _), r in zip(bounds, results):
+            host_errors.update({a + f: e for f, e in r["host_errors"].items()})
+        self.last = {"model": cat("model"), "best_ic": cat("best_ic"), "used": cat("used"), "n_kept": cat("n_kept"),
+                     "status": status, "height_level": level, "raw_scale": raw}
+        if stage:
+            for k in ("valid", "tris2", "tri_flags"):
+                self.last[k] = [x for r in results for x in r["stage"][k]]
+        return self._push_device(raw, status, level, host_errors)
+
+    def _push_device(self, raw, status, level, host_errors):
+        """The cross-frame tail (rescale.py:169-178) on the device over the frames before the first one at which the
+        reference raises; then that frame's exception."""
+        F = len(raw)
+        bad = np.isin(status, (K.ST_ERR_SINGULAR, K.ST_ERR_MASK, K.ST_ERR_EMPTY))
+        for f in host_errors:
+            bad[f] = True
+        n_ok = int(np.argmax(bad)) if bad.any() else F
+        ctx = self.ctx
+        filtered = np.zeros(0)
+        if n_ok:
+            io = ctx.block([("raw", n_ok, np.float64), ("apply", n_ok, np.int32)])
+            io.upload({"raw": raw[:n_ok], "apply": (status[:n_ok] == 0).astype(np.int32)})
+            res = ctx.block([("pushed", n_ok, np.float64), ("filtered", n_ok, np.float64)])
+            q = np.ascontiguousarray(np.asarray(list(self.scale_queue), dtype=np.float64))
+            _lib.check(ctx.lib.mvosr_slew_median(ctx.handle, io["raw"].ptr, io["apply"].ptr, n_ok, SLEW, float(self.scale),
+                                                 int(self.window_size), _lib.addr(q) if q.size else None, int(q.size),
+                                                 res["pushed"].ptr, res["filtered"].ptr), "mvosr_slew_median")
+            pushed, filtered = res["pushed"].download(), res["filtered"].download()
+            io.free()
+            res.free()
+            self.scale = float(pushed[-1])                                                  # :169-174
+            tail = list(self.scale_queue) + list(pushed[max(0, n_ok - self.window_size):])
+            self.scale_queue.clear()
+            self.scale_queue.extend(tail[-self.window_size:])                               # :175-177
+            self.height_level = level[n_ok - 1]                                             # :92
+        self._frame_counter += n_ok + (1 if n_ok < F else 0)
+        if n_ok < F:
+            if n_ok in host_errors and isinstance(host_errors[n_ok], Exception):
+                raise host_errors[n_ok]
+            if status[n_ok] == K.ST_ERR_SINGULAR:
+                raise np.linalg.LinAlgError("Singular matrix (frame %d of the batch)" % n_ok)  # :79
+            if status[n_ok] == K.ST_ERR_MASK:
+                raise _lib.MvosrLibraryError("triangulation with an out-of-range vertex id (frame %d of the batch)" % n_ok)
+            raise ValueError("frame %d of the batch has no triangles below the vanishing row" % n_ok)
+        return filtered, np.ones(F)

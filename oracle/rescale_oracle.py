@@ -187,17 +187,64 @@ def scale_from_model(m, absolute_reference):
     return absolute_reference / (1 / norm_norm)
 
 
+_M64 = (1 << 64) - 1
+
+
+def mix64(x):
+    """splitmix64's finaliser (the product's counter-based sample sequence, include/mvosr.h: mvosr_flat_ransac_batch)."""
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def device_triples(seed, frame_counter, m, n_hyp=RANSAC_ITERATIONS):
+    """The list positions hypothesis h = 0..n_hyp-1 of frame `frame_counter` draws from a list of m points under key
+    `seed`: three distinct positions, uniform (the reference draws them with random.sample from OS entropy,
+    /root/reference/src/thirdparty/Ransac/ransac.py:6,10 — any uniform draw realises it)."""
+    key = mix64((seed ^ ((frame_counter * 0xD1B54A32D192ED03) & _M64)) & _M64)
+    out = np.zeros((n_hyp, 3), dtype=np.int64)
+    for h in range(n_hyp):
+        r = [mix64((key + 4 * h + k) & _M64) for k in range(3)]
+        i0 = (r[0] * m) >> 64
+        i1 = (r[1] * (m - 1)) >> 64
+        if i1 >= i0:
+            i1 += 1
+        i2 = (r[2] * (m - 2)) >> 64
+        lo, hi = min(i0, i1), max(i0, i1)
+        if i2 >= lo:
+            i2 += 1
+        if i2 >= hi:
+            i2 += 1
+        out[h] = (i0, i1, i2)
+    return out
+
+
+def canonical_rows(tri):
+    """Vertex ids ascending inside a row, rows in lexicographic order: the row form of the device triangulation, a
+    function of the triangle set alone.  GraphChecker's vote (graph.py:18-36,124-145, a symmetric edge potential) and
+    flat_selection's kept SET (rescale.py:75-96) do not depend on the row form; the ORDER of flat_selection's point list
+    (:101) does, and with it which points a given sequence of sample positions picks — immaterial for a sampler that
+    draws positions uniformly."""
+    t = np.sort(np.asarray(tri, dtype=np.int32).reshape(-1, 3), axis=1)
+    return t if t.shape[0] == 0 else np.ascontiguousarray(t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))])
+
+
 class OracleRescaleEstimator:
     """Same call surface as rescale.ScaleEstimator; `sampler(n) -> (H,3)` supplies the RANSAC
-    index triples for a list of n points."""
+    index triples for a list of n points.  `device_seed` (instead of a sampler): the product's counter-based sample
+    sequence (device_triples) over rows in canonical form — the restatement of the device-resident path."""
 
-    def __init__(self, absolute_reference, window_size=6, sampler=None):
+    def __init__(self, absolute_reference, window_size=6, sampler=None, device_seed=None, canonical=None):
         self.absolute_reference = absolute_reference
         self.window_size = window_size
         self.vanish = VANISH
         self.scale = 1
         self.scale_queue = deque()
         self.sampler = sampler
+        self.device_seed = device_seed
+        self.canonical = (device_seed is not None) if canonical is None else canonical
+        self.frame_counter = 0
         self.last = {}
 
     def initial_estimation(self, motion_matrix):
@@ -208,18 +255,26 @@ class OracleRescaleEstimator:
         low = feature2d[:, 1] > self.vanish                        # :115
         f2, f3 = feature2d[low], feature3d[low]
         tri = Delaunay(f2).simplices                               # :124
+        if self.canonical:
+            tri = canonical_rows(tri)
         valid, good, total = graph_inliers(f2[:, 1], f3[:, 2], tri)
         self.last.update(tri1=tri, valid=valid, good=good, total=total)
         if np.sum(valid) > MIN_VALID_FOR_RETRI:                    # :133
             f2, f3 = f2[valid], f3[valid]
             tri = Delaunay(f2).simplices
+            if self.canonical:
+                tri = canonical_rows(tri)
         fs = flat_selection(f3, tri)
         self.last.update(tri2=tri, flat=fs)
         return f3[fs.ids], fs.heights_loose
 
     def scale_calculation_ransac(self, pts):
+        self.last.pop("model", None)
         if pts.shape[0] >= RANSAC_MIN_POINTS:                      # :152
-            triples = self.sampler(pts.shape[0])
+            if self.device_seed is not None:
+                triples = device_triples(self.device_seed, self.frame_counter, pts.shape[0])
+            else:
+                triples = self.sampler(pts.shape[0])
             m, ic, used = run_ransac(np.array(pts), triples)
             self.last.update(model=m, best_ic=ic, used=used)
             scale = scale_from_model(m, self.absolute_reference)
@@ -232,6 +287,7 @@ class OracleRescaleEstimator:
         self.scale_queue.append(self.scale)                        # :175-178
         if len(self.scale_queue) > self.window_size:
             self.scale_queue.popleft()
+        self.frame_counter += 1
         return np.median(self.scale_queue), 1
 
     def scale_calculation(self, feature3d, feature2d, img=None):

@@ -1455,6 +1455,171 @@ def test_rescale_variant_batch_equals_per_frame(gpu):
     assert list(a.scale_queue) == list(b.scale_queue)
 
 
+def _rescale_frames(sizes, base_seed=2468):
+    from mvoscalerecovery_amd import synth
+    return [synth.synth_frame(i, n, base_seed=base_seed, upper_fraction=0.1) for i, n in enumerate(sizes)]
+
+
+def _check_rescale_device_against_oracle(est, ref, frames, batch):
+    """est: product estimator in a device-sampling mode with stage outputs; ref: OracleRescaleEstimator(device_seed=...)."""
+    want, snap = [], []
+    for f3, f2 in frames:
+        want.append(ref.scale_calculation(f3, f2)[0])
+        snap.append(dict(valid=ref.last["valid"].copy(), ids=ref.last["flat"].ids.copy(), level=ref.last["flat"].height_level,
+                         model=None if "model" not in ref.last else np.array(ref.last["model"]),
+                         best_ic=ref.last.get("best_ic"), used=ref.last.get("used")))
+    if batch:
+        got, sd = est.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames], stage=True)
+        lasts = [est.last] * len(frames)
+        idx = list(range(len(frames)))
+    else:
+        est.stage_outputs = True
+        got, lasts, idx = [], [], []
+        for f3, f2 in frames:
+            got.append(est.scale_calculation(f3, f2)[0])
+            lasts.append(dict(est.last))
+            idx.append(0)
+    for i, (w, sn) in enumerate(zip(want, snap)):
+        L, j = lasts[i], idx[i]
+        assert np.array_equal(L["valid"][j], sn["valid"]), i                                  # graph.py:35
+        ids = L["tris2"][j][(L["tri_flags"][j] & 4) != 0].reshape(-1)
+        assert np.array_equal(ids, sn["ids"]), i                                              # rescale.py:101 (canonical rows both sides)
+        np.testing.assert_allclose(L["height_level"][j], sn["level"], rtol=1e-9)
+        if sn["model"] is not None:
+            assert int(L["status"][j]) == 0
+            m_ref = sn["model"] if sn["model"][1] >= 0 else -sn["model"]
+            np.testing.assert_allclose(L["model"][j], m_ref, rtol=1e-7, atol=1e-11)
+            assert int(L["best_ic"][j]) == sn["best_ic"] and int(L["used"][j]) == sn["used"], i
+        else:
+            assert int(L["status"][j]) == 11
+        assert abs(got[i] - w) <= 1e-9 * abs(w), (i, got[i], w)
+    assert list(est.scale_queue) == pytest.approx(list(ref.scale_queue), rel=1e-9)
+
+
+@pytest.mark.parametrize("batch", [True, False])
+def test_rescale_device_resident_vs_oracle(gpu, batch):
+    """rescale.ScaleEstimator(triangulation="gpu") — Delaunay, vote, Delaunay, flat_selection + RANSAC, slew limiter and
+    window median all on the device — against the oracle's restatement of /root/reference/src/rescale.py:113-178 with the
+    same counter-based sample sequence and SciPy's triangulations in canonical row form: masks, point lists, inlier
+    counts and consumed hypotheses exact; heights / planes / scales to 1e-9 (LU vs LAPACK's inverse, cross product vs SVD)."""
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    from oracle import rescale_oracle as ro
+    frames = _rescale_frames([400, 640, 900, 1300, 2000, 150, 2000, 777, 1024, 2000, 333, 1800])
+    est = ScaleEstimator(1.75, window_size=5, triangulation="gpu", ransac_seed=1234)
+    ref = ro.OracleRescaleEstimator(1.75, window_size=5, device_seed=1234)
+    _check_rescale_device_against_oracle(est, ref, frames, batch)
+    assert est.last_declined == 0
+
+
+def test_rescale_gpu_equals_scipy_device_sampling(gpu):
+    """triangulation="gpu" and triangulation="scipy" with sampling="device" are the same function: bit-identical scales,
+    planes and counts over a ragged batch that spans several chunks of the streaming path, batch == per-frame."""
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    rng = np.random.default_rng(3)
+    frames = _rescale_frames([int(n) for n in rng.integers(120, 1500, 96)], base_seed=77)
+    f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
+    a = ScaleEstimator(1.75, window_size=5, triangulation="gpu", ransac_seed=99)
+    a.GPU_CHUNK = 20                                                  # several chunks, a pipeline
+    sa, _ = a.scale_calculation_batch(f3s, f2s)
+    b = ScaleEstimator(1.75, window_size=5, triangulation="scipy", sampling="device", ransac_seed=99)
+    sb, _ = b.scale_calculation_batch(f3s, f2s)
+    assert np.array_equal(sa, sb)
+    for k in ("model", "best_ic", "used", "n_kept", "status", "height_level", "raw_scale"):
+        assert np.array_equal(a.last[k], b.last[k], equal_nan=True), k
+    c = ScaleEstimator(1.75, window_size=5, triangulation="gpu", ransac_seed=99)
+    sc = [c.scale_calculation(f3, f2)[0] for f3, f2 in frames[:24]]
+    assert sc == list(sa[:24])
+    # two calls == one call (the window state, the running scale and the sample counter carry over)
+    d = ScaleEstimator(1.75, window_size=5, triangulation="gpu", ransac_seed=99)
+    s1, _ = d.scale_calculation_batch(f3s[:40], f2s[:40])
+    s2, _ = d.scale_calculation_batch(f3s[40:], f2s[40:])
+    assert np.array_equal(np.concatenate([s1, s2]), sa)
+    assert list(d.scale_queue) == list(a.scale_queue) and d.scale == a.scale
+
+
+def test_rescale_device_resident_reference_golden(gpu):
+    """The device-resident path against the REFERENCE's own run (tests/golden/rescale.npz: rescale.ScaleEstimator with
+    random.sample replaying recorded triples).  The recorded triples are list positions in SciPy's row order; mapped to
+    the point ids they picked (id_triples) they replay the same hypotheses on the device's canonical rows: vote masks
+    equal, kept-vertex multisets equal, inlier counts and consumed hypotheses equal, level / plane / scale to 1e-9."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    z, meta = load_npz("rescale.npz")
+    est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], triangulation="gpu", ransac_seed=0)
+    est.stage_outputs = True
+    call = -1
+    for i, fr in enumerate(meta["frames"]):
+        f3, f2 = synth.synth_frame(fr["frame_idx"], fr["n"], base_seed=fr["seed"], upper_fraction=fr["upper_fraction"])
+        ids_ref = z["f%d_ids" % i]
+        tr = None
+        if len(ids_ref) >= 12:
+            call += 1
+            tr = [ids_ref[_ransac_triples(meta["ransac_seed"], call, len(ids_ref))].astype(np.int32)]
+        s, sd = est.scale_calculation_batch([f3], [f2], id_triples=tr, stage=True)
+        assert np.array_equal(est.last["valid"][0], z["f%d_valid" % i]), i
+        ids = est.last["tris2"][0][(est.last["tri_flags"][0] & 4) != 0].reshape(-1)
+        assert np.array_equal(np.sort(ids), np.sort(ids_ref)), i
+        np.testing.assert_allclose(est.last["height_level"][0], float(z["f%d_height_level" % i]), rtol=1e-9)
+        if "f%d_model" % i in z.files:
+            m_ref = z["f%d_model" % i]
+            m_ref = m_ref if m_ref[1] >= 0 else -m_ref
+            np.testing.assert_allclose(est.last["model"][0], m_ref, rtol=1e-7, atol=1e-11)
+            assert int(est.last["best_ic"][0]) == int(z["f%d_best_ic" % i]), i
+            assert int(est.last["used"][0]) == int(z["f%d_used" % i]), i
+        assert abs(s[0] - float(z["f%d_scale" % i])) <= 1e-9 * abs(float(z["f%d_scale" % i])), (i, s)
+
+
+def test_rescale_device_resident_steady_state_allocates_nothing(gpu):
+    """A steady-state call of the device-resident path takes every buffer from the context's caches: no hipMalloc /
+    hipHostMalloc between the second and the third call over the same shapes."""
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    frames = _rescale_frames([900] * 64, base_seed=5)
+    f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
+    est = ScaleEstimator(1.75, window_size=5, triangulation="gpu", ransac_seed=1)
+    est.scale_calculation_batch(f3s, f2s)
+    est.scale_calculation_batch(f3s, f2s)
+    before = gpu.alloc_stats()
+    est.scale_calculation_batch(f3s, f2s)
+    after = gpu.alloc_stats()
+    assert after["hip_malloc"] == before["hip_malloc"] and after["host_malloc"] == before["host_malloc"], (before, after)
+
+
+def test_slew_median_kernel(gpu):
+    """mvosr_slew_median against the reference's recurrence (rescale.py:169-178) written out in Python: jumps beyond
+    +-0.3, frames without a plane, a carried-in queue, lengths around the 64-frame blocks of the kernel."""
+    import ctypes as C
+    from collections import deque
+    from mvoscalerecovery_amd import _lib
+    rng = np.random.default_rng(8)
+    for n in (1, 5, 63, 64, 65, 1000):
+        raw = rng.uniform(0.5, 3.5, n)
+        raw[rng.random(n) < 0.1] += 5.0
+        apply = (rng.random(n) > 0.2).astype(np.int32)
+        raw[apply == 0] = np.nan
+        q_in, s_in, window = [1.25, 1.5], 1.5, 5
+        scale, q, want_p, want_f = s_in, deque(q_in), [], []
+        for i in range(n):
+            if apply[i]:
+                if raw[i] - scale > 0.3:
+                    scale += 0.3
+                elif raw[i] - scale < -0.3:
+                    scale -= 0.3
+                else:
+                    scale = raw[i]
+            q.append(scale)
+            if len(q) > window:
+                q.popleft()
+            want_p.append(scale)
+            want_f.append(np.median(q))
+        io = gpu.block([("raw", n, np.float64), ("apply", n, np.int32), ("pushed", n, np.float64), ("filtered", n, np.float64)])
+        io.upload({"raw": raw, "apply": apply})
+        qa = np.array(q_in)
+        _lib.check(gpu.lib.mvosr_slew_median(gpu.handle, io["raw"].ptr, io["apply"].ptr, n, 0.3, s_in, window, _lib.addr(qa), 2,
+                                             io["pushed"].ptr, io["filtered"].ptr))
+        assert io["pushed"].download().tolist() == want_p and io["filtered"].download().tolist() == want_f, n
+        io.free()
+
+
 def test_triangle_batch_golden(gpu):
     """Row a12: the legacy per-triangle batch vs what /root/reference/src/triangle_batch.py printed."""
     from mvoscalerecovery_amd import synth, triangle_batch

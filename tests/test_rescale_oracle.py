@@ -68,3 +68,35 @@ def test_road_norm_helpers_golden():
         assert ic == c["best_ic"] and used == c["used"]
         ref = np.array(c["model"])
         assert min(np.abs(m - ref).max(), np.abs(m + ref).max()) <= 1e-12          # SVD null vector: sign is arbitrary
+
+
+def test_rescale_row_form_invariance_golden():
+    """What makes the device triangulation usable for this estimator without a declared deviation: on the reference's own
+    frames (tests/golden/rescale.npz) the vote's mask and flat_selection's kept triangles are the same whether the rows
+    are SciPy's or brought to canonical form (vertex ids ascending, rows sorted) — graph.py:18-36,124-145 is symmetric in
+    a row's vertices, rescale.py:75-96 keeps a set.  Only the ORDER of the point list (:101) follows the rows."""
+    from mvoscalerecovery_amd import synth
+    z, meta = load_npz("rescale.npz")
+    est = ro.OracleRescaleEstimator(meta["abs_ref"], window_size=meta["window"], device_seed=5)
+    for i, fr in enumerate(meta["frames"]):
+        f3, f2 = synth.synth_frame(fr["frame_idx"], fr["n"], base_seed=fr["seed"], upper_fraction=fr["upper_fraction"])
+        est.scale_calculation(f3, f2)
+        assert np.array_equal(est.last["valid"], z["f%d_valid" % i]), i
+        fs = est.last["flat"]
+        assert np.array_equal(np.sort(fs.ids), np.sort(z["f%d_ids" % i])), i
+        assert abs(fs.height_level - float(z["f%d_height_level" % i])) <= 1e-12 * abs(fs.height_level)
+        assert np.array_equal(ro.canonical_rows(est.last["tri2"]), est.last["tri2"])
+
+
+def test_device_sample_sequence():
+    """The counter-based sample sequence: three distinct positions below m, a function of (seed, frame counter,
+    hypothesis) only, and close to uniform over positions."""
+    a = ro.device_triples(7, 3, 50)
+    assert a.shape == (100, 3) and a.min() >= 0 and a.max() < 50
+    assert all(len(set(r)) == 3 for r in a.tolist())
+    assert np.array_equal(a, ro.device_triples(7, 3, 50)) and not np.array_equal(a, ro.device_triples(7, 4, 50))
+    assert not np.array_equal(a, ro.device_triples(8, 3, 50))
+    small = ro.device_triples(1, 0, 12, n_hyp=2000)
+    counts = np.bincount(small.reshape(-1), minlength=12)
+    assert counts.min() > 400 and counts.max() < 600                      # 500 expected per position
+    assert ro.mix64(0) == 0xE220A8397B1DCDAF                              # splitmix64's first output for state 0
