@@ -297,6 +297,50 @@ def e2e_leg(args, device, sizes, seed, budget_frames):
                     "process pool (overlapped with the GPU stages chunk by chunk), uploads, kernels, window median"}
 
 
+_E2E_FRAMES = {}
+
+
+def _e2e_frames(sizes, seed, n_frames):
+    """The end-to-end legs' input: a list of n_frames per-frame arrays drawn from a pool of DISTINCT synthetic frames larger
+    than the host's last-level cache (4096 frames of 2000 features = 330 MB), so that the packer streams its input from
+    DRAM as it would for a real sequence; the pool is repeated to n_frames (its size is reported as distinct_frames)."""
+    from mvoscalerecovery_amd import synth
+    key = (tuple(sizes[:8]), len(sizes), seed, n_frames)
+    if key not in _E2E_FRAMES:
+        npool = min(n_frames, 4096 if max(sizes) <= 6000 else 16)
+        pool = [synth.synth_frame(200000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(npool)]
+        _E2E_FRAMES.clear()
+        _E2E_FRAMES[key] = (pool, [pool[i % npool][0] for i in range(n_frames)], [pool[i % npool][1] for i in range(n_frames)])
+    return _E2E_FRAMES[key]
+
+
+def e2e_rescale_leg(args, device, sizes, seed, n_frames):
+    """The estimator the reference's drivers really import (/root/reference/src/main.py:20: rescale.ScaleEstimator), end to
+    end from per-frame arrays, device-resident: C packer -> one upload per chunk -> Delaunay #1 -> GraphChecker vote ->
+    Delaunay #2 -> flat_selection + RANSAC plane (one kernel) -> slew limiter + window median.  No declared deviation:
+    the vote and the kept triangle set do not depend on the row form, and the reference's RANSAC is unseeded."""
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    pool, f3s, f2s = _e2e_frames(sizes, seed, n_frames)
+    est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, triangulation="gpu", delaunay_workers=0, ransac_seed=2024)
+    for _ in range(2):
+        est.scale_calculation_batch(f3s, f2s)
+    ctx = est.ctx
+    a0 = ctx.alloc_stats()
+    t0 = time.perf_counter()
+    scales, _ = est.scale_calculation_batch(f3s, f2s)
+    dt = time.perf_counter() - t0
+    a1 = ctx.alloc_stats()
+    st = est.last["status"]
+    return {"value": n_frames / dt, "unit": "frames/s", "frames": n_frames, "distinct_frames": len(pool),
+            "declined": int(est.last_declined), "frames_with_plane": int((st == 0).sum()),
+            "scale_median": float(np.median(scales)),
+            "hip_malloc_calls_in_timed_call": a1["hip_malloc"] - a0["hip_malloc"],
+            "hip_host_malloc_calls_in_timed_call": a1["host_malloc"] - a0["host_malloc"],
+            "what": "rescale.ScaleEstimator(triangulation='gpu').scale_calculation_batch on a list of per-frame arrays: the "
+                    "estimator /root/reference/src/main.py:20 imports, every stage on the device (Delaunay x2, GraphChecker vote, "
+                    "flat_selection + 100-hypothesis RANSAC plane, slew limiter, window median); reference-faithful: no declared deviation"}
+
+
 def e2e_gpu_leg(args, device, sizes, seed, n_frames):
     """The batch call end to end with BOTH TRIANGULATIONS BUILT ON THE DEVICE (triangulation="gpu", which selects
     check_triangle="fixed": DESIGN.md §3.8): C packer -> one upload per chunk -> Delaunay #1 -> vote -> Delaunay #2 ->
@@ -304,10 +348,8 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames):
     (mvosr_delaunay_batch on resident point sets), and the alloc counters of a steady-state call."""
     from mvoscalerecovery_amd import _lib, packing, synth
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
-    npool = 256 if max(sizes) <= 6000 else 16
-    pool = [synth.synth_frame(200000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(npool)]
-    f3s = [pool[i % npool][0] for i in range(n_frames)]
-    f2s = [pool[i % npool][1] for i in range(n_frames)]
+    pool, f3s, f2s = _e2e_frames(sizes, seed, n_frames)
+    npool = len(pool)
     est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
     for _ in range(2):                                                        # warm-up: kernels, allocator caches (same sizes as the timed call)
         est.scale_calculation_batch(f3s, f2s)
@@ -343,8 +385,8 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames):
             b.free()
     else:
         dt_alone = None
-    return {"value": n_frames / dt, "unit": "frames/s", "frames": n_frames, "declined_last_chunk": int(est.last_declined),
-            "delaunay_kernel": dt_alone,
+    return {"value": n_frames / dt, "unit": "frames/s", "frames": n_frames, "distinct_frames": npool,
+            "declined_last_chunk": int(est.last_declined), "delaunay_kernel": dt_alone,
             "hip_malloc_calls_in_timed_call": a1["hip_malloc"] - a0["hip_malloc"], "hip_host_malloc_calls_in_timed_call": a1["host_malloc"] - a0["host_malloc"],
             "what": "ScaleEstimator(triangulation='gpu').scale_calculation_batch on a list of per-frame arrays: vanishing-row filter + "
                     "packing by the C packer into page-locked memory, one upload per chunk, Delaunay #1 / vote / Delaunay #2 / scale "
@@ -701,6 +743,10 @@ def main():
                 line["e2e_gpu_triangulation"] = e2e_gpu_leg(args, local, sizes, 2024, 32768)
             except Exception as exc:                                    # noqa: BLE001
                 line["e2e_gpu_triangulation"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                line["e2e_rescale"] = e2e_rescale_leg(args, local, sizes, 2024, 32768)
+            except Exception as exc:                                    # noqa: BLE001
+                line["e2e_rescale"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             try:
                 line["latency"] = latency_leg(args, local, sizes, 2024)
             except Exception as exc:                                    # noqa: BLE001

@@ -732,26 +732,33 @@ __global__ __launch_bounds__(kRsBlock) void triangle_batch_kernel(const TriBatch
 // The slew limiter of scale_calculation_ransac (/root/reference/src/rescale.py:169-177) over a run of frames: a sequential
 // recurrence of rounded additions, walked by ONE wavefront — 64 frames are loaded at a time, their values broadcast lane by
 // lane (v_readlane), the running scale identical in every lane; lane j keeps the value pushed at its frame.
+template <int J>
+__device__ __forceinline__ void slew_step(double r, unsigned long long am, double slew, int lane, double &s, double &out) {
+    if constexpr (J < kWave) {
+        // branch-free: the three candidates depend on s alone, the selects on one subtraction (the recurrence's only chain)
+        const double rj = readlane_d(r, J);                                  // (constant lane: no M0 set-up)
+        const double d = rj - s;
+        const double up = s + slew, dn = s - slew;
+        const double moved = d > slew ? up : (d < -slew ? dn : rj);          // rescale.py:169-174
+        s = ((am >> J) & 1ull) ? moved : s;                                  // :152 — only a frame with a RANSAC plane moves the scale
+        out = lane == J ? s : out;                                           // :175 scale_queue.append(self.scale)
+        slew_step<J + 1>(r, am, slew, lane, s, out);
+    }
+}
+
 __global__ __launch_bounds__(kWave) void slew_kernel(const double *raw, const int32_t *apply, int64_t n, double slew, double s_in,
                                                      double *pushed) {
     const int lane = lane_id();
     double s = s_in;
+    double r = lane < n ? raw[lane] : 0.0;
+    int ap = lane < n ? apply[lane] : 0;
     for (int64_t i0 = 0; i0 < n; i0 += kWave) {
         const int64_t i = i0 + lane;
-        const double r = i < n ? raw[i] : 0.0;
-        const unsigned long long am = __ballot(i < n && apply[i] != 0);
-        const int cnt = (int)((n - i0) < (int64_t)kWave ? (n - i0) : (int64_t)kWave);
+        const double r_cur = r;
+        const unsigned long long am = __ballot(ap != 0);                     // (lanes beyond n: no plane, the scale stays)
+        if (i + kWave < n) { r = raw[i + kWave]; ap = apply[i + kWave]; } else ap = 0;   // the next 64 frames load under this block's chain
         double out = 0.0;
-        for (int j = 0; j < cnt; ++j) {
-            if ((am >> j) & 1ull) {                                          // :152 — the frame has a RANSAC plane
-                const double rj = readlane_d(r, j);
-                const double d = rj - s;
-                if (d > slew) s += slew;                                     // :169-170
-                else if (d < -slew) s -= slew;                               // :171-172
-                else s = rj;                                                 // :173-174
-            }
-            if (lane == j) out = s;                                          // :175 scale_queue.append(self.scale)
-        }
+        slew_step<0>(r_cur, am, slew, lane, s, out);
         if (i < n) pushed[i] = out;
     }
 }

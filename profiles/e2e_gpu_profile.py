@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where the host time of the drop-in batch call goes with triangulation="gpu" (cProfile, cumulative):
-    python profiles/e2e_gpu_profile.py [frames] [features]"""
+    python profiles/e2e_gpu_profile.py [frames] [features] [scale|rescale]
+(third argument "rescale": the estimator /root/reference/src/main.py:20 imports, device-resident)"""
 import cProfile
 import os
 import pstats
@@ -13,9 +14,15 @@ from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-pool = [synth.synth_frame(i, N, base_seed=2024) for i in range(256)]
-f3, f2 = [pool[i % 256][0] for i in range(F)], [pool[i % 256][1] for i in range(F)]
-est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
+WHICH = sys.argv[3] if len(sys.argv) > 3 else "scale"
+P = min(F, 4096)                      # distinct frames (larger than the host's last-level cache)
+pool = [synth.synth_frame(i, N, base_seed=2024) for i in range(P)]
+f3, f2 = [pool[i % P][0] for i in range(F)], [pool[i % P][1] for i in range(F)]
+if WHICH == "rescale":
+    from mvoscalerecovery_amd.rescale import ScaleEstimator as RescaleEstimator
+    est = RescaleEstimator(1.75, window_size=5, triangulation="gpu", delaunay_workers=0, ransac_seed=2024)
+else:
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
 est.scale_calculation_batch(f3, f2)
 t0 = time.perf_counter()
 pr = cProfile.Profile()
@@ -23,5 +30,5 @@ pr.enable()
 s, e = est.scale_calculation_batch(f3, f2)
 pr.disable()
 dt = time.perf_counter() - t0
-print("triangulation=gpu N=%d frames=%d: %.0f frames/s (%.3f ms/frame)" % (N, F, F / dt, 1e3 * dt / F))
+print(WHICH, "triangulation=gpu N=%d frames=%d: %.0f frames/s (%.3f ms/frame)" % (N, F, F / dt, 1e3 * dt / F))
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
