@@ -672,10 +672,16 @@ def test_triangulation_gpu_fixed_seq4541_and_fuzz(gpu):
     want = offline.run_sequence(data, ora)
     np.testing.assert_array_equal(res["scales"], want["scales"])
     np.testing.assert_array_equal(res["error"], want["error"])
+    # ... and to the REFERENCE itself run with the one line of check_triangle patched (tests/golden/seq4541_fixed.npz)
+    zfix, _ = load_npz("seq4541_fixed.npz")
+    np.testing.assert_array_equal(res["scales"], zfix["scales"])
+    np.testing.assert_array_equal(res["error"], zfix["error"])
     same_as_reference = float(np.mean(res["scales"] == z["scales"]))
     assert same_as_reference > 0.5, same_as_reference                    # (the declared deviation, measured in profiles/)
-    # adversarial frames: same outcome (scale or exception type) as the fixed-mode oracle, frame by frame
-    zf = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_fuzz.npz"))
+    # adversarial frames: same outcome (scale or exception type) as the fixed-mode oracle — and as the patched reference
+    # (tests/golden/frame_fuzz_fixed.npz) —, frame by frame
+    zf = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_fuzz_fixed.npz"))
+    ref_names = list(zf["exception_names"])
     declined = 0
     for i in range(len(zf["scale"])):
         f3, f2 = synth.fuzz_frame(i, int(zf["seed"]))
@@ -693,8 +699,34 @@ def test_triangulation_gpu_fixed_seq4541_and_fuzz(gpu):
         if want_exc is None:
             assert (np.isnan(want_s[0]) and np.isnan(got_s[0])) or got_s[0] == want_s[0], (i, got_s, want_s)
             assert got_s[1] == want_s[1], i
+        ref_exc = ref_names[zf["raised"][i] - 1] if zf["raised"][i] else None
+        assert (got_exc is None) == (ref_exc is None), (i, got_exc, ref_exc)
+        if ref_exc is None:
+            assert (np.isnan(zf["scale"][i]) and np.isnan(got_s[0])) or got_s[0] == zf["scale"][i], (i, got_s, zf["scale"][i])
+            assert got_s[1] == zf["std"][i], i
         declined += est.last_declined
     assert declined > 0                                                  # the fallback was exercised
+
+
+def test_triangulation_gpu_fixed_stage_goldens_of_the_patched_reference(gpu):
+    """The 20 stage frames through ScaleEstimator(triangulation="gpu") against the reference run with check_triangle's
+    one line patched (tests/golden/stages_fixed.npz): scale, height_level, the selected road points' count, per frame."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z, meta = load_npz("stages_fixed.npz")
+    f3s, f2s = [], []
+    for k, fr in enumerate(meta["frames"]):
+        f3, f2 = synth.synth_frame(fr["frame_idx"], fr["n"], base_seed=fr["seed"], upper_fraction=fr["upper_fraction"])
+        est = ScaleEstimator(meta["abs_ref"], window_size=5, triangulation="gpu", mutate_inputs=False)
+        s, sd = est.scale_calculation(f3, f2)
+        assert s == float(z["f%d_scale_first_call" % k]) and sd == float(z["f%d_std" % k]), k
+        assert est.height_level == float(z["f%d_height_level" % k]), k
+        assert len(est.flat_feature) == len(z["f%d_selected_ids" % k]), k
+        f3s.append(f3)
+        f2s.append(f2)
+    est = ScaleEstimator(meta["abs_ref"], window_size=5, triangulation="gpu", mutate_inputs=False)
+    raw, status, level, _ = est.raw_scale_batch(f3s, f2s)
+    assert raw.tolist() == [float(z["f%d_scale_first_call" % k]) for k in range(len(f3s))]
 
 
 def test_road_cases_kernel(gpu):

@@ -260,7 +260,7 @@ def test_dense_golden():
 
 
 # ---------------------------------------------------------------- whole-sequence goldens
-def _run_oracle_sequence(name):
+def _run_oracle_sequence(name, **est_kw):
     from mvoscalerecovery_amd import synth, offline
     z, meta = load_npz(name)
     data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
@@ -269,7 +269,7 @@ def _run_oracle_sequence(name):
         if len(a3):
             crc = synth.checksum(np.array([crc], dtype=np.int64), a3, a2)
     assert crc == meta["crc"], "synthetic sequence drifted from the fixture"
-    est = so.OracleScaleEstimator(meta["abs_ref"], window_size=meta["window"])
+    est = so.OracleScaleEstimator(meta["abs_ref"], window_size=meta["window"], **est_kw)
     raws = []
     real = est.scale_filtering
     est.scale_filtering = lambda s: (raws.append(s), real(s))[1]
@@ -294,6 +294,60 @@ def test_seq4541_golden():
     np.testing.assert_array_equal(raws, z["raw_scales"])
     np.testing.assert_array_equal(res["scales"], z["scales"])
     np.testing.assert_array_equal(res["error"], z["error"])
+
+
+# ---------------------------------------------------------------- the declared deviation, pinned to the reference's code
+def test_fixed_mode_stage_goldens_from_the_patched_reference():
+    """check_triangle="fixed" against the REFERENCE run with that one line patched (tests/golden/make_golden.py:
+    fixed_reference — /root/reference/src/scale_calculator.py:113-115 marking vertices 0 and 2, rows in canonical form):
+    vote masks, selected ids, height_level, histogram, modes, height and scale of the 20 stage frames."""
+    from mvoscalerecovery_amd import synth
+    z, meta = load_npz("stages_fixed.npz")
+    for k, fr in enumerate(meta["frames"]):
+        f3, f2 = synth.synth_frame(fr["frame_idx"], fr["n"], base_seed=fr["seed"], upper_fraction=fr["upper_fraction"])
+        assert synth.checksum(f3, f2) == fr["crc"]
+        g = {name[len("f%d_" % k):]: z[name] for name in z.files if name.startswith("f%d_" % k)}
+        r = so.frame_raw_scale(f3, f2, meta["abs_ref"], check_triangle="fixed")
+        assert np.array_equal(r.valid, g["valid"]), k
+        assert np.array_equal(r.sel.selected_ids, g["selected_ids"]), k
+        assert r.height_level == float(g["height_level"]) and r.height == float(g["height"]), k
+        assert r.raw_scale == float(g["scale_first_call"]) and r.std == float(g["std"]), k
+        assert np.array_equal(r.road.hist_raw, g["hist_raw"]) and r.road.n_kept == int(g["n_kept"]) and r.road.n_modes == int(g["n_modes"])
+        if "skew" in g:
+            assert r.road.skew == float(g["skew"])
+
+
+def test_fixed_mode_seq4541_from_the_patched_reference():
+    """Config C3's 4541-frame sequence in the fixed mode: every raw and filtered scale equals the patched reference's."""
+    z, res, raws = _run_oracle_sequence("seq4541_fixed.npz", check_triangle="fixed")
+    assert np.array_equal(res["kinds"], z["kinds"])
+    np.testing.assert_array_equal(raws, z["raw_scales"])
+    np.testing.assert_array_equal(res["scales"], z["scales"])
+    np.testing.assert_array_equal(res["error"], z["error"])
+    ref, _ = load_npz("seq4541.npz")
+    agree = float(np.mean(z["raw_scales"] == ref["raw_scales"]))
+    assert 0.90 < agree < 0.97, agree            # the deviation itself, reference vs patched reference (profiles/fixed_mode_accuracy.md)
+
+
+def test_fixed_mode_frame_fuzz_from_the_patched_reference():
+    """The 400 adversarial frames: same return value or exception type as the patched reference."""
+    from mvoscalerecovery_amd import synth
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_fuzz_fixed.npz"))
+    names = list(z["exception_names"])
+    for i in range(len(z["scale"])):
+        f3, f2 = synth.fuzz_frame(i, int(z["seed"]))
+        assert float(np.sum(f3)) + float(np.sum(f2)) == z["sums"][i], i
+        est = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+        want_exc = names[z["raised"][i] - 1] if z["raised"][i] else None
+        try:
+            s, sd = est.scale_calculation(f3.copy(), f2.copy())
+            got_exc = None
+        except Exception as exc:  # noqa: BLE001 - the type is what is compared
+            got_exc = type(exc).__name__
+        assert got_exc == want_exc, (i, got_exc, want_exc)
+        if want_exc is None:
+            assert sd == z["std"][i], i
+            assert (np.isnan(s) and np.isnan(z["scale"][i])) or s == z["scale"][i], (i, s, z["scale"][i])
 
 
 def test_too_few_lower_features_branch():
