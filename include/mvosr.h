@@ -541,6 +541,17 @@ int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, const int64_t 
                                 const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
                                 int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status,
                                 const int64_t *seed_off, const int32_t *seed_tri, const int32_t *seed_cnt);
+/* The same with the per-point facts that let the SECOND triangulation skip the stars the vote did not touch.  info_out
+ * (optional; laid out like u, one word per point; only for a call without `keep`): rows the point owns | star degree << 6 |
+ * hull flag << 15, and in the high half the index of its first row within the frame's rows.  seed_info (optional, with
+ * seeds): what the call that built the seeds wrote.  A kept point none of whose seed triangles lost a vertex has the same
+ * star among the survivors (its triangles keep their empty circles and still close the fan): its rows are copied with the
+ * ids mapped to ranks and its star is not walked — at 95 % kept points three stars in four.  Same rows as without. */
+int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                            const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
+                            int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status,
+                            const int64_t *seed_off, const int32_t *seed_tri, const int32_t *seed_cnt,
+                            const uint32_t *seed_info, uint32_t *info_out);
 /* Largest frame mvosr_delaunay_batch takes (32 000 points: ids and row indices are 16-bit), and the largest frame whose
  * points, grid and rows fit one workgroup's LDS (about 4 700): a launch whose max_pts is larger runs the kernel's
  * global-memory variant — the same algorithm with the per-frame arrays in a slice of the context's workspace, read

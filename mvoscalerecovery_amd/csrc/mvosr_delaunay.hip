@@ -75,6 +75,15 @@ constexpr int kDtLaneDeg = 24;           // star degree on the lane path
 #define MVOSR_DT_RWIDE 8
 #endif
 constexpr int kDtBudget = MVOSR_DT_BUDGET;   // candidates per lane and scan step
+#ifndef MVOSR_DT_STRAGGLERS
+#define MVOSR_DT_STRAGGLERS 0
+#endif
+constexpr int kDtStragglers = MVOSR_DT_STRAGGLERS;
+constexpr int kDtMinTrips = 12;              // ... but every scanning lane makes that many trips per step at least (progress)
+#ifndef MVOSR_DT_COOP_CELLS
+#define MVOSR_DT_COOP_CELLS 36
+#endif
+constexpr int kDtCoopCells = MVOSR_DT_COOP_CELLS;    // a circumcircle's cell box larger than this is scanned by the whole wavefront
 constexpr int kDtRWide = MVOSR_DT_RWIDE;              // the block a search is widened to before it takes the whole frame
 constexpr int kDtWaveRows = 32;          // rows a point may own at all
 constexpr int kDtWaveDeg = 60;
@@ -104,6 +113,12 @@ struct DtArgs {
     // triangle of it whose three vertices are kept is a triangle of this one — its circumcircle was empty among more
     // points — so its three corners go into the hint caches before the first star is started.
     const int64_t *seed_off; const int32_t *seed_tri; const int32_t *seed_cnt;
+    // Per point of the SEED triangulation (laid out like u), written by the launch that built it (info_out) and read by the
+    // seeded launch (seed_info): rows owned | star degree << 6 | open << 15 in the low half, index of the point's first row
+    // within the frame's rows in the high half.  A kept point none of whose seed triangles lost a vertex has the SAME star in
+    // this triangulation — the triangles stay Delaunay among fewer points and still close the fan — so its rows are copied
+    // (ids mapped to ranks) and its star is not walked at all: at 95 % kept points that is three stars in four.
+    const uint32_t *seed_info; uint32_t *info_out;
 #ifdef MVOSR_STAMPS
     unsigned long long *stamps;                          // diagnostic builds: 16 values per frame (phase boundaries, list lengths)
 #endif
@@ -156,7 +171,16 @@ template <bool GLOBAL> constexpr bool kDtHintsOn = kDtHintK > 0 && (!GLOBAL || M
 #endif
 template <bool GLOBAL> constexpr bool kDtCoop = MVOSR_DT_COOP && (!GLOBAL || MVOSR_DT_GLOBAL_COOP);    // (frames in global memory: 26 k -> 19 k sets/s with it at 20 000 points)   // hinted triangles taken in a row before the lane goes back to searching
 
-struct DtPlan { uint32_t S, oid, od, astart, cs, arena, big, hard, wrows, red, misc, total; int max_cells, arena_cap; };
+#ifndef MVOSR_DT_LDSWALK
+#define MVOSR_DT_LDSWALK 0
+#endif
+// The lane pass's walk over the (up to five) cell rows of a scan step: 1 = the non-empty rows' ranges are packed into one
+// word each (start | end << 13 | row << 26) in a per-lane LDS slot, the walk keeps the current and the next range in two
+// registers and fetches the one after when it moves on (LDS variant only: 13-bit indices); 0 = all ranges in registers,
+// shifted down at every row change (17-40 v_mov whenever ANY lane of the wavefront ends a row).
+constexpr bool kDtLdsWalk = MVOSR_DT_LDSWALK != 0;
+
+struct DtPlan { uint32_t S, oid, od, astart, cs, arena, big, hard, wrows, red, misc, aff, total; int max_cells, arena_cap; };
 constexpr int kDtMaxCellsGlobal = 32768;
 constexpr int kDtMaxPointsGlobal = 32000;      // (row arena indices and point ids are 16-bit)
 
@@ -178,10 +202,15 @@ __host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false, int 
     p.arena = p.cs + 4u * (uint32_t)(p.max_cells + 8);   // u32 rows (b << 16 | c) in the order they were found
     p.big = (p.arena + 4u * (uint32_t)p.arena_cap + 255u) & ~255u;
     p.hard = p.big;                                      // u16 sorted indices
-    p.wrows = p.hard + 2u * kDtHardCap;                  // u32 [groups of 16 lanes][kDtWaveRows]
-    p.red = p.wrows + 4u * (uint32_t)(waves * kWave / 16) * kDtWaveRows;    // doubles: block reductions
+    p.wrows = p.hard + 2u * kDtHardCap;                  // u32 [groups of 16 lanes][kDtWaveRows] (phase 2); phase 1: the lanes' row ranges [row][lane]
+    {
+        const uint32_t rows2 = 4u * (uint32_t)(waves * kWave / 16) * kDtWaveRows;
+        const uint32_t walk = (kDtLdsWalk && !global) ? 4u * (uint32_t)(waves * kWave) * (uint32_t)(2 * MVOSR_DT_R + 1) : 0u;
+        p.red = p.wrows + (rows2 > walk ? rows2 : walk);  // doubles: block reductions
+    }
     p.misc = p.red + 8u * 4u * (uint32_t)waves;
-    p.total = p.misc + 4u * 64u;
+    p.aff = p.misc + 4u * 64u;                           // u8 per sorted index (LDS variant): the star has to be built (see seed_info)
+    p.total = p.aff + (global ? 0u : npad);
     return p;
 }
 
@@ -406,6 +435,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
     uint16_t *hard = reinterpret_cast<uint16_t *>(small + L.hard);
     double *red = reinterpret_cast<double *>(small + L.red);
     int *misc = reinterpret_cast<int *>(small + L.misc);
+    uint8_t *aff = reinterpret_cast<uint8_t *>(small + L.aff);
     const size_t hint_pts = (size_t)((a.max_pts + 7) & ~7);
     uint32_t *hints = (kDtHintsOn<GLOBAL> && a.hints) ? a.hints + (size_t)f * ((size_t)(kDtHintK + 3) * hint_pts) : nullptr;
     uint32_t *start = hints ? hints + (size_t)(kDtHintK + 1) * hint_pts : nullptr;               // one known triangle per point: its star starts there
@@ -450,7 +480,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
         if (lane == 0) { red[4 * w] = a0; red[4 * w + 1] = a1; red[4 * w + 2] = a2; red[4 * w + 3] = a3; misc[DM_WCNT + w] = wcnt; }
         if (tid < 8) misc[tid] = tid == DM_NEXT ? BLOCK : 0;
 #ifdef MVOSR_STAMPS
-        if (tid >= 48 && tid < 64) misc[tid] = 0;
+        if (tid >= 40 && tid < 64) misc[tid] = 0;
 #endif
     }
     __syncthreads();
@@ -531,6 +561,83 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
         }
     }
     __syncthreads();
+    // carry: stars without a lost neighbour are copied from the seed triangulation instead of walked (LDS variant, seeds with info)
+    const bool carry = !GLOBAL && inv && order && a.seed_info && a.seed_cnt[f] > 0;
+    int n_work = n;                                           // points whose star phase 1 builds
+    if (inv) {
+        const int32_t *st = a.seed_tri + 3 * a.seed_off[f];
+        const int ns = a.seed_cnt[f];
+        if (carry) {
+            for (int j = tid; j < n; j += BLOCK) aff[j] = 0;
+            __syncthreads();
+            // a seed row that lost a vertex: its other vertices' stars change
+            for (int r = tid; r < ns; r += BLOCK) {
+                const int ra = st[3 * r], rb = st[3 * r + 1], rc = st[3 * r + 2];
+                if ((unsigned)ra >= (unsigned)n_in || (unsigned)rb >= (unsigned)n_in || (unsigned)rc >= (unsigned)n_in) continue;
+                const uint32_t pa = __hip_atomic_load(inv + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t pb = __hip_atomic_load(inv + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t pc = __hip_atomic_load(inv + rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ka = pa < (uint32_t)n, kb = pb < (uint32_t)n, kc = pc < (uint32_t)n;
+                if (ka && kb && kc) continue;
+                if (ka) aff[pa] = 1;
+                if (kb) aff[pb] = 1;
+                if (kc) aff[pc] = 1;
+            }
+            __syncthreads();
+            // the unchanged stars' bookkeeping: row count, degree and hull flag as they were, room for the rows
+            const uint32_t *info = a.seed_info + off;
+            for (int i0 = tid; i0 < n_in; i0 += BLOCK) {
+                const uint32_t pos = __hip_atomic_load(inv + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pos >= (uint32_t)n || aff[pos]) continue;
+                const uint32_t wd = info[i0];
+                const int nown = (int)(wd & 63u);
+                const int at = nown ? atomicAdd(&misc[DM_ARENA], nown) : 0;
+                if (at + nown > L.arena_cap) { atomicOr(&misc[DM_FLAGS], (int)DT_WHY_ROWS); aff[pos] = 1; continue; }
+                const int o = oid[pos];
+                od[o] = (uint16_t)(wd & 0xFFFFu);
+                astart[o] = (uint16_t)at;
+            }
+            __syncthreads();
+        }
+        // the seeds' corners into the hint caches (orientation from the points: the rows are in canonical, not in
+        // counter-clockwise order); with carry: only where a star that will be walked reads them, and the unchanged
+        // stars' rows straight into the arena
+        for (int r = tid; r < ns; r += BLOCK) {
+            const int ra = st[3 * r], rb = st[3 * r + 1], rc = st[3 * r + 2];
+            if ((unsigned)ra >= (unsigned)n_in || (unsigned)rb >= (unsigned)n_in || (unsigned)rc >= (unsigned)n_in) continue;
+            const uint32_t pa = __hip_atomic_load(inv + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t pb = __hip_atomic_load(inv + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t pc = __hip_atomic_load(inv + rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pa >= (uint32_t)n || pb >= (uint32_t)n || pc >= (uint32_t)n) continue;          // a vertex that is not kept (all ones)
+            bool ha = true, hb = true, hc = true;
+            if (carry) {
+                ha = aff[pa] != 0; hb = aff[pb] != 0; hc = aff[pc] != 0;
+                if (!ha) {                                   // ra is the row's smallest id: its owner, and the ranks keep the order
+                    const int idx = r - (int)(a.seed_info[off + ra] >> 16);
+                    if (idx >= 0 && idx < (int)(od[oid[pa]] & 63u)) arena[astart[oid[pa]] + idx] = ((uint32_t)oid[pb] << 16) | (uint32_t)oid[pc];
+                    else atomicOr(&misc[DM_FLAGS], (int)DT_WHY_ROWS);
+                }
+                if (!(ha || hb || hc)) continue;
+            }
+            const double2 A_ = S[pa], B_ = S[pb], C_ = S[pc];
+            const double cr = (B_.x - A_.x) * (C_.y - A_.y) - (B_.y - A_.y) * (C_.x - A_.x);
+            if (!(cr != 0.0)) continue;
+            if (cr < 0.0) { const uint32_t t = pb; pb = pc; pc = t; const bool tb = hb; hb = hc; hc = tb; }   // (pa, pb, pc) counter-clockwise now
+            if (ha) {
+                __hip_atomic_store(hints + (size_t)pa * kDtHintK + (pb % kDtHintK), (pb << 16) | pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(start + pa, (pb << 16) | pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (hb) {
+                __hip_atomic_store(hints + (size_t)pb * kDtHintK + (pc % kDtHintK), (pc << 16) | pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(start + pb, (pc << 16) | pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (hc) {
+                __hip_atomic_store(hints + (size_t)pc * kDtHintK + (pa % kDtHintK), (pa << 16) | pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(start + pc, (pa << 16) | pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
     if (order) {
         // The points are taken cell colour by cell colour — (x & 1, y & 1): all even/even cells first, and so on.  In the
         // sorted order 512 consecutive points are in flight at once, a band of five or six cell rows in which every point's
@@ -544,47 +651,33 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
         __syncthreads();
         for (int c = tid; c < ncell; c += BLOCK) {
             const int cx = c % G.gx, cy = c / G.gx, col = (cx & 1) | ((cy & 1) << 1);
-            const int k = (int)cs[c] - (c ? (int)cs[c - 1] : 0);
-            for (int r = 0; r < min(k, 4); ++r) atomicAdd(&ccnt[4 * r + col], r < 3 ? 1 : k - 3);
+            const int b = c ? (int)cs[c - 1] : 0, e = (int)cs[c];
+            int k = 0;                                        // (with carry: only the points whose star is walked)
+            for (int j = b; j < e; ++j) {
+                if (carry && !aff[j]) continue;
+                atomicAdd(&ccnt[4 * min(k, 3) + col], 1);
+                ++k;
+            }
         }
         __syncthreads();
         int mine = tid < 16 ? ccnt[tid] : 0, base = 0;
         __syncthreads();
-        for (int q = 0; q < 16; ++q) { const int v = __shfl(mine, q); if (q < tid) base += v; }
+        int total_ = 0;
+        for (int q = 0; q < 16; ++q) { const int v = __shfl(mine, q); if (q < tid) base += v; total_ += v; }
         if (tid < 16) ccnt[tid] = base;
+        if (tid == 0) misc[DM_VQ] = total_;
         __syncthreads();
+        n_work = misc[DM_VQ];
         for (int c = tid; c < ncell; c += BLOCK) {
             const int cx = c % G.gx, cy = c / G.gx, col = (cx & 1) | ((cy & 1) << 1);
             const int b = c ? (int)cs[c - 1] : 0, e = (int)cs[c];
+            int k = 0;
             for (int j = b; j < e; ++j) {
-                const int at = atomicAdd(&ccnt[4 * min(j - b, 3) + col], 1);
+                if (carry && !aff[j]) continue;
+                const int at = atomicAdd(&ccnt[4 * min(k, 3) + col], 1);
                 __hip_atomic_store(order + at, (uint32_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++k;
             }
-        }
-        __syncthreads();
-    }
-    if (inv) {
-        // the seeds' corners into the hint caches (orientation from the points: the rows are in canonical, not in
-        // counter-clockwise order)
-        const int32_t *st = a.seed_tri + 3 * a.seed_off[f];
-        const int ns = a.seed_cnt[f];
-        for (int r = tid; r < ns; r += BLOCK) {
-            const int ra = st[3 * r], rb = st[3 * r + 1], rc = st[3 * r + 2];
-            if ((unsigned)ra >= (unsigned)n_in || (unsigned)rb >= (unsigned)n_in || (unsigned)rc >= (unsigned)n_in) continue;
-            const uint32_t pa = __hip_atomic_load(inv + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t pb = __hip_atomic_load(inv + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t pc = __hip_atomic_load(inv + rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (pa >= (uint32_t)n || pb >= (uint32_t)n || pc >= (uint32_t)n) continue;          // a vertex that is not kept (all ones)
-            const double2 A_ = S[pa], B_ = S[pb], C_ = S[pc];
-            const double cr = (B_.x - A_.x) * (C_.y - A_.y) - (B_.y - A_.y) * (C_.x - A_.x);
-            if (!(cr != 0.0)) continue;
-            if (cr < 0.0) { const uint32_t t = pb; pb = pc; pc = t; }                            // (pa, pb, pc) counter-clockwise now
-            __hip_atomic_store(hints + (size_t)pa * kDtHintK + (pb % kDtHintK), (pb << 16) | pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(hints + (size_t)pb * kDtHintK + (pc % kDtHintK), (pc << 16) | pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(hints + (size_t)pc * kDtHintK + (pa % kDtHintK), (pa << 16) | pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(start + pa, (pb << 16) | pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(start + pb, (pc << 16) | pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(start + pc, (pa << 16) | pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
@@ -609,8 +702,8 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
             if (order) return (int)__hip_atomic_load(order + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return (idx & 1) ? n - 1 - (idx >> 1) : (idx >> 1);
         };
-        int i = tid < n ? point_of(tid) : -1;       // (misc[DM_NEXT] starts at BLOCK)
-        bool exhausted = tid >= n;
+        int i = tid < n_work ? point_of(tid) : -1;       // (misc[DM_NEXT] starts at BLOCK)
+        bool exhausted = tid >= n_work;
         int nn_level = 0;                           // nearest-neighbour search: 3x3 block, then 5x5, then the frame
         int mode = 0, oi = 0, q0 = -1, iq = -1, deg = 0, nown = 0, open = 0;
         int coop = 0;
@@ -682,12 +775,24 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 // and a row's range costs as much as its candidates (one row at a time with all 64 lanes: 648 k sets/s at
                 // 2000 points; four: 741 k)
                 constexpr int kLanesPerRow = kWave / kDtServeRows;
+#ifdef MVOSR_STAMPS
+                int my_trips = 0;
+#endif
                 for (int y0 = bb.ya; y0 <= bb.yb; y0 += kDtServeRows) {
                     const int y = y0 + lane / kLanesPerRow;
                     int j0 = 0, j1 = 0;
                     if (y <= bb.yb) dt_row_range(G, E2, y, bb.xa, bb.xb, j0, j1);
+#ifdef MVOSR_STAMPS
+                    int t_ = 0;
+                    for (int j = j0 + (lane & (kLanesPerRow - 1)); j < j1; j += kLanesPerRow) { dt_step(A2, E2, j, S[j]); ++t_; }
+                    my_trips += wave_max(t_);
+#else
                     for (int j = j0 + (lane & (kLanesPerRow - 1)); j < j1; j += kLanesPerRow) dt_step(A2, E2, j, S[j]);
+#endif
                 }
+#ifdef MVOSR_STAMPS
+                if (lane == 0) { atomicAdd(&misc[41], my_trips); atomicAdd(&misc[42], 1); atomicAdd(&misc[43], (bb.yb - bb.ya + 1 + kDtServeRows - 1) / kDtServeRows); }
+#endif
                 const DtPick pk = dt_wave_pick(A2);
                 if (pk.flag) degenerate |= DT_WHY_COLLINEAR;
                 if (pk.tie) degenerate |= DT_WHY_TIE;
@@ -700,7 +805,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
         for (;;) {
             if (i < 0 && !exhausted) {
                 const int idx = atomicAdd(&misc[DM_NEXT], 1);
-                if (idx < n) {
+                if (idx < n_work) {
                     i = point_of(idx); p = S[i]; oi = oid[i]; mode = 0; deg = 0; nown = 0; iq = -1; open = 0; sgn = 1.0; nn_level = 0;
 #pragma unroll
                     for (int k = 0; k < kDtLaneRows; ++k) rows[k] = 0xFFFFFFFFu;
@@ -718,6 +823,42 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
             if (m1) E.set(p, S[max(iq, 0)], i, iq, sgn); else E.set_nn(p, i);
             // up to five rows of the search's box as ranges of the sorted array, walked as ONE loop (a loop per row would
             // run for the longest row of any lane, five times over)
+            int budget = kDtBudget;
+            if constexpr (kDtLdsWalk && !GLOBAL) {
+                uint32_t *wr = reinterpret_cast<uint32_t *>(small + L.wrows) + tid;      // this lane's slot: wr[k * BLOCK]
+                int nseg = 0;
+#pragma unroll
+                for (int r = 0; r < kDtRows; ++r) {
+                    const int y = y_next + r;
+                    int a0 = 0, a1 = 0;
+                    if (act && y <= box.yb) dt_row_range(G, E, y, box.xa, box.xb, a0, a1);
+                    if (r == 0) a0 = max(a0, j_resume);
+                    if (a0 < a1) { wr[nseg * BLOCK] = (uint32_t)a0 | ((uint32_t)a1 << 13) | ((uint32_t)r << 26); ++nseg; }
+                }
+                uint32_t cur = nseg > 0 ? wr[0] : 0u, nxt = nseg > 1 ? wr[BLOCK] : 0u;
+                int seg = 0;
+                int j = (int)(cur & 0x1FFFu), je = (int)((cur >> 13) & 0x1FFFu);
+                // (the step ends for everybody once no more than kDtStragglers lanes are still scanning: they go on in the next
+                // step — as a lane out of budget does — instead of holding the other lanes' completions back)
+                while (j < je && budget > 0) {
+                    if (kDtStragglers > 0 && budget <= kDtBudget - kDtMinTrips && __popcll(__ballot(true)) <= kDtStragglers) break;
+                    const double2 c = S[j];
+                    const int jc = j;
+                    ++j; --budget;
+                    if (j >= je) {                                   // this row is done: the next non-empty one (or none: 0 | 0)
+                        cur = nxt; ++seg;
+                        j = (int)(cur & 0x1FFFu); je = (int)((cur >> 13) & 0x1FFFu);
+                        nxt = seg + 1 < nseg ? wr[(seg + 1) * BLOCK] : 0u;
+                    }
+                    dt_step_lane(A, E, m1, jc, c);
+                }
+                if (j < je) { y_next += (int)(cur >> 26); j_resume = j; }    // out of budget: go on from here in the next iteration
+                else { y_next += kDtRows; j_resume = 0; }
+#ifdef MVOSR_STAMPS
+                { const int t_ = wave_max(kDtBudget - budget); if (lane == 0) { atomicAdd(&misc[40], t_); atomicAdd(&misc[44], 1); }
+                  atomicAdd(&misc[45], kDtBudget - budget); }
+#endif
+            } else {
             int j0[kDtRows], j1[kDtRows];
 #pragma unroll
             for (int r = 0; r < kDtRows; ++r) {
@@ -726,7 +867,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 if (act && y <= box.yb) dt_row_range(G, E, y, box.xa, box.xb, j0[r], j1[r]);
             }
             j0[0] = max(j0[0], j_resume);
-            int seg = 0, budget = kDtBudget;
+            int seg = 0;
             {
                 int j = j0[0], je = j1[0];
                 auto advance = [&]() {
@@ -748,6 +889,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 }
                 if (j < je) { y_next += seg; j_resume = j; }        // out of budget: go on from here in the next iteration
                 else { y_next += kDtRows; j_resume = 0; }
+            }
             }
             // (twice: a wide search the first pass raises is scanned by the wavefront at once and completed in the same step)
             for (int rep = 0; rep < 2; ++rep) {
@@ -790,7 +932,10 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 } else if (ic >= 0) {
                     const DtBox cb = dt_circle_box(G, p.x, p.y, S[iq], S[ic]);
                     if (dt_inside(cb, box)) accept = ic;
-                    else begin_search(cb, 1);                        // the circumcircle leaves what was searched: its cell box decides
+                    // the circumcircle leaves what was searched: its cell box decides.  A small box — the block and a row or
+                    // a column more, as a rule — is one more scan step of this lane, walked under the other lanes' steps; only a
+                    // large one (a sliver's circle) is worth stopping the wavefront for
+                    else begin_search(cb, 1, (cb.xb - cb.xa + 1) * (cb.yb - cb.ya + 1) > kDtCoopCells ? 1 : 0);
                 }
                 // nothing on that side within the block: the frame's half beside the edge, scanned by the wavefront (an
                 // intermediate 17 x 17 block first was measured: equal at 2000 points, 20 % slower at 300-600); the lane
@@ -894,6 +1039,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
 #ifdef MVOSR_STAMPS
     DT_NOTE(10, misc[48]); DT_NOTE(11, misc[49]); DT_NOTE(12, misc[50]); DT_NOTE(13, misc[51]);
     DT_NOTE(26, misc[61]); DT_NOTE(27, misc[62]); DT_NOTE(28, misc[63]);
+    DT_NOTE(29, misc[40]); DT_NOTE(30, misc[41]); DT_NOTE(31, misc[42]); DT_NOTE(7, misc[43]); DT_NOTE(8, misc[44]); DT_NOTE(14, misc[45]);
     if (tid == 0 && a.stamps) for (int k = 52; k < 61; ++k) a.stamps[32 * f + 16 + (k - 52)] = (unsigned long long)misc[k];
 #endif
 
@@ -1022,6 +1168,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
         int at = base + incl - mine;
         for (int o = o0; o < o1; ++o) {
             const int k = od[o] & 63;
+            if (a.info_out && !gk) a.info_out[off + o] = (uint32_t)od[o] | ((uint32_t)at << 16);    // (no keep mask: rank o = position o)
             const uint32_t *src = arena + astart[o];
             for (int j = 0; j < k; ++j) {
                 const uint32_t key = src[j];
@@ -1065,6 +1212,17 @@ extern "C" int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, con
                                            const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
                                            int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status,
                                            const int64_t *seed_off, const int32_t *seed_tri, const int32_t *seed_cnt) {
+    return mvosr_delaunay_batch_ex(ctx, n_frames, pts_off, pts_cnt, u, v, keep, max_pts, tri_off, tri, tri_cnt, n_used, status,
+                                   seed_off, seed_tri, seed_cnt, nullptr, nullptr);
+}
+
+extern "C" int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                                       const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
+                                       int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status,
+                                       const int64_t *seed_off, const int32_t *seed_tri, const int32_t *seed_cnt,
+                                       const uint32_t *seed_info, uint32_t *info_out) {
+    if (seed_info && !seed_tri) return set_error(MVOSR_ERR_ARG, "delaunay_batch_ex: seed_info without seeds");
+    if (info_out && keep) return set_error(MVOSR_ERR_ARG, "delaunay_batch_ex: info_out describes a triangulation of ALL the points (no keep mask)");
     if (!ctx || !pts_off || !pts_cnt || !u || !v || !tri_off || !tri || !tri_cnt || !status)
         return set_error(MVOSR_ERR_ARG, "delaunay_batch: null argument");
     if ((seed_off || seed_tri || seed_cnt) && !(seed_off && seed_tri && seed_cnt))
@@ -1083,6 +1241,7 @@ extern "C" int mvosr_delaunay_batch_seeded(mvosr_ctx *ctx, int64_t n_frames, con
     a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
     a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.max_pts = max_pts; a.ws = nullptr; a.hints = nullptr;
     a.seed_off = seed_off; a.seed_tri = seed_tri; a.seed_cnt = seed_cnt;
+    a.seed_info = seed_info; a.info_out = info_out;
 #ifdef MVOSR_STAMPS
     a.stamps = g_dt_stamps;
 #endif

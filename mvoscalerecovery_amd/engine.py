@@ -118,11 +118,12 @@ class DeviceBatch:
         self.device_triangulation = bool(device_triangulation)
         if device_triangulation:
             F, T = pf.n_frames, 2 * pf.total_padded
-            work = ctx.block([("tri1", (T, 3), np.int32), ("tri2", (T, 3), np.int32), ("vote_counters", pf.total_padded, np.int32)])
+            work = ctx.block([("tri1", (T, 3), np.int32), ("tri2", (T, 3), np.int32), ("vote_counters", pf.total_padded, np.int32),
+                              ("dt_info", pf.total_padded, np.uint32)])
             info = ctx.block([(k, max(F, 1), np.int32) for k in ("tri1_cnt", "tri2_cnt", "dt1_status", "dt2_status", "n2_expected")])
             self.blocks += [work, info]
             self.info = info
-            for k in ("tri1", "tri2", "vote_counters"):
+            for k in ("tri1", "tri2", "vote_counters", "dt_info"):
                 self.bufs[k] = work[k]
             for k in info.views:
                 self.bufs[k] = info[k]
@@ -137,19 +138,22 @@ class DeviceBatch:
         ctx, lib, b = self.ctx, self.ctx.lib, self.bufs
         assert self.device_triangulation
         self.info.invalidate()
-        _lib.check(lib.mvosr_delaunay_batch(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
-                                            None, int(self.max_feat), b["tri_off"].ptr, b["tri1"].ptr, b["tri1_cnt"].ptr, None,
-                                            b["dt1_status"].ptr), "mvosr_delaunay_batch (first triangulation)")
+        # (the first triangulation leaves per-point facts — rows owned, degree, hull flag, first row — from which the second
+        # carries over every star the vote did not touch instead of walking it: mvosr_delaunay_batch_ex)
+        _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
+                                               None, int(self.max_feat), b["tri_off"].ptr, b["tri1"].ptr, b["tri1_cnt"].ptr, None,
+                                               b["dt1_status"].ptr, None, None, None, None, b["dt_info"].ptr),
+                   "mvosr_delaunay_batch_ex (first triangulation)")
         o = _lib.Outputs()
         o.vote_counters = b["vote_counters"].ptr
         bs = self.struct()
         _lib.check(lib.mvosr_outlier_vote_batch(ctx.handle, C.byref(engine.params), C.byref(bs), C.byref(o), 0), "mvosr_outlier_vote_batch")
         # (seeded with the first triangulation: its triangles among the survivors are triangles of the second)
-        _lib.check(lib.mvosr_delaunay_batch_seeded(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
-                                                   b["vote_counters"].ptr, int(self.max_feat), b["tri_off"].ptr, b["tri2"].ptr,
-                                                   b["tri2_cnt"].ptr, b["n2_expected"].ptr, b["dt2_status"].ptr,
-                                                   b["tri_off"].ptr, b["tri1"].ptr, b["tri1_cnt"].ptr),
-                   "mvosr_delaunay_batch_seeded (second triangulation)")
+        _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
+                                               b["vote_counters"].ptr, int(self.max_feat), b["tri_off"].ptr, b["tri2"].ptr,
+                                               b["tri2_cnt"].ptr, b["n2_expected"].ptr, b["dt2_status"].ptr,
+                                               b["tri_off"].ptr, b["tri1"].ptr, b["tri1_cnt"].ptr, b["dt_info"].ptr, None),
+                   "mvosr_delaunay_batch_ex (second triangulation)")
 
     def triangulation_status(self):
         """Host copies of (first, second) triangulation status per frame (mvosr_dt_status; non-zero: declined)."""

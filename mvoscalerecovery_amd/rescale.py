@@ -372,18 +372,19 @@ class ScaleEstimator:
             db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True)
         bufs = db.bufs
         db.info.invalidate()
-        _lib.check(lib.mvosr_delaunay_batch(ctx.handle, db.n_frames, bufs["feat_off"].ptr, bufs["feat_cnt"].ptr, bufs["u"].ptr,
-                                            bufs["v"].ptr, None, int(db.max_feat), bufs["tri_off"].ptr, bufs["tri1"].ptr,
-                                            bufs["tri1_cnt"].ptr, None, bufs["dt1_status"].ptr), "mvosr_delaunay_batch (first triangulation)")
+        _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, db.n_frames, bufs["feat_off"].ptr, bufs["feat_cnt"].ptr, bufs["u"].ptr,
+                                               bufs["v"].ptr, None, int(db.max_feat), bufs["tri_off"].ptr, bufs["tri1"].ptr,
+                                               bufs["tri1_cnt"].ptr, None, bufs["dt1_status"].ptr, None, None, None, None,
+                                               bufs["dt_info"].ptr), "mvosr_delaunay_batch_ex (first triangulation)")
         bs = db.struct()
         keep = bufs["vote_counters"]                                        # (the block's per-feature int32 plane: here the keep flags)
         _lib.check(lib.mvosr_graph_keep_batch(ctx.handle, C.byref(bs), C.c_uint32(self._good_bits), MIN_VALID_FOR_RETRI,
                                               bufs["dt1_status"].ptr, keep.ptr, None, None), "mvosr_graph_keep_batch")   # graph.py:18-36, rescale.py:133
-        _lib.check(lib.mvosr_delaunay_batch_seeded(ctx.handle, db.n_frames, bufs["feat_off"].ptr, bufs["feat_cnt"].ptr, bufs["u"].ptr,
-                                                   bufs["v"].ptr, keep.ptr, int(db.max_feat), bufs["tri_off"].ptr, bufs["tri2"].ptr,
-                                                   bufs["tri2_cnt"].ptr, bufs["n2_expected"].ptr, bufs["dt2_status"].ptr,
-                                                   bufs["tri_off"].ptr, bufs["tri1"].ptr, bufs["tri1_cnt"].ptr),
-                   "mvosr_delaunay_batch_seeded (second triangulation)")       # rescale.py:134-137
+        _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, db.n_frames, bufs["feat_off"].ptr, bufs["feat_cnt"].ptr, bufs["u"].ptr,
+                                               bufs["v"].ptr, keep.ptr, int(db.max_feat), bufs["tri_off"].ptr, bufs["tri2"].ptr,
+                                               bufs["tri2_cnt"].ptr, bufs["n2_expected"].ptr, bufs["dt2_status"].ptr,
+                                               bufs["tri_off"].ptr, bufs["tri1"].ptr, bufs["tri1_cnt"].ptr, bufs["dt_info"].ptr, None),
+                   "mvosr_delaunay_batch_ex (second triangulation)")           # rescale.py:134-137
         db.n_rows2 = 2 * pf.total_padded
         out, flags, side = self._launch_flat_ransac(db, keep.ptr, bufs["dt2_status"].ptr, frame_base, None, id_triples, stage,
                                                     2 * int(db.max_feat))

@@ -10,8 +10,8 @@ for sz in ${AB_SIZES:-2000:4096 600:8192}; do
     echo "$a"
     for rep in 1 2; do
       for l in prod ${AB_LIBS:-col0}; do
-        if [ $l = prod ]; then r=$(python profiles/bench_delaunay.py $a 2>&1 | tail -1)
-        else r=$(MVOSR_LIB_PATH=$R/profiles/ab/libmvosr_$l.so python profiles/bench_delaunay.py $a 2>&1 | tail -1); fi
+        if [ $l = prod ]; then r=$(timeout 120 python profiles/bench_delaunay.py $a 2>&1 | tail -1)
+        else r=$(MVOSR_LIB_PATH=$R/profiles/ab/libmvosr_$l.so timeout 120 python profiles/bench_delaunay.py $a 2>&1 | tail -1); fi
         echo "$l $(echo $r | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f sets/s, declined %d' % (d['sets_per_s'], d['declined']))")"
       done
     done

