@@ -146,7 +146,7 @@ def pyhelper():
         try:
             h = C.PyDLL(path)
             h.mvosr_py_frame_pointers.restype = C.c_long
-            h.mvosr_py_frame_pointers.argtypes = [C.py_object, C.py_object, C.c_void_p, C.c_void_p, C.c_void_p]
+            h.mvosr_py_frame_pointers.argtypes = [C.py_object, C.py_object, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             _pyhelper = h
         except (OSError, AttributeError):
             _pyhelper = None

@@ -23,22 +23,29 @@ def make_params(absolute_reference, camera_pitch=K.CAMERA_PITCH, pitch_threshold
                        _lib.VOTE_FIXED if check_triangle == "fixed" else _lib.VOTE_REFERENCE)
 
 
-def frame_tables(feature3ds, feature2ds):
+def frame_tables(feature3ds, feature2ds, remap_in_place=False):
     """(data pointers of feature3ds, of feature2ds, rows per frame) as uint64 / uint64 / int32 arrays when every frame is
     a C-contiguous float64 (n,3) / (n,2) pair the C packer can read in place, else ``None``.  Through libmvosr_py.so
-    (one C loop over the lists) when it is there."""
+    (one C loop over the lists) when it is there.  ``remap_in_place``: the packer will also write feature_remap into the
+    feature3d arrays (/root/reference/src/scale_calculator.py:414) — they must then be WRITABLE (a read-only array goes to
+    the Python path, which raises ValueError at the assignment as the reference does) and DISTINCT: the packer's threads
+    would otherwise read a frame's raw values while another thread remaps the same memory (a batch that holds one array
+    object twice is packed in Python, raw values for every occurrence, remapped once per occurrence)."""
     from . import packing
     F = len(feature3ds)
     h = _lib.pyhelper()
+    tables = None
     if h is not None and type(feature3ds) is list and type(feature2ds) is list:
         p3, p2, npts = np.empty(F, np.uint64), np.empty(F, np.uint64), np.empty(F, np.int32)
-        r = h.mvosr_py_frame_pointers(feature3ds, feature2ds, _lib.addr(p3), _lib.addr(p2), _lib.addr(npts))
-        return (p3, p2, npts) if r == F else None
-    if not packing.native_packable(feature3ds, feature2ds):
+        r = h.mvosr_py_frame_pointers(feature3ds, feature2ds, _lib.addr(p3), _lib.addr(p2), _lib.addr(npts), 1 if remap_in_place else 0)
+        tables = (p3, p2, npts) if r == F else None
+    elif packing.native_packable(feature3ds, feature2ds, writable=remap_in_place) and F:
+        tables = (np.fromiter((a.__array_interface__["data"][0] for a in feature3ds), dtype=np.uint64, count=F),
+                  np.fromiter((a.__array_interface__["data"][0] for a in feature2ds), dtype=np.uint64, count=F),
+                  np.fromiter((a.shape[0] for a in feature3ds), dtype=np.int32, count=F))
+    if tables is not None and remap_in_place and F > 1 and np.unique(tables[0]).size != F:
         return None
-    return None if F == 0 else (np.fromiter((a.__array_interface__["data"][0] for a in feature3ds), dtype=np.uint64, count=F),
-                                np.fromiter((a.__array_interface__["data"][0] for a in feature2ds), dtype=np.uint64, count=F),
-                                np.fromiter((a.shape[0] for a in feature3ds), dtype=np.int32, count=F))
+    return tables
 
 
 def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=0, tables=None):

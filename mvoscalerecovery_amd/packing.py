@@ -422,12 +422,14 @@ def pack_features(feature3ds, feature2ds, vanish=VANISH):
     return PackedFrames(F, off, cnt, x, y, z, v, u, lower_index, max_feat=int(cnt.max()) if F else 0)
 
 
-def native_packable(feature3ds, feature2ds):
-    """Can the C packer (mvosr_pack_*) read these frames in place?  C-contiguous float64 (N,3) / (N,2) NumPy arrays."""
+def native_packable(feature3ds, feature2ds, writable=False):
+    """Can the C packer (mvosr_pack_*) read these frames in place?  C-contiguous float64 (N,3) / (N,2) NumPy arrays —
+    ``writable``: and may it write feature_remap into the feature3d arrays (not into a read-only one)?"""
     f64 = np.dtype(np.float64)
     for a, b in zip(feature3ds, feature2ds):
         if not (type(a) is np.ndarray and type(b) is np.ndarray and a.dtype == f64 and b.dtype == f64 and a.ndim == 2 and b.ndim == 2
-                and a.flags.c_contiguous and b.flags.c_contiguous and a.shape[1] == 3 and b.shape[1] == 2 and a.shape[0] == b.shape[0]):
+                and a.flags.c_contiguous and b.flags.c_contiguous and a.shape[1] == 3 and b.shape[1] == 2 and a.shape[0] == b.shape[0]
+                and (a.flags.writeable or not writable)):
             return False
     return True
 

@@ -453,7 +453,7 @@ class ScaleEstimator:
         the download of the results, all queued; nothing is waited for here (``_chunk_gpu_finish`` does)."""
         from .engine import frame_tables, pack_upload_native
         ctx = self.engine.ctx
-        tables = frame_tables(f3s, f2s) if len(f3s) > 0 else None
+        tables = frame_tables(f3s, f2s, remap_in_place=bool(self.mutate_inputs)) if len(f3s) > 0 else None
         native = tables is not None
         blk = None
         if native:

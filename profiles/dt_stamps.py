@@ -25,24 +25,28 @@ d_tcnt, d_st, d_used = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32), ctx.zeros
 d_stamps = ctx.zeros((F, 32), np.uint64)
 ctx.lib.mvosr_debug_dt_stamps.argtypes = [C.c_void_p]
 ctx.lib.mvosr_debug_dt_stamps(d_stamps.ptr)
+d_info = ctx.zeros(F * n, np.uint32)
 for _ in range(2):
-    _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n, d_toff.ptr,
-                                            d_tri.ptr, d_tcnt.ptr, d_used.ptr, d_st.ptr), "dt")
+    _lib.check(ctx.lib.mvosr_delaunay_batch_ex(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n, d_toff.ptr,
+                                               d_tri.ptr, d_tcnt.ptr, d_used.ptr, d_st.ptr, None, None, None, None, d_info.ptr), "dt")
 ctx.sync()
 if os.environ.get("DT_SEEDED"):
     # the second triangulation's shape: 85 % of the points kept, seeded with the rows just computed
     rng = np.random.default_rng(5)
-    keep = np.where(rng.uniform(size=F * n) < 0.85, 1, -1).astype(np.int32)
+    KEEP = float(os.environ.get("DT_KEEP", "0.85"))
+    CARRY = os.environ.get("DT_CARRY", "1") == "1"
+    keep = np.where(rng.uniform(size=F * n) < KEEP, 1, -1).astype(np.int32)
     d_keep = ctx.to_device(keep)
     d_tri2 = ctx.empty((2 * F * n, 3), np.int32)
     d_tcnt2 = ctx.zeros(F, np.int32)
     seeded = os.environ["DT_SEEDED"] == "1"
     for _ in range(2):
-        _lib.check(ctx.lib.mvosr_delaunay_batch_seeded(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n, d_toff.ptr,
-                                                       d_tri2.ptr, d_tcnt2.ptr, d_used.ptr, d_st.ptr,
-                                                       d_toff.ptr if seeded else None, d_tri.ptr if seeded else None, d_tcnt.ptr if seeded else None), "dt2")
+        _lib.check(ctx.lib.mvosr_delaunay_batch_ex(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n, d_toff.ptr,
+                                                   d_tri2.ptr, d_tcnt2.ptr, d_used.ptr, d_st.ptr,
+                                                   d_toff.ptr if seeded else None, d_tri.ptr if seeded else None, d_tcnt.ptr if seeded else None,
+                                                   d_info.ptr if (seeded and CARRY) else None, None), "dt2")
     ctx.sync()
-    print("second triangulation over 85 %% of the points, %s:" % ("seeded" if seeded else "not seeded"))
+    print("second triangulation over %.0f %% of the points, %s%s:" % (100 * KEEP, "seeded" if seeded else "not seeded", ", untouched stars carried over" if (seeded and CARRY) else ""))
 s = d_stamps.download().astype(np.float64)
 d = np.diff(s[:, :7], axis=1)
 tot = s[:, 6] - s[:, 0]

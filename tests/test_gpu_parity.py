@@ -721,6 +721,30 @@ def test_triangulation_gpu_fixed_seq4541_and_fuzz(gpu):
     assert declined > 0                                                  # the fallback was exercised
 
 
+def test_read_only_and_aliased_inputs_in_the_batch_path(gpu):
+    """with mutate_inputs (the reference's behaviour, scale_calculator.py:414) a read-only feature3d raises
+    ValueError as the reference's own assignment does — the C packer is never handed a pointer it may not write through —
+    and a batch that holds one array object twice gives the same scales in every run (no race between packer threads)."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    frames = [synth.synth_frame(i, 400 + 50 * i, base_seed=606, upper_fraction=0.1) for i in range(6)]
+    ro = frames[2][0].copy()
+    ro.flags.writeable = False
+    est = ScaleEstimator(1.75, window_size=5, triangulation="gpu")
+    with pytest.raises(ValueError):
+        est.scale_calculation_batch([f[0].copy() for f in frames[:2]] + [ro], [f[1] for f in frames[:3]])
+    assert np.array_equal(ro, frames[2][0])                                # untouched
+    keep = ScaleEstimator(1.75, window_size=5, triangulation="gpu", mutate_inputs=False)
+    want, _ = keep.scale_calculation_batch([f[0] for f in frames[:2]] + [ro], [f[1] for f in frames[:3]])
+    assert np.isfinite(want).all()
+    runs = []
+    for _ in range(3):
+        est = ScaleEstimator(1.75, window_size=5, triangulation="gpu")
+        a, b = frames[0][0].copy(), frames[1][0].copy()
+        runs.append(est.scale_calculation_batch([a, b] * 100, [frames[0][1], frames[1][1]] * 100)[0])
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+
+
 def test_triangulation_gpu_fixed_stage_goldens_of_the_patched_reference(gpu):
     """The 20 stage frames through ScaleEstimator(triangulation="gpu") against the reference run with check_triangle's
     one line patched (tests/golden/stages_fixed.npz): scale, height_level, the selected road points' count, per frame."""

@@ -93,6 +93,18 @@ def test_c_packer_equals_python_packer():
     assert engine.frame_tables([f3s[0].astype(np.float32)], [f2s[0]]) is None
     assert engine.frame_tables([f3s[0][::2]], [f2s[0][::2]]) is None
     assert engine.frame_tables([f3s[0]], [f2s[3]]) is None
+    # ... and what it must not WRITE to: a read-only feature3d when the batch remaps in place (the reference raises
+    # ValueError at /root/reference/src/scale_calculator.py:393 — so does the Python path the caller falls back to), and a
+    # batch that holds one array object twice (two packer threads on the same memory); without the remap both are fine
+    ro = f3s[0].copy()
+    ro.flags.writeable = False
+    frozen = np.frombuffer(f3s[3].tobytes(), dtype=np.float64).reshape(-1, 3)
+    for lst in ([ro], [frozen]):
+        assert engine.frame_tables(lst, [f2s[0] if lst[0] is ro else f2s[3]]) is not None
+        assert engine.frame_tables(lst, [f2s[0] if lst[0] is ro else f2s[3]], remap_in_place=True) is None
+    assert engine.frame_tables([f3s[0], f3s[3], f3s[0]], [f2s[0], f2s[3], f2s[0]], remap_in_place=True) is None
+    assert engine.frame_tables([f3s[0], f3s[3], f3s[0]], [f2s[0], f2s[3], f2s[0]]) is not None
+    assert not packing.native_packable([ro], [f2s[0]], writable=True) and packing.native_packable([ro], [f2s[0]])
 
 
 def test_lds_plan_three_frames_per_cu():
