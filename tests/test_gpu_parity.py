@@ -2035,6 +2035,41 @@ def test_bench_multi_rank_dry_runs(gpu):
     assert p.returncode != 0 and "rank 1" in p.stderr and "injected failure" in p.stderr, p.stderr[-2000:]
 
 
+def test_bench_n_rank_step_over_rccl_at_world_size_one(gpu):
+    """The exact N-rank step of bench.py — scale kernels into the rank's record, ONE RCCL all-gather of the records, the
+    window median over the gathered buffer read in place — at world size 1 over the real backend (MVOSR_BENCH_FORCE_GATHER):
+    backend nccl (= RCCL), one collective per step, and the same raw scales as the ungathered single-GPU run; --c4
+    (BASELINE configs[3]: a fixed job split over the ranks) the same way."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MVOSR_BENCH_FORCE_GATHER", "MVOSR_FORCE_DIST"):
+        base.pop(k, None)
+    common = ["--steps", "3", "--warmup", "1", "--no-e2e", "--no-cpu-baseline", "--pool", "64"]
+
+    def run(extra, gathered):
+        env = dict(base)
+        if gathered:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MVOSR_BENCH_FORCE_GATHER="1",
+                       MVOSR_FORCE_DIST="1")
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + extra + common, capture_output=True, text=True,
+                           env=env, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+
+    for extra in (["--frames", "4096"], ["--c4", "--total-frames", "10001"]):
+        g, s = run(extra, True), run(extra, False)
+        assert g["backend"] == "nccl" and g["world_size"] == 1 and g["collectives_per_step"] == 1.0, (g["backend"], g["collectives_per_step"])
+        assert s["collectives_per_step"] == 0.0
+        assert g["raw_scale_crc32"] == s["raw_scale_crc32"] and g["status_histogram"] == s["status_histogram"]
+
+
 def _device_count():
     from mvoscalerecovery_amd import _lib
     return int(_lib.load().mvosr_device_count())
