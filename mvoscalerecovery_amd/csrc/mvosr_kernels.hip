@@ -2207,6 +2207,8 @@ __global__ __launch_bounds__(DW *kWave, (DW == 8 ? 4 : 1)) void scale_frames_til
 #pragma unroll
             for (int j = 0; j < kTailBatch; ++j) {
                 const bool have = ((cb + j) << 6) + lane < cand_cnt;
+                // (|hl| IS sum |h| / count here — the form of the LDS-resident kernels' guard — because frames whose steep heights
+                // have both signs never get this far: `near` starts at 1 for them, above; tests: fuzz kind 10)
                 if (have && fabs(hm[j] - hl) <= kLevelGuard * fabs(hl)) near = 1;
                 const bool sel = have && hm[j] > hl;                                            // :243-244
                 if (sel && cb + j < 64) selbits |= 1ull << (cb + j);

@@ -168,6 +168,8 @@ def fuzz_frame(i: int, seed: int = 4321):
     (vote products exactly zero), nearly collinear pixel rows, extreme depth scales, ground-only and
     obstacle-only scenes, very few points, features above the vanishing row, negative heights."""
     rng = np.random.default_rng([seed, i])
+    if i >= 400:                                    # frames 400..: kind 10, added in round 4 (frames 0..399 are as they were)
+        return _fuzz_level_at_zero(rng)
     kind = i % 10
     n = int(rng.integers(12, 420))
     f3, f2 = synth_frame(i, n, base_seed=seed, upper_fraction=0.0)
@@ -197,6 +199,45 @@ def fuzz_frame(i: int, seed: int = 4321):
         x = (u - CX) * z / FX
         y = (v - CY) * z / FX
     return np.stack([x, y, z], axis=1).astype(np.float64), np.stack([u, v], axis=1).astype(np.float64)
+
+
+def _fuzz_level_at_zero(rng):
+    """Fuzz kind 10: the guard bands' worst case.  Steep triangles above AND below y' = 0 whose mean height — the
+    ``height_level`` of /root/reference/src/scale_calculator.py:239-241 — is tuned to within ~1e-13 of a ground plane at
+    y' = c0 ~ 1e-7: the level is within 1e-6 of zero (a guard band relative to |level| alone would be 1e-19 wide while the
+    sum's rounding error is relative to mean |h| ~ 1), and every flat triangle's height is within 1e-13 of it, so the
+    selection ``heights > height_level`` (:243-244) turns on the last bits of NumPy's pairwise sum.  Depth decreases
+    strictly with the pixel row, so every feature survives the vote and the second triangulation is the first."""
+    from scipy.spatial import Delaunay
+    n = int(rng.integers(150, 420))
+    u = rng.uniform(0.0, IMG_W, n)
+    v = rng.uniform(190.0, IMG_H, n)
+    zp = 2000.0 / (v - 150.0)                                   # z' after the remap
+    ground = rng.uniform(size=n) < 0.6
+    c0 = 1e-7 * (1.0 + rng.uniform())
+    side = np.where(rng.uniform(size=n) < 0.5, 1.0, -1.0)
+    yp = np.where(ground, c0 + rng.uniform(-1e-13, 1e-13, n), side * rng.uniform(0.3, 2.0, n))
+    xp = (u - CX) * zp / FX
+    tri = np.sort(np.asarray(Delaunay(np.stack([u, v], axis=1)).simplices), axis=1)
+    tri = tri[np.lexsort((tri[:, 2], tri[:, 1], tri[:, 0]))]     # (a function of the triangle set: the frame must not depend on the row form)
+    for _ in range(8):                                          # the level is linear in a common shift of the obstacles
+        P = np.stack([xp, yp, zp], axis=1)[tri]
+        nrm = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+        sgn = np.sign(np.einsum("ij,ij->i", nrm, P[:, 0]))      # n = A^-1 . 1 points away from the origin's side of the plane
+        with np.errstate(all="ignore"):
+            pitch = np.degrees(np.arcsin(-sgn * nrm[:, 1] / np.linalg.norm(nrm, axis=1)))
+        steep = ~(pitch < -80.0)
+        if not steep.any():
+            break
+        level = P[:, :, 1].mean(axis=1)[steep].mean()
+        k = (~ground)[tri].sum(axis=1)[steep].mean() / 3.0
+        if not k > 0:
+            break
+        yp = np.where(ground, yp, yp + (c0 - level) / k)
+    c, s_ = np.cos(-0.5 * np.pi / 180), np.sin(-0.5 * np.pi / 180)   # invert feature_remap (:390-394): the path rotates back
+    y = yp * c + zp * s_
+    z = -yp * s_ + zp * c
+    return np.stack([xp, y, z], axis=1).astype(np.float64), np.stack([u, v], axis=1).astype(np.float64)
 
 
 def too_few_sequence(seed: int = 2718, n_frames: int = 12, few_at=(0, 4, 5, 9)):

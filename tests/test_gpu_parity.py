@@ -301,6 +301,49 @@ def test_dense_tiled_kernel(gpu):
     db.free()
 
 
+def test_level_at_zero_family_through_every_kernel(gpu):
+    """Fuzz kind 10 — steep triangles above and below y' = 0, height_level within 1e-6 of zero, every flat triangle within
+    1e-13 of it: the case a guard band relative to |level| alone would miss — through the product (HOT + its exact pass)
+    variants with 1/4/8/16 wavefronts, the EXACT variant, the tiled dense kernel and the device-triangulation path,
+    against the reference's own selection (tests/golden/level_zero.npz, level_zero_fixed.npz): selected counts, the
+    selected mask and the level to the last bit where the variant promises it."""
+    from mvoscalerecovery_amd import synth, constants as K
+    from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs, ScaleEngine
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "level_zero.npz"))
+    n = int(z["count"])
+    frames = [synth.fuzz_frame(int(z["first"]) + k, int(z["seed"])) for k in range(n)]
+    ores = _oracle_frames(frames)
+    want_sel = [len(z["f%d_selected_ids" % k]) for k in range(n)]
+    eng = ScaleEngine(1.75, ctx=gpu)
+    for waves in (0, 1, 4, 8, 16):
+        for stage in (False, True):
+            pf, res = _run_fused(gpu, frames, ores, waves=waves, stage=stage, hist=False)
+            for k in range(n):
+                assert res["status"][k] == ores[k].status, (waves, stage, k)
+                assert res["counts"][k, K.CNT_SELECTED] == want_sel[k], (waves, stage, k, res["counts"][k, K.CNT_SELECTED], want_sel[k])
+                if stage:
+                    assert res["height_level"][k] == float(z["f%d_height_level" % k]), (waves, k)
+                    sel = np.nonzero(res["selected"][pf.frame_slice(k)][:int(ores[k].valid.sum())])[0]
+                    assert np.array_equal(sel, z["f%d_selected_ids" % k]), (waves, k)
+    pf = _pack_tiled(frames, ores)                       # the tiled dense kernel on the same frames
+    db = DeviceBatch(gpu, pf)
+    out = DeviceOutputs(gpu, db, counts=True)
+    eng.scale_batch(db, out)
+    gpu.sync()
+    st, cnt = out.get("status"), out.get("counts")
+    out.free(); db.free()
+    for k in range(n):
+        assert st[k] == ores[k].status and cnt[k, K.CNT_SELECTED] == want_sel[k], ("tiled", k)
+    zf = np.load(os.path.join(os.path.dirname(__file__), "golden", "level_zero_fixed.npz"))
+    est = ScaleEstimator(1.75, window_size=5, triangulation="gpu", mutate_inputs=False)
+    raw, status, level, _ = est.raw_scale_batch([f[0] for f in frames], [f[1] for f in frames])
+    for k in range(n):
+        assert est.last_counts[k, K.CNT_SELECTED] == len(zf["f%d_selected_ids" % k]), ("gpu triangulation", k)
+        assert status[k] == K.ST_ERR_LEFT
+
+
 def test_dense_tiled_kernel_refuses_a_bad_index(gpu):
     """The tile index is input too: a non-monotone index, or one that walks a row after the tile of its smallest vertex
     has left the ring, gives MVOSR_ST_ERR_MASK for that frame (and only that frame)."""

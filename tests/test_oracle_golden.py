@@ -350,6 +350,25 @@ def test_fixed_mode_frame_fuzz_from_the_patched_reference():
             assert (np.isnan(s) and np.isnan(z["scale"][i])) or s == z["scale"][i], (i, s, z["scale"][i])
 
 
+def test_level_at_zero_family_golden():
+    """Fuzz kind 10 (steep triangles of both signs, height_level within 1e-6 of zero, flat triangles within 1e-13 of it)
+    against the reference's own stage methods (tests/golden/level_zero.npz; level_zero_fixed.npz for the patched
+    reference): the level to the last bit, the selected ids."""
+    from mvoscalerecovery_amd import synth
+    for name, mode in (("level_zero.npz", "reference"), ("level_zero_fixed.npz", "fixed")):
+        z = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+        for k in range(int(z["count"])):
+            f3, f2 = synth.fuzz_frame(int(z["first"]) + k, int(z["seed"]))
+            assert float(np.sum(f3)) + float(np.sum(f2)) == float(z["f%d_sum" % k]), k
+            r = so.frame_raw_scale(f3, f2, 1.75, check_triangle=mode)
+            assert np.array_equal(r.valid, z["f%d_valid" % k]), (name, k)
+            assert r.height_level == float(z["f%d_height_level" % k]), (name, k, r.height_level)
+            assert abs(r.height_level) < 1e-6
+            assert np.array_equal(r.sel.selected_ids, z["f%d_selected_ids" % k]), (name, k)
+            h, flat = r.sel.heights, r.sel.valid_pitch
+            assert (h[~flat] > 0).any() and (h[~flat] < 0).any() and (np.abs(h[flat] - r.height_level) < 1e-12).sum() > 20
+
+
 def test_too_few_lower_features_branch():
     """scale_calculator.py:263-270: exactly three features below the vanishing row -> no second triangulation,
     the scale is absolute_reference / (height_level of an earlier frame), std 100; AttributeError on a fresh estimator."""
