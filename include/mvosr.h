@@ -180,6 +180,12 @@ typedef struct mvosr_batch {
      * (/root/reference/src/scale_calculator.py:239-240): with the table the exact pass sums in the original order and
      * the level is the reference's double to the last bit; without it (NULL) in the stored order (equal to rounding). */
     const int32_t *tri2_order;
+    /* Optional [F] (NULL: none): frames whose byte is non-zero are finished in the EXACT mode — height_level summed in
+     * NumPy's own order — by the product launch itself (they join the few frames its exact pass redoes anyway).  For the
+     * frames whose level a LATER step reads: the frame before one that takes the reference's "no enough feature for
+     * triangulation" branch and divides by the previous level (/root/reference/src/scale_calculator.py:263-270,:420-422),
+     * the last frame of a chunk, the frame the estimator's height_level is left at when the next one raises. */
+    const uint8_t *exact_mask;
 } mvosr_batch;
 
 #define MVOSR_TILE_W 512
@@ -313,6 +319,9 @@ void mvosr_default_params(mvosr_params *p, double absolute_reference);
  * single frames this way when a later step will read their level).
  */
 #define MVOSR_WAVES_EXACT 0x100
+/* or-ed into waves_per_frame: ONLY the frames of the range with a non-zero exact_mask byte are (re)done, in the exact mode;
+ * every other frame's outputs stay as they are (the host asks for the neighbours of a frame that raised, once it knows). */
+#define MVOSR_WAVES_EXACT_MASKED 0x200
 int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b,
                       const mvosr_outputs *o, int waves_per_frame,
                       int64_t first_frame, int64_t n_launch);

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("MVOSR_LIB_PATH") or os.path.join(os.path.dirname(os.p
 ABI_VERSION = 8
 VOTE_REFERENCE, VOTE_FIXED = 0, 1          # mvosr_params.vote_mode
 WAVES_EXACT = 0x100                        # MVOSR_WAVES_EXACT, or-ed into waves_per_frame
+WAVES_EXACT_MASKED = 0x200                 # MVOSR_WAVES_EXACT_MASKED: only the frames of mvosr_batch.exact_mask, in the exact mode
 MARK_NOW, MARK_IDLE, MARK_UPLOAD = 1, 2, 3 # mvosr_block_mark
 TRI2_SURVIVORS, TRI2_FEATURES = 0, 1      # mvosr_batch.tri2_ids
 N_COUNTS = 8
@@ -42,7 +43,7 @@ class Batch(C.Structure):
                 ("tile_w", C.c_int32), ("min_feat", C.c_int32), ("tile_base", C.c_void_p),
                 ("tile1_off", C.c_void_p), ("tile2_off", C.c_void_p), ("size_hint", C.c_int32 * 4),
                 ("tile_far", C.c_void_p), ("tile_far_off", C.c_void_p),
-                ("tri1_cnt", C.c_void_p), ("tri2_cnt", C.c_void_p), ("tri2_order", C.c_void_p)]
+                ("tri1_cnt", C.c_void_p), ("tri2_cnt", C.c_void_p), ("tri2_order", C.c_void_p), ("exact_mask", C.c_void_p)]
 
 
 class Outputs(C.Structure):

@@ -2503,6 +2503,23 @@ static int check_fit(const mvosr_batch *b, int waves, int sc, size_t lds) {
     return MVOSR_OK;
 }
 
+// mvosr_batch.exact_mask: frames the caller wants finished in the exact mode (their height_level is read by a later step)
+// are appended to the redo list behind the HOT kernel — unless that kernel put them there itself or refused them.  The HOT
+// kernels are untouched: a masked frame is simply done twice, and a chunk has one or two of them.
+__global__ __launch_bounds__(256) void append_mask_kernel(const uint8_t *mask, const int32_t *status, int64_t first, int64_t n, int32_t *redo) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t f = first + k;
+    // (behind the HOT kernel: only frames it left for the road model — not the ones already on the list, refused, or in error)
+    if (mask[f] && (!status || status[f] == kStPending)) redo[1 + atomicAdd(redo, 1)] = (int32_t)f;
+}
+static int launch_append_mask(mvosr_ctx *ctx, const KArgs &ka, int64_t nl, bool check_status) {
+    if (!ka.b.exact_mask) return MVOSR_OK;
+    hipLaunchKernelGGL(append_mask_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx_stream(ctx), ka.b.exact_mask,
+                       check_status ? ka.o.status : (const int32_t *)nullptr, ka.first_frame, nl, ka.redo);
+    return check_launch("append_mask_kernel");
+}
+
 // One step of a scale-kernel family (its HOT / EXACT / FULL instantiations): FULL and EXACT run every frame of the
 // range in that mode; HOT runs the product variant and then the EXACT variant over the redo list the HOT kernel
 // filled (a short persistent grid: the list's length is only known on the device, and is almost always zero).
@@ -2540,6 +2557,7 @@ static int launch_modes(mvosr_ctx *ctx, void (*k_hot)(const Args), void (*k_exac
     if (e != hipSuccess) return set_hip_error("hipMemsetAsync(redo list)", e);
     hipLaunchKernelGGL(k_hot, dim3((unsigned)nl), dim3(threads_hot), lds_hot, ctx_stream(ctx), args);
     if ((rc = check_launch(name))) return rc;
+    if ((rc = launch_append_mask(ctx, kargs_of(args), nl, true))) return rc;
     kargs_of(args).redo_pass = 1;
     const unsigned grid = (unsigned)(nl < (int64_t)kRedoGrid ? nl : (int64_t)kRedoGrid);
     hipLaunchKernelGGL(k_exact, dim3(grid), dim3(threads), lds, ctx_stream(ctx), args);
@@ -2732,7 +2750,8 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     int rc = check_common(ctx, p, b, o);
     if (rc) return rc;
     const bool want_exact = (waves_per_frame & MVOSR_WAVES_EXACT) != 0;
-    waves_per_frame &= ~MVOSR_WAVES_EXACT;
+    const bool want_masked = (waves_per_frame & MVOSR_WAVES_EXACT_MASKED) != 0;
+    waves_per_frame &= ~(MVOSR_WAVES_EXACT | MVOSR_WAVES_EXACT_MASKED);
     if (!b->x || !b->y || !b->z || !b->v || !b->tri1_off || !b->tri2_off || !b->tri2)
         return set_error(MVOSR_ERR_ARG, "scale_batch: missing input plane / triangulation");
     if (!o->raw_scale || !o->height || !o->height_level || !o->status)
@@ -2777,8 +2796,21 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     const bool by_class = mode == MODE_HOT && !dense && waves_per_frame == 0 && n_launch >= kClassMinFrames &&
                           b->max_feat > kClassThr0 && !(debug_skip_env() & 64) &&
                           (b->min_feat <= 0 || pick_waves(0, b->min_feat) != waves);
+    if (want_masked) {
+        // the EXACT variant over the frames of the range whose exact_mask byte is set, the road model over the same list;
+        // every other frame's outputs stay as they are
+        if (!b->exact_mask) return set_error(MVOSR_ERR_ARG, "scale_batch: MVOSR_WAVES_EXACT_MASKED without batch.exact_mask");
+        const hipError_t e0 = hipMemsetAsync(ka.redo, 0, sizeof(int32_t), ctx_stream(ctx));
+        if (e0 != hipSuccess) return set_hip_error("hipMemsetAsync(redo list)", e0);
+        if ((rc = launch_append_mask(ctx, ka, n_launch, false))) return rc;
+        if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, kModeExactList, false) : dispatch_scale(ctx, ka, waves, n_launch, kModeExactList))) return rc;
+        ra.first_frame = first_frame; ra.n_frames = n_launch; ra.list = ka.redo;
+        ra.wide = (dense && !(debug_skip_env() & 256)) ? 1 : 0;
+        return launch_road(ctx, ra, ctx_stream(ctx));
+    }
     if (by_class) {
         if ((rc = launch_scale_classes(ctx, ka, n_launch))) return rc;
+        if ((rc = launch_append_mask(ctx, ka, n_launch, true))) return rc;
         if ((rc = dispatch_scale(ctx, ka, waves, n_launch, kModeExactList))) return rc;
     } else if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, mode, false) : dispatch_scale(ctx, ka, waves, n_launch, mode))) return rc;
     if (pev && (ee = hipEventRecord(pev[1], ctx_stream(ctx))) != hipSuccess) return set_hip_error("hipEventRecord(profile)", ee);

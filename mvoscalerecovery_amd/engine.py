@@ -23,6 +23,24 @@ def make_params(absolute_reference, camera_pitch=K.CAMERA_PITCH, pitch_threshold
                        _lib.VOTE_FIXED if check_triangle == "fixed" else _lib.VOTE_REFERENCE)
 
 
+def exact_mask_of(feat_cnt, everything=False):
+    """mvosr_batch.exact_mask for a chunk: the frames whose ``height_level`` a LATER step reads get it summed in NumPy's own
+    order by the product launch itself — the last frame of the chunk that sets a level (the next chunk, or the caller, may
+    read it: a frame with exactly three features below the vanishing row divides by the level an earlier frame left,
+    /root/reference/src/scale_calculator.py:263-270,:420-422; a frame that raises leaves the estimator at it) and every frame
+    directly followed by such a three-feature frame.  ``everything``: all frames (small re-run batches)."""
+    cnt = np.asarray(feat_cnt)
+    if everything:
+        return np.ones(len(cnt), dtype=np.uint8)
+    m = np.zeros(len(cnt), dtype=np.uint8)
+    ok = np.nonzero(cnt > 3)[0]
+    if len(ok):
+        m[ok[-1]] = 1
+        nxt = ok[ok + 1 < len(cnt)]
+        m[nxt[cnt[nxt + 1] == 3]] = 1
+    return m
+
+
 def frame_tables(feature3ds, feature2ds, remap_in_place=False):
     """(data pointers of feature3ds, of feature2ds, rows per frame) as uint64 / uint64 / int32 arrays when every frame is
     a C-contiguous float64 (n,3) / (n,2) pair the C packer can read in place, else ``None``.  Through libmvosr_py.so
@@ -68,7 +86,8 @@ def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=
     # above the vanishing row) and the packer reports how many it kept
     off, total = packing.pack_layout(npts)
     blk = ctx.block([("feat_off", F, np.int64), ("feat_cnt", F, np.int32), ("x", total, np.float64), ("y", total, np.float64),
-                     ("z", total, np.float64), ("v", total, np.float64), ("u", total, np.float64), ("tri_off", F, np.int64)])
+                     ("z", total, np.float64), ("v", total, np.float64), ("u", total, np.float64), ("tri_off", F, np.int64),
+                     ("exact_mask", F, np.uint8)])
     stage = blk.staging()
     sv = lambda k: stage.view(blk[k].offset, blk[k].shape, blk[k].dtype)
     sv("feat_off")[:] = off
@@ -82,6 +101,7 @@ def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=
                                    _lib.addr(cnt_view)),
                "mvosr_pack_fill")
     cnt = np.array(cnt_view, dtype=np.int32, copy=True)
+    sv("exact_mask")[:] = exact_mask_of(cnt)
     blk.commit(stage)
     pf = PackedFrames(F, off, cnt, None, None, None, None, None, [None] * F, max_feat=int(cnt.max()) if F else 0)
     pf.extra["total_padded"] = total
@@ -92,7 +112,7 @@ class DeviceBatch:
     """HBM-resident image of a packed batch: ONE device block per upload (features + first triangulation; second
     triangulation + tile index), each filled by one staged asynchronous copy (``_lib.DeviceBlock``)."""
 
-    def __init__(self, ctx: _lib.Context, pf: PackedFrames, with_tri2=True, device_triangulation=False, uploaded=None):
+    def __init__(self, ctx: _lib.Context, pf: PackedFrames, with_tri2=True, device_triangulation=False, uploaded=None, exact_all=False):
         """``device_triangulation``: both triangulations will be BUILT on the device (:meth:`triangulate`) — the pixel
         column ``u`` travels too, and rows, row counts, vote counters and survivor counts get device buffers that the
         stages hand to each other; nothing of them visits the host."""
@@ -112,7 +132,8 @@ class DeviceBatch:
             self.blocks.append(uploaded)
             self.bufs.update(uploaded.views)
         else:
-            arrays = {"feat_off": (pf.feat_off, np.int64), "feat_cnt": (pf.feat_cnt, np.int32)}
+            arrays = {"feat_off": (pf.feat_off, np.int64), "feat_cnt": (pf.feat_cnt, np.int32),
+                      "exact_mask": (exact_mask_of(pf.feat_cnt, exact_all) if pf.n_frames else np.zeros(1, np.uint8), np.uint8)}
             for name in ("x", "y", "z", "v"):
                 arrays[name] = (getattr(pf, name), np.float64)
             if pf.tri1_off is not None and not device_triangulation:
@@ -216,12 +237,17 @@ class DeviceBatch:
             self._struct.tri1_cnt = p("tri1_cnt")
             self._struct.tri2_cnt = p("tri2_cnt")
             self._struct.tri2_order = p("tri2_order")
+            self._struct.exact_mask = p("exact_mask")
             if self.n_frames:               # min_feat + the size classes' counts (ragged batches launch per class)
                 mf = self._struct.max_feat
                 _lib.check(self.ctx.lib.mvosr_batch_size_hint(_lib.addr(self._feat_cnt_host), self.n_frames,
                                                               C.byref(self._struct)), "mvosr_batch_size_hint")
                 self._struct.max_feat = max(mf, self._struct.max_feat)
         return self._struct
+
+    def set_exact_mask(self, mask):
+        """Replace the batch's exact mask (``engine.scale_batch(..., masked=True)`` then redoes exactly those frames)."""
+        self.bufs["exact_mask"].upload(np.ascontiguousarray(mask, dtype=np.uint8))
 
     def free(self):
         for b in self.blocks:
@@ -302,13 +328,16 @@ class ScaleEngine:
         self.lib = self.ctx.lib
         self.params = make_params(absolute_reference, **param_kw)
 
-    def scale_batch(self, batch: DeviceBatch, out: DeviceOutputs, waves=0, first=0, count=0, exact=False):
+    def scale_batch(self, batch: DeviceBatch, out: DeviceOutputs, waves=0, first=0, count=0, exact=False, masked=False):
+        """``exact``: every frame of the range in the exact mode; ``masked``: ONLY the frames of the batch's exact mask, in
+        the exact mode — the other frames' outputs stay as they are."""
         b, o = batch.struct(), out.struct()
         out.invalidate()
         if getattr(batch, "_marked", False):
             batch.mark(False)
+        flags = (_lib.WAVES_EXACT if exact else 0) | (_lib.WAVES_EXACT_MASKED if masked else 0)
         _lib.check(self.lib.mvosr_scale_batch(self.ctx.handle, C.byref(self.params), C.byref(b), C.byref(o),
-                                              int(waves) | (_lib.WAVES_EXACT if exact else 0), int(first), int(count)), "mvosr_scale_batch")
+                                              int(waves) | flags, int(first), int(count)), "mvosr_scale_batch")
 
     def outlier_vote_batch(self, batch: DeviceBatch, out: DeviceOutputs, waves=0):
         b, o = batch.struct(), out.struct()

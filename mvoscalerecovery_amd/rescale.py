@@ -495,11 +495,15 @@ class ScaleEstimator:
         results, bounds = [], []
         if self.triangulation == "gpu":
             C_ = int(min(self.GPU_CHUNK, max(512, -(-F // 4))))
+            # short first chunks (C/8, C/4, C/2): the GPU starts after the pack + upload of an eighth of a chunk
+            ramp = [C_ // 8, C_ // 4, C_ // 2] if (C_ >= 2048 and F >= 3 * C_) else []
             queue, a = [], 0
             while a < F:
-                b = min(F, a + C_)
-                tot = np.cumsum(np.fromiter((len(x) for x in feature3ds[a:b]), dtype=np.int64, count=b - a))
-                b = min(b, a + max(int(np.searchsorted(tot, self.GPU_CHUNK_POINTS, side="right")), 1))
+                b = min(F, a + (ramp[len(bounds)] if len(bounds) < len(ramp) else C_))
+                lens = np.fromiter((len(x) for x in feature3ds[a:b]), dtype=np.int64, count=b - a)
+                b = min(b, a + max(int(np.searchsorted(np.cumsum(lens), self.GPU_CHUNK_POINTS, side="right")), 1))
+                while b - a > 1 and (b - a) * int(lens[:b - a].max()) > 2 * self.GPU_CHUNK_POINTS:     # (workspace = frames x largest frame)
+                    b = a + max(1, (b - a) // 2)
                 tr = None if id_triples is None else id_triples[a:b]
                 queue.append((self._chunk_dev_gpu(feature3ds[a:b], feature2ds[a:b], base + a, tr, stage), a, b))
                 bounds.append((a, b))

@@ -293,7 +293,7 @@ class ScaleEstimator:
         return filtered, stds
 
     # -- one chunk of frames through the stages; the Delaunay calls are submitted to the pool and collected later
-    def _chunk_begin(self, f3s, f2s, k, tri1s=None, _packed=None, _remapped=False):
+    def _chunk_begin(self, f3s, f2s, k, tri1s=None, _packed=None, _remapped=False, _exact_all=False):
         """Vanishing-row filter + packing (:252-254) and the start of the first triangulation (:257), on the host."""
         if _packed is not None:
             pf = _packed                                               # (packed — and the caller's arrays remapped — already)
@@ -312,7 +312,7 @@ class ScaleEstimator:
             h1 = tri1s
         else:
             h1 = packing.submit_tri1(pf, self.delaunay_workers, slot=k % 4)
-        st = {"pf": pf, "h1": h1, "n": len(f3s), "out": None, "dbatch": None, "masks": None}
+        st = {"pf": pf, "h1": h1, "n": len(f3s), "out": None, "dbatch": None, "masks": None, "exact_all": bool(_exact_all)}
         if _remapped:
             st["eng"] = self._plain_engine()
         return st
@@ -327,7 +327,7 @@ class ScaleEstimator:
             # dense frames gather from global memory: lay the batch out for the tiled kernel (results are
             # order-independent; vertex order inside triangle rows is untouched)
             packing.apply_tile_order(pf)
-        st["dbatch"] = DeviceBatch(ctx, pf, with_tri2=False)
+        st["dbatch"] = DeviceBatch(ctx, pf, with_tri2=False, exact_all=st.get("exact_all", False))
         if tri2s is None:
             vote_out = DeviceOutputs(ctx, st["dbatch"], counts=True, stage=True)
             eng.outlier_vote_batch(st["dbatch"], vote_out)
@@ -356,50 +356,47 @@ class ScaleEstimator:
         eng.scale_batch(st["dbatch"], out)
         host_errors = dict(pf.extra["tri2_errors"])                           # QhullError at :266
         host_errors.update(pf.extra["tri1_errors"])                           # ... or already at :257
-        if not stage:
-            self._exact_rerun(eng, st["dbatch"], out, pf, host_errors)
         ctx.sync()
         res = (out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts"))
+        if not stage:
+            res = (res[0], res[1], self._exact_after(eng, st["dbatch"], out, res[1], res[2], host_errors), res[3])
         st["out"] = out
         if not keep:
             self._chunk_free(st)
         return res + (host_errors,)
 
-    def _exact_rerun(self, eng, db, out, pf, host_errors, errors_only=False, last=True):
-        """The product (HOT) kernel leaves ``height_level`` as its own fixed-order sum wherever the level decides nothing
-        in the frame itself.  Where a LATER step reads a frame's level, it must be np.mean's own double: the frame before
-        one that takes the "no enough feature for triangulation" branch (3 features below the vanishing row: :263-270
-        divides by the previous level, :420-422), the last frame of the chunk (``last``: unless the caller knows that the
-        next chunk does not start with such a frame), and —
-        since the estimator keeps the level of the last frame that reached :241 when a frame raises — the frame before
-        the chunk's first error and that frame itself when its road model raised (:343-344 come after :241).  Those
-        frames run once more, alone, in the exact mode the stage outputs select.  ``host_errors is None``: only the
-        frames known before any result is (no wait for the GPU); ``errors_only``: only the error-related ones."""
-        ctx = self.engine.ctx
-        cnt = pf.feat_cnt
-        ok = np.nonzero(cnt > 3)[0]
-        again = set()
-        if not errors_only:
-            nxt = ok[ok + 1 < len(cnt)]
-            again = set(int(g) for g in nxt[cnt[nxt + 1] == 3])
-            if len(ok) and last:
-                again.add(int(ok[-1]))
-        if host_errors is not None:
-            status = out.get("status")
-            bad = np.isin(status, K.ERROR_STATUSES)
-            for f in host_errors:
-                bad[f] = True
-            if bad.any():
-                e = int(np.argmax(bad))
-                if status[e] in (K.ST_ERR_LEFT, K.ST_ERR_RIGHT) and e not in host_errors:
-                    again.add(e)
-                prev = [int(g) for g in ok if g < e]
-                if prev:
-                    again.add(prev[-1])
-        for g in sorted(again):
-            eng.scale_batch(db, out, first=g, count=1, exact=True)
-        if again and host_errors is not None:
-            ctx.sync()
+    def _exact_after(self, eng, db, out, status, level, host_errors, skip=()):
+        """The product (HOT) kernel leaves ``height_level`` as its own fixed-order sum wherever the level decides nothing in
+        the frame itself; the frames whose level a LATER step reads are finished in the exact mode by the launch itself
+        (``engine.exact_mask_of``: a chunk's last level-setting frame, the frame before a three-feature frame).  What only
+        the results can tell is a frame that RAISES: the estimator then keeps the level of the last frame that reached :241
+        — the frame before the chunk's first error, and that frame itself when it was its road model that raised
+        (:343-344 come after :241).  Those one or two frames are redone here, in ONE masked launch; ``skip``: frames whose
+        values came from an all-exact re-run already.  Returns the chunk's levels."""
+        status = np.asarray(status)
+        bad = np.isin(status, K.ERROR_STATUSES)
+        for f in host_errors:
+            bad[f] = True
+        if not bad.any():
+            return level
+        e = int(np.argmax(bad))
+        mask = np.zeros(len(status), dtype=np.uint8)
+        setters = np.nonzero(~np.isin(status[:e], (K.ST_TOO_FEW,) + tuple(K.ERROR_STATUSES)))[0]
+        if len(setters):
+            mask[int(setters[-1])] = 1
+        if status[e] in (K.ST_ERR_LEFT, K.ST_ERR_RIGHT) and e not in host_errors:
+            mask[e] = 1
+        for f in skip:
+            mask[int(f)] = 0
+        if not mask.any():
+            return level
+        db.set_exact_mask(mask)
+        eng.scale_batch(db, out, masked=True)
+        self.engine.ctx.sync()
+        new = out.get("height_level")
+        level = np.array(level, copy=True)
+        level[mask != 0] = new[mask != 0]
+        return level
 
     @staticmethod
     def _chunk_free(st):
@@ -447,7 +444,7 @@ class ScaleEstimator:
     GPU_CHUNK = 8192            # frames per chunk of the device-triangulation path, at most (a call of F frames uses chunks of F/4, 512 at least: the pipeline needs a few)
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk (40 B each in staging memory, ~180 B each on the device)
 
-    def _chunk_gpu(self, f3s, f2s, stage, last=True):
+    def _chunk_gpu(self, f3s, f2s, stage):
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
         ONE upload -> Delaunay #1, vote, Delaunay #2, scale kernel, road model, the exact re-runs known in advance and
         the download of the results, all queued; nothing is waited for here (``_chunk_gpu_finish`` does)."""
@@ -476,9 +473,7 @@ class ScaleEstimator:
         db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk)
         db.triangulate(self.engine)
         out = DeviceOutputs(ctx, db, counts=True, stage=stage)
-        self.engine.scale_batch(db, out)
-        if not stage:
-            self._exact_rerun(self.engine, db, out, pf, None, last=last)
+        self.engine.scale_batch(db, out)          # (the frames whose level a later step reads are on the batch's exact mask)
         out.prefetch()
         db.prefetch_info()
         db.mark()                     # the chunk's last launch is queued: its blocks' next users need not wait for later chunks
@@ -501,17 +496,19 @@ class ScaleEstimator:
         db, out = st["dbatch"], st["out"]
         s1, s2 = db.triangulation_status()
         redo = np.nonzero((s1 != 0) | (s2 != 0))[0]
-        if not stage:
-            self._exact_rerun(eng, db, out, pf, {int(f): True for f in redo}, errors_only=True)
         raw, status, level, counts = out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts")
         host_errors = {}
         self.last_declined = len(redo)
         if len(redo):
-            sub = self._chunk_begin([f3s[f] for f in redo], [f2s[f] for f in redo], 0, _remapped=st["remapped"])
+            # (every frame of the small re-run in the exact mode: a declined frame's level may be the one a later frame reads)
+            sub = self._chunk_begin([f3s[f] for f in redo], [f2s[f] for f in redo], 0, _remapped=st["remapped"], _exact_all=True)
             self._chunk_vote(sub, None, 0)
             r_raw, r_status, r_level, r_counts, r_err = self._chunk_scale(sub, None, False)
             raw[redo], status[redo], level[redo], counts[redo] = r_raw, r_status, r_level, r_counts
             host_errors = {int(redo[k]): e for k, e in r_err.items()}
+        if not stage:
+            # with the re-run's results merged in: the neighbours of the chunk's first REAL error
+            level = self._exact_after(eng, db, out, status, level, host_errors, skip=redo)
         if stage:
             c = db.bufs["vote_counters"].download()
             st["masks"] = [c[pf.frame_slice(f)] >= 0 for f in range(pf.n_frames)]
@@ -546,25 +543,21 @@ class ScaleEstimator:
             a_, k_ = 0, 0
             while a_ < F:
                 b_ = min(F, a_ + (ramp[k_] if k_ < len(ramp) else C))
-                tot = np.cumsum(np.fromiter((len(x) for x in feature3ds[a_:b_]), dtype=np.int64, count=b_ - a_))
-                over = int(np.searchsorted(tot, self.GPU_CHUNK_POINTS, side="right"))
+                lens = np.fromiter((len(x) for x in feature3ds[a_:b_]), dtype=np.int64, count=b_ - a_)
+                over = int(np.searchsorted(np.cumsum(lens), self.GPU_CHUNK_POINTS, side="right"))
                 b_ = min(b_, a_ + max(over, 1))
+                # the triangulation's workspace is sized frames x LARGEST frame (mvosr_delaunay_batch): one 20 000-point frame
+                # among thousands of small ones must not turn into a 20 GB request — such a chunk is cut short
+                while b_ - a_ > 1 and (b_ - a_) * int(lens[:b_ - a_].max()) > 2 * self.GPU_CHUNK_POINTS:
+                    b_ = a_ + max(1, (b_ - a_) // 2)
                 yield a_, b_
                 a_, k_ = b_, k_ + 1
 
         bounds = []
-        results, queue, reran_last = [], [], []
+        results, queue = [], []
         for k, (a, b) in enumerate(chunk_bounds()):
             bounds.append((a, b))
-            # the chunk's last level is read later only by the batch's caller (last chunk) or by a frame with exactly three
-            # features below the vanishing row at the head of the next chunk (:263-270): one exact single-frame run less
-            # per chunk otherwise (a serial ~0.3 ms each)
-            last = b == F
-            if not last:
-                nxt = np.asarray(feature2ds[b])
-                last = nxt.ndim != 2 or nxt.shape[0] == 0 or int(np.count_nonzero(nxt[:, 1] > self.vanish)) <= 3
-            reran_last.append(last)
-            queue.append((self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage, last=last), a, b))
+            queue.append((self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage), a, b))
             # GPU_PIPELINE chunks stay queued behind the one whose results are collected: this process packs and uploads
             # the next chunk meanwhile (the kernel timeline shows the GPU 98 % busy between a call's first and last chunk
             # with one: what a call pays beyond its kernels is its first chunk's pack + upload and the host's epilogue)
@@ -581,23 +574,6 @@ class ScaleEstimator:
         host_errors = {}
         for (a, _), r in zip(bounds, results):
             host_errors.update({a + f: e for f, e in r[4].items()})
-        # A frame that raises leaves the level of the last frame that reached :241 on the estimator.  Inside a chunk that
-        # frame was run in the exact mode (_exact_rerun); when it is the tail of an EARLIER chunk whose last frame was not
-        # (see above), it is run once more now, alone, through the host's path with the stage outputs.
-        bad = np.isin(status, K.ERROR_STATUSES)
-        for f in host_errors:
-            bad[f] = True
-        if bad.any() and not stage:
-            e = int(np.argmax(bad))
-            setters = np.nonzero(status[:e] != K.ST_TOO_FEW)[0]
-            if len(setters):
-                g = int(setters[-1])
-                k = next(i for i, (a, b) in enumerate(bounds) if a <= g < b)
-                if e >= bounds[k][1] and not reran_last[k]:
-                    one = self._chunk_begin([feature3ds[g]], [feature2ds[g]], 0, _remapped=bool(self.mutate_inputs))
-                    self._chunk_vote(one, None, 0)
-                    r = self._chunk_scale(one, None, True)
-                    level[g] = r[2][0]
         return raw, status, level, counts, host_errors, ps
 
     def _flat_feature_of(self, feature3d, feature2d, st):

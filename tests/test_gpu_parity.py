@@ -616,8 +616,8 @@ def test_triangulation_gpu_fixed_is_bit_equal_to_oracle(gpu):
 
 def test_triangulation_gpu_error_at_a_chunk_head_leaves_the_exact_level(gpu):
     """A frame that raises leaves the level of the last frame that reached :241 on the estimator.  When the raising frame
-    heads a chunk, that frame is the tail of the chunk before — which the streaming path no longer re-runs in the exact
-    mode unless something reads its level: here something does (the single-frame exact run after the fact)."""
+    heads a chunk, that frame is the tail of the chunk before — which every chunk's launch finishes in the exact mode
+    (mvosr_batch.exact_mask), whatever comes after it."""
     from mvoscalerecovery_amd import synth
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
     so = _oracle()
@@ -626,9 +626,6 @@ def test_triangulation_gpu_error_at_a_chunk_head_leaves_the_exact_level(gpu):
     f2s[32][:, 0] = f2s[32][:, 1]                               # collinear image points: the triangulation raises (QhullError)
     est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
     est.GPU_CHUNK = 32
-    exact_runs = []
-    inner = est._chunk_scale
-    est._chunk_scale = lambda st, tri2s, stage, keep=False: (exact_runs.append(stage), inner(st, tri2s, stage, keep=keep))[1]
     with pytest.raises(Exception) as got:
         est.scale_calculation_batch(f3s, f2s)
     ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
@@ -638,7 +635,69 @@ def test_triangulation_gpu_error_at_a_chunk_head_leaves_the_exact_level(gpu):
     assert type(got.value).__name__ == type(want.value).__name__
     assert est.height_level == ref.height_level
     assert list(est.scale_queue) == list(ref.scale_queue)
-    assert True in exact_runs                                   # frame 31 was run again on its own, stage outputs on
+
+
+@pytest.mark.parametrize("mode", ["gpu", "scipy"])
+def test_chunk_boundary_fuzz_of_the_cross_frame_state(gpu, mode):
+    """The cross-frame reads of height_level — a frame with exactly three features below the vanishing row divides by the
+    level an EARLIER frame left (scale_calculator.py:263-270,:420-422), a frame that raises leaves the estimator at the
+    level of the last frame that reached :241 (and at its own when its road model raised, :343-344) — with such frames, frames
+    whose point sets the device triangulation declines (duplicate pixels: redone on the host) and frames that raise
+    sprinkled over chunk heads, tails and interiors of the streaming paths: scales, stds, the exception's type, the
+    estimator's height_level and window afterwards, all equal to the oracle's frame-by-frame run."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    rng = np.random.default_rng(20 if mode == "gpu" else 21)
+    few = synth.too_few_sequence()[4]                              # three features below the vanishing row
+    level_zero = synth.fuzz_frame(400)                             # its road model raises IndexError after :241
+    for trial in range(6):
+        chunk = int(rng.integers(5, 9))
+        F = chunk * int(rng.integers(5, 8)) + int(rng.integers(0, chunk))
+        frames = [synth.synth_frame(1000 * trial + i, int(rng.integers(150, 420)), base_seed=31 + trial, upper_fraction=0.1) for i in range(F)]
+        spots = sorted(set(int(x) for x in np.concatenate([np.arange(chunk, F, chunk)[rng.random(len(np.arange(chunk, F, chunk))) < 0.5],
+                                                            np.arange(chunk - 1, F, chunk)[rng.random(len(np.arange(chunk - 1, F, chunk))) < 0.4],
+                                                            rng.integers(1, F, 3)])))
+        for j, f in enumerate(spots):
+            kind = (j + trial) % 4
+            if kind == 0:
+                frames[f] = few
+            elif kind == 1:                                        # duplicate pixels: the device triangulation declines, Qhull copes
+                a3, a2 = frames[f][0].copy(), frames[f][1].copy()
+                a2[5] = a2[60]
+                a3[5] = a3[60]
+                frames[f] = (a3, a2)
+            elif kind == 2 and j % 2:
+                frames[f] = few                                    # (two in a row now and then)
+        err_at = int(rng.integers(F // 2, F)) if trial % 3 != 2 else None
+        if err_at is not None:
+            if trial % 2:
+                a3, a2 = frames[err_at][0].copy(), frames[err_at][1].copy()
+                a2[:, 0] = a2[:, 1]                                # collinear pixels: QhullError at :257
+                frames[err_at] = (a3, a2)
+            else:
+                frames[err_at] = level_zero
+        f3s, f2s = [f[0].copy() for f in frames], [f[1].copy() for f in frames]
+        est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation=mode, delaunay_workers=4)
+        est.GPU_CHUNK, est.GPU_RAMP, est.PIPELINE_CHUNK = chunk, False, chunk
+        ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed" if mode == "gpu" else "reference")
+        want, want_exc = [], None
+        for f3, f2 in zip(f3s, f2s):
+            try:
+                want.append(ref.scale_calculation(f3.copy(), f2.copy()))
+            except Exception as exc:                               # noqa: BLE001
+                want_exc = type(exc).__name__
+                break
+        got_exc, got = None, None
+        try:
+            got = est.scale_calculation_batch(f3s, f2s)
+        except Exception as exc:                                   # noqa: BLE001
+            got_exc = type(exc).__name__
+        assert got_exc == want_exc or (want_exc == "StatusError" and got_exc is not None), (trial, got_exc, want_exc)
+        if want_exc is None:
+            assert [w[0] for w in want] == list(got[0]) and [w[1] for w in want] == list(got[1]), trial
+        assert list(est.scale_queue) == list(ref.scale_queue), trial
+        assert getattr(est, "height_level", None) == getattr(ref, "height_level", None), (trial, mode)
 
 
 def test_triangulation_gpu_dense_frames(gpu):
@@ -1833,16 +1892,20 @@ def test_full_size_properties(gpu):
     for f in range(pool):
         assert res["status"][f] == ores[f].status and res["raw_scale"][f] == ores[f].raw_scale, f
     # (1) checksum of checksums over the copies
-    def crc(r, sl):
+    def crc(r, sl, level=False):
         c = 0
-        for k in ("raw_scale", "height", "height_level", "status", "counts"):
+        for k in ("raw_scale", "height", "status", "counts") + (("height_level",) if level else ()):
             c = zlib.crc32(np.ascontiguousarray(r[k][sl]).tobytes(), c)
         return c
     sums = {crc(res, slice(r * pool, (r + 1) * pool)) for r in range(repeats)}
     assert len(sums) == 1
+    # (height_level: the product mode's own fixed-order sum — except for a batch's LAST frame, which the launch finishes
+    # in the exact mode for whoever reads it next (mvosr_batch.exact_mask): equal to rounding across the copies)
+    for r in range(1, repeats):
+        np.testing.assert_allclose(res["height_level"][r * pool:(r + 1) * pool], res["height_level"][:pool], rtol=1e-13)
     # (5) determinism
     res_b = run(pf)
-    assert crc(res, slice(None)) == crc(res_b, slice(None))
+    assert crc(res, slice(None), level=True) == crc(res_b, slice(None), level=True)
     # (3) triangle rows permuted (vertex order inside rows untouched)
     rng = np.random.default_rng(0)
     t1 = [r.tri1[rng.permutation(len(r.tri1))] for r in ores]
@@ -1856,8 +1919,9 @@ def test_full_size_properties(gpu):
     rev = list(range(pool))[::-1]
     pf_rev = _pack([frames[i] for i in rev], [ores[i].tri1 for i in rev], [ores[i].tri2 for i in rev], [ores[i].valid for i in rev])
     res_r = run(pf_rev)
-    for k in ("raw_scale", "height", "height_level", "status"):
+    for k in ("raw_scale", "height", "status"):
         assert np.array_equal(res_r[k], res[k][:pool][::-1], equal_nan=True), k
+    np.testing.assert_allclose(res_r["height_level"], res["height_level"][:pool][::-1], rtol=1e-13)   # (the batch's last frame: exact mode)
     # (6) window median over the whole sequence
     want, _ = so.window_median(res["raw_scale"], 5)
     assert np.array_equal(eng.window_median_host(res["raw_scale"], 5), want)
