@@ -495,6 +495,13 @@ int mvosr_flat_ransac_batch(mvosr_ctx *ctx, const mvosr_batch *b, const int32_t 
 int mvosr_slew_median(mvosr_ctx *ctx, const double *raw, const int32_t *apply, int64_t n, double slew, double scale_in,
                       int window, const double *queue_in, int n_queue, double *pushed, double *filtered);
 
+/* The same on HOST arrays, without the GPU: the recurrence is sequential, and when the per-frame results are on the host
+ * anyway (the estimator needs the statuses there to raise where the reference does) one core walks a million frames in a
+ * few milliseconds — the device kernel's single wavefront needs 55 ns per frame.  scale_out (optional): the running scale
+ * after the run. */
+int mvosr_slew_median_host(const double *raw, const int32_t *apply, int64_t n, double slew, double scale_in, int window,
+                           const double *queue_in, int n_queue, double *pushed, double *filtered, double *scale_out);
+
 /*
  * The legacy per-triangle batch of /root/reference/src/triangle_batch.py:14-68: features are
  * [u, v, depth] (b->x = u, b->v = v, b->z = depth; b->tri1 = Delaunay over (u,v), :23-25).  Per

@@ -118,6 +118,7 @@ SYMBOLS = {
     "mvosr_flat_ransac_batch": (C.c_int, [_P, C.POINTER(Batch), _P, C.POINTER(RescaleParams), _P, _P, _P, C.POINTER(RescaleOutputs),
                                           C.c_int64]),
     "mvosr_slew_median": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_int, _P, C.c_int, _P, _P]),
+    "mvosr_slew_median_host": (C.c_int, [_P, _P, C.c_int64, C.c_double, C.c_double, C.c_int, _P, C.c_int, _P, _P, _P]),
     "mvosr_ransac_plane_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int, C.c_double, C.c_double,
                                            _P, _P, _P, _P]),
     "mvosr_ransac_line_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, C.c_double, C.c_double,

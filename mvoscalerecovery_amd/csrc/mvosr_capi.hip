@@ -554,4 +554,36 @@ int mvosr_pack_fill(int64_t n_frames, double *const *feature3d, const double *co
     return MVOSR_OK;
 }
 
+int mvosr_slew_median_host(const double *raw, const int32_t *apply, int64_t n, double slew, double scale_in, int window,
+                           const double *queue_in, int n_queue, double *pushed, double *filtered, double *scale_out) {
+    if (n < 0 || (n > 0 && (!raw || !apply || !pushed || !filtered))) return set_error(MVOSR_ERR_ARG, "slew_median_host: null argument");
+    if (window < 1 || window > 64) return set_error(MVOSR_ERR_ARG, "slew_median_host: window must be in 1..64");
+    if (n_queue < 0 || n_queue > window || (n_queue > 0 && !queue_in)) return set_error(MVOSR_ERR_ARG, "slew_median_host: bad carried-in queue");
+    double s = scale_in;
+    double ring[64], sorted[64];
+    int len = n_queue;
+    for (int k = 0; k < n_queue; ++k) ring[k] = queue_in[k];
+    for (int64_t i = 0; i < n; ++i) {
+        if (apply[i]) {                                          // rescale.py:152 — the frame has a RANSAC plane
+            const double d = raw[i] - s;
+            if (d > slew) s += slew;                             // :169-170
+            else if (d < -slew) s -= slew;                       // :171-172
+            else s = raw[i];                                     // :173-174
+        }
+        pushed[i] = s;
+        if (len == window) { for (int k = 1; k < len; ++k) ring[k - 1] = ring[k]; --len; }   // :176-177 popleft
+        ring[len++] = s;                                         // :175 append
+        for (int k = 0; k < len; ++k) {                          // np.median(self.scale_queue), :178 (NaNs sort last, as in np.sort)
+            const double v = ring[k];
+            int j = k;
+            while (j > 0 && (sorted[j - 1] > v || (sorted[j - 1] != sorted[j - 1] && v == v))) { sorted[j] = sorted[j - 1]; --j; }
+            sorted[j] = v;
+        }
+        filtered[i] = (len & 1) ? sorted[len / 2] : (sorted[len / 2 - 1] + sorted[len / 2]) / 2.0;
+        if (sorted[len - 1] != sorted[len - 1]) filtered[i] = sorted[len - 1];               // a NaN in the window: np.median gives NaN
+    }
+    if (scale_out) *scale_out = s;
+    return MVOSR_OK;
+}
+
 }  // extern "C"

@@ -546,16 +546,15 @@ class ScaleEstimator:
         ctx = self.ctx
         filtered = np.zeros(0)
         if n_ok:
-            io = ctx.block([("raw", n_ok, np.float64), ("apply", n_ok, np.int32)])
-            io.upload({"raw": raw[:n_ok], "apply": (status[:n_ok] == 0).astype(np.int32)})
-            res = ctx.block([("pushed", n_ok, np.float64), ("filtered", n_ok, np.float64)])
+            # (the recurrence is sequential and the raw scales are on the host already — the statuses decide where the
+            # reference raises —: one core walks it in C, mvosr_slew_median_host; mvosr_slew_median is the same on device arrays)
+            r = np.ascontiguousarray(raw[:n_ok], dtype=np.float64)
+            ap = np.ascontiguousarray(status[:n_ok] == 0, dtype=np.int32)
+            pushed, filtered = np.empty(n_ok, np.float64), np.empty(n_ok, np.float64)
             q = np.ascontiguousarray(np.asarray(list(self.scale_queue), dtype=np.float64))
-            _lib.check(ctx.lib.mvosr_slew_median(ctx.handle, io["raw"].ptr, io["apply"].ptr, n_ok, SLEW, float(self.scale),
-                                                 int(self.window_size), _lib.addr(q) if q.size else None, int(q.size),
-                                                 res["pushed"].ptr, res["filtered"].ptr), "mvosr_slew_median")
-            pushed, filtered = res["pushed"].download(), res["filtered"].download()
-            io.free()
-            res.free()
+            _lib.check(ctx.lib.mvosr_slew_median_host(_lib.addr(r), _lib.addr(ap), n_ok, SLEW, float(self.scale), int(self.window_size),
+                                                      _lib.addr(q) if q.size else None, int(q.size), _lib.addr(pushed),
+                                                      _lib.addr(filtered), None), "mvosr_slew_median_host")
             self.scale = float(pushed[-1])                                                  # :169-174
             tail = list(self.scale_queue) + list(pushed[max(0, n_ok - self.window_size):])
             self.scale_queue.clear()

@@ -107,6 +107,43 @@ def test_c_packer_equals_python_packer():
     assert not packing.native_packable([ro], [f2s[0]], writable=True) and packing.native_packable([ro], [f2s[0]])
 
 
+def test_slew_median_host_equals_the_references_recurrence():
+    """mvosr_slew_median_host (no GPU): the slew limiter and window median of /root/reference/src/rescale.py:169-178 written
+    out in Python — jumps beyond +-0.3, frames without a plane, a NaN scale that sticks, a carried-in queue."""
+    from collections import deque
+    from mvoscalerecovery_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(8)
+    for n in (1, 5, 63, 64, 65, 1000):
+        raw = rng.uniform(0.5, 3.5, n)
+        raw[rng.random(n) < 0.1] += 5.0
+        apply = (rng.random(n) > 0.2).astype(np.int32)
+        raw[apply == 0] = np.nan
+        if n == 1000:
+            raw[700], apply[700] = np.nan, 1                      # a NaN plane: the reference's comparisons fail, the scale becomes NaN
+        q_in, s, w = [1.25, 1.5], 1.5, 5
+        q, want_p, want_f = deque(q_in), [], []
+        for i in range(n):
+            if apply[i]:
+                if raw[i] - s > 0.3:
+                    s += 0.3
+                elif raw[i] - s < -0.3:
+                    s -= 0.3
+                else:
+                    s = raw[i]
+            q.append(s)
+            if len(q) > w:
+                q.popleft()
+            want_p.append(s)
+            with np.errstate(all="ignore"):
+                want_f.append(np.median(q))
+        p, f, qa, s_out = np.empty(n), np.empty(n), np.array(q_in), np.zeros(1)
+        _lib.check(lib.mvosr_slew_median_host(_lib.addr(raw), _lib.addr(apply), n, 0.3, 1.5, w, _lib.addr(qa), 2, _lib.addr(p), _lib.addr(f),
+                                              _lib.addr(s_out)))
+        assert np.array_equal(p, np.array(want_p), equal_nan=True) and np.array_equal(f, np.array(want_f), equal_nan=True), n
+        assert (np.isnan(s_out[0]) and np.isnan(want_p[-1])) or s_out[0] == want_p[-1]
+
+
 def test_lds_plan_three_frames_per_cu():
     from mvoscalerecovery_amd import _lib
     lib = _lib.load()
