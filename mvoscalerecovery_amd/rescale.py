@@ -353,11 +353,12 @@ class ScaleEstimator:
             blk.mark(True)
         return out, flags, side
 
-    def _chunk_dev_gpu(self, f3s, f2s, frame_base, id_triples, stage):
+    def _chunk_dev_gpu(self, f3s, f2s, frame_base, id_triples, stage, tables=False):
         """One chunk, both triangulations on the device: pack (C packer into page-locked memory) -> ONE upload -> every
         launch and the download of the results queued; nothing is waited for here."""
         ctx, lib = self.ctx, self.ctx.lib
-        tables = frame_tables(f3s, f2s) if len(f3s) else None
+        if tables is False:
+            tables = frame_tables(f3s, f2s) if len(f3s) else None
         if tables is not None:
             pf, blk = pack_upload_native(ctx, f3s, f2s, self.vanish, None, tables=tables)             # rescale.py:115-117
             too_large = pf.max_feat > self._max_points()
@@ -500,12 +501,14 @@ class ScaleEstimator:
             queue, a = [], 0
             while a < F:
                 b = min(F, a + (ramp[len(bounds)] if len(bounds) < len(ramp) else C_))
-                lens = np.fromiter((len(x) for x in feature3ds[a:b]), dtype=np.int64, count=b - a)
+                tb = frame_tables(feature3ds[a:b], feature2ds[a:b])          # (sizes from the packer's pointer tables: one C loop)
+                lens = tb[2].astype(np.int64) if tb is not None else np.fromiter((len(x) for x in feature3ds[a:b]), dtype=np.int64, count=b - a)
                 b = min(b, a + max(int(np.searchsorted(np.cumsum(lens), self.GPU_CHUNK_POINTS, side="right")), 1))
                 while b - a > 1 and (b - a) * int(lens[:b - a].max()) > 2 * self.GPU_CHUNK_POINTS:     # (workspace = frames x largest frame)
                     b = a + max(1, (b - a) // 2)
                 tr = None if id_triples is None else id_triples[a:b]
-                queue.append((self._chunk_dev_gpu(feature3ds[a:b], feature2ds[a:b], base + a, tr, stage), a, b))
+                queue.append((self._chunk_dev_gpu(feature3ds[a:b], feature2ds[a:b], base + a, tr, stage,
+                                                  tables=(tuple(t[:b - a] for t in tb) if tb is not None else None)), a, b))
                 bounds.append((a, b))
                 while len(queue) > self.GPU_PIPELINE:
                     st, pa, pb = queue.pop(0)

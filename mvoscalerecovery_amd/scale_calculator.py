@@ -444,13 +444,14 @@ class ScaleEstimator:
     GPU_CHUNK = 8192            # frames per chunk of the device-triangulation path, at most (a call of F frames uses chunks of F/4, 512 at least: the pipeline needs a few)
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk (40 B each in staging memory, ~180 B each on the device)
 
-    def _chunk_gpu(self, f3s, f2s, stage):
+    def _chunk_gpu(self, f3s, f2s, stage, tables=False):
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
         ONE upload -> Delaunay #1, vote, Delaunay #2, scale kernel, road model, the exact re-runs known in advance and
         the download of the results, all queued; nothing is waited for here (``_chunk_gpu_finish`` does)."""
         from .engine import frame_tables, pack_upload_native
         ctx = self.engine.ctx
-        tables = frame_tables(f3s, f2s, remap_in_place=bool(self.mutate_inputs)) if len(f3s) > 0 else None
+        if tables is False:             # (not looked up by the caller yet)
+            tables = frame_tables(f3s, f2s, remap_in_place=bool(self.mutate_inputs)) if len(f3s) > 0 else None
         native = tables is not None
         blk = None
         if native:
@@ -537,27 +538,32 @@ class ScaleEstimator:
         # one, and the host, which prepares a frame in less time than the GPU spends on it, is ahead from then on
         ramp = [C // 8, C // 4, C // 2] if (self.GPU_RAMP and C >= 2048 and F >= 3 * C) else []
 
+        from .engine import frame_tables
+
         def chunk_bounds():
             # (a chunk's sizes are looked at when its turn comes — one pass over the whole call's frames before the first
             # chunk was 5 ms at 32 768 frames, with an idle GPU)
             a_, k_ = 0, 0
             while a_ < F:
                 b_ = min(F, a_ + (ramp[k_] if k_ < len(ramp) else C))
-                lens = np.fromiter((len(x) for x in feature3ds[a_:b_]), dtype=np.int64, count=b_ - a_)
+                # (the frames' sizes from the pointer tables the C packer wants anyway — one C loop over the lists — where the
+                # frames are packable in place; a Python loop over them was 7 ms per 32 768 frames)
+                tb = frame_tables(feature3ds[a_:b_], feature2ds[a_:b_], remap_in_place=bool(self.mutate_inputs))
+                lens = tb[2].astype(np.int64) if tb is not None else np.fromiter((len(x) for x in feature3ds[a_:b_]), dtype=np.int64, count=b_ - a_)
                 over = int(np.searchsorted(np.cumsum(lens), self.GPU_CHUNK_POINTS, side="right"))
                 b_ = min(b_, a_ + max(over, 1))
                 # the triangulation's workspace is sized frames x LARGEST frame (mvosr_delaunay_batch): one 20 000-point frame
                 # among thousands of small ones must not turn into a 20 GB request — such a chunk is cut short
                 while b_ - a_ > 1 and (b_ - a_) * int(lens[:b_ - a_].max()) > 2 * self.GPU_CHUNK_POINTS:
                     b_ = a_ + max(1, (b_ - a_) // 2)
-                yield a_, b_
+                yield a_, b_, (tuple(t[:b_ - a_] for t in tb) if tb is not None else None)
                 a_, k_ = b_, k_ + 1
 
         bounds = []
         results, queue = [], []
-        for k, (a, b) in enumerate(chunk_bounds()):
+        for k, (a, b, tb) in enumerate(chunk_bounds()):
             bounds.append((a, b))
-            queue.append((self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage), a, b))
+            queue.append((self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage, tables=tb), a, b))
             # GPU_PIPELINE chunks stay queued behind the one whose results are collected: this process packs and uploads
             # the next chunk meanwhile (the kernel timeline shows the GPU 98 % busy between a call's first and last chunk
             # with one: what a call pays beyond its kernels is its first chunk's pack + upload and the host's epilogue)
