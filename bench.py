@@ -35,6 +35,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
   e2e_gpu_triangulation   the same call with both triangulations built on the device (triangulation="gpu",
                 check_triangle="fixed": a declared deviation, bit-equal to the fixed-mode oracle), plus the Delaunay kernel
                 alone and the allocation counters of the timed call;
+  e2e_rescale   the estimator the reference's drivers really import (rescale.ScaleEstimator, /root/reference/src/main.py:20),
+                device-resident end to end (Delaunay x2, GraphChecker vote, flat_selection + RANSAC plane, slew limiter, window
+                median) from per-frame arrays: no declared deviation;
   latency       per-frame latency of the drop-in scale_calculation call in the reference's loop shape.
 """
 from __future__ import annotations
@@ -343,7 +346,7 @@ def e2e_rescale_leg(args, device, sizes, seed, n_frames):
 
 def e2e_gpu_leg(args, device, sizes, seed, n_frames):
     """The batch call end to end with BOTH TRIANGULATIONS BUILT ON THE DEVICE (triangulation="gpu", which selects
-    check_triangle="fixed": DESIGN.md §3.8): C packer -> one upload per chunk -> Delaunay #1 -> vote -> Delaunay #2 ->
+    check_triangle="fixed": DESIGN.md §3.5): C packer -> one upload per chunk -> Delaunay #1 -> vote -> Delaunay #2 ->
     scale kernel -> road model -> results; rows, masks and counts never leave HBM.  Also: the device triangulation alone
     (mvosr_delaunay_batch on resident point sets), and the alloc counters of a steady-state call."""
     from mvoscalerecovery_amd import _lib, packing, synth

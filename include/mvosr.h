@@ -533,7 +533,7 @@ enum mvosr_dt_status {
  * lexicographic order — a function of the set alone.  Qhull's own rotation of each row, which the reference's vote
  * depends on (:113-115), is not reproducible from the geometry: these rows are meant for MVOSR_VOTE_FIXED, under which
  * they and SciPy's rows give bit-identical results (the host selects both with triangulation="gpu",
- * check_triangle="fixed"); with MVOSR_VOTE_REFERENCE they are a measured deviation (DESIGN.md §3.8).
+ * check_triangle="fixed"); with MVOSR_VOTE_REFERENCE they are a measured deviation (DESIGN.md §3.5).
  * Frame f's points are (u, v)[pts_off[f] .. +pts_cnt[f]); with `keep` (laid out like u; e.g. the vote counters of
  * mvosr_outlier_vote_batch) only the points with keep[i] >= 0 take part and the ids are their ranks among those, in
  * order — the second triangulation over the survivors of the vote (:264-266) without a compaction pass.  n_used[f]
@@ -541,7 +541,7 @@ enum mvosr_dt_status {
  * tri + 3*tri_off[f] (room for 2 * points rows), tri_cnt[f] says how many; status[f] is an mvosr_dt_status (a declined
  * frame has tri_cnt 0 and the reason in the status' bits 8..).  max_pts = max(pts_cnt) <= mvosr_delaunay_max_points();
  * The context's workspace (grow-only, hipMalloc when it grows) holds 76 bytes per point of the LAUNCH — n_frames * max_pts
- * points: the stars' hint caches and the order the points are taken in (DESIGN.md §3.8) — and ~33 more above mvosr_delaunay_lds_points(): callers with very many
+ * points: the stars' hint caches and the order the points are taken in (DESIGN.md §3.5) — and ~33 more above mvosr_delaunay_lds_points(): callers with very many
  * frames launch in chunks (the host class uses up to 8192 frames or 10 M points).
  */
 int mvosr_delaunay_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,

@@ -8,7 +8,7 @@
 // processing order that the reference's depth-order vote depends on (scale_calculator.py:113-115 sets flag[1] where
 // flag[2] is meant).  The rows are therefore meant for the order-invariant vote (check_triangle="fixed",
 // mvosr_params.vote_mode = MVOSR_VOTE_FIXED), with which SciPy's rows and these rows give bit-identical results; with the
-// reference's flag pattern they are a measured deviation (DESIGN.md §3.8).
+// reference's flag pattern they are a measured deviation (DESIGN.md §3.5).
 //
 // Algorithm (round 3; the round-2 kernel scanned all points of the frame for every point): one workgroup of 8
 // wavefronts per frame, the frame's points in LDS in fp64, counting-sorted into a uniform grid of ~1.5 points per cell

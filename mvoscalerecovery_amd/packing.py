@@ -70,7 +70,7 @@ def canonical_rows(tri):
 
 
 def delaunay_gpu(ctx, point_sets, keeps=None):
-    """The device stage for the triangulations (``mvosr_delaunay_batch``; DESIGN.md §3.8): per point set the (T,3) int32
+    """The device stage for the triangulations (``mvosr_delaunay_batch``; DESIGN.md §3.5): per point set the (T,3) int32
     rows — the triangle set SciPy returns for points in general position, in canonical form (:func:`canonical_rows`) —
     or ``None`` where the kernel declined (duplicate / collinear / cocircular points within its guard bands, fewer than
     3 points): those sets are for the host's Qhull.  ``keeps`` (optional, one int array per set): only the points with

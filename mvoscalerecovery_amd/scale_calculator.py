@@ -78,7 +78,7 @@ class ScaleEstimator:
         # check_triangle = "reference": the vote's flag pattern exactly as the reference has it (:113-115 sets flag[1]
         # where flag[2] is meant), which depends on Qhull's rotation of each row — with SciPy's rows, verbatim, this is
         # the reference bit for bit (the default).  "fixed": the (0,2) pair marks vertices 0 and 2 — a DECLARED DEVIATION
-        # (DESIGN.md §3.8 has the measured agreement with the reference) under which the vote, and with
+        # (DESIGN.md §4 has the measured agreement with the reference) under which the vote, and with
         # rows in canonical form every stage, is a function of the triangle SET alone: "scipy" and "gpu" then give
         # bit-identical results, pinned by Oracle(check_triangle="fixed").  Default: "reference" with "scipy", "fixed"
         # with "gpu" ("gpu" with "reference" is accepted but unpinned: Qhull's row rotation cannot be reproduced).

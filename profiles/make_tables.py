@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Render the measured-numbers tables of BASELINE.md, README.md and DESIGN.md from the committed measurement files of a
+round (profiles/r0N_*.json / .jsonl / .csv / .txt), so that no number in those documents is typed by hand:
+
+    python profiles/make_tables.py [r04]        # rewrites the text between <!-- TAG-tables:begin --> and <!-- TAG-tables:end -->
+
+Sources: r0N_bench.json / r0N_bench_kitti.json (the bench lines: `python bench.py [--workload kitti]`), r0N_bench_c4_1gpu.json
+(BASELINE configs[3] literally, on one GPU), r0N_summary.md's source r0N_kernel_stats.csv (rocprofv3 --kernel-trace --stats),
+r0N_delaunay_bench.jsonl (profiles/bench_delaunay.py), r0N_e2e_{scale,rescale}_busy.txt (profiles/e2e_gpu_busy.py),
+r0N_fixed_mode_accuracy.json (profiles/fixed_mode_accuracy.py), traffic.json (PMC passes).
+"""
+import csv
+import json
+import os
+import re
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def load_line(name):
+    p = os.path.join(HERE, name)
+    if not os.path.isfile(p):
+        return None
+    return json.loads([ln for ln in open(p).read().splitlines() if ln.startswith("{")][-1])
+
+
+def k(x):
+    if x < 1e4:
+        return "%.2f k" % (x / 1e3)
+    return "%.0f k" % (x / 1e3) if x < 1e6 else "%.2f M" % (x / 1e6)
+
+
+def render(tag):
+    out = []
+    b = load_line(tag + "_bench.json")
+    kt = load_line(tag + "_bench_kitti.json")
+    c4 = load_line(tag + "_bench_c4_1gpu.json")
+    rows = []
+    if b:
+        r = b["roofline"]
+        rows.append(("headline step (`python bench.py`): %s" % b["config"]["workload"].split(",")[0],
+                     "**%s frames/s**, %.3f ms per step; `%s` %.3f ms by HIP events = %.0f GB/s algorithmic = **%.3f of 8 TB/s**; both kernels of the step %.3f"
+                     % (k(b["value"]), b["ms_per_step"], r["kernel"], r["kernel_ms_avg"], r["achieved"], r["frac"], r.get("step_frac", float("nan"))),
+                     "`profiles/%s_bench.json`" % tag))
+    stats = os.path.join(HERE, tag + "_kernel_stats.csv")
+    if os.path.isfile(stats) and b:
+        for r_ in csv.DictReader(open(stats)):
+            if "scale_frames_kernel<8, 4, 0, false>" in r_["Name"]:
+                ms = float(r_["AverageNs"]) / 1e6
+                bytes_launch = b["roofline"]["algorithmic_bytes_per_launch"]
+                tj = json.load(open(os.path.join(HERE, "traffic.json")))["entries"].get("c2_2000", {})
+                rows.append(("the same kernel under `rocprofv3 --kernel-trace --stats`", "%.3f ms average over %s launches = %.0f GB/s = **%.3f of 8 TB/s**; HBM traffic (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes) %.3f x the algorithmic bytes"
+                             % (ms, r_["Calls"], bytes_launch / ms / 1e6, bytes_launch / ms / 1e6 / 8000.0, tj.get("hbm_bytes_per_frame", float("nan")) / b["roofline"]["algorithmic_bytes_per_frame"]),
+                             "`profiles/%s_kernel_stats.csv`, `%s_summary.md`, `traffic.json`" % (tag, tag)))
+    if b:
+        for key, label in (("e2e_rescale", "end to end from per-frame arrays, `rescale.ScaleEstimator(triangulation=\"gpu\")` — the estimator `/root/reference/src/main.py:20` imports; no declared deviation"),
+                           ("e2e_gpu_triangulation", "end to end, `scale_calculator.ScaleEstimator(triangulation=\"gpu\")` (`check_triangle=\"fixed\"`: a declared deviation)"),
+                           ("e2e", "end to end, host SciPy triangulations (reference-exact default), worker pool on the box's CPUs")):
+            if key in b and "value" in b[key]:
+                e = b[key]
+                extra = ""
+                if kt and key in kt and "value" in kt[key]:
+                    extra = "; KITTI-sized frames (300-1500 features): %s" % k(kt[key]["value"])
+                if "hip_malloc_calls_in_timed_call" in e:
+                    extra += "; hipMalloc / hipHostMalloc calls in the timed call: %d / %d" % (e["hip_malloc_calls_in_timed_call"], e["hip_host_malloc_calls_in_timed_call"])
+                rows.append((label, "**%s frames/s** at 2000 features (%d frames, %s distinct)%s" % (k(e["value"]), e["frames"], e.get("distinct_frames", "all"), extra), "`%s` in the bench line" % key))
+        if "latency" in b:
+            la = b["latency"]
+            rows.append(("per-frame `scale_calculation` latency, 2000 features", "SciPy triangulations %.2f ms, device triangulations %.2f ms (median; 0 allocations per call)" % (la["scipy"]["median_ms"], la["gpu"]["median_ms"]), "`latency` in the bench line"))
+        cb = b.get("cpu_baseline")
+        if cb:
+            rows.append(("CPU oracle on the GPU box's host cores (baseline, not target)", "%.0f frames/s on %d core (vectorised NumPy port); all cores: %s; reference-shaped Python loops: %s"
+                         % (cb["value"], cb["cores"], ("%.0f on %d" % (b["cpu_baseline_all_cores"]["value"], b["cpu_baseline_all_cores"]["cores"])) if "cpu_baseline_all_cores" in b else "n/a",
+                            ("%.1f frames/s/core" % b["cpu_baseline_reference_shaped"]["value"]) if "cpu_baseline_reference_shaped" in b else "n/a"), "bench line"))
+    if kt:
+        r = kt["roofline"]
+        rows.append(("config C3's sizes (`--workload kitti`: ragged 300-1500 features, one launch per size class)", "%s frames/s, kernels %.3f of 8 TB/s, step %.3f" % (k(kt["value"]), r["frac"], r.get("step_frac", float("nan"))), "`profiles/%s_bench_kitti.json`" % tag))
+    if c4:
+        rows.append(("BASELINE configs[3] literally on ONE GPU (`bench.py --c4 --total-frames 1000000 --gpus 1`: %.0f GB resident)" % (c4["roofline"]["algorithmic_bytes_per_launch"] / 1e9),
+                     "%s frames/s, %.1f ms per step of 1 000 000 frames, kernel %.3f of 8 TB/s" % (k(c4["value"]), c4["ms_per_step"], c4["roofline"]["frac"]), "`profiles/%s_bench_c4_1gpu.json`" % tag))
+    dj = os.path.join(HERE, tag + "_delaunay_bench.jsonl")
+    if os.path.isfile(dj):
+        items = [json.loads(ln) for ln in open(dj) if ln.startswith("{")]
+        txt = "; ".join("%s, %d points: **%s sets/s**" % (d["what"], d["points_per_set"], k(d["sets_per_s"])) for d in items if d["points_per_set"] == 2000)
+        rows.append(("`delaunay_kernel` alone, 4096 resident sets", txt, "`profiles/%s_delaunay_bench.jsonl`" % tag))
+        small = "; ".join("%s, <= %d points: %s" % (d["what"], d["points_per_set"], k(d["sets_per_s"])) for d in items if d["points_per_set"] != 2000)
+        if small:
+            rows.append(("... smaller sets (8192 per launch)", small, "same"))
+    for w in ("scale", "rescale"):
+        p = os.path.join(HERE, "%s_e2e_%s_busy.txt" % (tag, w))
+        if os.path.isfile(p):
+            t = open(p).read()
+            m = re.search(r"span ([\d.]+) ms, busy ([\d.]+) ms \(([\d.]+) %\)", t)
+            d = re.search(r"delaunay_kernel.*?\s([\d.]+) ms\s+(\d+) launches", t)
+            if m and d:
+                rows.append(("GPU timeline of one 32 768-frame end-to-end call (%s estimator)" % w,
+                             "kernel span %s ms, busy %s ms (%s %%); `delaunay_kernel` %s ms = %.2f us per frame for both triangulations" % (m.group(1), m.group(2), m.group(3), d.group(1), float(d.group(1)) * 1e3 / 32768),
+                             "`profiles/%s_e2e_%s_busy.txt`, `%s_e2e_%s_kernel_stats.csv`" % (tag, w, tag, w)))
+    fa = os.path.join(HERE, tag + "_fixed_mode_accuracy.json")
+    if os.path.isfile(fa):
+        for r in json.load(open(fa))["rows"]:
+            a, d = r["all_frames"], r["differing_frames"]
+            rows.append(("declared deviation `check_triangle=\"fixed\"` vs the reference, raw scales, %s" % r["set"],
+                         "%.1f %% bit-equal; mean relative error against the generator's true scale: reference %.4f / fixed %.4f over all frames, %.3f / %.3f over the %d frames that differ (fixed closer on %d, reference on %d)"
+                         % (100 * r["bit_equal_fraction"], a["reference_mean_rel_err"], a["fixed_mean_rel_err"], d["reference_mean_rel_err"], d["fixed_mean_rel_err"], d["count"], d["fixed_closer_to_truth"], d["reference_closer_to_truth"]),
+                         "`profiles/%s_fixed_mode_accuracy.json`" % tag))
+    out.append("| quantity (round %s, one MI355X) | value | source |" % tag[1:].lstrip("0"))
+    out.append("|---|---|---|")
+    for a_, b_, c_ in rows:
+        out.append("| %s | %s | %s |" % (a_, b_, c_))
+    return "\n".join(out)
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    text = render(tag)
+    open(os.path.join(HERE, tag + "_tables.md"), "w").write(text + "\n")
+    begin, end = "<!-- %s-tables:begin -->" % tag, "<!-- %s-tables:end -->" % tag
+    for doc in ("BASELINE.md", "README.md", "DESIGN.md"):
+        p = os.path.join(ROOT, doc)
+        s = open(p).read()
+        if begin in s and end in s:
+            s = s[:s.index(begin) + len(begin)] + "\n" + text + "\n" + s[s.index(end):]
+            open(p, "w").write(s)
+            print("updated", doc)
+    print(text)
+
+
+if __name__ == "__main__":
+    main()
