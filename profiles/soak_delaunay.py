@@ -63,9 +63,16 @@ for rnd in range(rounds):
     tri1, tri2 = ctx.empty((rows, 3), np.int32), ctx.empty((rows, 3), np.int32)
     c1, c2, s1, s2 = (ctx.zeros(F, np.int32) for _ in range(4))
     nmax = int(cnt.max())
-    _lib.check(lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, nmax, d_toff.ptr, tri1.ptr, c1.ptr, None, s1.ptr), "dt1")
-    _lib.check(lib.mvosr_delaunay_batch_seeded(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, nmax, d_toff.ptr, tri2.ptr, c2.ptr, None,
-                                               s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr), "dt2")
+    # (round 4: the second triangulation carries over the stars the mask did not touch — mvosr_delaunay_batch_ex with the
+    # first launch's per-point facts; every third round keeps 90-99 % of the points, the vote's regime)
+    if rnd % 3 == 2:
+        keep = np.concatenate([np.where(rng.uniform(size=n) < rng.uniform(0.9, 0.99), 1, -1) for n in cnt]).astype(np.int32)
+        d_keep = ctx.to_device(keep)
+    d_info = ctx.zeros(int(cnt.sum()), np.uint32)
+    _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, nmax, d_toff.ptr, tri1.ptr, c1.ptr, None, s1.ptr,
+                                           None, None, None, None, d_info.ptr), "dt1")
+    _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, nmax, d_toff.ptr, tri2.ptr, c2.ptr, None,
+                                           s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr, d_info.ptr, None), "dt2")
     t1, t2, n1, n2, h1, h2 = tri1.download(), tri2.download(), c1.download(), c2.download(), s1.download(), s2.download()
     for f, p in enumerate(sets):
         a = int(2 * off[f])
