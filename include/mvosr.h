@@ -472,8 +472,11 @@ typedef struct mvosr_rescale_outputs {
  * with repeats (rescale.py:101), are the RANSAC's point list, which never leaves LDS.  The reference draws its sample
  * triples from OS entropy (/root/reference/src/thirdparty/Ransac/ransac.py:6,10), so any uniform draw of three distinct
  * list positions per hypothesis is a realisation of it; here hypothesis h of frame f takes
- *     r_k = mix(mix(seed ^ (frame_base + f) * 0xD1B54A32D192ED03) + 4 h + k),  k = 0, 1, 2      (mix = splitmix64's finaliser)
- *     i0 = mulhi(r_0, M), i1 = mulhi(r_1, M - 1) skipping i0, i2 = mulhi(r_2, M - 2) skipping both
+ *     key = mix(seed ^ (frame_base + f) * 0xD1B54A32D192ED03),  hk = mix(key + h),  r_k = mix(hk + 3 a + k),  k = 0, 1, 2
+ *     i0 = mulhi(r_0, M), i1 = mulhi(r_1, M - 1) skipping i0, i2 = mulhi(r_2, M - 2) skipping both      (mix = splitmix64's finaliser)
+ * for attempt a = 0, 1, ... until the three positions name three DIFFERENT vertices (at most 16 attempts): the list repeats
+ * every vertex once per kept triangle, and a sample with a repeated vertex is rank-deficient — the reference's SVD then
+ * returns whatever plane of the pencil through two points rounding noise selects; the product's sequence leaves those out
  * — a counter-based sequence that depends on (seed, frame counter, hypothesis) only, so a batch, its chunks and
  * per-frame calls draw the same triples (oracle/rescale_oracle.py restates it).  `id_triples` (optional, [F][n_hyp][3]
  * survivor-numbered VERTEX ids) replaces the draw: a recorded sample sequence of the reference mapped to point ids

@@ -153,14 +153,25 @@ __host__ __device__ __forceinline__ uint64_t rs_mix64(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
-__device__ __forceinline__ void rs_draw3(uint64_t key, int h, int M, int &i0, int &i1, int &i2) {
-    const uint64_t r0 = rs_mix64(key + (uint64_t)(4 * h)), r1 = rs_mix64(key + (uint64_t)(4 * h + 1)), r2 = rs_mix64(key + (uint64_t)(4 * h + 2));
-    i0 = (int)__umul64hi(r0, (uint64_t)M);                                  // uniform on [0, M) up to M / 2^64
-    i1 = (int)__umul64hi(r1, (uint64_t)(M - 1)); if (i1 >= i0) ++i1;         // ... on the M - 1 other positions
-    i2 = (int)__umul64hi(r2, (uint64_t)(M - 2));
-    const int lo = min(i0, i1), hi = max(i0, i1);
-    if (i2 >= lo) ++i2;
-    if (i2 >= hi) ++i2;
+constexpr int kRsDrawAttempts = 16;
+// Hypothesis h of a frame: three distinct list positions, uniform — drawn again (the next three values of the hypothesis' own
+// stream) while two of them name the SAME VERTEX.  The list repeats every vertex once per kept triangle (rescale.py:101), so
+// 0.5-2 % of the reference's samples are such rank-deficient triples; its SVD then returns a null vector that rounding noise
+// picks from the pencil of planes through two points (LAPACK's bidiagonalisation of a rank-2 matrix) — nothing a restatement
+// can reproduce or a test can pin.  The product's sequence simply does not contain them.
+__device__ __forceinline__ void rs_draw3(uint64_t key, int h, int M, const uint16_t *L, int &v0, int &v1, int &v2) {
+    const uint64_t hk = rs_mix64(key + (uint64_t)h);
+    for (int att = 0; att < kRsDrawAttempts; ++att) {
+        const uint64_t r0 = rs_mix64(hk + (uint64_t)(3 * att)), r1 = rs_mix64(hk + (uint64_t)(3 * att + 1)), r2 = rs_mix64(hk + (uint64_t)(3 * att + 2));
+        const int i0 = (int)__umul64hi(r0, (uint64_t)M);                          // uniform on [0, M) up to M / 2^64
+        int i1 = (int)__umul64hi(r1, (uint64_t)(M - 1)); if (i1 >= i0) ++i1;       // ... on the M - 1 other positions
+        int i2 = (int)__umul64hi(r2, (uint64_t)(M - 2));
+        const int lo = min(i0, i1), hi = max(i0, i1);
+        if (i2 >= lo) ++i2;
+        if (i2 >= hi) ++i2;
+        v0 = L[i0]; v1 = L[i1]; v2 = L[i2];
+        if (v0 != v1 && v0 != v2 && v1 != v2) return;
+    }
 }
 
 template <bool DEV>
@@ -461,9 +472,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
                     const int32_t *t = a.id_triples + ((int64_t)f * H + h) * 3;
                     v0 = min(max(t[0], 0), n - 1); v1 = min(max(t[1], 0), n - 1); v2 = min(max(t[2], 0), n - 1);
                 } else {
-                    int i0, i1, i2;
-                    rs_draw3(key, h, M, i0, i1, i2);
-                    v0 = L[i0]; v1 = L[i1]; v2 = L[i2];
+                    rs_draw3(key, h, M, L, v0, v1, v2);
                 }
                 const double x0 = X[v0], y0 = Y[v0], z0 = Z[v0];
                 const double e1x = X[v1] - x0, e1y = Y[v1] - y0, e1z = Z[v1] - z0;

@@ -27,7 +27,8 @@ limiter and the window median on the device (mvosr_slew_median).  No host step b
 DEVIATION: the vote's edge potential is symmetric, so its mask is a function of the triangle SET (graph.py:18-36,124-145);
 flat_selection keeps a set of triangles (rescale.py:75-96); only the order of its point list (:101) follows the rows,
 and the RANSAC draws list positions uniformly (ransac.py:10) — here from a counter-based sequence keyed by
-``ransac_seed`` (None: OS entropy, the reference's behaviour).  ``triangulation="scipy", sampling="device"`` runs the
+``ransac_seed`` (None: OS entropy, the reference's behaviour); a draw that names one vertex twice (the list repeats
+vertices; the reference's SVD of such a rank-deficient sample returns a plane picked by rounding noise) is drawn again.  ``triangulation="scipy", sampling="device"`` runs the
 same kernels on SciPy's triangulations brought to the same row form, with bit-identical results.
 """
 from __future__ import annotations

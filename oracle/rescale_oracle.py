@@ -198,25 +198,36 @@ def mix64(x):
     return x ^ (x >> 31)
 
 
-def device_triples(seed, frame_counter, m, n_hyp=RANSAC_ITERATIONS):
-    """The list positions hypothesis h = 0..n_hyp-1 of frame `frame_counter` draws from a list of m points under key
-    `seed`: three distinct positions, uniform (the reference draws them with random.sample from OS entropy,
-    /root/reference/src/thirdparty/Ransac/ransac.py:6,10 — any uniform draw realises it)."""
+DRAW_ATTEMPTS = 16
+
+
+def device_triples(seed, frame_counter, ids, n_hyp=RANSAC_ITERATIONS):
+    """The list positions hypothesis h = 0..n_hyp-1 of frame `frame_counter` draws under key `seed` from the point list whose
+    vertex ids are `ids` (an int m: a list of m distinct points): three distinct positions, uniform — the reference draws
+    them with random.sample from OS entropy, /root/reference/src/thirdparty/Ransac/ransac.py:6,10 — drawn again while two
+    of them name the same vertex (the list repeats vertices, /root/reference/src/rescale.py:101; the reference's SVD of such
+    a rank-deficient sample returns a plane that rounding noise picks: the product's sequence leaves those samples out)."""
+    ids = np.arange(ids) if np.isscalar(ids) else np.asarray(ids)
+    m = len(ids)
     key = mix64((seed ^ ((frame_counter * 0xD1B54A32D192ED03) & _M64)) & _M64)
     out = np.zeros((n_hyp, 3), dtype=np.int64)
     for h in range(n_hyp):
-        r = [mix64((key + 4 * h + k) & _M64) for k in range(3)]
-        i0 = (r[0] * m) >> 64
-        i1 = (r[1] * (m - 1)) >> 64
-        if i1 >= i0:
-            i1 += 1
-        i2 = (r[2] * (m - 2)) >> 64
-        lo, hi = min(i0, i1), max(i0, i1)
-        if i2 >= lo:
-            i2 += 1
-        if i2 >= hi:
-            i2 += 1
-        out[h] = (i0, i1, i2)
+        hk = mix64((key + h) & _M64)
+        for att in range(DRAW_ATTEMPTS):
+            r = [mix64((hk + 3 * att + k) & _M64) for k in range(3)]
+            i0 = (r[0] * m) >> 64
+            i1 = (r[1] * (m - 1)) >> 64
+            if i1 >= i0:
+                i1 += 1
+            i2 = (r[2] * (m - 2)) >> 64
+            lo, hi = min(i0, i1), max(i0, i1)
+            if i2 >= lo:
+                i2 += 1
+            if i2 >= hi:
+                i2 += 1
+            out[h] = (i0, i1, i2)
+            if len({int(ids[i0]), int(ids[i1]), int(ids[i2])}) == 3:
+                break
     return out
 
 
@@ -272,7 +283,7 @@ class OracleRescaleEstimator:
         self.last.pop("model", None)
         if pts.shape[0] >= RANSAC_MIN_POINTS:                      # :152
             if self.device_seed is not None:
-                triples = device_triples(self.device_seed, self.frame_counter, pts.shape[0])
+                triples = device_triples(self.device_seed, self.frame_counter, self.last["flat"].ids)
             else:
                 triples = self.sampler(pts.shape[0])
             m, ic, used = run_ransac(np.array(pts), triples)

@@ -100,3 +100,7 @@ def test_device_sample_sequence():
     counts = np.bincount(small.reshape(-1), minlength=12)
     assert counts.min() > 400 and counts.max() < 600                      # 500 expected per position
     assert ro.mix64(0) == 0xE220A8397B1DCDAF                              # splitmix64's first output for state 0
+    # a list that repeats its vertices (rescale.py:101): no hypothesis names one vertex twice
+    ids = np.repeat(np.arange(8), 3)
+    t = ro.device_triples(3, 9, ids, n_hyp=500)
+    assert all(len(set(ids[list(r)])) == 3 for r in t.tolist()) and len({tuple(r) for r in t.tolist()}) > 400
