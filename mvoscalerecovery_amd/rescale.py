@@ -311,6 +311,7 @@ class ScaleEstimator:
 
     # ---- the device-resident path ------------------------------------------------------------------------------
     GPU_CHUNK = 8192            # frames per chunk, at most (a call of F frames uses chunks of F/4, 512 at least)
+    GPU_RESIDENT = 512          # frames the GPU works on at once (two 8-wavefront workgroups per CU)
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk
     GPU_PIPELINE = 2            # chunks queued on the device behind the one being collected
     N_HYP = RANSAC_ITERATIONS
@@ -507,6 +508,8 @@ class ScaleEstimator:
                 b = min(b, a + max(int(np.searchsorted(np.cumsum(lens), self.GPU_CHUNK_POINTS, side="right")), 1))
                 while b - a > 1 and (b - a) * int(lens[:b - a].max()) > 2 * self.GPU_CHUNK_POINTS:     # (workspace = frames x largest frame)
                     b = a + max(1, (b - a) // 2)
+                if b < F and b - a >= 2 * self.GPU_RESIDENT:           # whole rounds of the GPU's resident frames: no partly filled last round
+                    b = a + ((b - a) // self.GPU_RESIDENT) * self.GPU_RESIDENT
                 tr = None if id_triples is None else id_triples[a:b]
                 queue.append((self._chunk_dev_gpu(feature3ds[a:b], feature2ds[a:b], base + a, tr, stage,
                                                   tables=(tuple(t[:b - a] for t in tb) if tb is not None else None)), a, b))
