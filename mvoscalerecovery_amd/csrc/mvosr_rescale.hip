@@ -143,7 +143,7 @@ constexpr int kMaxHyp = 512;
 constexpr int kRansacPPT = 8;           // points per thread per chunk (chunks of 4096 points)
 // misc[] slots of flat_selection_kernel (slots below FM_WSUM are zeroed at the start)
 enum { FM_K = 0, FM_SINGULAR = 1, FM_BADID = 2, FM_KEPT = 3, FM_BIN = 4, FM_RANK = 5, FM_BINCNT = 6, FM_LE = 7, FM_LIST = 8,
-       FM_WSUM = 16 /* [8] per-wave bin totals */, FM_CW = 24 /* [8] per-wave counts of the ordered compactions */, FM_N = 32 };
+       FM_WSUM = 16 /* [16] per-wave bin totals */, FM_CW = 32 /* [16] per-wave counts of the ordered compactions */, FM_N = 48 };
 
 // The sample sequence of the device-resident RANSAC (include/mvosr.h, mvosr_flat_ransac_batch): splitmix64's finaliser as a
 // counter-based generator.  oracle/rescale_oracle.py restates it.
@@ -174,8 +174,15 @@ __device__ __forceinline__ void rs_draw3(uint64_t key, int h, int M, const uint1
     }
 }
 
-template <bool DEV>
-__global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs a) {
+#ifndef MVOSR_FLAT_DEV_WAVES
+#define MVOSR_FLAT_DEV_WAVES 16
+#endif
+constexpr int kFlatDevWaves = MVOSR_FLAT_DEV_WAVES;   // the device-resident form holds 96 KB of LDS — one workgroup per CU —, so it brings its own occupancy: 16 wavefronts
+
+template <bool DEV, int WAVES = kRsWaves>
+__global__ __launch_bounds__(WAVES *kWave) void flat_selection_kernel(const FlatArgs a) {
+    constexpr int BLK = WAVES * kWave;
+    static_assert(WAVES <= 16 && kFlatBins % BLK == 0, "flat_selection_kernel: misc slots / bins per thread");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = blockIdx.x;
     const int n_all = a.feat_cnt[f];
@@ -223,14 +230,14 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
     TriIds rows[kFlatRows];
     auto load_rows = [&](int t0) {
 #pragma unroll
-        for (int j = 0; j < kFlatRows; ++j) rows[j] = load_tri(a.tri + 3 * tb, min(t0 + j * kRsBlock, tn - 1));
+        for (int j = 0; j < kFlatRows; ++j) rows[j] = load_tri(a.tri + 3 * tb, min(t0 + j * BLK, tn - 1));
     };
     load_rows(tid);
     int n = n_all;                                               // features in LDS (the survivors)
     if (DEV && a.keep) {
         // ordered compaction at load (rescale.py:134-135: feature3d[valid_id]): every wavefront owns a contiguous segment of
         // the frame, counts its survivors, and after one barrier knows where its segment starts in LDS
-        const int seg = ((n_all + kRsBlock - 1) / kRsBlock) * kWave;
+        const int seg = ((n_all + BLK - 1) / BLK) * kWave;
         const int s0 = wave * seg, s1 = min(n_all, s0 + seg);
         int c = 0;
         for (int i0 = s0; i0 < s1; i0 += kWave) {
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
         __syncthreads();
         int base = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < kRsWaves; ++w) { const int cw = misc[FM_CW + w]; total += cw; if (w < wave) base += cw; }
+        for (int w = 0; w < WAVES; ++w) { const int cw = misc[FM_CW + w]; total += cw; if (w < wave) base += cw; }
         n = total;
         for (int i0 = s0; i0 < s1; i0 += kWave) {
             const int i = i0 + lane;
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
         }
     } else {
 #pragma unroll 4
-        for (int i = tid; i < n_all; i += kRsBlock) { X[i] = a.x[off + i]; Y[i] = a.y[off + i]; Z[i] = a.z[off + i]; }
+        for (int i = tid; i < n_all; i += BLK) { X[i] = a.x[off + i]; Y[i] = a.y[off + i]; Z[i] = a.z[off + i]; }
     }
     const double s_loose = sin(a.loose_deg * 3.141592653589793 / 180.0), s_tight = sin(a.tight_deg * 3.141592653589793 / 180.0);
     __syncthreads();
@@ -289,13 +296,13 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
                 ++k_mine; umin = u < umin ? u : umin; umax = u > umax ? u : umax;
             }
         };
-        for (int t0 = tid; t0 < tn; t0 += kFlatRows * kRsBlock) {
+        for (int t0 = tid; t0 < tn; t0 += kFlatRows * BLK) {
             TriIds cur[kFlatRows];
 #pragma unroll
             for (int j = 0; j < kFlatRows; ++j) cur[j] = rows[j];
-            if (t0 + kFlatRows * kRsBlock < tn) load_rows(t0 + kFlatRows * kRsBlock);
+            if (t0 + kFlatRows * BLK < tn) load_rows(t0 + kFlatRows * BLK);
 #pragma unroll
-            for (int j = 0; j < kFlatRows; ++j) if (t0 + j * kRsBlock < tn) one_row(cur[j], t0 + j * kRsBlock);
+            for (int j = 0; j < kFlatRows; ++j) if (t0 + j * BLK < tn) one_row(cur[j], t0 + j * BLK);
         }
         k_mine = wave_sum(k_mine);
 #pragma unroll
@@ -323,17 +330,18 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
             if (range == 0ull) { vlo_bits = lo; break; }
             const int bits = 64 - __clzll((long long)range);                             // range < 2^bits
             const int shift = bits > 11 ? bits - 11 : 0;
-            for (int b = tid; b < kFlatBins; b += kRsBlock) hist[b] = 0;
+            for (int b = tid; b < kFlatBins; b += BLK) hist[b] = 0;
             __syncthreads();
             #pragma unroll 4
-            for (int t = tid; t < tn; t += kRsBlock) {
+            for (int t = tid; t < tn; t += BLK) {
                 if (!(Fl[t] & 1)) continue;
                 const unsigned long long u = U[t];
                 if (u >= lo && u <= hi) atomicAdd(&hist[(int)((u - lo) >> shift)], 1);
             }
             __syncthreads();
             {   // the bin whose cumulative count passes the rank: four bins per thread, wave scan, wave totals through LDS
-                const int b0 = hist[4 * tid], b1 = hist[4 * tid + 1], b2 = hist[4 * tid + 2], b3 = hist[4 * tid + 3];
+                constexpr int BPT = kFlatBins / BLK;                // bins per thread (4 with 512 threads, 2 with 1024)
+                const int b0 = hist[BPT * tid], b1 = BPT > 1 ? hist[BPT * tid + 1] : 0, b2 = BPT > 2 ? hist[BPT * tid + 2] : 0, b3 = BPT > 3 ? hist[BPT * tid + 3] : 0;
                 const int mine = (b0 + b1) + (b2 + b3);
                 int incl = mine;
 #pragma unroll
@@ -342,11 +350,11 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
                 __syncthreads();
                 int before = 0;
 #pragma unroll
-                for (int w = 0; w < kRsWaves; ++w) if (w < wave) before += misc[FM_WSUM + w];
+                for (int w = 0; w < WAVES; ++w) if (w < wave) before += misc[FM_WSUM + w];
                 incl += before;
                 const int excl = incl - mine;
                 if (rank >= excl && rank < incl) {               // exactly one thread
-                    int r = rank - excl, bin = 4 * tid, c = b0;
+                    int r = rank - excl, bin = BPT * tid, c = b0;
                     if (r >= b0) { r -= b0; ++bin; c = b1; if (r >= b1) { r -= b1; ++bin; c = b2; if (r >= b2) { r -= b2; ++bin; c = b3; } } }
                     misc[FM_BIN] = bin; misc[FM_RANK] = r; misc[FM_BINCNT] = c;
                 }
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
                 unsigned long long *list = reinterpret_cast<unsigned long long *>(hist);
                 __syncthreads();                                 // every thread has read misc / hist
                 #pragma unroll 4
-                for (int t = tid; t < tn; t += kRsBlock) {
+                for (int t = tid; t < tn; t += BLK) {
                     if (!(Fl[t] & 1)) continue;
                     const unsigned long long u = U[t];
                     if (u >= lo && u <= hi) list[atomicAdd(&misc[FM_LIST], 1)] = u;
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
             int le = 0;
             unsigned long long above = ~0ull;
             #pragma unroll 4
-            for (int t = tid; t < tn; t += kRsBlock) {
+            for (int t = tid; t < tn; t += BLK) {
                 if (!(Fl[t] & 1)) continue;
                 const unsigned long long u = U[t];
                 if (u <= vlo_bits) ++le; else above = u < above ? u : above;
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
     if constexpr (!DEV) {
         int kept = 0;
         #pragma unroll 4
-        for (int t = tid; t < tn; t += kRsBlock) {
+        for (int t = tid; t < tn; t += BLK) {
             uint8_t fl = Fl[t];
             if ((fl & 2) && Hh[t] > level) { fl |= 4; ++kept; }                                 // :94-96
             a.tri_flags[tb + t] = fl;
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
     } else {
         // ---- the kept rows (:94-96), wavefront by wavefront over contiguous row segments so that the point list —
         // triangle_ids[valid_id].reshape(-1), :101 — comes out in row order without a sort
-        const int seg = ((tn + kRsBlock - 1) / kRsBlock) * kWave;
+        const int seg = ((tn + BLK - 1) / BLK) * kWave;
         const int s0 = wave * seg, s1 = min(tn, s0 + seg);
         int c = 0;
         for (int t0 = s0; t0 < s1; t0 += kWave) {
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
         __syncthreads();                                         // (every height has been compared: their room is the list's now)
         int base = 0, K = 0;
 #pragma unroll
-        for (int w = 0; w < kRsWaves; ++w) { const int cw = misc[FM_CW + w]; K += cw; if (w < wave) base += cw; }
+        for (int w = 0; w < WAVES; ++w) { const int cw = misc[FM_CW + w]; K += cw; if (w < wave) base += cw; }
         const int M = 3 * K;                                     // len(point_selected), :140
         uint16_t *L = reinterpret_cast<uint16_t *>(Hh);          // the point list as vertex ids
         const int H = a.n_hyp;
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
             // the hypotheses' planes, one thread each (ransac.py:10-11, estimate_road_norm.py:13-15)
             const uint64_t fc = (uint64_t)(a.frame_ids ? a.frame_ids[f] : a.frame_base + f);
             const uint64_t key = rs_mix64(a.seed ^ (fc * 0xD1B54A32D192ED03ull));
-            for (int h = tid; h < H; h += kRsBlock) {
+            for (int h = tid; h < H; h += BLK) {
                 int v0, v1, v2;
                 if (a.id_triples) {
                     const int32_t *t = a.id_triples + ((int64_t)f * H + h) * 3;
@@ -486,17 +494,20 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
             }
             __syncthreads();
             // inlier counts (estimate_road_norm.py:17-18 over every list entry, repeats included): a thread's points in
-            // registers, gathered from the LDS planes once, the hypotheses streamed past them
-            for (int c0 = 0; c0 < M; c0 += kRsBlock * kRansacPPT) {
+            // registers, gathered from the LDS planes once, the hypotheses streamed past them.  (Counting over the ~600 distinct
+            // VERTICES weighted with their multiplicities — bit-sliced: sum_b 2^b popcount(inliers & lanes with bit b — a fifth
+            // of the fp64 work, was measured: 1.26 ms against 1.03 ms per chunk; the scalar ballot arithmetic and the extra
+            // passes that build the vertex list cost more than the products they save.)
+            for (int c0 = 0; c0 < M; c0 += BLK * kRansacPPT) {
                 double qx[kRansacPPT], qy[kRansacPPT], qz[kRansacPPT];
 #pragma unroll
                 for (int kk = 0; kk < kRansacPPT; ++kk) {
-                    const int j = c0 + kk * kRsBlock + tid;
+                    const int j = c0 + kk * BLK + tid;
                     const int id = L[min(j, M - 1)];
                     qx[kk] = X[id]; qy[kk] = Y[id]; qz[kk] = Z[id];
                     if (j >= M) qx[kk] = nan("");                    // never an inlier
                 }
-                const int rws = min(kRansacPPT, (M - c0 + kRsBlock - 1) / kRsBlock);
+                const int rws = min(kRansacPPT, (M - c0 + BLK - 1) / BLK);
 #pragma unroll 2
                 for (int h = 0; h < H; ++h) {
                     const double2 m0 = mods[2 * h], m1 = mods[2 * h + 1];
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(kRsBlock) void flat_selection_kernel(const FlatArgs
                 }
             }
             __syncthreads();
-            if (a.hyp_counts) for (int h = tid; h < H; h += kRsBlock) a.hyp_counts[(int64_t)f * H + h] = cnts[h];
+            if (a.hyp_counts) for (int h = tid; h < H; h += BLK) a.hyp_counts[(int64_t)f * H + h] = cnts[h];
         }
         if (tid == 0) {
             int status = misc[FM_BADID] ? MVOSR_ST_ERR_MASK : (misc[FM_SINGULAR] ? MVOSR_ST_ERR_SINGULAR : (fit ? 0 : MVOSR_ST_RS_FEW));
@@ -847,7 +858,7 @@ int mvosr_flat_selection_batch(mvosr_ctx *ctx, const mvosr_batch *b, double loos
     if (max_tri <= 0) max_tri = 2 * (int64_t)b->max_feat;
     size_t lds = 24u * (size_t)((b->max_feat + 1) & ~1);
     if (lds < 4u * 2048) lds = 4u * 2048;                        // (the histogram of the median search reuses the vertex planes)
-    lds += 9u * (size_t)max_tri + 32 + 4u * 32 + 16;
+    lds += 9u * (size_t)max_tri + 32 + 4u * 48 + 16;
     if ((rc = rs_prepare(flat_selection_kernel<false>, lds))) return rc;
     hipLaunchKernelGGL(flat_selection_kernel<false>, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
     return check_launch("flat_selection_kernel");
@@ -879,10 +890,10 @@ int mvosr_flat_ransac_batch(mvosr_ctx *ctx, const mvosr_batch *b, const int32_t 
     a.seed = rp->seed; a.frame_base = rp->frame_base;
     a.raw_scale = o->raw_scale; a.model = o->model; a.best_ic = o->best_ic; a.used = o->used; a.hyp_counts = o->hyp_counts;
     // heights (reused by the 16-bit point list: 6 B per row <= 8), scalars, planes, histogram, flags, hypotheses
-    const size_t lds = 8u * (size_t)max_tri + 32 + 4u * 32 + 24u * (size_t)((b->max_feat + 1) & ~1) + 4u * 2048 + (size_t)max_tri + 32
+    const size_t lds = 8u * (size_t)max_tri + 32 + 4u * 48 + 24u * (size_t)((b->max_feat + 1) & ~1) + 4u * 2048 + (size_t)max_tri + 32
                        + 36u * (size_t)rp->n_hyp + 16;
-    if ((rc = rs_prepare(flat_selection_kernel<true>, lds))) return rc;
-    hipLaunchKernelGGL(flat_selection_kernel<true>, dim3((unsigned)b->n_frames), dim3(kRsBlock), lds, ctx_stream(ctx), a);
+    if ((rc = rs_prepare(flat_selection_kernel<true, kFlatDevWaves>, lds))) return rc;
+    hipLaunchKernelGGL((flat_selection_kernel<true, kFlatDevWaves>), dim3((unsigned)b->n_frames), dim3(kFlatDevWaves * kWave), lds, ctx_stream(ctx), a);
     return check_launch("flat_selection_kernel<device>");
 }
 
