@@ -129,7 +129,11 @@ def run_sequence_sharded(data, estimator, group=None, minimum_feature_for_scale=
     mine = idx[start:stop]
     f3 = [np.asarray(data["feature3ds"][i], dtype=np.float64) for i in mine]
     f2 = [np.asarray(data["feature2ds"][i], dtype=np.float64) for i in mine]
-    raw, status, level, host_errors = estimator.raw_scale_batch(f3, f2)
+    import inspect
+    if "frame_base" in inspect.signature(estimator.raw_scale_batch).parameters:      # (rescale.ScaleEstimator: its sample
+        raw, status, level, host_errors = estimator.raw_scale_batch(f3, f2, frame_base=start)   # sequence is keyed by the frame's position)
+    else:
+        raw, status, level, host_errors = estimator.raw_scale_batch(f3, f2)
     status = np.array(status, dtype=np.int32)
     for f, exc in host_errors.items():
         status[f] = ST_HOST_QHULL if type(exc).__name__ == "QhullError" else ST_HOST_OTHER

@@ -489,7 +489,7 @@ class ScaleEstimator:
                         res["stage"][k][f] = sub["stage"][k][j]
         return res
 
-    def _stream_device(self, feature3ds, feature2ds, id_triples, stage):
+    def _stream_device(self, feature3ds, feature2ds, id_triples, stage, push=True):
         F = len(feature3ds)
         if F == 0:
             return np.zeros(0), np.zeros(0)
@@ -540,7 +540,33 @@ class ScaleEstimator:
         if stage:
             for k in ("valid", "tris2", "tri_flags"):
                 self.last[k] = [x for r in results for x in r["stage"][k]]
+        if not push:
+            return raw, status, level, host_errors
         return self._push_device(raw, status, level, host_errors)
+
+    # ---- the two halves on their own: what a driver that shards a sequence over GPUs needs (offline.run_sequence_sharded) ----
+    def raw_scale_batch(self, feature3ds, feature2ds, frame_base=0):
+        """Per-frame half only (no cross-frame state touched): ``(raw_scale[F], status[F], height_level[F], host_errors)``.
+        ``frame_base``: position of the block's first frame in the whole sequence — the sample sequence is keyed by the
+        frame's position, so a sequence split over ranks draws the triples the single-process run draws."""
+        if self.sampling != "device":
+            raise ValueError("the sharded driver needs the device sample sequence: ScaleEstimator(..., triangulation='gpu') "
+                             "or (..., sampling='device')")
+        if len(feature3ds) == 0:
+            return np.zeros(0), np.zeros(0, dtype=np.int32), np.zeros(0), {}
+        keep, self._frame_counter = self._frame_counter, self._frame_counter + int(frame_base)
+        try:
+            return self._stream_device(feature3ds, feature2ds, None, False, push=False)
+        finally:
+            self._frame_counter = keep
+
+    def push_raw_scales(self, raw, status, level=None, host_errors=None):
+        """Cross-frame half (slew limiter, window median, raise sites) for raw scales computed elsewhere (other ranks):
+        returns ``(scales, stds)`` like ``scale_calculation_batch``."""
+        raw = np.asarray(raw, dtype=np.float64)
+        status = np.asarray(status, dtype=np.int32)
+        level = np.full(len(raw), np.nan) if level is None else np.asarray(level, dtype=np.float64)
+        return self._push_device(raw, status, level, host_errors or {})
 
     def _push_device(self, raw, status, level, host_errors):
         """The cross-frame tail (rescale.py:169-178) on the device over the frames before the first one at which the

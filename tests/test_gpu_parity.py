@@ -1984,6 +1984,56 @@ def test_estimator_stage_methods(gpu, stages):
         est.road_model_calculation_static(pts)
 
 
+def test_rescale_sharded_sequence_driver_two_ranks_one_gpu(gpu, tmp_path):
+    """The estimator the reference's main_offline.py imports behind the sharded driver: two ranks (gloo, sharing this GPU)
+    each run the device-resident per-frame half on their block of the 200-frame sequence, ONE all-gather reassembles the raw
+    scales, every rank applies the slew limiter and window median — the same scales, bit for bit, as the single-process
+    batched run and as the per-frame loop (the sample sequence is keyed by a frame's position in the sequence)."""
+    import subprocess
+    import sys
+    import textwrap
+    from conftest import ROOT
+    from mvoscalerecovery_amd import offline, synth
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    data = synth.synth_sequence_dict(200, base_seed=41, n_lo=300, n_hi=1500)
+    one = offline.run_sequence_batched(data, ScaleEstimator(1.75, window_size=5, triangulation="gpu", ransac_seed=8))
+    loop = offline.run_sequence(data, ScaleEstimator(1.75, window_size=5, triangulation="gpu", ransac_seed=8))
+    np.testing.assert_array_equal(one["scales"], loop["scales"])
+    solo = offline.run_sequence_sharded(data, ScaleEstimator(1.75, window_size=5, triangulation="gpu", ransac_seed=8))
+    np.testing.assert_array_equal(solo["scales"], one["scales"])
+    np.save(tmp_path / "want.npy", one["scales"])
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %(root)r)
+        import numpy as np
+        import torch.distributed as dist
+        from mvoscalerecovery_amd import offline, sharding, synth
+        from mvoscalerecovery_amd.rescale import ScaleEstimator
+        rank, local, world = sharding.init_distributed("gloo")
+        data = synth.synth_sequence_dict(200, base_seed=41, n_lo=300, n_hi=1500)
+        res = offline.run_sequence_sharded(data, ScaleEstimator(1.75, window_size=5, triangulation="gpu", ransac_seed=8))
+        assert np.array_equal(res["scales"], np.load(%(want)r)), "rank %%d differs" %% rank
+        dist.barrier()
+        dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """) % {"root": ROOT, "want": str(tmp_path / "want.npy")})
+    port = 29500 + os.getpid() % 150
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MVOSR_SHARE_GPU="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for rank, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        assert p.returncode == 0, out
+        assert "rank %d ok" % rank in out
+
+
 def test_sharded_sequence_driver_two_ranks_one_gpu(gpu, tmp_path):
     """Config C4 in driver form: offline.run_sequence_sharded with the real ScaleEstimator on two ranks
     (gloo, both on this GPU: MVOSR_SHARE_GPU) reproduces the reference's 200-frame golden on every rank;
