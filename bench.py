@@ -419,6 +419,21 @@ def latency_leg(args, device, sizes, seed, frames=40):
         t = np.array(t) * 1e3
         out[name] = {"median_ms": float(np.median(t)), "p90_ms": float(np.percentile(t, 90)),
                      "hip_malloc_calls": a1["hip_malloc"] - a0["hip_malloc"], "hip_host_malloc_calls": a1["host_malloc"] - a0["host_malloc"]}
+    # the estimator the reference's drivers import, device-resident (one frame per call: /root/reference/src/main.py:113)
+    from mvoscalerecovery_amd.rescale import ScaleEstimator as RescaleEstimator
+    est = RescaleEstimator(ABS_REF, window_size=WINDOW, device=device, delaunay_workers=0, triangulation="gpu", ransac_seed=2024)
+    for f3, f2 in fr[:5]:
+        est.scale_calculation(f3, f2)
+    a0 = est.ctx.alloc_stats()
+    t = []
+    for f3, f2 in fr:
+        t0 = time.perf_counter()
+        est.scale_calculation(f3, f2)
+        t.append(time.perf_counter() - t0)
+    a1 = est.ctx.alloc_stats()
+    t = np.array(t) * 1e3
+    out["rescale_gpu"] = {"median_ms": float(np.median(t)), "p90_ms": float(np.percentile(t, 90)),
+                          "hip_malloc_calls": a1["hip_malloc"] - a0["hip_malloc"], "hip_host_malloc_calls": a1["host_malloc"] - a0["host_malloc"]}
     out["what"] = "ScaleEstimator.scale_calculation per frame (stage outputs, flat_feature), %d frames after 5 warm-up calls" % frames
     return out
 

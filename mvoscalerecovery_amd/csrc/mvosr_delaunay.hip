@@ -802,6 +802,12 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
             }
             return any;
         };
+#ifdef MVOSR_STAMPS
+        unsigned long long t_sec[4] = {0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();      // take a point / ranges / scan / completion
+#define DT_SEC(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); t_sec[k] += now_ - t_last; t_last = now_; } while (0)
+#else
+#define DT_SEC(k) do {} while (0)
+#endif
         for (;;) {
             if (i < 0 && !exhausted) {
                 const int idx = atomicAdd(&misc[DM_NEXT], 1);
@@ -818,6 +824,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
 #ifdef MVOSR_STAMPS
             ++n_iter; n_busy += act ? 1 : 0; steps_pt += act ? 1 : 0;
 #endif
+            DT_SEC(0);
             serve_wide();
             DtEdge E;
             if (m1) E.set(p, S[max(iq, 0)], i, iq, sgn); else E.set_nn(p, i);
@@ -891,6 +898,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 else { y_next += kDtRows; j_resume = 0; }
             }
             }
+            DT_SEC(2);
             // (twice: a wide search the first pass raises is scanned by the wavefront at once and completed in the same step)
             for (int rep = 0; rep < 2; ++rep) {
             if (i >= 0 && y_next > box.yb) {                         // the search is finished
@@ -1029,8 +1037,10 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
             }
             if (rep == 1 || !serve_wide()) break;
             }
+            DT_SEC(3);
         }
 #ifdef MVOSR_STAMPS
+        if (lane == 0) { atomicAdd(&misc[46], (int)(t_sec[2] >> 4)); atomicAdd(&misc[47], (int)(t_sec[3] >> 4)); }   // (sixteenths of a cycle count: 32-bit sums)
         atomicAdd(&misc[48], n_by_search); atomicAdd(&misc[49], n_by_hint); atomicAdd(&misc[50], n_iter); atomicAdd(&misc[51], n_busy);
 #endif
     }
@@ -1039,6 +1049,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
 #ifdef MVOSR_STAMPS
     DT_NOTE(10, misc[48]); DT_NOTE(11, misc[49]); DT_NOTE(12, misc[50]); DT_NOTE(13, misc[51]);
     DT_NOTE(26, misc[61]); DT_NOTE(27, misc[62]); DT_NOTE(28, misc[63]);
+    DT_NOTE(15, misc[46]); DT_NOTE(25, misc[47]);
     DT_NOTE(29, misc[40]); DT_NOTE(30, misc[41]); DT_NOTE(31, misc[42]); DT_NOTE(7, misc[43]); DT_NOTE(8, misc[44]); DT_NOTE(14, misc[45]);
     if (tid == 0 && a.stamps) for (int k = 52; k < 61; ++k) a.stamps[32 * f + 16 + (k - 52)] = (unsigned long long)misc[k];
 #endif

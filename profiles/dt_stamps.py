@@ -61,3 +61,6 @@ print("  scan steps per lane: %.1f   lanes with a point in a step: %.1f %%" % (n
 print("  searches whose hint had arrived by the time they finished: %.0f per set; whose slot held another neighbour's hint: %.0f; nearest-neighbour searches completed: %.0f" % (np.mean(s[:, 26]), np.mean(s[:, 27]), np.mean(s[:, 28])))
 print("  wave-level candidate trips per set: lane pass %.0f (in %.0f wave-steps, %.0f lane-candidates), shared wide scans %.0f (in %.0f scans, %.0f row passes)" % (
     np.mean(s[:, 29]), np.mean(s[:, 8]), np.mean(s[:, 14]), np.mean(s[:, 30]), np.mean(s[:, 31]), np.mean(s[:, 7])))
+print("  phase 1 by section, summed over the 8 wavefronts (share of 8 x phase-1 cycles): ranges + scans (incl. shared wide scans) %.1f %%, completions %.1f %%, rest (taking points, idle at the tail) %.1f %%" % (
+    100 * 16 * np.mean(s[:, 15]) / (8 * np.mean(d[:, 2])), 100 * 16 * np.mean(s[:, 25]) / (8 * np.mean(d[:, 2])),
+    100 - 100 * 16 * (np.mean(s[:, 15]) + np.mean(s[:, 25])) / (8 * np.mean(d[:, 2]))))

@@ -68,7 +68,8 @@ def render(tag):
                 rows.append((label, "**%s frames/s** at 2000 features (%d frames, %s distinct)%s" % (k(e["value"]), e["frames"], e.get("distinct_frames", "all"), extra), "`%s` in the bench line" % key))
         if "latency" in b:
             la = b["latency"]
-            rows.append(("per-frame `scale_calculation` latency, 2000 features", "SciPy triangulations %.2f ms, device triangulations %.2f ms (median; 0 allocations per call)" % (la["scipy"]["median_ms"], la["gpu"]["median_ms"]), "`latency` in the bench line"))
+            extra = (", `rescale` estimator device-resident %.2f ms" % la["rescale_gpu"]["median_ms"]) if "rescale_gpu" in la else ""
+            rows.append(("per-frame `scale_calculation` latency, 2000 features", "SciPy triangulations %.2f ms, device triangulations %.2f ms%s (median; 0 allocations per call)" % (la["scipy"]["median_ms"], la["gpu"]["median_ms"], extra), "`latency` in the bench line"))
         cb = b.get("cpu_baseline")
         if cb:
             rows.append(("CPU oracle on the GPU box's host cores (baseline, not target)", "%.0f frames/s on %d core (vectorised NumPy port); all cores: %s; reference-shaped Python loops: %s"
