@@ -148,6 +148,10 @@ static unsigned long long *g_dt_stamps = nullptr;
 #define MVOSR_DT_HINTS 16
 #endif
 constexpr int kDtHintK = MVOSR_DT_HINTS;       // 0: no hints
+#ifndef MVOSR_DT_SCOPE
+#define MVOSR_DT_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+constexpr int kDtScope = MVOSR_DT_SCOPE;
 #ifndef MVOSR_DT_CHAIN
 #define MVOSR_DT_CHAIN 8
 #endif
@@ -198,7 +202,7 @@ __host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false, int 
     p.oid = p.S + 16u * npad;                            // u16: sorted index -> id of the point
     p.od = p.oid + 2u * npad;                            // u16 per id: rows owned | star degree << 6 | listed << 14 | open << 15
     p.astart = p.od + 2u * npad;                         // u16 per id: the point's rows in the arena
-    p.cs = p.astart + 2u * npad;                         // u32 per cell (+1): end of the cell in the sorted array
+    p.cs = p.astart + 2u * npad + 4u;                    // u32 per cell (+1): end of the cell in the sorted array; cs[-1] = 0 (the start of cell 0)
     p.arena = p.cs + 4u * (uint32_t)(p.max_cells + 8);   // u32 rows (b << 16 | c) in the order they were found
     p.big = (p.arena + 4u * (uint32_t)p.arena_cap + 255u) & ~255u;
     p.hard = p.big;                                      // u16 sorted indices
@@ -222,7 +226,7 @@ struct DtGrid {
     const uint32_t *cs;
     __device__ __forceinline__ int cellx(double x) const { return (int)fmin(fmax((x - lo_u) * ix, 0.0), (double)(gx - 1)); }
     __device__ __forceinline__ int celly(double y) const { return (int)fmin(fmax((y - lo_v) * iy, 0.0), (double)(gy - 1)); }
-    __device__ __forceinline__ int row_begin(int cy, int cxa) const { const int c = cy * gx + cxa; return c ? (int)cs[c - 1] : 0; }
+    __device__ __forceinline__ int row_begin(int cy, int cxa) const { return (int)cs[cy * gx + cxa - 1]; }     // (cs[-1] = 0)
     __device__ __forceinline__ int row_end(int cy, int cxb) const { return (int)cs[cy * gx + cxb]; }
 };
 
@@ -310,21 +314,40 @@ __device__ __forceinline__ void dt_row_range(const DtGrid &G, const DtEdge &E, i
     if (xa <= xb) { j0 = G.row_begin(y, xa); j1 = G.row_end(y, xb); }
 }
 
+// The same for the lane pass, where every lane has its own edge: without branches (lanes with side > 0, side < 0 and side = 0
+// share a wavefront: the branches ran one after the other, 55 instructions per row and five rows per scan step), the same
+// arithmetic.  `ok` = the row is wanted at all; a row that is not, or is cut away, is the empty range 0..0.
+__device__ __forceinline__ void dt_row_range_lane(const DtGrid &G, const DtEdge &E, int y, bool ok, int xa, int xb, int &j0, int &j1) {
+    const double v0 = G.lo_v + ((double)y - 1e-6) * G.sy, v1 = G.lo_v + ((double)(y + 1) + 1e-6) * G.sy;
+    const double t0 = E.k * (v0 - E.py), t1 = E.k * (v1 - E.py);
+    const double m = E.side > 0 ? fmax(t0, t1) : fmin(t0, t1);
+    const int c = G.cellx(E.px + m) + E.side;
+    xb = E.side > 0 ? min(xb, c) : xb;
+    xa = E.side < 0 ? max(xa, c) : xa;
+    const int row = min(y, G.gy - 1) * G.gx;
+    const int b = (int)G.cs[row + xa - 1], e = (int)G.cs[row + xb];
+    ok = ok && xa <= xb;
+    j0 = ok ? b : 0; j1 = ok ? e : 0;
+}
+
 // Lane pass, cold: is any candidate of the block other than the winner within the guard band of the winner?
-__device__ __attribute__((noinline)) bool dt_confirm_tie(const double2 *S, const DtGrid &G, const DtBox &blk, const DtEdge &E,
-                                                         int b1, double n1, double c1) {
+// (Everything by VALUE: a reference parameter of an out-of-line function gives its argument a home in scratch memory, and the
+// loop around the call kept the edge, the box and the grid up to date there — a dozen scratch stores per scan step.)
+__device__ __attribute__((noinline)) bool dt_confirm_tie(const double2 *S, const uint32_t *cs, int gx, int xa, int xb, int ya, int yb,
+                                                         double px, double py, double ax, double ay, double sgn, double a2col,
+                                                         int ei, int eiq, int b1, double n1, double c1) {
     const double s1 = kDtTieTol * (fabs(n1) + c1);
     bool tie = false;
-    for (int y = blk.ya; y <= blk.yb; ++y) {
-        const int j1 = G.row_end(y, blk.xb);
-        for (int j = G.row_begin(y, blk.xa); j < j1; ++j) {
-            if (j == E.i || j == E.iq || j == b1) continue;
+    for (int y = ya; y <= yb; ++y) {
+        const int j1 = (int)cs[y * gx + xb];
+        for (int j = (int)cs[y * gx + xa - 1]; j < j1; ++j) {
+            if (j == ei || j == eiq || j == b1) continue;
             const double2 c = S[j];
-            const double bx = c.x - E.px, by = c.y - E.py;
-            const double cr = E.sgn * __builtin_fma(E.ax, by, -(E.ay * bx));
+            const double bx = c.x - px, by = c.y - py;
+            const double cr = sgn * __builtin_fma(ax, by, -(ay * bx));
             const double b2 = __builtin_fma(bx, bx, by * by);
-            if (cr * cr <= E.a2col * b2 || !(cr > 0.0)) continue;
-            const double num = b2 - __builtin_fma(bx, E.ax, by * E.ay);
+            if (cr * cr <= a2col * b2 || !(cr > 0.0)) continue;
+            const double num = b2 - __builtin_fma(bx, ax, by * ay);
             if (fabs(__builtin_fma(num, c1, -(n1 * cr))) <= s1 * cr) tie = true;
         }
     }
@@ -514,7 +537,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
     }
     const int ncell = G.gx * G.gy;
     DT_STAMP(1);
-    for (int c = tid; c <= ncell; c += BLOCK) cs[c] = 0u;
+    for (int c = tid - 1; c <= ncell; c += BLOCK) cs[c] = 0u;          // (from cs[-1] on)
     for (int i = tid; i < ((n + 1) >> 1); i += BLOCK) reinterpret_cast<uint32_t *>(od)[i] = 0u;
     __syncthreads();
 
@@ -555,7 +578,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 const int pos = (int)atomicAdd(&cs[G.celly(p.y) * G.gx + G.cellx(p.x)], 1u);
                 S[pos] = p;
                 oid[pos] = (uint16_t)(rank + __popcll(m & ((1ull << lane) - 1ull)));
-                if (inv) __hip_atomic_store(inv + i, (uint32_t)pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (inv) __hip_atomic_store(inv + i, (uint32_t)pos, __ATOMIC_RELAXED, kDtScope);
             }
             rank += __popcll(m);
         }
@@ -574,9 +597,9 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
             for (int r = tid; r < ns; r += BLOCK) {
                 const int ra = st[3 * r], rb = st[3 * r + 1], rc = st[3 * r + 2];
                 if ((unsigned)ra >= (unsigned)n_in || (unsigned)rb >= (unsigned)n_in || (unsigned)rc >= (unsigned)n_in) continue;
-                const uint32_t pa = __hip_atomic_load(inv + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t pb = __hip_atomic_load(inv + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t pc = __hip_atomic_load(inv + rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t pa = __hip_atomic_load(inv + ra, __ATOMIC_RELAXED, kDtScope);
+                const uint32_t pb = __hip_atomic_load(inv + rb, __ATOMIC_RELAXED, kDtScope);
+                const uint32_t pc = __hip_atomic_load(inv + rc, __ATOMIC_RELAXED, kDtScope);
                 const bool ka = pa < (uint32_t)n, kb = pb < (uint32_t)n, kc = pc < (uint32_t)n;
                 if (ka && kb && kc) continue;
                 if (ka) aff[pa] = 1;
@@ -587,7 +610,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
             // the unchanged stars' bookkeeping: row count, degree and hull flag as they were, room for the rows
             const uint32_t *info = a.seed_info + off;
             for (int i0 = tid; i0 < n_in; i0 += BLOCK) {
-                const uint32_t pos = __hip_atomic_load(inv + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t pos = __hip_atomic_load(inv + i0, __ATOMIC_RELAXED, kDtScope);
                 if (pos >= (uint32_t)n || aff[pos]) continue;
                 const uint32_t wd = info[i0];
                 const int nown = (int)(wd & 63u);
@@ -605,9 +628,9 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
         for (int r = tid; r < ns; r += BLOCK) {
             const int ra = st[3 * r], rb = st[3 * r + 1], rc = st[3 * r + 2];
             if ((unsigned)ra >= (unsigned)n_in || (unsigned)rb >= (unsigned)n_in || (unsigned)rc >= (unsigned)n_in) continue;
-            const uint32_t pa = __hip_atomic_load(inv + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t pb = __hip_atomic_load(inv + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t pc = __hip_atomic_load(inv + rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t pa = __hip_atomic_load(inv + ra, __ATOMIC_RELAXED, kDtScope);
+            uint32_t pb = __hip_atomic_load(inv + rb, __ATOMIC_RELAXED, kDtScope);
+            uint32_t pc = __hip_atomic_load(inv + rc, __ATOMIC_RELAXED, kDtScope);
             if (pa >= (uint32_t)n || pb >= (uint32_t)n || pc >= (uint32_t)n) continue;          // a vertex that is not kept (all ones)
             bool ha = true, hb = true, hc = true;
             if (carry) {
@@ -624,16 +647,16 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
             if (!(cr != 0.0)) continue;
             if (cr < 0.0) { const uint32_t t = pb; pb = pc; pc = t; const bool tb = hb; hb = hc; hc = tb; }   // (pa, pb, pc) counter-clockwise now
             if (ha) {
-                __hip_atomic_store(hints + (size_t)pa * kDtHintK + (pb % kDtHintK), (pb << 16) | pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(start + pa, (pb << 16) | pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(hints + (size_t)pa * kDtHintK + (pb % kDtHintK), (pb << 16) | pc, __ATOMIC_RELAXED, kDtScope);
+                __hip_atomic_store(start + pa, (pb << 16) | pc, __ATOMIC_RELAXED, kDtScope);
             }
             if (hb) {
-                __hip_atomic_store(hints + (size_t)pb * kDtHintK + (pc % kDtHintK), (pc << 16) | pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(start + pb, (pc << 16) | pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(hints + (size_t)pb * kDtHintK + (pc % kDtHintK), (pc << 16) | pa, __ATOMIC_RELAXED, kDtScope);
+                __hip_atomic_store(start + pb, (pc << 16) | pa, __ATOMIC_RELAXED, kDtScope);
             }
             if (hc) {
-                __hip_atomic_store(hints + (size_t)pc * kDtHintK + (pa % kDtHintK), (pa << 16) | pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(start + pc, (pa << 16) | pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(hints + (size_t)pc * kDtHintK + (pa % kDtHintK), (pa << 16) | pb, __ATOMIC_RELAXED, kDtScope);
+                __hip_atomic_store(start + pc, (pa << 16) | pb, __ATOMIC_RELAXED, kDtScope);
             }
         }
         __syncthreads();
@@ -675,7 +698,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
             for (int j = b; j < e; ++j) {
                 if (carry && !aff[j]) continue;
                 const int at = atomicAdd(&ccnt[4 * min(k, 3) + col], 1);
-                __hip_atomic_store(order + at, (uint32_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(order + at, (uint32_t)j, __ATOMIC_RELAXED, kDtScope);
                 ++k;
             }
         }
@@ -699,7 +722,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
         // the hull and the points next to it, whose stars need wide searches — the long tasks start first, the short
         // ones fill the tail.  (All boundary cells' points first — an order array built per frame — measured the same.)
         auto point_of = [&](int idx) {
-            if (order) return (int)__hip_atomic_load(order + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (order) return (int)__hip_atomic_load(order + idx, __ATOMIC_RELAXED, kDtScope);
             return (idx & 1) ? n - 1 - (idx >> 1) : (idx >> 1);
         };
         int i = tid < n_work ? point_of(tid) : -1;       // (misc[DM_NEXT] starts at BLOCK)
@@ -740,7 +763,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
 #if MVOSR_DT_HINT_START
             if constexpr (kDtHintsOn<GLOBAL>) {
                 if (hints && i >= 0) {
-                    const uint32_t h = __hip_atomic_load(start + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t h = __hip_atomic_load(start + i, __ATOMIC_RELAXED, kDtScope);
                     const int from = (int)(h >> 16), to = (int)(h & 0xFFFFu);
                     if (h != 0xFFFFFFFFu && from < n && to < n && from != to && from != i && to != i) {
                         mode = 1; q0 = from; iq = from; nn_level = 0;
@@ -808,7 +831,13 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
 #else
 #define DT_SEC(k) do {} while (0)
 #endif
+#ifdef MVOSR_DT_MARKS
+#define DT_MARK(n) asm volatile("; DTMARK " #n ::: "memory")
+#else
+#define DT_MARK(n) do {} while (0)
+#endif
         for (;;) {
+            DT_MARK(loop_top);
             if (i < 0 && !exhausted) {
                 const int idx = atomicAdd(&misc[DM_NEXT], 1);
                 if (idx < n_work) {
@@ -825,7 +854,9 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
             ++n_iter; n_busy += act ? 1 : 0; steps_pt += act ? 1 : 0;
 #endif
             DT_SEC(0);
+            DT_MARK(serve1);
             serve_wide();
+            DT_MARK(edge_ranges);
             DtEdge E;
             if (m1) E.set(p, S[max(iq, 0)], i, iq, sgn); else E.set_nn(p, i);
             // up to five rows of the search's box as ranges of the sorted array, walked as ONE loop (a loop per row would
@@ -870,8 +901,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
 #pragma unroll
             for (int r = 0; r < kDtRows; ++r) {
                 const int y = y_next + r;
-                j0[r] = 0; j1[r] = 0;
-                if (act && y <= box.yb) dt_row_range(G, E, y, box.xa, box.xb, j0[r], j1[r]);
+                dt_row_range_lane(G, E, y, act && y <= box.yb, box.xa, box.xb, j0[r], j1[r]);
             }
             j0[0] = max(j0[0], j_resume);
             int seg = 0;
@@ -887,6 +917,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                     } while (j >= je && seg < kDtRows - 1);
                 };
                 if (j >= je) advance();
+                DT_MARK(scan_loop);
                 while (j < je && budget > 0) {
                     const double2 c = S[j];
                     const int jc = j;
@@ -894,11 +925,13 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                     if (j >= je && seg < kDtRows - 1) advance();
                     dt_step_lane(A, E, m1, jc, c);
                 }
+                DT_MARK(scan_done);
                 if (j < je) { y_next += seg; j_resume = j; }        // out of budget: go on from here in the next iteration
                 else { y_next += kDtRows; j_resume = 0; }
             }
             }
             DT_SEC(2);
+            DT_MARK(completion);
             // (twice: a wide search the first pass raises is scanned by the wavefront at once and completed in the same step)
             for (int rep = 0; rep < 2; ++rep) {
             if (i >= 0 && y_next > box.yb) {                         // the search is finished
@@ -910,6 +943,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
             int state = 0;                                           // 1: finished, 2: hard
             int accept = -1;
             if (!m1) {
+                DT_MARK(c_nn);
                 // the nearest neighbour is a Delaunay neighbour — certified when its disc lies within what was searched
                 q0 = A.b1;
 #ifdef MVOSR_STAMPS
@@ -927,6 +961,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                     else begin_search(all, 1);
                 }
             } else {
+                DT_MARK(c_m1);
                 if (A.flag) degenerate |= DT_WHY_COLLINEAR;
                 const int ic = A.b1;
                 if (wide) {
@@ -950,19 +985,21 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 // on its own (global-memory variant) looks at 17 x 17 cells first
                 else if (!kDtCoop<GLOBAL> && nn_level == 0) { nn_level = 1; begin_search(block_r(p, kDtRWide), 0); }
                 else begin_search(all, 1);
+                DT_MARK(c_accept);
                 if (accept >= 0) {
-                    if (A.tie && dt_confirm_tie(S, G, box, E, A.b1, A.n1, A.c1)) degenerate |= DT_WHY_TIE;
+                    if (A.tie && dt_confirm_tie(S, cs, G.gx, box.xa, box.xb, box.ya, box.yb, E.px, E.py, E.ax, E.ay, E.sgn, E.a2col, E.i, E.iq, A.b1, A.n1, A.c1))
+                        degenerate |= DT_WHY_TIE;
                     if constexpr (kDtHintsOn<GLOBAL>) {
                         if (hints) {
                             // counter-clockwise walk: (p, iq, accept) is the triangle; clockwise: (p, accept, iq)
                             const uint32_t a_ = (uint32_t)(sgn > 0.0 ? iq : accept), c_ = (uint32_t)(sgn > 0.0 ? accept : iq);
                             __hip_atomic_store(hints + (size_t)a_ * kDtHintK + (c_ % kDtHintK), (c_ << 16) | (uint32_t)i,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // in a's star: after c comes p
+                                               __ATOMIC_RELAXED, kDtScope);        // in a's star: after c comes p
                             __hip_atomic_store(hints + (size_t)c_ * kDtHintK + ((uint32_t)i % kDtHintK), ((uint32_t)i << 16) | a_,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // in c's star: after p comes a
+                                               __ATOMIC_RELAXED, kDtScope);        // in c's star: after p comes a
 #if MVOSR_DT_HINT_START
-                            __hip_atomic_store(start + a_, (c_ << 16) | (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(start + c_, ((uint32_t)i << 16) | a_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(start + a_, (c_ << 16) | (uint32_t)i, __ATOMIC_RELAXED, kDtScope);
+                            __hip_atomic_store(start + c_, ((uint32_t)i << 16) | a_, __ATOMIC_RELAXED, kDtScope);
 #endif
                         }
                     }
@@ -970,11 +1007,12 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
 #ifdef MVOSR_STAMPS
                     ++n_by_search;
                     if (hints && sgn > 0.0) {       // did the hint arrive while the search ran?
-                        const uint32_t h_ = __hip_atomic_load(hints + (size_t)i * kDtHintK + ((uint32_t)iq % kDtHintK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t h_ = __hip_atomic_load(hints + (size_t)i * kDtHintK + ((uint32_t)iq % kDtHintK), __ATOMIC_RELAXED, kDtScope);
                         if ((h_ >> 16) == (uint32_t)iq) atomicAdd(&misc[61], 1);
                         else if (h_ != 0xFFFFFFFFu) atomicAdd(&misc[62], 1);      // the slot holds another neighbour's hint
                     }
 #endif
+                    DT_MARK(c_chain);
                     for (;;) {
                         if (++deg > kDtLaneDeg) state = 2;
                         const int oq = oid[iq], oc = oid[accept];
@@ -996,7 +1034,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                         if constexpr (kDtHintsOn<GLOBAL>) {
                             if (hints && sgn > 0.0 && chain < kDtHintChain) {
                                 const uint32_t h = __hip_atomic_load(hints + (size_t)i * kDtHintK + ((uint32_t)iq % kDtHintK),
-                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                                     __ATOMIC_RELAXED, kDtScope);
                                 if ((h >> 16) == (uint32_t)iq && (int)(h & 0xFFFFu) < n) accept = (int)(h & 0xFFFFu);
                             }
                         }
@@ -1017,6 +1055,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 steps_pt = 0;
             }
 #endif
+            DT_MARK(c_state);
             if (state == 1) {
                 const int at = nown ? atomicAdd(&misc[DM_ARENA], nown) : 0;
                 if (at + nown > L.arena_cap) degenerate |= DT_WHY_ROWS;
@@ -1035,8 +1074,10 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 i = -1;
             }
             }
+            DT_MARK(serve2);
             if (rep == 1 || !serve_wide()) break;
             }
+            DT_MARK(loop_end);
             DT_SEC(3);
         }
 #ifdef MVOSR_STAMPS

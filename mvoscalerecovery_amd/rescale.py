@@ -313,6 +313,7 @@ class ScaleEstimator:
     GPU_CHUNK = 8192            # frames per chunk, at most (a call of F frames uses chunks of F/4, 512 at least)
     GPU_RESIDENT = 512          # frames the GPU works on at once (two 8-wavefront workgroups per CU)
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk
+    GPU_RAMP_FRACTIONS = (0.125, 0.2, 0.33, 0.55)   # the short first chunks, as fractions of a full one (scale_calculator.py)
     GPU_PIPELINE = 2            # chunks queued on the device behind the one being collected
     N_HYP = RANSAC_ITERATIONS
 
@@ -499,7 +500,7 @@ class ScaleEstimator:
         if self.triangulation == "gpu":
             C_ = int(min(self.GPU_CHUNK, max(512, -(-F // 4))))
             # short first chunks (C/8, C/4, C/2): the GPU starts after the pack + upload of an eighth of a chunk
-            ramp = [C_ // 8, C_ // 4, C_ // 2] if (C_ >= 2048 and F >= 3 * C_) else []
+            ramp = [int(C_ * x) for x in self.GPU_RAMP_FRACTIONS] if (C_ >= 2048 and F >= 3 * C_) else []
             queue, a = [], 0
             while a < F:
                 b = min(F, a + (ramp[len(bounds)] if len(bounds) < len(ramp) else C_))

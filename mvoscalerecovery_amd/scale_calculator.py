@@ -440,6 +440,9 @@ class ScaleEstimator:
         return raw, status, level, counts, host_errors, S[n - 1]
 
     GPU_RAMP = True                 # short first chunks (see _stream_gpu)
+    GPU_RAMP_FRACTIONS = (0.125, 0.2, 0.33, 0.55)   # their sizes, as fractions of a full chunk: each at most 1.7x the one before,
+                                    # the ratio of the GPU's time per frame to the host's (1/8, 1/4, 1/2 left the GPU waiting for the
+                                    # second and third chunk: 366-392 k frames/s at 2000 features, this ramp 391-396 k)
     GPU_PIPELINE = 2                # chunks queued on the device behind the one being collected (with the short first chunks 1 -> 2 is +3 % at 32 768 frames, +6 % at 16 384; 3: the same)
     GPU_CHUNK = 8192            # frames per chunk of the device-triangulation path, at most (a call of F frames uses chunks of F/4, 512 at least: the pipeline needs a few)
     GPU_RESIDENT = 512          # frames the GPU works on at once (two 8-wavefront workgroups per CU): chunks are multiples of it
@@ -537,7 +540,7 @@ class ScaleEstimator:
         # scale with its points: dense frames travel in smaller chunks)
         # the first chunks are short (C/8, C/4, C/2): the GPU starts after the pack + upload of 1/8 chunk instead of a whole
         # one, and the host, which prepares a frame in less time than the GPU spends on it, is ahead from then on
-        ramp = [C // 8, C // 4, C // 2] if (self.GPU_RAMP and C >= 2048 and F >= 3 * C) else []
+        ramp = [int(C * x) for x in self.GPU_RAMP_FRACTIONS] if (self.GPU_RAMP and C >= 2048 and F >= 3 * C) else []
 
         from .engine import frame_tables
 
