@@ -75,11 +75,6 @@ constexpr int kDtLaneDeg = 24;           // star degree on the lane path
 #define MVOSR_DT_RWIDE 8
 #endif
 constexpr int kDtBudget = MVOSR_DT_BUDGET;   // candidates per lane and scan step
-#ifndef MVOSR_DT_STRAGGLERS
-#define MVOSR_DT_STRAGGLERS 0
-#endif
-constexpr int kDtStragglers = MVOSR_DT_STRAGGLERS;
-constexpr int kDtMinTrips = 12;              // ... but every scanning lane makes that many trips per step at least (progress)
 #ifndef MVOSR_DT_COOP_CELLS
 #define MVOSR_DT_COOP_CELLS 36
 #endif
@@ -126,8 +121,8 @@ struct DtArgs {
 
 #ifdef MVOSR_STAMPS
 static unsigned long long *g_dt_stamps = nullptr;
-#define DT_STAMP(i) do { if (tid == 0 && a.stamps) a.stamps[32 * f + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define DT_NOTE(i, v) do { if (tid == 0 && a.stamps) a.stamps[32 * f + (i)] = (unsigned long long)(v); } while (0)
+#define DT_STAMP(i) do { if (tid == 0 && a.stamps) a.stamps[48 * f + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DT_NOTE(i, v) do { if (tid == 0 && a.stamps) a.stamps[48 * f + (i)] = (unsigned long long)(v); } while (0)
 #else
 #define DT_STAMP(i) do {} while (0)
 #define DT_NOTE(i, v) do {} while (0)
@@ -175,15 +170,6 @@ template <bool GLOBAL> constexpr bool kDtHintsOn = kDtHintK > 0 && (!GLOBAL || M
 #endif
 template <bool GLOBAL> constexpr bool kDtCoop = MVOSR_DT_COOP && (!GLOBAL || MVOSR_DT_GLOBAL_COOP);    // (frames in global memory: 26 k -> 19 k sets/s with it at 20 000 points)   // hinted triangles taken in a row before the lane goes back to searching
 
-#ifndef MVOSR_DT_LDSWALK
-#define MVOSR_DT_LDSWALK 0
-#endif
-// The lane pass's walk over the (up to five) cell rows of a scan step: 1 = the non-empty rows' ranges are packed into one
-// word each (start | end << 13 | row << 26) in a per-lane LDS slot, the walk keeps the current and the next range in two
-// registers and fetches the one after when it moves on (LDS variant only: 13-bit indices); 0 = all ranges in registers,
-// shifted down at every row change (17-40 v_mov whenever ANY lane of the wavefront ends a row).
-constexpr bool kDtLdsWalk = MVOSR_DT_LDSWALK != 0;
-
 struct DtPlan { uint32_t S, oid, od, astart, cs, arena, big, hard, wrows, red, misc, aff, total; int max_cells, arena_cap; };
 constexpr int kDtMaxCellsGlobal = 32768;
 constexpr int kDtMaxPointsGlobal = 32000;      // (row arena indices and point ids are 16-bit)
@@ -206,11 +192,10 @@ __host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false, int 
     p.arena = p.cs + 4u * (uint32_t)(p.max_cells + 8);   // u32 rows (b << 16 | c) in the order they were found
     p.big = (p.arena + 4u * (uint32_t)p.arena_cap + 255u) & ~255u;
     p.hard = p.big;                                      // u16 sorted indices
-    p.wrows = p.hard + 2u * kDtHardCap;                  // u32 [groups of 16 lanes][kDtWaveRows] (phase 2); phase 1: the lanes' row ranges [row][lane]
+    p.wrows = p.hard + 2u * kDtHardCap;                  // u32 [groups of 16 lanes][kDtWaveRows] (phase 2)
     {
         const uint32_t rows2 = 4u * (uint32_t)(waves * kWave / 16) * kDtWaveRows;
-        const uint32_t walk = (kDtLdsWalk && !global) ? 4u * (uint32_t)(waves * kWave) * (uint32_t)(2 * MVOSR_DT_R + 1) : 0u;
-        p.red = p.wrows + (rows2 > walk ? rows2 : walk);  // doubles: block reductions
+        p.red = p.wrows + rows2;                          // doubles: block reductions
     }
     p.misc = p.red + 8u * 4u * (uint32_t)waves;
     p.aff = p.misc + 4u * 64u;                           // u8 per sorted index (LDS variant): the star has to be built (see seed_info)
@@ -503,7 +488,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
         if (lane == 0) { red[4 * w] = a0; red[4 * w + 1] = a1; red[4 * w + 2] = a2; red[4 * w + 3] = a3; misc[DM_WCNT + w] = wcnt; }
         if (tid < 8) misc[tid] = tid == DM_NEXT ? BLOCK : 0;
 #ifdef MVOSR_STAMPS
-        if (tid >= 40 && tid < 64) misc[tid] = 0;
+        if ((tid >= 40 && tid < 64) || (tid >= 24 && tid < 40)) misc[tid] = 0;    // (24..39: scratch of the last stage, free until then)
 #endif
     }
     __syncthreads();
@@ -826,7 +811,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
             return any;
         };
 #ifdef MVOSR_STAMPS
-        unsigned long long t_sec[4] = {0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();      // take a point / ranges / scan / completion
+        unsigned long long t_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();      // take a point / ranges / scan / completion
 #define DT_SEC(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); t_sec[k] += now_ - t_last; t_last = now_; } while (0)
 #else
 #define DT_SEC(k) do {} while (0)
@@ -856,81 +841,56 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
             DT_SEC(0);
             DT_MARK(serve1);
             serve_wide();
+            DT_SEC(1);
             DT_MARK(edge_ranges);
             DtEdge E;
             if (m1) E.set(p, S[max(iq, 0)], i, iq, sgn); else E.set_nn(p, i);
             // up to five rows of the search's box as ranges of the sorted array, walked as ONE loop (a loop per row would
             // run for the longest row of any lane, five times over)
             int budget = kDtBudget;
-            if constexpr (kDtLdsWalk && !GLOBAL) {
-                uint32_t *wr = reinterpret_cast<uint32_t *>(small + L.wrows) + tid;      // this lane's slot: wr[k * BLOCK]
-                int nseg = 0;
+            {
+                // the rows' ranges, one word each (start | end << 16: at most 32 000 points), the non-empty ones first: when a
+                // lane's row ends, the walk takes the next word and shifts the rest down — 5 moves.  (Ten registers of starts and
+                // ends, shifted in a loop that skipped the empty rows, were 17-40 moves in nested branches whenever ANY lane of the
+                // wavefront ended a row: every trip, as good as.)
+                uint32_t sg[kDtRows];
 #pragma unroll
                 for (int r = 0; r < kDtRows; ++r) {
                     const int y = y_next + r;
-                    int a0 = 0, a1 = 0;
-                    if (act && y <= box.yb) dt_row_range(G, E, y, box.xa, box.xb, a0, a1);
-                    if (r == 0) a0 = max(a0, j_resume);
-                    if (a0 < a1) { wr[nseg * BLOCK] = (uint32_t)a0 | ((uint32_t)a1 << 13) | ((uint32_t)r << 26); ++nseg; }
+                    int b_, e_;
+                    dt_row_range_lane(G, E, y, act && y <= box.yb, box.xa, box.xb, b_, e_);
+                    if (r == 0) b_ = max(b_, j_resume);
+                    sg[r] = b_ < e_ ? ((uint32_t)b_ | ((uint32_t)e_ << 16)) : 0u;
                 }
-                uint32_t cur = nseg > 0 ? wr[0] : 0u, nxt = nseg > 1 ? wr[BLOCK] : 0u;
-                int seg = 0;
-                int j = (int)(cur & 0x1FFFu), je = (int)((cur >> 13) & 0x1FFFu);
-                // (the step ends for everybody once no more than kDtStragglers lanes are still scanning: they go on in the next
-                // step — as a lane out of budget does — instead of holding the other lanes' completions back)
-                while (j < je && budget > 0) {
-                    if (kDtStragglers > 0 && budget <= kDtBudget - kDtMinTrips && __popcll(__ballot(true)) <= kDtStragglers) break;
-                    const double2 c = S[j];
-                    const int jc = j;
-                    ++j; --budget;
-                    if (j >= je) {                                   // this row is done: the next non-empty one (or none: 0 | 0)
-                        cur = nxt; ++seg;
-                        j = (int)(cur & 0x1FFFu); je = (int)((cur >> 13) & 0x1FFFu);
-                        nxt = seg + 1 < nseg ? wr[(seg + 1) * BLOCK] : 0u;
+#pragma unroll
+                for (int pass = 0; pass < kDtRows - 1; ++pass)
+#pragma unroll
+                    for (int r = 0; r < kDtRows - 1 - pass; ++r) {
+                        const bool z = sg[r] == 0u;
+                        sg[r] = z ? sg[r + 1] : sg[r]; sg[r + 1] = z ? 0u : sg[r + 1];
                     }
-                    dt_step_lane(A, E, m1, jc, c);
-                }
-                if (j < je) { y_next += (int)(cur >> 26); j_resume = j; }    // out of budget: go on from here in the next iteration
-                else { y_next += kDtRows; j_resume = 0; }
-#ifdef MVOSR_STAMPS
-                { const int t_ = wave_max(kDtBudget - budget); if (lane == 0) { atomicAdd(&misc[40], t_); atomicAdd(&misc[44], 1); }
-                  atomicAdd(&misc[45], kDtBudget - budget); }
-#endif
-            } else {
-            int j0[kDtRows], j1[kDtRows];
-#pragma unroll
-            for (int r = 0; r < kDtRows; ++r) {
-                const int y = y_next + r;
-                dt_row_range_lane(G, E, y, act && y <= box.yb, box.xa, box.xb, j0[r], j1[r]);
-            }
-            j0[0] = max(j0[0], j_resume);
-            int seg = 0;
-            {
-                int j = j0[0], je = j1[0];
-                auto advance = [&]() {
-                    do {
-                        j = j0[1]; je = j1[1];
-#pragma unroll
-                        for (int r = 1; r < kDtRows - 1; ++r) { j0[r] = j0[r + 1]; j1[r] = j1[r + 1]; }
-                        j0[kDtRows - 1] = 0; j1[kDtRows - 1] = 0;
-                        ++seg;
-                    } while (j >= je && seg < kDtRows - 1);
-                };
-                if (j >= je) advance();
+                int j = (int)(sg[0] & 0xFFFFu), je = (int)(sg[0] >> 16);
+                DT_SEC(2);
                 DT_MARK(scan_loop);
                 while (j < je && budget > 0) {
                     const double2 c = S[j];
                     const int jc = j;
                     ++j; --budget;
-                    if (j >= je && seg < kDtRows - 1) advance();
+                    if (j >= je) {
+                        const uint32_t nx = sg[1];
+#pragma unroll
+                        for (int r = 1; r < kDtRows - 1; ++r) sg[r] = sg[r + 1];
+                        sg[kDtRows - 1] = 0u;
+                        j = (int)(nx & 0xFFFFu); je = (int)(nx >> 16);
+                    }
                     dt_step_lane(A, E, m1, jc, c);
                 }
                 DT_MARK(scan_done);
-                if (j < je) { y_next += seg; j_resume = j; }        // out of budget: go on from here in the next iteration
+                // out of budget: the next step goes on from candidate j, in the cell row it lies in
+                if (j < je) { y_next = G.celly(S[j].y); j_resume = j; }
                 else { y_next += kDtRows; j_resume = 0; }
             }
-            }
-            DT_SEC(2);
+            DT_SEC(3);
             DT_MARK(completion);
             // (twice: a wide search the first pass raises is scanned by the wavefront at once and completed in the same step)
             for (int rep = 0; rep < 2; ++rep) {
@@ -985,6 +945,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 // on its own (global-memory variant) looks at 17 x 17 cells first
                 else if (!kDtCoop<GLOBAL> && nn_level == 0) { nn_level = 1; begin_search(block_r(p, kDtRWide), 0); }
                 else begin_search(all, 1);
+                DT_SEC(4);
                 DT_MARK(c_accept);
                 if (accept >= 0) {
                     if (A.tie && dt_confirm_tie(S, cs, G.gx, box.xa, box.xb, box.ya, box.yb, E.px, E.py, E.ax, E.ay, E.sgn, E.a2col, E.i, E.iq, A.b1, A.n1, A.c1))
@@ -1055,6 +1016,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 steps_pt = 0;
             }
 #endif
+            DT_SEC(5);
             DT_MARK(c_state);
             if (state == 1) {
                 const int at = nown ? atomicAdd(&misc[DM_ARENA], nown) : 0;
@@ -1074,14 +1036,15 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 i = -1;
             }
             }
+            DT_SEC(6);
             DT_MARK(serve2);
             if (rep == 1 || !serve_wide()) break;
             }
             DT_MARK(loop_end);
-            DT_SEC(3);
+            DT_SEC(7);
         }
 #ifdef MVOSR_STAMPS
-        if (lane == 0) { atomicAdd(&misc[46], (int)(t_sec[2] >> 4)); atomicAdd(&misc[47], (int)(t_sec[3] >> 4)); }   // (sixteenths of a cycle count: 32-bit sums)
+        if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&misc[24 + k], (int)(t_sec[k] >> 4));   // (sixteenths of a cycle count: 32-bit sums)
         atomicAdd(&misc[48], n_by_search); atomicAdd(&misc[49], n_by_hint); atomicAdd(&misc[50], n_iter); atomicAdd(&misc[51], n_busy);
 #endif
     }
@@ -1090,9 +1053,9 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
 #ifdef MVOSR_STAMPS
     DT_NOTE(10, misc[48]); DT_NOTE(11, misc[49]); DT_NOTE(12, misc[50]); DT_NOTE(13, misc[51]);
     DT_NOTE(26, misc[61]); DT_NOTE(27, misc[62]); DT_NOTE(28, misc[63]);
-    DT_NOTE(15, misc[46]); DT_NOTE(25, misc[47]);
+    if (tid == 0 && a.stamps) for (int k = 0; k < 8; ++k) a.stamps[48 * f + 32 + k] = (unsigned long long)misc[24 + k];
     DT_NOTE(29, misc[40]); DT_NOTE(30, misc[41]); DT_NOTE(31, misc[42]); DT_NOTE(7, misc[43]); DT_NOTE(8, misc[44]); DT_NOTE(14, misc[45]);
-    if (tid == 0 && a.stamps) for (int k = 52; k < 61; ++k) a.stamps[32 * f + 16 + (k - 52)] = (unsigned long long)misc[k];
+    if (tid == 0 && a.stamps) for (int k = 52; k < 61; ++k) a.stamps[48 * f + 16 + (k - 52)] = (unsigned long long)misc[k];
 #endif
 
     // The two passes below work in GROUPS of 16 lanes (a DPP row): a completion has a few dozen candidates at most, so

@@ -22,7 +22,7 @@ d_u, d_v = ctx.to_device(np.ascontiguousarray(uv[:, 0])), ctx.to_device(np.ascon
 d_off, d_cnt, d_toff = ctx.to_device(off), ctx.to_device(cnt), ctx.to_device(2 * off)
 d_tri = ctx.empty((2 * F * n, 3), np.int32)
 d_tcnt, d_st, d_used = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
-d_stamps = ctx.zeros((F, 32), np.uint64)
+d_stamps = ctx.zeros((F, 48), np.uint64)
 ctx.lib.mvosr_debug_dt_stamps.argtypes = [C.c_void_p]
 ctx.lib.mvosr_debug_dt_stamps(d_stamps.ptr)
 d_info = ctx.zeros(F * n, np.uint32)
@@ -61,6 +61,9 @@ print("  scan steps per lane: %.1f   lanes with a point in a step: %.1f %%" % (n
 print("  searches whose hint had arrived by the time they finished: %.0f per set; whose slot held another neighbour's hint: %.0f; nearest-neighbour searches completed: %.0f" % (np.mean(s[:, 26]), np.mean(s[:, 27]), np.mean(s[:, 28])))
 print("  wave-level candidate trips per set: lane pass %.0f (in %.0f wave-steps, %.0f lane-candidates), shared wide scans %.0f (in %.0f scans, %.0f row passes)" % (
     np.mean(s[:, 29]), np.mean(s[:, 8]), np.mean(s[:, 14]), np.mean(s[:, 30]), np.mean(s[:, 31]), np.mean(s[:, 7])))
-print("  phase 1 by section, summed over the 8 wavefronts (share of 8 x phase-1 cycles): ranges + scans (incl. shared wide scans) %.1f %%, completions %.1f %%, rest (taking points, idle at the tail) %.1f %%" % (
-    100 * 16 * np.mean(s[:, 15]) / (8 * np.mean(d[:, 2])), 100 * 16 * np.mean(s[:, 25]) / (8 * np.mean(d[:, 2])),
-    100 - 100 * 16 * (np.mean(s[:, 15]) + np.mean(s[:, 25])) / (8 * np.mean(d[:, 2]))))
+SEC = ["take a point", "shared wide scans (before the step)", "edge + row ranges", "scan loop", "search finished: nearest neighbour / circle box / widen", "hints out + chain of hinted triangles",
+       "star finished: rows to the arena", "shared wide scans (after) + loop end"]
+tot1 = 8 * np.mean(d[:, 2])
+print("  phase 1 by section, summed over the 8 wavefronts (share of 8 x phase-1 cycles):")
+for k, name in enumerate(SEC):
+    print("    %-58s %5.1f %%" % (name, 100 * 16 * np.mean(s[:, 32 + k]) / tot1))
