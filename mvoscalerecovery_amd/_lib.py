@@ -374,6 +374,19 @@ class DeviceBlock:
         stage.free(MARK_UPLOAD)
         return self
 
+    def commit_ranges(self, stage, ranges, last=False):
+        """Parts of a staging image, as they become ready: ``ranges`` = (offset, bytes) within the block, one asynchronous
+        copy each on the upload stream.  ``last``: the compute stream waits for everything uploaded so far and the staging
+        buffer goes back to the cache."""
+        ctx = self.ctx
+        for off, nb in ranges:
+            if nb > 0:
+                check(ctx.lib.mvosr_memcpy_h2d_async(ctx.handle, self.ptr + int(off), stage.ptr + int(off), int(nb)), "h2d_async")
+        if last:
+            check(ctx.lib.mvosr_upload_fence(ctx.handle), "upload_fence")
+            stage.free(MARK_UPLOAD)
+        return self
+
     def zero(self):
         check(self.ctx.lib.mvosr_memset(self.ctx.handle, self.ptr, 0, self.nbytes), "memset")
         return self

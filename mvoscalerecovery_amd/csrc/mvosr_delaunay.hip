@@ -886,6 +886,12 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                     dt_step_lane(A, E, m1, jc, c);
                 }
                 DT_MARK(scan_done);
+#ifdef MVOSR_STAMPS
+                { const int t_ = wave_max(kDtBudget - budget); if (lane == 0) { atomicAdd(&misc[40], t_); atomicAdd(&misc[44], 1); }
+                  atomicAdd(&misc[45], kDtBudget - budget);
+                  if (lane == 0) atomicAdd(&misc[36 + min(t_ / 12, 3)], 1);
+                  atomicAdd(&misc[32 + (kDtBudget - budget == 0 ? 0 : min((kDtBudget - budget + 11) / 12, 3))], 1); }
+#endif
                 // out of budget: the next step goes on from candidate j, in the cell row it lies in
                 if (j < je) { y_next = G.celly(S[j].y); j_resume = j; }
                 else { y_next += kDtRows; j_resume = 0; }
@@ -1053,7 +1059,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
 #ifdef MVOSR_STAMPS
     DT_NOTE(10, misc[48]); DT_NOTE(11, misc[49]); DT_NOTE(12, misc[50]); DT_NOTE(13, misc[51]);
     DT_NOTE(26, misc[61]); DT_NOTE(27, misc[62]); DT_NOTE(28, misc[63]);
-    if (tid == 0 && a.stamps) for (int k = 0; k < 8; ++k) a.stamps[48 * f + 32 + k] = (unsigned long long)misc[24 + k];
+    if (tid == 0 && a.stamps) for (int k = 0; k < 16; ++k) a.stamps[48 * f + 32 + k] = (unsigned long long)misc[24 + k];
     DT_NOTE(29, misc[40]); DT_NOTE(30, misc[41]); DT_NOTE(31, misc[42]); DT_NOTE(7, misc[43]); DT_NOTE(8, misc[44]); DT_NOTE(14, misc[45]);
     if (tid == 0 && a.stamps) for (int k = 52; k < 61; ++k) a.stamps[48 * f + 16 + (k - 52)] = (unsigned long long)misc[k];
 #endif

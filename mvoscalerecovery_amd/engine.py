@@ -66,6 +66,10 @@ def frame_tables(feature3ds, feature2ds, remap_in_place=False):
     return tables
 
 
+UPLOAD_PIECES = 4              # pieces a chunk's upload is cut into (pack_upload_native) ...
+UPLOAD_PIECE_FRAMES = 256      # ... of at least that many frames
+
+
 def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=0, tables=None):
     """The batch path's front end without a Python loop over the frames' CONTENTS: the C packer (mvosr_pack_count /
     mvosr_pack_fill, a few host threads) applies the vanishing-row filter (/root/reference/src/scale_calculator.py:252-254)
@@ -95,14 +99,28 @@ def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=
     cnt_view = sv("feat_cnt")
     base = stage.ptr
     c, s_ = (remap if remap is not None else (1.0, 0.0))
-    _lib.check(lib.mvosr_pack_fill(F, _lib.addr(p3), _lib.addr(p2), _lib.addr(npts), float(vanish), _lib.addr(off),
-                                   base + blk["x"].offset, base + blk["y"].offset, base + blk["z"].offset, base + blk["u"].offset,
-                                   base + blk["v"].offset, 1 if remap is not None else 0, float(c), float(s_), int(threads),
-                                   _lib.addr(cnt_view)),
-               "mvosr_pack_fill")
+    # A chunk is packed and uploaded in up to four pieces: the copy of a piece's planes runs while the packer fills the next
+    # piece, so the chunk's kernels wait for the LAST piece's copy only (one copy after the whole pack: 4.9 ms of packing, then
+    # 6.5 ms of PCIe per 4608 frames of 2000 features before the first kernel — it is the first chunks of a call that pay for that)
+    n_pieces = max(1, min(UPLOAD_PIECES, F // UPLOAD_PIECE_FRAMES))
+    edges = [F * k // n_pieces for k in range(n_pieces + 1)]
+    a3, a2, an, ao, ac = _lib.addr(p3), _lib.addr(p2), _lib.addr(npts), _lib.addr(off), _lib.addr(cnt_view)
+    for a, b in zip(edges[:-1], edges[1:]):
+        _lib.check(lib.mvosr_pack_fill(b - a, a3 + 8 * a, a2 + 8 * a, an + 4 * a, float(vanish), ao + 8 * a,
+                                       base + blk["x"].offset, base + blk["y"].offset, base + blk["z"].offset, base + blk["u"].offset,
+                                       base + blk["v"].offset, 1 if remap is not None else 0, float(c), float(s_), int(threads),
+                                       ac + 4 * a),
+                   "mvosr_pack_fill")
+        if n_pieces > 1:
+            lo, hi = int(off[a]), (int(off[b]) if b < F else int(total))
+            blk.commit_ranges(stage, [(blk[k].offset + 8 * lo, 8 * (hi - lo)) for k in ("x", "y", "z", "v", "u")])
     cnt = np.array(cnt_view, dtype=np.int32, copy=True)
     sv("exact_mask")[:] = exact_mask_of(cnt)
-    blk.commit(stage)
+    if n_pieces > 1:
+        head, tail = blk["feat_off"].offset, blk["tri_off"].offset
+        blk.commit_ranges(stage, [(head, blk["x"].offset - head), (tail, blk.nbytes - tail)], last=True)
+    else:
+        blk.commit(stage)
     pf = PackedFrames(F, off, cnt, None, None, None, None, None, [None] * F, max_feat=int(cnt.max()) if F else 0)
     pf.extra["total_padded"] = total
     return pf, blk

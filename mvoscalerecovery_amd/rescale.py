@@ -36,6 +36,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import random
+import time
 from collections import deque
 
 import numpy as np
@@ -364,11 +365,13 @@ class ScaleEstimator:
             tables = frame_tables(f3s, f2s) if len(f3s) else None
         if tables is not None:
             pf, blk = pack_upload_native(ctx, f3s, f2s, self.vanish, None, tables=tables)             # rescale.py:115-117
+            if getattr(self, "chunk_trace", None) is not None: self.chunk_trace.append(("packed", -1, len(f3s), time.perf_counter()))
             too_large = pf.max_feat > self._max_points()
             if too_large:
                 blk.free()
                 return {"gpu": False}
             db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk)
+            if getattr(self, "chunk_trace", None) is not None: self.chunk_trace.append(("blocks", -1, len(f3s), time.perf_counter()))
         else:
             pf = packing.pack_features(f3s, f2s, self.vanish)
             if pf.max_feat > self._max_points() or pf.n_frames == 0:
@@ -502,6 +505,11 @@ class ScaleEstimator:
             # short first chunks (C/8, C/4, C/2): the GPU starts after the pack + upload of an eighth of a chunk
             ramp = [int(C_ * x) for x in self.GPU_RAMP_FRACTIONS] if (C_ >= 2048 and F >= 3 * C_) else []
             queue, a = [], 0
+            # MVOSR_TRACE_CHUNKS=1: when this process started and finished each chunk's pack + launches and each collection
+            # (self.chunk_trace: (what, chunk, frames, seconds since the call began))
+            trace = [] if os.environ.get("MVOSR_TRACE_CHUNKS") else None
+            t_call = time.perf_counter()
+            self.chunk_trace = trace
             while a < F:
                 b = min(F, a + (ramp[len(bounds)] if len(bounds) < len(ramp) else C_))
                 tb = frame_tables(feature3ds[a:b], feature2ds[a:b])          # (sizes from the packer's pointer tables: one C loop)
@@ -512,11 +520,14 @@ class ScaleEstimator:
                 if b < F and b - a >= 2 * self.GPU_RESIDENT:           # whole rounds of the GPU's resident frames: no partly filled last round
                     b = a + ((b - a) // self.GPU_RESIDENT) * self.GPU_RESIDENT
                 tr = None if id_triples is None else id_triples[a:b]
+                if trace is not None: trace.append(("launch", len(bounds), b - a, time.perf_counter() - t_call))
                 queue.append((self._chunk_dev_gpu(feature3ds[a:b], feature2ds[a:b], base + a, tr, stage,
                                                   tables=(tuple(t[:b - a] for t in tb) if tb is not None else None)), a, b))
                 bounds.append((a, b))
+                if trace is not None: trace.append(("launched", len(bounds) - 1, b - a, time.perf_counter() - t_call))
                 while len(queue) > self.GPU_PIPELINE:
                     st, pa, pb = queue.pop(0)
+                    if trace is not None: trace.append(("collect", len(results), pb - pa, time.perf_counter() - t_call))
                     results.append(self._chunk_dev_finish(st, feature3ds[pa:pb], feature2ds[pa:pb], base + pa,
                                                           None if id_triples is None else id_triples[pa:pb], stage))
                 a = b

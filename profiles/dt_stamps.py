@@ -67,3 +67,5 @@ tot1 = 8 * np.mean(d[:, 2])
 print("  phase 1 by section, summed over the 8 wavefronts (share of 8 x phase-1 cycles):")
 for k, name in enumerate(SEC):
     print("    %-58s %5.1f %%" % (name, 100 * 16 * np.mean(s[:, 32 + k]) / tot1))
+print("  lane-pass scan steps by the wavefront's trips (0-11 / 12-23 / 24-35 / 36+): %s;  lanes by their own trips (0 / 1-12 / 13-24 / 25+): %s" % (
+    " / ".join("%.0f" % np.mean(s[:, 44 + k]) for k in range(4)), " / ".join("%.0f" % np.mean(s[:, 40 + k]) for k in range(4))))

@@ -107,6 +107,73 @@ def test_c_packer_equals_python_packer():
     assert not packing.native_packable([ro], [f2s[0]], writable=True) and packing.native_packable([ro], [f2s[0]])
 
 
+def test_c_packer_wide_path_and_thread_pool():
+    """The packer without the in-place remap takes eight features per step where the CPU has AVX-512 (and the same scalar loop
+    where not): every size 0..40 and a ragged batch, rows at / above / below the vanishing row, NaN and infinite pixel rows
+    (`>` is false for NaN, as in NumPy), against packing.pack_features bit for bit; many calls in a row and calls from two
+    threads at once through the library's thread pool."""
+    import threading
+    from mvoscalerecovery_amd import _lib, engine, packing
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    sizes = list(range(0, 41)) + [int(v) for v in rng.integers(41, 3000, 30)]
+    f3s = [np.ascontiguousarray(rng.normal(size=(n, 3))) for n in sizes]
+    f2s = []
+    for n in sizes:
+        a = np.ascontiguousarray(rng.uniform(100, 300, size=(n, 2)))
+        if n:
+            a[rng.integers(0, n, max(1, n // 7)), 1] = 185.0               # exactly at the vanishing row: dropped
+            a[rng.integers(0, n, max(1, n // 9)), 1] = np.nan
+            a[rng.integers(0, n, max(1, n // 11)), 1] = np.inf
+            a[rng.integers(0, n, max(1, n // 13)), 1] = -np.inf
+        f2s.append(a)
+    keep3 = [a.copy() for a in f3s]
+    ref = packing.pack_features(f3s, f2s, 185)
+    p3, p2, npts = engine.frame_tables(f3s, f2s)
+    F = len(sizes)
+    off, total = packing.pack_layout(npts)
+
+    def one(threads):
+        planes = {k: np.full(total + 8, -7.0) for k in "xyzuv"}
+        cnt = np.zeros(F, np.int32)
+        assert lib.mvosr_pack_fill(F, p3.ctypes.data, p2.ctypes.data, npts.ctypes.data, 185.0, off.ctypes.data,
+                                   planes["x"].ctypes.data, planes["y"].ctypes.data, planes["z"].ctypes.data, planes["u"].ctypes.data,
+                                   planes["v"].ctypes.data, 0, 1.0, 0.0, threads, cnt.ctypes.data) == 0
+        assert np.array_equal(cnt, ref.feat_cnt)
+        for f in range(F):
+            n, a, b = int(cnt[f]), int(off[f]), ref.frame_slice(f)
+            for k in "xyzuv":
+                assert np.array_equal(planes[k][a:a + n], getattr(ref, k)[b], equal_nan=True), (f, k)
+        for k in "xyzuv":
+            assert np.all(planes[k][total:] == -7.0)             # nothing past the last frame's slot
+
+    for threads in (1, 2, 5, 16, 0):
+        one(threads)
+    for _ in range(20):
+        one(4)
+    errs = []
+    def hammer():
+        try:
+            for _ in range(10):
+                one(3)
+        except BaseException as e:                               # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=hammer) for _ in range(3)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    assert all(np.array_equal(a, b) for a, b in zip(f3s, keep3))  # (no remap: the caller's arrays are untouched)
+    # a forked child has none of the pool's threads: the library starts a pool of its own there
+    import os
+    pid = os.fork()
+    if pid == 0:
+        try:
+            one(4)
+            os._exit(0)
+        except BaseException:                                    # noqa: BLE001
+            os._exit(1)
+    assert os.waitpid(pid, 0)[1] == 0
+
+
 def test_slew_median_host_equals_the_references_recurrence():
     """mvosr_slew_median_host (no GPU): the slew limiter and window median of /root/reference/src/rescale.py:169-178 written
     out in Python — jumps beyond +-0.3, frames without a plane, a NaN scale that sticks, a carried-in queue."""
