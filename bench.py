@@ -405,7 +405,7 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames):
                     "bit-equal to the fixed-mode oracle"}
 
 
-def latency_leg(args, device, sizes, seed, frames=40):
+def latency_leg(args, device, sizes, seed, frames=100):
     """Per-frame latency of the drop-in call in the reference's loop shape (/root/reference/src/main.py:110-113): one
     scale_calculation per frame — with SciPy's triangulations (the default, bit-exact path) and with the device's."""
     from mvoscalerecovery_amd import synth

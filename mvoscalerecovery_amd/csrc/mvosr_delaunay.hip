@@ -872,6 +872,7 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 int j = (int)(sg[0] & 0xFFFFu), je = (int)(sg[0] >> 16);
                 DT_SEC(2);
                 DT_MARK(scan_loop);
+#pragma unroll 2
                 while (j < je && budget > 0) {
                     const double2 c = S[j];
                     const int jc = j;
@@ -980,37 +981,46 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                     }
 #endif
                     DT_MARK(c_chain);
+                    // The chain as a loop of the whole (sub-)wavefront: it runs while ANY lane is still taking hinted triangles and
+                    // every lane makes every round, a lane that is out making it without effect — its state is updated by
+                    // selects, and what it inserts into its sorted rows is all ones, which changes nothing.  (As a loop that
+                    // each lane left on its own, the rows of the lanes that had left were kept in a second set of registers and
+                    // copied back every round: 12 moves, and 18 selects for the search the leaving lanes begin.)
+                    bool search_on = false, in_chain = true;
                     for (;;) {
-                        if (++deg > kDtLaneDeg) state = 2;
-                        const int oq = oid[iq], oc = oid[accept];
-                        if (oi < oq && oi < oc) {
-                            if (nown == kDtLaneRows) state = 2;
-                            else {
-                                uint32_t key = ((uint32_t)min(oq, oc) << 16) | (uint32_t)max(oq, oc);
+                        deg += in_chain ? 1 : 0;
+                        if (in_chain && deg > kDtLaneDeg) state = 2;
+                        const int oq = oid[iq], oc = oid[max(accept, 0)];
+                        const bool own = in_chain && oi < oq && oi < oc;
+                        if (own && nown == kDtLaneRows) state = 2;
+                        const bool put = own && nown < kDtLaneRows;
+                        uint32_t key = put ? (((uint32_t)min(oq, oc) << 16) | (uint32_t)max(oq, oc)) : 0xFFFFFFFFu;
 #pragma unroll
-                                for (int k = 0; k < kDtLaneRows; ++k) { const uint32_t lo = min(key, rows[k]), hi = max(key, rows[k]); rows[k] = lo; key = hi; }
-                                ++nown;
-                            }
-                        }
-                        iq = accept;
-                        nn_level = 0;
-                        if (state != 0) break;
-                        if (sgn > 0.0 && iq == q0) { state = 1; break; }      // closed
+                        for (int k = 0; k < kDtLaneRows; ++k) { const uint32_t hi = max(key, rows[k]); rows[k] = min(key, rows[k]); key = hi; }
+                        nown += put ? 1 : 0;
+                        iq = in_chain ? accept : iq;
+                        bool go = in_chain && state == 0;
+                        if (go && sgn > 0.0 && iq == q0) { state = 1; go = false; }      // closed
                         // the next edge of the star: already known from a neighbour's star?
-                        accept = -1;
+                        int nxt = -1;
                         if constexpr (kDtHintsOn<GLOBAL>) {
-                            if (hints && sgn > 0.0 && chain < kDtHintChain) {
+                            if (go && hints && sgn > 0.0 && chain < kDtHintChain) {
                                 const uint32_t h = __hip_atomic_load(hints + (size_t)i * kDtHintK + ((uint32_t)iq % kDtHintK),
                                                                      __ATOMIC_RELAXED, kDtScope);
-                                if ((h >> 16) == (uint32_t)iq && (int)(h & 0xFFFFu) < n) accept = (int)(h & 0xFFFFu);
+                                if ((h >> 16) == (uint32_t)iq && (int)(h & 0xFFFFu) < n) nxt = (int)(h & 0xFFFFu);
                             }
                         }
-                        if (accept < 0) { begin_search(blk, 0); break; }
-                        ++chain;
+                        search_on = search_on || (go && nxt < 0);
+                        in_chain = go && nxt >= 0;
+                        accept = in_chain ? nxt : accept;
+                        chain += in_chain ? 1 : 0;
 #ifdef MVOSR_STAMPS
-                        ++n_by_hint;
+                        n_by_hint += in_chain ? 1 : 0;
 #endif
+                        if (__ballot(in_chain) == 0ull) break;
                     }
+                    nn_level = 0;
+                    if (search_on) begin_search(blk, 0);               // (once, after the chain: inside the loop every lane paid for it in every round)
                 }
             }
 #ifdef MVOSR_STAMPS
