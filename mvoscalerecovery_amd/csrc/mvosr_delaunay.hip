@@ -779,6 +779,18 @@ __global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs 
                 E2.set(S[bi], S[biq], bi, biq, bneg ? -1.0 : 1.0);
                 DtAcc A2;
                 A2.reset();
+                // The rows that can hold a point on the wanted side at all: sax (v - py) > say (X - px) for some X within the box's
+                // columns is a half-line in v.  The whole-frame searches beside hull edges — two per hull vertex, a quarter of all
+                // shared scans and, at ten row passes each, most of their row passes — look at the two or three rows along the
+                // edge instead of all of them (a row more on either side: points on the line itself must be seen, they decline
+                // the frame).
+                if (E2.sax != 0.0) {
+                    const double X0 = G.lo_u + ((double)bb.xa - 1e-6) * G.sx, X1 = G.lo_u + ((double)(bb.xb + 1) + 1e-6) * G.sx;
+                    const double w_ = fmin(E2.say * (X0 - E2.px), E2.say * (X1 - E2.px));
+                    const int yc = G.celly(E2.py + w_ / E2.sax);
+                    if (E2.sax > 0.0) bb.ya = max(bb.ya, __builtin_amdgcn_readfirstlane(yc) - 1);
+                    else bb.yb = min(bb.yb, __builtin_amdgcn_readfirstlane(yc) + 1);
+                }
                 // kDtServeRows cell rows at a time, 64 / kDtServeRows lanes each: a wide box is many rows of a dozen candidates,
                 // and a row's range costs as much as its candidates (one row at a time with all 64 lanes: 648 k sets/s at
                 // 2000 points; four: 741 k)
