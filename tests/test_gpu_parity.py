@@ -823,6 +823,46 @@ def test_triangulation_gpu_fixed_seq4541_and_fuzz(gpu):
     assert declined > 0                                                  # the fallback was exercised
 
 
+def test_piecewise_upload_equals_one_copy(gpu):
+    """engine.pack_upload_native packs and uploads a chunk in up to four pieces (the copy of a piece under the pack of the
+    next): 1 300 ragged frames — with frames that keep nothing below the vanishing row, and one-feature frames, at piece
+    borders — through both estimators with the device triangulation, pieces 4 and 8 against ONE copy after the whole pack: every
+    scale bit-equal; the packer's thread pool at 1, 3 and 16 threads."""
+    from mvoscalerecovery_amd import engine, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    from mvoscalerecovery_amd.rescale import ScaleEstimator as RescaleEstimator
+    rng = np.random.default_rng(77)
+    F = 1300
+    frames = [synth.synth_frame(7000 + i, int(rng.integers(40, 900)), base_seed=5, upper_fraction=0.15) for i in range(F)]
+    f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
+    keep = engine.UPLOAD_PIECES, engine.UPLOAD_PIECE_FRAMES
+    out = {}
+    try:
+        for pieces in (1, 4, 8):
+            engine.UPLOAD_PIECES, engine.UPLOAD_PIECE_FRAMES = pieces, 128
+            a = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
+            b = RescaleEstimator(1.75, window_size=5, triangulation="gpu", delaunay_workers=0, ransac_seed=9)
+            out[pieces] = (a.scale_calculation_batch(f3s, f2s)[0], b.scale_calculation_batch(f3s, f2s)[0])
+    finally:
+        engine.UPLOAD_PIECES, engine.UPLOAD_PIECE_FRAMES = keep
+    for pieces in (4, 8):
+        for k in (0, 1):
+            assert np.array_equal(out[1][k], out[pieces][k], equal_nan=True), (pieces, k)
+    assert np.isfinite(out[1][0]).mean() > 0.9 and np.isfinite(out[1][1]).mean() > 0.9
+    # the layout the pieces fill, against the Python packer, for several thread counts
+    from mvoscalerecovery_amd import _lib, packing
+    ctx = _lib.default_context(0)
+    ref = packing.pack_features(f3s, f2s, 185)
+    for threads in (1, 3, 16):
+        pf, blk = engine.pack_upload_native(ctx, f3s, f2s, 185, None, threads=threads)
+        assert np.array_equal(pf.feat_cnt, ref.feat_cnt)
+        x = blk["x"].download(); v = blk["v"].download()
+        for f in (0, 1, 324, 325, 649, 650, 974, 975, F - 1):
+            a0, n = int(pf.feat_off[f]), int(pf.feat_cnt[f])
+            assert np.array_equal(x[a0:a0 + n], ref.x[ref.frame_slice(f)]) and np.array_equal(v[a0:a0 + n], ref.v[ref.frame_slice(f)]), f
+        blk.free()
+
+
 def test_read_only_and_aliased_inputs_in_the_batch_path(gpu):
     """with mutate_inputs (the reference's behaviour, scale_calculator.py:414) a read-only feature3d raises
     ValueError as the reference's own assignment does — the C packer is never handed a pointer it may not write through —
