@@ -142,7 +142,7 @@ constexpr int kFlatDirect = 64;         // that few candidates left: wavefront 0
 constexpr int kMaxHyp = 512;
 constexpr int kRansacPPT = 8;           // points per thread per chunk (chunks of 4096 points)
 // misc[] slots of flat_selection_kernel (slots below FM_WSUM are zeroed at the start)
-enum { FM_K = 0, FM_SINGULAR = 1, FM_BADID = 2, FM_KEPT = 3, FM_BIN = 4, FM_RANK = 5, FM_BINCNT = 6, FM_LE = 7, FM_LIST = 8,
+enum { FM_K = 0, FM_SINGULAR = 1, FM_BADID = 2, FM_KEPT = 3, FM_BIN = 4, FM_RANK = 5, FM_BINCNT = 6, FM_LE = 7, FM_LIST = 8, FM_ND = 9,
        FM_WSUM = 16 /* [16] per-wave bin totals */, FM_CW = 32 /* [16] per-wave counts of the ordered compactions */, FM_N = 48 };
 
 // The sample sequence of the device-resident RANSAC (include/mvosr.h, mvosr_flat_ransac_batch): splitmix64's finaliser as a
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(WAVES *kWave) void flat_selection_kernel(const Flat
     const uint32_t planes = DEV ? 24u * npad + 4u * kFlatBins : (24u * npad > 4u * kFlatBins ? 24u * npad : 4u * kFlatBins);
     uint8_t *Fl = reinterpret_cast<uint8_t *>(X) + planes;       // every triangle's flags, by row
 #ifdef MVOSR_FS_STAMPS
-    unsigned long long st[6];
+    unsigned long long st[10];
 #define FS_STAMP(i) st[i] = __builtin_amdgcn_s_memtime()
 #else
 #define FS_STAMP(i) do {} while (0)
@@ -471,6 +471,7 @@ __global__ __launch_bounds__(WAVES *kWave) void flat_selection_kernel(const Flat
                 base += __popcll(m);
             }
             __syncthreads();
+            FS_STAMP(4);
             // the hypotheses' planes, one thread each (ransac.py:10-11, estimate_road_norm.py:13-15)
             const uint64_t fc = (uint64_t)(a.frame_ids ? a.frame_ids[f] : a.frame_base + f);
             const uint64_t key = rs_mix64(a.seed ^ (fc * 0xD1B54A32D192ED03ull));
@@ -493,47 +494,121 @@ __global__ __launch_bounds__(WAVES *kWave) void flat_selection_kernel(const Flat
                 cnts[h] = 0;
             }
             __syncthreads();
-            // inlier counts (estimate_road_norm.py:17-18 over every list entry, repeats included): a thread's points in
-            // registers, gathered from the LDS planes once, the hypotheses streamed past them.  (Counting over the ~600 distinct
-            // VERTICES weighted with their multiplicities — bit-sliced: sum_b 2^b popcount(inliers & lanes with bit b — a fifth
-            // of the fp64 work, was measured: 1.26 ms against 1.03 ms per chunk; the scalar ballot arithmetic and the extra
-            // passes that build the vertex list cost more than the products they save.)
-            for (int c0 = 0; c0 < M; c0 += BLK * kRansacPPT) {
-                double qx[kRansacPPT], qy[kRansacPPT], qz[kRansacPPT];
+            // Inlier counts (estimate_road_norm.py:17-18 over every list entry, repeats included).  The list names each of its
+            // ~600 distinct vertices five or six times (once per kept triangle): a vertex is tested ONCE per hypothesis and
+            // counts with its multiplicity.  Multiplicities by LDS atomics into 16-bit halves (the histogram's room is free by
+            // now), the distinct vertices as (id | multiplicity << 16) behind the list, then one wavefront per hypothesis: ten
+            // trips over the vertices, an integer sum per lane, one reduction.  (3 300 list entries against 100 hypotheses
+            // with ballots and popcounts — the points in registers — was two thirds of this kernel's instructions; the first
+            // attempt at the multiplicities kept the ballots, bit-sliced, and was slower than the list.)
+            FS_STAMP(5);
+            uint32_t *W2 = reinterpret_cast<uint32_t *>(hist);                   // [n / 2 + 1] two 16-bit counts per word
+            uint16_t *Dv = L + ((M + 1) & ~1);                                   // the distinct vertices, behind the list
+            // (the list and the vertices share the heights' 8 bytes per row: 6 per KEPT row + 2 per vertex — they fit unless
+            // nearly every row is kept in a frame of a few points; then the list itself is counted, entry by entry)
+            const bool dedup = 2 * ((M + 1) & ~1) + 2 * n <= 8 * tn && n <= 2 * kFlatBins - 2;
+            int n_items = M;
+            if (dedup) {
+                for (int v = tid; v < (n + 1) / 2 + 1; v += BLK) W2[v] = 0u;
+                if (tid == 0) misc[FM_ND] = 0;
+                __syncthreads();
+                for (int j = tid; j < M; j += BLK) { const uint32_t id = L[j]; atomicAdd(&W2[id >> 1], 1u << (16u * (id & 1u))); }
+                __syncthreads();
+                for (int v = tid; v < n; v += BLK)
+                    if ((W2[v >> 1] >> (16u * ((uint32_t)v & 1u))) & 0xFFFFu) Dv[atomicAdd(&misc[FM_ND], 1)] = (uint16_t)v;
+                __syncthreads();
+                n_items = misc[FM_ND];
+            }
+            // ... and, where they fit the heights' room (28 bytes per distinct vertex: they do unless more than ~1 000 of a frame's
+            // vertices lie on kept rows), the vertices' coordinates and multiplicities side by side, in the order of the list of
+            // distinct vertices: the counting loop then reads four contiguous arrays instead of gathering by id
+            const bool packed = dedup && n_items <= 2 * BLK && 28 * n_items + 8 <= 8 * tn;
+            double *PX = Hh, *PY = PX + n_items, *PZ = PY + n_items;
+            int *PW = reinterpret_cast<int *>(PZ + n_items);
+            if (packed) {
+                double gx[2], gy[2], gz[2];
+                int gw[2];
 #pragma unroll
-                for (int kk = 0; kk < kRansacPPT; ++kk) {
-                    const int j = c0 + kk * BLK + tid;
-                    const int id = L[min(j, M - 1)];
-                    qx[kk] = X[id]; qy[kk] = Y[id]; qz[kk] = Z[id];
-                    if (j >= M) qx[kk] = nan("");                    // never an inlier
+                for (int r = 0; r < 2; ++r) {
+                    const int j = tid + r * BLK;
+                    const uint32_t id = Dv[min(j, n_items - 1)];
+                    gx[r] = X[id]; gy[r] = Y[id]; gz[r] = Z[id]; gw[r] = (int)((W2[id >> 1] >> (16u * (id & 1u))) & 0xFFFFu);
                 }
-                const int rws = min(kRansacPPT, (M - c0 + BLK - 1) / BLK);
-#pragma unroll 2
-                for (int h = 0; h < H; ++h) {
-                    const double2 m0 = mods[2 * h], m1 = mods[2 * h + 1];
-                    int ic = 0;
+                __syncthreads();                                                 // (the list and the ids have been read: their room is the arrays')
 #pragma unroll
-                    for (int kk = 0; kk < kRansacPPT; ++kk)
-                        if (kk < rws) ic += __popcll(__ballot(fabs(((qx[kk] * m0.x + qy[kk] * m0.y) + qz[kk] * m1.x) + m1.y) < a.threshold));
-                    if (lane == 0 && ic) atomicAdd(&cnts[h], ic);
+                for (int r = 0; r < 2; ++r) {
+                    const int j = tid + r * BLK;
+                    if (j < n_items) { PX[j] = gx[r]; PY[j] = gy[r]; PZ[j] = gz[r]; PW[j] = gw[r]; }
+                }
+                __syncthreads();
+            }
+            FS_STAMP(6);
+            const uint16_t *items = dedup ? Dv : L;
+            // a wavefront's hypotheses seven at a time (all of them, with 100 hypotheses on 16 wavefronts), their planes in registers: a vertex is gathered (id -> multiplicity, x, y,
+            // z: four LDS gathers with bank conflicts) once per pass and tested against all four (one hypothesis per pass spent
+            // 41 % of the kernel's time on those gathers)
+            constexpr int kHypPass = 7;
+            for (int k0 = 0; wave + WAVES * k0 < H; k0 += kHypPass) {
+                double2 ma[kHypPass], mb[kHypPass];
+                int acc[kHypPass];
+#pragma unroll
+                for (int q = 0; q < kHypPass; ++q) {
+                    const int h = min(wave + WAVES * (k0 + q), H - 1);
+                    ma[q] = mods[2 * h]; mb[q] = mods[2 * h + 1]; acc[q] = 0;
+                }
+                if (packed) {
+                    for (int j = lane; j < n_items; j += kWave) {
+                        const double px = PX[j], py = PY[j], pz = PZ[j];
+                        const int wgt = PW[j];
+#pragma unroll
+                        for (int q = 0; q < kHypPass; ++q)
+                            acc[q] += (fabs(((px * ma[q].x + py * ma[q].y) + pz * mb[q].x) + mb[q].y) < a.threshold) ? wgt : 0;   // estimate_road_norm.py:18
+                    }
+                } else {
+                    for (int j = lane; j < n_items; j += kWave) {
+                        const uint32_t id = items[j];
+                        const int wgt = dedup ? (int)((W2[id >> 1] >> (16u * (id & 1u))) & 0xFFFFu) : 1;
+                        const double px = X[id], py = Y[id], pz = Z[id];
+#pragma unroll
+                        for (int q = 0; q < kHypPass; ++q)
+                            acc[q] += (fabs(((px * ma[q].x + py * ma[q].y) + pz * mb[q].x) + mb[q].y) < a.threshold) ? wgt : 0;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < kHypPass; ++q) {
+                    const int h = wave + WAVES * (k0 + q);
+                    const int sum = wave_sum(acc[q]);
+                    if (lane == 0 && h < H) cnts[h] = sum;
                 }
             }
             __syncthreads();
+            FS_STAMP(7);
             if (a.hyp_counts) for (int h = tid; h < H; h += BLK) a.hyp_counts[(int64_t)f * H + h] = cnts[h];
         }
-        if (tid == 0) {
+        if (wave == 0) {
             int status = misc[FM_BADID] ? MVOSR_ST_ERR_MASK : (misc[FM_SINGULAR] ? MVOSR_ST_ERR_SINGULAR : (fit ? 0 : MVOSR_ST_RS_FEW));
             int best = -1, best_ic = 0, used = 0;
             double m[4] = {nan(""), nan(""), nan(""), nan("")};
             double raw = nan("");
             if (fit) {
+                // ransac.py:9-22 — a hypothesis is the new best when it counts MORE than the best so far, and the loop stops
+                // at a new best above the goal — by the wavefront, 64 hypotheses at a time: the loop stops at the first count
+                // above the goal (the best before it was not, so it is a new best), and the best is the first occurrence of
+                // the largest count up to there.  (One thread walking the hundred counts was 16 % of the kernel's time.)
                 const double goal = (double)M * a.goal_fraction;                  // estimate_road_norm.py:68
-                for (int h = 0; h < H; ++h) {                                     // ransac.py:9-22
-                    used = h + 1;
-                    if (cnts[h] > best_ic) {
-                        best_ic = cnts[h]; best = h;
-                        if ((double)best_ic > goal) break;
+                used = H;
+                for (int h0 = 0; h0 < H; h0 += kWave) {
+                    const int h = h0 + lane;
+                    const int c = h < H ? cnts[h] : -1;
+                    const unsigned long long over = __ballot(h < H && (double)c > goal);
+                    const int limit = over ? (int)__ffsll((long long)over) - 1 : kWave - 1;
+                    const bool in = h < H && lane <= limit;
+                    const int mx = wave_max(in ? c : -1);
+                    if (mx > best_ic) {
+                        const unsigned long long who = __ballot(in && c == mx);
+                        best = h0 + (int)__ffsll((long long)who) - 1; best_ic = mx;
                     }
+                    if (over) { used = h0 + limit + 1; break; }
                 }
                 if (best >= 0) {
                     const double2 b0 = mods[2 * best], b1 = mods[2 * best + 1];
@@ -545,12 +620,23 @@ __global__ __launch_bounds__(WAVES *kWave) void flat_selection_kernel(const Flat
                     raw = a.absolute_reference / cam_h;                            // :167
                 } else status = MVOSR_ST_RS_FEW;                                   // (no hypothesis with an inlier: NaN planes only)
             }
-            a.height_level[f] = level;
-            a.n_kept[f] = K;
-            a.status[f] = status;
-            a.raw_scale[f] = raw;
-            a.best_ic[f] = best_ic; a.used[f] = used;
-            for (int kk = 0; kk < 4; ++kk) a.model[4 * f + kk] = m[kk];
+            if (lane == 0) {
+                a.height_level[f] = level;
+                a.n_kept[f] = K;
+                a.status[f] = status;
+                a.raw_scale[f] = raw;
+                a.best_ic[f] = best_ic; a.used[f] = used;
+                for (int kk = 0; kk < 4; ++kk) a.model[4 * f + kk] = m[kk];
+            }
+#ifdef MVOSR_FS_STAMPS
+            // diagnostic build: the results are overwritten by the phase durations (profiles/stamps_flat_dev.py)
+            FS_STAMP(8);
+            if (fit && lane == 0) {
+                a.model[4 * f] = (double)(st[1] - st[0]); a.model[4 * f + 1] = (double)(st[2] - st[1]); a.model[4 * f + 2] = (double)(st[3] - st[2]);
+                a.model[4 * f + 3] = (double)(st[4] - st[3]); a.raw_scale[f] = (double)(st[5] - st[4]); a.height_level[f] = (double)(st[6] - st[5]);
+                a.best_ic[f] = (int)(st[7] - st[6]); a.used[f] = (int)(st[8] - st[7]);
+            }
+#endif
         }
     }
 }
