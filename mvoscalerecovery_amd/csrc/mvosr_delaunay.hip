@@ -49,7 +49,11 @@ constexpr int kDtBlock = kDtWaves * kWave;
 #define MVOSR_DT_SMALL_LADDER 1
 #endif
 constexpr int kDtLadderMinFrames = 512;      // two eight-wavefront frames on each of 256 CUs
-constexpr bool kDtSmallLadder = MVOSR_DT_SMALL_LADDER != 0;   // 2- and 4-wavefront instantiations for small frames (see the launcher)
+constexpr bool kDtSmallLadder = MVOSR_DT_SMALL_LADDER != 0;
+#ifndef MVOSR_DT_ARENA_OUT
+#define MVOSR_DT_ARENA_OUT 1
+#endif
+constexpr bool kDtArenaOut = MVOSR_DT_ARENA_OUT != 0;   // three four-wavefront frames per CU with the rows' arena in global memory (see the launcher)   // 2- and 4-wavefront instantiations for small frames (see the launcher)
 #ifndef MVOSR_DT_R
 #define MVOSR_DT_R 2
 #endif
@@ -103,6 +107,7 @@ struct DtArgs {
     int32_t *status;                                     // [F] MVOSR_DT_*
     int max_pts;
     char *ws;                                            // GLOBAL variant: a slice of dt_plan().big bytes per frame
+    char *aws;                                           // ARENA_OUT variant: a slice of dt_plan().out_bytes per frame (arena + starts)
     uint32_t *hints;                                     // LDS variant: kDtHintK (+1: see seeds) words per point and frame (all ones = empty), or null
     // seeds (mvosr_delaunay_batch_seeded): rows of a triangulation of ALL the frame's points (ids = positions in u/v).  A
     // triangle of it whose three vertices are kept is a triangle of this one — its circumcircle was empty among more
@@ -170,7 +175,7 @@ template <bool GLOBAL> constexpr bool kDtHintsOn = kDtHintK > 0 && (!GLOBAL || M
 #endif
 template <bool GLOBAL> constexpr bool kDtCoop = MVOSR_DT_COOP && (!GLOBAL || MVOSR_DT_GLOBAL_COOP);    // (frames in global memory: 26 k -> 19 k sets/s with it at 20 000 points)   // hinted triangles taken in a row before the lane goes back to searching
 
-struct DtPlan { uint32_t S, oid, od, astart, cs, arena, big, hard, wrows, red, misc, aff, total; int max_cells, arena_cap; };
+struct DtPlan { uint32_t S, oid, od, astart, cs, arena, big, hard, wrows, red, misc, aff, total, out_bytes; int max_cells, arena_cap; };
 constexpr int kDtMaxCellsGlobal = 32768;
 constexpr int kDtMaxPointsGlobal = 32000;      // (row arena indices and point ids are 16-bit)
 
@@ -179,7 +184,9 @@ __host__ __device__ inline int dt_cell_cap(int max_pts, bool global) {
     const int cap = global ? kDtMaxCellsGlobal : kDtMaxCells;
     return c > cap ? cap : c;
 }
-__host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false, int waves = kDtWaves) {
+// arena_out: the rows' arena and the points' starts in it live in a per-frame slice of GLOBAL memory (out_bytes; offsets astart and
+// arena are into that slice) instead of LDS: 20 KB less per 2000-point frame, which is what lets THREE such frames share a CU
+__host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false, int waves = kDtWaves, bool arena_out = false) {
     DtPlan p;
     const uint32_t npad = (uint32_t)((max_pts + 7) & ~7);
     p.max_cells = dt_cell_cap(max_pts, global);
@@ -191,6 +198,14 @@ __host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false, int 
     p.cs = p.astart + 2u * npad + 4u;                    // u32 per cell (+1): end of the cell in the sorted array; cs[-1] = 0 (the start of cell 0)
     p.arena = p.cs + 4u * (uint32_t)(p.max_cells + 8);   // u32 rows (b << 16 | c) in the order they were found
     p.big = (p.arena + 4u * (uint32_t)p.arena_cap + 255u) & ~255u;
+    p.out_bytes = 0u;
+    if (arena_out) {
+        p.cs = p.od + 2u * npad + 4u;
+        p.big = (p.cs + 4u * (uint32_t)(p.max_cells + 8) + 255u) & ~255u;
+        p.astart = 0u;
+        p.arena = (2u * npad + 15u) & ~15u;
+        p.out_bytes = (p.arena + 4u * (uint32_t)p.arena_cap + 255u) & ~255u;
+    }
     p.hard = p.big;                                      // u16 sorted indices
     p.wrows = p.hard + 2u * kDtHardCap;                  // u32 [groups of 16 lanes][kDtWaveRows] (phase 2)
     {
@@ -438,22 +453,23 @@ __device__ __forceinline__ int dt_incl_scan(int v) {
     return v;
 }
 
-template <bool GLOBAL, int WAVES = kDtWaves>
-__global__ __launch_bounds__(WAVES *kWave, 4) void delaunay_kernel(const DtArgs a) {
+template <bool GLOBAL, int WAVES = kDtWaves, bool ARENA_OUT = false>
+__global__ __launch_bounds__(WAVES *kWave, ARENA_OUT ? 3 : 4) void delaunay_kernel(const DtArgs a) {
     constexpr int BLOCK = WAVES * kWave;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = blockIdx.x;
     const int n_in = a.pts_cnt[f];
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    const DtPlan L = dt_plan(a.max_pts, GLOBAL, WAVES);
+    const DtPlan L = dt_plan(a.max_pts, GLOBAL, WAVES, ARENA_OUT);
     char *big = GLOBAL ? a.ws + (size_t)f * L.big : smem;                  // the frame's big arrays
     char *small = GLOBAL ? smem - L.big : smem;                            // (the plan's offsets of the small ones start at L.big)
     double2 *S = reinterpret_cast<double2 *>(big + L.S);
     uint16_t *oid = reinterpret_cast<uint16_t *>(big + L.oid);
     uint16_t *od = reinterpret_cast<uint16_t *>(big + L.od);
-    uint16_t *astart = reinterpret_cast<uint16_t *>(big + L.astart);
+    char *outp = ARENA_OUT ? a.aws + (size_t)f * L.out_bytes : big;           // (the arena and the starts: LDS, or the frame's global slice)
+    uint16_t *astart = reinterpret_cast<uint16_t *>(outp + L.astart);
     uint32_t *cs = reinterpret_cast<uint32_t *>(big + L.cs);
-    uint32_t *arena = reinterpret_cast<uint32_t *>(big + L.arena);
+    uint32_t *arena = reinterpret_cast<uint32_t *>(outp + L.arena);
     uint16_t *hard = reinterpret_cast<uint16_t *>(small + L.hard);
     double *red = reinterpret_cast<double *>(small + L.red);
     int *misc = reinterpret_cast<int *>(small + L.misc);
@@ -1296,7 +1312,7 @@ extern "C" int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const i
     const DtPlan L = dt_plan(max_pts, global);
     DtArgs a;
     a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
-    a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.max_pts = max_pts; a.ws = nullptr; a.hints = nullptr;
+    a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.max_pts = max_pts; a.ws = nullptr; a.aws = nullptr; a.hints = nullptr;
     a.seed_off = seed_off; a.seed_tri = seed_tri; a.seed_cnt = seed_cnt;
     a.seed_info = seed_info; a.info_out = info_out;
 #ifdef MVOSR_STAMPS
@@ -1325,23 +1341,39 @@ extern "C" int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const i
     // A launch that cannot fill the GPU with eight-wavefront frames (a per-frame call: ONE frame) keeps all eight: there the
     // lanes per frame are what shortens the call (900 points: 0.96 against 1.26 ms per frame call).
     int waves = kDtWaves;
+    bool arena_out = false;
     if (kDtSmallLadder && n_frames >= kDtLadderMinFrames) {
-        if (8u * dt_plan(max_pts, false, 2).total <= 160u * 1024u) waves = 2;
-        else if (3u * dt_plan(max_pts, false, 4).total <= 160u * 1024u) waves = 4;
+        // (LDS is handed out in granules of 1 280 bytes: 128 per CU)
+        auto fits = [](uint32_t frames, uint32_t bytes) { return frames * ((bytes + 1279u) / 1280u) <= 128u; };
+        if (fits(8u, dt_plan(max_pts, false, 2).total)) waves = 2;
+        else if (fits(3u, dt_plan(max_pts, false, 4).total)) waves = 4;
+        // up to ~2 100 points three frames still share a CU when the rows' arena and the points' starts in it move to global
+        // memory (written once per star, read once at the end): 52 KB of LDS per 2000-point frame instead of 74.  Three
+        // four-wavefront frames against two eight-wavefront ones: 12 wavefronts per CU with 170 registers each (no spills), a
+        // quarter fewer points of a frame in flight at once (more triangles arrive as hints), and a third frame's work
+        // under the dependent steps of the second triangulation, which is bound by its longest star
+        else if (kDtArenaOut && fits(3u, dt_plan(max_pts, false, 4, true).total)) { waves = 4; arena_out = true; }
     }
-    lds = dt_plan(max_pts, false, waves).total;
-    const void *kfn = waves == 2 ? reinterpret_cast<const void *>(delaunay_kernel<false, 2>)
+    const DtPlan LP = dt_plan(max_pts, false, waves, arena_out);
+    lds = LP.total;
+    const void *kfn = arena_out ? reinterpret_cast<const void *>(delaunay_kernel<false, 4, true>)
+                    : waves == 2 ? reinterpret_cast<const void *>(delaunay_kernel<false, 2>)
                     : waves == 4 ? reinterpret_cast<const void *>(delaunay_kernel<false, 4>) : reinterpret_cast<const void *>(delaunay_kernel<false>);
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_hip_error("hipFuncSetAttribute(delaunay_kernel)", e);
-    if (kDtHintK > 0) {
-        // the stars' hint caches (see kDtHintK): 4 * (kDtHintK + 1) bytes per point
+    {
+        // the stars' hint caches (see kDtHintK): 4 * (kDtHintK + 3) bytes per point; behind them the arena slices
         void *ws = nullptr;
-        const size_t bytes = (size_t)n_frames * (size_t)(kDtHintK + 3) * (size_t)((max_pts + 7) & ~7) * sizeof(uint32_t);
-        if ((rc = ctx_workspace_bytes(ctx, bytes, &ws))) return rc;
-        a.hints = reinterpret_cast<uint32_t *>(ws);              // (every workgroup empties its own frame's caches: no memset of the whole block)
+        const size_t hint_bytes = ((size_t)n_frames * (size_t)(kDtHintK + 3) * (size_t)((max_pts + 7) & ~7) * sizeof(uint32_t) + 255) & ~(size_t)255;
+        const size_t out_bytes = arena_out ? (size_t)n_frames * LP.out_bytes : 0;
+        if (hint_bytes + out_bytes) {
+            if ((rc = ctx_workspace_bytes(ctx, hint_bytes + out_bytes, &ws))) return rc;
+            if (kDtHintK > 0) a.hints = reinterpret_cast<uint32_t *>(ws);   // (every workgroup empties its own frame's caches: no memset of the whole block)
+            a.aws = reinterpret_cast<char *>(ws) + hint_bytes;
+        }
     }
-    if (waves == 2) hipLaunchKernelGGL((delaunay_kernel<false, 2>), dim3((unsigned)n_frames), dim3(2 * kWave), lds, ctx_stream(ctx), a);
+    if (arena_out) hipLaunchKernelGGL((delaunay_kernel<false, 4, true>), dim3((unsigned)n_frames), dim3(4 * kWave), lds, ctx_stream(ctx), a);
+    else if (waves == 2) hipLaunchKernelGGL((delaunay_kernel<false, 2>), dim3((unsigned)n_frames), dim3(2 * kWave), lds, ctx_stream(ctx), a);
     else if (waves == 4) hipLaunchKernelGGL((delaunay_kernel<false, 4>), dim3((unsigned)n_frames), dim3(4 * kWave), lds, ctx_stream(ctx), a);
     else hipLaunchKernelGGL(delaunay_kernel<false>, dim3((unsigned)n_frames), dim3(kDtBlock), lds, ctx_stream(ctx), a);
     return check_launch("delaunay_kernel");
