@@ -350,6 +350,20 @@ int mvosr_device_count(void) {
     return n;
 }
 
+int mvosr_device_numa_node(int device) {
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');       // (sysfs names are lower case)
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *fp = fopen(path, "r");
+    if (!fp) return -1;
+    int node = -1;
+    if (fscanf(fp, "%d", &node) != 1) node = -1;
+    fclose(fp);
+    return node;
+}
+
 int mvosr_ctx_create(int device, mvosr_ctx **out) {
     if (!out) return set_error(MVOSR_ERR_ARG, "ctx_create: null out pointer");
     *out = nullptr;
