@@ -454,7 +454,7 @@ __device__ __forceinline__ int dt_incl_scan(int v) {
 }
 
 template <bool GLOBAL, int WAVES = kDtWaves, bool ARENA_OUT = false>
-__global__ __launch_bounds__(WAVES *kWave, ARENA_OUT ? 3 : 4) void delaunay_kernel(const DtArgs a) {
+__global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) void delaunay_kernel(const DtArgs a) {
     constexpr int BLOCK = WAVES * kWave;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t f = blockIdx.x;
@@ -1353,10 +1353,17 @@ extern "C" int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const i
         // quarter fewer points of a frame in flight at once (more triangles arrive as hints), and a third frame's work
         // under the dependent steps of the second triangulation, which is bound by its longest star
         else if (kDtArenaOut && fits(3u, dt_plan(max_pts, false, 4, true).total)) { waves = 4; arena_out = true; }
+        // beyond that, two eight-wavefront frames per CU as long as they fit — with the arena in global memory up to ~3 100
+        // points instead of ~2 350 (one frame per CU is half the wavefronts)
+        else if (kDtArenaOut && !fits(2u, dt_plan(max_pts, false, 8).total) && fits(2u, dt_plan(max_pts, false, 8, true).total)) arena_out = true;
+        // (where three four-wavefront frames fit a CU either way — 1 100 to 1 480 points — the arena-out build, which is compiled
+        // for three wavefronts per SIMD: 154 registers, no spills: +3-5 %)
+        if (kDtArenaOut && waves == 4 && !arena_out && !fits(4u, dt_plan(max_pts, false, 4).total)) arena_out = true;
     }
     const DtPlan LP = dt_plan(max_pts, false, waves, arena_out);
     lds = LP.total;
-    const void *kfn = arena_out ? reinterpret_cast<const void *>(delaunay_kernel<false, 4, true>)
+    const void *kfn = (arena_out && waves == 4) ? reinterpret_cast<const void *>(delaunay_kernel<false, 4, true>)
+                    : arena_out ? reinterpret_cast<const void *>(delaunay_kernel<false, 8, true>)
                     : waves == 2 ? reinterpret_cast<const void *>(delaunay_kernel<false, 2>)
                     : waves == 4 ? reinterpret_cast<const void *>(delaunay_kernel<false, 4>) : reinterpret_cast<const void *>(delaunay_kernel<false>);
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1372,7 +1379,8 @@ extern "C" int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const i
             a.aws = reinterpret_cast<char *>(ws) + hint_bytes;
         }
     }
-    if (arena_out) hipLaunchKernelGGL((delaunay_kernel<false, 4, true>), dim3((unsigned)n_frames), dim3(4 * kWave), lds, ctx_stream(ctx), a);
+    if (arena_out && waves == 4) hipLaunchKernelGGL((delaunay_kernel<false, 4, true>), dim3((unsigned)n_frames), dim3(4 * kWave), lds, ctx_stream(ctx), a);
+    else if (arena_out) hipLaunchKernelGGL((delaunay_kernel<false, 8, true>), dim3((unsigned)n_frames), dim3(kDtBlock), lds, ctx_stream(ctx), a);
     else if (waves == 2) hipLaunchKernelGGL((delaunay_kernel<false, 2>), dim3((unsigned)n_frames), dim3(2 * kWave), lds, ctx_stream(ctx), a);
     else if (waves == 4) hipLaunchKernelGGL((delaunay_kernel<false, 4>), dim3((unsigned)n_frames), dim3(4 * kWave), lds, ctx_stream(ctx), a);
     else hipLaunchKernelGGL(delaunay_kernel<false>, dim3((unsigned)n_frames), dim3(kDtBlock), lds, ctx_stream(ctx), a);
