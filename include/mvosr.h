@@ -582,6 +582,11 @@ int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts
  * through L1/L2 (dense frames, BASELINE configs[4]); slower per point, same rows. */
 int mvosr_delaunay_max_points(void);
 int mvosr_delaunay_lds_points(void);
+/* Frames of a batch whose largest frame has max_pts points that ONE compute unit works on at a time in a launch of 512 frames
+ * and more (the launcher's choice of wavefronts per frame and of the arena's home: 8, 4, 3, 2 or 1; 1 for the global-memory
+ * variant).  A host that cuts a long batch into chunks makes a chunk a multiple of this x the device's CU count: the kernel
+ * then has no partly filled last round. */
+int mvosr_delaunay_frames_per_cu(int max_pts);
 
 /* LDS bytes the fused kernel requests for a frame of n features (host-side planning). */
 size_t mvosr_lds_bytes(int n_features);

@@ -132,6 +132,7 @@ SYMBOLS = {
     "mvosr_delaunay_batch_ex": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mvosr_delaunay_max_points": (C.c_int, []),
     "mvosr_delaunay_lds_points": (C.c_int, []),
+    "mvosr_delaunay_frames_per_cu": (C.c_int, [C.c_int]),
     "mvosr_lds_bytes": (C.c_size_t, [C.c_int]),
     "mvosr_max_lds_features": (C.c_int, []),
 }

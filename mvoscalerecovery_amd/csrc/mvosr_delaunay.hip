@@ -1271,6 +1271,43 @@ static int dt_lds_points() {
     return lo;
 }
 
+// The launcher's instantiation for a batch (of 512 frames and more) whose largest frame has max_pts points: wavefronts per frame,
+// whether the rows' arena lives in global memory, and how many such frames share a CU.
+static void dt_ladder(int max_pts, int &waves, bool &arena_out, int &per_cu) {
+    waves = kDtWaves; arena_out = false;
+    {
+        // (LDS is handed out in granules of 1 280 bytes: 128 per CU)
+        auto fits = [](uint32_t frames, uint32_t bytes) { return frames * ((bytes + 1279u) / 1280u) <= 128u; };
+        if (fits(8u, dt_plan(max_pts, false, 2).total)) waves = 2;
+        else if (fits(3u, dt_plan(max_pts, false, 4).total)) waves = 4;
+        // up to ~2 100 points three frames still share a CU when the rows' arena and the points' starts in it move to global
+        // memory (written once per star, read once at the end): 52 KB of LDS per 2000-point frame instead of 74.  Three
+        // four-wavefront frames against two eight-wavefront ones: 12 wavefronts per CU with 170 registers each (no spills), a
+        // quarter fewer points of a frame in flight at once (more triangles arrive as hints), and a third frame's work
+        // under the dependent steps of the second triangulation, which is bound by its longest star
+        else if (kDtArenaOut && fits(3u, dt_plan(max_pts, false, 4, true).total)) { waves = 4; arena_out = true; }
+        // beyond that, two eight-wavefront frames per CU as long as they fit — with the arena in global memory up to ~3 100
+        // points instead of ~2 350 (one frame per CU is half the wavefronts)
+        else if (kDtArenaOut && !fits(2u, dt_plan(max_pts, false, 8).total) && fits(2u, dt_plan(max_pts, false, 8, true).total)) arena_out = true;
+        // (where three four-wavefront frames fit a CU either way — 1 100 to 1 480 points — the arena-out build, which is compiled
+        // for three wavefronts per SIMD: 154 registers, no spills: +3-5 %)
+        if (kDtArenaOut && waves == 4 && !arena_out && !fits(4u, dt_plan(max_pts, false, 4).total)) arena_out = true;
+    }
+    auto fits_n = [](uint32_t frames, uint32_t bytes) { return frames * ((bytes + 1279u) / 1280u) <= 128u; };
+    const uint32_t bytes = dt_plan(max_pts, false, waves, arena_out).total;
+    per_cu = waves == 2 ? 8 : 1;
+    // (registers: the four-wavefront builds run 16 wavefronts per CU — the arena-out one, with 154 registers, 12 —, the eight-wavefront ones 16)
+    if (waves != 2) for (int k = waves == 4 ? (arena_out ? 3 : 4) : 2; k >= 1; --k) if (fits_n((uint32_t)k, bytes)) { per_cu = k; break; }
+}
+
+extern "C" int mvosr_delaunay_frames_per_cu(int max_pts) {
+    if (max_pts < 3) max_pts = 3;
+    if (max_pts > dt_lds_points()) return 1;
+    int waves, per_cu; bool arena_out;
+    dt_ladder(max_pts, waves, arena_out, per_cu);
+    return per_cu;
+}
+
 extern "C" int mvosr_delaunay_max_points(void) { return kDtMaxPointsGlobal; }
 extern "C" int mvosr_delaunay_lds_points(void) { return dt_lds_points(); }
 
@@ -1340,26 +1377,9 @@ extern "C" int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const i
     // while eight fit (up to ~500 points: +20-50 % over four).
     // A launch that cannot fill the GPU with eight-wavefront frames (a per-frame call: ONE frame) keeps all eight: there the
     // lanes per frame are what shortens the call (900 points: 0.96 against 1.26 ms per frame call).
-    int waves = kDtWaves;
+    int waves = kDtWaves, per_cu = 1;
     bool arena_out = false;
-    if (kDtSmallLadder && n_frames >= kDtLadderMinFrames) {
-        // (LDS is handed out in granules of 1 280 bytes: 128 per CU)
-        auto fits = [](uint32_t frames, uint32_t bytes) { return frames * ((bytes + 1279u) / 1280u) <= 128u; };
-        if (fits(8u, dt_plan(max_pts, false, 2).total)) waves = 2;
-        else if (fits(3u, dt_plan(max_pts, false, 4).total)) waves = 4;
-        // up to ~2 100 points three frames still share a CU when the rows' arena and the points' starts in it move to global
-        // memory (written once per star, read once at the end): 52 KB of LDS per 2000-point frame instead of 74.  Three
-        // four-wavefront frames against two eight-wavefront ones: 12 wavefronts per CU with 170 registers each (no spills), a
-        // quarter fewer points of a frame in flight at once (more triangles arrive as hints), and a third frame's work
-        // under the dependent steps of the second triangulation, which is bound by its longest star
-        else if (kDtArenaOut && fits(3u, dt_plan(max_pts, false, 4, true).total)) { waves = 4; arena_out = true; }
-        // beyond that, two eight-wavefront frames per CU as long as they fit — with the arena in global memory up to ~3 100
-        // points instead of ~2 350 (one frame per CU is half the wavefronts)
-        else if (kDtArenaOut && !fits(2u, dt_plan(max_pts, false, 8).total) && fits(2u, dt_plan(max_pts, false, 8, true).total)) arena_out = true;
-        // (where three four-wavefront frames fit a CU either way — 1 100 to 1 480 points — the arena-out build, which is compiled
-        // for three wavefronts per SIMD: 154 registers, no spills: +3-5 %)
-        if (kDtArenaOut && waves == 4 && !arena_out && !fits(4u, dt_plan(max_pts, false, 4).total)) arena_out = true;
-    }
+    if (kDtSmallLadder && n_frames >= kDtLadderMinFrames) dt_ladder(max_pts, waves, arena_out, per_cu);
     const DtPlan LP = dt_plan(max_pts, false, waves, arena_out);
     lds = LP.total;
     const void *kfn = (arena_out && waves == 4) ? reinterpret_cast<const void *>(delaunay_kernel<false, 4, true>)

@@ -399,6 +399,10 @@ class ScaleEstimator:
         db.mark()
         return {"gpu": True, "pf": pf, "db": db, "out": out, "flags": flags, "side": side}
 
+    def _resident_frames(self, max_pts):
+        """Frames the triangulation kernel works on at a time (mvosr_delaunay_frames_per_cu x CUs)."""
+        return max(self.GPU_RESIDENT, int(self.ctx.lib.mvosr_delaunay_frames_per_cu(int(max_pts))) * int(self.ctx.n_cu))
+
     def _max_points(self):
         """Largest frame the device-resident kernels take (flat_selection + RANSAC hold a frame's survivors, rows'
         heights and flags in one workgroup's LDS: 42 B per feature + 12 KB)."""
@@ -517,8 +521,9 @@ class ScaleEstimator:
                 b = min(b, a + max(int(np.searchsorted(np.cumsum(lens), self.GPU_CHUNK_POINTS, side="right")), 1))
                 while b - a > 1 and (b - a) * int(lens[:b - a].max()) > 2 * self.GPU_CHUNK_POINTS:     # (workspace = frames x largest frame)
                     b = a + max(1, (b - a) // 2)
-                if b < F and b - a >= 2 * self.GPU_RESIDENT:           # whole rounds of the GPU's resident frames: no partly filled last round
-                    b = a + ((b - a) // self.GPU_RESIDENT) * self.GPU_RESIDENT
+                res = self._resident_frames(int(lens[:b - a].max()))
+                if b < F and b - a >= 2 * res:                         # whole rounds of the GPU's resident frames: no partly filled last round
+                    b = a + ((b - a) // res) * res
                 tr = None if id_triples is None else id_triples[a:b]
                 if trace is not None: trace.append(("launch", len(bounds), b - a, time.perf_counter() - t_call))
                 queue.append((self._chunk_dev_gpu(feature3ds[a:b], feature2ds[a:b], base + a, tr, stage,

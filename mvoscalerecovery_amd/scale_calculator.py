@@ -563,8 +563,10 @@ class ScaleEstimator:
                 # a chunk is a whole number of the GPU's resident sets of frames (512 eight-wavefront workgroups on 256 CUs):
                 # the triangulation kernels then have no partly filled last round (32 768 frames of 2000 features in chunks of
                 # 5000: 349-388 k frames/s, of 4096: 379-408 k)
-                if b_ < F and b_ - a_ >= 2 * self.GPU_RESIDENT:
-                    b_ = a_ + ((b_ - a_) // self.GPU_RESIDENT) * self.GPU_RESIDENT
+                ctx_ = self.engine.ctx
+                res = max(self.GPU_RESIDENT, int(ctx_.lib.mvosr_delaunay_frames_per_cu(int(lens[:b_ - a_].max()))) * int(ctx_.n_cu))
+                if b_ < F and b_ - a_ >= 2 * res:
+                    b_ = a_ + ((b_ - a_) // res) * res
                 yield a_, b_, (tuple(t[:b_ - a_] for t in tb) if tb is not None else None)
                 a_, k_ = b_, k_ + 1
 
