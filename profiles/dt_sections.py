@@ -1,11 +1,12 @@
-"""Static instruction counts of delaunay_kernel<false, 8> between the DT_MARK markers of a -DMVOSR_DT_MARKS -S build:
+"""Static instruction counts of one delaunay_kernel instantiation (default <false, 4, true>: the 2000-point build) between the DT_MARK markers of a -DMVOSR_DT_MARKS -S build:
    (cd mvoscalerecovery_amd/csrc && hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off --cuda-device-only -DMVOSR_DT_MARKS -S mvosr_delaunay.hip -o /tmp/dt_marks.s)
-   python profiles/dt_sections.py [/tmp/dt_marks.s] [section to print]"""
+   python profiles/dt_sections.py [/tmp/dt_marks.s] [section to print] [mangled name prefix, e.g. _ZN5mvosr15delaunay_kernelILb0ELi8ELb0]"""
 import re, sys
 path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/dt_marks.s"
 show = sys.argv[2] if len(sys.argv) > 2 else None
 lines = open(path).read().split("\n")
-start = [i for i, l in enumerate(lines) if l.startswith("_ZN5mvosr15delaunay_kernelILb0ELi8")][0]
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "_ZN5mvosr15delaunay_kernelILb0ELi4ELb1"
+start = [i for i, l in enumerate(lines) if l.startswith(KERNEL)][0]
 marks = []
 for i in range(start, len(lines)):
     m = re.search(r"; DTMARK (\w+)", lines[i])
