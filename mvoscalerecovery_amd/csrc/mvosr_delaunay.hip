@@ -53,7 +53,12 @@ constexpr bool kDtSmallLadder = MVOSR_DT_SMALL_LADDER != 0;
 #ifndef MVOSR_DT_ARENA_OUT
 #define MVOSR_DT_ARENA_OUT 1
 #endif
-constexpr bool kDtArenaOut = MVOSR_DT_ARENA_OUT != 0;   // three four-wavefront frames per CU with the rows' arena in global memory (see the launcher)   // 2- and 4-wavefront instantiations for small frames (see the launcher)
+constexpr bool kDtArenaOut = MVOSR_DT_ARENA_OUT != 0;
+#ifndef MVOSR_DT_WIDE16
+#define MVOSR_DT_WIDE16 1
+#endif
+constexpr bool kDtWide16 = MVOSR_DT_WIDE16 != 0;          // sixteen wavefronts per frame for launches of a few frames (see the launcher)
+constexpr int kDtWide16MaxFrames = 128;   // three four-wavefront frames per CU with the rows' arena in global memory (see the launcher)   // 2- and 4-wavefront instantiations for small frames (see the launcher)
 #ifndef MVOSR_DT_R
 #define MVOSR_DT_R 2
 #endif
@@ -175,7 +180,7 @@ template <bool GLOBAL> constexpr bool kDtHintsOn = kDtHintK > 0 && (!GLOBAL || M
 #endif
 template <bool GLOBAL> constexpr bool kDtCoop = MVOSR_DT_COOP && (!GLOBAL || MVOSR_DT_GLOBAL_COOP);    // (frames in global memory: 26 k -> 19 k sets/s with it at 20 000 points)   // hinted triangles taken in a row before the lane goes back to searching
 
-struct DtPlan { uint32_t S, oid, od, astart, cs, arena, big, hard, wrows, red, misc, aff, total, out_bytes; int max_cells, arena_cap; };
+struct DtPlan { uint32_t S, oid, od, astart, cs, arena, big, hard, wrows, red, misc, wsl, aff, total, out_bytes; int max_cells, arena_cap; };
 constexpr int kDtMaxCellsGlobal = 32768;
 constexpr int kDtMaxPointsGlobal = 32000;      // (row arena indices and point ids are 16-bit)
 
@@ -213,12 +218,14 @@ __host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false, int 
         p.red = p.wrows + rows2;                          // doubles: block reductions
     }
     p.misc = p.red + 8u * 4u * (uint32_t)waves;
-    p.aff = p.misc + 4u * 64u;                           // u8 per sorted index (LDS variant): the star has to be built (see seed_info)
+    p.wsl = p.misc + 4u * 64u;                           // int [4][16]: per-wavefront counts and partial sums (up to 16 wavefronts)
+    p.aff = p.wsl + 4u * 64u;                            // u8 per sorted index (LDS variant): the star has to be built (see seed_info)
     p.total = p.aff + (global ? 0u : npad);
     return p;
 }
 
-enum { DM_FLAGS = 0, DM_ARENA = 1, DM_VQ = 2, DM_NHARD = 3, DM_NEXT = 4, DM_WCNT = 8 /* [8..15] */, DM_WSUM = 16 /* [16..23] */, DM_WSUM2 = 24, DM_WSUM3 = 32 };
+enum { DM_FLAGS = 0, DM_ARENA = 1, DM_VQ = 2, DM_NHARD = 3, DM_NEXT = 4 };
+enum { DW_CNT = 0, DW_SUM = 16, DW_SUM2 = 32, DW_SUM3 = 48 };        // wsl[]: 16 slots each
 
 struct DtGrid {
     double lo_u, lo_v, ix, iy, sx, sy;
@@ -473,6 +480,7 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
     uint16_t *hard = reinterpret_cast<uint16_t *>(small + L.hard);
     double *red = reinterpret_cast<double *>(small + L.red);
     int *misc = reinterpret_cast<int *>(small + L.misc);
+    int *wsl = reinterpret_cast<int *>(small + L.wsl);
     uint8_t *aff = reinterpret_cast<uint8_t *>(small + L.aff);
     const size_t hint_pts = (size_t)((a.max_pts + 7) & ~7);
     uint32_t *hints = (kDtHintsOn<GLOBAL> && a.hints) ? a.hints + (size_t)f * ((size_t)(kDtHintK + 3) * hint_pts) : nullptr;
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
     }
     {
         const double a0 = dt_wave_min(lo_u), a1 = dt_wave_min(-hi_u), a2 = dt_wave_min(lo_v), a3 = dt_wave_min(-hi_v);
-        if (lane == 0) { red[4 * w] = a0; red[4 * w + 1] = a1; red[4 * w + 2] = a2; red[4 * w + 3] = a3; misc[DM_WCNT + w] = wcnt; }
+        if (lane == 0) { red[4 * w] = a0; red[4 * w + 1] = a1; red[4 * w + 2] = a2; red[4 * w + 3] = a3; wsl[DW_CNT + w] = wcnt; }
         if (tid < 8) misc[tid] = tid == DM_NEXT ? BLOCK : 0;
 #ifdef MVOSR_STAMPS
         if ((tid >= 40 && tid < 64) || (tid >= 24 && tid < 40)) misc[tid] = 0;    // (24..39: scratch of the last stage, free until then)
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
     lo_u = INFINITY; hi_u = INFINITY; lo_v = INFINITY; hi_v = INFINITY;
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) {
-        const int c = misc[DM_WCNT + i];
+        const int c = wsl[DW_CNT + i];
         if (i < w) rank_base += c;
         n += c;
         lo_u = fmin(lo_u, red[4 * i]); hi_u = fmin(hi_u, red[4 * i + 1]); lo_v = fmin(lo_v, red[4 * i + 2]); hi_v = fmin(hi_v, red[4 * i + 3]);
@@ -571,11 +579,11 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
         int mine = 0;
         for (int c = c0; c < c1; ++c) mine += (int)cs[c];
         const int incl = dt_incl_scan(mine);
-        if (lane == kWave - 1) misc[DM_WSUM + w] = incl;
+        if (lane == kWave - 1) wsl[DW_SUM + w] = incl;
         __syncthreads();
         int base = 0;
 #pragma unroll
-        for (int i = 0; i < WAVES; ++i) if (i < w) base += misc[DM_WSUM + i];
+        for (int i = 0; i < WAVES; ++i) if (i < w) base += wsl[DW_SUM + i];
         int at = base + incl - mine;
         for (int c = c0; c < c1; ++c) { const int k = (int)cs[c]; cs[c] = (uint32_t)at; at += k; }
     }
@@ -1224,15 +1232,15 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
         for (int o = o0; o < o1; ++o) { const int d = od[o]; mine += d & 63; sdeg += (d >> 6) & 63; hull += (d >> 15) & 1; }
         const int incl = dt_incl_scan(mine);
         const int wdeg = wave_sum(sdeg), whull = wave_sum(hull);
-        if (lane == kWave - 1) misc[DM_WSUM + w] = incl;
-        if (lane == 0) { misc[DM_WSUM2 + w] = wdeg; misc[DM_WSUM3 + w] = whull; }
+        if (lane == kWave - 1) wsl[DW_SUM + w] = incl;
+        if (lane == 0) { wsl[DW_SUM2 + w] = wdeg; wsl[DW_SUM3 + w] = whull; }
         __syncthreads();
         int base = 0, total = 0, tdeg = 0, thull = 0;
 #pragma unroll
         for (int i = 0; i < WAVES; ++i) {
-            const int c = misc[DM_WSUM + i];
+            const int c = wsl[DW_SUM + i];
             if (i < w) base += c;
-            total += c; tdeg += misc[DM_WSUM2 + i]; thull += misc[DM_WSUM3 + i];
+            total += c; tdeg += wsl[DW_SUM2 + i]; thull += wsl[DW_SUM3 + i];
         }
         int why = misc[DM_FLAGS];
         if (total != 2 * n - 2 - thull || tdeg != 3 * total) why |= DT_WHY_EULER;
@@ -1380,9 +1388,14 @@ extern "C" int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const i
     int waves = kDtWaves, per_cu = 1;
     bool arena_out = false;
     if (kDtSmallLadder && n_frames >= kDtLadderMinFrames) dt_ladder(max_pts, waves, arena_out, per_cu);
+    // A launch of a few frames (the per-frame call of /root/reference/src/main.py:110-113: ONE) leaves most CUs idle and its length is
+    // one frame's: sixteen wavefronts per frame — four per SIMD instead of two: the lanes' dependent steps overlap, and a
+    // lane walks two stars instead of four
+    else if (kDtWide16 && n_frames <= kDtWide16MaxFrames && max_pts >= 256) waves = 16;
     const DtPlan LP = dt_plan(max_pts, false, waves, arena_out);
     lds = LP.total;
-    const void *kfn = (arena_out && waves == 4) ? reinterpret_cast<const void *>(delaunay_kernel<false, 4, true>)
+    const void *kfn = waves == 16 ? reinterpret_cast<const void *>(delaunay_kernel<false, 16>)
+                    : (arena_out && waves == 4) ? reinterpret_cast<const void *>(delaunay_kernel<false, 4, true>)
                     : arena_out ? reinterpret_cast<const void *>(delaunay_kernel<false, 8, true>)
                     : waves == 2 ? reinterpret_cast<const void *>(delaunay_kernel<false, 2>)
                     : waves == 4 ? reinterpret_cast<const void *>(delaunay_kernel<false, 4>) : reinterpret_cast<const void *>(delaunay_kernel<false>);
@@ -1399,7 +1412,8 @@ extern "C" int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const i
             a.aws = reinterpret_cast<char *>(ws) + hint_bytes;
         }
     }
-    if (arena_out && waves == 4) hipLaunchKernelGGL((delaunay_kernel<false, 4, true>), dim3((unsigned)n_frames), dim3(4 * kWave), lds, ctx_stream(ctx), a);
+    if (waves == 16) hipLaunchKernelGGL((delaunay_kernel<false, 16>), dim3((unsigned)n_frames), dim3(16 * kWave), lds, ctx_stream(ctx), a);
+    else if (arena_out && waves == 4) hipLaunchKernelGGL((delaunay_kernel<false, 4, true>), dim3((unsigned)n_frames), dim3(4 * kWave), lds, ctx_stream(ctx), a);
     else if (arena_out) hipLaunchKernelGGL((delaunay_kernel<false, 8, true>), dim3((unsigned)n_frames), dim3(kDtBlock), lds, ctx_stream(ctx), a);
     else if (waves == 2) hipLaunchKernelGGL((delaunay_kernel<false, 2>), dim3((unsigned)n_frames), dim3(2 * kWave), lds, ctx_stream(ctx), a);
     else if (waves == 4) hipLaunchKernelGGL((delaunay_kernel<false, 4>), dim3((unsigned)n_frames), dim3(4 * kWave), lds, ctx_stream(ctx), a);
