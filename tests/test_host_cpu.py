@@ -174,6 +174,36 @@ def test_c_packer_wide_path_and_thread_pool():
     assert os.waitpid(pid, 0)[1] == 0
 
 
+def test_pin_thread_to_node_respects_what_it_finds():
+    """_lib.pin_thread_to_node (the binding keeps a process that opens a context on the device's NUMA node): unknown node, the
+    opt-out, a thread already confined to one node and a node without CPUs of ours leave the affinity alone; a real node
+    narrows it to that node's CPUs (and the test puts it back)."""
+    import glob
+    import os
+    from mvoscalerecovery_amd import _lib
+    if not hasattr(os, "sched_getaffinity"):
+        pytest.skip("no sched_getaffinity")
+    before = os.sched_getaffinity(0)
+    try:
+        assert _lib.pin_thread_to_node(-1) is None and _lib.pin_thread_to_node(None) is None
+        assert _lib.pin_thread_to_node(4096) is None                       # no such node
+        os.environ["MVOSR_AFFINITY"] = "0"
+        assert _lib.pin_thread_to_node(0) is None
+        del os.environ["MVOSR_AFFINITY"]
+        assert os.sched_getaffinity(0) == before
+        nodes = sorted(glob.glob("/sys/devices/system/node/node[0-9]*/cpulist"))
+        got = _lib.pin_thread_to_node(0) if nodes else None
+        if got is not None:                                                # more than one node, and we were on several
+            assert got < before and got == os.sched_getaffinity(0) and got <= _lib._cpulist(open(nodes[0]).read())
+            assert _lib.pin_thread_to_node(0) is None                      # confined to one node now: left alone
+        else:
+            assert os.sched_getaffinity(0) == before
+        assert _lib._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    finally:
+        os.environ.pop("MVOSR_AFFINITY", None)
+        os.sched_setaffinity(0, before)
+
+
 def test_slew_median_host_equals_the_references_recurrence():
     """mvosr_slew_median_host (no GPU): the slew limiter and window median of /root/reference/src/rescale.py:169-178 written
     out in Python — jumps beyond +-0.3, frames without a plane, a NaN scale that sticks, a carried-in queue."""
