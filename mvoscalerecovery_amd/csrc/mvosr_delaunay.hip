@@ -185,7 +185,7 @@ constexpr int kDtMaxCellsGlobal = 32768;
 constexpr int kDtMaxPointsGlobal = 32000;      // (row arena indices and point ids are 16-bit)
 
 __host__ __device__ inline int dt_cell_cap(int max_pts, bool global) {
-    int c = (int)((double)max_pts / kDtPerCell * 1.25) + 64;
+    int c = (int)((double)max_pts / kDtPerCell * 1.15) + 64;        // (an elongated frame's grid may want more: it is then made coarser, see the kernel)
     const int cap = global ? kDtMaxCellsGlobal : kDtMaxCells;
     return c > cap ? cap : c;
 }
@@ -215,12 +215,15 @@ __host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false, int 
     p.wrows = p.hard + 2u * kDtHardCap;                  // u32 [groups of 16 lanes][kDtWaveRows] (phase 2)
     {
         const uint32_t rows2 = 4u * (uint32_t)(waves * kWave / 16) * kDtWaveRows;
-        p.red = p.wrows + rows2;                          // doubles: block reductions
+        // (the flags of the stars to walk — aff, a byte per point, LDS variant — are dead when phase 1 begins, phase 2's rows
+        // are not alive before: they share their room)
+        const uint32_t affb = global ? 0u : ((npad + 7u) & ~7u);
+        p.aff = p.wrows;
+        p.red = p.wrows + (rows2 > affb ? rows2 : affb);  // doubles: block reductions
     }
     p.misc = p.red + 8u * 4u * (uint32_t)waves;
     p.wsl = p.misc + 4u * 64u;                           // int [4][16]: per-wavefront counts and partial sums (up to 16 wavefronts)
-    p.aff = p.wsl + 4u * 64u;                            // u8 per sorted index (LDS variant): the star has to be built (see seed_info)
-    p.total = p.aff + (global ? 0u : npad);
+    p.total = p.wsl + 4u * 64u;
     return p;
 }
 

@@ -478,12 +478,12 @@ def test_seeded_second_triangulation_equals_scipy_on_the_survivors(gpu):
                                            tri1.ptr, c2.ptr, None, s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr) != 0
 
 
-@pytest.mark.parametrize("n_max", [40, 470, 520, 1000, 1100, 1500, 1700, 2040, 2100, 2500, 3050, 3300])
+@pytest.mark.parametrize("n_max", [40, 470, 530, 1000, 1120, 1140, 1500, 2000, 2160, 2180, 2500, 3300, 3320])
 def test_delaunay_small_frame_variants(gpu, n_max):
     """The launcher's instantiations by the batch's largest frame: two wavefronts per frame while eight frames' arrays fit a
-    CU's LDS (up to ~500 points), four while four fit (~1 050), four with the rows' arena in global memory while three fit
-    (~2 050), eight (two frames per CU) with the arena in LDS up to ~2 350 and in global memory up to ~3 100, eight with one frame
-    per CU above: ragged batches sized on either side of every limit, tiny and degenerate frames among them, first and seeded
+    CU's LDS (up to ~520 points), four while four fit (~1 120), four with the rows' arena in global memory while three fit
+    (~2 160), eight (two frames per CU) with the arena in LDS or in global memory up to ~3 300, eight with one frame per CU
+    above: ragged batches sized on either side of every limit, tiny and degenerate frames among them, first and seeded
     second triangulation (untouched stars carried over) against SciPy."""
     from scipy.spatial import Delaunay
     from mvoscalerecovery_amd import _lib, packing, synth
