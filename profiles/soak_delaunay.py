@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of mvosr_delaunay_batch / _seeded against scipy.spatial.Delaunay (canonical rows): random point sets of several
 distributions and sizes, plus a second triangulation over a random 40-97 % of each set seeded with the first.
-    python profiles/soak_delaunay.py [rounds]      (160 sets per round)"""
+    [SOAK_SETS=520 SOAK_NMAX=2150] python profiles/soak_delaunay.py [rounds]      (160 sets per round by default)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +11,9 @@ from scipy.spatial import Delaunay
 from fractions import Fraction as Fr
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+# SOAK_SETS (160) sets per launch of up to SOAK_NMAX (4700) points: 512 sets and more let the launcher pick its small-frame and
+# arena-out instantiations by the largest set (SOAK_SETS=520 SOAK_NMAX=2150 / 3300 / 1100 / 500)
+SETS, NMAX = int(os.environ.get("SOAK_SETS", "160")), int(os.environ.get("SOAK_NMAX", "4700"))
 
 
 def empty_circle_violations(p, tris, verts):
@@ -38,8 +41,8 @@ rng = np.random.default_rng(31337)
 total = bad = declined = bad2 = declined2 = qhull_inexact = device_wrong = qhull_inexact2 = device_wrong2 = 0
 for rnd in range(rounds):
     sets = []
-    for k in range(160):
-        n = int(rng.integers(4, 4700))
+    for k in range(SETS):
+        n = int(rng.integers(4, NMAX))
         kind = k % 6
         if kind == 0: p = rng.uniform(0, 1, (n, 2)) * [1241.0, 376.0]
         elif kind == 1: p = rng.normal(0, 1, (n, 2)) * [300.0, 40.0] + [600, 200]
