@@ -1394,7 +1394,7 @@ extern "C" int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const i
     // A launch of a few frames (the per-frame call of /root/reference/src/main.py:110-113: ONE) leaves most CUs idle and its length is
     // one frame's: sixteen wavefronts per frame — four per SIMD instead of two: the lanes' dependent steps overlap, and a
     // lane walks two stars instead of four
-    else if (kDtWide16 && n_frames <= kDtWide16MaxFrames && max_pts >= 256) waves = 16;
+    else if (kDtWide16 && n_frames <= kDtWide16MaxFrames && max_pts >= 256 && dt_plan(max_pts, false, 16).total <= 160u * 1024u) waves = 16;   // (its phase-2 rows are 6 KB more: the largest LDS frames keep eight)
     const DtPlan LP = dt_plan(max_pts, false, waves, arena_out);
     lds = LP.total;
     const void *kfn = waves == 16 ? reinterpret_cast<const void *>(delaunay_kernel<false, 16>)

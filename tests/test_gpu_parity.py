@@ -478,6 +478,34 @@ def test_seeded_second_triangulation_equals_scipy_on_the_survivors(gpu):
                                            tri1.ptr, c2.ptr, None, s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr) != 0
 
 
+def test_delaunay_few_frames_up_to_the_lds_limit(gpu):
+    """Launches of a few frames run sixteen wavefronts per frame where that fits the LDS and eight where it does not (the
+    largest LDS-resident frames): one frame of mvosr_delaunay_lds_points() points, and five frames around the limits, against
+    SciPy."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import _lib, packing
+    top = int(gpu.lib.mvosr_delaunay_lds_points())
+    rng = np.random.default_rng(4)
+    for sizes in ([top], [top - 150, 4300, 3000, 300, 255], [4500, 2000]):
+        sets = [np.ascontiguousarray(rng.uniform(0, 1, (m, 2)) * [1241.0, 376.0]) for m in sizes]
+        cnt = np.array(sizes, dtype=np.int32)
+        off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+        uv = np.concatenate(sets)
+        d_u, d_v = gpu.to_device(np.ascontiguousarray(uv[:, 0])), gpu.to_device(np.ascontiguousarray(uv[:, 1]))
+        d_off, d_cnt, d_toff = gpu.to_device(off), gpu.to_device(cnt), gpu.to_device(2 * off)
+        tri = gpu.empty((int(2 * cnt.sum()), 3), np.int32)
+        c1, s1 = gpu.zeros(len(sizes), np.int32), gpu.zeros(len(sizes), np.int32)
+        _lib.check(gpu.lib.mvosr_delaunay_batch(gpu.handle, len(sizes), d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, int(cnt.max()), d_toff.ptr,
+                                                tri.ptr, c1.ptr, None, s1.ptr), "delaunay")
+        t, n1, h1 = tri.download(), c1.download(), s1.download()
+        for f, q in enumerate(sets):
+            assert h1[f] == 0, (sizes, f)
+            a = int(2 * off[f])
+            assert np.array_equal(t[a:a + n1[f]], packing.canonical_rows(Delaunay(q).simplices)), (sizes, f)
+        for b in (d_u, d_v, d_off, d_cnt, d_toff, tri, c1, s1):
+            b.free()
+
+
 @pytest.mark.parametrize("n_max", [40, 470, 530, 1000, 1120, 1140, 1500, 2000, 2160, 2180, 2500, 3300, 3320])
 def test_delaunay_small_frame_variants(gpu, n_max):
     """The launcher's instantiations by the batch's largest frame: two wavefronts per frame while eight frames' arrays fit a
