@@ -19,7 +19,7 @@ while time.time() < t_end:
     big = rng.uniform() < 0.35          # a chunk that fills the GPU: the Delaunay kernel's two- / four-wavefront instantiations
     if big:
         F = int(rng.integers(520, 1400))
-        sizes = rng.integers(60, int(rng.choice([450, 1100, 1500])), F)
+        sizes = rng.integers(60, int(rng.choice([450, 1100, 1500, 2100, 3200])), F)
     else:
         F = int(rng.integers(40, 400))
         sizes = rng.integers(150, 2600, F)
