@@ -131,8 +131,8 @@ struct DtArgs {
 
 #ifdef MVOSR_STAMPS
 static unsigned long long *g_dt_stamps = nullptr;
-#define DT_STAMP(i) do { if (tid == 0 && a.stamps) a.stamps[48 * f + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define DT_NOTE(i, v) do { if (tid == 0 && a.stamps) a.stamps[48 * f + (i)] = (unsigned long long)(v); } while (0)
+#define DT_STAMP(i) do { if (tid == 0 && a.stamps) a.stamps[64 * f + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DT_NOTE(i, v) do { if (tid == 0 && a.stamps) a.stamps[64 * f + (i)] = (unsigned long long)(v); } while (0)
 #else
 #define DT_STAMP(i) do {} while (0)
 #define DT_NOTE(i, v) do {} while (0)
@@ -514,6 +514,30 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
     const int s_begin = w * per, s_end = min(n_in, s_begin + per);
     double lo_u = INFINITY, hi_u = -INFINITY, lo_v = INFINITY, hi_v = -INFINITY;
     int wcnt = 0;
+    // A lane's points — up to kDtOwn of them: 2 048 points on four wavefronts — stay in registers for the three passes that need
+    // them (bounding box, count, scatter): loaded once, all at once.  (Each pass loaded them again, one dependent global load
+    // per point and pass: the scatter alone was 73 k of a carried-over second triangulation's 930 k cycles.)
+    constexpr int kDtOwn = 8;
+    const bool own = per <= kDtOwn * kWave;
+    double own_u[kDtOwn], own_v[kDtOwn];
+    int own_pos[kDtOwn];                                        // (where the scatter put them)
+    unsigned own_k = 0u;
+    if (own) {
+#pragma unroll
+        for (int r = 0; r < kDtOwn; ++r) {
+            const int i = s_begin + r * kWave + lane;
+            bool k = i < s_end;
+            if (k && gk) k = gk[i] >= 0;
+            own_k |= k ? (1u << r) : 0u;
+            own_u[r] = k ? gu[i] : 0.0; own_v[r] = k ? gv[i] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < kDtOwn; ++r) {
+            const bool k = (own_k >> r) & 1u;
+            if (k) { lo_u = fmin(lo_u, own_u[r]); hi_u = fmax(hi_u, own_u[r]); lo_v = fmin(lo_v, own_v[r]); hi_v = fmax(hi_v, own_v[r]); }
+            wcnt += __popcll(__ballot(k));
+        }
+    } else
     for (int i0 = s_begin; i0 < s_end; i0 += kWave) {
         const int i = i0 + lane;
         bool k = i < s_end;
@@ -563,11 +587,16 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
     }
     const int ncell = G.gx * G.gy;
     DT_STAMP(1);
+    DT_STAMP(48);
     for (int c = tid - 1; c <= ncell; c += BLOCK) cs[c] = 0u;          // (from cs[-1] on)
     for (int i = tid; i < ((n + 1) >> 1); i += BLOCK) reinterpret_cast<uint32_t *>(od)[i] = 0u;
     __syncthreads();
 
     // ---- pass 1: points per cell
+    if (own) {
+#pragma unroll
+        for (int r = 0; r < kDtOwn; ++r) if ((own_k >> r) & 1u) atomicAdd(&cs[G.celly(own_v[r]) * G.gx + G.cellx(own_u[r])], 1u);
+    } else
     for (int i0 = s_begin; i0 < s_end; i0 += kWave) {
         const int i = i0 + lane;
         bool k = i < s_end;
@@ -575,6 +604,7 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
         if (k) atomicAdd(&cs[G.celly(gv[i]) * G.gx + G.cellx(gu[i])], 1u);
     }
     __syncthreads();
+    DT_STAMP(49);
     // exclusive scan over the cells (cs[c] = start of cell c; pass 2 advances it to the cell's end)
     {
         const int cper = (ncell + BLOCK - 1) / BLOCK;
@@ -591,9 +621,26 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
         for (int c = c0; c < c1; ++c) { const int k = (int)cs[c]; cs[c] = (uint32_t)at; at += k; }
     }
     __syncthreads();
+    DT_STAMP(50);
     // ---- pass 2: scatter (the order inside a cell is whatever the atomics give: no output depends on it)
     {
         int rank = rank_base;
+        if (own) {
+#pragma unroll
+            for (int r = 0; r < kDtOwn; ++r) {
+                const bool k = (own_k >> r) & 1u;
+                const unsigned long long m = __ballot(k);
+                if (k) {
+                    double2 p; p.x = own_u[r]; p.y = own_v[r];
+                    const int pos = (int)atomicAdd(&cs[G.celly(p.y) * G.gx + G.cellx(p.x)], 1u);
+                    S[pos] = p;
+                    oid[pos] = (uint16_t)(rank + __popcll(m & ((1ull << lane) - 1ull)));
+                    if (inv) __hip_atomic_store(inv + (s_begin + r * kWave + lane), (uint32_t)pos, __ATOMIC_RELAXED, kDtScope);
+                    own_pos[r] = pos;
+                }
+                rank += __popcll(m);
+            }
+        } else
         for (int i0 = s_begin; i0 < s_end; i0 += kWave) {
             const int i = i0 + lane;
             bool k = i < s_end;
@@ -610,6 +657,7 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
         }
     }
     __syncthreads();
+    DT_STAMP(51);
     // carry: stars without a lost neighbour are copied from the seed triangulation instead of walked (LDS variant, seeds with info)
     const bool carry = !GLOBAL && inv && order && a.seed_info && a.seed_cnt[f] > 0;
     int n_work = n;                                           // points whose star phase 1 builds
@@ -619,22 +667,59 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
         if (carry) {
             for (int j = tid; j < n; j += BLOCK) aff[j] = 0;
             __syncthreads();
-            // a seed row that lost a vertex: its other vertices' stars change
-            for (int r = tid; r < ns; r += BLOCK) {
-                const int ra = st[3 * r], rb = st[3 * r + 1], rc = st[3 * r + 2];
-                if ((unsigned)ra >= (unsigned)n_in || (unsigned)rb >= (unsigned)n_in || (unsigned)rc >= (unsigned)n_in) continue;
-                const uint32_t pa = __hip_atomic_load(inv + ra, __ATOMIC_RELAXED, kDtScope);
-                const uint32_t pb = __hip_atomic_load(inv + rb, __ATOMIC_RELAXED, kDtScope);
-                const uint32_t pc = __hip_atomic_load(inv + rc, __ATOMIC_RELAXED, kDtScope);
-                const bool ka = pa < (uint32_t)n, kb = pb < (uint32_t)n, kc = pc < (uint32_t)n;
-                if (ka && kb && kc) continue;
-                if (ka) aff[pa] = 1;
-                if (kb) aff[pb] = 1;
-                if (kc) aff[pc] = 1;
+            // a seed row that lost a vertex: its other vertices' stars change.  (Four rows at a time: their twelve ids, then their
+            // twelve positions, are in flight together — one row at a time was fifteen times two dependent global loads per lane.)
+            for (int r0 = tid; r0 < ns; r0 += 4 * BLOCK) {
+                int ids[4][3];
+                uint32_t ps[4][3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = min(r0 + q * BLOCK, ns - 1);
+                    ids[q][0] = st[3 * r]; ids[q][1] = st[3 * r + 1]; ids[q][2] = st[3 * r + 2];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        ps[q][c] = (unsigned)ids[q][c] < (unsigned)n_in ? __hip_atomic_load(inv + ids[q][c], __ATOMIC_RELAXED, kDtScope) : 0xFFFFFFFEu;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (r0 + q * BLOCK >= ns) continue;
+                    if (ps[q][0] == 0xFFFFFFFEu || ps[q][1] == 0xFFFFFFFEu || ps[q][2] == 0xFFFFFFFEu) continue;     // (an id out of range: not a row of this frame)
+                    const bool ka = ps[q][0] < (uint32_t)n, kb = ps[q][1] < (uint32_t)n, kc = ps[q][2] < (uint32_t)n;
+                    if (ka && kb && kc) continue;
+                    if (ka) aff[ps[q][0]] = 1;
+                    if (kb) aff[ps[q][1]] = 1;
+                    if (kc) aff[ps[q][2]] = 1;
+                }
             }
             __syncthreads();
+            DT_STAMP(52);
             // the unchanged stars' bookkeeping: row count, degree and hull flag as they were, room for the rows
             const uint32_t *info = a.seed_info + off;
+            if (own) {
+                // (a lane's own points again: their positions are in registers, their facts loaded together, and the room for
+                // a wavefront's rows is one prefix sum and one LDS atomic instead of one atomic per point)
+                uint32_t wds[kDtOwn];
+#pragma unroll
+                for (int r = 0; r < kDtOwn; ++r) wds[r] = ((own_k >> r) & 1u) ? info[s_begin + r * kWave + lane] : 0u;
+#pragma unroll
+                for (int r = 0; r < kDtOwn; ++r) {
+                    const bool k = ((own_k >> r) & 1u) && !aff[own_pos[r]];
+                    const int nown = k ? (int)(wds[r] & 63u) : 0;
+                    const int incl = dt_incl_scan(nown);
+                    const int tot = __builtin_amdgcn_readlane(incl, kWave - 1);
+                    int base = 0;
+                    if (lane == 0 && tot) base = atomicAdd(&misc[DM_ARENA], tot);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const int at = base + incl - nown;
+                    if (!k) continue;
+                    if (at + nown > L.arena_cap) { atomicOr(&misc[DM_FLAGS], (int)DT_WHY_ROWS); aff[own_pos[r]] = 1; continue; }
+                    const int o = oid[own_pos[r]];
+                    od[o] = (uint16_t)(wds[r] & 0xFFFFu);
+                    astart[o] = (uint16_t)at;
+                }
+            } else
             for (int i0 = tid; i0 < n_in; i0 += BLOCK) {
                 const uint32_t pos = __hip_atomic_load(inv + i0, __ATOMIC_RELAXED, kDtScope);
                 if (pos >= (uint32_t)n || aff[pos]) continue;
@@ -647,6 +732,7 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
                 astart[o] = (uint16_t)at;
             }
             __syncthreads();
+            DT_STAMP(53);
         }
         // the seeds' corners into the hint caches (orientation from the points: the rows are in canonical, not in
         // counter-clockwise order); with carry: only where a star that will be walked reads them, and the unchanged
@@ -686,6 +772,7 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
             }
         }
         __syncthreads();
+        DT_STAMP(54);
     }
     if (order) {
         // The points are taken cell colour by cell colour — (x & 1, y & 1): all even/even cells first, and so on.  In the
@@ -1122,9 +1209,9 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
 #ifdef MVOSR_STAMPS
     DT_NOTE(10, misc[48]); DT_NOTE(11, misc[49]); DT_NOTE(12, misc[50]); DT_NOTE(13, misc[51]);
     DT_NOTE(26, misc[61]); DT_NOTE(27, misc[62]); DT_NOTE(28, misc[63]);
-    if (tid == 0 && a.stamps) for (int k = 0; k < 16; ++k) a.stamps[48 * f + 32 + k] = (unsigned long long)misc[24 + k];
+    if (tid == 0 && a.stamps) for (int k = 0; k < 16; ++k) a.stamps[64 * f + 32 + k] = (unsigned long long)misc[24 + k];
     DT_NOTE(29, misc[40]); DT_NOTE(30, misc[41]); DT_NOTE(31, misc[42]); DT_NOTE(7, misc[43]); DT_NOTE(8, misc[44]); DT_NOTE(14, misc[45]);
-    if (tid == 0 && a.stamps) for (int k = 52; k < 61; ++k) a.stamps[48 * f + 16 + (k - 52)] = (unsigned long long)misc[k];
+    if (tid == 0 && a.stamps) for (int k = 52; k < 61; ++k) a.stamps[64 * f + 16 + (k - 52)] = (unsigned long long)misc[k];
 #endif
 
     // The two passes below work in GROUPS of 16 lanes (a DPP row): a completion has a few dozen candidates at most, so

@@ -22,7 +22,7 @@ d_u, d_v = ctx.to_device(np.ascontiguousarray(uv[:, 0])), ctx.to_device(np.ascon
 d_off, d_cnt, d_toff = ctx.to_device(off), ctx.to_device(cnt), ctx.to_device(2 * off)
 d_tri = ctx.empty((2 * F * n, 3), np.int32)
 d_tcnt, d_st, d_used = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
-d_stamps = ctx.zeros((F, 48), np.uint64)
+d_stamps = ctx.zeros((F, 64), np.uint64)
 ctx.lib.mvosr_debug_dt_stamps.argtypes = [C.c_void_p]
 ctx.lib.mvosr_debug_dt_stamps(d_stamps.ptr)
 d_info = ctx.zeros(F * n, np.uint32)
@@ -69,3 +69,10 @@ for k, name in enumerate(SEC):
     print("    %-58s %5.1f %%" % (name, 100 * 16 * np.mean(s[:, 32 + k]) / tot1))
 print("  lane-pass scan steps by the wavefront's trips (0-11 / 12-23 / 24-35 / 36+): %s;  lanes by their own trips (0 / 1-12 / 13-24 / 25+): %s" % (
     " / ".join("%.0f" % np.mean(s[:, 44 + k]) for k in range(4)), " / ".join("%.0f" % np.mean(s[:, 40 + k]) for k in range(4))))
+if os.environ.get("DT_SEEDED"):
+    sub = ["zero the cell index", "count", "scan", "scatter (+ position table)", "mark the stars that lost a neighbour (seed rows, pass 1)",
+           "unchanged stars' bookkeeping", "seed rows pass 2 (arena copies, hints)", "order of the points to walk (until phase 1)"]
+    st = np.concatenate([s[:, 48:55], s[:, 2:3]], axis=1)
+    print("  between stamps 1 and 2 (cycles, median):")
+    for k, nm in enumerate(sub):
+        print("    %-62s %8.0f" % (nm, np.median(st[:, k + 1] - st[:, k])))
