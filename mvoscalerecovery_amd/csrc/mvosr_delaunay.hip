@@ -1337,14 +1337,33 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
         if (why) { decline(why, n); return; }
         int32_t *rows = a.tri + 3 * a.tri_off[f];
         int at = base + incl - mine;
-        for (int o = o0; o < o1; ++o) {
-            const int k = od[o] & 63;
-            if (a.info_out && !gk) a.info_out[off + o] = (uint32_t)od[o] | ((uint32_t)at << 16);    // (no keep mask: rank o = position o)
-            const uint32_t *src = arena + astart[o];
-            for (int j = 0; j < k; ++j) {
-                const uint32_t key = src[j];
-                rows[3 * at] = o; rows[3 * at + 1] = (int32_t)(key >> 16); rows[3 * at + 2] = (int32_t)(key & 0xFFFFu);
-                ++at;
+        // (a thread's points eight at a time: their starts, then their rows four at a time, are in flight together — with the
+        // arena in global memory every one of them is a load the next step waits for)
+        for (int ob = o0; ob < o1; ob += 8) {
+            int ks[8], sts[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int o = min(ob + q, o1 - 1);
+                ks[q] = ob + q < o1 ? (od[o] & 63) : 0;
+                sts[q] = astart[o];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int o = ob + q;
+                if (o >= o1) break;
+                if (a.info_out && !gk) a.info_out[off + o] = (uint32_t)od[o] | ((uint32_t)at << 16);    // (no keep mask: rank o = position o)
+                const uint32_t *src = arena + sts[q];
+                for (int j = 0; j < ks[q]; j += 4) {
+                    uint32_t key[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) key[c] = src[min(j + c, ks[q] - 1)];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (j + c >= ks[q]) break;
+                        rows[3 * at] = o; rows[3 * at + 1] = (int32_t)(key[c] >> 16); rows[3 * at + 2] = (int32_t)(key[c] & 0xFFFFu);
+                        ++at;
+                    }
+                }
             }
         }
         if (tid == 0) { a.tri_cnt[f] = total; a.status[f] = MVOSR_DT_OK; if (a.n_used) a.n_used[f] = n; }
