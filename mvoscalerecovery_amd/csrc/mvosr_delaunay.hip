@@ -703,21 +703,28 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
                 uint32_t wds[kDtOwn];
 #pragma unroll
                 for (int r = 0; r < kDtOwn; ++r) wds[r] = ((own_k >> r) & 1u) ? info[s_begin + r * kWave + lane] : 0u;
+                unsigned carried = 0u;
+                int mine_rows = 0;
 #pragma unroll
                 for (int r = 0; r < kDtOwn; ++r) {
                     const bool k = ((own_k >> r) & 1u) && !aff[own_pos[r]];
-                    const int nown = k ? (int)(wds[r] & 63u) : 0;
-                    const int incl = dt_incl_scan(nown);
-                    const int tot = __builtin_amdgcn_readlane(incl, kWave - 1);
-                    int base = 0;
-                    if (lane == 0 && tot) base = atomicAdd(&misc[DM_ARENA], tot);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    const int at = base + incl - nown;
-                    if (!k) continue;
+                    carried |= k ? (1u << r) : 0u;
+                    mine_rows += k ? (int)(wds[r] & 63u) : 0;
+                }
+                const int incl = dt_incl_scan(mine_rows);
+                const int tot = __builtin_amdgcn_readlane(incl, kWave - 1);
+                int base = 0;
+                if (lane == 0 && tot) base = atomicAdd(&misc[DM_ARENA], tot);
+                int at = __builtin_amdgcn_readfirstlane(base) + incl - mine_rows;
+#pragma unroll
+                for (int r = 0; r < kDtOwn; ++r) {
+                    if (!((carried >> r) & 1u)) continue;
+                    const int nown = (int)(wds[r] & 63u);
                     if (at + nown > L.arena_cap) { atomicOr(&misc[DM_FLAGS], (int)DT_WHY_ROWS); aff[own_pos[r]] = 1; continue; }
                     const int o = oid[own_pos[r]];
                     od[o] = (uint16_t)(wds[r] & 0xFFFFu);
                     astart[o] = (uint16_t)at;
+                    at += nown;
                 }
             } else
             for (int i0 = tid; i0 < n_in; i0 += BLOCK) {

@@ -73,6 +73,7 @@ if os.environ.get("DT_SEEDED"):
     sub = ["zero the cell index", "count", "scan", "scatter (+ position table)", "mark the stars that lost a neighbour (seed rows, pass 1)",
            "unchanged stars' bookkeeping", "seed rows pass 2 (arena copies, hints)", "order of the points to walk (until phase 1)"]
     st = np.concatenate([s[:, 48:55], s[:, 2:3]], axis=1)
+    sub = sub[:st.shape[1] - 1]
     print("  between stamps 1 and 2 (cycles, median):")
     for k, nm in enumerate(sub):
         print("    %-62s %8.0f" % (nm, np.median(st[:, k + 1] - st[:, k])))
