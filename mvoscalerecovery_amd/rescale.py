@@ -314,7 +314,7 @@ class ScaleEstimator:
     GPU_CHUNK = 8192            # frames per chunk, at most (a call of F frames uses chunks of F/4, 512 at least)
     GPU_RESIDENT = 512          # frames the GPU works on at once (two 8-wavefront workgroups per CU)
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk
-    GPU_RAMP_FRACTIONS = (0.125, 0.2, 0.33, 0.55)   # the short first chunks, as fractions of a full one (scale_calculator.py)
+    GPU_RAMP_FRACTIONS = (1 / 6, 1 / 3, 1 / 2, 2 / 3)   # the short first chunks, as fractions of a full one (scale_calculator.py)
     GPU_PIPELINE = 2            # chunks queued on the device behind the one being collected
     N_HYP = RANSAC_ITERATIONS
 

@@ -440,9 +440,10 @@ class ScaleEstimator:
         return raw, status, level, counts, host_errors, S[n - 1]
 
     GPU_RAMP = True                 # short first chunks (see _stream_gpu)
-    GPU_RAMP_FRACTIONS = (0.125, 0.2, 0.33, 0.55)   # their sizes, as fractions of a full chunk: each at most 1.7x the one before,
-                                    # the ratio of the GPU's time per frame to the host's (1/8, 1/4, 1/2 left the GPU waiting for the
-                                    # second and third chunk: 366-392 k frames/s at 2000 features, this ramp 391-396 k)
+    GPU_RAMP_FRACTIONS = (1 / 6, 1 / 3, 1 / 2, 2 / 3)   # their sizes, as fractions of a full chunk: with 2000-feature frames one, two,
+                                    # three and four whole rounds of the triangulation kernel's resident frames (768) before the
+                                    # six-round chunks.  (The shape barely matters any more — every ramp tried gave 520-530 k
+                                    # frames/s —: the pipeline's stages are balanced, PCIe at 6.5 ms per chunk against the GPU's 7.2.)
     GPU_PIPELINE = 2                # chunks queued on the device behind the one being collected (with the short first chunks 1 -> 2 is +3 % at 32 768 frames, +6 % at 16 384; 3: the same)
     GPU_CHUNK = 8192            # frames per chunk of the device-triangulation path, at most (a call of F frames uses chunks of F/4, 512 at least: the pipeline needs a few)
     GPU_RESIDENT = 512          # frames the GPU works on at once (two 8-wavefront workgroups per CU): chunks are multiples of it
