@@ -314,7 +314,7 @@ class ScaleEstimator:
     GPU_CHUNK = 8192            # frames per chunk, at most (a call of F frames uses chunks of F/4, 512 at least)
     GPU_RESIDENT = 512          # frames the GPU works on at once (two 8-wavefront workgroups per CU)
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk
-    GPU_RAMP_FRACTIONS = (1 / 6, 1 / 3, 1 / 2, 2 / 3)   # the short first chunks, as fractions of a full one (scale_calculator.py)
+    GPU_RAMP_FRACTIONS = (1 / 6, 1 / 3, 1 / 2, 2 / 3, 5 / 6)   # the short first chunks, as fractions of a full one (scale_calculator.py)
     GPU_PIPELINE = 2            # chunks queued on the device behind the one being collected
     N_HYP = RANSAC_ITERATIONS
 
@@ -506,6 +506,8 @@ class ScaleEstimator:
         results, bounds = [], []
         if self.triangulation == "gpu":
             C_ = int(min(self.GPU_CHUNK, max(512, -(-F // 4))))
+            mean_pts = max(1, sum(len(x) for x in feature3ds[:64]) // min(F, 64))
+            C_ = int(max(512, min(C_, self.GPU_CHUNK_POINTS // mean_pts)))     # (the points cap as it will bite: the short first chunks are fractions of that)
             # short first chunks (C/8, C/4, C/2): the GPU starts after the pack + upload of an eighth of a chunk
             ramp = [int(C_ * x) for x in self.GPU_RAMP_FRACTIONS] if (C_ >= 2048 and F >= 3 * C_) else []
             queue, a = [], 0

@@ -440,8 +440,8 @@ class ScaleEstimator:
         return raw, status, level, counts, host_errors, S[n - 1]
 
     GPU_RAMP = True                 # short first chunks (see _stream_gpu)
-    GPU_RAMP_FRACTIONS = (1 / 6, 1 / 3, 1 / 2, 2 / 3)   # their sizes, as fractions of a full chunk: with 2000-feature frames one, two,
-                                    # three and four whole rounds of the triangulation kernel's resident frames (768) before the
+    GPU_RAMP_FRACTIONS = (1 / 6, 1 / 3, 1 / 2, 2 / 3, 5 / 6)   # their sizes, as fractions of a full chunk: with 2000-feature frames one, two,
+                                    # three, four and five whole rounds of the triangulation kernel's resident frames (768) before the
                                     # six-round chunks.  (The shape barely matters any more — every ramp tried gave 520-530 k
                                     # frames/s —: the pipeline's stages are balanced, PCIe at 6.5 ms per chunk against the GPU's 7.2.)
     GPU_PIPELINE = 2                # chunks queued on the device behind the one being collected (with the short first chunks 1 -> 2 is +3 % at 32 768 frames, +6 % at 16 384; 3: the same)
@@ -537,6 +537,9 @@ class ScaleEstimator:
         # profiles/e2e_chunk_sweep.py; the points cap keeps 2000-feature frames at 5000 per chunk), but a call that is ONE chunk packs,
         # uploads and computes one after the other: at least four chunks per call, of 512 frames or more
         C = int(min(self.GPU_CHUNK, max(512, -(-F // 4))))
+        # (the points cap as it will bite, from the first frames' sizes: the short first chunks are fractions of THAT chunk)
+        mean_pts = max(1, sum(len(x) for x in feature3ds[:64]) // min(F, 64))
+        C = int(max(512, min(C, self.GPU_CHUNK_POINTS // mean_pts)))
         # chunks of at most GPU_CHUNK frames and GPU_CHUNK_POINTS features (a chunk's planes, rows and staging memory
         # scale with its points: dense frames travel in smaller chunks)
         # the first chunks are short (C/8, C/4, C/2): the GPU starts after the pack + upload of 1/8 chunk instead of a whole
