@@ -204,6 +204,19 @@ def test_pin_thread_to_node_respects_what_it_finds():
         os.sched_setaffinity(0, before)
 
 
+def test_delaunay_residency_query():
+    """mvosr_delaunay_frames_per_cu (host-side: what the batch paths round their chunks with): 8, 4, 3, 2, 1 frames per CU,
+    never more for a larger frame; one beyond the LDS-resident sizes."""
+    from mvoscalerecovery_amd import _lib
+    lib = _lib.load()
+    top = int(lib.mvosr_delaunay_lds_points())
+    vals = [int(lib.mvosr_delaunay_frames_per_cu(n)) for n in range(3, top + 200, 7)]
+    assert set(vals) <= {8, 4, 3, 2, 1} and vals[0] == 8 and vals[-1] == 1
+    assert all(a >= b for a, b in zip(vals, vals[1:]))
+    assert int(lib.mvosr_delaunay_frames_per_cu(2000)) == 3 and int(lib.mvosr_delaunay_frames_per_cu(0)) == 8
+    assert int(lib.mvosr_delaunay_frames_per_cu(top + 1)) == 1 and int(lib.mvosr_delaunay_frames_per_cu(20000)) == 1
+
+
 def test_slew_median_host_equals_the_references_recurrence():
     """mvosr_slew_median_host (no GPU): the slew limiter and window median of /root/reference/src/rescale.py:169-178 written
     out in Python — jumps beyond +-0.3, frames without a plane, a NaN scale that sticks, a carried-in queue."""
