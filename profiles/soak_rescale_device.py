@@ -17,7 +17,7 @@ if __name__ == "__main__":
     F = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     rng = np.random.default_rng(12)
     gpu = rescale.ScaleEstimator(1.75, window_size=5, triangulation="gpu", ransac_seed=77, delaunay_workers=4)
-    gpu.GPU_CHUNK = 24
+    gpu.GPU_CHUNK = int(os.environ.get("SOAK_CHUNK", "24"))       # (SOAK_CHUNK=8192 with 600 frames per batch: chunks of 512 frames and more take the triangulation kernel's small-frame and arena-out instantiations)
     ora = ro.OracleRescaleEstimator(1.75, window_size=5, device_seed=77)
     bad, worst, declined, frames_total = 0, 0.0, 0, 0
     for b in range(B):
