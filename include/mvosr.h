@@ -588,6 +588,23 @@ int mvosr_delaunay_lds_points(void);
  * then has no partly filled last round. */
 int mvosr_delaunay_frames_per_cu(int max_pts);
 
+/*
+ * SciPy/Qhull's rows themselves: the triangle set, the ORDER of the rows and the ROTATION of every row of
+ * scipy.spatial.Delaunay(points).simplices (/root/reference/src/scale_calculator.py:257-258, :266-267) — what the reference's
+ * check_triangle (:105-119) reads.  The kernel replays the beneath-beyond of the Qhull SciPy bundles (qhull_r 7.3.2,
+ * options `d Qbb Qc Qz Q12 Qt`) decision by decision, one wavefront per frame, for points in general position; a frame in
+ * which a decision falls inside a roundoff guard band (Qhull would merge facets) is declined like mvosr_delaunay_batch
+ * declines (status = MVOSR_DT_DEGENERATE | reason << 8, tri_cnt 0): the host triangulates it with SciPy.  Rows are meant for
+ * MVOSR_VOTE_REFERENCE: with them triangulation="gpu" IS the reference's result.  Arguments as mvosr_delaunay_batch;
+ * order_out (optional, laid out like u): the insertion step at which a point became a vertex (0: initial simplex), indexed
+ * by the point's rank among the kept points.  max_pts <= mvosr_delaunay_qhull_max_points() (8000: facet ids are 16-bit).
+ * Workspace: ~0.56 KB per point of the launch (n_frames * (max_pts + 1)), grow-only, in the context.
+ */
+int mvosr_delaunay_qhull_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                               const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
+                               int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status, int32_t *order_out);
+int mvosr_delaunay_qhull_max_points(void);
+
 /* LDS bytes the fused kernel requests for a frame of n features (host-side planning). */
 size_t mvosr_lds_bytes(int n_features);
 /* Largest frame the LDS-resident variant accepts on this build. */

@@ -1,0 +1,775 @@
+// mvosr_qhull.hip — SciPy/Qhull's Delaunay ROWS on the device: the triangle set AND the order of the rows AND the rotation of
+// every row, i.e. exactly `scipy.spatial.Delaunay(points2d).simplices` of /root/reference/src/scale_calculator.py:257-258 and
+// :266-267.  The reference's check_triangle (:105-119) reads the rotation of a row, and that rotation is Qhull's insertion
+// order (a row is the facet's vertices by decreasing vertex id, first two swapped for orientation): this kernel replays
+// Qhull's beneath-beyond (qhull_r 7.3.2 / 2019.1.r inside SciPy 1.15.3, options `d Qbb Qc Qz Q12 Qt`) decision for decision,
+// for sites in general position.  oracle/qhull_rows.py is the CPU restatement the tests compare it with; it carries the
+// step-by-step description.  A frame that leaves the general-position regime (a decision inside a roundoff guard band, a
+// merge, a narrow initial simplex) is DECLINED (status != 0): the host triangulates it with SciPy itself.
+//
+// One wavefront per frame; the algorithm is a chain of ~n dependent insertions, each a handful of dependent memory round
+// trips, so the GPU is filled with FRAMES (thousands of wavefronts), not with lanes: a frame's state (64 B per facet, ~5.6
+// facets per point over the run) lives in a slice of the context's workspace and is read through L2; the lanes of a
+// wavefront share the visibility search (three neighbours per visible facet at a time), build the cone's facets (one lane
+// each, planes in LDS) and partition the visible facets' points among them (one lane per point, a directed walk over the
+// cone in LDS).  What is order-dependent in Qhull is kept order-exact: the breadth-first visible list, the creation order of
+// the cone's facets, the arrival order inside every outside set (the furthest point rides last; a displaced furthest point
+// takes the arrival slot of its displacer), the point from which a 'sharp' cone switches the partition to a linear scan.
+#include "mvosr_device.hpp"
+#include "mvosr_host.hpp"
+
+using namespace mvosr;
+
+namespace {
+
+constexpr int kQhMaxPoints = 8000;        // facet ids are 16-bit: 7 * (n + 1) + 64 facets per run
+constexpr int kQhMaxNew = 64;             // facets of one cone (one lane each)
+constexpr int kQhMaxVis = 256;            // visible facets of one insertion
+constexpr double kQhEps = 2.220446049250313e-16;
+constexpr double kQhHuge = 1.797e308;
+constexpr uint16_t kQhNone = 0xFFFFu;
+
+enum QhWhy : int {
+    QH_OK = 0, QH_FEW_POINTS = 1, QH_ZERO_WIDTH = 2, QH_SIMPLEX_SEARCH = 3, QH_FLAT_SIMPLEX = 4, QH_NARROW = 5, QH_INSIDE_SIMPLEX = 6,
+    QH_BAND = 7, QH_COPLANAR_HORIZON = 8, QH_TOO_MANY_VISIBLE = 9, QH_CONE_TOO_LARGE = 10, QH_OPEN_CONE = 11, QH_NOT_CONVEX = 12,
+    QH_GAUSS = 13, QH_NOT_SHARP = 14, QH_ABOVE_NONE = 15, QH_FACETS_FULL = 16, QH_ARENA_FULL = 17, QH_VERTICAL = 18
+};
+
+struct __attribute__((aligned(16))) QhFacet {
+    uint16_t p[3];      // vertices as point ids, by decreasing vertex id (reverse insertion order)
+    uint16_t flags;     // 1 top-oriented, 2 upper Delaunay, 4 dead
+    uint16_t nb[3];     // neighbour k is opposite vertex k
+    uint16_t bestp;     // the outside set's furthest point (kQhNone: empty set)
+    uint32_t off;       // the rest of the outside set: arena[off .. off + cnt), in Qhull's list order
+    uint16_t cnt;
+    uint16_t mark;      // 2 * insertion + (visible ? 1 : 0) of the last visibility test
+    double bestd;
+    double n0, n1, n2, d;
+};
+static_assert(sizeof(QhFacet) == 64, "one facet per 64-byte line");
+
+struct QhArgs {
+    int64_t n_frames;
+    const int64_t *pts_off; const int32_t *pts_cnt; const double *u; const double *v; const int32_t *keep;
+    const int64_t *tri_off; int32_t *tri; int32_t *tri_cnt; int32_t *n_used; int32_t *status; int32_t *order_out;
+    char *ws; size_t ws_stride; int cap_pts;      // per-frame slice, laid out by QhPlan for cap_pts = max_pts + 1 points
+};
+
+struct QhPlan { size_t x, y, z, fac, arena, tt, dd, total; uint32_t fcap, acap; };
+__host__ __device__ inline QhPlan qh_plan(int cap_pts) {
+    QhPlan P;
+    const size_t n = (size_t)cap_pts;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    P.x = take(8 * n); P.y = take(8 * n); P.z = take(8 * n);
+    P.fcap = (uint32_t)(7 * n + 64); if (P.fcap > 65534u) P.fcap = 65534u;
+    P.fac = take(sizeof(QhFacet) * (size_t)(P.fcap + 1));
+    P.acap = (uint32_t)(28 * n + 256);
+    P.arena = take(2 * (size_t)P.acap);
+    P.tt = take(2 * n); P.dd = take(8 * n);
+    P.total = o;
+    return P;
+}
+
+struct QhLds {
+    double npl[kQhMaxNew][4];        // the cone's planes (n0, n1, n2, offset)
+    double nxy[kQhMaxNew][6];        // coordinates of a cone facet's two horizon vertices (convexity test between cone facets)
+    uint16_t nva[kQhMaxNew], nvb[kQhMaxNew];     // a cone facet's horizon vertices (point ids)
+    uint8_t nnb[kQhMaxNew][4];       // cone neighbours 1, 2 as cone-local indices; [3] = upper flag
+    uint16_t visq[kQhMaxVis];        // visible facets in Qhull's breadth-first order
+    uint16_t visnb[kQhMaxVis][3];
+    uint16_t visrep[kQhMaxVis];      // cone-local index of the visible facet's replacement (kQhNone: the first cone facet)
+    uint32_t visoff[kQhMaxVis];
+    uint16_t viscnt[kQhMaxVis];      // points of its outside set without the furthest
+    uint16_t visbest[kQhMaxVis];
+    uint32_t viscum[kQhMaxVis + 1];
+    uint16_t nhz[kQhMaxNew];         // a cone facet's horizon neighbour (facet id)
+    uint32_t t_off[kQhMaxNew]; uint32_t t_total[kQhMaxNew]; uint32_t t_cnt[kQhMaxNew]; uint16_t t_bestp[kQhMaxNew]; double t_bestd[kQhMaxNew];
+};
+
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
+__device__ __forceinline__ int ffs64(uint64_t m) { return __ffsll((long long)m) - 1; }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const double w = __shfl_xor(v, o); v = w > v ? w : v; }
+    return v;
+}
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const double w = __shfl_xor(v, o); v = w < v ? w : v; }
+    return v;
+}
+
+struct QhPlane { double n0, n1, n2, d; bool gauss; bool upper; };
+
+// qh_sethyperplane_det for three vertices (rows in the facet's vertex order), qh_normalize2, the offset; `gauss`: Qhull would
+// redo the plane by Gaussian elimination (a vertex further than DISTround from it) — not restated, the frame is declined.
+__device__ __forceinline__ QhPlane qh_plane(double x0, double y0, double z0, double x1, double y1, double z1, double x2, double y2, double z2,
+                                            bool top, double distround, double anground) {
+    QhPlane P;
+    const double dx1 = x1 - x0, dy1 = y1 - y0, dz1 = z1 - z0;
+    const double dx2 = x2 - x0, dy2 = y2 - y0, dz2 = z2 - z0;
+    double n0 = dy2 * dz1 - dz2 * dy1;
+    double n1 = dx1 * dz2 - dz1 * dx2;
+    double n2 = dx2 * dy1 - dy2 * dx1;
+    double norm = __builtin_sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+    P.gauss = !(norm > 1e-290);
+    if (!top) norm = -norm;
+    n0 = n0 / norm; n1 = n1 / norm; n2 = n2 / norm;
+    P.n0 = n0; P.n1 = n1; P.n2 = n2;
+    P.d = -(x0 * n0 + y0 * n1 + z0 * n2);
+    const double e2 = P.d + (x2 * n0 + y2 * n1 + z2 * n2);
+    const double e1 = P.d + (x1 * n0 + y1 * n1 + z1 * n2);
+    if (e2 > distround || e2 < -distround || e1 > distround || e1 < -distround) P.gauss = true;
+    P.upper = n2 > -anground * 2.0;
+    if (__builtin_fabs(n2) < 1e-9) P.gauss = true;
+    return P;
+}
+
+__device__ __forceinline__ double qh_dist(double x, double y, double z, double n0, double n1, double n2, double d) {
+    return d + x * n0 + y * n1 + z * n2;
+}
+
+struct QhConst { double distround, minvisible, minoutside, distoutside, guard, anground; };
+
+struct QhWalk { int tgt; double d; int state; int best; };     // state 0 placed, 1 ended below its best, 2 no best, 3 bad (band / above none)
+
+// qh_findbestnew over the cone in LDS: list order from `start`, wrapping; the first facet 2 MINoutside above wins
+__device__ __forceinline__ QhWalk qh_scan_cone(const QhLds &L, int m, int start, double x, double y, double z, const QhConst &K) {
+    QhWalk R; R.state = 3; R.tgt = 0; R.d = 0.0; R.best = -1;
+    double bestd = -kQhHuge;
+    bool bad = false;
+    for (int i = 0; i < m; ++i) {
+        int j = start + i; if (j >= m) j -= m;
+        const double d = qh_dist(x, y, z, L.npl[j][0], L.npl[j][1], L.npl[j][2], L.npl[j][3]);
+        if (d > -K.guard && d < K.guard) bad = true;
+        if (d > bestd && (!L.nnb[j][3] || d >= K.minoutside)) {
+            if (d >= K.distoutside) { R.tgt = j; R.d = d; R.state = bad ? 3 : 0; return R; }
+            bestd = d;
+        }
+    }
+    return R;         // above no cone facet by 2 MINoutside: Qhull goes on to qh_findbesthorizon — declined
+}
+
+// qh_findbest(isnewfacets): the directed walk; visited cone facets as a bit mask
+__device__ __forceinline__ QhWalk qh_walk_cone(const QhLds &L, int start, double x, double y, double z, const QhConst &K) {
+    QhWalk R; R.state = 0; R.best = -1;
+    bool bad = false;
+    double d = qh_dist(x, y, z, L.npl[start][0], L.npl[start][1], L.npl[start][2], L.npl[start][3]);
+    if (d > -K.guard && d < K.guard) bad = true;
+    if (d >= K.minoutside) { R.tgt = start; R.d = d; R.state = bad ? 3 : 0; return R; }
+    double bestd = d;
+    int best = L.nnb[start][3] ? -1 : start;
+    uint64_t seen = 1ull << start;
+    int f = start;
+    while (f >= 0) {
+        int nxt = -1;
+        for (int k = 1; k <= 2; ++k) {                      // neighbour 0 is the horizon facet (not new)
+            const int g = L.nnb[f][k];
+            if (seen >> g & 1ull) continue;
+            seen |= 1ull << g;
+            d = qh_dist(x, y, z, L.npl[g][0], L.npl[g][1], L.npl[g][2], L.npl[g][3]);
+            if (d > -K.guard && d < K.guard) bad = true;
+            if (d > bestd) {
+                if (d >= K.minoutside) { R.tgt = g; R.d = d; R.state = bad ? 3 : 0; return R; }
+                if (!L.nnb[g][3]) { best = g; bestd = d; nxt = g; break; }
+                else if (best < 0) { bestd = d; nxt = g; break; }
+            }
+        }
+        f = nxt;
+    }
+    R.tgt = 0; R.d = bestd; R.best = best;
+    R.state = bad ? 3 : (best < 0 ? 2 : (bestd < -K.distround ? 1 : 3));
+    return R;
+}
+
+// One chunk (<= 64 arrivals, lane order = Qhull's processing order) appended to the targets' outside sets: qh_partitionpoint's
+// list rule.  A target's list is arena[t_off .. t_off + t_cnt) + [t_bestp]; the furthest point stays last, a point that
+// arrives further than it takes over and the old one enters the list in the arrival's place.
+__device__ __forceinline__ void qh_place_chunk(QhLds &L, uint16_t *arena, bool valid, int tgt, int p, double d) {
+    const int lane = lane_id();
+    uint64_t rem = __ballot(valid);
+    while (rem) {
+        const int l0 = ffs64(rem);
+        const int g = __shfl(tgt, l0);
+        const bool in_g = valid && tgt == g;
+        const uint64_t grp = __ballot(in_g);
+        rem &= ~grp;
+        const double cbd = L.t_bestd[g];
+        const int cbp = L.t_bestp[g];
+        const uint32_t base = L.t_off[g] + L.t_cnt[g];
+        // inclusive scan of (d, lane): the later arrival wins only when strictly further
+        double sd = in_g ? d : -kQhHuge;
+        int si = lane;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double pd = __shfl_up(sd, o);
+            const int pi = __shfl_up(si, o);
+            if (lane >= o && !(sd > pd)) { sd = pd; si = pi; }
+        }
+        double ed = __shfl_up(sd, 1);
+        int ei = __shfl_up(si, 1);
+        if (lane == 0) { ed = -kQhHuge; ei = 0; }
+        const bool from_lanes = ed > cbd || (cbp == kQhNone && ed > -kQhHuge);       // the furthest before me arrived in this chunk
+        const double prevd = from_lanes ? ed : (cbp == kQhNone ? -kQhHuge : cbd);
+        const int ep = __shfl(p, ei);
+        const int prevp = from_lanes ? ep : cbp;
+        const bool record = in_g && (d > prevd || prevp == kQhNone);
+        const int entry = record ? prevp : p;
+        const bool has = in_g && entry != kQhNone;
+        const uint64_t hm = __ballot(has);
+        if (has) arena[base + popc64(hm & lanemask_lt())] = (uint16_t)entry;
+        const int lastl = 63 - __clzll((long long)grp);
+        const double gd = __shfl(sd, lastl);
+        const int gi = __shfl(si, lastl);
+        const int gp = __shfl(p, gi);
+        if (lane == 0) {
+            L.t_cnt[g] += (uint32_t)popc64(hm);
+            if (cbp == kQhNone || gd > cbd) { L.t_bestd[g] = gd; L.t_bestp[g] = (uint16_t)gp; }
+        }
+        __syncthreads();
+    }
+}
+
+// One frame, one wavefront.  Returns the reason the frame was declined (QH_OK: rows written, `nrows` of them).
+__device__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
+    const int lane = lane_id();
+    const QhPlan P = qh_plan(a.cap_pts);
+    char *ws = a.ws + (size_t)f * a.ws_stride;
+    double *X = reinterpret_cast<double *>(ws + P.x), *Y = reinterpret_cast<double *>(ws + P.y), *Z = reinterpret_cast<double *>(ws + P.z);
+    QhFacet *fac = reinterpret_cast<QhFacet *>(ws + P.fac);
+    uint16_t *arena = reinterpret_cast<uint16_t *>(ws + P.arena);
+    uint16_t *TT = reinterpret_cast<uint16_t *>(ws + P.tt);
+    double *DD = reinterpret_cast<double *>(ws + P.dd);
+    const int64_t off = a.pts_off[f];
+    const int cnt = a.pts_cnt[f];
+    int why = QH_OK, n = 0;
+    nrows = 0;
+    QhConst K;
+    int nfac = 0;                 // facets created (ids 1 .. nfac)
+    uint32_t atop = 0;            // arena bump pointer
+    int perm0 = 1;                // the initial facet moved to the head of the list (qh_furthestnext)
+
+    // ---- 0. the sites: kept points compacted, lifted; the point 'at infinity'; extremes ----
+    for (int base = 0; base < cnt; base += 64) {
+        const int i = base + lane;
+        bool k = i < cnt;
+        if (k && a.keep) k = a.keep[off + i] >= 0;
+        const uint64_t m = __ballot(k);
+        if (k) {
+            const int r = n + popc64(m & lanemask_lt());
+            if (r < a.cap_pts - 1) {
+                const double x = a.u[off + i], y = a.v[off + i];
+                X[r] = x; Y[r] = y; Z[r] = x * x + y * y;
+            }
+        }
+        n += popc64(m);
+    }
+    n = uni(n);
+    if (a.n_used) { if (lane == 0) a.n_used[f] = n; }
+    if (n < 3 || n > a.cap_pts - 1 || n > kQhMaxPoints) return QH_FEW_POINTS;
+    __threadfence_block();
+    {
+        // sums in input order (the point at infinity sits over the mean), the largest lifted height
+        double sx = 0.0, sy = 0.0, mz = -kQhHuge;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            const double x = i < n ? X[i] : 0.0, y = i < n ? Y[i] : 0.0, z = i < n ? Z[i] : -kQhHuge;
+            const int c = min(64, n - base);
+            for (int j = 0; j < c; ++j) { sx += readlane_d(x, j); sy += readlane_d(y, j); }
+            mz = fmax(mz, wave_max_d(z));
+        }
+        if (lane == 0) { X[n] = sx / (double)n; Y[n] = sy / (double)n; Z[n] = mz * 1.1; }
+    }
+    __threadfence_block();
+    int ext[6];
+    double maxabs = 0.0, maxwidth = 0.0, maxsum = 0.0, zlow = 0.0, zhigh = 0.0, nz1 = 0.0, nz2 = 0.0;
+    {
+        const int m1 = n + 1;
+        for (int k = 0; k < 3; ++k) {
+            const double *C = k == 0 ? X : (k == 1 ? Y : Z);
+            double hi = -kQhHuge, lo = kQhHuge; int hii = 0, loi = 0;
+            for (int base = 0; base < m1; base += 64) {
+                const int i = base + lane;
+                const double c = i < m1 ? C[i] : 0.0;
+                const double cm = wave_max_d(i < m1 ? c : -kQhHuge), cn = wave_min_d(i < m1 ? c : kQhHuge);
+                if (cm > hi) { hi = cm; hii = base + ffs64(__ballot(i < m1 && c == cm)); }
+                if (cn < lo) { lo = cn; loi = base + ffs64(__ballot(i < m1 && c == cn)); }
+            }
+            double maxcoord;
+            if (k == 2) { zlow = lo; zhigh = hi; maxcoord = maxabs; }
+            else { maxcoord = fmax(hi, -lo); maxwidth = fmax(maxwidth, hi - lo); }
+            maxabs = fmax(maxabs, maxcoord);
+            maxsum += maxcoord;
+            ext[2 * k] = loi; ext[2 * k + 1] = hii;
+            if (k == 1) nz1 = 80 * maxsum * kQhEps;
+            if (k == 2) nz2 = 80 * maxsum * kQhEps;
+        }
+    }
+    if (!(maxwidth > 0.0) || !(zhigh > zlow)) return QH_ZERO_WIDTH;
+    {
+        // 'Qbb': the lifted coordinate scaled to [0, maxabs]
+        const double scale = maxabs / (zhigh - zlow);
+        const double shift = 0.0 - zlow * scale;
+        for (int i = lane; i <= n; i += 64) Z[i] = Z[i] * scale + shift;
+        const double maxdistsum = fmin(__builtin_sqrt(3.0) * maxabs, maxsum);
+        K.distround = kQhEps * (3 * maxdistsum * 1.01 + maxabs);
+        K.anground = 1.01 * 3 * kQhEps;
+        K.minvisible = 2 * K.distround;
+        K.minoutside = 2 * K.minvisible;
+        K.distoutside = 2 * K.minoutside;
+        K.guard = 64 * K.distround;
+    }
+    __threadfence_block();
+
+    // ---- 1. the initial simplex (qh_maxsimplex over the six extreme points) and its four facets ----
+    int simplex[4];
+    {
+        double maxc = -kQhHuge, minc = kQhHuge; int maxx = -1, minx = -1;
+        for (int k = 0; k < 6; ++k) {
+            const double x = X[ext[k]];
+            if (maxc < x) { maxc = x; maxx = ext[k]; }
+            if (minc > x) { minc = x; minx = ext[k]; }
+        }
+        if (maxx == minx) return QH_ZERO_WIDTH;
+        simplex[0] = minx; simplex[1] = maxx;
+        double maxdet = maxc - minc;
+        for (int i = 2; i < 4; ++i) {
+            const double prevdet = maxdet;
+            int maxpoint = -1; bool maxnear = false;
+            maxdet = -1.0;
+            for (int k = 0; k < 6; ++k) {
+                const int p = ext[k];
+                bool in = false;
+                for (int j = 0; j < i; ++j) in = in || simplex[j] == p;
+                if (in) continue;
+                double det; bool near;
+                const double ax = X[p], ay = Y[p], az = Z[p];
+                if (i == 2) {
+                    const double r00 = X[simplex[0]] - ax, r01 = Y[simplex[0]] - ay, r10 = X[simplex[1]] - ax, r11 = Y[simplex[1]] - ay;
+                    det = r00 * r11 - r01 * r10;
+                    near = __builtin_fabs(det) < 10 * nz1;
+                } else {
+                    const double a1 = X[simplex[0]] - ax, a2 = Y[simplex[0]] - ay, a3 = Z[simplex[0]] - az;
+                    const double b1 = X[simplex[1]] - ax, b2 = Y[simplex[1]] - ay, b3 = Z[simplex[1]] - az;
+                    const double c1 = X[simplex[2]] - ax, c2 = Y[simplex[2]] - ay, c3 = Z[simplex[2]] - az;
+                    det = a1 * (b2 * c3 - b3 * c2) - b1 * (a2 * c3 - a3 * c2) + c1 * (a2 * b3 - a3 * b2);
+                    near = __builtin_fabs(det) < 10 * nz2;
+                }
+                det = __builtin_fabs(det);
+                if (det > maxdet) { maxdet = det; maxpoint = p; maxnear = near; }
+            }
+            const double targetdet = prevdet * maxwidth;
+            if (maxpoint < 0 || maxnear || (maxdet > 0.0 && maxdet / targetdet < 0.02)) return QH_SIMPLEX_SEARCH;
+            simplex[i] = maxpoint;
+        }
+    }
+    {
+        // vertices v1..v4 = simplex[0..3]; facet i omits the i-th of (v4, v3, v2, v1); orientation alternates from 'top'
+        const int vs[4] = {simplex[3], simplex[2], simplex[1], simplex[0]};
+        double cx = 0.0, cy = 0.0, cz = 0.0;
+        for (int k = 0; k < 4; ++k) { cx += X[vs[k]]; cy += Y[vs[k]]; cz += Z[vs[k]]; }
+        cx = cx / 4; cy = cy / 4; cz = cz / 4;
+        bool flip = false;
+        {
+            const QhPlane F0 = qh_plane(X[vs[1]], Y[vs[1]], Z[vs[1]], X[vs[2]], Y[vs[2]], Z[vs[2]], X[vs[3]], Y[vs[3]], Z[vs[3]], true, K.distround, K.anground);
+            if (F0.gauss) return QH_GAUSS;
+            const double d = F0.d + cx * F0.n0 + cy * F0.n1 + cz * F0.n2;
+            if (d > K.distround) flip = true;
+            else if (d > -K.distround) return QH_FLAT_SIMPLEX;
+        }
+        bool gauss = false;
+        if (lane < 4) {
+            int q[3], k = 0;
+            for (int j = 0; j < 4; ++j) if (j != lane) q[k++] = vs[j];
+            const bool top = ((lane & 1) == 0) != flip;
+            const QhPlane F = qh_plane(X[q[0]], Y[q[0]], Z[q[0]], X[q[1]], Y[q[1]], Z[q[1]], X[q[2]], Y[q[2]], Z[q[2]], top, K.distround, K.anground);
+            gauss = F.gauss;
+            L.npl[lane][0] = F.n0; L.npl[lane][1] = F.n1; L.npl[lane][2] = F.n2; L.npl[lane][3] = F.d;
+            L.nnb[lane][3] = F.upper ? 1 : 0;
+            QhFacet G;
+            G.p[0] = (uint16_t)q[0]; G.p[1] = (uint16_t)q[1]; G.p[2] = (uint16_t)q[2];
+            G.flags = (uint16_t)((top ? 1 : 0) | (F.upper ? 2 : 0));
+            k = 0;
+            for (int j = 0; j < 4; ++j) if (j != lane) G.nb[k++] = (uint16_t)(j + 1);
+            G.bestp = kQhNone; G.off = 0; G.cnt = 0; G.mark = 0; G.bestd = 0.0;
+            G.n0 = F.n0; G.n1 = F.n1; G.n2 = F.n2; G.d = F.d;
+            fac[lane + 1] = G;
+            L.t_total[lane] = 0;
+        }
+        if (__any(gauss)) return QH_GAUSS;
+        nfac = 4;
+        __syncthreads();
+        // narrow initial simplex: Qhull switches to another furthest-point rule
+        if (lane < 4) {
+            double mina = 2.0;
+            for (int j = 0; j < 4; ++j) if (j != lane)
+                mina = fmin(mina, L.npl[lane][0] * L.npl[j][0] + L.npl[lane][1] * L.npl[j][1] + L.npl[lane][2] * L.npl[j][2]);
+            gauss = mina < -0.99999999;
+        }
+        if (__any(gauss)) return QH_NARROW;
+    }
+    __threadfence_block();
+
+    // ---- 2. qh_partitionall: every other point to the first initial facet it is 2 MINoutside above ----
+    {
+        const int total = n + 1;
+        bool bad = false, inside = false;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+                if (lane < 4) {
+                    uint32_t o = 0;
+                    for (int j = 0; j < lane; ++j) o += L.t_total[j];
+                    L.t_off[lane] = o; L.t_cnt[lane] = 0; L.t_bestp[lane] = kQhNone; L.t_bestd[lane] = -kQhHuge;
+                }
+                atop = L.t_total[0] + L.t_total[1] + L.t_total[2] + L.t_total[3];
+                __syncthreads();
+            }
+            for (int base = 0; base < total; base += 64) {
+                const int p = base + lane;
+                bool valid = p < total && p != simplex[0] && p != simplex[1] && p != simplex[2] && p != simplex[3];
+                int tgt = 0; double d = 0.0;
+                if (valid) {
+                    if (pass == 0) {
+                        const double x = X[p], y = Y[p], z = Z[p];
+                        tgt = -1;
+                        for (int j = 0; j < 4 && tgt < 0; ++j) {
+                            d = qh_dist(x, y, z, L.npl[j][0], L.npl[j][1], L.npl[j][2], L.npl[j][3]);
+                            if (d >= K.distoutside) tgt = j;
+                            else if (d > -K.guard) bad = true;
+                        }
+                        if (d < K.guard && tgt >= 0) bad = true;
+                        if (tgt < 0) { inside = true; tgt = 0; }
+                        TT[p] = (uint16_t)tgt; DD[p] = d;
+                        atomicAdd(&L.t_total[tgt], 1u);
+                    } else { tgt = TT[p]; d = DD[p]; }
+                }
+                if (pass == 1) qh_place_chunk(L, arena, valid, tgt, p, d);
+            }
+            __syncthreads();
+            __threadfence_block();
+            if (__any(inside)) return QH_INSIDE_SIMPLEX;
+            if (__any(bad)) return QH_BAND;
+        }
+        if (lane < 4) {
+            fac[lane + 1].off = L.t_off[lane]; fac[lane + 1].cnt = (uint16_t)L.t_cnt[lane];
+            fac[lane + 1].bestp = L.t_bestp[lane]; fac[lane + 1].bestd = L.t_bestd[lane];
+        }
+        // qh_furthestnext: the facet with the furthest point of all goes to the head of the list
+        double bd = -kQhHuge; perm0 = 0;
+        for (int j = 0; j < 4; ++j) if (L.t_bestp[j] != kQhNone && L.t_bestd[j] > bd) { bd = L.t_bestd[j]; perm0 = j + 1; }
+        __syncthreads();
+        __threadfence_block();
+    }
+
+    // ---- 3. the insertions ----
+    {
+        // list position -> facet id: perm0 first, then the other initial facets in order, then creation order
+        auto pos2id = [&](int pos) { return pos >= 4 || perm0 == 0 ? pos + 1 : (pos == 0 ? perm0 : (pos < perm0 ? pos : pos + 1)); };
+        int pos = 0, step = 0;
+        while (true) {
+            // (a) the first facet in list order with an outside set
+            int cur = -1;
+            while (pos < nfac) {
+                const int id = pos + lane < nfac ? pos2id(pos + lane) : 0;
+                bool has = false;
+                if (id) { const QhFacet *G = &fac[id]; has = !(G->flags & 4) && G->bestp != kQhNone; }
+                const uint64_t m = __ballot(has);
+                if (m) { pos += ffs64(m); cur = pos2id(pos); break; }
+                pos += 64;
+            }
+            if (cur < 0) break;
+            cur = uni(cur);
+            ++step;
+            const QhFacet C = fac[cur];
+            const int p = C.bestp;
+            const double px = X[p], py = Y[p], pz = Z[p];
+            if (a.order_out) { if (lane == 0 && p < n) a.order_out[off + p] = step; }     // (compacted ids when `keep` is given)
+            // (b) qh_findhorizon: visible facets, breadth first, neighbours in order
+            int nvis = 1, head = 0;
+            if (lane == 0) {
+                L.visq[0] = (uint16_t)cur; L.visnb[0][0] = C.nb[0]; L.visnb[0][1] = C.nb[1]; L.visnb[0][2] = C.nb[2];
+                L.visoff[0] = C.off; L.viscnt[0] = C.cnt; L.visbest[0] = kQhNone;
+                fac[cur].mark = (uint16_t)(2 * step + 1);
+            }
+            __syncthreads();
+            __threadfence_block();
+            bool bad = false, copl = false;
+            while (head < nvis) {
+                const int ne = min(nvis - head, 21);
+                const int e = head + lane / 3, k = lane % 3;
+                const bool act = lane < 3 * ne;
+                int g = 0;
+                QhFacet G;
+                bool cand = false;
+                if (act) {
+                    g = L.visnb[e][k];
+                    G = fac[g];
+                    cand = (G.mark >> 1) != step;
+                }
+                // the same facet reached twice in this round: the earlier (entry, neighbour) pair tests it
+                uint64_t cm = __ballot(cand);
+                bool dup = false;
+                for (uint64_t r = cm; r; r &= r - 1) {
+                    const int j = ffs64(r);
+                    const int gj = __shfl(g, j);
+                    if (cand && lane > j && gj == g) dup = true;
+                }
+                bool vis = false;
+                if (cand && !dup) {
+                    const double d = qh_dist(px, py, pz, G.n0, G.n1, G.n2, G.d);
+                    if (d > K.minvisible) { vis = true; if (d < K.guard) bad = true; }
+                    else if (d >= -K.guard) copl = true;
+                    fac[g].mark = (uint16_t)(2 * step + (vis ? 1 : 0));
+                }
+                const uint64_t vm = __ballot(vis);
+                const int add = popc64(vm);
+                if (nvis + add > kQhMaxVis) { why = QH_TOO_MANY_VISIBLE; break; }
+                if (vis) {
+                    const int q = nvis + popc64(vm & lanemask_lt());
+                    L.visq[q] = (uint16_t)g; L.visnb[q][0] = G.nb[0]; L.visnb[q][1] = G.nb[1]; L.visnb[q][2] = G.nb[2];
+                    L.visoff[q] = G.off; L.viscnt[q] = G.cnt; L.visbest[q] = G.bestp;
+                }
+                head += ne; nvis += add;
+                __syncthreads();
+                __threadfence_block();
+            }
+            if (why) return why;
+            if (__any(copl)) return QH_COPLANAR_HORIZON;
+            if (__any(bad)) return QH_BAND;
+            // (c) qh_makenewfacets: for each visible facet in order, for each horizon neighbour in order, a facet (apex first)
+            int m = 0;
+            if (lane == 0) for (int e = 0; e < nvis; ++e) L.visrep[e] = kQhNone;
+            __syncthreads();
+            bool gauss = false, notconv = false;
+            for (int base = 0; base < nvis; base += 21) {
+                const int ne = min(nvis - base, 21);
+                const int e = base + lane / 3, k = lane % 3;
+                const bool act = lane < 3 * ne;
+                int g = 0; QhFacet G; bool hz = false;
+                if (act) { g = L.visnb[e][k]; G = fac[g]; hz = G.mark != (uint16_t)(2 * step + 1); }
+                const uint64_t hm = __ballot(hz);
+                const int j = m + popc64(hm & lanemask_lt());
+                const int add = popc64(hm);
+                if (m + add > kQhMaxNew) { why = QH_CONE_TOO_LARGE; break; }
+                if (nfac + m + add > (int)P.fcap) { why = QH_FACETS_FULL; break; }
+                if (hz) {
+                    const int vid = L.visq[e];
+                    const int skip = G.nb[0] == vid ? 0 : (G.nb[1] == vid ? 1 : 2);
+                    const int va = skip == 0 ? G.p[1] : G.p[0], vb = skip == 2 ? G.p[1] : G.p[2], vo = G.p[skip];
+                    const bool gtop = G.flags & 1;
+                    const bool top = gtop ? (skip & 1) : !(skip & 1);
+                    const double ax = X[va], ay = Y[va], az = Z[va], bx = X[vb], by = Y[vb], bz = Z[vb];
+                    const QhPlane F = qh_plane(px, py, pz, ax, ay, az, bx, by, bz, top, K.distround, K.anground);
+                    gauss = gauss || F.gauss;
+                    // the horizon facet's vertex opposite the shared ridge must lie below the cone facet (else Qhull merges)
+                    if (qh_dist(X[vo], Y[vo], Z[vo], F.n0, F.n1, F.n2, F.d) > -K.guard) notconv = true;
+                    L.npl[j][0] = F.n0; L.npl[j][1] = F.n1; L.npl[j][2] = F.n2; L.npl[j][3] = F.d;
+                    L.nxy[j][0] = ax; L.nxy[j][1] = ay; L.nxy[j][2] = az; L.nxy[j][3] = bx; L.nxy[j][4] = by; L.nxy[j][5] = bz;
+                    L.nva[j] = (uint16_t)va; L.nvb[j] = (uint16_t)vb;
+                    L.nnb[j][0] = (uint8_t)(top ? 1 : 0); L.nnb[j][3] = F.upper ? 1 : 0;
+                    L.t_total[j] = 0;
+                    L.nhz[j] = (uint16_t)g;
+                    fac[g].nb[skip] = (uint16_t)(nfac + 1 + j);
+                }
+                // a visible facet's replacement: the last cone facet made from it
+                if (hz) {
+                    const uint64_t mine = hm & (7ull << (3 * (lane / 3)));
+                    if ((63 - __clzll((long long)mine)) == lane) L.visrep[e] = (uint16_t)j;
+                }
+                m += add;
+            }
+            if (why) return why;
+            __syncthreads();
+            if (__any(gauss)) return QH_GAUSS;
+            if (__any(notconv)) return QH_NOT_CONVEX;
+            if (m < 3) return QH_OPEN_CONE;
+            // (d) qh_matchnewfacets: neighbour 1 shares the ridge {apex, b}, neighbour 2 the ridge {apex, a}
+            {
+                bool open = false; notconv = false;
+                int n1 = -1, n2 = -1;
+                if (lane < m) {
+                    const int va = L.nva[lane], vb = L.nvb[lane];
+                    int c1 = 0, c2 = 0;
+                    for (int i = 0; i < m; ++i) if (i != lane) {
+                        const int ia = L.nva[i], ib = L.nvb[i];
+                        if (ia == vb || ib == vb) { n1 = i; ++c1; }
+                        if (ia == va || ib == va) { n2 = i; ++c2; }
+                    }
+                    open = c1 != 1 || c2 != 1;
+                    if (!open) {
+                        // convexity between cone facets: the neighbour's other horizon vertex lies below this facet
+                        const int o1 = L.nva[n1] == vb ? 3 : 0, o2 = L.nva[n2] == va ? 3 : 0;
+                        const double d1 = qh_dist(L.nxy[n1][o1], L.nxy[n1][o1 + 1], L.nxy[n1][o1 + 2], L.npl[lane][0], L.npl[lane][1], L.npl[lane][2], L.npl[lane][3]);
+                        const double d2 = qh_dist(L.nxy[n2][o2], L.nxy[n2][o2 + 1], L.nxy[n2][o2 + 2], L.npl[lane][0], L.npl[lane][1], L.npl[lane][2], L.npl[lane][3]);
+                        notconv = d1 > -K.guard || d2 > -K.guard;
+                    }
+                }
+                if (__any(open)) return QH_OPEN_CONE;
+                if (__any(notconv)) return QH_NOT_CONVEX;
+                __syncthreads();
+                if (lane < m) { L.nnb[lane][1] = (uint8_t)n1; L.nnb[lane][2] = (uint8_t)n2; }
+                __syncthreads();
+            }
+            // qh_sharpnewfacets: the cone's normals in more than one orthant
+            bool sharp;
+            {
+                const int q0 = (L.npl[0][0] > 0 ? 1 : 0) | (L.npl[0][1] > 0 ? 2 : 0) | (L.npl[0][2] > 0 ? 4 : 0);
+                bool diff = false;
+                if (lane < m) diff = ((L.npl[lane][0] > 0 ? 1 : 0) | (L.npl[lane][1] > 0 ? 2 : 0) | (L.npl[lane][2] > 0 ? 4 : 0)) != q0;
+                sharp = __any(diff);
+            }
+            // (e) qh_partitionvisible: the visible facets' points, in list order, to the cone
+            int S = 0;
+            {
+                if (lane == 0) {
+                    uint32_t c = 0;
+                    for (int e = 0; e < nvis; ++e) { L.viscum[e] = c; c += L.viscnt[e] + (L.visbest[e] != kQhNone ? 1u : 0u); }
+                    L.viscum[nvis] = c;
+                }
+                __syncthreads();
+                S = (int)L.viscum[nvis];
+            }
+            if (atop + (uint32_t)S > P.acap) return QH_ARENA_FULL;
+            {
+                // targets: a directed walk per point; from the first point that ends below its best facet on a sharp cone,
+                // a linear scan (qh.findbestnew stays set for the rest of this insertion)
+                bool mode = false, fail_band = false, fail_sharp = false, fail_none = false;
+                bool valid0 = false; int q0 = 0, tgt0 = 0; double d0 = 0.0;
+                for (int base = 0; base < S; base += 64) {
+                    const int i = base + lane;
+                    const bool valid = i < S;
+                    int q = 0, start = 0;
+                    double x = 0.0, y = 0.0, z = 0.0;
+                    if (valid) {
+                        int e = 0;
+                        while (e + 1 < nvis && (int)L.viscum[e + 1] <= i) ++e;
+                        const int r = i - (int)L.viscum[e];
+                        q = r < (int)L.viscnt[e] ? arena[L.visoff[e] + r] : L.visbest[e];
+                        start = L.visrep[e] == kQhNone ? 0 : L.visrep[e];
+                        x = X[q]; y = Y[q]; z = Z[q];
+                    }
+                    QhWalk R; R.state = 0; R.tgt = 0; R.d = 0.0; R.best = -1;
+                    if (valid) R = mode ? qh_scan_cone(L, m, start, x, y, z, K) : qh_walk_cone(L, start, x, y, z, K);
+                    if (!mode) {
+                        if (valid && R.state == 2) R = qh_scan_cone(L, m, 0, x, y, z, K);       // no best: all cone facets from the first
+                        const uint64_t trig = __ballot(valid && R.state == 1);
+                        if (trig) {
+                            if (!sharp) fail_sharp = true;
+                            const int t = ffs64(trig);
+                            if (valid && lane >= t) R = qh_scan_cone(L, m, lane == t ? R.best : start, x, y, z, K);
+                            mode = true;
+                        }
+                    }
+                    if (valid && R.state != 0) { if (R.state == 3) fail_band = true; else fail_none = true; }
+                    if (valid) {
+                        atomicAdd(&L.t_total[R.tgt], 1u);
+                        if (S > 64) { TT[i] = (uint16_t)R.tgt; DD[i] = R.d; }
+                    }
+                    if (base == 0) { valid0 = valid; q0 = q; tgt0 = R.tgt; d0 = R.d; }
+                }
+                if (__any(fail_band)) return QH_BAND;
+                if (fail_sharp) return QH_NOT_SHARP;
+                if (__any(fail_none)) return QH_ABOVE_NONE;
+                __syncthreads();
+                __threadfence_block();
+                // room for the cone's outside sets, then the placement in arrival order
+                if (lane < m) {
+                    uint32_t o = atop;
+                    for (int j = 0; j < lane; ++j) o += L.t_total[j];
+                    L.t_off[lane] = o; L.t_cnt[lane] = 0; L.t_bestp[lane] = kQhNone; L.t_bestd[lane] = -kQhHuge;
+                }
+                atop += (uint32_t)S;
+                __syncthreads();
+                if (S > 0 && S <= 64) qh_place_chunk(L, arena, valid0, tgt0, q0, d0);
+                else for (int base = 0; base < S; base += 64) {
+                    const int i = base + lane;
+                    const bool valid = i < S;
+                    int q = 0, tgt = 0; double d = 0.0;
+                    if (valid) {
+                        int e = 0;
+                        while (e + 1 < nvis && (int)L.viscum[e + 1] <= i) ++e;
+                        const int r = i - (int)L.viscum[e];
+                        q = r < (int)L.viscnt[e] ? arena[L.visoff[e] + r] : L.visbest[e];
+                        tgt = TT[i]; d = DD[i];
+                    }
+                    qh_place_chunk(L, arena, valid, tgt, q, d);
+                }
+                __syncthreads();
+            }
+            // (f) the cone's facet records; the visible facets die
+            if (lane < m) {
+                QhFacet G;
+                G.p[0] = (uint16_t)p; G.p[1] = L.nva[lane]; G.p[2] = L.nvb[lane];
+                G.flags = (uint16_t)((L.nnb[lane][0] ? 1 : 0) | (L.nnb[lane][3] ? 2 : 0));
+                G.nb[0] = L.nhz[lane];
+                G.nb[1] = (uint16_t)(nfac + 1 + L.nnb[lane][1]); G.nb[2] = (uint16_t)(nfac + 1 + L.nnb[lane][2]);
+                G.bestp = L.t_bestp[lane]; G.off = L.t_off[lane]; G.cnt = (uint16_t)L.t_cnt[lane]; G.mark = 0; G.bestd = L.t_bestd[lane];
+                G.n0 = L.npl[lane][0]; G.n1 = L.npl[lane][1]; G.n2 = L.npl[lane][2]; G.d = L.npl[lane][3];
+                fac[nfac + 1 + lane] = G;
+            }
+            for (int e = lane; e < nvis; e += 64) fac[L.visq[e]].flags |= 4;
+            nfac += m;
+            __syncthreads();
+            __threadfence_block();
+        }
+        // ---- 4. SciPy's rows: lower facets in list order; vertices by decreasing vertex id, first two swapped unless top ----
+        const int64_t toff = a.tri_off[f];
+        for (int base = 0; base < nfac; base += 64) {
+            const int id = base + lane < nfac ? pos2id(base + lane) : 0;
+            bool row = false; QhFacet G;
+            if (id) { G = fac[id]; row = !(G.flags & 4) && !(G.flags & 2); }
+            const uint64_t rm = __ballot(row);
+            if (row) {
+                int32_t *t = a.tri + 3 * (toff + nrows + popc64(rm & lanemask_lt()));
+                const bool top = G.flags & 1;
+                t[0] = top ? G.p[0] : G.p[1]; t[1] = top ? G.p[1] : G.p[0]; t[2] = G.p[2];
+            }
+            nrows += popc64(rm);
+        }
+    }
+    return why;
+}
+
+__global__ __launch_bounds__(64) void qhull_rows_kernel(const QhArgs a) {
+    __shared__ QhLds L;
+    const int64_t f = blockIdx.x;
+    int nrows = 0;
+    const int why = qh_run(a, L, f, nrows);
+    if (lane_id() == 0) {
+        a.tri_cnt[f] = why ? 0 : nrows;
+        a.status[f] = why ? (MVOSR_DT_DEGENERATE | (why << 8)) : MVOSR_DT_OK;
+    }
+}
+
+}  // namespace
+
+extern "C" int mvosr_delaunay_qhull_max_points(void) { return kQhMaxPoints; }
+
+extern "C" int mvosr_delaunay_qhull_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                                          const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
+                                          int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status, int32_t *order_out) {
+    if (!ctx || !pts_off || !pts_cnt || !u || !v || !tri_off || !tri || !tri_cnt || !status)
+        return set_error(MVOSR_ERR_ARG, "delaunay_qhull_batch: null argument");
+    if (max_pts < 0) return set_error(MVOSR_ERR_ARG, "delaunay_qhull_batch: max_pts < 0");
+    if (n_frames <= 0) return MVOSR_OK;
+    int rc = ctx_activate(ctx);
+    if (rc) return rc;
+    if (max_pts < 3) max_pts = 3;
+    if (max_pts > kQhMaxPoints)
+        return set_error(MVOSR_ERR_TOO_LARGE, "delaunay_qhull_batch: %d points per frame (limit: %d)", max_pts, kQhMaxPoints);
+    QhArgs a;
+    a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
+    a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.order_out = order_out;
+    a.cap_pts = max_pts + 1;
+    const QhPlan P = qh_plan(a.cap_pts);
+    a.ws_stride = P.total;
+    void *ws = nullptr;
+    if ((rc = ctx_workspace_bytes(ctx, (size_t)n_frames * P.total, &ws))) return rc;
+    a.ws = reinterpret_cast<char *>(ws);
+    hipLaunchKernelGGL(qhull_rows_kernel, dim3((unsigned)n_frames), dim3(64), 0, ctx_stream(ctx), a);
+    return check_launch("qhull_rows_kernel");
+}

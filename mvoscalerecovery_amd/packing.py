@@ -69,8 +69,11 @@ def canonical_rows(tri):
     return np.ascontiguousarray(t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))])
 
 
-def delaunay_gpu(ctx, point_sets, keeps=None):
-    """The device stage for the triangulations (``mvosr_delaunay_batch``): per point set the (T,3) int32
+def delaunay_gpu(ctx, point_sets, keeps=None, rows="canonical", order_out=False):
+    """``rows="qhull"``: ``mvosr_delaunay_qhull_batch`` — SciPy's rows themselves, order and rotation (the kernel replays
+    Qhull's insertion order); ``order_out``: also the per-point insertion steps in ``delaunay_gpu.last_order``.
+
+    The device stage for the triangulations (``mvosr_delaunay_batch``): per point set the (T,3) int32
     rows — the triangle set SciPy returns for points in general position, in canonical form (:func:`canonical_rows`) —
     or ``None`` where the kernel declined (duplicate / collinear / cocircular points within its guard bands, fewer than
     3 points): those sets are for the host's Qhull.  ``keeps`` (optional, one int array per set): only the points with
@@ -96,11 +99,23 @@ def delaunay_gpu(ctx, point_sets, keeps=None):
     d_off, d_cnt, d_toff = ctx.to_device(off[:-1].astype(np.int64)), ctx.to_device(cnt), ctx.to_device(toff[:-1].astype(np.int64))
     d_tri = ctx.empty((2 * total, 3), np.int32)
     d_tcnt, d_st, d_used = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
-    _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr,
-                                            d_keep.ptr if d_keep is not None else None, int(cnt.max()), d_toff.ptr,
-                                            d_tri.ptr, d_tcnt.ptr, d_used.ptr, d_st.ptr), "mvosr_delaunay_batch")
+    d_ord = None
+    if rows == "qhull":
+        d_ord = ctx.zeros(total, np.int32) if order_out else None
+        _lib.check(ctx.lib.mvosr_delaunay_qhull_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr,
+                                                      d_keep.ptr if d_keep is not None else None, int(cnt.max()), d_toff.ptr,
+                                                      d_tri.ptr, d_tcnt.ptr, d_used.ptr, d_st.ptr,
+                                                      d_ord.ptr if d_ord is not None else None), "mvosr_delaunay_qhull_batch")
+    else:
+        _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr,
+                                                d_keep.ptr if d_keep is not None else None, int(cnt.max()), d_toff.ptr,
+                                                d_tri.ptr, d_tcnt.ptr, d_used.ptr, d_st.ptr), "mvosr_delaunay_batch")
     ctx.sync()
     tri, tcnt, st, used = d_tri.download(), d_tcnt.download(), d_st.download(), d_used.download()
+    if d_ord is not None:
+        o = d_ord.download()
+        delaunay_gpu.last_order = [o[off[f]:off[f + 1]] for f in range(F)]
+        d_ord.free()
     for b in (d_u, d_v, d_off, d_cnt, d_toff, d_tri, d_tcnt, d_st, d_used) + ((d_keep,) if d_keep is not None else ()):
         b.free()
     delaunay_gpu.last_status = st                      # (bits 8.. of a declined frame's status say why: mvosr_delaunay.hip)
