@@ -24,7 +24,8 @@ namespace {
 
 constexpr int kQhMaxPoints = 8000;        // facet ids are 16-bit: 7 * (n + 1) + 64 facets per run
 constexpr int kQhMaxNew = 64;             // facets of one cone (one lane each)
-constexpr int kQhMaxVis = 256;            // visible facets of one insertion
+constexpr int kQhMaxVis = 64;             // visible facets of one insertion
+constexpr int kQhMaxHz = 64;              // horizon facets of one insertion
 constexpr double kQhEps = 2.220446049250313e-16;
 constexpr double kQhHuge = 1.797e308;
 constexpr uint16_t kQhNone = 0xFFFFu;
@@ -42,7 +43,7 @@ struct __attribute__((aligned(16))) QhFacet {
     uint16_t bestp;     // the outside set's furthest point (kQhNone: empty set)
     uint32_t off;       // the rest of the outside set: arena[off .. off + cnt), in Qhull's list order
     uint16_t cnt;
-    uint16_t mark;      // 2 * insertion + (visible ? 1 : 0) of the last visibility test
+    uint16_t mark;      // (unused)
     double bestd;
     double n0, n1, n2, d;
 };
@@ -84,6 +85,8 @@ struct QhLds {
     uint16_t visbest[kQhMaxVis];
     uint32_t viscum[kQhMaxVis + 1];
     uint16_t nhz[kQhMaxNew];         // a cone facet's horizon neighbour (facet id)
+    uint16_t hzq[kQhMaxHz];          // horizon facets tested in this insertion, and their records (p0 p1 p2 flags nb0 nb1 nb2)
+    uint16_t hzr[kQhMaxHz][8];
     uint32_t t_off[kQhMaxNew]; uint32_t t_total[kQhMaxNew]; uint32_t t_cnt[kQhMaxNew]; uint16_t t_bestp[kQhMaxNew]; double t_bestd[kQhMaxNew];
 };
 
@@ -471,32 +474,37 @@ __device__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
         auto pos2id = [&](int pos) { return pos >= 4 || perm0 == 0 ? pos + 1 : (pos == 0 ? perm0 : (pos < perm0 ? pos : pos + 1)); };
         int pos = 0, step = 0;
         while (true) {
-            // (a) the first facet in list order with an outside set
+            // (a) the first facet in list order with an outside set (its record's first half comes along)
             int cur = -1;
+            uint32_t c2 = 0, c3 = 0, c4 = 0, c5 = 0;
             while (pos < nfac) {
                 const int id = pos + lane < nfac ? pos2id(pos + lane) : 0;
-                bool has = false;
-                if (id) { const QhFacet *G = &fac[id]; has = !(G->flags & 4) && G->bestp != kQhNone; }
-                const uint64_t m = __ballot(has);
-                if (m) { pos += ffs64(m); cur = pos2id(pos); break; }
+                uint4 r0 = make_uint4(0, 4u << 16, 0, 0), r1 = make_uint4(0, 0, 0, 0);
+                if (id) { const uint4 *G = reinterpret_cast<const uint4 *>(&fac[id]); r0 = G[0]; r1 = G[1]; }
+                const bool has = !((r0.y >> 16) & 4u) && (r0.w >> 16) != kQhNone;
+                const uint64_t hm = __ballot(has);
+                if (hm) {
+                    const int l = ffs64(hm);
+                    pos += l; cur = pos2id(pos);
+                    c2 = __shfl(r0.z, l); c3 = __shfl(r0.w, l); c4 = __shfl(r1.x, l); c5 = __shfl(r1.y, l);
+                    break;
+                }
                 pos += 64;
             }
             if (cur < 0) break;
             cur = uni(cur);
             ++step;
-            const QhFacet C = fac[cur];
-            const int p = C.bestp;
+            const int p = (int)(c3 >> 16);
             const double px = X[p], py = Y[p], pz = Z[p];
             if (a.order_out) { if (lane == 0 && p < n) a.order_out[off + p] = step; }     // (compacted ids when `keep` is given)
-            // (b) qh_findhorizon: visible facets, breadth first, neighbours in order
-            int nvis = 1, head = 0;
+            // (b) qh_findhorizon: visible facets, breadth first, neighbours in order.  Facets tested in this insertion are
+            // remembered in LDS (visible ones with their outside sets, horizon ones with their vertices and neighbours)
+            int nvis = 1, head = 0, nhz = 0;
             if (lane == 0) {
-                L.visq[0] = (uint16_t)cur; L.visnb[0][0] = C.nb[0]; L.visnb[0][1] = C.nb[1]; L.visnb[0][2] = C.nb[2];
-                L.visoff[0] = C.off; L.viscnt[0] = C.cnt; L.visbest[0] = kQhNone;
-                fac[cur].mark = (uint16_t)(2 * step + 1);
+                L.visq[0] = (uint16_t)cur; L.visnb[0][0] = (uint16_t)(c2 & 0xFFFFu); L.visnb[0][1] = (uint16_t)(c2 >> 16); L.visnb[0][2] = (uint16_t)(c3 & 0xFFFFu);
+                L.visoff[0] = c4; L.viscnt[0] = (uint16_t)(c5 & 0xFFFFu); L.visbest[0] = kQhNone;
             }
             __syncthreads();
-            __threadfence_block();
             bool bad = false, copl = false;
             while (head < nvis) {
                 const int ne = min(nvis - head, 21);
@@ -507,50 +515,60 @@ __device__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
                 bool cand = false;
                 if (act) {
                     g = L.visnb[e][k];
-                    G = fac[g];
-                    cand = (G.mark >> 1) != step;
+                    cand = true;
+                    for (int i = 0; i < nvis; ++i) if (L.visq[i] == g) cand = false;
+                    for (int i = 0; i < nhz; ++i) if (L.hzq[i] == g) cand = false;
+                    if (cand) G = fac[g];
                 }
                 // the same facet reached twice in this round: the earlier (entry, neighbour) pair tests it
-                uint64_t cm = __ballot(cand);
+                const uint64_t cm = __ballot(cand);
                 bool dup = false;
                 for (uint64_t r = cm; r; r &= r - 1) {
                     const int j = ffs64(r);
                     const int gj = __shfl(g, j);
                     if (cand && lane > j && gj == g) dup = true;
                 }
-                bool vis = false;
+                bool vis = false, hzn = false;
                 if (cand && !dup) {
                     const double d = qh_dist(px, py, pz, G.n0, G.n1, G.n2, G.d);
                     if (d > K.minvisible) { vis = true; if (d < K.guard) bad = true; }
-                    else if (d >= -K.guard) copl = true;
-                    fac[g].mark = (uint16_t)(2 * step + (vis ? 1 : 0));
+                    else { hzn = true; if (d >= -K.guard) copl = true; }
                 }
-                const uint64_t vm = __ballot(vis);
-                const int add = popc64(vm);
-                if (nvis + add > kQhMaxVis) { why = QH_TOO_MANY_VISIBLE; break; }
+                const uint64_t vm = __ballot(vis), zm = __ballot(hzn);
+                const int add = popc64(vm), addz = popc64(zm);
+                if (nvis + add > kQhMaxVis || nhz + addz > kQhMaxHz) { why = QH_TOO_MANY_VISIBLE; break; }
                 if (vis) {
                     const int q = nvis + popc64(vm & lanemask_lt());
                     L.visq[q] = (uint16_t)g; L.visnb[q][0] = G.nb[0]; L.visnb[q][1] = G.nb[1]; L.visnb[q][2] = G.nb[2];
                     L.visoff[q] = G.off; L.viscnt[q] = G.cnt; L.visbest[q] = G.bestp;
                 }
-                head += ne; nvis += add;
+                if (hzn) {
+                    const int q = nhz + popc64(zm & lanemask_lt());
+                    L.hzq[q] = (uint16_t)g;
+                    L.hzr[q][0] = G.p[0]; L.hzr[q][1] = G.p[1]; L.hzr[q][2] = G.p[2]; L.hzr[q][3] = G.flags;
+                    L.hzr[q][4] = G.nb[0]; L.hzr[q][5] = G.nb[1]; L.hzr[q][6] = G.nb[2];
+                }
+                head += ne; nvis += add; nhz += addz;
                 __syncthreads();
-                __threadfence_block();
             }
             if (why) return why;
             if (__any(copl)) return QH_COPLANAR_HORIZON;
             if (__any(bad)) return QH_BAND;
             // (c) qh_makenewfacets: for each visible facet in order, for each horizon neighbour in order, a facet (apex first)
             int m = 0;
-            if (lane == 0) for (int e = 0; e < nvis; ++e) L.visrep[e] = kQhNone;
+            for (int e = lane; e < nvis; e += 64) L.visrep[e] = kQhNone;
             __syncthreads();
             bool gauss = false, notconv = false;
             for (int base = 0; base < nvis; base += 21) {
                 const int ne = min(nvis - base, 21);
                 const int e = base + lane / 3, k = lane % 3;
                 const bool act = lane < 3 * ne;
-                int g = 0; QhFacet G; bool hz = false;
-                if (act) { g = L.visnb[e][k]; G = fac[g]; hz = G.mark != (uint16_t)(2 * step + 1); }
+                int g = 0, hi = -1;
+                if (act) {
+                    g = L.visnb[e][k];
+                    for (int i = 0; i < nhz; ++i) if (L.hzq[i] == g) hi = i;
+                }
+                const bool hz = hi >= 0;
                 const uint64_t hm = __ballot(hz);
                 const int j = m + popc64(hm & lanemask_lt());
                 const int add = popc64(hm);
@@ -558,15 +576,17 @@ __device__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
                 if (nfac + m + add > (int)P.fcap) { why = QH_FACETS_FULL; break; }
                 if (hz) {
                     const int vid = L.visq[e];
-                    const int skip = G.nb[0] == vid ? 0 : (G.nb[1] == vid ? 1 : 2);
-                    const int va = skip == 0 ? G.p[1] : G.p[0], vb = skip == 2 ? G.p[1] : G.p[2], vo = G.p[skip];
-                    const bool gtop = G.flags & 1;
+                    const int g0 = L.hzr[hi][0], g1 = L.hzr[hi][1], g2 = L.hzr[hi][2], gf = L.hzr[hi][3];
+                    const int skip = L.hzr[hi][4] == vid ? 0 : (L.hzr[hi][5] == vid ? 1 : 2);
+                    const int va = skip == 0 ? g1 : g0, vb = skip == 2 ? g1 : g2, vo = skip == 0 ? g0 : (skip == 1 ? g1 : g2);
+                    const bool gtop = gf & 1;
                     const bool top = gtop ? (skip & 1) : !(skip & 1);
                     const double ax = X[va], ay = Y[va], az = Z[va], bx = X[vb], by = Y[vb], bz = Z[vb];
+                    const double ox = X[vo], oy = Y[vo], oz = Z[vo];
                     const QhPlane F = qh_plane(px, py, pz, ax, ay, az, bx, by, bz, top, K.distround, K.anground);
                     gauss = gauss || F.gauss;
                     // the horizon facet's vertex opposite the shared ridge must lie below the cone facet (else Qhull merges)
-                    if (qh_dist(X[vo], Y[vo], Z[vo], F.n0, F.n1, F.n2, F.d) > -K.guard) notconv = true;
+                    if (qh_dist(ox, oy, oz, F.n0, F.n1, F.n2, F.d) > -K.guard) notconv = true;
                     L.npl[j][0] = F.n0; L.npl[j][1] = F.n1; L.npl[j][2] = F.n2; L.npl[j][3] = F.d;
                     L.nxy[j][0] = ax; L.nxy[j][1] = ay; L.nxy[j][2] = az; L.nxy[j][3] = bx; L.nxy[j][4] = by; L.nxy[j][5] = bz;
                     L.nva[j] = (uint16_t)va; L.nvb[j] = (uint16_t)vb;
@@ -574,9 +594,7 @@ __device__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
                     L.t_total[j] = 0;
                     L.nhz[j] = (uint16_t)g;
                     fac[g].nb[skip] = (uint16_t)(nfac + 1 + j);
-                }
-                // a visible facet's replacement: the last cone facet made from it
-                if (hz) {
+                    // a visible facet's replacement: the last cone facet made from it
                     const uint64_t mine = hm & (7ull << (3 * (lane / 3)));
                     if ((63 - __clzll((long long)mine)) == lane) L.visrep[e] = (uint16_t)j;
                 }
@@ -675,7 +693,7 @@ __device__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
                 if (fail_sharp) return QH_NOT_SHARP;
                 if (__any(fail_none)) return QH_ABOVE_NONE;
                 __syncthreads();
-                __threadfence_block();
+                if (S > 64) __threadfence_block();
                 // room for the cone's outside sets, then the placement in arrival order
                 if (lane < m) {
                     uint32_t o = atop;

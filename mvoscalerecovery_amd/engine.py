@@ -184,6 +184,21 @@ class DeviceBatch:
         ctx, lib, b = self.ctx, self.ctx.lib, self.bufs
         assert self.device_triangulation
         self.info.invalidate()
+        if getattr(engine, "check_triangle", "reference") == "reference":
+            # the reference's vote reads the ROTATION of every row (:113-115): SciPy's rows themselves, order and rotation, from
+            # the kernel that replays Qhull's insertion order (mvosr_delaunay_qhull_batch)
+            _lib.check(lib.mvosr_delaunay_qhull_batch(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
+                                                      None, int(self.max_feat), b["tri_off"].ptr, b["tri1"].ptr, b["tri1_cnt"].ptr, None,
+                                                      b["dt1_status"].ptr, None), "mvosr_delaunay_qhull_batch (first triangulation)")
+            o = _lib.Outputs()
+            o.vote_counters = b["vote_counters"].ptr
+            bs = self.struct()
+            _lib.check(lib.mvosr_outlier_vote_batch(ctx.handle, C.byref(engine.params), C.byref(bs), C.byref(o), 0), "mvosr_outlier_vote_batch")
+            _lib.check(lib.mvosr_delaunay_qhull_batch(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
+                                                      b["vote_counters"].ptr, int(self.max_feat), b["tri_off"].ptr, b["tri2"].ptr,
+                                                      b["tri2_cnt"].ptr, b["n2_expected"].ptr, b["dt2_status"].ptr, None),
+                       "mvosr_delaunay_qhull_batch (second triangulation)")
+            return
         # (the first triangulation leaves per-point facts — rows owned, degree, hull flag, first row — from which the second
         # carries over every star the vote did not touch instead of walking it: mvosr_delaunay_batch_ex)
         _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
@@ -344,6 +359,7 @@ class ScaleEngine:
     def __init__(self, absolute_reference, device=0, ctx=None, **param_kw):
         self.ctx = ctx if ctx is not None else _lib.default_context(device)
         self.lib = self.ctx.lib
+        self.check_triangle = param_kw.get("check_triangle", "reference")
         self.params = make_params(absolute_reference, **param_kw)
 
     def scale_batch(self, batch: DeviceBatch, out: DeviceOutputs, waves=0, first=0, count=0, exact=False, masked=False):

@@ -129,6 +129,12 @@ def delaunay_gpu_max_points():
     return int(_lib.load().mvosr_delaunay_max_points())
 
 
+def delaunay_qhull_max_points():
+    """Largest point set ``mvosr_delaunay_qhull_batch`` takes (its facet ids are 16-bit)."""
+    from . import _lib
+    return int(_lib.load().mvosr_delaunay_qhull_max_points())
+
+
 def delaunay_gpu_or_host(ctx, point_sets, workers=0, canonical=True):
     """``triangulation="gpu"`` for host-side point sets: :func:`delaunay_gpu` for every set it accepts, SciPy/Qhull (the
     reference's call) for the ones it declines — degenerate inputs, sets too large for its LDS plan — and for sets SciPy

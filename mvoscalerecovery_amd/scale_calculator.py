@@ -471,7 +471,8 @@ class ScaleEstimator:
         pf.extra["canonical"] = self.check_triangle == "fixed"
         st = {"pf": pf, "n": len(f3s), "out": None, "dbatch": None, "masks": None, "gpu": True, "stage": stage,
               "remapped": bool(self.mutate_inputs)}
-        if pf.max_feat > packing.delaunay_gpu_max_points() or pf.n_frames == 0:
+        cap = packing.delaunay_gpu_max_points() if self.check_triangle == "fixed" else packing.delaunay_qhull_max_points()
+        if pf.max_feat > cap or pf.n_frames == 0:
             st["gpu"] = False                                                # frames the device stage does not take: the host's path
             if blk is not None:
                 blk.free()

@@ -2301,3 +2301,85 @@ def _device_count():
     from mvoscalerecovery_amd import _lib
     return int(_lib.load().mvosr_device_count())
 
+
+
+# ---- round 5: Qhull's rows themselves on the device (SURVEY §8 f1 without the declared deviation) ----
+
+def test_qhull_rows_kernel_equals_scipy_rows(gpu):
+    """mvosr_delaunay_qhull_batch: the rows are scipy.spatial.Delaunay(points).simplices — same rows, same ORDER, same
+    ROTATION (what /root/reference/src/scale_calculator.py:105-119 reads) — on frames of 5 to 4000 points, on the survivors of
+    a mask (ids = ranks), run to run; degenerate sets are declined, never mis-triangulated; the insertion order the kernel
+    reports equals the CPU restatement's (oracle/qhull_rows.py)."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import packing, synth
+    from oracle.qhull_rows import QhullDelaunay2D
+    rng = np.random.default_rng(23)
+    sizes = [2000, 1500, 700, 300, 120, 40, 9, 5, 4000, 2300] + [int(x) for x in rng.integers(100, 2200, 30)]
+    sets = [synth.synth_frame(i, n, base_seed=515)[1] for i, n in enumerate(sizes)]
+    sets.append(rng.uniform(0, 1, (1800, 2)) * [1241.0, 376.0])
+    sets.append(np.concatenate([rng.uniform(0, 100, (500, 2)), rng.uniform(40, 41, (500, 2))]))      # a dense cluster in a sparse field
+    got = packing.delaunay_gpu(gpu, sets, rows="qhull", order_out=True)
+    declined = 0
+    for k, (pts, tri) in enumerate(zip(sets, got)):
+        if tri is None:
+            declined += 1
+            continue
+        ref = Delaunay(pts).simplices
+        assert tri.shape == ref.shape and np.array_equal(tri, ref), (k, len(pts))
+    assert declined <= 2, declined
+    q = QhullDelaunay2D(sets[3])
+    order = packing.delaunay_gpu.last_order[3]
+    assert [int(p) for p in np.argsort(order, kind="stable") if order[p] > 0] == [p for p in q.order[4:] if p < len(sets[3])]
+    keep = np.where(rng.uniform(size=len(sets[0])) < 0.93, 3, -2).astype(np.int32)
+    t2 = packing.delaunay_gpu(gpu, [sets[0]], [keep], rows="qhull")[0]
+    assert np.array_equal(t2, Delaunay(sets[0][keep >= 0]).simplices)
+    assert int(packing.delaunay_gpu.last_used[0]) == int((keep >= 0).sum())
+    again = packing.delaunay_gpu(gpu, sets[:4], rows="qhull")
+    for x, y in zip(got[:4], again):
+        assert np.array_equal(x, y)
+    grid = np.stack(np.meshgrid(np.arange(20.0), np.arange(15.0)), axis=-1).reshape(-1, 2)
+    dup = sets[3].copy(); dup[10] = dup[200]
+    line = np.stack([np.arange(50.0), 2.0 * np.arange(50.0)], axis=1)
+    assert all(t is None for t in packing.delaunay_gpu(gpu, [grid, dup, line, sets[3][:2]], rows="qhull"))
+
+
+def test_seq4541_golden_device_triangulation_reference_exact(gpu):
+    """Config C3 with BOTH triangulations built on the device and the reference's own vote: triangulation="gpu",
+    check_triangle="reference" — no declared deviation.  Every raw and filtered scale of the 4541-frame main_offline-shaped
+    sequence equals the reference's (north_star: 1e-4; here bit-equal), and almost no frame needs the host's Qhull."""
+    from mvoscalerecovery_amd import offline, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z, meta = load_npz("seq4541.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, triangulation="gpu",
+                         check_triangle="reference", delaunay_workers=0)
+    res = offline.run_sequence_batched(data, est)
+    assert np.array_equal(res["kinds"], z["kinds"])
+    assert np.array_equal(est.last_raw_scale, z["raw_scales"], equal_nan=True)
+    np.testing.assert_array_equal(res["scales"], z["scales"])
+    np.testing.assert_array_equal(res["error"], z["error"])
+    assert est.last_declined <= 0.02 * meta["n_frames"]
+
+
+def test_stage_goldens_device_triangulation_reference_exact(gpu):
+    """The 20 stage frames of the UNPATCHED reference (tests/golden/stages.npz) through triangulation="gpu",
+    check_triangle="reference": scale, std, height_level and the selected road points per frame — per-frame calls and one
+    batch call."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z, meta = load_npz("stages.npz")
+    f3s, f2s = [], []
+    for k, fr in enumerate(meta["frames"]):
+        f3, f2 = synth.synth_frame(fr["frame_idx"], fr["n"], base_seed=fr["seed"], upper_fraction=fr["upper_fraction"])
+        est = ScaleEstimator(meta["abs_ref"], window_size=5, triangulation="gpu", check_triangle="reference", mutate_inputs=False,
+                             delaunay_workers=0)
+        s, sd = est.scale_calculation(f3, f2)
+        assert s == float(z["f%d_scale_first_call" % k]) and sd == float(z["f%d_std" % k]), k
+        assert est.height_level == float(z["f%d_height_level" % k]), k
+        assert len(est.flat_feature) == len(z["f%d_selected_ids" % k]), k
+        f3s.append(f3)
+        f2s.append(f2)
+    est = ScaleEstimator(meta["abs_ref"], window_size=5, triangulation="gpu", check_triangle="reference", mutate_inputs=False,
+                         delaunay_workers=0)
+    raw, status, level, _ = est.raw_scale_batch(f3s, f2s)
+    assert raw.tolist() == [float(z["f%d_scale_first_call" % k]) for k in range(len(f3s))]
