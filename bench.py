@@ -35,6 +35,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
   e2e_gpu_triangulation   the same call with both triangulations built on the device (triangulation="gpu",
                 check_triangle="fixed": a declared deviation, bit-equal to the fixed-mode oracle), plus the Delaunay kernel
                 alone and the allocation counters of the timed call;
+  e2e_gpu_exact   the same call with check_triangle="reference": SciPy/Qhull's own rows built on the device by replaying Qhull's
+                insertion order — the reference's result, bit for bit, with nothing on the host but packing;
   e2e_rescale   the estimator the reference's drivers really import (rescale.ScaleEstimator, /root/reference/src/main.py:20),
                 device-resident end to end (Delaunay x2, GraphChecker vote, flat_selection + RANSAC plane, slew limiter, window
                 median) from per-frame arrays: no declared deviation;
@@ -348,7 +350,7 @@ def e2e_rescale_leg(args, device, sizes, seed, n_frames):
                     "flat_selection + 100-hypothesis RANSAC plane, slew limiter, window median); reference-faithful: no declared deviation"}
 
 
-def e2e_gpu_leg(args, device, sizes, seed, n_frames):
+def e2e_gpu_leg(args, device, sizes, seed, n_frames, exact=False):
     """The batch call end to end with BOTH TRIANGULATIONS BUILT ON THE DEVICE (triangulation="gpu", which selects
     check_triangle="fixed": DESIGN.md §3.5): C packer -> one upload per chunk -> Delaunay #1 -> vote -> Delaunay #2 ->
     scale kernel -> road model -> results; rows, masks and counts never leave HBM.  Also: the device triangulation alone
@@ -357,7 +359,8 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames):
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
     pool, f3s, f2s = _e2e_frames(sizes, seed, n_frames)
     npool = len(pool)
-    est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
+    est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="gpu", delaunay_workers=0,
+                         check_triangle="reference" if exact else "fixed")
     for _ in range(2):                                                        # warm-up: kernels, allocator caches (same sizes as the timed call)
         est.scale_calculation_batch(f3s, f2s)
     ctx = est.engine.ctx
@@ -380,8 +383,12 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames):
         d_off, d_cnt, d_toff = ctx.to_device(off), ctx.to_device(cnt), ctx.to_device(2 * off)
         d_tri = ctx.empty((2 * F * n, 3), np.int32)
         d_tcnt, d_st = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
-        launch = lambda: _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n, d_toff.ptr,
-                                                                 d_tri.ptr, d_tcnt.ptr, None, d_st.ptr), "mvosr_delaunay_batch")
+        if exact:
+            launch = lambda: _lib.check(ctx.lib.mvosr_delaunay_qhull_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n, d_toff.ptr,
+                                                                           d_tri.ptr, d_tcnt.ptr, None, d_st.ptr, None), "mvosr_delaunay_qhull_batch")
+        else:
+            launch = lambda: _lib.check(ctx.lib.mvosr_delaunay_batch(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n, d_toff.ptr,
+                                                                     d_tri.ptr, d_tcnt.ptr, None, d_st.ptr), "mvosr_delaunay_batch")
         launch(); ctx.sync()
         e0, e1 = ctx.event(), ctx.event()
         ctx.record(e0)
@@ -399,10 +406,14 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames):
             "timed_calls_frames_per_s": [n_frames / t for t in times],
             "declined_last_chunk": int(est.last_declined), "delaunay_kernel": dt_alone,
             "hip_malloc_calls_in_timed_call": a1["hip_malloc"] - a0["hip_malloc"], "hip_host_malloc_calls_in_timed_call": a1["host_malloc"] - a0["host_malloc"],
-            "what": "ScaleEstimator(triangulation='gpu').scale_calculation_batch on a list of per-frame arrays: vanishing-row filter + "
-                    "packing by the C packer into page-locked memory, one upload per chunk, Delaunay #1 / vote / Delaunay #2 / scale "
-                    "kernel / road model on the device, window median; a declared deviation from the reference (check_triangle='fixed'), "
-                    "bit-equal to the fixed-mode oracle"}
+            "what": ("ScaleEstimator(triangulation='gpu', check_triangle='reference').scale_calculation_batch on a list of per-frame arrays: "
+                     "the C packer, one upload per chunk, Qhull's rows #1 (insertion order replayed on the device) / the reference's vote / "
+                     "Qhull's rows #2 / scale kernel / road model on the device, window median; NO declared deviation: bit-equal to the "
+                     "reference (tests/golden/seq4541.npz through this path)") if exact else
+                    ("ScaleEstimator(triangulation='gpu').scale_calculation_batch on a list of per-frame arrays: vanishing-row filter + "
+                     "packing by the C packer into page-locked memory, one upload per chunk, Delaunay #1 / vote / Delaunay #2 / scale "
+                     "kernel / road model on the device, window median; a declared deviation from the reference (check_triangle='fixed'), "
+                     "bit-equal to the fixed-mode oracle")}
 
 
 def latency_leg(args, device, sizes, seed, frames=100):
@@ -412,7 +423,7 @@ def latency_leg(args, device, sizes, seed, frames=100):
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
     fr = [synth.synth_frame(300000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(frames)]
     out = {}
-    for name, kw in (("scipy", {}), ("gpu", {"triangulation": "gpu"})):
+    for name, kw in (("scipy", {}), ("gpu", {"triangulation": "gpu"}), ("gpu_exact", {"triangulation": "gpu", "check_triangle": "reference"})):
         est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, delaunay_workers=0, **kw)
         for f3, f2 in fr[:5]:
             est.scale_calculation(f3.copy(), f2)
@@ -769,6 +780,10 @@ def main():
                 line["e2e_gpu_triangulation"] = e2e_gpu_leg(args, local, sizes, 2024, 32768)
             except Exception as exc:                                    # noqa: BLE001
                 line["e2e_gpu_triangulation"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                line["e2e_gpu_exact"] = e2e_gpu_leg(args, local, sizes, 2024, 16384, exact=True)
+            except Exception as exc:                                    # noqa: BLE001
+                line["e2e_gpu_exact"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             try:
                 line["e2e_rescale"] = e2e_rescale_leg(args, local, sizes, 2024, 32768)
             except Exception as exc:                                    # noqa: BLE001

@@ -23,8 +23,8 @@ using namespace mvosr;
 namespace {
 
 constexpr int kQhMaxPoints = 8000;        // facet ids are 16-bit: 7 * (n + 1) + 64 facets per run
-constexpr int kQhMaxNew = 64;             // facets of one cone (one lane each)
-constexpr int kQhMaxVis = 64;             // visible facets of one insertion
+constexpr int kQhMaxNew = 64;             // facets of one cone (one lane each; 5.6 on average, 35 the most seen in 512 frames of 2000 points)
+constexpr int kQhMaxVis = 64;             // visible facets of one insertion (3.6 on average, 33 the most seen)
 constexpr int kQhMaxHz = 64;              // horizon facets of one insertion
 constexpr double kQhEps = 2.220446049250313e-16;
 constexpr double kQhHuge = 1.797e308;
@@ -189,56 +189,33 @@ __device__ __forceinline__ QhWalk qh_walk_cone(const QhLds &L, int start, double
     return R;
 }
 
-// One chunk (<= 64 arrivals, lane order = Qhull's processing order) appended to the targets' outside sets: qh_partitionpoint's
-// list rule.  A target's list is arena[t_off .. t_off + t_cnt) + [t_bestp]; the furthest point stays last, a point that
-// arrives further than it takes over and the old one enters the list in the arrival's place.
-__device__ __forceinline__ void qh_place_chunk(QhLds &L, uint16_t *arena, bool valid, int tgt, int p, double d) {
+// One chunk (<= 64 arrivals, lanes 0 .. count-1 in Qhull's processing order) appended to the targets' outside sets:
+// qh_partitionpoint's list rule.  A target's list is arena[t_off .. t_off + t_cnt) + [t_bestp]; the furthest point stays last, a
+// point that arrives further than it takes over and the old one enters the list in the arrival's place.  Lane j keeps target
+// j's state in registers and the arrivals are broadcast one by one (v_readlane): ~14 instructions per arrival.
+__device__ __forceinline__ void qh_place_chunk(QhLds &L, uint16_t *arena, int count, int m, int tgt, int p, double d) {
     const int lane = lane_id();
-    uint64_t rem = __ballot(valid);
-    while (rem) {
-        const int l0 = ffs64(rem);
-        const int g = __shfl(tgt, l0);
-        const bool in_g = valid && tgt == g;
-        const uint64_t grp = __ballot(in_g);
-        rem &= ~grp;
-        const double cbd = L.t_bestd[g];
-        const int cbp = L.t_bestp[g];
-        const uint32_t base = L.t_off[g] + L.t_cnt[g];
-        // inclusive scan of (d, lane): the later arrival wins only when strictly further
-        double sd = in_g ? d : -kQhHuge;
-        int si = lane;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const double pd = __shfl_up(sd, o);
-            const int pi = __shfl_up(si, o);
-            if (lane >= o && !(sd > pd)) { sd = pd; si = pi; }
+    uint32_t base = 0, cnt = 0; int bestp = kQhNone; double bestd = -kQhHuge;
+    if (lane < m) { base = L.t_off[lane]; cnt = L.t_cnt[lane]; bestp = L.t_bestp[lane]; bestd = L.t_bestd[lane]; }
+    for (int i = 0; i < count; ++i) {
+        const int ti = __builtin_amdgcn_readlane(tgt, i);
+        const int pi = __builtin_amdgcn_readlane(p, i);
+        const double di = readlane_d(d, i);
+        if (lane == ti) {
+            if (bestp == kQhNone) { bestp = pi; bestd = di; }
+            else {
+                const bool further = di > bestd;
+                arena[base + cnt] = (uint16_t)(further ? bestp : pi);
+                ++cnt;
+                if (further) { bestp = pi; bestd = di; }
+            }
         }
-        double ed = __shfl_up(sd, 1);
-        int ei = __shfl_up(si, 1);
-        if (lane == 0) { ed = -kQhHuge; ei = 0; }
-        const bool from_lanes = ed > cbd || (cbp == kQhNone && ed > -kQhHuge);       // the furthest before me arrived in this chunk
-        const double prevd = from_lanes ? ed : (cbp == kQhNone ? -kQhHuge : cbd);
-        const int ep = __shfl(p, ei);
-        const int prevp = from_lanes ? ep : cbp;
-        const bool record = in_g && (d > prevd || prevp == kQhNone);
-        const int entry = record ? prevp : p;
-        const bool has = in_g && entry != kQhNone;
-        const uint64_t hm = __ballot(has);
-        if (has) arena[base + popc64(hm & lanemask_lt())] = (uint16_t)entry;
-        const int lastl = 63 - __clzll((long long)grp);
-        const double gd = __shfl(sd, lastl);
-        const int gi = __shfl(si, lastl);
-        const int gp = __shfl(p, gi);
-        if (lane == 0) {
-            L.t_cnt[g] += (uint32_t)popc64(hm);
-            if (cbp == kQhNone || gd > cbd) { L.t_bestd[g] = gd; L.t_bestp[g] = (uint16_t)gp; }
-        }
-        __syncthreads();
     }
+    if (lane < m) { L.t_cnt[lane] = cnt; L.t_bestp[lane] = (uint16_t)bestp; L.t_bestd[lane] = bestd; }
 }
 
 // One frame, one wavefront.  Returns the reason the frame was declined (QH_OK: rows written, `nrows` of them).
-__device__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
+__device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
     const int lane = lane_id();
     const QhPlan P = qh_plan(a.cap_pts);
     char *ws = a.ws + (size_t)f * a.ws_stride;
@@ -450,7 +427,7 @@ __device__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
                         atomicAdd(&L.t_total[tgt], 1u);
                     } else { tgt = TT[p]; d = DD[p]; }
                 }
-                if (pass == 1) qh_place_chunk(L, arena, valid, tgt, p, d);
+                if (pass == 1) qh_place_chunk(L, arena, min(64, total - base), 4, valid ? tgt : -1, p, d);
             }
             __syncthreads();
             __threadfence_block();
@@ -702,7 +679,7 @@ __device__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
                 }
                 atop += (uint32_t)S;
                 __syncthreads();
-                if (S > 0 && S <= 64) qh_place_chunk(L, arena, valid0, tgt0, q0, d0);
+                if (S > 0 && S <= 64) qh_place_chunk(L, arena, S, m, tgt0, q0, d0);
                 else for (int base = 0; base < S; base += 64) {
                     const int i = base + lane;
                     const bool valid = i < S;
@@ -714,7 +691,8 @@ __device__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
                         q = r < (int)L.viscnt[e] ? arena[L.visoff[e] + r] : L.visbest[e];
                         tgt = TT[i]; d = DD[i];
                     }
-                    qh_place_chunk(L, arena, valid, tgt, q, d);
+                    qh_place_chunk(L, arena, min(64, S - base), m, tgt, q, d);
+                    __syncthreads();
                 }
                 __syncthreads();
             }
@@ -752,6 +730,8 @@ __device__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
     return why;
 }
 
+// 119 registers and 9.7 KB of LDS: four wavefronts per SIMD.  (Compiled for five, six and eight — 96 / 80 / 64 registers with
+// spills, the LDS tables halved — the same launch of 4096 frames took 41 / 50 / 66 ms instead of 34: LABNOTES §9.)
 __global__ __launch_bounds__(64) void qhull_rows_kernel(const QhArgs a) {
     __shared__ QhLds L;
     const int64_t f = blockIdx.x;

@@ -270,7 +270,10 @@ class ScaleEstimator:
         if F == 0:
             return np.zeros(0), np.zeros(0)
         stage = bool(_single)
-        if self.triangulation == "gpu" and tri1s is None and tri2s is None:
+        # (the Qhull-rows kernel is a chain of dependent insertions: ~20 ms per 2000-point triangulation however few the frames —
+        # a handful of frames, the per-frame call of /root/reference/src/main.py:113 among them, is quicker through SciPy: 6 ms)
+        few_exact = self.check_triangle == "reference" and F < self.GPU_EXACT_MIN_FRAMES
+        if self.triangulation == "gpu" and tri1s is None and tri2s is None and not few_exact:
             raw, status, level, counts, host_errors, last = self._stream_gpu(feature3ds, feature2ds, stage)
         elif tri1s is None and tri2s is None and not _single and F > self.PIPELINE_CHUNK:
             raw, status, level, counts, host_errors, last = self._stream_chunks(feature3ds, feature2ds)
@@ -448,6 +451,9 @@ class ScaleEstimator:
     GPU_CHUNK = 8192            # frames per chunk of the device-triangulation path, at most (a call of F frames uses chunks of F/4, 512 at least: the pipeline needs a few)
     GPU_RESIDENT = 512          # frames the GPU works on at once (two 8-wavefront workgroups per CU): chunks are multiples of it
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk (40 B each in staging memory, ~180 B each on the device)
+    GPU_EXACT_MIN_FRAMES = 8    # ... calls of fewer frames take SciPy's triangulations (same rows, lower latency)
+    GPU_EXACT_CHUNK = 16384     # check_triangle="reference" (the Qhull-rows kernel): frames per chunk, at most ...
+    GPU_EXACT_CHUNK_POINTS = 33000000   # ... and features per chunk (~0.75 KB each on the device: 25 GB at the cap)
 
     def _chunk_gpu(self, f3s, f2s, stage, tables=False):
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
@@ -538,14 +544,22 @@ class ScaleEstimator:
         # profiles/e2e_chunk_sweep.py; the points cap keeps 2000-feature frames at 5000 per chunk), but a call that is ONE chunk packs,
         # uploads and computes one after the other: at least four chunks per call, of 512 frames or more
         C = int(min(self.GPU_CHUNK, max(512, -(-F // 4))))
+        exact = self.check_triangle == "reference"
+        chunk_points = self.GPU_CHUNK_POINTS
+        if exact:
+            # The Qhull-rows kernel is a chain of ~n dependent insertions per frame (one wavefront each): a launch lasts ~25 ms
+            # whether it holds 500 frames or 4 000, and only resident wavefronts fill the GPU — chunks as large as the workspace
+            # allows (0.56 KB per point of frames x largest frame), no short first chunks: the host's packing is 1 % of the time
+            C = int(min(self.GPU_EXACT_CHUNK, F))
+            chunk_points = self.GPU_EXACT_CHUNK_POINTS
         # (the points cap as it will bite, from the first frames' sizes: the short first chunks are fractions of THAT chunk)
         mean_pts = max(1, sum(len(x) for x in feature3ds[:64]) // min(F, 64))
-        C = int(max(512, min(C, self.GPU_CHUNK_POINTS // mean_pts)))
+        C = int(max(512, min(C, chunk_points // mean_pts)))
         # chunks of at most GPU_CHUNK frames and GPU_CHUNK_POINTS features (a chunk's planes, rows and staging memory
         # scale with its points: dense frames travel in smaller chunks)
         # the first chunks are short (C/8, C/4, C/2): the GPU starts after the pack + upload of 1/8 chunk instead of a whole
         # one, and the host, which prepares a frame in less time than the GPU spends on it, is ahead from then on
-        ramp = [int(C * x) for x in self.GPU_RAMP_FRACTIONS] if (self.GPU_RAMP and C >= 2048 and F >= 3 * C) else []
+        ramp = [int(C * x) for x in self.GPU_RAMP_FRACTIONS] if (self.GPU_RAMP and not exact and C >= 2048 and F >= 3 * C) else []
 
         from .engine import frame_tables
 
@@ -559,17 +573,18 @@ class ScaleEstimator:
                 # frames are packable in place; a Python loop over them was 7 ms per 32 768 frames)
                 tb = frame_tables(feature3ds[a_:b_], feature2ds[a_:b_], remap_in_place=bool(self.mutate_inputs))
                 lens = tb[2].astype(np.int64) if tb is not None else np.fromiter((len(x) for x in feature3ds[a_:b_]), dtype=np.int64, count=b_ - a_)
-                over = int(np.searchsorted(np.cumsum(lens), self.GPU_CHUNK_POINTS, side="right"))
+                over = int(np.searchsorted(np.cumsum(lens), chunk_points, side="right"))
                 b_ = min(b_, a_ + max(over, 1))
                 # the triangulation's workspace is sized frames x LARGEST frame (mvosr_delaunay_batch): one 20 000-point frame
                 # among thousands of small ones must not turn into a 20 GB request — such a chunk is cut short
-                while b_ - a_ > 1 and (b_ - a_) * int(lens[:b_ - a_].max()) > 2 * self.GPU_CHUNK_POINTS:
+                while b_ - a_ > 1 and (b_ - a_) * int(lens[:b_ - a_].max()) > 2 * chunk_points:
                     b_ = a_ + max(1, (b_ - a_) // 2)
                 # a chunk is a whole number of the GPU's resident sets of frames (512 eight-wavefront workgroups on 256 CUs):
                 # the triangulation kernels then have no partly filled last round (32 768 frames of 2000 features in chunks of
                 # 5000: 349-388 k frames/s, of 4096: 379-408 k)
                 ctx_ = self.engine.ctx
-                res = max(self.GPU_RESIDENT, int(ctx_.lib.mvosr_delaunay_frames_per_cu(int(lens[:b_ - a_].max()))) * int(ctx_.n_cu))
+                res = (16 * int(ctx_.n_cu)) if exact else \
+                    max(self.GPU_RESIDENT, int(ctx_.lib.mvosr_delaunay_frames_per_cu(int(lens[:b_ - a_].max()))) * int(ctx_.n_cu))
                 if b_ < F and b_ - a_ >= 2 * res:
                     b_ = a_ + ((b_ - a_) // res) * res
                 yield a_, b_, (tuple(t[:b_ - a_] for t in tb) if tb is not None else None)
@@ -609,7 +624,7 @@ class ScaleEstimator:
         f2 = np.asarray(feature2d, dtype=np.float64)
         mutate, self.mutate_inputs = self.mutate_inputs, False
         try:
-            if self.triangulation == "gpu" and not mutate:
+            if self.triangulation == "gpu" and not mutate and self.check_triangle == "fixed":
                 # (the device's triangulations for this one frame as well: two host Delaunay calls are 5 ms, the whole
                 # per-frame device path 1.5)
                 one = self._chunk_gpu([f3], [f2], True)

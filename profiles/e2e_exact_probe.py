@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""End-to-end calls of the reference-exact device path (triangulation="gpu", check_triangle="reference") under different chunking.
+   python profiles/e2e_exact_probe.py [frames] [features]     (MVOSR_QH_WAVES=4|5|6|8 picks the kernel's register budget)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvoscalerecovery_amd import synth                                     # noqa: E402
+from mvoscalerecovery_amd.scale_calculator import ScaleEstimator            # noqa: E402
+
+
+def main():
+    F = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+    pool = [synth.synth_frame(i, n, base_seed=2024) for i in range(min(F, 2048))]
+    f3s = [pool[i % len(pool)][0] for i in range(F)]
+    f2s = [pool[i % len(pool)][1] for i in range(F)]
+    for ramp, chunk in ((True, 8192), (False, 8192), (False, 4096), (False, 16384)):
+        est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle="reference", delaunay_workers=0)
+        est.GPU_RAMP = ramp
+        est.GPU_CHUNK = chunk
+        est.GPU_CHUNK_POINTS = 40000000
+        est.scale_calculation_batch(f3s, f2s)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            est.scale_calculation_batch(f3s, f2s)
+            ts.append(time.perf_counter() - t0)
+        print("ramp %-5s chunk %5d: %.1f ms per call of %d frames = %.1f k frames/s (declined in last chunk %d)" % (
+            ramp, chunk, min(ts) * 1e3, F, F / min(ts) / 1e3, est.last_declined), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,7 @@ def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     npts = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
     ctx = _lib.Context(0)
-    for n, count in ((30, 8), (150, 16), (400, 16), (1000, 8), (npts, 16)):
+    for n, count in ((30, 8), (150, 16), (400, 16), (1000, 8), (npts if npts > 0 else 777, 16)):
         sets = [synth.synth_frame(s, n, base_seed=31415)[1] for s in range(count)]
         got = packing.delaunay_gpu(ctx, sets, rows="qhull", order_out=True)
         ok = bad = dec = 0
@@ -65,8 +65,11 @@ def throughput(ctx, frames, npts):
         ctx.sync()
         best = min(best, time.perf_counter() - t0)
     st = d_st.download()
-    print("launch of %6d sets of %s points: %8.2f ms = %7.1f k sets/s (declined %d)" % (
-        frames, npts if npts > 0 else "300-1500", best * 1e3, frames / best / 1e3, int((st != 0).sum())), flush=True)
+    why = {}
+    for x in st[st != 0]:
+        why[WHY[int(x) >> 8]] = why.get(WHY[int(x) >> 8], 0) + 1
+    print("launch of %6d sets of %s points: %8.2f ms = %7.1f k sets/s (declined %d %s)" % (
+        frames, npts if npts > 0 else "300-1500", best * 1e3, frames / best / 1e3, int((st != 0).sum()), why if why else ""), flush=True)
     for b in (d_u, d_v, d_off, d_cnt, d_toff, d_tri, d_tc, d_st):
         b.free()
 
