@@ -53,8 +53,16 @@ struct QhArgs {
     int64_t n_frames;
     const int64_t *pts_off; const int32_t *pts_cnt; const double *u; const double *v; const int32_t *keep;
     const int64_t *tri_off; int32_t *tri; int32_t *tri_cnt; int32_t *n_used; int32_t *status; int32_t *order_out;
+    unsigned long long *stamps;
     char *ws; size_t ws_stride; int cap_pts;      // per-frame slice, laid out by QhPlan for cap_pts = max_pts + 1 points
 };
+
+#ifdef MVOSR_QH_STAMPS
+static unsigned long long *g_qh_stamps = nullptr;
+#define QH_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc[k] += t_ - t_last; t_last = t_; } while (0)
+#else
+#define QH_STAMP(k) do { } while (0)
+#endif
 
 struct QhPlan { size_t x, y, z, fac, arena, tt, dd, total; uint32_t fcap, acap; };
 __host__ __device__ inline QhPlan qh_plan(int cap_pts) {
@@ -106,12 +114,22 @@ __device__ __forceinline__ double wave_min_d(double v) {
     return v;
 }
 
+// One wavefront per workgroup: LDS instructions of a wavefront execute in order, so a write by one lane is seen by a later read
+// of another lane without a barrier — only the COMPILER must keep the order.  (__syncthreads() also waits for every global
+// load and store in flight: in the insertion loop that was a memory round trip per call.)
+__device__ __forceinline__ void qh_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 struct QhPlane { double n0, n1, n2, d; bool gauss; bool upper; };
 
-// qh_sethyperplane_det for three vertices (rows in the facet's vertex order), qh_normalize2, the offset; `gauss`: Qhull would
-// redo the plane by Gaussian elimination (a vertex further than DISTround from it) — not restated, the frame is declined.
+// qh_sethyperplane_det for three vertices (rows in the facet's vertex order), qh_normalize2, the offset; where a vertex is
+// further than DISTround from that plane (thin facets), qh_sethyperplane_gauss as Qhull does: elimination with partial
+// pivoting on the two edge vectors, back substitution from normal[2] = -+1, positive normalisation.  `gauss` (declined): a
+// pivot within Qhull's NEARzero, where it would go on to qh_orientoutside.
 __device__ __forceinline__ QhPlane qh_plane(double x0, double y0, double z0, double x1, double y1, double z1, double x2, double y2, double z2,
-                                            bool top, double distround, double anground) {
+                                            bool top, double distround, double anground, double nz0, double nz1) {
     QhPlane P;
     const double dx1 = x1 - x0, dy1 = y1 - y0, dz1 = z1 - z0;
     const double dx2 = x2 - x0, dy2 = y2 - y0, dz2 = z2 - z0;
@@ -122,11 +140,39 @@ __device__ __forceinline__ QhPlane qh_plane(double x0, double y0, double z0, dou
     P.gauss = !(norm > 1e-290);
     if (!top) norm = -norm;
     n0 = n0 / norm; n1 = n1 / norm; n2 = n2 / norm;
-    P.n0 = n0; P.n1 = n1; P.n2 = n2;
-    P.d = -(x0 * n0 + y0 * n1 + z0 * n2);
-    const double e2 = P.d + (x2 * n0 + y2 * n1 + z2 * n2);
-    const double e1 = P.d + (x1 * n0 + y1 * n1 + z1 * n2);
-    if (e2 > distround || e2 < -distround || e1 > distround || e1 < -distround) P.gauss = true;
+    double d = -(x0 * n0 + y0 * n1 + z0 * n2);
+    const double e2 = d + (x2 * n0 + y2 * n1 + z2 * n2);
+    const double e1 = d + (x1 * n0 + y1 * n1 + z1 * n2);
+    if (e2 > distround || e2 < -distround || e1 > distround || e1 < -distround) {
+        double a0 = dx1, a1 = dy1, a2 = dz1, b0 = dx2, b1 = dy2, b2 = dz2;
+        bool sign = top;
+        if (__builtin_fabs(b0) > __builtin_fabs(a0)) {
+            double t;
+            t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; t = a2; a2 = b2; b2 = t;
+            sign = !sign;
+        }
+        if (__builtin_fabs(a0) <= nz0) P.gauss = true;
+        const double q = b0 / a0;
+        b1 -= q * a1;
+        b2 -= q * a2;
+        if (__builtin_fabs(b1) <= nz1) P.gauss = true;
+        if (b1 < 0) sign = !sign;
+        if (a0 < 0) sign = !sign;
+        n2 = sign ? -1.0 : 1.0;
+        n1 = 0.0;
+        n1 -= b2 * n2;
+        n1 /= b1;
+        n0 = 0.0;
+        n0 -= a1 * n1;
+        n0 -= a2 * n2;
+        n0 /= a0;
+        norm = __builtin_sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+        n0 = n0 / norm; n1 = n1 / norm; n2 = n2 / norm;
+        d = -(x0 * n0);
+        d -= y0 * n1;
+        d -= z0 * n2;
+    }
+    P.n0 = n0; P.n1 = n1; P.n2 = n2; P.d = d;
     P.upper = n2 > -anground * 2.0;
     if (__builtin_fabs(n2) < 1e-9) P.gauss = true;
     return P;
@@ -136,7 +182,7 @@ __device__ __forceinline__ double qh_dist(double x, double y, double z, double n
     return d + x * n0 + y * n1 + z * n2;
 }
 
-struct QhConst { double distround, minvisible, minoutside, distoutside, guard, anground; };
+struct QhConst { double distround, minvisible, minoutside, distoutside, guard, anground, nz0, nz1; };
 
 struct QhWalk { int tgt; double d; int state; int best; };     // state 0 placed, 1 ended below its best, 2 no best, 3 bad (band / above none)
 
@@ -266,7 +312,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
     }
     __threadfence_block();
     int ext[6];
-    double maxabs = 0.0, maxwidth = 0.0, maxsum = 0.0, zlow = 0.0, zhigh = 0.0, nz1 = 0.0, nz2 = 0.0;
+    double maxabs = 0.0, maxwidth = 0.0, maxsum = 0.0, zlow = 0.0, zhigh = 0.0, nz0 = 0.0, nz1 = 0.0, nz2 = 0.0;
     {
         const int m1 = n + 1;
         for (int k = 0; k < 3; ++k) {
@@ -285,6 +331,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
             maxabs = fmax(maxabs, maxcoord);
             maxsum += maxcoord;
             ext[2 * k] = loi; ext[2 * k + 1] = hii;
+            if (k == 0) nz0 = 80 * maxsum * kQhEps;
             if (k == 1) nz1 = 80 * maxsum * kQhEps;
             if (k == 2) nz2 = 80 * maxsum * kQhEps;
         }
@@ -302,6 +349,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
         K.minoutside = 2 * K.minvisible;
         K.distoutside = 2 * K.minoutside;
         K.guard = 64 * K.distround;
+        K.nz0 = nz0; K.nz1 = nz1;
     }
     __threadfence_block();
 
@@ -355,7 +403,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
         cx = cx / 4; cy = cy / 4; cz = cz / 4;
         bool flip = false;
         {
-            const QhPlane F0 = qh_plane(X[vs[1]], Y[vs[1]], Z[vs[1]], X[vs[2]], Y[vs[2]], Z[vs[2]], X[vs[3]], Y[vs[3]], Z[vs[3]], true, K.distround, K.anground);
+            const QhPlane F0 = qh_plane(X[vs[1]], Y[vs[1]], Z[vs[1]], X[vs[2]], Y[vs[2]], Z[vs[2]], X[vs[3]], Y[vs[3]], Z[vs[3]], true, K.distround, K.anground, K.nz0, K.nz1);
             if (F0.gauss) return QH_GAUSS;
             const double d = F0.d + cx * F0.n0 + cy * F0.n1 + cz * F0.n2;
             if (d > K.distround) flip = true;
@@ -366,7 +414,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
             int q[3], k = 0;
             for (int j = 0; j < 4; ++j) if (j != lane) q[k++] = vs[j];
             const bool top = ((lane & 1) == 0) != flip;
-            const QhPlane F = qh_plane(X[q[0]], Y[q[0]], Z[q[0]], X[q[1]], Y[q[1]], Z[q[1]], X[q[2]], Y[q[2]], Z[q[2]], top, K.distround, K.anground);
+            const QhPlane F = qh_plane(X[q[0]], Y[q[0]], Z[q[0]], X[q[1]], Y[q[1]], Z[q[1]], X[q[2]], Y[q[2]], Z[q[2]], top, K.distround, K.anground, K.nz0, K.nz1);
             gauss = F.gauss;
             L.npl[lane][0] = F.n0; L.npl[lane][1] = F.n1; L.npl[lane][2] = F.n2; L.npl[lane][3] = F.d;
             L.nnb[lane][3] = F.upper ? 1 : 0;
@@ -450,6 +498,10 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
         // list position -> facet id: perm0 first, then the other initial facets in order, then creation order
         auto pos2id = [&](int pos) { return pos >= 4 || perm0 == 0 ? pos + 1 : (pos == 0 ? perm0 : (pos < perm0 ? pos : pos + 1)); };
         int pos = 0, step = 0;
+#ifdef MVOSR_QH_STAMPS
+        unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
         while (true) {
             // (a) the first facet in list order with an outside set (its record's first half comes along)
             int cur = -1;
@@ -472,8 +524,8 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
             cur = uni(cur);
             ++step;
             const int p = (int)(c3 >> 16);
-            const double px = X[p], py = Y[p], pz = Z[p];
             if (a.order_out) { if (lane == 0 && p < n) a.order_out[off + p] = step; }     // (compacted ids when `keep` is given)
+            QH_STAMP(0);
             // (b) qh_findhorizon: visible facets, breadth first, neighbours in order.  Facets tested in this insertion are
             // remembered in LDS (visible ones with their outside sets, horizon ones with their vertices and neighbours)
             int nvis = 1, head = 0, nhz = 0;
@@ -481,7 +533,8 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                 L.visq[0] = (uint16_t)cur; L.visnb[0][0] = (uint16_t)(c2 & 0xFFFFu); L.visnb[0][1] = (uint16_t)(c2 >> 16); L.visnb[0][2] = (uint16_t)(c3 & 0xFFFFu);
                 L.visoff[0] = c4; L.viscnt[0] = (uint16_t)(c5 & 0xFFFFu); L.visbest[0] = kQhNone;
             }
-            __syncthreads();
+            qh_lds_sync();
+            const double px = X[p], py = Y[p], pz = Z[p];        // (in flight together with the first round's facet records)
             bool bad = false, copl = false;
             while (head < nvis) {
                 const int ne = min(nvis - head, 21);
@@ -526,15 +579,16 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                     L.hzr[q][4] = G.nb[0]; L.hzr[q][5] = G.nb[1]; L.hzr[q][6] = G.nb[2];
                 }
                 head += ne; nvis += add; nhz += addz;
-                __syncthreads();
+                qh_lds_sync();
             }
             if (why) return why;
             if (__any(copl)) return QH_COPLANAR_HORIZON;
             if (__any(bad)) return QH_BAND;
+            QH_STAMP(1);
             // (c) qh_makenewfacets: for each visible facet in order, for each horizon neighbour in order, a facet (apex first)
             int m = 0;
             for (int e = lane; e < nvis; e += 64) L.visrep[e] = kQhNone;
-            __syncthreads();
+            qh_lds_sync();
             bool gauss = false, notconv = false;
             for (int base = 0; base < nvis; base += 21) {
                 const int ne = min(nvis - base, 21);
@@ -560,7 +614,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                     const bool top = gtop ? (skip & 1) : !(skip & 1);
                     const double ax = X[va], ay = Y[va], az = Z[va], bx = X[vb], by = Y[vb], bz = Z[vb];
                     const double ox = X[vo], oy = Y[vo], oz = Z[vo];
-                    const QhPlane F = qh_plane(px, py, pz, ax, ay, az, bx, by, bz, top, K.distround, K.anground);
+                    const QhPlane F = qh_plane(px, py, pz, ax, ay, az, bx, by, bz, top, K.distround, K.anground, K.nz0, K.nz1);
                     gauss = gauss || F.gauss;
                     // the horizon facet's vertex opposite the shared ridge must lie below the cone facet (else Qhull merges)
                     if (qh_dist(ox, oy, oz, F.n0, F.n1, F.n2, F.d) > -K.guard) notconv = true;
@@ -578,10 +632,11 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                 m += add;
             }
             if (why) return why;
-            __syncthreads();
+            qh_lds_sync();
             if (__any(gauss)) return QH_GAUSS;
             if (__any(notconv)) return QH_NOT_CONVEX;
             if (m < 3) return QH_OPEN_CONE;
+            QH_STAMP(2);
             // (d) qh_matchnewfacets: neighbour 1 shares the ridge {apex, b}, neighbour 2 the ridge {apex, a}
             {
                 bool open = false; notconv = false;
@@ -605,9 +660,9 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                 }
                 if (__any(open)) return QH_OPEN_CONE;
                 if (__any(notconv)) return QH_NOT_CONVEX;
-                __syncthreads();
+                qh_lds_sync();
                 if (lane < m) { L.nnb[lane][1] = (uint8_t)n1; L.nnb[lane][2] = (uint8_t)n2; }
-                __syncthreads();
+                qh_lds_sync();
             }
             // qh_sharpnewfacets: the cone's normals in more than one orthant
             bool sharp;
@@ -617,6 +672,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                 if (lane < m) diff = ((L.npl[lane][0] > 0 ? 1 : 0) | (L.npl[lane][1] > 0 ? 2 : 0) | (L.npl[lane][2] > 0 ? 4 : 0)) != q0;
                 sharp = __any(diff);
             }
+            QH_STAMP(3);
             // (e) qh_partitionvisible: the visible facets' points, in list order, to the cone
             int S = 0;
             {
@@ -625,7 +681,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                     for (int e = 0; e < nvis; ++e) { L.viscum[e] = c; c += L.viscnt[e] + (L.visbest[e] != kQhNone ? 1u : 0u); }
                     L.viscum[nvis] = c;
                 }
-                __syncthreads();
+                qh_lds_sync();
                 S = (int)L.viscum[nvis];
             }
             if (atop + (uint32_t)S > P.acap) return QH_ARENA_FULL;
@@ -669,8 +725,9 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                 if (__any(fail_band)) return QH_BAND;
                 if (fail_sharp) return QH_NOT_SHARP;
                 if (__any(fail_none)) return QH_ABOVE_NONE;
-                __syncthreads();
+                qh_lds_sync();
                 if (S > 64) __threadfence_block();
+                QH_STAMP(4);
                 // room for the cone's outside sets, then the placement in arrival order
                 if (lane < m) {
                     uint32_t o = atop;
@@ -678,7 +735,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                     L.t_off[lane] = o; L.t_cnt[lane] = 0; L.t_bestp[lane] = kQhNone; L.t_bestd[lane] = -kQhHuge;
                 }
                 atop += (uint32_t)S;
-                __syncthreads();
+                qh_lds_sync();
                 if (S > 0 && S <= 64) qh_place_chunk(L, arena, S, m, tgt0, q0, d0);
                 else for (int base = 0; base < S; base += 64) {
                     const int i = base + lane;
@@ -692,10 +749,11 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                         tgt = TT[i]; d = DD[i];
                     }
                     qh_place_chunk(L, arena, min(64, S - base), m, tgt, q, d);
-                    __syncthreads();
+                    qh_lds_sync();
                 }
-                __syncthreads();
+                qh_lds_sync();
             }
+            QH_STAMP(5);
             // (f) the cone's facet records; the visible facets die
             if (lane < m) {
                 QhFacet G;
@@ -709,9 +767,13 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
             }
             for (int e = lane; e < nvis; e += 64) fac[L.visq[e]].flags |= 4;
             nfac += m;
-            __syncthreads();
+            qh_lds_sync();
             __threadfence_block();
+            QH_STAMP(6);
         }
+#ifdef MVOSR_QH_STAMPS
+        if (a.stamps && f == 0 && lane == 0) { for (int k = 0; k < 8; ++k) a.stamps[k] = acc[k]; a.stamps[8] = (unsigned long long)step; }
+#endif
         // ---- 4. SciPy's rows: lower facets in list order; vertices by decreasing vertex id, first two swapped unless top ----
         const int64_t toff = a.tri_off[f];
         for (int base = 0; base < nfac; base += 64) {
@@ -732,7 +794,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
 
 // 119 registers and 9.7 KB of LDS: four wavefronts per SIMD.  (Compiled for five, six and eight — 96 / 80 / 64 registers with
 // spills, the LDS tables halved — the same launch of 4096 frames took 41 / 50 / 66 ms instead of 34: LABNOTES §9.)
-__global__ __launch_bounds__(64) void qhull_rows_kernel(const QhArgs a) {
+__global__ __launch_bounds__(64, 4) void qhull_rows_kernel(const QhArgs a) {
     __shared__ QhLds L;
     const int64_t f = blockIdx.x;
     int nrows = 0;
@@ -744,6 +806,10 @@ __global__ __launch_bounds__(64) void qhull_rows_kernel(const QhArgs a) {
 }
 
 }  // namespace
+
+#ifdef MVOSR_QH_STAMPS
+extern "C" void mvosr_debug_qh_stamps(void *dptr) { g_qh_stamps = reinterpret_cast<unsigned long long *>(dptr); }
+#endif
 
 extern "C" int mvosr_delaunay_qhull_max_points(void) { return kQhMaxPoints; }
 
@@ -763,6 +829,11 @@ extern "C" int mvosr_delaunay_qhull_batch(mvosr_ctx *ctx, int64_t n_frames, cons
     a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
     a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.order_out = order_out;
     a.cap_pts = max_pts + 1;
+#ifdef MVOSR_QH_STAMPS
+    a.stamps = g_qh_stamps;
+#else
+    a.stamps = nullptr;
+#endif
     const QhPlan P = qh_plan(a.cap_pts);
     a.ws_stride = P.total;
     void *ws = nullptr;

@@ -366,16 +366,17 @@ class ScaleEstimator:
         if tables is not None:
             pf, blk = pack_upload_native(ctx, f3s, f2s, self.vanish, None, tables=tables)             # rescale.py:115-117
             if getattr(self, "chunk_trace", None) is not None: self.chunk_trace.append(("packed", -1, len(f3s), time.perf_counter()))
-            too_large = pf.max_feat > self._max_points()
-            if too_large:
+            if pf.max_feat > self._max_points():
                 blk.free()
-                return {"gpu": False}
+                self._refuse_oversized(pf, frame_base)
             db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk)
             if getattr(self, "chunk_trace", None) is not None: self.chunk_trace.append(("blocks", -1, len(f3s), time.perf_counter()))
         else:
             pf = packing.pack_features(f3s, f2s, self.vanish)
-            if pf.max_feat > self._max_points() or pf.n_frames == 0:
+            if pf.n_frames == 0:
                 return {"gpu": False}
+            if pf.max_feat > self._max_points():
+                self._refuse_oversized(pf, frame_base)
             db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True)
         bufs = db.bufs
         db.info.invalidate()
@@ -399,6 +400,16 @@ class ScaleEstimator:
         db.mark()
         return {"gpu": True, "pf": pf, "db": db, "out": out, "flags": flags, "side": side}
 
+    def _refuse_oversized(self, pf, frame_base):
+        """flat_selection + RANSAC hold a frame's survivors, heights and flags in ONE workgroup's LDS: a frame beyond that has no
+        kernel here (the reference takes any size — /root/reference/src/rescale.py:113-148 — at seconds per frame).  Said up
+        front, with the frame named, instead of a library error from the middle of the host path."""
+        cnt = np.asarray(pf.feat_cnt)
+        f = int(np.argmax(cnt))
+        raise ValueError("rescale.ScaleEstimator: frame %d has %d features below the vanishing row; the device-resident path takes at "
+                         "most %d per frame (one workgroup's LDS).  Thin the frame, or use scale_calculator.ScaleEstimator, whose "
+                         "dense kernels take any size." % (frame_base - self._frame_counter + f, int(cnt[f]), self._max_points()))
+
     def _resident_frames(self, max_pts):
         """Frames the triangulation kernel works on at a time (mvosr_delaunay_frames_per_cu x CUs)."""
         return max(self.GPU_RESIDENT, int(self.ctx.lib.mvosr_delaunay_frames_per_cu(int(max_pts))) * int(self.ctx.n_cu))
@@ -414,6 +425,8 @@ class ScaleEstimator:
         sampling="device", and the frames the device triangulation declined.  Synchronous."""
         ctx, lib = self.ctx, self.ctx.lib
         pf = packing.pack_features(f3s, f2s, self.vanish)                                   # rescale.py:115-117
+        if pf.n_frames and pf.max_feat > self._max_points():
+            self._refuse_oversized(pf, frame_base if np.isscalar(frame_base) else self._frame_counter)
         pf.extra["canonical"] = True
         packing.attach_tri1(pf, None, self.delaunay_workers)                                # :124
         db = DeviceBatch(ctx, pf, with_tri2=False)

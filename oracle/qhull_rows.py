@@ -249,10 +249,47 @@ class QhullDelaunay2D:
         n0, n1, n2 = n0 / norm, n1 / norm, n2 / norm
         f.n0, f.n1, f.n2 = n0, n1, n2
         f.off = -(x[p0] * n0 + y[p0] * n1 + z[p0] * n2)
+        gauss = False
         for p in (p2, p1):
             d = f.off + (x[p] * n0 + y[p] * n1 + z[p] * n2)
             if d > self.distround or d < -self.distround:
-                raise Declined("facet plane needs Gaussian elimination")
+                gauss = True
+                break
+        if gauss:
+            # qh_sethyperplane_gauss: Gaussian elimination with partial pivoting on the two edge vectors, back substitution
+            # from normal[2] = -+1, positive normalisation; the sign follows the row swaps and the signs of the pivots
+            r0 = [dx1, dy1, dz1]
+            r1 = [dx2, dy2, dz2]
+            sign = bool(f.top)
+            if abs(r1[0]) > abs(r0[0]):
+                r0, r1 = r1, r0
+                sign = not sign
+            if abs(r0[0]) <= self.nearzero[0]:
+                raise Declined("near-zero pivot")
+            q = r1[0] / r0[0]
+            r1[1] -= q * r0[1]
+            r1[2] -= q * r0[2]
+            if abs(r1[1]) <= self.nearzero[1]:
+                raise Declined("near-zero pivot")
+            if r1[1] < 0:
+                sign = not sign
+            if r0[0] < 0:
+                sign = not sign
+            n2 = -1.0 if sign else 1.0
+            n1 = 0.0
+            n1 -= r1[2] * n2
+            n1 /= r1[1]
+            n0 = 0.0
+            n0 -= r0[1] * n1
+            n0 -= r0[2] * n2
+            n0 /= r0[0]
+            norm = math.sqrt(n0 * n0 + n1 * n1 + n2 * n2)
+            n0, n1, n2 = n0 / norm, n1 / norm, n2 / norm
+            f.n0, f.n1, f.n2 = n0, n1, n2
+            off = -(x[p0] * n0)
+            off -= y[p0] * n1
+            off -= z[p0] * n2
+            f.off = off
         f.upper = n2 > -self.anground * 2.0
         if abs(n2) < 1e-9:
             raise Declined("vertical facet")

@@ -2383,3 +2383,19 @@ def test_stage_goldens_device_triangulation_reference_exact(gpu):
                          delaunay_workers=0)
     raw, status, level, _ = est.raw_scale_batch(f3s, f2s)
     assert raw.tolist() == [float(z["f%d_scale_first_call" % k]) for k in range(len(f3s))]
+
+
+def test_rescale_oversized_frame_is_refused_up_front(gpu):
+    """one 5000-feature frame inside a normal batch of the device-resident rescale path: a ValueError that names the
+    frame and the limit, raised before any host triangulation of the chunk — not a library error from mvosr_flat_ransac_batch."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    frames = [synth.synth_frame(i, 600, base_seed=77) for i in range(6)]
+    frames.insert(3, synth.synth_frame(99, 5000, base_seed=77))
+    for kw in ({"triangulation": "gpu"}, {"triangulation": "scipy", "sampling": "device"}):
+        est = ScaleEstimator(1.75, window_size=5, ransac_seed=3, delaunay_workers=0, **kw)
+        with pytest.raises(ValueError, match="frame 3 has 5000 features"):
+            est.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames])
+    est = ScaleEstimator(1.75, window_size=5, ransac_seed=3, delaunay_workers=0, triangulation="gpu")
+    s, _ = est.scale_calculation_batch([f[0] for f in frames[:3]], [f[1] for f in frames[:3]])      # the estimator is still usable
+    assert np.all(np.isfinite(s))
