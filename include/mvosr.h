@@ -42,7 +42,9 @@ enum mvosr_err {
     MVOSR_ERR_HIP = -1,          /* a HIP runtime call failed (message has hipGetErrorString) */
     MVOSR_ERR_ARG = -2,          /* bad argument (null pointer, negative size, ...) */
     MVOSR_ERR_TOO_LARGE = -3,    /* a frame does not fit the requested kernel variant */
-    MVOSR_ERR_NO_DEVICE = -4     /* no gfx950 device visible */
+    MVOSR_ERR_NO_DEVICE = -4,    /* no gfx950 device visible */
+    MVOSR_ERR_ALLOC = -5         /* device memory for a grow-only workspace could not be allocated (the triangulation kernels'
+                                    per-frame arrays): nothing was launched; the caller may retry with fewer frames or take its host path */
 };
 
 /* per-frame status codes written to mvosr_outputs.status.  0-3 are the reference's normal

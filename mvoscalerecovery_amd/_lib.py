@@ -24,8 +24,16 @@ TILE_W = 512                              # MVOSR_TILE_W
 HIST_BINS = 169
 
 
+ERR_ALLOC = -5
+
+
 class MvosrLibraryError(RuntimeError):
     """libmvosr.so is missing / not loadable / a call into it failed."""
+
+
+class MvosrAllocError(MvosrLibraryError):
+    """MVOSR_ERR_ALLOC: a grow-only device workspace could not be allocated; nothing was launched (the batch paths send the chunk
+    through the host's triangulations instead)."""
 
 
 class Params(C.Structure):
@@ -188,6 +196,8 @@ def load():
 def check(rc, what=""):
     if rc != 0:
         msg = load().mvosr_last_error()
+        if rc == ERR_ALLOC:
+            raise MvosrAllocError("%s failed (%d): %s" % (what or "libmvosr call", rc, (msg or b"").decode()))
         raise MvosrLibraryError("%s failed (%d): %s" % (what or "libmvosr call", rc, (msg or b"").decode()))
 
 
@@ -551,9 +561,10 @@ def pin_thread_to_node(node):
     of NUMA node ``node`` (the device's, see mvosr_device_numa_node): page-locked staging memory is then allocated next to the
     device's PCIe root port and packed by cores next to it (two-socket host, 32 768 frames of 2000 features end to end:
     502-505 k frames/s there, 460-488 k on the other node, 441-468 k left to the scheduler).  Nothing is done when the node
-    is unknown, when the thread is already confined to one node (a launcher's own pinning is respected), or with
-    MVOSR_AFFINITY=0.  Returns the CPU set applied, or None."""
-    if node is None or node < 0 or os.environ.get("MVOSR_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+    is unknown, when the thread is already confined to one node (a launcher's own pinning is respected), or WITHOUT
+    MVOSR_AFFINITY=1: the affinity of the calling thread is the host application's business — threads it starts later inherit it
+    — so the pinning is opt-in (bench.py opts in and says so).  Returns the CPU set applied, or None."""
+    if node is None or node < 0 or os.environ.get("MVOSR_AFFINITY", "0") != "1" or not hasattr(os, "sched_setaffinity"):
         return None
     try:
         mine = os.sched_getaffinity(0)

@@ -17,6 +17,8 @@
 
 #include "mvosr_host.hpp"
 
+#include <cstdlib>
+
 namespace mvosr {
 
 static thread_local char g_err[512] = "";
@@ -70,7 +72,12 @@ int ctx_workspace_bytes(mvosr_ctx *ctx, size_t bytes, void **ptr) {
         if (ctx->ws_bytes) (void)hipFree(ctx->ws_bytes);
         ctx->ws_bytes = nullptr; ctx->ws_bytes_len = 0;
         const size_t want = bytes + bytes / 4;
-        hipError_t e = hipMalloc(&ctx->ws_bytes, want);
+        hipError_t e = getenv("MVOSR_TEST_FAIL_ALLOC") ? hipErrorOutOfMemory : hipMalloc(&ctx->ws_bytes, want);      // (test hook: tests/test_gpu_parity.py)
+        if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+            (void)hipGetLastError();
+            ctx->ws_bytes = nullptr;
+            return set_error(MVOSR_ERR_ALLOC, "workspace of %zu bytes (per-frame arrays of the triangulation kernels) could not be allocated", want);
+        }
         if (e != hipSuccess) return set_hip_error("hipMalloc(workspace: per-frame arrays of large triangulations)", e);
         ctx->ws_bytes_len = want;
     }

@@ -51,7 +51,14 @@ __global__ __launch_bounds__(kRsBlock) void graph_inliers_kernel(const GraphArgs
     const int64_t f = blockIdx.x;
     const int n = a.feat_cnt[f];
     if (n <= 0) { if (threadIdx.x == 0) { if (a.status) a.status[f] = MVOSR_ST_ERR_EMPTY; if (KEEP && a.n_valid) a.n_valid[f] = 0; } return; }
-    if (KEEP && a.dt_status && a.dt_status[f] != 0) { if (threadIdx.x == 0) { if (a.status) a.status[f] = MVOSR_ST_ERR_EMPTY; if (a.n_valid) a.n_valid[f] = 0; } return; }
+    if (KEEP && a.dt_status && a.dt_status[f] != 0) {
+        // a declined first triangulation: the frame is redone on the host; its keep flags say "dropped" so that the second
+        // triangulation and flat_selection of this chunk see an empty frame instead of whatever the recycled block held
+        const int64_t off0 = a.feat_off[f];
+        for (int i = threadIdx.x; i < n; i += kRsBlock) a.keep[off0 + i] = -1;
+        if (threadIdx.x == 0) { if (a.status) a.status[f] = MVOSR_ST_ERR_EMPTY; if (a.n_valid) a.n_valid[f] = 0; }
+        return;
+    }
     const int64_t off = a.feat_off[f];
     const int64_t tb = a.tri_off[f];
     const int tn = a.tri_cnt ? a.tri_cnt[f] : (int)(a.tri_off[f + 1] - tb);

@@ -86,17 +86,18 @@ def run_sequence(data, estimator, minimum_feature_for_scale=MINIMUM_FEATURE_FOR_
             "pitchs": np.array(pitchs, dtype=np.float64), "kinds": kinds}
 
 
-def run_sequence_batched(data, estimator, minimum_feature_for_scale=MINIMUM_FEATURE_FOR_SCALE):
+def run_sequence_batched(data, estimator, minimum_feature_for_scale=MINIMUM_FEATURE_FOR_SCALE, **batch_kw):
     """Same outputs as :func:`run_sequence`, but all processed frames go through ONE call of the
     estimator's ``scale_calculation_batch`` (frames stay in order, so the window median sees the
-    same sequence).  This is the throughput path for ``main_offline``-shaped replays."""
+    same sequence).  This is the throughput path for ``main_offline``-shaped replays.  ``batch_kw`` goes to that call
+    (``id_triples`` of ``rescale.ScaleEstimator``: one entry per PROCESSED frame)."""
     kinds = plan_sequence(data, minimum_feature_for_scale)
     idx = [i for i, k in enumerate(kinds) if k == 1]
     pitchs = [estimator.initial_estimation(np.asarray(data["motions"][i], dtype=np.float64)[3:12:4].reshape(-1))
               for i in idx]
     f3 = [np.asarray(data["feature3ds"][i], dtype=np.float64) for i in idx]
     f2 = [np.asarray(data["feature2ds"][i], dtype=np.float64) for i in idx]
-    est_scales, est_stds = estimator.scale_calculation_batch(f3, f2)
+    est_scales, est_stds = estimator.scale_calculation_batch(f3, f2, **batch_kw)
     scales, error = assemble_outputs(kinds, list(est_scales), list(est_stds))
     return {"scales": np.array(scales[1:], dtype=np.float64), "error": np.array(error, dtype=np.float64),
             "pitchs": np.array(pitchs, dtype=np.float64), "kinds": kinds}

@@ -23,12 +23,16 @@ reference's (tests/golden/rescale.npz); without, agreement is statistical only.
 ``triangulation="gpu"`` is the device-resident path: C packer -> ONE upload -> Delaunay #1 (mvosr_delaunay_batch) ->
 GraphChecker vote with the decision made on the device (mvosr_graph_keep_batch) -> Delaunay #2 over the survivors, seeded
 -> flat_selection + RANSAC plane in one kernel per frame (mvosr_flat_ransac_batch) -> after the last chunk the slew
-limiter and the window median on the device (mvosr_slew_median).  No host step between the stages and NO DECLARED
-DEVIATION: the vote's edge potential is symmetric, so its mask is a function of the triangle SET (graph.py:18-36,124-145);
+limiter and the window median: a sequential recurrence over results that are on the host anyway (the statuses decide where
+the reference would raise), walked by one core in C (mvosr_slew_median_host; the device form mvosr_slew_median exists and is
+tested, the estimator does not use it).  No host step between the device stages.  The deterministic stages carry no deviation:
+the vote's edge potential is symmetric, so its mask is a function of the triangle SET (graph.py:18-36,124-145);
 flat_selection keeps a set of triangles (rescale.py:75-96); only the order of its point list (:101) follows the rows,
 and the RANSAC draws list positions uniformly (ransac.py:10) — here from a counter-based sequence keyed by
-``ransac_seed`` (None: OS entropy, the reference's behaviour); a draw that names one vertex twice (the list repeats
-vertices; the reference's SVD of such a rank-deficient sample returns a plane picked by rounding noise) is drawn again.  ``triangulation="scipy", sampling="device"`` runs the
+``ransac_seed`` (None: OS entropy, the reference's behaviour).  ONE DECLARED DEVIATION, in the sampler: a draw that names one
+vertex twice (the list repeats vertices: 0.5-2 % of the reference's draws; its SVD of such a rank-deficient sample returns a
+plane picked by rounding noise and the iteration is spent) is drawn again — DESIGN.md §3.4; the scale distribution is compared
+with the unseeded reference's in tests/test_gpu_parity.py.  ``triangulation="scipy", sampling="device"`` runs the
 same kernels on SciPy's triangulations brought to the same row form, with bit-identical results.
 """
 from __future__ import annotations
@@ -89,6 +93,9 @@ class ScaleEstimator:
         self.scale = 1
         self.inliers = None
         self.scale_queue = deque()
+        if not (1 <= int(window_size) <= 64):
+            # (the reference takes any window — np.median of an empty deque is nan for 0 —; the C loop's ring buffer holds 64)
+            raise ValueError("window_size must be between 1 and 64 (mvosr_slew_median_host's ring buffer), got %r" % (window_size,))
         self.window_size = window_size
         self.vanish = VANISH
         # build-side state
@@ -380,19 +387,25 @@ class ScaleEstimator:
             db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True)
         bufs = db.bufs
         db.info.invalidate()
-        _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, db.n_frames, bufs["feat_off"].ptr, bufs["feat_cnt"].ptr, bufs["u"].ptr,
-                                               bufs["v"].ptr, None, int(db.max_feat), bufs["tri_off"].ptr, bufs["tri1"].ptr,
-                                               bufs["tri1_cnt"].ptr, None, bufs["dt1_status"].ptr, None, None, None, None,
-                                               bufs["dt_info"].ptr), "mvosr_delaunay_batch_ex (first triangulation)")
-        bs = db.struct()
-        keep = bufs["vote_counters"]                                        # (the block's per-feature int32 plane: here the keep flags)
-        _lib.check(lib.mvosr_graph_keep_batch(ctx.handle, C.byref(bs), C.c_uint32(self._good_bits), MIN_VALID_FOR_RETRI,
-                                              bufs["dt1_status"].ptr, keep.ptr, None, None), "mvosr_graph_keep_batch")   # graph.py:18-36, rescale.py:133
-        _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, db.n_frames, bufs["feat_off"].ptr, bufs["feat_cnt"].ptr, bufs["u"].ptr,
-                                               bufs["v"].ptr, keep.ptr, int(db.max_feat), bufs["tri_off"].ptr, bufs["tri2"].ptr,
-                                               bufs["tri2_cnt"].ptr, bufs["n2_expected"].ptr, bufs["dt2_status"].ptr,
-                                               bufs["tri_off"].ptr, bufs["tri1"].ptr, bufs["tri1_cnt"].ptr, bufs["dt_info"].ptr, None),
-                   "mvosr_delaunay_batch_ex (second triangulation)")           # rescale.py:134-137
+        try:
+            _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, db.n_frames, bufs["feat_off"].ptr, bufs["feat_cnt"].ptr, bufs["u"].ptr,
+                                                   bufs["v"].ptr, None, int(db.max_feat), bufs["tri_off"].ptr, bufs["tri1"].ptr,
+                                                   bufs["tri1_cnt"].ptr, None, bufs["dt1_status"].ptr, None, None, None, None,
+                                                   bufs["dt_info"].ptr), "mvosr_delaunay_batch_ex (first triangulation)")
+            bs = db.struct()
+            keep = bufs["vote_counters"]                                        # (the block's per-feature int32 plane: here the keep flags)
+            _lib.check(lib.mvosr_graph_keep_batch(ctx.handle, C.byref(bs), C.c_uint32(self._good_bits), MIN_VALID_FOR_RETRI,
+                                                  bufs["dt1_status"].ptr, keep.ptr, None, None), "mvosr_graph_keep_batch")   # graph.py:18-36, rescale.py:133
+            _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, db.n_frames, bufs["feat_off"].ptr, bufs["feat_cnt"].ptr, bufs["u"].ptr,
+                                                   bufs["v"].ptr, keep.ptr, int(db.max_feat), bufs["tri_off"].ptr, bufs["tri2"].ptr,
+                                                   bufs["tri2_cnt"].ptr, bufs["n2_expected"].ptr, bufs["dt2_status"].ptr,
+                                                   bufs["tri_off"].ptr, bufs["tri1"].ptr, bufs["tri1_cnt"].ptr, bufs["dt_info"].ptr, None),
+                       "mvosr_delaunay_batch_ex (second triangulation)")           # rescale.py:134-137
+        except _lib.MvosrAllocError:
+            # (MVOSR_ERR_ALLOC: the triangulation's workspace could not be allocated; nothing was launched — the host's path)
+            db.free()
+            self.alloc_fallbacks = getattr(self, "alloc_fallbacks", 0) + 1
+            return {"gpu": False}
         db.n_rows2 = 2 * pf.total_padded
         out, flags, side = self._launch_flat_ransac(db, keep.ptr, bufs["dt2_status"].ptr, frame_base, None, id_triples, stage,
                                                     2 * int(db.max_feat))

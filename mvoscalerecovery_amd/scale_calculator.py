@@ -484,7 +484,15 @@ class ScaleEstimator:
                 blk.free()
             return st
         db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk)
-        db.triangulate(self.engine)
+        try:
+            db.triangulate(self.engine)
+        except _lib.MvosrAllocError:
+            # the triangulation kernels' workspace (frames x largest frame) did not fit next to whatever else lives on the
+            # device: nothing was launched — this chunk takes the host's triangulations (MVOSR_ERR_ALLOC)
+            db.free()
+            st["gpu"] = False
+            self.alloc_fallbacks = getattr(self, "alloc_fallbacks", 0) + 1
+            return st
         out = DeviceOutputs(ctx, db, counts=True, stage=stage)
         self.engine.scale_batch(db, out)          # (the frames whose level a later step reads are on the batch's exact mask)
         out.prefetch()

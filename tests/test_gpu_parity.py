@@ -1795,8 +1795,9 @@ def test_rescale_device_resident_reference_golden(gpu):
         tr = None
         if len(ids_ref) >= 12:
             call += 1
-            tr = [ids_ref[_ransac_triples(meta["ransac_seed"], call, len(ids_ref))].astype(np.int32)]
-        s, sd = est.scale_calculation_batch([f3], [f2], id_triples=tr, stage=True)
+            lt = z["f%d_list_triples" % i] if "f%d_list_triples" % i in z.files else _ransac_triples(meta["ransac_seed"], call, len(ids_ref))
+            tr = [ids_ref[lt].astype(np.int32)]        # (frame 26: every tenth triple names one vertex twice — counted as zero inliers here,
+        s, sd = est.scale_calculation_batch([f3], [f2], id_triples=tr, stage=True)      # as rounding noise by the reference: same best plane)
         assert np.array_equal(est.last["valid"][0], z["f%d_valid" % i]), i
         ids = est.last["tris2"][0][(est.last["tri_flags"][0] & 4) != 0].reshape(-1)
         assert np.array_equal(np.sort(ids), np.sort(ids_ref)), i
@@ -2399,3 +2400,98 @@ def test_rescale_oversized_frame_is_refused_up_front(gpu):
     est = ScaleEstimator(1.75, window_size=5, ransac_seed=3, delaunay_workers=0, triangulation="gpu")
     s, _ = est.scale_calculation_batch([f[0] for f in frames[:3]], [f[1] for f in frames[:3]])      # the estimator is still usable
     assert np.all(np.isfinite(s))
+
+
+def test_rescale_main_offline_reference_golden_device_resident(gpu):
+    """/root/reference/src/main_offline.py ITSELF with the estimator it really imports (rescale.ScaleEstimator,
+    random.sample replaying recorded triples) on the 200-frame dict (tests/golden/seq200_rescale_main_offline.npz) against
+    offline.run_sequence_batched with rescale.ScaleEstimator(triangulation="gpu") and the same triples mapped to point ids: the
+    scales file to 1e-9 — move_flag skips, the N > 100 gate, "repeat the previous scale", slew limiter and window median included."""
+    from mvoscalerecovery_amd import offline, synth
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    z, meta = load_npz("seq200_rescale_main_offline.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    ids, ids_off, ran = z["ids"], z["ids_off"], z["ran"]
+    triples, call = [], -1
+    for k in range(len(ran)):
+        lst = ids[ids_off[k]:ids_off[k + 1]]
+        if ran[k]:
+            call += 1
+            triples.append(lst[_ransac_triples(meta["ransac_seed"], call, len(lst))].astype(np.int32))
+        else:
+            triples.append(np.zeros((100, 3), np.int32))
+    est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], triangulation="gpu", ransac_seed=0)
+    res = offline.run_sequence_batched(data, est, id_triples=triples)
+    assert res["scales"].shape == z["scales"].shape
+    np.testing.assert_allclose(res["scales"], z["scales"], rtol=1e-9, atol=0)
+    loop = offline.run_sequence(data, ScaleEstimator(meta["abs_ref"], window_size=meta["window"], triangulation="gpu", ransac_seed=0))
+    assert loop["scales"].shape == z["scales"].shape and np.all((loop["scales"] == 0) == (z["scales"] == 0))    # same skips with its own draws
+
+
+def test_rescale_device_distribution_matches_the_unseeded_reference(gpu):
+    """VERDICT r4 item 2d / ADVICE r4: the reference's RANSAC is unseeded, so parity is statistical.  Six 400-600-feature frames; the
+    reference's raw scales over 200 unseeded runs each (tests/golden/rescale_distribution.npz) against the device path over 200
+    seeds: means within 3 standard errors, two-sample Kolmogorov-Smirnov p > 0.01 — with the sampler's declared deviation (a
+    triple naming one vertex twice is drawn again) in effect."""
+    from scipy import stats
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    z, meta = load_npz("rescale_distribution.npz")
+    frames = [synth.synth_frame(fr["frame_idx"], fr["n"], base_seed=fr["seed"], upper_fraction=fr["upper_fraction"]) for fr in meta["frames"]]
+    f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
+    runs = int(meta["runs"])
+    dev = np.zeros((runs, len(frames)))
+    for seed in range(runs):
+        est = ScaleEstimator(meta["abs_ref"], window_size=5, triangulation="gpu", ransac_seed=1000 + seed)
+        est.scale_calculation_batch(f3s, f2s)
+        dev[seed] = est.last["raw_scale"]
+    for k in range(len(frames)):
+        ref = z["f%d_raw_scales" % k]
+        d = dev[:, k]
+        se = np.sqrt(ref.var(ddof=1) / len(ref) + d.var(ddof=1) / len(d))
+        assert abs(ref.mean() - d.mean()) <= 3 * se + 1e-12, (k, ref.mean(), d.mean(), se)
+        assert stats.ks_2samp(ref, d).pvalue > 0.01, (k, stats.ks_2samp(ref, d))
+
+
+def test_workspace_allocation_failure_takes_the_host_path(gpu, tmp_path):
+    """MVOSR_ERR_ALLOC: when the triangulation kernels' grow-only workspace cannot be allocated, nothing is
+    launched and the chunk goes through the host's triangulations — same results, no exception.  MVOSR_TEST_FAIL_ALLOC=1 makes
+    every growth of that workspace fail; a fresh process, so that the workspace has to grow."""
+    import subprocess
+    import sys
+    import textwrap
+    from conftest import ROOT
+    script = tmp_path / "alloc.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        from mvoscalerecovery_amd import _lib, synth
+        from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+        from mvoscalerecovery_amd.rescale import ScaleEstimator as Rescale
+        frames = [synth.synth_frame(i, 500 + 7 * i, base_seed=31) for i in range(40)]
+        f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
+        ctx = _lib.default_context(0)
+        os.environ["MVOSR_TEST_FAIL_ALLOC"] = "1"
+        rc = ctx.lib.mvosr_delaunay_qhull_batch(ctx.handle, 1, None, None, None, None, None, 10, None, None, None, None, None, None)
+        assert rc == -2                                                     # (argument check comes first)
+        a = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
+        sa, _ = a.scale_calculation_batch(f3s, f2s)
+        e = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle="reference", delaunay_workers=0)
+        se, _ = e.scale_calculation_batch(f3s, f2s)
+        r = Rescale(1.75, window_size=5, triangulation="gpu", ransac_seed=4, delaunay_workers=0)
+        sr, _ = r.scale_calculation_batch(f3s, f2s)
+        assert a.alloc_fallbacks >= 1 and e.alloc_fallbacks >= 1 and r.alloc_fallbacks >= 1
+        del os.environ["MVOSR_TEST_FAIL_ALLOC"]
+        b = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
+        sb, _ = b.scale_calculation_batch(f3s, f2s)
+        f = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=0)
+        sf, _ = f.scale_calculation_batch(f3s, f2s)
+        q = Rescale(1.75, window_size=5, triangulation="gpu", ransac_seed=4, delaunay_workers=0)
+        sq, _ = q.scale_calculation_batch(f3s, f2s)
+        assert getattr(b, "alloc_fallbacks", 0) == 0
+        assert np.array_equal(sa, sb) and np.array_equal(se, sf) and np.array_equal(sr, sq)
+        print("ALLOC-FALLBACK-OK")
+    """ % ROOT))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert "ALLOC-FALLBACK-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

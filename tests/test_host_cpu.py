@@ -175,8 +175,8 @@ def test_c_packer_wide_path_and_thread_pool():
 
 
 def test_pin_thread_to_node_respects_what_it_finds():
-    """_lib.pin_thread_to_node (the binding keeps a process that opens a context on the device's NUMA node): unknown node, the
-    opt-out, a thread already confined to one node and a node without CPUs of ours leave the affinity alone; a real node
+    """_lib.pin_thread_to_node (the binding keeps a process that opens a context on the device's NUMA node): unknown node, no
+    opt-in (MVOSR_AFFINITY=1), a thread already confined to one node and a node without CPUs of ours leave the affinity alone; a real node
     narrows it to that node's CPUs (and the test puts it back)."""
     import glob
     import os
@@ -187,9 +187,11 @@ def test_pin_thread_to_node_respects_what_it_finds():
     try:
         assert _lib.pin_thread_to_node(-1) is None and _lib.pin_thread_to_node(None) is None
         assert _lib.pin_thread_to_node(4096) is None                       # no such node
+        os.environ.pop("MVOSR_AFFINITY", None)
+        assert _lib.pin_thread_to_node(0) is None                          # opt-in: nothing without MVOSR_AFFINITY=1
         os.environ["MVOSR_AFFINITY"] = "0"
         assert _lib.pin_thread_to_node(0) is None
-        del os.environ["MVOSR_AFFINITY"]
+        os.environ["MVOSR_AFFINITY"] = "1"
         assert os.sched_getaffinity(0) == before
         nodes = sorted(glob.glob("/sys/devices/system/node/node[0-9]*/cpulist"))
         got = _lib.pin_thread_to_node(0) if nodes else None

@@ -28,11 +28,16 @@ def test_rescale_sequence_golden():
     z, meta = load_npz("rescale.npz")
     call = {"k": -1}
 
+    frame = {"i": 0}
+
     def sampler(n):
         call["k"] += 1
+        if "f%d_list_triples" % frame["i"] in z.files:          # frame 26: every tenth triple names one vertex twice (the reference's
+            return z["f%d_list_triples" % frame["i"]]           # random.sample draws such rank-deficient samples 0.5-2 % of the time)
         return ransac_triples(meta["ransac_seed"], call["k"], n)
     est = ro.OracleRescaleEstimator(meta["abs_ref"], window_size=meta["window"], sampler=sampler)
     for i, fr in enumerate(meta["frames"]):
+        frame["i"] = i
         f3, f2 = synth.synth_frame(fr["frame_idx"], fr["n"], base_seed=fr["seed"], upper_fraction=fr["upper_fraction"])
         assert synth.checksum(f3, f2) == fr["crc"]
         s, sd = est.scale_calculation(f3, f2)
