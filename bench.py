@@ -419,6 +419,56 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames, exact=False):
                      "bit-equal to the fixed-mode oracle")}
 
 
+def e2e_sharded_leg(args, device, rank, world, sizes, seed, per_rank):
+    """offline.run_sequence_sharded end to end on `world` ranks (VERDICT r4 #4/#6a): a main_offline-shaped sequence of
+    per_rank * world frames given as per-frame arrays; every rank packs, uploads and computes its contiguous block, ONE
+    all-gather reassembles the (raw scale, level, status) records, every rank applies the cross-frame half.  Timed between
+    barriers, the slowest rank counts.  All three estimators."""
+    import torch
+    import torch.distributed as dist
+    from mvoscalerecovery_amd import offline, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    from mvoscalerecovery_amd.rescale import ScaleEstimator as RescaleEstimator
+    multi = dist.is_available() and dist.is_initialized()
+    out = {}
+    pool = [synth.synth_frame(400000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(min(1024, per_rank))]
+    motion = np.array([1, 0, 0, 0.01, 0, 1, 0, -0.02, 0, 0, 1, 0.9997], dtype=np.float64)
+    for name, make, frames_rank in (
+            ("scale_fixed", lambda: ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="gpu", delaunay_workers=0), per_rank),
+            ("scale_exact", lambda: ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="gpu",
+                                                   check_triangle="reference", delaunay_workers=0), max(per_rank // 2, 1)),
+            ("rescale", lambda: RescaleEstimator(ABS_REF, window_size=WINDOW, device=device, delaunay_workers=0, triangulation="gpu", ransac_seed=2024), per_rank)):
+        total = frames_rank * world
+        data = {"motions": [motion] * total, "move_flags": [True] * total,
+                "feature3ds": [pool[i % len(pool)][0] for i in range(total)], "feature2ds": [pool[i % len(pool)][1] for i in range(total)]}
+        est = make()
+        offline.run_sequence_sharded(data, est)                        # warm-up: kernels, allocator caches, RCCL
+        times = []
+        for _ in range(2):
+            est = make()
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = offline.run_sequence_sharded(data, est)
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            if multi:
+                t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", device) if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            times.append(dt)
+        out[name] = {"value": total / min(times), "unit": "frames/s", "frames_total": total, "frames_per_rank": frames_rank,
+                     "scales_finite": int(np.isfinite(res["scales"]).sum())}
+    out["what"] = ("offline.run_sequence_sharded over per-frame arrays on %d rank(s): contiguous blocks of frames per rank, pack + upload + "
+                   "device triangulations + kernels on each rank's GPU, one all-gather of the 20-byte records, window median on every rank; "
+                   "scale_fixed = check_triangle='fixed' (declared deviation), scale_exact = the reference's result (Qhull's rows on the device), "
+                   "rescale = the estimator main.py imports" % world)
+    return out
+
+
 def latency_leg(args, device, sizes, seed, frames=100):
     """Per-frame latency of the drop-in call in the reference's loop shape (/root/reference/src/main.py:110-113): one
     scale_calculation per frame — with SciPy's triangulations (the default, bit-exact path) and with the device's."""
@@ -478,6 +528,7 @@ def main():
     ap.add_argument("--no-tiles", action="store_true", help="diagnostic: dense frames without the tile index (the two-sweep gather kernel)")
     ap.add_argument("--no-far-table", action="store_true", help="diagnostic: dense frames without the far rows' vertex table (the kernel gathers)")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-sharded", action="store_true", help="also at N = 1: the sharded end-to-end leg (runs by itself for N > 1)")
     ap.add_argument("--c4", action="store_true",
                     help="BASELINE configs[3] literally: --total-frames (default 1 000 000) frames SPLIT over the ranks in contiguous, "
                          "possibly ragged blocks (strong scaling) instead of --frames per rank (weak scaling)")
@@ -670,6 +721,17 @@ def main():
         raw_crc = zlib.crc32(whole_raw.cpu().numpy().tobytes())
         st_all = whole_st.cpu().numpy()
 
+    sharded = None
+    if not args.no_e2e and not args.c4 and pf_pool.max_feat <= 4000 and (n_gpus > 1 or args.e2e_sharded):
+        # every rank takes part (the leg has a collective); this context's streams go first (see below)
+        torch.cuda.synchronize()
+        keep.clear()
+        del rec, height
+        ctx.close()
+        try:
+            sharded = e2e_sharded_leg(args, local, rank, n_gpus, sizes, 2024, 16384 if F >= 16384 else 4096)
+        except Exception as exc:                                        # noqa: BLE001
+            sharded = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank == 0:
         value = total_frames * args.steps / elapsed
         achieved = bytes_per_launch / (kernel_ms_avg * 1e-3) / 1e9
@@ -764,6 +826,8 @@ def main():
             torch.cuda.synchronize()
             keep.clear()
             ctx.close()
+        if sharded is not None:
+            line["e2e_sharded"] = sharded
         if n_gpus == 1 and not args.no_e2e and dense:
             # dense frames end to end: host Qhull (~140 CPU-ms per call and frame) bounds it; the tile layout is included
             try:

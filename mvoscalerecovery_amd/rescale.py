@@ -372,12 +372,12 @@ class ScaleEstimator:
             tables = frame_tables(f3s, f2s) if len(f3s) else None
         if tables is not None:
             pf, blk = pack_upload_native(ctx, f3s, f2s, self.vanish, None, tables=tables)             # rescale.py:115-117
-            if getattr(self, "chunk_trace", None) is not None: self.chunk_trace.append(("packed", -1, len(f3s), time.perf_counter()))
+            self._trace("packed", -1, len(f3s))
             if pf.max_feat > self._max_points():
                 blk.free()
                 self._refuse_oversized(pf, frame_base)
             db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk)
-            if getattr(self, "chunk_trace", None) is not None: self.chunk_trace.append(("blocks", -1, len(f3s), time.perf_counter()))
+            self._trace("blocks", -1, len(f3s))
         else:
             pf = packing.pack_features(f3s, f2s, self.vanish)
             if pf.n_frames == 0:
@@ -412,6 +412,13 @@ class ScaleEstimator:
         db.prefetch_info()
         db.mark()
         return {"gpu": True, "pf": pf, "db": db, "out": out, "flags": flags, "side": side}
+
+    def _trace(self, what, chunk, frames):
+        """MVOSR_TRACE_CHUNKS=1: (what, chunk, frames, seconds since the call began) into ``self.chunk_trace`` — when this process
+        started and finished each chunk's pack + launches and each collection (profiles/e2e_host_trace.py reads it)."""
+        tr = getattr(self, "chunk_trace", None)
+        if tr is not None:
+            tr.append((what, chunk, frames, time.perf_counter() - getattr(self, "_trace_t0", 0.0)))
 
     def _refuse_oversized(self, pf, frame_base):
         """flat_selection + RANSAC hold a frame's survivors, heights and flags in ONE workgroup's LDS: a frame beyond that has no
@@ -539,9 +546,8 @@ class ScaleEstimator:
             queue, a = [], 0
             # MVOSR_TRACE_CHUNKS=1: when this process started and finished each chunk's pack + launches and each collection
             # (self.chunk_trace: (what, chunk, frames, seconds since the call began))
-            trace = [] if os.environ.get("MVOSR_TRACE_CHUNKS") else None
-            t_call = time.perf_counter()
-            self.chunk_trace = trace
+            self.chunk_trace = [] if os.environ.get("MVOSR_TRACE_CHUNKS") else None
+            self._trace_t0 = time.perf_counter()
             while a < F:
                 b = min(F, a + (ramp[len(bounds)] if len(bounds) < len(ramp) else C_))
                 tb = frame_tables(feature3ds[a:b], feature2ds[a:b])          # (sizes from the packer's pointer tables: one C loop)
@@ -553,14 +559,14 @@ class ScaleEstimator:
                 if b < F and b - a >= 2 * res:                         # whole rounds of the GPU's resident frames: no partly filled last round
                     b = a + ((b - a) // res) * res
                 tr = None if id_triples is None else id_triples[a:b]
-                if trace is not None: trace.append(("launch", len(bounds), b - a, time.perf_counter() - t_call))
+                self._trace("launch", len(bounds), b - a)
                 queue.append((self._chunk_dev_gpu(feature3ds[a:b], feature2ds[a:b], base + a, tr, stage,
                                                   tables=(tuple(t[:b - a] for t in tb) if tb is not None else None)), a, b))
                 bounds.append((a, b))
-                if trace is not None: trace.append(("launched", len(bounds) - 1, b - a, time.perf_counter() - t_call))
+                self._trace("launched", len(bounds) - 1, b - a)
                 while len(queue) > self.GPU_PIPELINE:
                     st, pa, pb = queue.pop(0)
-                    if trace is not None: trace.append(("collect", len(results), pb - pa, time.perf_counter() - t_call))
+                    self._trace("collect", len(results), pb - pa)
                     results.append(self._chunk_dev_finish(st, feature3ds[pa:pb], feature2ds[pa:pb], base + pa,
                                                           None if id_triples is None else id_triples[pa:pb], stage))
                 a = b

@@ -22,6 +22,6 @@ tr = est.chunk_trace
 base = None
 for what, k, n, t in tr:
     if what in ("packed", "blocks"):
-        print("      %-9s %27.2f ms" % (what, 1e3 * (t - t0)))
+        print("      %-9s %27.2f ms" % (what, 1e3 * t))
     else:
         print("%-9s chunk %2d (%5d frames) %8.2f ms" % (what, k, n, 1e3 * t))
