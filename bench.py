@@ -710,6 +710,47 @@ def main():
     road_ms_avg = float(np.mean([p[1] for p in prof]))                                 # road_model_kernel
     ctx.profile(False)
 
+    # ---- probe: the same K steps alternating between TWO streams (two contexts: a workspace and a record each),
+    # so that the road model of step k — serial behind its scale kernel on one stream — can run under the scale kernel of step
+    # k+1.  Reported beside the headline (whose config is "single stream"), never in its place.
+    two_streams = None
+    if n_gpus == 1 and not args.c4 and not dense and not os.environ.get("MVOSR_BENCH_NO_TWO_STREAMS"):
+        try:
+            ctx2 = _lib.Context(local)
+            stream2 = torch.cuda.Stream(device=local)
+            ctx2.set_stream(stream2.cuda_stream)
+            engine2 = ScaleEngine(ABS_REF, ctx=ctx2)
+            rec2 = sharding.RankRecord(F, dev)
+            height2 = torch.empty(F, dtype=torch.float64, device=dev)
+            outs2 = _lib.Outputs(rec2.raw.data_ptr(), height2.data_ptr(), rec2.level.data_ptr(), rec2.status.data_ptr(),
+                                 None, None, None, None, None, None, None, None)
+            _lib.check(ctx2.lib.mvosr_ctx_reserve(ctx2.handle, F, pool_pad * repeats), "mvosr_ctx_reserve")
+            median2 = sharding.make_gpu_median(engine2)
+            sets = ((ctx, engine, outs, rec, median, stream), (ctx2, engine2, outs2, rec2, median2, stream2))
+
+            def step2(k):
+                c_, e_, o_, r_, m_, s_ = sets[k & 1]
+                with torch.cuda.stream(s_):
+                    _lib.check(c_.lib.mvosr_scale_batch(c_.handle, C.byref(e_.params), C.byref(bstruct), C.byref(o_), args.waves, 0, 0), "mvosr_scale_batch")
+                    return m_(r_.raw, WINDOW)
+            for k in range(4):
+                step2(k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                step2(k)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            same = bool(torch.equal(rec.raw.nan_to_num(nan=-1.0), rec2.raw.nan_to_num(nan=-1.0)))
+            two_streams = {"ms_per_step": dt2 / args.steps * 1e3, "value": F * args.steps / dt2, "unit": "frames/s",
+                           "step_frac": bytes_per_launch / (dt2 / args.steps) / 1e9 / HBM_PEAK_GBPS, "raw_scales_equal": same,
+                           "what": "the same %d steps, alternating between two streams (a context, workspace and record each): the road model of "
+                                   "step k may run under the scale kernel of step k+1; wall clock per step against the 8 TB/s x algorithmic bytes" % args.steps}
+            torch.cuda.set_stream(stream)
+            del rec2, height2
+            ctx2.close()
+        except Exception as exc:                                        # noqa: BLE001
+            two_streams = {"error": "%s: %s" % (type(exc).__name__, exc)}
     gpu_raw = rec.raw[:pool_n].cpu().numpy()
     gpu_status = rec.status[:pool_n].cpu().numpy()
     st_all = rec.status.cpu().numpy()
@@ -828,6 +869,8 @@ def main():
             ctx.close()
         if sharded is not None:
             line["e2e_sharded"] = sharded
+        if two_streams is not None:
+            line["two_streams"] = two_streams
         if n_gpus == 1 and not args.no_e2e and dense:
             # dense frames end to end: host Qhull (~140 CPU-ms per call and frame) bounds it; the tile layout is included
             try:

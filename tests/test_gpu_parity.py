@@ -2342,6 +2342,25 @@ def test_qhull_rows_kernel_equals_scipy_rows(gpu):
     dup = sets[3].copy(); dup[10] = dup[200]
     line = np.stack([np.arange(50.0), 2.0 * np.arange(50.0)], axis=1)
     assert all(t is None for t in packing.delaunay_gpu(gpu, [grid, dup, line, sets[3][:2]], rows="qhull"))
+    # what trackers hand over: float32-rounded positions, bucketed detections, clusters: exact; sites snapped to a pixel grid:
+    # exact or declined — a row that is emitted is SciPy's row
+    must, may = [], []
+    for seed in range(6):
+        must.append(synth.synth_frame(seed, 800, base_seed=5)[1].astype(np.float32).astype(np.float64))
+        r = np.random.default_rng(seed)
+        gx, gy = np.meshgrid(np.arange(0, 1241, 30), np.arange(186, 376, 30))
+        c = np.stack([gx.ravel(), gy.ravel()], 1).astype(float)
+        pts = np.concatenate([c + r.uniform(0, 30, c.shape), c + r.uniform(0, 30, c.shape)])
+        must.append(pts[r.random(len(pts)) < 0.8])
+        cen = r.uniform([0, 186], [1241, 376], (12, 2))
+        must.append(np.concatenate([k + r.normal(0, 8, (60, 2)) for k in cen] + [r.uniform([0, 186], [1241, 376], (200, 2))]))
+        may.append(np.unique(np.round(synth.synth_frame(seed, 500, base_seed=5)[1]), axis=0))
+        may.append(np.unique(np.round(synth.synth_frame(seed, 800, base_seed=5)[1] * 4) / 4, axis=0))
+    out = packing.delaunay_gpu(gpu, must + may, rows="qhull")
+    for k, (pts, tri) in enumerate(zip(must + may, out)):
+        assert tri is not None or k >= len(must), k
+        if tri is not None:
+            assert np.array_equal(tri, Delaunay(pts).simplices), k
 
 
 def test_seq4541_golden_device_triangulation_reference_exact(gpu):

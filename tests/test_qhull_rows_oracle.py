@@ -60,3 +60,31 @@ def test_degenerate_input_is_declined_not_guessed():
     g = np.stack(np.meshgrid(np.arange(12.0), np.arange(12.0)), -1).reshape(-1, 2) * 10 + 200    # cocircular quadruples
     with pytest.raises(Declined):
         QhullDelaunay2D(g)
+
+
+def test_quantised_and_clustered_sites_are_exact_or_declined_never_wrong():
+    """What real trackers hand over: float32-rounded sub-pixel positions, bucketed detections (<= 2 per 30-px bucket,
+    /root/reference/src/detector.py:65-95), clusters — rows equal SciPy's; sites snapped to a pixel grid (collinear hull points,
+    cocircular quadruples: Qhull merges facets there) may be declined, but a row that is emitted is SciPy's row."""
+    from scipy.spatial import Delaunay
+
+    def check(P, must):
+        try:
+            rows = QhullDelaunay2D(P).simplices()
+        except Declined:
+            assert not must
+            return 0
+        assert np.array_equal(rows, Delaunay(P).simplices)
+        return 1
+    for seed in range(6):
+        check(_frame(seed, 800).astype(np.float32).astype(np.float64), True)
+        r = np.random.default_rng(seed)
+        gx, gy = np.meshgrid(np.arange(0, 1241, 30), np.arange(186, 376, 30))
+        c = np.stack([gx.ravel(), gy.ravel()], 1).astype(float)
+        pts = np.concatenate([c + r.uniform(0, 30, c.shape), c + r.uniform(0, 30, c.shape)])
+        check(pts[r.random(len(pts)) < 0.8], True)
+        cen = r.uniform([0, 186], [1241, 376], (12, 2))
+        check(np.concatenate([k + r.normal(0, 8, (60, 2)) for k in cen] + [r.uniform([0, 186], [1241, 376], (200, 2))]), True)
+    emitted = sum(check(np.unique(np.round(_frame(seed, 500)), axis=0), False) for seed in range(10))
+    emitted += sum(check(np.unique(np.round(_frame(seed, 800) * 4) / 4, axis=0), False) for seed in range(10))
+    assert emitted >= 5                                           # (most quarter-pixel frames still go through)
