@@ -26,6 +26,7 @@ constexpr int kQhMaxPoints = 8000;        // facet ids are 16-bit: 7 * (n + 1) +
 constexpr int kQhMaxNew = 64;             // facets of one cone (one lane each; 5.6 on average, 35 the most seen in 512 frames of 2000 points)
 constexpr int kQhMaxVis = 64;             // visible facets of one insertion (3.6 on average, 33 the most seen)
 constexpr int kQhMaxHz = 64;              // horizon facets of one insertion
+constexpr int kQhPickWindow = 16;
 constexpr double kQhEps = 2.220446049250313e-16;
 constexpr double kQhHuge = 1.797e308;
 constexpr uint16_t kQhNone = 0xFFFFu;
@@ -64,13 +65,13 @@ static unsigned long long *g_qh_stamps = nullptr;
 #define QH_STAMP(k) do { } while (0)
 #endif
 
-struct QhPlan { size_t x, y, z, fac, arena, tt, dd, total; uint32_t fcap, acap; };
+struct QhPlan { size_t pts, fac, arena, tt, dd, total; uint32_t fcap, acap; };
 __host__ __device__ inline QhPlan qh_plan(int cap_pts) {
     QhPlan P;
     const size_t n = (size_t)cap_pts;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
-    P.x = take(8 * n); P.y = take(8 * n); P.z = take(8 * n);
+    P.pts = take(32 * n);            // (x, y, lifted z, pad): one 32-byte sector per point — three planes were three sectors per access
     P.fcap = (uint32_t)(7 * n + 64); if (P.fcap > 65534u) P.fcap = 65534u;
     P.fac = take(sizeof(QhFacet) * (size_t)(P.fcap + 1));
     P.acap = (uint32_t)(28 * n + 256);
@@ -79,6 +80,12 @@ __host__ __device__ inline QhPlan qh_plan(int cap_pts) {
     P.total = o;
     return P;
 }
+
+// a coordinate of the per-point records, indexed like an array
+struct QhCoord {
+    double4 *p; int k;
+    __device__ __forceinline__ double &operator[](int i) const { return (&p[i].x)[k]; }
+};
 
 struct QhLds {
     double npl[kQhMaxNew][4];        // the cone's planes (n0, n1, n2, offset)
@@ -265,7 +272,8 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
     const int lane = lane_id();
     const QhPlan P = qh_plan(a.cap_pts);
     char *ws = a.ws + (size_t)f * a.ws_stride;
-    double *X = reinterpret_cast<double *>(ws + P.x), *Y = reinterpret_cast<double *>(ws + P.y), *Z = reinterpret_cast<double *>(ws + P.z);
+    double4 *PT = reinterpret_cast<double4 *>(ws + P.pts);
+    const QhCoord X{PT, 0}, Y{PT, 1}, Z{PT, 2};
     QhFacet *fac = reinterpret_cast<QhFacet *>(ws + P.fac);
     uint16_t *arena = reinterpret_cast<uint16_t *>(ws + P.arena);
     uint16_t *TT = reinterpret_cast<uint16_t *>(ws + P.tt);
@@ -316,7 +324,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
     {
         const int m1 = n + 1;
         for (int k = 0; k < 3; ++k) {
-            const double *C = k == 0 ? X : (k == 1 ? Y : Z);
+            const QhCoord C{PT, k};
             double hi = -kQhHuge, lo = kQhHuge; int hii = 0, loi = 0;
             for (int base = 0; base < m1; base += 64) {
                 const int i = base + lane;
@@ -507,7 +515,9 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
             int cur = -1;
             uint32_t c2 = 0, c3 = 0, c4 = 0, c5 = 0;
             while (pos < nfac) {
-                const int id = pos + lane < nfac ? pos2id(pos + lane) : 0;
+                // (the next facet with an outside set is 3 positions on in the median, within 16 in 94 % of the insertions: a window of
+                // 16 records — 512 bytes — instead of 64)
+                const int id = (lane < kQhPickWindow && pos + lane < nfac) ? pos2id(pos + lane) : 0;
                 uint4 r0 = make_uint4(0, 4u << 16, 0, 0), r1 = make_uint4(0, 0, 0, 0);
                 if (id) { const uint4 *G = reinterpret_cast<const uint4 *>(&fac[id]); r0 = G[0]; r1 = G[1]; }
                 const bool has = !((r0.y >> 16) & 4u) && (r0.w >> 16) != kQhNone;
@@ -518,7 +528,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                     c2 = __shfl(r0.z, l); c3 = __shfl(r0.w, l); c4 = __shfl(r1.x, l); c5 = __shfl(r1.y, l);
                     break;
                 }
-                pos += 64;
+                pos += kQhPickWindow;
             }
             if (cur < 0) break;
             cur = uni(cur);

@@ -11,6 +11,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export TMPDIR=/tmp
 # no forked Delaunay workers under the profiler: its preloaded library lives in them too and has hung their exit
 export MVOSR_DELAUNAY_WORKERS=0
+# (bench.py's two-stream probe overlaps kernels of two streams: it would pollute the per-kernel averages of the stats pass)
+export MVOSR_BENCH_NO_TWO_STREAMS=1
 cd /tmp
 OUT=$R/gpurun_out
 mkdir -p $OUT

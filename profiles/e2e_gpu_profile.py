@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the host time of the drop-in batch call goes with triangulation="gpu" (cProfile, cumulative):
     python profiles/e2e_gpu_profile.py [frames] [features] [scale|rescale]
-(third argument "rescale": the estimator /root/reference/src/main.py:20 imports, device-resident)"""
+(third argument "rescale": the estimator /root/reference/src/main.py:20 imports, device-resident; "exact": check_triangle="reference")"""
 import cProfile
 import os
 import pstats
@@ -21,6 +21,8 @@ f3, f2 = [pool[i % P][0] for i in range(F)], [pool[i % P][1] for i in range(F)]
 if WHICH == "rescale":
     from mvoscalerecovery_amd.rescale import ScaleEstimator as RescaleEstimator
     est = RescaleEstimator(1.75, window_size=5, triangulation="gpu", delaunay_workers=0, ransac_seed=2024)
+elif WHICH == "exact":                # the reference's own vote on Qhull's rows built on the device (no declared deviation)
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle="reference", delaunay_workers=0)
 else:
     est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
 est.scale_calculation_batch(f3, f2)

@@ -66,9 +66,23 @@ def render(tag):
                 if "hip_malloc_calls_in_timed_call" in e:
                     extra += "; hipMalloc / hipHostMalloc calls in the timed call: %d / %d" % (e["hip_malloc_calls_in_timed_call"], e["hip_host_malloc_calls_in_timed_call"])
                 rows.append((label, "**%s frames/s** at 2000 features (%d frames, %s distinct)%s" % (k(e["value"]), e["frames"], e.get("distinct_frames", "all"), extra), "`%s` in the bench line" % key))
+        if "e2e_gpu_exact" in b and "value" in b["e2e_gpu_exact"]:
+            e = b["e2e_gpu_exact"]
+            dk = e.get("delaunay_kernel") or {}
+            extra = "; KITTI-sized frames (300-1500 features): %s" % k(kt["e2e_gpu_exact"]["value"]) if (kt and "value" in kt.get("e2e_gpu_exact", {})) else ""
+            rows.append(("end to end, `scale_calculator.ScaleEstimator(triangulation=\"gpu\", check_triangle=\"reference\")` — **the reference's result, bit for bit, both triangulations on the device** (Qhull's rows by `qhull_rows_kernel`)",
+                         "**%s frames/s** at 2000 features (%d frames, %s distinct; declined to the host in the last chunk: %d)%s; `qhull_rows_kernel` alone: %s sets/s (%d resident sets of %d points)"
+                         % (k(e["value"]), e["frames"], e.get("distinct_frames", "all"), e.get("declined_last_chunk", 0), extra,
+                            k(dk.get("sets_per_s", float("nan"))), dk.get("sets", 0), dk.get("points_per_set", 0)), "`e2e_gpu_exact` in the bench line"))
+        if "two_streams" in b and "ms_per_step" in b["two_streams"]:
+            t2 = b["two_streams"]
+            rows.append(("the headline steps alternating between two streams (road model of step k under the scale kernel of step k+1)",
+                         "%.3f ms per step = %.3f of 8 TB/s (one stream: %.3f ms = %.3f); raw scales identical: %s" % (t2["ms_per_step"], t2["step_frac"], b["ms_per_step"], b["roofline"].get("step_frac", float("nan")), t2.get("raw_scales_equal")), "`two_streams` in the bench line"))
         if "latency" in b:
             la = b["latency"]
             extra = (", `rescale` estimator device-resident %.2f ms" % la["rescale_gpu"]["median_ms"]) if "rescale_gpu" in la else ""
+            if "gpu_exact" in la:
+                extra += ", `check_triangle=\"reference\"` with `triangulation=\"gpu\"` %.2f ms (a single frame takes SciPy's triangulations: the device chain is 37 ms)" % la["gpu_exact"]["median_ms"]
             rows.append(("per-frame `scale_calculation` latency, 2000 features", "SciPy triangulations %.2f ms, device triangulations %.2f ms%s (median; 0 allocations per call)" % (la["scipy"]["median_ms"], la["gpu"]["median_ms"], extra), "`latency` in the bench line"))
         cb = b.get("cpu_baseline")
         if cb:
@@ -89,6 +103,10 @@ def render(tag):
         small = "; ".join("%s, <= %d points: %s" % (d["what"], d["points_per_set"], k(d["sets_per_s"])) for d in items if d["points_per_set"] != 2000)
         if small:
             rows.append(("... smaller sets (8192 per launch)", small, "same"))
+    qc = os.path.join(HERE, tag + "_qhull_check.txt")
+    if os.path.isfile(qc):
+        launches = [ln.strip() for ln in open(qc) if ln.startswith("launch of")]
+        rows.append(("`qhull_rows_kernel` alone (resident point sets, one launch)", "; ".join(launches), "`profiles/%s_qhull_check.txt`" % tag))
     for w in ("scale", "rescale"):
         p = os.path.join(HERE, "%s_e2e_%s_busy.txt" % (tag, w))
         if os.path.isfile(p):
