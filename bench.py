@@ -881,6 +881,10 @@ def main():
                 line["e2e_gpu_triangulation"] = e2e_gpu_leg(args, local, sizes, 2024, 1024)
             except Exception as exc:                                    # noqa: BLE001
                 line["e2e_gpu_triangulation"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                line["e2e_gpu_exact"] = e2e_gpu_leg(args, local, sizes, 2024, 1024, exact=True)
+            except Exception as exc:                                    # noqa: BLE001
+                line["e2e_gpu_exact"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if n_gpus == 1 and not args.no_e2e and not dense:
             try:
                 line["e2e"] = e2e_leg(args, local, sizes, 2024, 4096)

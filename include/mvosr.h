@@ -599,8 +599,9 @@ int mvosr_delaunay_frames_per_cu(int max_pts);
  * declines (status = MVOSR_DT_DEGENERATE | reason << 8, tri_cnt 0): the host triangulates it with SciPy.  Rows are meant for
  * MVOSR_VOTE_REFERENCE: with them triangulation="gpu" IS the reference's result.  Arguments as mvosr_delaunay_batch;
  * order_out (optional, laid out like u): the insertion step at which a point became a vertex (0: initial simplex), indexed
- * by the point's rank among the kept points.  max_pts <= mvosr_delaunay_qhull_max_points() (8000: facet ids are 16-bit).
- * Workspace: ~0.56 KB per point of the launch (n_frames * (max_pts + 1)), grow-only, in the context.
+ * by the point's rank among the kept points.  max_pts <= mvosr_delaunay_qhull_max_points() (60 000; launches whose max_pts is above
+ * 8 000 use 32-bit facet ids and 80-byte facet records).  Workspace: ~0.55 KB (0.66 KB) per point of the launch
+ * (n_frames * (max_pts + 1)), grow-only, in the context.
  */
 int mvosr_delaunay_qhull_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
                                const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,

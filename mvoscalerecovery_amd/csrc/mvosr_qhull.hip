@@ -23,6 +23,7 @@ using namespace mvosr;
 namespace {
 
 constexpr int kQhMaxPoints = 8000;        // facet ids are 16-bit: 7 * (n + 1) + 64 facets per run
+constexpr int kQhMaxPointsWide = 60000;   // 32-bit facet ids (80-byte records); point ids stay 16-bit
 constexpr int kQhMaxNew = 64;             // facets of one cone (one lane each; 5.6 on average, 35 the most seen in 512 frames of 2000 points)
 constexpr int kQhMaxVis = 64;             // visible facets of one insertion (3.6 on average, 33 the most seen)
 constexpr int kQhMaxHz = 64;              // horizon facets of one insertion
@@ -37,7 +38,10 @@ enum QhWhy : int {
     QH_GAUSS = 13, QH_NOT_SHARP = 14, QH_ABOVE_NONE = 15, QH_FACETS_FULL = 16, QH_ARENA_FULL = 17, QH_VERTICAL = 18
 };
 
-struct __attribute__((aligned(16))) QhFacet {
+// A facet record, FID = the type of a facet id: 16 bits up to 8 000 points (7 n + 64 facets per run fit), 32 bits beyond
+// (the dense frames of BASELINE configs[4]: 20 000 points, 140 000 facets).
+template <typename FID> struct QhFacetT;
+template <> struct __attribute__((aligned(16))) QhFacetT<uint16_t> {
     uint16_t p[3];      // vertices as point ids, by decreasing vertex id (reverse insertion order)
     uint16_t flags;     // 1 top-oriented, 2 upper Delaunay, 4 dead
     uint16_t nb[3];     // neighbour k is opposite vertex k
@@ -48,7 +52,33 @@ struct __attribute__((aligned(16))) QhFacet {
     double bestd;
     double n0, n1, n2, d;
 };
-static_assert(sizeof(QhFacet) == 64, "one facet per 64-byte line");
+template <> struct __attribute__((aligned(16))) QhFacetT<uint32_t> {
+    uint16_t p[3];
+    uint16_t flags;
+    uint32_t nb[3];
+    uint16_t bestp;
+    uint16_t cnt;
+    uint32_t off;
+    uint32_t mark;
+    double bestd;
+    double n0, n1, n2, d;
+    double pad;
+};
+static_assert(sizeof(QhFacetT<uint16_t>) == 64, "one facet per 64-byte line");
+static_assert(sizeof(QhFacetT<uint32_t>) == 80, "five 16-byte words");
+
+// the first 32 bytes of a record (what the pick reads for a window of facets): flags, furthest point, neighbours, list
+template <typename FID> struct QhHead { uint32_t flags, bestp, nb0, nb1, nb2, off, cnt; };
+__device__ __forceinline__ QhHead<uint16_t> qh_head(const QhFacetT<uint16_t> *, uint4 r0, uint4 r1) {
+    QhHead<uint16_t> h;
+    h.flags = r0.y >> 16; h.bestp = r0.w >> 16; h.nb0 = r0.z & 0xFFFFu; h.nb1 = r0.z >> 16; h.nb2 = r0.w & 0xFFFFu; h.off = r1.x; h.cnt = r1.y & 0xFFFFu;
+    return h;
+}
+__device__ __forceinline__ QhHead<uint32_t> qh_head(const QhFacetT<uint32_t> *, uint4 r0, uint4 r1) {
+    QhHead<uint32_t> h;
+    h.flags = r0.y >> 16; h.nb0 = r0.z; h.nb1 = r0.w; h.nb2 = r1.x; h.bestp = r1.y & 0xFFFFu; h.cnt = r1.y >> 16; h.off = r1.z;
+    return h;
+}
 
 struct QhArgs {
     int64_t n_frames;
@@ -66,14 +96,14 @@ static unsigned long long *g_qh_stamps = nullptr;
 #endif
 
 struct QhPlan { size_t pts, fac, arena, tt, dd, total; uint32_t fcap, acap; };
-__host__ __device__ inline QhPlan qh_plan(int cap_pts) {
+__host__ __device__ inline QhPlan qh_plan(int cap_pts, bool wide) {
     QhPlan P;
     const size_t n = (size_t)cap_pts;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
     P.pts = take(32 * n);            // (x, y, lifted z, pad): one 32-byte sector per point — three planes were three sectors per access
-    P.fcap = (uint32_t)(7 * n + 64); if (P.fcap > 65534u) P.fcap = 65534u;
-    P.fac = take(sizeof(QhFacet) * (size_t)(P.fcap + 1));
+    P.fcap = (uint32_t)(7 * n + 64); if (!wide && P.fcap > 65534u) P.fcap = 65534u;
+    P.fac = take((wide ? sizeof(QhFacetT<uint32_t>) : sizeof(QhFacetT<uint16_t>)) * (size_t)(P.fcap + 1));
     P.acap = (uint32_t)(28 * n + 256);
     P.arena = take(2 * (size_t)P.acap);
     P.tt = take(2 * n); P.dd = take(8 * n);
@@ -87,21 +117,21 @@ struct QhCoord {
     __device__ __forceinline__ double &operator[](int i) const { return (&p[i].x)[k]; }
 };
 
-struct QhLds {
+template <typename FID> struct QhLdsT {
     double npl[kQhMaxNew][4];        // the cone's planes (n0, n1, n2, offset)
     double nxy[kQhMaxNew][6];        // coordinates of a cone facet's two horizon vertices (convexity test between cone facets)
     uint16_t nva[kQhMaxNew], nvb[kQhMaxNew];     // a cone facet's horizon vertices (point ids)
     uint8_t nnb[kQhMaxNew][4];       // cone neighbours 1, 2 as cone-local indices; [3] = upper flag
-    uint16_t visq[kQhMaxVis];        // visible facets in Qhull's breadth-first order
-    uint16_t visnb[kQhMaxVis][3];
+    FID visq[kQhMaxVis];        // visible facets in Qhull's breadth-first order
+    FID visnb[kQhMaxVis][3];
     uint16_t visrep[kQhMaxVis];      // cone-local index of the visible facet's replacement (kQhNone: the first cone facet)
     uint32_t visoff[kQhMaxVis];
     uint16_t viscnt[kQhMaxVis];      // points of its outside set without the furthest
     uint16_t visbest[kQhMaxVis];
     uint32_t viscum[kQhMaxVis + 1];
-    uint16_t nhz[kQhMaxNew];         // a cone facet's horizon neighbour (facet id)
-    uint16_t hzq[kQhMaxHz];          // horizon facets tested in this insertion, and their records (p0 p1 p2 flags nb0 nb1 nb2)
-    uint16_t hzr[kQhMaxHz][8];
+    FID nhz[kQhMaxNew];         // a cone facet's horizon neighbour (facet id)
+    FID hzq[kQhMaxHz];          // horizon facets tested in this insertion, and their records (p0 p1 p2 flags nb0 nb1 nb2)
+    FID hzr[kQhMaxHz][8];
     uint32_t t_off[kQhMaxNew]; uint32_t t_total[kQhMaxNew]; uint32_t t_cnt[kQhMaxNew]; uint16_t t_bestp[kQhMaxNew]; double t_bestd[kQhMaxNew];
 };
 
@@ -194,7 +224,7 @@ struct QhConst { double distround, minvisible, minoutside, distoutside, guard, a
 struct QhWalk { int tgt; double d; int state; int best; };     // state 0 placed, 1 ended below its best, 2 no best, 3 bad (band / above none)
 
 // qh_findbestnew over the cone in LDS: list order from `start`, wrapping; the first facet 2 MINoutside above wins
-__device__ __forceinline__ QhWalk qh_scan_cone(const QhLds &L, int m, int start, double x, double y, double z, const QhConst &K) {
+template <typename FID> __device__ __forceinline__ QhWalk qh_scan_cone(const QhLdsT<FID> &L, int m, int start, double x, double y, double z, const QhConst &K) {
     QhWalk R; R.state = 3; R.tgt = 0; R.d = 0.0; R.best = -1;
     double bestd = -kQhHuge;
     bool bad = false;
@@ -211,7 +241,7 @@ __device__ __forceinline__ QhWalk qh_scan_cone(const QhLds &L, int m, int start,
 }
 
 // qh_findbest(isnewfacets): the directed walk; visited cone facets as a bit mask
-__device__ __forceinline__ QhWalk qh_walk_cone(const QhLds &L, int start, double x, double y, double z, const QhConst &K) {
+template <typename FID> __device__ __forceinline__ QhWalk qh_walk_cone(const QhLdsT<FID> &L, int start, double x, double y, double z, const QhConst &K) {
     QhWalk R; R.state = 0; R.best = -1;
     bool bad = false;
     double d = qh_dist(x, y, z, L.npl[start][0], L.npl[start][1], L.npl[start][2], L.npl[start][3]);
@@ -246,7 +276,7 @@ __device__ __forceinline__ QhWalk qh_walk_cone(const QhLds &L, int start, double
 // qh_partitionpoint's list rule.  A target's list is arena[t_off .. t_off + t_cnt) + [t_bestp]; the furthest point stays last, a
 // point that arrives further than it takes over and the old one enters the list in the arrival's place.  Lane j keeps target
 // j's state in registers and the arrivals are broadcast one by one (v_readlane): ~14 instructions per arrival.
-__device__ __forceinline__ void qh_place_chunk(QhLds &L, uint16_t *arena, int count, int m, int tgt, int p, double d) {
+template <typename FID> __device__ __forceinline__ void qh_place_chunk(QhLdsT<FID> &L, uint16_t *arena, int count, int m, int tgt, int p, double d) {
     const int lane = lane_id();
     uint32_t base = 0, cnt = 0; int bestp = kQhNone; double bestd = -kQhHuge;
     if (lane < m) { base = L.t_off[lane]; cnt = L.t_cnt[lane]; bestp = L.t_bestp[lane]; bestd = L.t_bestd[lane]; }
@@ -268,9 +298,10 @@ __device__ __forceinline__ void qh_place_chunk(QhLds &L, uint16_t *arena, int co
 }
 
 // One frame, one wavefront.  Returns the reason the frame was declined (QH_OK: rows written, `nrows` of them).
-__device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f, int &nrows) {
+template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, QhLdsT<FID> &L, const int64_t f, int &nrows) {
+    typedef QhFacetT<FID> QhFacet;
     const int lane = lane_id();
-    const QhPlan P = qh_plan(a.cap_pts);
+    const QhPlan P = qh_plan(a.cap_pts, sizeof(FID) == 4);
     char *ws = a.ws + (size_t)f * a.ws_stride;
     double4 *PT = reinterpret_cast<double4 *>(ws + P.pts);
     const QhCoord X{PT, 0}, Y{PT, 1}, Z{PT, 2};
@@ -304,7 +335,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
     }
     n = uni(n);
     if (a.n_used) { if (lane == 0) a.n_used[f] = n; }
-    if (n < 3 || n > a.cap_pts - 1 || n > kQhMaxPoints) return QH_FEW_POINTS;
+    if (n < 3 || n > a.cap_pts - 1 || n > (sizeof(FID) == 4 ? kQhMaxPointsWide : kQhMaxPoints)) return QH_FEW_POINTS;
     __threadfence_block();
     {
         // sums in input order (the point at infinity sits over the mean), the largest lifted height
@@ -430,7 +461,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
             G.p[0] = (uint16_t)q[0]; G.p[1] = (uint16_t)q[1]; G.p[2] = (uint16_t)q[2];
             G.flags = (uint16_t)((top ? 1 : 0) | (F.upper ? 2 : 0));
             k = 0;
-            for (int j = 0; j < 4; ++j) if (j != lane) G.nb[k++] = (uint16_t)(j + 1);
+            for (int j = 0; j < 4; ++j) if (j != lane) G.nb[k++] = (FID)(j + 1);
             G.bestp = kQhNone; G.off = 0; G.cnt = 0; G.mark = 0; G.bestd = 0.0;
             G.n0 = F.n0; G.n1 = F.n1; G.n2 = F.n2; G.d = F.d;
             fac[lane + 1] = G;
@@ -513,19 +544,22 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
         while (true) {
             // (a) the first facet in list order with an outside set (its record's first half comes along)
             int cur = -1;
-            uint32_t c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+            QhHead<FID> H;
+            H.flags = 0; H.bestp = kQhNone; H.nb0 = H.nb1 = H.nb2 = H.off = H.cnt = 0;
             while (pos < nfac) {
                 // (the next facet with an outside set is 3 positions on in the median, within 16 in 94 % of the insertions: a window of
                 // 16 records — 512 bytes — instead of 64)
                 const int id = (lane < kQhPickWindow && pos + lane < nfac) ? pos2id(pos + lane) : 0;
-                uint4 r0 = make_uint4(0, 4u << 16, 0, 0), r1 = make_uint4(0, 0, 0, 0);
+                uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
                 if (id) { const uint4 *G = reinterpret_cast<const uint4 *>(&fac[id]); r0 = G[0]; r1 = G[1]; }
-                const bool has = !((r0.y >> 16) & 4u) && (r0.w >> 16) != kQhNone;
+                const QhHead<FID> h = qh_head(static_cast<const QhFacet *>(nullptr), r0, r1);
+                const bool has = id && !(h.flags & 4u) && h.bestp != kQhNone;
                 const uint64_t hm = __ballot(has);
                 if (hm) {
                     const int l = ffs64(hm);
                     pos += l; cur = pos2id(pos);
-                    c2 = __shfl(r0.z, l); c3 = __shfl(r0.w, l); c4 = __shfl(r1.x, l); c5 = __shfl(r1.y, l);
+                    H.bestp = __shfl(h.bestp, l); H.nb0 = __shfl(h.nb0, l); H.nb1 = __shfl(h.nb1, l); H.nb2 = __shfl(h.nb2, l);
+                    H.off = __shfl(h.off, l); H.cnt = __shfl(h.cnt, l);
                     break;
                 }
                 pos += kQhPickWindow;
@@ -533,15 +567,15 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
             if (cur < 0) break;
             cur = uni(cur);
             ++step;
-            const int p = (int)(c3 >> 16);
+            const int p = (int)H.bestp;
             if (a.order_out) { if (lane == 0 && p < n) a.order_out[off + p] = step; }     // (compacted ids when `keep` is given)
             QH_STAMP(0);
             // (b) qh_findhorizon: visible facets, breadth first, neighbours in order.  Facets tested in this insertion are
             // remembered in LDS (visible ones with their outside sets, horizon ones with their vertices and neighbours)
             int nvis = 1, head = 0, nhz = 0;
             if (lane == 0) {
-                L.visq[0] = (uint16_t)cur; L.visnb[0][0] = (uint16_t)(c2 & 0xFFFFu); L.visnb[0][1] = (uint16_t)(c2 >> 16); L.visnb[0][2] = (uint16_t)(c3 & 0xFFFFu);
-                L.visoff[0] = c4; L.viscnt[0] = (uint16_t)(c5 & 0xFFFFu); L.visbest[0] = kQhNone;
+                L.visq[0] = (FID)cur; L.visnb[0][0] = (FID)H.nb0; L.visnb[0][1] = (FID)H.nb1; L.visnb[0][2] = (FID)H.nb2;
+                L.visoff[0] = H.off; L.viscnt[0] = (uint16_t)H.cnt; L.visbest[0] = kQhNone;
             }
             qh_lds_sync();
             const double px = X[p], py = Y[p], pz = Z[p];        // (in flight together with the first round's facet records)
@@ -579,12 +613,12 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                 if (nvis + add > kQhMaxVis || nhz + addz > kQhMaxHz) { why = QH_TOO_MANY_VISIBLE; break; }
                 if (vis) {
                     const int q = nvis + popc64(vm & lanemask_lt());
-                    L.visq[q] = (uint16_t)g; L.visnb[q][0] = G.nb[0]; L.visnb[q][1] = G.nb[1]; L.visnb[q][2] = G.nb[2];
+                    L.visq[q] = (FID)g; L.visnb[q][0] = G.nb[0]; L.visnb[q][1] = G.nb[1]; L.visnb[q][2] = G.nb[2];
                     L.visoff[q] = G.off; L.viscnt[q] = G.cnt; L.visbest[q] = G.bestp;
                 }
                 if (hzn) {
                     const int q = nhz + popc64(zm & lanemask_lt());
-                    L.hzq[q] = (uint16_t)g;
+                    L.hzq[q] = (FID)g;
                     L.hzr[q][0] = G.p[0]; L.hzr[q][1] = G.p[1]; L.hzr[q][2] = G.p[2]; L.hzr[q][3] = G.flags;
                     L.hzr[q][4] = G.nb[0]; L.hzr[q][5] = G.nb[1]; L.hzr[q][6] = G.nb[2];
                 }
@@ -633,8 +667,8 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                     L.nva[j] = (uint16_t)va; L.nvb[j] = (uint16_t)vb;
                     L.nnb[j][0] = (uint8_t)(top ? 1 : 0); L.nnb[j][3] = F.upper ? 1 : 0;
                     L.t_total[j] = 0;
-                    L.nhz[j] = (uint16_t)g;
-                    fac[g].nb[skip] = (uint16_t)(nfac + 1 + j);
+                    L.nhz[j] = (FID)g;
+                    fac[g].nb[skip] = (FID)(nfac + 1 + j);
                     // a visible facet's replacement: the last cone facet made from it
                     const uint64_t mine = hm & (7ull << (3 * (lane / 3)));
                     if ((63 - __clzll((long long)mine)) == lane) L.visrep[e] = (uint16_t)j;
@@ -770,7 +804,7 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
                 G.p[0] = (uint16_t)p; G.p[1] = L.nva[lane]; G.p[2] = L.nvb[lane];
                 G.flags = (uint16_t)((L.nnb[lane][0] ? 1 : 0) | (L.nnb[lane][3] ? 2 : 0));
                 G.nb[0] = L.nhz[lane];
-                G.nb[1] = (uint16_t)(nfac + 1 + L.nnb[lane][1]); G.nb[2] = (uint16_t)(nfac + 1 + L.nnb[lane][2]);
+                G.nb[1] = (FID)(nfac + 1 + L.nnb[lane][1]); G.nb[2] = (FID)(nfac + 1 + L.nnb[lane][2]);
                 G.bestp = L.t_bestp[lane]; G.off = L.t_off[lane]; G.cnt = (uint16_t)L.t_cnt[lane]; G.mark = 0; G.bestd = L.t_bestd[lane];
                 G.n0 = L.npl[lane][0]; G.n1 = L.npl[lane][1]; G.n2 = L.npl[lane][2]; G.d = L.npl[lane][3];
                 fac[nfac + 1 + lane] = G;
@@ -804,11 +838,12 @@ __device__ __forceinline__ int qh_run(const QhArgs &a, QhLds &L, const int64_t f
 
 // 119 registers and 9.7 KB of LDS: four wavefronts per SIMD.  (Compiled for five, six and eight — 96 / 80 / 64 registers with
 // spills, the LDS tables halved — the same launch of 4096 frames took 41 / 50 / 66 ms instead of 34: LABNOTES §9.)
+template <typename FID>
 __global__ __launch_bounds__(64, 4) void qhull_rows_kernel(const QhArgs a) {
-    __shared__ QhLds L;
+    __shared__ QhLdsT<FID> L;
     const int64_t f = blockIdx.x;
     int nrows = 0;
-    const int why = qh_run(a, L, f, nrows);
+    const int why = qh_run<FID>(a, L, f, nrows);
     if (lane_id() == 0) {
         a.tri_cnt[f] = why ? 0 : nrows;
         a.status[f] = why ? (MVOSR_DT_DEGENERATE | (why << 8)) : MVOSR_DT_OK;
@@ -821,7 +856,7 @@ __global__ __launch_bounds__(64, 4) void qhull_rows_kernel(const QhArgs a) {
 extern "C" void mvosr_debug_qh_stamps(void *dptr) { g_qh_stamps = reinterpret_cast<unsigned long long *>(dptr); }
 #endif
 
-extern "C" int mvosr_delaunay_qhull_max_points(void) { return kQhMaxPoints; }
+extern "C" int mvosr_delaunay_qhull_max_points(void) { return kQhMaxPointsWide; }
 
 extern "C" int mvosr_delaunay_qhull_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
                                           const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
@@ -833,8 +868,9 @@ extern "C" int mvosr_delaunay_qhull_batch(mvosr_ctx *ctx, int64_t n_frames, cons
     int rc = ctx_activate(ctx);
     if (rc) return rc;
     if (max_pts < 3) max_pts = 3;
-    if (max_pts > kQhMaxPoints)
-        return set_error(MVOSR_ERR_TOO_LARGE, "delaunay_qhull_batch: %d points per frame (limit: %d)", max_pts, kQhMaxPoints);
+    if (max_pts > kQhMaxPointsWide)
+        return set_error(MVOSR_ERR_TOO_LARGE, "delaunay_qhull_batch: %d points per frame (limit: %d)", max_pts, kQhMaxPointsWide);
+    const bool wide = max_pts > kQhMaxPoints;
     QhArgs a;
     a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
     a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.order_out = order_out;
@@ -844,11 +880,12 @@ extern "C" int mvosr_delaunay_qhull_batch(mvosr_ctx *ctx, int64_t n_frames, cons
 #else
     a.stamps = nullptr;
 #endif
-    const QhPlan P = qh_plan(a.cap_pts);
+    const QhPlan P = qh_plan(a.cap_pts, wide);
     a.ws_stride = P.total;
     void *ws = nullptr;
     if ((rc = ctx_workspace_bytes(ctx, (size_t)n_frames * P.total, &ws))) return rc;
     a.ws = reinterpret_cast<char *>(ws);
-    hipLaunchKernelGGL(qhull_rows_kernel, dim3((unsigned)n_frames), dim3(64), 0, ctx_stream(ctx), a);
+    if (wide) hipLaunchKernelGGL(qhull_rows_kernel<uint32_t>, dim3((unsigned)n_frames), dim3(64), 0, ctx_stream(ctx), a);
+    else hipLaunchKernelGGL(qhull_rows_kernel<uint16_t>, dim3((unsigned)n_frames), dim3(64), 0, ctx_stream(ctx), a);
     return check_launch("qhull_rows_kernel");
 }

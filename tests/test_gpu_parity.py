@@ -2536,3 +2536,32 @@ def test_bench_e2e_sharded_leg(gpu):
         for name in ("scale_fixed", "scale_exact", "rescale"):
             assert sh[name]["frames_total"] == sh[name]["frames_per_rank"] * world and sh[name]["scales_finite"] == sh[name]["frames_total"]
             assert sh[name]["value"] > 1000.0
+
+
+def test_dense_frames_reference_exact_on_the_device(gpu):
+    """BASELINE configs[4]'s shape through the exact device path: 20 000-point sets are beyond 16-bit facet ids (7 n facets per
+    run) — qhull_rows_kernel<uint32_t>: rows == SciPy's rows (20 000 and 9 000 points, and the survivors of a mask); the
+    reference's N = 20 000 golden (tests/golden/dense.npz) with both triangulations built on the device and the reference's vote:
+    raw scale, status and selected count as the reference's."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import constants as K, packing, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z, meta = load_npz("dense.npz")
+    f3, f2 = synth.synth_frame(meta["frame_idx"], meta["n"], base_seed=meta["seed"])
+    low = f2[f2[:, 1] > 185]
+    sets = [low, synth.synth_frame(5, 9000, base_seed=808)[1]]
+    got = packing.delaunay_gpu(gpu, sets, rows="qhull")
+    for pts, tri in zip(sets, got):
+        assert tri is not None, int(packing.delaunay_gpu.last_status[0]) >> 8
+        assert np.array_equal(tri, Delaunay(pts).simplices)
+    assert np.array_equal(got[0], z["tri1"].astype(np.int32))                       # ... which is the golden's first triangulation
+    keep = np.where(z["valid"], 1, -1).astype(np.int32)
+    t2 = packing.delaunay_gpu(gpu, [low], [keep], rows="qhull")[0]
+    assert np.array_equal(t2, z["tri2"].astype(np.int32))                           # and, over the vote's survivors, its second
+    est = ScaleEstimator(meta["abs_ref"], window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle="reference", delaunay_workers=0)
+    est.GPU_EXACT_MIN_FRAMES = 1
+    raw, status, level, _ = est.raw_scale_batch([f3, f3], [f2, f2])
+    assert est.last_declined == 0
+    for k in range(2):
+        assert raw[k] == float(z["scale_first_call"]) and status[k] in (K.ST_MODE, K.ST_RIGHT), (k, raw[k], status[k])
+        assert est.last_counts[k, K.CNT_SELECTED] == len(z["selected_ids"])
