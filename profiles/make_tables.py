@@ -92,6 +92,16 @@ def render(tag):
     if kt:
         r = kt["roofline"]
         rows.append(("config C3's sizes (`--workload kitti`: ragged 300-1500 features, one launch per size class)", "%s frames/s, kernels %.3f of 8 TB/s, step %.3f" % (k(kt["value"]), r["frac"], r.get("step_frac", float("nan"))), "`profiles/%s_bench_kitti.json`" % tag))
+    dn = load_line(tag + "_bench_dense.json")
+    if dn:
+        r = dn["roofline"]
+        ex = dn.get("e2e_gpu_exact", {})
+        rows.append(("config C5's shape (`--features 20000`: dense frames, tiled kernel)",
+                     "%s frames/s, `%s` %.3f of 8 TB/s, step %.3f; end to end: SciPy on the host %s, device triangulations (fixed mode) %s%s frames/s"
+                     % (k(dn["value"]), r["kernel"], r["frac"], r.get("step_frac", float("nan")), k(dn.get("e2e", {}).get("value", float("nan"))),
+                        k(dn.get("e2e_gpu_triangulation", {}).get("value", float("nan"))),
+                        (", the reference's result with device triangulations (`qhull_rows_kernel<uint32_t>`) **%s**" % k(ex["value"])) if "value" in ex else ""),
+                     "`profiles/%s_bench_dense.json`" % tag))
     if c4:
         rows.append(("BASELINE configs[3] literally on ONE GPU (`bench.py --c4 --total-frames 1000000 --gpus 1`: %.0f GB resident)" % (c4["roofline"]["algorithmic_bytes_per_launch"] / 1e9),
                      "%s frames/s, %.1f ms per step of 1 000 000 frames, kernel %.3f of 8 TB/s" % (k(c4["value"]), c4["ms_per_step"], c4["roofline"]["frac"]), "`profiles/%s_bench_c4_1gpu.json`" % tag))
