@@ -211,7 +211,6 @@ __device__ __forceinline__ QhPlane qh_plane(double x0, double y0, double z0, dou
     }
     P.n0 = n0; P.n1 = n1; P.n2 = n2; P.d = d;
     P.upper = n2 > -anground * 2.0;
-    if (__builtin_fabs(n2) < 1e-9) P.gauss = true;
     return P;
 }
 

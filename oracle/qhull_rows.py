@@ -291,8 +291,6 @@ class QhullDelaunay2D:
             off -= z[p0] * n2
             f.off = off
         f.upper = n2 > -self.anground * 2.0
-        if abs(n2) < 1e-9:
-            raise Declined("vertical facet")
 
     def _dist(self, p, f):
         return f.off + self.x[p] * f.n0 + self.y[p] * f.n1 + self.z[p] * f.n2
