@@ -272,7 +272,12 @@ class ScaleEstimator:
         stage = bool(_single)
         # (the Qhull-rows kernel is a chain of dependent insertions: ~20 ms per 2000-point triangulation however few the frames —
         # a handful of frames, the per-frame call of /root/reference/src/main.py:113 among them, is quicker through SciPy: 6 ms)
-        few_exact = self.check_triangle == "reference" and F < self.GPU_EXACT_MIN_FRAMES
+        few_exact = False
+        if self.check_triangle == "reference" and self.triangulation == "gpu":
+            # device: two chains of n dependent insertions, ~11 us each, whatever the frame count (up to ~4 000 frames);
+            # host: ~3 us per point and triangulation (SciPy), spread over the pool's workers — the break-even count of frames
+            w = max(1, packing.resolve_workers(self.delaunay_workers))
+            few_exact = F < max(self.GPU_EXACT_MIN_FRAMES, int(3.7 * w))
         if self.triangulation == "gpu" and tri1s is None and tri2s is None and not few_exact:
             raw, status, level, counts, host_errors, last = self._stream_gpu(feature3ds, feature2ds, stage)
         elif tri1s is None and tri2s is None and not _single and F > self.PIPELINE_CHUNK:
@@ -451,7 +456,7 @@ class ScaleEstimator:
     GPU_CHUNK = 8192            # frames per chunk of the device-triangulation path, at most (a call of F frames uses chunks of F/4, 512 at least: the pipeline needs a few)
     GPU_RESIDENT = 512          # frames the GPU works on at once (two 8-wavefront workgroups per CU): chunks are multiples of it
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk (40 B each in staging memory, ~180 B each on the device)
-    GPU_EXACT_MIN_FRAMES = 8    # ... calls of fewer frames take SciPy's triangulations (same rows, lower latency)
+    GPU_EXACT_MIN_FRAMES = 8    # ... calls of fewer frames (or fewer than ~3.7 per Delaunay worker) take SciPy's triangulations (same rows, lower latency)
     GPU_EXACT_CHUNK = 16384     # check_triangle="reference" (the Qhull-rows kernel): frames per chunk, at most ...
     GPU_EXACT_CHUNK_POINTS = 33000000   # ... and features per chunk (~0.75 KB each on the device: 25 GB at the cap)
 

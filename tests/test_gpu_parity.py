@@ -2560,8 +2560,8 @@ def test_dense_frames_reference_exact_on_the_device(gpu):
     assert np.array_equal(t2, z["tri2"].astype(np.int32))                           # and, over the vote's survivors, its second
     est = ScaleEstimator(meta["abs_ref"], window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle="reference", delaunay_workers=0)
     est.GPU_EXACT_MIN_FRAMES = 1
-    raw, status, level, _ = est.raw_scale_batch([f3, f3], [f2, f2])
+    raw, status, level, _ = est.raw_scale_batch([f3] * 4, [f2] * 4)                 # (four frames: above the host's break-even)
     assert est.last_declined == 0
-    for k in range(2):
+    for k in range(4):
         assert raw[k] == float(z["scale_first_call"]) and status[k] in (K.ST_MODE, K.ST_RIGHT), (k, raw[k], status[k])
         assert est.last_counts[k, K.CNT_SELECTED] == len(z["selected_ids"])
