@@ -2528,6 +2528,9 @@ constexpr int kModeExactList = 3;
 static inline KArgs &kargs_of(KArgs &a) { return a; }
 static inline KArgs &kargs_of(DenseArgs &a) { return a.k; }
 
+// set by mvosr_scale_batch around its HOT dispatch: the exact pass over the redo list is left to the caller
+static thread_local bool g_defer_exact = false;
+
 template <class Args>
 static int launch_modes(mvosr_ctx *ctx, void (*k_hot)(const Args), void (*k_exact)(const Args), void (*k_full)(const Args),
                         Args args, int64_t nl, int threads, size_t lds, int mode, const char *name, size_t lds_hot = 0,
@@ -2558,6 +2561,7 @@ static int launch_modes(mvosr_ctx *ctx, void (*k_hot)(const Args), void (*k_exac
     hipLaunchKernelGGL(k_hot, dim3((unsigned)nl), dim3(threads_hot), lds_hot, ctx_stream(ctx), args);
     if ((rc = check_launch(name))) return rc;
     if ((rc = launch_append_mask(ctx, kargs_of(args), nl, true))) return rc;
+    if (g_defer_exact) return MVOSR_OK;           // mvosr_scale_batch runs ONE exact pass, after the road model has added its frames to the list
     kargs_of(args).redo_pass = 1;
     const unsigned grid = (unsigned)(nl < (int64_t)kRedoGrid ? nl : (int64_t)kRedoGrid);
     hipLaunchKernelGGL(k_exact, dim3(grid), dim3(threads), lds, ctx_stream(ctx), args);
@@ -2808,29 +2812,46 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
         ra.wide = (dense && !(debug_skip_env() & 256)) ? 1 : 0;
         return launch_road(ctx, ra, ctx_stream(ctx));
     }
+    // HOT: ONE exact pass per call (round 5; two before: one behind the HOT kernel, one behind the road model).  The HOT kernel
+    // and the exact mask put their frames on the redo list; the road model runs over every other frame and APPENDS the frames that
+    // end on the fallback level (:334-335; rare) to the same list; then the EXACT variant over the list, then the road model over it.
+    const bool fold = mode == MODE_HOT && !(debug_skip_env() & 16) && !(debug_skip_env() & 512);
     if (by_class) {
         if ((rc = launch_scale_classes(ctx, ka, n_launch))) return rc;
         if ((rc = launch_append_mask(ctx, ka, n_launch, true))) return rc;
-        if ((rc = dispatch_scale(ctx, ka, waves, n_launch, kModeExactList))) return rc;
-    } else if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, mode, false) : dispatch_scale(ctx, ka, waves, n_launch, mode))) return rc;
+        if (!fold && (rc = dispatch_scale(ctx, ka, waves, n_launch, kModeExactList))) return rc;
+    } else {
+        g_defer_exact = fold;
+        rc = dense ? launch_scale_dense(ctx, ka, n_launch, mode, false) : dispatch_scale(ctx, ka, waves, n_launch, mode);
+        g_defer_exact = false;
+        if (rc) return rc;
+    }
     if (pev && (ee = hipEventRecord(pev[1], ctx_stream(ctx))) != hipSuccess) return set_hip_error("hipEventRecord(profile)", ee);
     ra.first_frame = first_frame; ra.n_frames = n_launch;
     ra.wide = (dense && !(debug_skip_env() & 256)) ? 1 : 0;     // dense batches: thousands of values per list, few frames
     if (!(debug_skip_env() & 16)) {
-        if (mode == MODE_HOT) {
-            // frames whose road model ends on the fallback level (:334-335; rare) come back on a second list: the EXACT
-            // variant redoes them (height_level in NumPy's order), then the road model runs on that list alone
-            const hipError_t e2 = hipMemsetAsync(redo2, 0, sizeof(int32_t), ctx_stream(ctx));
-            if (e2 != hipSuccess) return set_hip_error("hipMemsetAsync(redo list 2)", e2);
-            ra.level_redo = redo2;
-        }
-        if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc;
-        if (mode == MODE_HOT) {
-            KArgs k2 = ka;
-            k2.redo = redo2;
-            if ((rc = dense ? launch_scale_dense(ctx, k2, n_launch, kModeExactList, false) : dispatch_scale(ctx, k2, waves, n_launch, kModeExactList))) return rc;
-            ra.level_redo = nullptr; ra.list = redo2;
+        if (fold) {
+            ra.level_redo = ka.redo;
             if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc;
+            if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, kModeExactList, false) : dispatch_scale(ctx, ka, waves, n_launch, kModeExactList))) return rc;
+            ra.level_redo = nullptr; ra.list = ka.redo;
+            if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc;
+        } else {
+            if (mode == MODE_HOT) {
+                // frames whose road model ends on the fallback level come back on a second list: the EXACT variant redoes them
+                // (height_level in NumPy's order), then the road model runs on that list alone
+                const hipError_t e2 = hipMemsetAsync(redo2, 0, sizeof(int32_t), ctx_stream(ctx));
+                if (e2 != hipSuccess) return set_hip_error("hipMemsetAsync(redo list 2)", e2);
+                ra.level_redo = redo2;
+            }
+            if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc;
+            if (mode == MODE_HOT) {
+                KArgs k2 = ka;
+                k2.redo = redo2;
+                if ((rc = dense ? launch_scale_dense(ctx, k2, n_launch, kModeExactList, false) : dispatch_scale(ctx, k2, waves, n_launch, kModeExactList))) return rc;
+                ra.level_redo = nullptr; ra.list = redo2;
+                if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc;
+            }
         }
     }
     if (pev) {
