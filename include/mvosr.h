@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MVOSR_ABI_VERSION 9
+#define MVOSR_ABI_VERSION 10
 
 /* error codes (function return values) */
 enum mvosr_err {
@@ -188,6 +188,22 @@ typedef struct mvosr_batch {
      * triangulation" branch and divides by the previous level (/root/reference/src/scale_calculator.py:263-270,:420-422),
      * the last frame of a chunk, the frame the estimator's height_level is left at when the next one raises. */
     const uint8_t *exact_mask;
+    /* Optional (all NULL: none) — tri2 is a STAND-IN: the triangle set of the second triangulation with other rows than SciPy's
+     * (mvosr_delaunay_batch's canonical form: ~1 us per frame instead of the ~8 us of mvosr_delaunay_qhull_batch).  The rows of
+     * tri2 reach the result only through rounding — the LU solve sees the vertices in row order (:229), height_level is summed in
+     * row order (:239-240) —, and every frame in which rounding can decide is on the exact pass's list already (a flat triangle
+     * within the guard band of the level, a pitch inside the band where the reference's own formulation is evaluated, a level
+     * that is itself the result, the exact mask): for THOSE frames mvosr_scale_batch builds SciPy's own rows in place
+     * (mvosr_delaunay_qhull_batch's kernel over the list) before the exact pass reads them.  HOT mode only (no stage outputs),
+     * survivor-numbered rows, frames that fit the LDS-resident kernels.  standin_u: pixel columns laid out like v; standin_keep:
+     * the vote the second triangulation was built on (>= 0: kept), laid out like v; standin_rows / standin_cnt: tri2 / tri2_cnt
+     * again, writable; standin_status [F]: receives MVOSR_DT_DEGENERATE | reason << 8 for a listed frame whose rows Qhull's
+     * replay declines (the caller then takes that frame through the host's SciPy). */
+    const double *standin_u;
+    const int32_t *standin_keep;
+    int32_t *standin_rows;
+    int32_t *standin_cnt;
+    int32_t *standin_status;
 } mvosr_batch;
 
 #define MVOSR_TILE_W 512

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 LIB_PATH = os.environ.get("MVOSR_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")   # (override: A/B builds in profiles/)
-ABI_VERSION = 9
+ABI_VERSION = 10
 VOTE_REFERENCE, VOTE_FIXED = 0, 1          # mvosr_params.vote_mode
 WAVES_EXACT = 0x100                        # MVOSR_WAVES_EXACT, or-ed into waves_per_frame
 WAVES_EXACT_MASKED = 0x200                 # MVOSR_WAVES_EXACT_MASKED: only the frames of mvosr_batch.exact_mask, in the exact mode
@@ -51,7 +51,9 @@ class Batch(C.Structure):
                 ("tile_w", C.c_int32), ("min_feat", C.c_int32), ("tile_base", C.c_void_p),
                 ("tile1_off", C.c_void_p), ("tile2_off", C.c_void_p), ("size_hint", C.c_int32 * 4),
                 ("tile_far", C.c_void_p), ("tile_far_off", C.c_void_p),
-                ("tri1_cnt", C.c_void_p), ("tri2_cnt", C.c_void_p), ("tri2_order", C.c_void_p), ("exact_mask", C.c_void_p)]
+                ("tri1_cnt", C.c_void_p), ("tri2_cnt", C.c_void_p), ("tri2_order", C.c_void_p), ("exact_mask", C.c_void_p),
+                ("standin_u", C.c_void_p), ("standin_keep", C.c_void_p), ("standin_rows", C.c_void_p), ("standin_cnt", C.c_void_p),
+                ("standin_status", C.c_void_p)]
 
 
 class Outputs(C.Structure):

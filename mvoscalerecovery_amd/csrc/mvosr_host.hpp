@@ -72,3 +72,8 @@ int ctx_workspace_dense(mvosr_ctx *ctx, int64_t total_feat, void *planes[2]);   
 int ctx_workspace_bytes(mvosr_ctx *ctx, size_t bytes, void **ptr);               // generic grow-only scratch
 
 }  // namespace mvosr
+
+// mvosr_qhull.hip: SciPy/Qhull's rows for the frames of a device-side list (list[0] = how many), written in place
+int qh_rows_for_list(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt, const double *u, const double *v,
+                     const int32_t *keep, int max_pts, const int64_t *tri_off, int32_t *tri, int32_t *tri_cnt, int32_t *status,
+                     const int32_t *list);

@@ -548,7 +548,9 @@ __device__ __forceinline__ int classify_triangle(double x0, double y0, double z0
             if (g_heights) g_heights[tg] = h;
         }
     }
-    return (is_flat ? 1 : 0) | (is_steep ? 2 : 0) | (is_singular ? 4 : 0);
+    // bit 3: decided by the reference's own formulation — the one place where the ROTATION of the row (the order LAPACK's LU sees the
+    // vertices in) can move the outcome: a caller whose rows are stand-ins for SciPy's (same triangles, other rotation) redoes the frame
+    return (is_flat ? 1 : 0) | (is_steep ? 2 : 0) | (is_singular ? 4 : 0) | (decided ? 0 : 8);
 }
 
 // The heights of the frame's STEEP triangles (pitch_deg >= thr, :239) in the row order of tri2, one at a time and
@@ -715,6 +717,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     unsigned long long flat_hi = 0ull;       // bits 64..127 (FW == 2: dense frames, up to 128 triangles per thread)
     double hsum = 0.0, hcnt = 0.0, habs = 0.0;
     int npitch = 0, singular = 0, bad = 0;
+    int undecided = 0;       // HOT: a triangle inside the pitch test's band (classified by the reference's formulation): the frame joins the redo list
     // more rows than the per-thread flag words can name (not a triangulation of this frame's points): refuse
     if (t2_count > 64 * FW * B) { bad = 1; t2_count = 0; }
     // One triangle of the first sweep (:229-240).
@@ -730,6 +733,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
     const int r = classify_triangle<FULL>(x0, y0, z0, x1, y1, z1, x2, y2, z2, h, pt, g_normals, g_pitch, g_heights, t2_begin + t);
     const bool is_flat = r & 1, is_steep = r & 2;
     if (r & 4) singular = 1;
+    if constexpr (MODE == MODE_HOT) { if (r & 8) undecided = 1; }
     if (is_steep) { hsum += h; hcnt += 1.0; if constexpr (MODE == MODE_HOT) habs += fabs(h); }     // :240
     if (is_flat) {
         if (FW == 1 || kk < 64) flat |= 1ull << (kk & 63); else flat_hi |= 1ull << (kk & 63);
@@ -769,7 +773,7 @@ __device__ __forceinline__ SelectResult phase_select(const Smem &s, int n_valid,
         else
             hl = exact_height_level<FULL>(tri2 + 3 * t2_begin, t2_count, (int)hcnt, pt, LdsFetch{s.P, s.Y, n_valid});
     }
-    int ntv = 0, near = 0;
+    int ntv = 0, near = undecided;
     auto mark_triangle = [&](int kk, int qa, int qb, int qc) {
         const unsigned long long fw = (FW == 1 || kk < 64) ? flat : flat_hi;
         if (!((fw >> (kk & 63)) & 1ull)) return;
@@ -2800,6 +2804,19 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     const bool by_class = mode == MODE_HOT && !dense && waves_per_frame == 0 && n_launch >= kClassMinFrames &&
                           b->max_feat > kClassThr0 && !(debug_skip_env() & 64) &&
                           (b->min_feat <= 0 || pick_waves(0, b->min_feat) != waves);
+    // stand-in rows (mvosr_batch.standin_*): the frames of the exact pass's list get SciPy's own rows before the pass reads them
+    const bool standin = b->standin_u != nullptr;
+    if (standin) {
+        if (!b->standin_keep || !b->standin_rows || !b->standin_cnt || !b->standin_status || !b->tri2_cnt || b->tri2_ids != MVOSR_TRI2_SURVIVORS)
+            return set_error(MVOSR_ERR_ARG, "scale_batch: stand-in rows need standin_keep/_rows/_cnt/_status, tri2_cnt and survivor-numbered rows");
+        if (dense) return set_error(MVOSR_ERR_TOO_LARGE, "scale_batch: stand-in rows are for frames that fit the LDS-resident kernels");
+        if (!(want_masked || (mode == MODE_HOT && !(debug_skip_env() & (16 | 512)))))
+            return set_error(MVOSR_ERR_ARG, "scale_batch: stand-in rows need the HOT mode (no stage outputs, no EXACT-for-all)");
+    }
+    auto standin_rows = [&](const int32_t *list) {
+        return qh_rows_for_list(ctx, b->n_frames, b->feat_off, b->feat_cnt, b->standin_u, b->v, b->standin_keep, b->max_feat, b->tri2_off,
+                                b->standin_rows, b->standin_cnt, b->standin_status, list);
+    };
     if (want_masked) {
         // the EXACT variant over the frames of the range whose exact_mask byte is set, the road model over the same list;
         // every other frame's outputs stay as they are
@@ -2807,6 +2824,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
         const hipError_t e0 = hipMemsetAsync(ka.redo, 0, sizeof(int32_t), ctx_stream(ctx));
         if (e0 != hipSuccess) return set_hip_error("hipMemsetAsync(redo list)", e0);
         if ((rc = launch_append_mask(ctx, ka, n_launch, false))) return rc;
+        if (standin && (rc = standin_rows(ka.redo))) return rc;
         if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, kModeExactList, false) : dispatch_scale(ctx, ka, waves, n_launch, kModeExactList))) return rc;
         ra.first_frame = first_frame; ra.n_frames = n_launch; ra.list = ka.redo;
         ra.wide = (dense && !(debug_skip_env() & 256)) ? 1 : 0;
@@ -2833,6 +2851,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
         if (fold) {
             ra.level_redo = ka.redo;
             if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc;
+            if (standin && (rc = standin_rows(ka.redo))) return rc;          // SciPy's own rows for the frames the exact pass redoes
             if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, kModeExactList, false) : dispatch_scale(ctx, ka, waves, n_launch, kModeExactList))) return rc;
             ra.level_redo = nullptr; ra.list = ka.redo;
             if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc;

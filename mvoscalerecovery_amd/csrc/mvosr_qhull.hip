@@ -85,6 +85,7 @@ struct QhArgs {
     const int64_t *pts_off; const int32_t *pts_cnt; const double *u; const double *v; const int32_t *keep;
     const int64_t *tri_off; int32_t *tri; int32_t *tri_cnt; int32_t *n_used; int32_t *status; int32_t *order_out;
     unsigned long long *stamps;
+    const int32_t *list;         // null, or: list[0] frames list[1..] (a redo list of the scale kernels), walked by a persistent grid
     char *ws; size_t ws_stride; int cap_pts;      // per-frame slice, laid out by QhPlan for cap_pts = max_pts + 1 points
 };
 
@@ -297,11 +298,11 @@ template <typename FID> __device__ __forceinline__ void qh_place_chunk(QhLdsT<FI
 }
 
 // One frame, one wavefront.  Returns the reason the frame was declined (QH_OK: rows written, `nrows` of them).
-template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, QhLdsT<FID> &L, const int64_t f, int &nrows) {
+template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, QhLdsT<FID> &L, const int64_t f, const int64_t slot, int &nrows) {
     typedef QhFacetT<FID> QhFacet;
     const int lane = lane_id();
     const QhPlan P = qh_plan(a.cap_pts, sizeof(FID) == 4);
-    char *ws = a.ws + (size_t)f * a.ws_stride;
+    char *ws = a.ws + (size_t)slot * a.ws_stride;
     double4 *PT = reinterpret_cast<double4 *>(ws + P.pts);
     const QhCoord X{PT, 0}, Y{PT, 1}, Z{PT, 2};
     QhFacet *fac = reinterpret_cast<QhFacet *>(ws + P.fac);
@@ -840,9 +841,26 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
 template <typename FID>
 __global__ __launch_bounds__(64, 4) void qhull_rows_kernel(const QhArgs a) {
     __shared__ QhLdsT<FID> L;
+    if (a.list) {
+        // the frames of a list whose length is known on the device only: a persistent grid, one workspace slice per workgroup
+        const int64_t todo = (int64_t)a.list[0];
+        for (int64_t it = blockIdx.x; it < todo; it += gridDim.x) {
+            const int64_t f = (int64_t)a.list[1 + it];
+            if (f < 0 || f >= a.n_frames) continue;
+            int nrows = 0;
+            __syncthreads();
+            const int why = qh_run<FID>(a, L, f, (int64_t)blockIdx.x, nrows);
+            if (lane_id() == 0) {
+                if (why) { a.tri_cnt[f] = 0; a.status[f] = MVOSR_DT_DEGENERATE | (why << 8); }
+                else a.tri_cnt[f] = nrows;           // (status stays what the stand-in triangulation left: 0)
+            }
+            __threadfence_block();
+        }
+        return;
+    }
     const int64_t f = blockIdx.x;
     int nrows = 0;
-    const int why = qh_run<FID>(a, L, f, nrows);
+    const int why = qh_run<FID>(a, L, f, f, nrows);
     if (lane_id() == 0) {
         a.tri_cnt[f] = why ? 0 : nrows;
         a.status[f] = why ? (MVOSR_DT_DEGENERATE | (why << 8)) : MVOSR_DT_OK;
@@ -857,9 +875,9 @@ extern "C" void mvosr_debug_qh_stamps(void *dptr) { g_qh_stamps = reinterpret_ca
 
 extern "C" int mvosr_delaunay_qhull_max_points(void) { return kQhMaxPointsWide; }
 
-extern "C" int mvosr_delaunay_qhull_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
-                                          const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
-                                          int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status, int32_t *order_out) {
+static int qh_launch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt, const double *u, const double *v,
+                     const int32_t *keep, int max_pts, const int64_t *tri_off, int32_t *tri, int32_t *tri_cnt, int32_t *n_used,
+                     int32_t *status, int32_t *order_out, const int32_t *list, int list_blocks) {
     if (!ctx || !pts_off || !pts_cnt || !u || !v || !tri_off || !tri || !tri_cnt || !status)
         return set_error(MVOSR_ERR_ARG, "delaunay_qhull_batch: null argument");
     if (max_pts < 0) return set_error(MVOSR_ERR_ARG, "delaunay_qhull_batch: max_pts < 0");
@@ -872,7 +890,7 @@ extern "C" int mvosr_delaunay_qhull_batch(mvosr_ctx *ctx, int64_t n_frames, cons
     const bool wide = max_pts > kQhMaxPoints;
     QhArgs a;
     a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
-    a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.order_out = order_out;
+    a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.order_out = order_out; a.list = list;
     a.cap_pts = max_pts + 1;
 #ifdef MVOSR_QH_STAMPS
     a.stamps = g_qh_stamps;
@@ -881,10 +899,25 @@ extern "C" int mvosr_delaunay_qhull_batch(mvosr_ctx *ctx, int64_t n_frames, cons
 #endif
     const QhPlan P = qh_plan(a.cap_pts, wide);
     a.ws_stride = P.total;
+    const int64_t slices = list ? (int64_t)(list_blocks < n_frames ? list_blocks : n_frames) : n_frames;
     void *ws = nullptr;
-    if ((rc = ctx_workspace_bytes(ctx, (size_t)n_frames * P.total, &ws))) return rc;
+    if ((rc = ctx_workspace_bytes(ctx, (size_t)slices * P.total, &ws))) return rc;
     a.ws = reinterpret_cast<char *>(ws);
-    if (wide) hipLaunchKernelGGL(qhull_rows_kernel<uint32_t>, dim3((unsigned)n_frames), dim3(64), 0, ctx_stream(ctx), a);
-    else hipLaunchKernelGGL(qhull_rows_kernel<uint16_t>, dim3((unsigned)n_frames), dim3(64), 0, ctx_stream(ctx), a);
+    if (wide) hipLaunchKernelGGL(qhull_rows_kernel<uint32_t>, dim3((unsigned)slices), dim3(64), 0, ctx_stream(ctx), a);
+    else hipLaunchKernelGGL(qhull_rows_kernel<uint16_t>, dim3((unsigned)slices), dim3(64), 0, ctx_stream(ctx), a);
     return check_launch("qhull_rows_kernel");
+}
+
+extern "C" int mvosr_delaunay_qhull_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt,
+                                          const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
+                                          int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status, int32_t *order_out) {
+    return qh_launch(ctx, n_frames, pts_off, pts_cnt, u, v, keep, max_pts, tri_off, tri, tri_cnt, n_used, status, order_out, nullptr, 0);
+}
+
+// The frames of a device-side list (list[0] = how many, list[1..] = frame indices): the exact pass of mvosr_scale_batch asks for
+// SciPy's own rows of the frames it redoes when the batch's second triangulation is a stand-in (mvosr_batch.standin_*).
+int qh_rows_for_list(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, const int32_t *pts_cnt, const double *u, const double *v,
+                     const int32_t *keep, int max_pts, const int64_t *tri_off, int32_t *tri, int32_t *tri_cnt, int32_t *status,
+                     const int32_t *list) {
+    return qh_launch(ctx, n_frames, pts_off, pts_cnt, u, v, keep, max_pts, tri_off, tri, tri_cnt, nullptr, status, nullptr, list, 1024);
 }

@@ -178,12 +178,17 @@ class DeviceBatch:
             self.set_tri2(pf)
         self._struct = None
 
-    def triangulate(self, engine):
+    def triangulate(self, engine, standin=False):
         """Delaunay #1 -> depth-order vote -> Delaunay #2 over the survivors (/root/reference/src/scale_calculator.py:
-        257-267), three launches on the context's stream; rows, counters and counts stay in HBM."""
+        257-267), three launches on the context's stream; rows, counters and counts stay in HBM.  ``standin`` (reference vote
+        only; HOT launches without stage outputs, frames that fit the LDS-resident kernels): the second triangulation by the fast
+        canonical-row kernel as a stand-in — its rows reach the result only through rounding, and mvosr_scale_batch replaces them
+        with SciPy's own (Qhull's replay over its exact pass's list) for exactly the frames in which rounding can decide."""
         ctx, lib, b = self.ctx, self.ctx.lib, self.bufs
         assert self.device_triangulation
         self.info.invalidate()
+        self.standin = False
+        self._struct = None
         if getattr(engine, "check_triangle", "reference") == "reference":
             # the reference's vote reads the ROTATION of every row (:113-115): SciPy's rows themselves, order and rotation, from
             # the kernel that replays Qhull's insertion order (mvosr_delaunay_qhull_batch; DESIGN.md §3.6)
@@ -194,6 +199,14 @@ class DeviceBatch:
             o.vote_counters = b["vote_counters"].ptr
             bs = self.struct()
             _lib.check(lib.mvosr_outlier_vote_batch(ctx.handle, C.byref(engine.params), C.byref(bs), C.byref(o), 0), "mvosr_outlier_vote_batch")
+            if standin and self.max_feat <= int(lib.mvosr_max_lds_features()) and self.max_feat <= int(lib.mvosr_delaunay_max_points()):
+                _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
+                                                       b["vote_counters"].ptr, int(self.max_feat), b["tri_off"].ptr, b["tri2"].ptr,
+                                                       b["tri2_cnt"].ptr, b["n2_expected"].ptr, b["dt2_status"].ptr,
+                                                       None, None, None, None, None), "mvosr_delaunay_batch_ex (stand-in second triangulation)")
+                self.standin = True
+                self._struct = None
+                return
             _lib.check(lib.mvosr_delaunay_qhull_batch(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
                                                       b["vote_counters"].ptr, int(self.max_feat), b["tri_off"].ptr, b["tri2"].ptr,
                                                       b["tri2_cnt"].ptr, b["n2_expected"].ptr, b["dt2_status"].ptr, None),
@@ -271,6 +284,12 @@ class DeviceBatch:
             self._struct.tri2_cnt = p("tri2_cnt")
             self._struct.tri2_order = p("tri2_order")
             self._struct.exact_mask = p("exact_mask")
+            if getattr(self, "standin", False):
+                self._struct.standin_u = p("u")
+                self._struct.standin_keep = p("vote_counters")
+                self._struct.standin_rows = p("tri2")
+                self._struct.standin_cnt = p("tri2_cnt")
+                self._struct.standin_status = p("dt2_status")
             if self.n_frames:               # min_feat + the size classes' counts (ragged batches launch per class)
                 mf = self._struct.max_feat
                 _lib.check(self.ctx.lib.mvosr_batch_size_hint(_lib.addr(self._feat_cnt_host), self.n_frames,

@@ -456,6 +456,8 @@ class ScaleEstimator:
     GPU_CHUNK = 8192            # frames per chunk of the device-triangulation path, at most (a call of F frames uses chunks of F/4, 512 at least: the pipeline needs a few)
     GPU_RESIDENT = 512          # frames the GPU works on at once (two 8-wavefront workgroups per CU): chunks are multiples of it
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk (40 B each in staging memory, ~180 B each on the device)
+    GPU_EXACT_STANDIN = True    # check_triangle="reference": the second triangulation by the fast kernel as a stand-in; Qhull's own rows only for
+                                # the frames of the exact pass (engine.DeviceBatch.triangulate); False: Qhull's replay for every frame
     GPU_EXACT_MIN_FRAMES = 8    # ... calls of fewer frames (or fewer than ~3.7 per Delaunay worker) take SciPy's triangulations (same rows, lower latency)
     GPU_EXACT_CHUNK = 16384     # check_triangle="reference" (the Qhull-rows kernel): frames per chunk, at most ...
     GPU_EXACT_CHUNK_POINTS = 33000000   # ... and features per chunk (~0.75 KB each on the device: 25 GB at the cap)
@@ -490,7 +492,7 @@ class ScaleEstimator:
             return st
         db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk)
         try:
-            db.triangulate(self.engine)
+            db.triangulate(self.engine, standin=self.GPU_EXACT_STANDIN and not stage)
         except _lib.MvosrAllocError:
             # the triangulation kernels' workspace (frames x largest frame) did not fit next to whatever else lives on the
             # device: nothing was launched — this chunk takes the host's triangulations (MVOSR_ERR_ALLOC)
