@@ -2573,3 +2573,32 @@ def test_dense_frames_reference_exact_on_the_device(gpu, monkeypatch):
     for k in range(4):
         assert raw[k] == float(z["scale_first_call"]) and status[k] in (K.ST_MODE, K.ST_RIGHT), (k, raw[k], status[k])
         assert est.last_counts[k, K.CNT_SELECTED] == len(z["selected_ids"])
+
+
+@pytest.mark.parametrize("standin", [True, False])
+def test_frame_fuzz_batched_device_triangulation_reference_exact(gpu, standin):
+    """The 440 adversarial frames (levels within 1e-13 of a flat triangle, levels that ARE the result, every raise site's
+    neighbourhood) in one batch through triangulation="gpu", check_triangle="reference": raw scales bit-equal to the reference's,
+    statuses the oracle's, the levels that decide bit-equal — with the second triangulation as a stand-in (SciPy's own rows built
+    only for the frames of the exact pass) and with Qhull's replay for every frame."""
+    from mvoscalerecovery_amd import constants as K, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_fuzz.npz"))
+    idx = [i for i in range(len(z["scale"])) if not z["raised"][i]]
+    frames = [synth.fuzz_frame(i, int(z["seed"])) for i in idx]
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle="reference", delaunay_workers=0)
+    est.GPU_EXACT_STANDIN = standin
+    est.GPU_EXACT_CHUNK = 128
+    raw, status, level, errors = est.raw_scale_batch([f[0] for f in frames], [f[1] for f in frames])
+    assert not errors
+    seen = set()
+    for k, i in enumerate(idx):
+        want = z["scale"][i]
+        assert (np.isnan(raw[k]) and np.isnan(want)) or raw[k] == want, (i, raw[k], want, status[k])
+        r = so.frame_raw_scale(frames[k][0], frames[k][1], 1.75)
+        assert status[k] == r.status, (i, status[k], r.status)
+        if status[k] in (K.ST_NO_FLAT, K.ST_LEVEL) and not np.isnan(r.height_level):
+            assert level[k] == r.height_level, i
+        seen.add(int(status[k]))
+    assert {K.ST_MODE, K.ST_RIGHT, K.ST_MEDIAN, K.ST_NO_FLAT} <= seen
