@@ -411,8 +411,9 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames, exact=False):
             "hip_malloc_calls_in_timed_call": a1["hip_malloc"] - a0["hip_malloc"], "hip_host_malloc_calls_in_timed_call": a1["host_malloc"] - a0["host_malloc"],
             "what": ("ScaleEstimator(triangulation='gpu', check_triangle='reference').scale_calculation_batch on a list of per-frame arrays: "
                      "the C packer, one upload per chunk, Qhull's rows #1 (insertion order replayed on the device) / the reference's vote / "
-                     "Qhull's rows #2 / scale kernel / road model on the device, window median; NO declared deviation: bit-equal to the "
-                     "reference (tests/golden/seq4541.npz through this path)") if exact else
+                     "second triangulation as a stand-in (canonical rows) with Qhull's own rows for the frames of the exact pass / scale "
+                     "kernel / road model on the device, window median; NO declared deviation: bit-equal to the reference "
+                     "(tests/golden/seq4541.npz through this path)") if exact else
                     ("ScaleEstimator(triangulation='gpu').scale_calculation_batch on a list of per-frame arrays: vanishing-row filter + "
                      "packing by the C packer into page-locked memory, one upload per chunk, Delaunay #1 / vote / Delaunay #2 / scale "
                      "kernel / road model on the device, window median; a declared deviation from the reference (check_triangle='fixed'), "
