@@ -400,7 +400,7 @@ class ScaleEstimator:
             return level
         db.set_exact_mask(mask)
         eng.scale_batch(db, out, masked=True)
-        self.engine.ctx.sync()
+        eng.ctx.sync()
         new = out.get("height_level")
         level = np.array(level, copy=True)
         level[mask != 0] = new[mask != 0]
@@ -456,24 +456,33 @@ class ScaleEstimator:
     GPU_CHUNK = 8192            # frames per chunk of the device-triangulation path, at most (a call of F frames uses chunks of F/4, 512 at least: the pipeline needs a few)
     GPU_RESIDENT = 512          # frames the GPU works on at once (two 8-wavefront workgroups per CU): chunks are multiples of it
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk (40 B each in staging memory, ~180 B each on the device)
+    GPU_EXACT_TWO_CONTEXTS = True   # check_triangle="reference": the chunks of a call alternate between two contexts (see _stream_gpu)
     GPU_EXACT_STANDIN = True    # check_triangle="reference": the second triangulation by the fast kernel as a stand-in; Qhull's own rows only for
                                 # the frames of the exact pass (engine.DeviceBatch.triangulate); False: Qhull's replay for every frame
     GPU_EXACT_MIN_FRAMES = 8    # ... calls of fewer frames (or fewer than ~3.7 per Delaunay worker) take SciPy's triangulations (same rows, lower latency)
     GPU_EXACT_CHUNK = 16384     # check_triangle="reference" (the Qhull-rows kernel): frames per chunk, at most ...
     GPU_EXACT_CHUNK_POINTS = 33000000   # ... and features per chunk (~0.75 KB each on the device: 25 GB at the cap)
 
-    def _chunk_gpu(self, f3s, f2s, stage, tables=False):
+    def _second_engine(self):
+        """A second context on the same device (its own compute and upload streams, workspace and caches) with the same parameters."""
+        if getattr(self, "_engine2", None) is None:
+            self._engine2 = ScaleEngine(self.absolute_reference, ctx=_lib.Context(self.engine.ctx.device), camera_pitch=self.camera_pitch,
+                                        check_triangle=self.check_triangle)
+        return self._engine2
+
+    def _chunk_gpu(self, f3s, f2s, stage, tables=False, eng=None):
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
         ONE upload -> Delaunay #1, vote, Delaunay #2, scale kernel, road model, the exact re-runs known in advance and
         the download of the results, all queued; nothing is waited for here (``_chunk_gpu_finish`` does)."""
         from .engine import frame_tables, pack_upload_native
-        ctx = self.engine.ctx
+        eng = eng or self.engine
+        ctx = eng.ctx
         if tables is False:             # (not looked up by the caller yet)
             tables = frame_tables(f3s, f2s, remap_in_place=bool(self.mutate_inputs)) if len(f3s) > 0 else None
         native = tables is not None
         blk = None
         if native:
-            remap = (self.engine.params.cos_pitch, self.engine.params.sin_pitch) if self.mutate_inputs else None
+            remap = (eng.params.cos_pitch, eng.params.sin_pitch) if self.mutate_inputs else None
             pf, blk = pack_upload_native(ctx, f3s, f2s, self.vanish, remap, tables=tables)     # (:252-254, and :414 on the caller's arrays)
         else:
             pf = packing.pack_features(f3s, f2s, self.vanish)          # raw values, packed BEFORE the in-place remap below
@@ -483,7 +492,7 @@ class ScaleEstimator:
                         self.feature_remap(f3)                                   # :414
         pf.extra["canonical"] = self.check_triangle == "fixed"
         st = {"pf": pf, "n": len(f3s), "out": None, "dbatch": None, "masks": None, "gpu": True, "stage": stage,
-              "remapped": bool(self.mutate_inputs)}
+              "remapped": bool(self.mutate_inputs), "engine": eng}
         cap = packing.delaunay_gpu_max_points() if self.check_triangle == "fixed" else packing.delaunay_qhull_max_points()
         if pf.max_feat > cap or pf.n_frames == 0:
             st["gpu"] = False                                                # frames the device stage does not take: the host's path
@@ -492,7 +501,7 @@ class ScaleEstimator:
             return st
         db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk)
         try:
-            db.triangulate(self.engine, standin=self.GPU_EXACT_STANDIN and not stage)
+            db.triangulate(eng, standin=self.GPU_EXACT_STANDIN and not stage)
         except _lib.MvosrAllocError:
             # the triangulation kernels' workspace (frames x largest frame) did not fit next to whatever else lives on the
             # device: nothing was launched — this chunk takes the host's triangulations (MVOSR_ERR_ALLOC)
@@ -501,7 +510,7 @@ class ScaleEstimator:
             self.alloc_fallbacks = getattr(self, "alloc_fallbacks", 0) + 1
             return st
         out = DeviceOutputs(ctx, db, counts=True, stage=stage)
-        self.engine.scale_batch(db, out)          # (the frames whose level a later step reads are on the batch's exact mask)
+        eng.scale_batch(db, out)                  # (the frames whose level a later step reads are on the batch's exact mask)
         out.prefetch()
         db.prefetch_info()
         db.mark()                     # the chunk's last launch is queued: its blocks' next users need not wait for later chunks
@@ -511,7 +520,8 @@ class ScaleEstimator:
     def _chunk_gpu_finish(self, st, f3s, f2s, keep=False):
         """Results of a chunk started by ``_chunk_gpu``; frames whose triangulation the device stage declined (degenerate
         point sets, fewer than 3 points) are redone through the host's path (SciPy's rows, canonical form in "fixed" mode)."""
-        eng, ctx, pf = self.engine, self.engine.ctx, st["pf"]
+        eng = st.get("engine") or self.engine
+        ctx, pf = eng.ctx, st["pf"]
         stage = st["stage"]
         if not st["gpu"]:
             sub = self._chunk_begin(f3s, f2s, 0, _remapped=st["remapped"])
@@ -560,6 +570,7 @@ class ScaleEstimator:
         # uploads and computes one after the other: at least four chunks per call, of 512 frames or more
         C = int(min(self.GPU_CHUNK, max(512, -(-F // 4))))
         exact = self.check_triangle == "reference"
+        engines = [self.engine]
         chunk_points = self.GPU_CHUNK_POINTS
         if exact:
             # The Qhull-rows kernel is a chain of ~n dependent insertions per frame (one wavefront each): a launch lasts ~25 ms
@@ -567,6 +578,13 @@ class ScaleEstimator:
             # allows (0.56 KB per point of frames x largest frame), no short first chunks: the host's packing is 1 % of the time
             C = int(min(self.GPU_EXACT_CHUNK, F))
             chunk_points = self.GPU_EXACT_CHUNK_POINTS
+            if self.GPU_EXACT_TWO_CONTEXTS and not stage and F >= 2 * 4096:
+                # ... and two contexts (a stream, a workspace and caches each) taking the chunks in turn: while one chunk is in the
+                # thin parts of its chain (the launch's tail, the stand-in triangulation, Qhull's rows for the exact pass's few frames
+                # — 20 ms at a few hundred wavefronts), the other chunk's replay fills the machine
+                engines.append(self._second_engine())
+                C = int(min(self.GPU_EXACT_CHUNK // 2, max(4096, ((-(-F // 2)) // 4096) * 4096)))
+                chunk_points //= 2
         # (the points cap as it will bite, from the first frames' sizes: the short first chunks are fractions of THAT chunk)
         mean_pts = max(1, sum(len(x) for x in feature3ds[:64]) // min(F, 64))
         C = int(max(512, min(C, chunk_points // mean_pts)))
@@ -609,7 +627,7 @@ class ScaleEstimator:
         results, queue = [], []
         for k, (a, b, tb) in enumerate(chunk_bounds()):
             bounds.append((a, b))
-            queue.append((self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage, tables=tb), a, b))
+            queue.append((self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage, tables=tb, eng=engines[k % len(engines)]), a, b))
             # GPU_PIPELINE chunks stay queued behind the one whose results are collected: this process packs and uploads
             # the next chunk meanwhile (the kernel timeline shows the GPU 98 % busy between a call's first and last chunk
             # with one: what a call pays beyond its kernels is its first chunk's pack + upload and the host's epilogue)
