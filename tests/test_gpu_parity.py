@@ -2602,3 +2602,25 @@ def test_frame_fuzz_batched_device_triangulation_reference_exact(gpu, standin):
             assert level[k] == r.height_level, i
         seen.add(int(status[k]))
     assert {K.ST_MODE, K.ST_RIGHT, K.ST_MEDIAN, K.ST_NO_FLAT} <= seen
+
+
+def test_exact_path_two_contexts_equal_one(gpu):
+    """A call of the exact device path large enough for its chunks to alternate between two contexts (>= 8 192 frames) gives the
+    arrays the one-context run gives — raw scales, statuses, levels, filtered scales — and the host-SciPy run's on a sample."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    pool = [synth.synth_frame(i, 250 + (37 * i) % 400, base_seed=4242, upper_fraction=0.1) for i in range(257)]
+    F = 9300
+    f3s, f2s = [pool[i % 257][0] for i in range(F)], [pool[i % 257][1] for i in range(F)]
+    res = []
+    for two in (True, False):
+        est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle="reference", delaunay_workers=0)
+        est.GPU_EXACT_TWO_CONTEXTS = two
+        s, sd = est.scale_calculation_batch(f3s, f2s)
+        res.append((np.asarray(s), np.asarray(sd), np.asarray(est.last_raw_scale), np.asarray(est.last_status)))
+        assert (getattr(est, "_engine2", None) is not None) == two
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b, equal_nan=True)
+    host = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=0)
+    raw_h, st_h, _, _ = host.raw_scale_batch(f3s[:257], f2s[:257])
+    assert np.array_equal(res[0][2][:257], raw_h, equal_nan=True) and np.array_equal(res[0][3][:257], st_h)
