@@ -45,6 +45,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
 from __future__ import annotations
 
 import os as _os
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # this process owns more than four streams (torch's, two contexts with an upload stream each): ROCm's default of four hardware queues would make them share
 _os.environ.setdefault("MVOSR_AFFINITY", "1")     # the end-to-end legs pin this process to the CPUs of the device's NUMA node (opt-in in the library)
 import argparse
 import ctypes as C
