@@ -294,7 +294,7 @@ def e2e_leg(args, device, sizes, seed, budget_frames):
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
     n = min(budget_frames, 4096)
     frames = [synth.synth_frame(100000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(n)]
-    est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False)
+    est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="scipy")
     nw = min(64, max(8, n // 8))
     est.scale_calculation_batch([f[0] for f in frames[:nw]], [f[1] for f in frames[:nw]])         # warm-up (pool, workspaces)
     t0 = time.perf_counter()
@@ -478,7 +478,7 @@ def latency_leg(args, device, sizes, seed, frames=100):
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
     fr = [synth.synth_frame(300000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(frames)]
     out = {}
-    for name, kw in (("scipy", {}), ("gpu", {"triangulation": "gpu"}), ("gpu_exact", {"triangulation": "gpu", "check_triangle": "reference"})):
+    for name, kw in (("scipy", {"triangulation": "scipy"}), ("gpu", {"triangulation": "gpu"}), ("gpu_exact", {"triangulation": "gpu", "check_triangle": "reference"})):
         est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, delaunay_workers=0, **kw)
         for f3, f2 in fr[:5]:
             est.scale_calculation(f3.copy(), f2)

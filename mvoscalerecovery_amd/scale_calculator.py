@@ -21,6 +21,7 @@ implementation behind this class: without libmvosr.so / a gfx950 device it raise
 """
 from __future__ import annotations
 
+import os
 from collections import deque
 
 import numpy as np
@@ -48,7 +49,7 @@ def raise_for_status(status, frame=None):
 
 class ScaleEstimator:
     def __init__(self, absolute_reference, window_size=6, vanish=K.VANISH, focus=K.FOCUS, device=0,
-                 delaunay_workers=None, verbose=False, mutate_inputs=True, triangulation="scipy", check_triangle=None):
+                 delaunay_workers=None, verbose=False, mutate_inputs=True, triangulation=None, check_triangle=None):
         # reference attributes (scale_calculator.py:23-40)
         self.absolute_reference = absolute_reference
         self.camera_pitch = K.CAMERA_PITCH
@@ -72,16 +73,22 @@ class ScaleEstimator:
         self.verbose = verbose
         self.mutate_inputs = mutate_inputs          # the reference remaps the caller's feature3d in place (:414)
         self.delaunay_workers = delaunay_workers
-        # triangulation = "scipy": both triangulations by scipy.spatial.Delaunay on the host.  "gpu": the device stage
-        # mvosr_delaunay_batch — same triangle set, canonical row form; rows, vote counters and survivor counts stay in
-        # HBM from the first triangulation to the scale kernel.
+        # triangulation = "scipy": both triangulations by scipy.spatial.Delaunay on the host.  "gpu": on the device; rows, vote
+        # counters and survivor counts stay in HBM from the first triangulation to the scale kernel.
         # check_triangle = "reference": the vote's flag pattern exactly as the reference has it (:113-115 sets flag[1]
-        # where flag[2] is meant), which depends on Qhull's rotation of each row — with SciPy's rows, verbatim, this is
-        # the reference bit for bit (the default).  "fixed": the (0,2) pair marks vertices 0 and 2 — a DECLARED DEVIATION
-        # (DESIGN.md §4 has the measured agreement with the reference) under which the vote, and with
-        # rows in canonical form every stage, is a function of the triangle SET alone: "scipy" and "gpu" then give
-        # bit-identical results, pinned by Oracle(check_triangle="fixed").  Default: "reference" with "scipy", "fixed"
-        # with "gpu" ("gpu" with "reference" is accepted but unpinned: Qhull's row rotation cannot be reproduced).
+        # where flag[2] is meant), which depends on Qhull's rotation of each row — with SciPy's rows this is the reference bit
+        # for bit, and "gpu" builds exactly those rows (mvosr_delaunay_qhull_batch replays Qhull's insertion order; DESIGN.md
+        # §3.6).  "fixed": the (0,2) pair marks vertices 0 and 2 — a DECLARED DEVIATION (DESIGN.md §4 has the
+        # measured agreement with the reference) under which the vote, and with rows in canonical form every stage, is a function
+        # of the triangle SET alone (the faster device kernels: mvosr_delaunay_batch).
+        # Defaults.  No triangulation given (the reference's own construction, /root/reference/src/main.py:55): the reference's
+        # result from the fastest path that gives it — "gpu" with "reference": batches on the device, a per-frame call (or a
+        # handful of frames) through SciPy, the same rows either way (round 5; MVOSR_TRIANGULATION=scipy restores the host default).
+        # triangulation="gpu" given explicitly: "fixed", the declared-deviation speed mode, as before.  "scipy": "reference".
+        if triangulation is None:
+            triangulation = os.environ.get("MVOSR_TRIANGULATION", "gpu")
+            if check_triangle is None:
+                check_triangle = "reference"
         if triangulation not in ("scipy", "gpu"):
             raise ValueError("triangulation must be 'scipy' or 'gpu'")
         if check_triangle is None:

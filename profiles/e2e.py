@@ -18,7 +18,7 @@ W = int(sys.argv[3]) if len(sys.argv) > 3 else packing.available_cpus()
 frames = [synth.synth_frame(i, N, base_seed=2024) for i in range(F)]
 f3, f2 = [f[0] for f in frames], [f[1] for f in frames]
 for workers in sorted({1, W // 2, W, 2 * W}):
-    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=workers)
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=workers, triangulation="scipy")
     est.scale_calculation_batch(f3[:8], f2[:8])
     n = F if workers > 1 else min(F, 64)
     t0 = time.perf_counter()

@@ -14,7 +14,7 @@ if __name__ == "__main__":
     W = int(sys.argv[2]) if len(sys.argv) > 2 else min(64, os.cpu_count() or 1)
     frames = [synth.synth_frame(i, 2000, base_seed=2024) for i in range(F)]
     f3, f2 = [f[0] for f in frames], [f[1] for f in frames]
-    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=W)
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=W, triangulation="scipy")
     est.scale_calculation_batch(f3[:256], f2[:256])
     t0 = time.perf_counter()
     est.scale_calculation_batch(f3, f2)

@@ -11,7 +11,7 @@ from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=8)
+est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=8, triangulation="scipy")
 pool = [synth.synth_frame(i, N, base_seed=7) for i in range(64)]
 eng = est.engine
 pf = packing.pack_features([p[0] for p in pool], [p[1] for p in pool])

@@ -22,7 +22,7 @@ packing.start_pool(None)
 out = {}
 z, meta = load_npz("seq4541.npz")
 data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
-for mode, kw in (("scipy", {}), ("gpu", {"triangulation": "gpu"}), ("scipy_fixed", {"check_triangle": "fixed"}),
+for mode, kw in (("scipy", {"triangulation": "scipy"}), ("gpu", {"triangulation": "gpu"}), ("scipy_fixed", {"triangulation": "scipy", "check_triangle": "fixed"}),
                  ("gpu_reference_pattern", {"triangulation": "gpu", "check_triangle": "reference"})):
     est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, **kw)
     offline.run_sequence_batched(data, ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, **kw))     # warm-up

@@ -14,7 +14,7 @@ from mvoscalerecovery_amd.scale_calculator import ScaleEstimator         # noqa:
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 frames = [synth.synth_frame(i, n, base_seed=77) for i in range(F)]
-est = ScaleEstimator(1.75, window_size=5)
+est = ScaleEstimator(1.75, window_size=5, triangulation="scipy")
 for f3, f2 in frames[:5]:
     est.scale_calculation(f3.copy(), f2)
 t = []

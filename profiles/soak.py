@@ -21,7 +21,7 @@ if __name__ == "__main__":
         n = int(rng.choice(sizes))
         frames.append(synth.synth_frame(i, n, base_seed=100000 * seed, sigma=float(rng.choice([0.0, 0.002, 0.01, 0.03, 0.08])),
                                         upper_fraction=float(rng.choice([0.0, 0.1, 0.4]))))
-    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False)
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="scipy")
     t0 = time.perf_counter()
     if os.environ.get("SOAK_ONE_LAUNCH"):
         # triangulations from the oracle, every frame in ONE launch: a ragged batch of >= 2048 frames is then launched

@@ -11,6 +11,12 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The suite's un-parametrised ScaleEstimator(...) constructions are the host-SciPy baseline every device path is compared with
+# (rounds 1-4 wrote them when that was the default).  Since round 5 the default is the fast exact path (triangulation="gpu" with
+# the reference's vote); here the baseline stays what it was, and the default itself has its own test
+# (tests/test_gpu_parity.py::test_default_construction_is_the_fast_exact_path).
+os.environ.setdefault("MVOSR_TRIANGULATION", "scipy")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -2624,3 +2624,29 @@ def test_exact_path_two_contexts_equal_one(gpu):
     host = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=0)
     raw_h, st_h, _, _ = host.raw_scale_batch(f3s[:257], f2s[:257])
     assert np.array_equal(res[0][2][:257], raw_h, equal_nan=True) and np.array_equal(res[0][3][:257], st_h)
+
+
+def test_default_construction_is_the_fast_exact_path(gpu, monkeypatch):
+    """ScaleEstimator(absolute_reference, window_size) as /root/reference/src/main.py:55 constructs it: the reference's result from
+    the device — triangulation "gpu", check_triangle "reference" — for a batch, SciPy's triangulations for a per-frame call, the same
+    numbers either way; MVOSR_TRIANGULATION=scipy (what this suite runs under) restores the host default."""
+    from mvoscalerecovery_amd import packing, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    assert ScaleEstimator(1.75, window_size=5).triangulation == "scipy"                       # (conftest's setting)
+    monkeypatch.delenv("MVOSR_TRIANGULATION")
+    est = ScaleEstimator(1.75, window_size=5, delaunay_workers=0)
+    assert (est.triangulation, est.check_triangle) == ("gpu", "reference")
+    assert ScaleEstimator(1.75, window_size=5, triangulation="gpu").check_triangle == "fixed"  # the explicit speed mode, as before
+    frames = [synth.synth_frame(i, 700 + 11 * i, base_seed=606, upper_fraction=0.1) for i in range(40)]
+    host_frames = []
+    real_attach = packing.attach_tri1
+    monkeypatch.setattr(packing, "attach_tri1", lambda pf, *a, **k: (host_frames.append(pf.n_frames), real_attach(pf, *a, **k))[1])
+    s, sd = est.scale_calculation_batch([f[0].copy() for f in frames], [f[1] for f in frames])
+    assert sum(host_frames) <= 1                                                             # (flat_feature of the last frame)
+    ref = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="scipy")
+    r, rd = ref.scale_calculation_batch([f[0].copy() for f in frames], [f[1] for f in frames])
+    assert np.array_equal(s, r) and np.array_equal(sd, rd)
+    one = ScaleEstimator(1.75, window_size=5, delaunay_workers=0)
+    host_frames.clear()
+    assert one.scale_calculation(frames[0][0].copy(), frames[0][1]) == (r[0], rd[0])          # per-frame: SciPy's rows, same numbers
+    assert sum(host_frames) >= 1
