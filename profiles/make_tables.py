@@ -57,7 +57,7 @@ def render(tag):
     if b:
         for key, label in (("e2e_rescale", "end to end from per-frame arrays, `rescale.ScaleEstimator(triangulation=\"gpu\")` — the estimator `/root/reference/src/main.py:20` imports; no declared deviation"),
                            ("e2e_gpu_triangulation", "end to end, `scale_calculator.ScaleEstimator(triangulation=\"gpu\")` (`check_triangle=\"fixed\"`: a declared deviation)"),
-                           ("e2e", "end to end, host SciPy triangulations (reference-exact default), worker pool on the box's CPUs")):
+                           ("e2e", "end to end, host SciPy triangulations (`triangulation=\"scipy\"`: reference-exact; the default of rounds 1-4), worker pool on the box's CPUs")):
             if key in b and "value" in b[key]:
                 e = b[key]
                 extra = ""
@@ -70,7 +70,7 @@ def render(tag):
             e = b["e2e_gpu_exact"]
             dk = e.get("delaunay_kernel") or {}
             extra = "; KITTI-sized frames (300-1500 features): %s" % k(kt["e2e_gpu_exact"]["value"]) if (kt and "value" in kt.get("e2e_gpu_exact", {})) else ""
-            rows.append(("end to end, `scale_calculator.ScaleEstimator(triangulation=\"gpu\", check_triangle=\"reference\")` — **the reference's result, bit for bit, both triangulations on the device** (Qhull's rows by `qhull_rows_kernel`)",
+            rows.append(("end to end, `scale_calculator.ScaleEstimator(...)` as the reference constructs it (= `triangulation=\"gpu\", check_triangle=\"reference\"`, the default since round 5) — **the reference's result, bit for bit, both triangulations on the device** (Qhull's rows by `qhull_rows_kernel`)",
                          "**%s frames/s** at 2000 features (%d frames, %s distinct; declined to the host in the last chunk: %d)%s; `qhull_rows_kernel` alone: %s sets/s (%d resident sets of %d points)"
                          % (k(e["value"]), e["frames"], e.get("distinct_frames", "all"), e.get("declined_last_chunk", 0), extra,
                             k(dk.get("sets_per_s", float("nan"))), dk.get("sets", 0), dk.get("points_per_set", 0)), "`e2e_gpu_exact` in the bench line"))
