@@ -838,10 +838,10 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
 
 // 119 registers and 9.7 KB of LDS: four wavefronts per SIMD.  (Compiled for five, six and eight — 96 / 80 / 64 registers with
 // spills, the LDS tables halved — the same launch of 4096 frames took 41 / 50 / 66 ms instead of 34: LABNOTES §9.)
-template <typename FID>
+template <typename FID, bool LIST>
 __global__ __launch_bounds__(64, 4) void qhull_rows_kernel(const QhArgs a) {
     __shared__ QhLdsT<FID> L;
-    if (a.list) {
+    if constexpr (LIST) {
         // the frames of a list whose length is known on the device only: a persistent grid, one workspace slice per workgroup
         const int64_t todo = (int64_t)a.list[0];
         for (int64_t it = blockIdx.x; it < todo; it += gridDim.x) {
@@ -903,8 +903,12 @@ static int qh_launch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, c
     void *ws = nullptr;
     if ((rc = ctx_workspace_bytes(ctx, (size_t)slices * P.total, &ws))) return rc;
     a.ws = reinterpret_cast<char *>(ws);
-    if (wide) hipLaunchKernelGGL(qhull_rows_kernel<uint32_t>, dim3((unsigned)slices), dim3(64), 0, ctx_stream(ctx), a);
-    else hipLaunchKernelGGL(qhull_rows_kernel<uint16_t>, dim3((unsigned)slices), dim3(64), 0, ctx_stream(ctx), a);
+    // (the list walk is an instantiation of its own: the loop around the run cost the product kernel registers — spills in its hot loop)
+    if (list) {
+        if (wide) hipLaunchKernelGGL((qhull_rows_kernel<uint32_t, true>), dim3((unsigned)slices), dim3(64), 0, ctx_stream(ctx), a);
+        else hipLaunchKernelGGL((qhull_rows_kernel<uint16_t, true>), dim3((unsigned)slices), dim3(64), 0, ctx_stream(ctx), a);
+    } else if (wide) hipLaunchKernelGGL((qhull_rows_kernel<uint32_t, false>), dim3((unsigned)slices), dim3(64), 0, ctx_stream(ctx), a);
+    else hipLaunchKernelGGL((qhull_rows_kernel<uint16_t, false>), dim3((unsigned)slices), dim3(64), 0, ctx_stream(ctx), a);
     return check_launch("qhull_rows_kernel");
 }
 
