@@ -407,6 +407,7 @@ class ScaleEstimator:
             return level
         db.set_exact_mask(mask)
         eng.scale_batch(db, out, masked=True)
+        self._masked_launched = True
         eng.ctx.sync()
         new = out.get("height_level")
         level = np.array(level, copy=True)
@@ -553,7 +554,19 @@ class ScaleEstimator:
             host_errors = {int(redo[k]): e for k, e in r_err.items()}
         if not stage:
             # with the re-run's results merged in: the neighbours of the chunk's first REAL error
+            self._masked_launched = False
             level = self._exact_after(eng, db, out, status, level, host_errors, skip=redo)
+            if self._masked_launched and getattr(db, "standin", False):
+                # stand-in rows: the masked relaunch asked Qhull's replay for the rows of its one or two frames; a frame it declined
+                # there (its bits arrive in the second triangulation's status only now) takes the host's path for its level
+                late = np.nonzero((db.bufs["dt2_status"].download() != 0) & (s2 == 0) & (s1 == 0))[0]
+                if len(late):
+                    sub = self._chunk_begin([f3s[f] for f in late], [f2s[f] for f in late], 0, _remapped=st["remapped"], _exact_all=True)
+                    self._chunk_vote(sub, None, 0)
+                    _, _, l_level, _, _ = self._chunk_scale(sub, None, False)
+                    level = np.array(level, copy=True)
+                    level[late] = l_level
+                    self.last_declined += len(late)
         if stage:
             c = db.bufs["vote_counters"].download()
             st["masks"] = [c[pf.frame_slice(f)] >= 0 for f in range(pf.n_frames)]
