@@ -462,6 +462,7 @@ class ScaleEstimator:
                                     # frames/s —: the pipeline's stages are balanced, PCIe at 6.5 ms per chunk against the GPU's 7.2.)
     GPU_PIPELINE = 2                # chunks queued on the device behind the one being collected (with the short first chunks 1 -> 2 is +3 % at 32 768 frames, +6 % at 16 384; 3: the same)
     GPU_CHUNK = 8192            # frames per chunk of the device-triangulation path, at most (a call of F frames uses chunks of F/4, 512 at least: the pipeline needs a few)
+    GPU_MIN_CHUNK = 512         # ... and at least (tests lower it to put chunk boundaries everywhere)
     GPU_RESIDENT = 512          # frames the GPU works on at once (two 8-wavefront workgroups per CU): chunks are multiples of it
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk (40 B each in staging memory, ~180 B each on the device)
     GPU_EXACT_TWO_CONTEXTS = True   # check_triangle="reference": the chunks of a call alternate between two contexts (see _stream_gpu)
@@ -588,7 +589,7 @@ class ScaleEstimator:
         # chunks of 4096; 900 features: 710 k / 756 k, and with the short first chunks 764 k / 807 k in chunks of 4096 / 8192 —
         # profiles/e2e_chunk_sweep.py; the points cap keeps 2000-feature frames at 5000 per chunk), but a call that is ONE chunk packs,
         # uploads and computes one after the other: at least four chunks per call, of 512 frames or more
-        C = int(min(self.GPU_CHUNK, max(512, -(-F // 4))))
+        C = int(min(self.GPU_CHUNK, max(self.GPU_MIN_CHUNK, -(-F // 4))))
         exact = self.check_triangle == "reference"
         engines = [self.engine]
         chunk_points = self.GPU_CHUNK_POINTS
@@ -607,7 +608,7 @@ class ScaleEstimator:
                 chunk_points //= 2
         # (the points cap as it will bite, from the first frames' sizes: the short first chunks are fractions of THAT chunk)
         mean_pts = max(1, sum(len(x) for x in feature3ds[:64]) // min(F, 64))
-        C = int(max(512, min(C, chunk_points // mean_pts)))
+        C = int(max(self.GPU_MIN_CHUNK, min(C, chunk_points // mean_pts)))
         # chunks of at most GPU_CHUNK frames and GPU_CHUNK_POINTS features (a chunk's planes, rows and staging memory
         # scale with its points: dense frames travel in smaller chunks)
         # the first chunks are short (C/8, C/4, C/2): the GPU starts after the pack + upload of 1/8 chunk instead of a whole

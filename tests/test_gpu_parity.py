@@ -667,7 +667,7 @@ def test_triangulation_gpu_error_at_a_chunk_head_leaves_the_exact_level(gpu):
     assert list(est.scale_queue) == list(ref.scale_queue)
 
 
-@pytest.mark.parametrize("mode", ["gpu", "scipy"])
+@pytest.mark.parametrize("mode", ["gpu", "scipy", "gpu_exact"])
 def test_chunk_boundary_fuzz_of_the_cross_frame_state(gpu, mode):
     """The cross-frame reads of height_level — a frame with exactly three features below the vanishing row divides by the
     level an EARLIER frame left (scale_calculator.py:263-270,:420-422), a frame that raises leaves the estimator at the
@@ -678,7 +678,7 @@ def test_chunk_boundary_fuzz_of_the_cross_frame_state(gpu, mode):
     from mvoscalerecovery_amd import synth
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
     so = _oracle()
-    rng = np.random.default_rng(20 if mode == "gpu" else 21)
+    rng = np.random.default_rng({"gpu": 20, "scipy": 21, "gpu_exact": 22}[mode])
     few = synth.too_few_sequence()[4]                              # three features below the vanishing row
     level_zero = synth.fuzz_frame(400)                             # its road model raises IndexError after :241
     for trial in range(6):
@@ -708,8 +708,12 @@ def test_chunk_boundary_fuzz_of_the_cross_frame_state(gpu, mode):
             else:
                 frames[err_at] = level_zero
         f3s, f2s = [f[0].copy() for f in frames], [f[1].copy() for f in frames]
-        est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation=mode, delaunay_workers=4)
-        est.GPU_CHUNK, est.GPU_RAMP, est.PIPELINE_CHUNK = chunk, False, chunk
+        if mode == "gpu_exact":            # device triangulations with the reference's vote: stand-in second triangulation, masked relaunches
+            est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle="reference", delaunay_workers=0)
+            est.GPU_EXACT_CHUNK, est.GPU_EXACT_MIN_FRAMES = chunk, 1
+        else:
+            est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation=mode, delaunay_workers=4)
+        est.GPU_CHUNK, est.GPU_RAMP, est.PIPELINE_CHUNK, est.GPU_MIN_CHUNK = chunk, False, chunk, 1
         ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed" if mode == "gpu" else "reference")
         want, want_exc = [], None
         for f3, f2 in zip(f3s, f2s):
