@@ -124,7 +124,7 @@ template <typename FID> struct QhLdsT {
     uint16_t nva[kQhMaxNew], nvb[kQhMaxNew];     // a cone facet's horizon vertices (point ids)
     uint8_t nnb[kQhMaxNew][4];       // cone neighbours 1, 2 as cone-local indices; [3] = upper flag
     FID visq[kQhMaxVis];        // visible facets in Qhull's breadth-first order
-    FID visnb[kQhMaxVis][3];
+    FID visnb[kQhMaxVis][4];          // (a stride of four: the entry/neighbour pair of a lane is a shift and a mask)
     uint16_t visrep[kQhMaxVis];      // cone-local index of the visible facet's replacement (kQhNone: the first cone facet)
     uint32_t visoff[kQhMaxVis];
     uint16_t viscnt[kQhMaxVis];      // points of its outside set without the furthest
@@ -581,9 +581,9 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
             const double px = X[p], py = Y[p], pz = Z[p];        // (in flight together with the first round's facet records)
             bool bad = false, copl = false;
             while (head < nvis) {
-                const int ne = min(nvis - head, 21);
-                const int e = head + lane / 3, k = lane % 3;
-                const bool act = lane < 3 * ne;
+                const int ne = min(nvis - head, 16);               // four lanes per visible facet: neighbours 0..2 (the fourth lane idles)
+                const int e = head + (lane >> 2), k = lane & 3;
+                const bool act = (lane >> 2) < ne && k < 3;
                 int g = 0;
                 QhFacet G;
                 bool cand = false;
@@ -634,10 +634,10 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
             for (int e = lane; e < nvis; e += 64) L.visrep[e] = kQhNone;
             qh_lds_sync();
             bool gauss = false, notconv = false;
-            for (int base = 0; base < nvis; base += 21) {
-                const int ne = min(nvis - base, 21);
-                const int e = base + lane / 3, k = lane % 3;
-                const bool act = lane < 3 * ne;
+            for (int base = 0; base < nvis; base += 16) {
+                const int ne = min(nvis - base, 16);
+                const int e = base + (lane >> 2), k = lane & 3;
+                const bool act = (lane >> 2) < ne && k < 3;
                 int g = 0, hi = -1;
                 if (act) {
                     g = L.visnb[e][k];
@@ -670,7 +670,7 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
                     L.nhz[j] = (FID)g;
                     fac[g].nb[skip] = (FID)(nfac + 1 + j);
                     // a visible facet's replacement: the last cone facet made from it
-                    const uint64_t mine = hm & (7ull << (3 * (lane / 3)));
+                    const uint64_t mine = hm & (15ull << (lane & ~3));
                     if ((63 - __clzll((long long)mine)) == lane) L.visrep[e] = (uint16_t)j;
                 }
                 m += add;
