@@ -2654,3 +2654,27 @@ def test_default_construction_is_the_fast_exact_path(gpu, monkeypatch):
     host_frames.clear()
     assert one.scale_calculation(frames[0][0].copy(), frames[0][1]) == (r[0], rd[0])          # per-frame: SciPy's rows, same numbers
     assert sum(host_frames) >= 1
+
+
+def test_qhull_rows_kernel_hostile_inputs_are_declined(gpu):
+    """NaN / infinite / huge / identical / collinear sites, a mask that keeps fewer than three points: the kernel declines (status
+    != 0, no rows) — it neither hangs nor writes outside its frame — and the sets around them are untouched."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import packing, synth
+    good = synth.synth_frame(1, 300, base_seed=99)[1]
+    nan = good.copy(); nan[17, 0] = np.nan
+    inf = good.copy(); inf[40, 1] = np.inf
+    huge = good.copy() * 1e200
+    same = np.tile(good[:1], (50, 1))
+    line = np.stack([np.linspace(0, 1000, 80), np.linspace(200, 300, 80)], axis=1)
+    allnan = np.full((30, 2), np.nan)
+    sets = [good, nan, good, inf, huge, same, line, allnan, good]
+    got = packing.delaunay_gpu(gpu, sets, rows="qhull")
+    ref = Delaunay(good).simplices
+    for k in (0, 2, 8):
+        assert got[k] is not None and np.array_equal(got[k], ref), k
+    for k in (1, 3, 5, 6, 7):
+        assert got[k] is None, k
+    assert got[4] is None or np.array_equal(got[4], Delaunay(huge).simplices)          # (scaled copies: either answer is fine, a wrong one is not)
+    keep = np.full(len(good), -1, np.int32); keep[:2] = 1
+    assert packing.delaunay_gpu(gpu, [good], [keep], rows="qhull")[0] is None
