@@ -35,7 +35,7 @@ constexpr uint16_t kQhNone = 0xFFFFu;
 enum QhWhy : int {
     QH_OK = 0, QH_FEW_POINTS = 1, QH_ZERO_WIDTH = 2, QH_SIMPLEX_SEARCH = 3, QH_FLAT_SIMPLEX = 4, QH_NARROW = 5, QH_INSIDE_SIMPLEX = 6,
     QH_BAND = 7, QH_COPLANAR_HORIZON = 8, QH_TOO_MANY_VISIBLE = 9, QH_CONE_TOO_LARGE = 10, QH_OPEN_CONE = 11, QH_NOT_CONVEX = 12,
-    QH_GAUSS = 13, QH_NOT_SHARP = 14, QH_ABOVE_NONE = 15, QH_FACETS_FULL = 16, QH_ARENA_FULL = 17, QH_VERTICAL = 18
+    QH_GAUSS = 13, QH_NOT_SHARP = 14, QH_ABOVE_NONE = 15, QH_FACETS_FULL = 16, QH_ARENA_FULL = 17
 };
 
 // A facet record, FID = the type of a facet id: 16 bits up to 8 000 points (7 n + 64 facets per run fit), 32 bits beyond
@@ -48,7 +48,7 @@ template <> struct __attribute__((aligned(16))) QhFacetT<uint16_t> {
     uint16_t bestp;     // the outside set's furthest point (kQhNone: empty set)
     uint32_t off;       // the rest of the outside set: arena[off .. off + cnt), in Qhull's list order
     uint16_t cnt;
-    uint16_t mark;      // (unused)
+    uint16_t mark;      // (spare)
     double bestd;
     double n0, n1, n2, d;
 };
@@ -733,7 +733,7 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
                 // targets: a directed walk per point; from the first point that ends below its best facet on a sharp cone,
                 // a linear scan (qh.findbestnew stays set for the rest of this insertion)
                 bool mode = false, fail_band = false, fail_sharp = false, fail_none = false;
-                bool valid0 = false; int q0 = 0, tgt0 = 0; double d0 = 0.0;
+                int q0 = 0, tgt0 = 0; double d0 = 0.0;
                 for (int base = 0; base < S; base += 64) {
                     const int i = base + lane;
                     const bool valid = i < S;
@@ -764,7 +764,7 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
                         atomicAdd(&L.t_total[R.tgt], 1u);
                         if (S > 64) { TT[i] = (uint16_t)R.tgt; DD[i] = R.d; }
                     }
-                    if (base == 0) { valid0 = valid; q0 = q; tgt0 = R.tgt; d0 = R.d; }
+                    if (base == 0) { q0 = q; tgt0 = R.tgt; d0 = R.d; }
                 }
                 if (__any(fail_band)) return QH_BAND;
                 if (fail_sharp) return QH_NOT_SHARP;

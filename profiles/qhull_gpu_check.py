@@ -12,8 +12,7 @@ from scipy.spatial import Delaunay                     # noqa: E402
 from mvoscalerecovery_amd import _lib, packing, synth   # noqa: E402
 
 WHY = ["ok", "few points", "zero width", "simplex search", "flat simplex", "narrow", "inside simplex", "band", "coplanar horizon",
-       "too many visible", "cone too large", "open cone", "not convex", "gauss", "not sharp", "above none", "facets full", "arena full",
-       "vertical"]
+       "too many visible", "cone too large", "open cone", "not convex", "gauss", "not sharp", "above none", "facets full", "arena full"]
 
 
 def main():
