@@ -24,9 +24,8 @@ namespace {
 
 constexpr int kQhMaxPoints = 8000;        // facet ids are 16-bit: 7 * (n + 1) + 64 facets per run
 constexpr int kQhMaxPointsWide = 60000;   // 32-bit facet ids (80-byte records); point ids stay 16-bit
-constexpr int kQhMaxNew = 64;             // facets of one cone (one lane each; 5.6 on average, 35 the most seen in 512 frames of 2000 points)
-constexpr int kQhMaxVis = 64;             // visible facets of one insertion (3.6 on average, 33 the most seen)
-constexpr int kQhMaxHz = 64;              // horizon facets of one insertion
+// table entries per insertion: 64 (one frame per wavefront) or 32 (packed kernels) — cone facets 5.6 on average, 35 the most seen
+// in 512 frames of 2000 points; visible facets 3.6 on average, 33 the most seen; horizon facets about as many
 constexpr int kQhPickWindow = 16;
 constexpr double kQhEps = 2.220446049250313e-16;
 constexpr double kQhHuge = 1.797e308;
@@ -85,6 +84,7 @@ struct QhArgs {
     const int64_t *pts_off; const int32_t *pts_cnt; const double *u; const double *v; const int32_t *keep;
     const int64_t *tri_off; int32_t *tri; int32_t *tri_cnt; int32_t *n_used; int32_t *status; int32_t *order_out;
     unsigned long long *stamps;
+    int32_t *redo;               // packed kernels: frames that overflowed a table ([0] = how many), for the list kernel
     const int32_t *list;         // null, or: list[0] frames list[1..] (a redo list of the scale kernels), walked by a persistent grid
     char *ws; size_t ws_stride; int cap_pts;      // per-frame slice, laid out by QhPlan for cap_pts = max_pts + 1 points
 };
@@ -118,45 +118,75 @@ struct QhCoord {
     __device__ __forceinline__ double &operator[](int i) const { return (&p[i].x)[k]; }
 };
 
-template <typename FID> struct QhLdsT {
-    double npl[kQhMaxNew][4];        // the cone's planes (n0, n1, n2, offset)
-    double nxy[kQhMaxNew][6];        // coordinates of a cone facet's two horizon vertices (convexity test between cone facets)
-    uint16_t nva[kQhMaxNew], nvb[kQhMaxNew];     // a cone facet's horizon vertices (point ids)
-    uint8_t nnb[kQhMaxNew][4];       // cone neighbours 1, 2 as cone-local indices; [3] = upper flag
-    FID visq[kQhMaxVis];        // visible facets in Qhull's breadth-first order
-    FID visnb[kQhMaxVis][4];          // (a stride of four: the entry/neighbour pair of a lane is a shift and a mask)
-    uint16_t visrep[kQhMaxVis];      // cone-local index of the visible facet's replacement (kQhNone: the first cone facet)
-    uint32_t visoff[kQhMaxVis];
-    uint16_t viscnt[kQhMaxVis];      // points of its outside set without the furthest
-    uint16_t visbest[kQhMaxVis];
-    uint32_t viscum[kQhMaxVis + 1];
-    FID nhz[kQhMaxNew];         // a cone facet's horizon neighbour (facet id)
-    FID hzq[kQhMaxHz];          // horizon facets tested in this insertion, and their records (p0 p1 p2 flags nb0 nb1 nb2)
-    FID hzr[kQhMaxHz][8];
-    uint32_t t_off[kQhMaxNew]; uint32_t t_total[kQhMaxNew]; uint32_t t_cnt[kQhMaxNew]; uint16_t t_bestp[kQhMaxNew]; double t_bestd[kQhMaxNew];
+// The tables of one insertion, TAB entries each (a frame whose insertion needs more is declined — or, from the packed kernel,
+// redone by the 64-entry one).
+template <typename FID, int TAB> struct QhLdsT {
+    double npl[TAB][4];        // the cone's planes (n0, n1, n2, offset)
+    double nxy[TAB][6];        // coordinates of a cone facet's two horizon vertices (convexity test between cone facets)
+    uint16_t nva[TAB], nvb[TAB];     // a cone facet's horizon vertices (point ids)
+    uint8_t nnb[TAB][4];       // cone neighbours 1, 2 as cone-local indices; [0] = top-oriented, [3] = upper flag
+    FID visq[TAB];             // visible facets in Qhull's breadth-first order
+    FID visnb[TAB][4];         // (a stride of four: the entry/neighbour pair of a lane is a shift and a mask)
+    uint16_t visrep[TAB];      // cone-local index of the visible facet's replacement (kQhNone: the first cone facet)
+    uint32_t visoff[TAB];
+    uint16_t viscnt[TAB];      // points of its outside set without the furthest
+    uint16_t visbest[TAB];
+    uint32_t viscum[TAB + 1];
+    FID nhz[TAB];              // a cone facet's horizon neighbour (facet id)
+    FID hzq[TAB];              // horizon facets tested in this insertion, and their records (p0 p1 p2 flags nb0 nb1 nb2)
+    FID hzr[TAB][8];
+    uint32_t t_off[TAB]; uint32_t t_total[TAB]; uint32_t t_cnt[TAB]; uint16_t t_bestp[TAB]; double t_bestd[TAB];
+};
+struct QhArrival { int tgt, p; double d; };      // (packed kernels: a chunk of arrivals staged over `nxy`, which placement no longer needs)
+
+// A frame's lanes: the whole wavefront (G = 64), or an aligned group of G = 32 / 16 lanes — then 64 / G frames share a wavefront
+// and every vector instruction serves all of them (one insertion is ~1 200 vector instructions whether it feeds one frame or
+// four).  The run is written for "the G lanes of a frame": ballots, shuffles and reductions stay inside the group; a loop whose
+// trip count differs between the groups of a wavefront diverges and reconverges like any SIMT loop; the lanes of a declined
+// frame drop out.  LDS instructions of a wavefront execute in order, so a group's writes are seen by its later reads.
+template <int G> struct Sg {
+    static_assert(G == 64 || G == 32 || G == 16, "lanes per frame");
+    static constexpr uint64_t kMask = ~0ull >> (64 - G);
+    static __device__ __forceinline__ int sl() { return lane_id() & (G - 1); }
+    static __device__ __forceinline__ int sub() { return lane_id() / G; }
+    static __device__ __forceinline__ int first() { return lane_id() & ~(G - 1); }
+    static __device__ __forceinline__ uint64_t ballot(bool p) {
+        const uint64_t b = __ballot(p);
+        if constexpr (G == 64) return b; else return (b >> first()) & kMask;
+    }
+    static __device__ __forceinline__ bool any(bool p) { if constexpr (G == 64) return __any(p); else return ballot(p) != 0ull; }
+    static __device__ __forceinline__ uint64_t below() { return (1ull << sl()) - 1ull; }
+    template <typename T> static __device__ __forceinline__ T shfl(T v, int i) {
+        if constexpr (G == 64) return __shfl(v, i); else return __shfl(v, first() + i);
+    }
+    static __device__ __forceinline__ int uni(int v) { if constexpr (G == 64) return __builtin_amdgcn_readfirstlane(v); else return v; }
+    // (i: uniform over the wavefront when G = 64)
+    static __device__ __forceinline__ double bcast_d(double v, int i) { if constexpr (G == 64) return readlane_d(v, i); else return __shfl(v, first() + i); }
+    static __device__ __forceinline__ double max_d(double v) {
+#pragma unroll
+        for (int o = G / 2; o >= 1; o >>= 1) { const double w = __shfl_xor(v, o); v = w > v ? w : v; }
+        return v;
+    }
+    static __device__ __forceinline__ double min_d(double v) {
+#pragma unroll
+        for (int o = G / 2; o >= 1; o >>= 1) { const double w = __shfl_xor(v, o); v = w < v ? w : v; }
+        return v;
+    }
 };
 
-__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 __device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
 __device__ __forceinline__ int ffs64(uint64_t m) { return __ffsll((long long)m) - 1; }
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { const double w = __shfl_xor(v, o); v = w > v ? w : v; }
-    return v;
-}
-__device__ __forceinline__ double wave_min_d(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { const double w = __shfl_xor(v, o); v = w < v ? w : v; }
-    return v;
-}
 
 // One wavefront per workgroup: LDS instructions of a wavefront execute in order, so a write by one lane is seen by a later read
 // of another lane without a barrier — only the COMPILER must keep the order.  (__syncthreads() also waits for every global
 // load and store in flight: in the insertion loop that was a memory round trip per call.)
 __device__ __forceinline__ void qh_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// ... and the same for global memory: the wavefront's earlier stores have landed before its later loads are issued
+__device__ __forceinline__ void qh_mem_sync() {
+    __threadfence_block();
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -224,7 +254,7 @@ struct QhConst { double distround, minvisible, minoutside, distoutside, guard, a
 struct QhWalk { int tgt; double d; int state; int best; };     // state 0 placed, 1 ended below its best, 2 no best, 3 bad (band / above none)
 
 // qh_findbestnew over the cone in LDS: list order from `start`, wrapping; the first facet 2 MINoutside above wins
-template <typename FID> __device__ __forceinline__ QhWalk qh_scan_cone(const QhLdsT<FID> &L, int m, int start, double x, double y, double z, const QhConst &K) {
+template <typename L_t> __device__ __forceinline__ QhWalk qh_scan_cone(const L_t &L, int m, int start, double x, double y, double z, const QhConst &K) {
     QhWalk R; R.state = 3; R.tgt = 0; R.d = 0.0; R.best = -1;
     double bestd = -kQhHuge;
     bool bad = false;
@@ -241,7 +271,7 @@ template <typename FID> __device__ __forceinline__ QhWalk qh_scan_cone(const QhL
 }
 
 // qh_findbest(isnewfacets): the directed walk; visited cone facets as a bit mask
-template <typename FID> __device__ __forceinline__ QhWalk qh_walk_cone(const QhLdsT<FID> &L, int start, double x, double y, double z, const QhConst &K) {
+template <typename L_t> __device__ __forceinline__ QhWalk qh_walk_cone(const L_t &L, int start, double x, double y, double z, const QhConst &K) {
     QhWalk R; R.state = 0; R.best = -1;
     bool bad = false;
     double d = qh_dist(x, y, z, L.npl[start][0], L.npl[start][1], L.npl[start][2], L.npl[start][3]);
@@ -272,35 +302,62 @@ template <typename FID> __device__ __forceinline__ QhWalk qh_walk_cone(const QhL
     return R;
 }
 
-// One chunk (<= 64 arrivals, lanes 0 .. count-1 in Qhull's processing order) appended to the targets' outside sets:
-// qh_partitionpoint's list rule.  A target's list is arena[t_off .. t_off + t_cnt) + [t_bestp]; the furthest point stays last, a
-// point that arrives further than it takes over and the old one enters the list in the arrival's place.  Lane j keeps target
-// j's state in registers and the arrivals are broadcast one by one (v_readlane): ~14 instructions per arrival.
-template <typename FID> __device__ __forceinline__ void qh_place_chunk(QhLdsT<FID> &L, uint16_t *arena, int count, int m, int tgt, int p, double d) {
-    const int lane = lane_id();
-    uint32_t base = 0, cnt = 0; int bestp = kQhNone; double bestd = -kQhHuge;
-    if (lane < m) { base = L.t_off[lane]; cnt = L.t_cnt[lane]; bestp = L.t_bestp[lane]; bestd = L.t_bestd[lane]; }
-    for (int i = 0; i < count; ++i) {
-        const int ti = __builtin_amdgcn_readlane(tgt, i);
-        const int pi = __builtin_amdgcn_readlane(p, i);
-        const double di = readlane_d(d, i);
-        if (lane == ti) {
-            if (bestp == kQhNone) { bestp = pi; bestd = di; }
-            else {
-                const bool further = di > bestd;
-                arena[base + cnt] = (uint16_t)(further ? bestp : pi);
-                ++cnt;
-                if (further) { bestp = pi; bestd = di; }
+// One chunk (<= G arrivals, lanes 0 .. count-1 of the frame's group in Qhull's processing order) appended to the targets' outside
+// sets: qh_partitionpoint's list rule.  A target's list is arena[t_off .. t_off + t_cnt) + [t_bestp]; the furthest point stays
+// last, a point that arrives further than it takes over and the old one enters the list in the arrival's place.  Lane j keeps
+// target j's state in registers and the arrivals are broadcast one by one (v_readlane; from LDS in the packed kernels):
+// ~14 instructions per arrival.
+template <int G, typename L_t> __device__ __forceinline__ void qh_place_chunk(L_t &L, uint16_t *arena, int count, int m, int tgt, int p, double d) {
+    const int sl = Sg<G>::sl();
+    if constexpr (G == 64) {
+        uint32_t base = 0, cnt = 0; int bestp = kQhNone; double bestd = -kQhHuge;
+        if (sl < m) { base = L.t_off[sl]; cnt = L.t_cnt[sl]; bestp = L.t_bestp[sl]; bestd = L.t_bestd[sl]; }
+        for (int i = 0; i < count; ++i) {
+            const int ti = __builtin_amdgcn_readlane(tgt, i);
+            const int pi = __builtin_amdgcn_readlane(p, i);
+            const double di = readlane_d(d, i);
+            if (sl == ti) {
+                if (bestp == kQhNone) { bestp = pi; bestd = di; }
+                else {
+                    const bool further = di > bestd;
+                    arena[base + cnt] = (uint16_t)(further ? bestp : pi);
+                    ++cnt;
+                    if (further) { bestp = pi; bestd = di; }
+                }
             }
         }
+        if (sl < m) { L.t_cnt[sl] = cnt; L.t_bestp[sl] = (uint16_t)bestp; L.t_bestd[sl] = bestd; }
+    } else {
+        QhArrival *A = reinterpret_cast<QhArrival *>(&L.nxy[0][0]);
+        { QhArrival a; a.tgt = tgt; a.p = p; a.d = d; A[sl] = a; }
+        qh_lds_sync();
+        for (int jb = 0; jb < m; jb += G) {
+            const int j = jb + sl;
+            uint32_t base = 0, cnt = 0; int bestp = kQhNone; double bestd = -kQhHuge;
+            if (j < m) { base = L.t_off[j]; cnt = L.t_cnt[j]; bestp = L.t_bestp[j]; bestd = L.t_bestd[j]; }
+            for (int i = 0; i < count; ++i) {
+                const QhArrival a = A[i];
+                if (j == a.tgt) {
+                    if (bestp == kQhNone) { bestp = a.p; bestd = a.d; }
+                    else {
+                        const bool further = a.d > bestd;
+                        arena[base + cnt] = (uint16_t)(further ? bestp : a.p);
+                        ++cnt;
+                        if (further) { bestp = a.p; bestd = a.d; }
+                    }
+                }
+            }
+            if (j < m) { L.t_cnt[j] = cnt; L.t_bestp[j] = (uint16_t)bestp; L.t_bestd[j] = bestd; }
+        }
+        qh_lds_sync();
     }
-    if (lane < m) { L.t_cnt[lane] = cnt; L.t_bestp[lane] = (uint16_t)bestp; L.t_bestd[lane] = bestd; }
 }
 
-// One frame, one wavefront.  Returns the reason the frame was declined (QH_OK: rows written, `nrows` of them).
-template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, QhLdsT<FID> &L, const int64_t f, const int64_t slot, int &nrows) {
+// One frame, G lanes.  Returns the reason the frame was declined (QH_OK: rows written, `nrows` of them).
+template <typename FID, int G, int TAB> __device__ __forceinline__ int qh_run(const QhArgs &a, QhLdsT<FID, TAB> &L, const int64_t f, const int64_t slot, int &nrows) {
     typedef QhFacetT<FID> QhFacet;
-    const int lane = lane_id();
+    typedef Sg<G> S_;
+    const int lane = S_::sl();
     const QhPlan P = qh_plan(a.cap_pts, sizeof(FID) == 4);
     char *ws = a.ws + (size_t)slot * a.ws_stride;
     double4 *PT = reinterpret_cast<double4 *>(ws + P.pts);
@@ -319,13 +376,13 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
     int perm0 = 1;                // the initial facet moved to the head of the list (qh_furthestnext)
 
     // ---- 0. the sites: kept points compacted, lifted; the point 'at infinity'; extremes ----
-    for (int base = 0; base < cnt; base += 64) {
+    for (int base = 0; base < cnt; base += G) {
         const int i = base + lane;
         bool k = i < cnt;
         if (k && a.keep) k = a.keep[off + i] >= 0;
-        const uint64_t m = __ballot(k);
+        const uint64_t m = S_::ballot(k);
         if (k) {
-            const int r = n + popc64(m & lanemask_lt());
+            const int r = n + popc64(m & S_::below());
             if (r < a.cap_pts - 1) {
                 const double x = a.u[off + i], y = a.v[off + i];
                 X[r] = x; Y[r] = y; Z[r] = x * x + y * y;
@@ -333,23 +390,23 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
         }
         n += popc64(m);
     }
-    n = uni(n);
+    n = S_::uni(n);
     if (a.n_used) { if (lane == 0) a.n_used[f] = n; }
     if (n < 3 || n > a.cap_pts - 1 || n > (sizeof(FID) == 4 ? kQhMaxPointsWide : kQhMaxPoints)) return QH_FEW_POINTS;
-    __threadfence_block();
+    qh_mem_sync();
     {
         // sums in input order (the point at infinity sits over the mean), the largest lifted height
         double sx = 0.0, sy = 0.0, mz = -kQhHuge;
-        for (int base = 0; base < n; base += 64) {
+        for (int base = 0; base < n; base += G) {
             const int i = base + lane;
             const double x = i < n ? X[i] : 0.0, y = i < n ? Y[i] : 0.0, z = i < n ? Z[i] : -kQhHuge;
-            const int c = min(64, n - base);
-            for (int j = 0; j < c; ++j) { sx += readlane_d(x, j); sy += readlane_d(y, j); }
-            mz = fmax(mz, wave_max_d(z));
+            const int c = min(G, n - base);
+            for (int j = 0; j < c; ++j) { sx += S_::bcast_d(x, j); sy += S_::bcast_d(y, j); }
+            mz = fmax(mz, S_::max_d(z));
         }
         if (lane == 0) { X[n] = sx / (double)n; Y[n] = sy / (double)n; Z[n] = mz * 1.1; }
     }
-    __threadfence_block();
+    qh_mem_sync();
     int ext[6];
     double maxabs = 0.0, maxwidth = 0.0, maxsum = 0.0, zlow = 0.0, zhigh = 0.0, nz0 = 0.0, nz1 = 0.0, nz2 = 0.0;
     {
@@ -357,12 +414,12 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
         for (int k = 0; k < 3; ++k) {
             const QhCoord C{PT, k};
             double hi = -kQhHuge, lo = kQhHuge; int hii = 0, loi = 0;
-            for (int base = 0; base < m1; base += 64) {
+            for (int base = 0; base < m1; base += G) {
                 const int i = base + lane;
                 const double c = i < m1 ? C[i] : 0.0;
-                const double cm = wave_max_d(i < m1 ? c : -kQhHuge), cn = wave_min_d(i < m1 ? c : kQhHuge);
-                if (cm > hi) { hi = cm; hii = base + ffs64(__ballot(i < m1 && c == cm)); }
-                if (cn < lo) { lo = cn; loi = base + ffs64(__ballot(i < m1 && c == cn)); }
+                const double cm = S_::max_d(i < m1 ? c : -kQhHuge), cn = S_::min_d(i < m1 ? c : kQhHuge);
+                if (cm > hi) { hi = cm; hii = base + ffs64(S_::ballot(i < m1 && c == cm)); }
+                if (cn < lo) { lo = cn; loi = base + ffs64(S_::ballot(i < m1 && c == cn)); }
             }
             double maxcoord;
             if (k == 2) { zlow = lo; zhigh = hi; maxcoord = maxabs; }
@@ -380,7 +437,7 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
         // 'Qbb': the lifted coordinate scaled to [0, maxabs]
         const double scale = maxabs / (zhigh - zlow);
         const double shift = 0.0 - zlow * scale;
-        for (int i = lane; i <= n; i += 64) Z[i] = Z[i] * scale + shift;
+        for (int i = lane; i <= n; i += G) Z[i] = Z[i] * scale + shift;
         const double maxdistsum = fmin(__builtin_sqrt(3.0) * maxabs, maxsum);
         K.distround = kQhEps * (3 * maxdistsum * 1.01 + maxabs);
         K.anground = 1.01 * 3 * kQhEps;
@@ -390,7 +447,7 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
         K.guard = 64 * K.distround;
         K.nz0 = nz0; K.nz1 = nz1;
     }
-    __threadfence_block();
+    qh_mem_sync();
 
     // ---- 1. the initial simplex (qh_maxsimplex over the six extreme points) and its four facets ----
     int simplex[4];
@@ -457,19 +514,19 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
             gauss = F.gauss;
             L.npl[lane][0] = F.n0; L.npl[lane][1] = F.n1; L.npl[lane][2] = F.n2; L.npl[lane][3] = F.d;
             L.nnb[lane][3] = F.upper ? 1 : 0;
-            QhFacet G;
-            G.p[0] = (uint16_t)q[0]; G.p[1] = (uint16_t)q[1]; G.p[2] = (uint16_t)q[2];
-            G.flags = (uint16_t)((top ? 1 : 0) | (F.upper ? 2 : 0));
+            QhFacet Gf;
+            Gf.p[0] = (uint16_t)q[0]; Gf.p[1] = (uint16_t)q[1]; Gf.p[2] = (uint16_t)q[2];
+            Gf.flags = (uint16_t)((top ? 1 : 0) | (F.upper ? 2 : 0));
             k = 0;
-            for (int j = 0; j < 4; ++j) if (j != lane) G.nb[k++] = (FID)(j + 1);
-            G.bestp = kQhNone; G.off = 0; G.cnt = 0; G.mark = 0; G.bestd = 0.0;
-            G.n0 = F.n0; G.n1 = F.n1; G.n2 = F.n2; G.d = F.d;
-            fac[lane + 1] = G;
+            for (int j = 0; j < 4; ++j) if (j != lane) Gf.nb[k++] = (FID)(j + 1);
+            Gf.bestp = kQhNone; Gf.off = 0; Gf.cnt = 0; Gf.mark = 0; Gf.bestd = 0.0;
+            Gf.n0 = F.n0; Gf.n1 = F.n1; Gf.n2 = F.n2; Gf.d = F.d;
+            fac[lane + 1] = Gf;
             L.t_total[lane] = 0;
         }
-        if (__any(gauss)) return QH_GAUSS;
+        if (S_::any(gauss)) return QH_GAUSS;
         nfac = 4;
-        __syncthreads();
+        qh_mem_sync();
         // narrow initial simplex: Qhull switches to another furthest-point rule
         if (lane < 4) {
             double mina = 2.0;
@@ -477,9 +534,9 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
                 mina = fmin(mina, L.npl[lane][0] * L.npl[j][0] + L.npl[lane][1] * L.npl[j][1] + L.npl[lane][2] * L.npl[j][2]);
             gauss = mina < -0.99999999;
         }
-        if (__any(gauss)) return QH_NARROW;
+        if (S_::any(gauss)) return QH_NARROW;
     }
-    __threadfence_block();
+    qh_mem_sync();
 
     // ---- 2. qh_partitionall: every other point to the first initial facet it is 2 MINoutside above ----
     {
@@ -493,9 +550,9 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
                     L.t_off[lane] = o; L.t_cnt[lane] = 0; L.t_bestp[lane] = kQhNone; L.t_bestd[lane] = -kQhHuge;
                 }
                 atop = L.t_total[0] + L.t_total[1] + L.t_total[2] + L.t_total[3];
-                __syncthreads();
+                qh_mem_sync();
             }
-            for (int base = 0; base < total; base += 64) {
+            for (int base = 0; base < total; base += G) {
                 const int p = base + lane;
                 bool valid = p < total && p != simplex[0] && p != simplex[1] && p != simplex[2] && p != simplex[3];
                 int tgt = 0; double d = 0.0;
@@ -514,12 +571,11 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
                         atomicAdd(&L.t_total[tgt], 1u);
                     } else { tgt = TT[p]; d = DD[p]; }
                 }
-                if (pass == 1) qh_place_chunk(L, arena, min(64, total - base), 4, valid ? tgt : -1, p, d);
+                if (pass == 1) qh_place_chunk<G>(L, arena, min(G, total - base), 4, valid ? tgt : -1, p, d);
             }
-            __syncthreads();
-            __threadfence_block();
-            if (__any(inside)) return QH_INSIDE_SIMPLEX;
-            if (__any(bad)) return QH_BAND;
+            qh_mem_sync();
+            if (S_::any(inside)) return QH_INSIDE_SIMPLEX;
+            if (S_::any(bad)) return QH_BAND;
         }
         if (lane < 4) {
             fac[lane + 1].off = L.t_off[lane]; fac[lane + 1].cnt = (uint16_t)L.t_cnt[lane];
@@ -528,8 +584,7 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
         // qh_furthestnext: the facet with the furthest point of all goes to the head of the list
         double bd = -kQhHuge; perm0 = 0;
         for (int j = 0; j < 4; ++j) if (L.t_bestp[j] != kQhNone && L.t_bestd[j] > bd) { bd = L.t_bestd[j]; perm0 = j + 1; }
-        __syncthreads();
-        __threadfence_block();
+        qh_mem_sync();
     }
 
     // ---- 3. the insertions ----
@@ -551,21 +606,21 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
                 // 16 records — 512 bytes — instead of 64)
                 const int id = (lane < kQhPickWindow && pos + lane < nfac) ? pos2id(pos + lane) : 0;
                 uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
-                if (id) { const uint4 *G = reinterpret_cast<const uint4 *>(&fac[id]); r0 = G[0]; r1 = G[1]; }
+                if (id) { const uint4 *Gp = reinterpret_cast<const uint4 *>(&fac[id]); r0 = Gp[0]; r1 = Gp[1]; }
                 const QhHead<FID> h = qh_head(static_cast<const QhFacet *>(nullptr), r0, r1);
                 const bool has = id && !(h.flags & 4u) && h.bestp != kQhNone;
-                const uint64_t hm = __ballot(has);
+                const uint64_t hm = S_::ballot(has);
                 if (hm) {
                     const int l = ffs64(hm);
                     pos += l; cur = pos2id(pos);
-                    H.bestp = __shfl(h.bestp, l); H.nb0 = __shfl(h.nb0, l); H.nb1 = __shfl(h.nb1, l); H.nb2 = __shfl(h.nb2, l);
-                    H.off = __shfl(h.off, l); H.cnt = __shfl(h.cnt, l);
+                    H.bestp = S_::shfl(h.bestp, l); H.nb0 = S_::shfl(h.nb0, l); H.nb1 = S_::shfl(h.nb1, l); H.nb2 = S_::shfl(h.nb2, l);
+                    H.off = S_::shfl(h.off, l); H.cnt = S_::shfl(h.cnt, l);
                     break;
                 }
                 pos += kQhPickWindow;
             }
             if (cur < 0) break;
-            cur = uni(cur);
+            cur = S_::uni(cur);
             ++step;
             const int p = (int)H.bestp;
             if (a.order_out) { if (lane == 0 && p < n) a.order_out[off + p] = step; }     // (compacted ids when `keep` is given)
@@ -581,61 +636,61 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
             const double px = X[p], py = Y[p], pz = Z[p];        // (in flight together with the first round's facet records)
             bool bad = false, copl = false;
             while (head < nvis) {
-                const int ne = min(nvis - head, 16);               // four lanes per visible facet: neighbours 0..2 (the fourth lane idles)
+                const int ne = min(nvis - head, G / 4);            // four lanes per visible facet: neighbours 0..2 (the fourth lane idles)
                 const int e = head + (lane >> 2), k = lane & 3;
                 const bool act = (lane >> 2) < ne && k < 3;
                 int g = 0;
-                QhFacet G;
+                QhFacet Gf;
                 bool cand = false;
                 if (act) {
                     g = L.visnb[e][k];
                     cand = true;
                     for (int i = 0; i < nvis; ++i) if (L.visq[i] == g) cand = false;
                     for (int i = 0; i < nhz; ++i) if (L.hzq[i] == g) cand = false;
-                    if (cand) G = fac[g];
+                    if (cand) Gf = fac[g];
                 }
                 // the same facet reached twice in this round: the earlier (entry, neighbour) pair tests it
-                const uint64_t cm = __ballot(cand);
+                const uint64_t cm = S_::ballot(cand);
                 bool dup = false;
                 for (uint64_t r = cm; r; r &= r - 1) {
                     const int j = ffs64(r);
-                    const int gj = __shfl(g, j);
+                    const int gj = S_::shfl(g, j);
                     if (cand && lane > j && gj == g) dup = true;
                 }
                 bool vis = false, hzn = false;
                 if (cand && !dup) {
-                    const double d = qh_dist(px, py, pz, G.n0, G.n1, G.n2, G.d);
+                    const double d = qh_dist(px, py, pz, Gf.n0, Gf.n1, Gf.n2, Gf.d);
                     if (d > K.minvisible) { vis = true; if (d < K.guard) bad = true; }
                     else { hzn = true; if (d >= -K.guard) copl = true; }
                 }
-                const uint64_t vm = __ballot(vis), zm = __ballot(hzn);
+                const uint64_t vm = S_::ballot(vis), zm = S_::ballot(hzn);
                 const int add = popc64(vm), addz = popc64(zm);
-                if (nvis + add > kQhMaxVis || nhz + addz > kQhMaxHz) { why = QH_TOO_MANY_VISIBLE; break; }
+                if (nvis + add > TAB || nhz + addz > TAB) { why = QH_TOO_MANY_VISIBLE; break; }
                 if (vis) {
-                    const int q = nvis + popc64(vm & lanemask_lt());
-                    L.visq[q] = (FID)g; L.visnb[q][0] = G.nb[0]; L.visnb[q][1] = G.nb[1]; L.visnb[q][2] = G.nb[2];
-                    L.visoff[q] = G.off; L.viscnt[q] = G.cnt; L.visbest[q] = G.bestp;
+                    const int q = nvis + popc64(vm & S_::below());
+                    L.visq[q] = (FID)g; L.visnb[q][0] = Gf.nb[0]; L.visnb[q][1] = Gf.nb[1]; L.visnb[q][2] = Gf.nb[2];
+                    L.visoff[q] = Gf.off; L.viscnt[q] = Gf.cnt; L.visbest[q] = Gf.bestp;
                 }
                 if (hzn) {
-                    const int q = nhz + popc64(zm & lanemask_lt());
+                    const int q = nhz + popc64(zm & S_::below());
                     L.hzq[q] = (FID)g;
-                    L.hzr[q][0] = G.p[0]; L.hzr[q][1] = G.p[1]; L.hzr[q][2] = G.p[2]; L.hzr[q][3] = G.flags;
-                    L.hzr[q][4] = G.nb[0]; L.hzr[q][5] = G.nb[1]; L.hzr[q][6] = G.nb[2];
+                    L.hzr[q][0] = Gf.p[0]; L.hzr[q][1] = Gf.p[1]; L.hzr[q][2] = Gf.p[2]; L.hzr[q][3] = Gf.flags;
+                    L.hzr[q][4] = Gf.nb[0]; L.hzr[q][5] = Gf.nb[1]; L.hzr[q][6] = Gf.nb[2];
                 }
                 head += ne; nvis += add; nhz += addz;
                 qh_lds_sync();
             }
             if (why) return why;
-            if (__any(copl)) return QH_COPLANAR_HORIZON;
-            if (__any(bad)) return QH_BAND;
+            if (S_::any(copl)) return QH_COPLANAR_HORIZON;
+            if (S_::any(bad)) return QH_BAND;
             QH_STAMP(1);
             // (c) qh_makenewfacets: for each visible facet in order, for each horizon neighbour in order, a facet (apex first)
             int m = 0;
-            for (int e = lane; e < nvis; e += 64) L.visrep[e] = kQhNone;
+            for (int e = lane; e < nvis; e += G) L.visrep[e] = kQhNone;
             qh_lds_sync();
             bool gauss = false, notconv = false;
-            for (int base = 0; base < nvis; base += 16) {
-                const int ne = min(nvis - base, 16);
+            for (int base = 0; base < nvis; base += G / 4) {
+                const int ne = min(nvis - base, G / 4);
                 const int e = base + (lane >> 2), k = lane & 3;
                 const bool act = (lane >> 2) < ne && k < 3;
                 int g = 0, hi = -1;
@@ -644,10 +699,10 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
                     for (int i = 0; i < nhz; ++i) if (L.hzq[i] == g) hi = i;
                 }
                 const bool hz = hi >= 0;
-                const uint64_t hm = __ballot(hz);
-                const int j = m + popc64(hm & lanemask_lt());
+                const uint64_t hm = S_::ballot(hz);
+                const int j = m + popc64(hm & S_::below());
                 const int add = popc64(hm);
-                if (m + add > kQhMaxNew) { why = QH_CONE_TOO_LARGE; break; }
+                if (m + add > TAB) { why = QH_CONE_TOO_LARGE; break; }
                 if (nfac + m + add > (int)P.fcap) { why = QH_FACETS_FULL; break; }
                 if (hz) {
                     const int vid = L.visq[e];
@@ -677,44 +732,42 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
             }
             if (why) return why;
             qh_lds_sync();
-            if (__any(gauss)) return QH_GAUSS;
-            if (__any(notconv)) return QH_NOT_CONVEX;
+            if (S_::any(gauss)) return QH_GAUSS;
+            if (S_::any(notconv)) return QH_NOT_CONVEX;
             if (m < 3) return QH_OPEN_CONE;
             QH_STAMP(2);
-            // (d) qh_matchnewfacets: neighbour 1 shares the ridge {apex, b}, neighbour 2 the ridge {apex, a}
-            {
-                bool open = false; notconv = false;
-                int n1 = -1, n2 = -1;
-                if (lane < m) {
-                    const int va = L.nva[lane], vb = L.nvb[lane];
-                    int c1 = 0, c2 = 0;
-                    for (int i = 0; i < m; ++i) if (i != lane) {
-                        const int ia = L.nva[i], ib = L.nvb[i];
-                        if (ia == vb || ib == vb) { n1 = i; ++c1; }
-                        if (ia == va || ib == va) { n2 = i; ++c2; }
-                    }
-                    open = c1 != 1 || c2 != 1;
-                    if (!open) {
-                        // convexity between cone facets: the neighbour's other horizon vertex lies below this facet
-                        const int o1 = L.nva[n1] == vb ? 3 : 0, o2 = L.nva[n2] == va ? 3 : 0;
-                        const double d1 = qh_dist(L.nxy[n1][o1], L.nxy[n1][o1 + 1], L.nxy[n1][o1 + 2], L.npl[lane][0], L.npl[lane][1], L.npl[lane][2], L.npl[lane][3]);
-                        const double d2 = qh_dist(L.nxy[n2][o2], L.nxy[n2][o2 + 1], L.nxy[n2][o2 + 2], L.npl[lane][0], L.npl[lane][1], L.npl[lane][2], L.npl[lane][3]);
-                        notconv = d1 > -K.guard || d2 > -K.guard;
-                    }
-                }
-                if (__any(open)) return QH_OPEN_CONE;
-                if (__any(notconv)) return QH_NOT_CONVEX;
-                qh_lds_sync();
-                if (lane < m) { L.nnb[lane][1] = (uint8_t)n1; L.nnb[lane][2] = (uint8_t)n2; }
-                qh_lds_sync();
-            }
-            // qh_sharpnewfacets: the cone's normals in more than one orthant
+            // (d) qh_matchnewfacets: neighbour 1 shares the ridge {apex, b}, neighbour 2 the ridge {apex, a};
+            //     qh_sharpnewfacets: the cone's normals in more than one orthant
             bool sharp;
             {
+                bool open = false, diff = false; notconv = false;
                 const int q0 = (L.npl[0][0] > 0 ? 1 : 0) | (L.npl[0][1] > 0 ? 2 : 0) | (L.npl[0][2] > 0 ? 4 : 0);
-                bool diff = false;
-                if (lane < m) diff = ((L.npl[lane][0] > 0 ? 1 : 0) | (L.npl[lane][1] > 0 ? 2 : 0) | (L.npl[lane][2] > 0 ? 4 : 0)) != q0;
-                sharp = __any(diff);
+                for (int jb = 0; jb < m; jb += G) {
+                    const int j = jb + lane;
+                    if (j < m) {
+                        const int va = L.nva[j], vb = L.nvb[j];
+                        int n1 = -1, n2 = -1, c1 = 0, c2 = 0;
+                        for (int i = 0; i < m; ++i) if (i != j) {
+                            const int ia = L.nva[i], ib = L.nvb[i];
+                            if (ia == vb || ib == vb) { n1 = i; ++c1; }
+                            if (ia == va || ib == va) { n2 = i; ++c2; }
+                        }
+                        if (c1 != 1 || c2 != 1) open = true;
+                        else {
+                            // convexity between cone facets: the neighbour's other horizon vertex lies below this facet
+                            const int o1 = L.nva[n1] == vb ? 3 : 0, o2 = L.nva[n2] == va ? 3 : 0;
+                            const double d1 = qh_dist(L.nxy[n1][o1], L.nxy[n1][o1 + 1], L.nxy[n1][o1 + 2], L.npl[j][0], L.npl[j][1], L.npl[j][2], L.npl[j][3]);
+                            const double d2 = qh_dist(L.nxy[n2][o2], L.nxy[n2][o2 + 1], L.nxy[n2][o2 + 2], L.npl[j][0], L.npl[j][1], L.npl[j][2], L.npl[j][3]);
+                            if (d1 > -K.guard || d2 > -K.guard) notconv = true;
+                            L.nnb[j][1] = (uint8_t)n1; L.nnb[j][2] = (uint8_t)n2;
+                        }
+                        if (((L.npl[j][0] > 0 ? 1 : 0) | (L.npl[j][1] > 0 ? 2 : 0) | (L.npl[j][2] > 0 ? 4 : 0)) != q0) diff = true;
+                    }
+                }
+                if (S_::any(open)) return QH_OPEN_CONE;
+                if (S_::any(notconv)) return QH_NOT_CONVEX;
+                sharp = S_::any(diff);
+                qh_lds_sync();
             }
             QH_STAMP(3);
             // (e) qh_partitionvisible: the visible facets' points, in list order, to the cone
@@ -734,7 +787,7 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
                 // a linear scan (qh.findbestnew stays set for the rest of this insertion)
                 bool mode = false, fail_band = false, fail_sharp = false, fail_none = false;
                 int q0 = 0, tgt0 = 0; double d0 = 0.0;
-                for (int base = 0; base < S; base += 64) {
+                for (int base = 0; base < S; base += G) {
                     const int i = base + lane;
                     const bool valid = i < S;
                     int q = 0, start = 0;
@@ -751,7 +804,7 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
                     if (valid) R = mode ? qh_scan_cone(L, m, start, x, y, z, K) : qh_walk_cone(L, start, x, y, z, K);
                     if (!mode) {
                         if (valid && R.state == 2) R = qh_scan_cone(L, m, 0, x, y, z, K);       // no best: all cone facets from the first
-                        const uint64_t trig = __ballot(valid && R.state == 1);
+                        const uint64_t trig = S_::ballot(valid && R.state == 1);
                         if (trig) {
                             if (!sharp) fail_sharp = true;
                             const int t = ffs64(trig);
@@ -762,26 +815,29 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
                     if (valid && R.state != 0) { if (R.state == 3) fail_band = true; else fail_none = true; }
                     if (valid) {
                         atomicAdd(&L.t_total[R.tgt], 1u);
-                        if (S > 64) { TT[i] = (uint16_t)R.tgt; DD[i] = R.d; }
+                        if (S > G) { TT[i] = (uint16_t)R.tgt; DD[i] = R.d; }
                     }
                     if (base == 0) { q0 = q; tgt0 = R.tgt; d0 = R.d; }
                 }
-                if (__any(fail_band)) return QH_BAND;
+                if (S_::any(fail_band)) return QH_BAND;
                 if (fail_sharp) return QH_NOT_SHARP;
-                if (__any(fail_none)) return QH_ABOVE_NONE;
+                if (S_::any(fail_none)) return QH_ABOVE_NONE;
                 qh_lds_sync();
-                if (S > 64) __threadfence_block();
+                if (S > G) __threadfence_block();
                 QH_STAMP(4);
                 // room for the cone's outside sets, then the placement in arrival order
-                if (lane < m) {
-                    uint32_t o = atop;
-                    for (int j = 0; j < lane; ++j) o += L.t_total[j];
-                    L.t_off[lane] = o; L.t_cnt[lane] = 0; L.t_bestp[lane] = kQhNone; L.t_bestd[lane] = -kQhHuge;
+                for (int jb = 0; jb < m; jb += G) {
+                    const int j = jb + lane;
+                    if (j < m) {
+                        uint32_t o = atop;
+                        for (int i = 0; i < j; ++i) o += L.t_total[i];
+                        L.t_off[j] = o; L.t_cnt[j] = 0; L.t_bestp[j] = kQhNone; L.t_bestd[j] = -kQhHuge;
+                    }
                 }
                 atop += (uint32_t)S;
                 qh_lds_sync();
-                if (S > 0 && S <= 64) qh_place_chunk(L, arena, S, m, tgt0, q0, d0);
-                else for (int base = 0; base < S; base += 64) {
+                if (S > 0 && S <= G) qh_place_chunk<G>(L, arena, S, m, tgt0, q0, d0);
+                else for (int base = 0; base < S; base += G) {
                     const int i = base + lane;
                     const bool valid = i < S;
                     int q = 0, tgt = 0; double d = 0.0;
@@ -792,27 +848,29 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
                         q = r < (int)L.viscnt[e] ? arena[L.visoff[e] + r] : L.visbest[e];
                         tgt = TT[i]; d = DD[i];
                     }
-                    qh_place_chunk(L, arena, min(64, S - base), m, tgt, q, d);
+                    qh_place_chunk<G>(L, arena, min(G, S - base), m, tgt, q, d);
                     qh_lds_sync();
                 }
                 qh_lds_sync();
             }
             QH_STAMP(5);
             // (f) the cone's facet records; the visible facets die
-            if (lane < m) {
-                QhFacet G;
-                G.p[0] = (uint16_t)p; G.p[1] = L.nva[lane]; G.p[2] = L.nvb[lane];
-                G.flags = (uint16_t)((L.nnb[lane][0] ? 1 : 0) | (L.nnb[lane][3] ? 2 : 0));
-                G.nb[0] = L.nhz[lane];
-                G.nb[1] = (FID)(nfac + 1 + L.nnb[lane][1]); G.nb[2] = (FID)(nfac + 1 + L.nnb[lane][2]);
-                G.bestp = L.t_bestp[lane]; G.off = L.t_off[lane]; G.cnt = (uint16_t)L.t_cnt[lane]; G.mark = 0; G.bestd = L.t_bestd[lane];
-                G.n0 = L.npl[lane][0]; G.n1 = L.npl[lane][1]; G.n2 = L.npl[lane][2]; G.d = L.npl[lane][3];
-                fac[nfac + 1 + lane] = G;
+            for (int jb = 0; jb < m; jb += G) {
+                const int j = jb + lane;
+                if (j < m) {
+                    QhFacet Gf;
+                    Gf.p[0] = (uint16_t)p; Gf.p[1] = L.nva[j]; Gf.p[2] = L.nvb[j];
+                    Gf.flags = (uint16_t)((L.nnb[j][0] ? 1 : 0) | (L.nnb[j][3] ? 2 : 0));
+                    Gf.nb[0] = L.nhz[j];
+                    Gf.nb[1] = (FID)(nfac + 1 + L.nnb[j][1]); Gf.nb[2] = (FID)(nfac + 1 + L.nnb[j][2]);
+                    Gf.bestp = L.t_bestp[j]; Gf.off = L.t_off[j]; Gf.cnt = (uint16_t)L.t_cnt[j]; Gf.mark = 0; Gf.bestd = L.t_bestd[j];
+                    Gf.n0 = L.npl[j][0]; Gf.n1 = L.npl[j][1]; Gf.n2 = L.npl[j][2]; Gf.d = L.npl[j][3];
+                    fac[nfac + 1 + j] = Gf;
+                }
             }
-            for (int e = lane; e < nvis; e += 64) fac[L.visq[e]].flags |= 4;
+            for (int e = lane; e < nvis; e += G) fac[L.visq[e]].flags |= 4;
             nfac += m;
-            qh_lds_sync();
-            __threadfence_block();
+            qh_mem_sync();
             QH_STAMP(6);
         }
 #ifdef MVOSR_QH_STAMPS
@@ -820,15 +878,15 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
 #endif
         // ---- 4. SciPy's rows: lower facets in list order; vertices by decreasing vertex id, first two swapped unless top ----
         const int64_t toff = a.tri_off[f];
-        for (int base = 0; base < nfac; base += 64) {
+        for (int base = 0; base < nfac; base += G) {
             const int id = base + lane < nfac ? pos2id(base + lane) : 0;
-            bool row = false; QhFacet G;
-            if (id) { G = fac[id]; row = !(G.flags & 4) && !(G.flags & 2); }
-            const uint64_t rm = __ballot(row);
+            bool row = false; QhFacet Gf;
+            if (id) { Gf = fac[id]; row = !(Gf.flags & 4) && !(Gf.flags & 2); }
+            const uint64_t rm = S_::ballot(row);
             if (row) {
-                int32_t *t = a.tri + 3 * (toff + nrows + popc64(rm & lanemask_lt()));
-                const bool top = G.flags & 1;
-                t[0] = top ? G.p[0] : G.p[1]; t[1] = top ? G.p[1] : G.p[0]; t[2] = G.p[2];
+                int32_t *t = a.tri + 3 * (toff + nrows + popc64(rm & S_::below()));
+                const bool top = Gf.flags & 1;
+                t[0] = top ? Gf.p[0] : Gf.p[1]; t[1] = top ? Gf.p[1] : Gf.p[0]; t[2] = Gf.p[2];
             }
             nrows += popc64(rm);
         }
@@ -836,12 +894,16 @@ template <typename FID> __device__ __forceinline__ int qh_run(const QhArgs &a, Q
     return why;
 }
 
-// 119 registers and 9.7 KB of LDS: four wavefronts per SIMD.  (Compiled for five, six and eight — 96 / 80 / 64 registers with
-// spills, the LDS tables halved — the same launch of 4096 frames took 41 / 50 / 66 ms instead of 34: LABNOTES §9.)
-template <typename FID, bool LIST>
-__global__ __launch_bounds__(64, 4) void qhull_rows_kernel(const QhArgs a) {
-    __shared__ QhLdsT<FID> L;
+// G = 64 (one frame per wavefront): 119 registers and 9.7 KB of LDS, four wavefronts per SIMD.  (Compiled for five, six and eight
+// — 96 / 80 / 64 registers with spills, the LDS tables halved — the same launch of 4096 frames took 41 / 50 / 66 ms instead of
+// 34: LABNOTES §9.)  G = 32 / 16 (two / four frames per wavefront, 32-entry tables): a frame whose insertion overflows a table goes
+// to the `redo` list, which the G = 64 list kernel walks next.
+template <typename FID, int G, int TAB, bool LIST>
+__global__ __launch_bounds__(64, (G == 16 ? 2 : 4)) void qhull_rows_kernel(const QhArgs a) {
+    __shared__ QhLdsT<FID, TAB> Ls[64 / G];
+    QhLdsT<FID, TAB> &L = Ls[Sg<G>::sub()];
     if constexpr (LIST) {
+        static_assert(G == 64, "the list walk is one frame per wavefront");
         // the frames of a list whose length is known on the device only: a persistent grid, one workspace slice per workgroup
         const int64_t todo = (int64_t)a.list[0];
         for (int64_t it = blockIdx.x; it < todo; it += gridDim.x) {
@@ -849,22 +911,47 @@ __global__ __launch_bounds__(64, 4) void qhull_rows_kernel(const QhArgs a) {
             if (f < 0 || f >= a.n_frames) continue;
             int nrows = 0;
             __syncthreads();
-            const int why = qh_run<FID>(a, L, f, (int64_t)blockIdx.x, nrows);
+            const int why = qh_run<FID, G, TAB>(a, L, f, (int64_t)blockIdx.x, nrows);
             if (lane_id() == 0) {
                 if (why) { a.tri_cnt[f] = 0; a.status[f] = MVOSR_DT_DEGENERATE | (why << 8); }
-                else a.tri_cnt[f] = nrows;           // (status stays what the stand-in triangulation left: 0)
+                else a.tri_cnt[f] = nrows;           // (status stays what the first attempt left: 0)
             }
             __threadfence_block();
         }
         return;
+    } else {
+        const int64_t f = (int64_t)blockIdx.x * (64 / G) + Sg<G>::sub();
+        if (f >= a.n_frames) return;
+        int nrows = 0;
+        const int why = qh_run<FID, G, TAB>(a, L, f, f, nrows);
+        if (Sg<G>::sl() == 0) {
+            if (G < 64 && a.redo && (why == QH_TOO_MANY_VISIBLE || why == QH_CONE_TOO_LARGE)) {
+                const int k = atomicAdd(&a.redo[0], 1);
+                a.redo[1 + k] = (int32_t)f;
+                a.tri_cnt[f] = 0; a.status[f] = MVOSR_DT_OK;
+            } else {
+                a.tri_cnt[f] = why ? 0 : nrows;
+                a.status[f] = why ? (MVOSR_DT_DEGENERATE | (why << 8)) : MVOSR_DT_OK;
+            }
+        }
     }
-    const int64_t f = blockIdx.x;
-    int nrows = 0;
-    const int why = qh_run<FID>(a, L, f, f, nrows);
-    if (lane_id() == 0) {
-        a.tri_cnt[f] = why ? 0 : nrows;
-        a.status[f] = why ? (MVOSR_DT_DEGENERATE | (why << 8)) : MVOSR_DT_OK;
-    }
+}
+
+// Lanes per frame of the product launch: 64.  The packed instantiations (two / four frames per wavefront) are measured A/B
+// variants of builds with -DMVOSR_ABLATE (env MVOSR_QH_GROUP = 32 | 16): rows identical, but a packed wavefront's insertion is
+// the LONGEST of its frames' steps (52.7 k clocks for four frames against 27.5 k for one, alone on a SIMD) and 20 KB of LDS
+// leave two wavefronts per SIMD: 113 k sets/s (G = 16), 103 k (G = 32) against 129 k (LABNOTES §9.8).
+int qh_group() {
+#ifdef MVOSR_ABLATE
+    static const int g = [] {
+        const char *e = getenv("MVOSR_QH_GROUP");
+        const int v = e ? atoi(e) : 0;
+        return v == 32 || v == 16 ? v : 64;
+    }();
+    return g;
+#else
+    return 64;
+#endif
 }
 
 }  // namespace
@@ -890,7 +977,7 @@ static int qh_launch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, c
     const bool wide = max_pts > kQhMaxPoints;
     QhArgs a;
     a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
-    a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.order_out = order_out; a.list = list;
+    a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.order_out = order_out; a.list = list; a.redo = nullptr;
     a.cap_pts = max_pts + 1;
 #ifdef MVOSR_QH_STAMPS
     a.stamps = g_qh_stamps;
@@ -900,15 +987,34 @@ static int qh_launch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, c
     const QhPlan P = qh_plan(a.cap_pts, wide);
     a.ws_stride = P.total;
     const int64_t slices = list ? (int64_t)(list_blocks < n_frames ? list_blocks : n_frames) : n_frames;
+    const int group = (list || wide) ? 64 : qh_group();
+    const size_t redo_bytes = group < 64 ? (((size_t)n_frames + 1) * sizeof(int32_t) + 255) & ~(size_t)255 : 0;
     void *ws = nullptr;
-    if ((rc = ctx_workspace_bytes(ctx, (size_t)slices * P.total, &ws))) return rc;
+    if ((rc = ctx_workspace_bytes(ctx, (size_t)slices * P.total + redo_bytes, &ws))) return rc;
     a.ws = reinterpret_cast<char *>(ws);
+    hipStream_t st = ctx_stream(ctx);
     // (the list walk is an instantiation of its own: the loop around the run cost the product kernel registers — spills in its hot loop)
     if (list) {
-        if (wide) hipLaunchKernelGGL((qhull_rows_kernel<uint32_t, true>), dim3((unsigned)slices), dim3(64), 0, ctx_stream(ctx), a);
-        else hipLaunchKernelGGL((qhull_rows_kernel<uint16_t, true>), dim3((unsigned)slices), dim3(64), 0, ctx_stream(ctx), a);
-    } else if (wide) hipLaunchKernelGGL((qhull_rows_kernel<uint32_t, false>), dim3((unsigned)slices), dim3(64), 0, ctx_stream(ctx), a);
-    else hipLaunchKernelGGL((qhull_rows_kernel<uint16_t, false>), dim3((unsigned)slices), dim3(64), 0, ctx_stream(ctx), a);
+        if (wide) hipLaunchKernelGGL((qhull_rows_kernel<uint32_t, 64, 64, true>), dim3((unsigned)slices), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((qhull_rows_kernel<uint16_t, 64, 64, true>), dim3((unsigned)slices), dim3(64), 0, st, a);
+    } else if (wide) hipLaunchKernelGGL((qhull_rows_kernel<uint32_t, 64, 64, false>), dim3((unsigned)slices), dim3(64), 0, st, a);
+    else if (group == 64) hipLaunchKernelGGL((qhull_rows_kernel<uint16_t, 64, 64, false>), dim3((unsigned)slices), dim3(64), 0, st, a);
+#ifdef MVOSR_ABLATE
+    else {
+        // several frames per wavefront; the frames that overflowed a 32-entry table, next, one per wavefront
+        a.redo = reinterpret_cast<int32_t *>(a.ws + (size_t)slices * P.total);
+        if (hipMemsetAsync(a.redo, 0, sizeof(int32_t), st) != hipSuccess) return set_error(MVOSR_ERR_HIP, "delaunay_qhull_batch: memset");
+        const int per = 64 / group;
+        const unsigned blocks = (unsigned)((n_frames + per - 1) / per);
+        if (group == 32) hipLaunchKernelGGL((qhull_rows_kernel<uint16_t, 32, 32, false>), dim3(blocks), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((qhull_rows_kernel<uint16_t, 16, 32, false>), dim3(blocks), dim3(64), 0, st, a);
+        if ((rc = check_launch("qhull_rows_kernel"))) return rc;
+        QhArgs b = a;
+        b.list = a.redo; b.redo = nullptr;
+        const int64_t rb = n_frames < 256 ? n_frames : 256;
+        hipLaunchKernelGGL((qhull_rows_kernel<uint16_t, 64, 64, true>), dim3((unsigned)rb), dim3(64), 0, st, b);
+    }
+#endif
     return check_launch("qhull_rows_kernel");
 }
 

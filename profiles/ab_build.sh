@@ -8,7 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 mkdir -p $R/profiles/ab/obj_$NAME
 cd $R/mvoscalerecovery_amd/csrc
-for f in mvosr_kernels mvosr_rescale mvosr_delaunay mvosr_capi; do
+for f in mvosr_kernels mvosr_rescale mvosr_delaunay mvosr_qhull mvosr_capi; do
   if [ -n "$ONLY" ] && [ $f != "$ONLY" ]; then cp $f.o $R/profiles/ab/obj_$NAME/$f.o; continue; fi
   if [ -n "$ONLY" ] || [ $f = mvosr_kernels ] || [ ! -f $R/profiles/ab/obj_$NAME/$f.o ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function $@ -c $f.hip -o $R/profiles/ab/obj_$NAME/$f.o &

@@ -36,6 +36,7 @@ def test_shipped_library_has_no_ablation_switch():
     from mvoscalerecovery_amd import _lib
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"MVOSR_DEBUG_SKIP" not in blob
+    assert b"MVOSR_QH_GROUP" not in blob          # (the packed variants of qhull_rows_kernel: A/B builds only)
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "mvosr_debug" not in nm
 
