@@ -400,6 +400,7 @@ int mvosr_ctx_create(int device, mvosr_ctx **out) {
     for (int i = 0; i < 2; ++i) ctx->ws_dense[i] = nullptr;
     ctx->ws_dense_len = 0;
     ctx->ws_bytes = nullptr; ctx->ws_bytes_len = 0;
+    ctx->dt_parts_head = nullptr;
     for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) ctx->prof_ev[i][j] = nullptr;
     ctx->ws_ysel = nullptr; ctx->ws_ysel_len = 0; ctx->ws_nsel = nullptr; ctx->ws_nsel_len = 0;
     ctx->n_hip_malloc = ctx->n_hip_free = ctx->n_host_malloc = ctx->n_host_free = ctx->n_cache_hits = 0;
@@ -434,6 +435,7 @@ int mvosr_ctx_destroy(mvosr_ctx *ctx) {
     if (ctx->ws_ysel) (void)hipFree(ctx->ws_ysel);
     if (ctx->ws_nsel) (void)hipFree(ctx->ws_nsel);
     if (ctx->ws_bytes) (void)hipFree(ctx->ws_bytes);
+    if (ctx->dt_parts_head) (void)hipFree(ctx->dt_parts_head);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MVOSR_OK;

@@ -124,6 +124,10 @@ struct DtArgs {
     // this triangulation — the triangles stay Delaunay among fewer points and still close the fan — so its rows are copied
     // (ids mapped to ranks) and its star is not walked at all: at 95 % kept points that is three stars in four.
     const uint32_t *seed_info; uint32_t *info_out;
+    // PARTS variant (a launch of a few frames — the per-frame call): `parts` workgroups per frame, each with the whole frame in
+    // its LDS, each building the stars of its own strip of cell columns; what they found meets in `pg` (DtPartsPlan, one slice per frame)
+    // and the last workgroup to arrive writes the rows.
+    int parts; char *pg; unsigned int *ph;       // ph: 16 words per frame — [0] parts arrived, [1] their decline flags (zero between launches)
 #ifdef MVOSR_STAMPS
     unsigned long long *stamps;                          // diagnostic builds: 16 values per frame (phase boundaries, list lengths)
 #endif
@@ -131,8 +135,9 @@ struct DtArgs {
 
 #ifdef MVOSR_STAMPS
 static unsigned long long *g_dt_stamps = nullptr;
-#define DT_STAMP(i) do { if (tid == 0 && a.stamps) a.stamps[64 * f + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define DT_NOTE(i, v) do { if (tid == 0 && a.stamps) a.stamps[64 * f + (i)] = (unsigned long long)(v); } while (0)
+// (PARTS: a row of 64 values per part)
+#define DT_STAMP(i) do { if (tid == 0 && a.stamps) a.stamps[64 * (PARTS ? (int64_t)blockIdx.x : f) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DT_NOTE(i, v) do { if (tid == 0 && a.stamps) a.stamps[64 * (PARTS ? (int64_t)blockIdx.x : f) + (i)] = (unsigned long long)(v); } while (0)
 #else
 #define DT_STAMP(i) do {} while (0)
 #define DT_NOTE(i, v) do {} while (0)
@@ -227,7 +232,23 @@ __host__ __device__ inline DtPlan dt_plan(int max_pts, bool global = false, int 
     return p;
 }
 
-enum { DM_FLAGS = 0, DM_ARENA = 1, DM_VQ = 2, DM_NHARD = 3, DM_NEXT = 4 };
+// PARTS: a frame's meeting place in global memory — per point its `od` word and the start of its rows; the parts' arenas one
+// after the other
+struct DtPartsPlan { uint32_t od, start, arena, total; };
+__host__ __device__ inline DtPartsPlan dt_parts_plan(int max_pts, int parts) {
+    DtPartsPlan p;
+    const uint32_t npad = (uint32_t)((max_pts + 7) & ~7);
+    p.od = 0u;
+    p.start = p.od + 2u * npad;
+    p.arena = p.start + 4u * npad;
+    p.total = (p.arena + 4u * (uint32_t)parts * (uint32_t)(2u * npad + kDtArenaSlack) + 255u) & ~255u;
+    return p;
+}
+constexpr int kDtPartsMaxFrames = 16;      // launches of up to this many frames take the PARTS variant
+constexpr int kDtPartsPoints = 128;        // points per part (four wavefronts: at most a star per lane)
+constexpr int kDtPartsMax = 16;
+
+enum { DM_FLAGS = 0, DM_ARENA = 1, DM_VQ = 2, DM_NHARD = 3, DM_NEXT = 4, DM_TICKET = 5 };
 enum { DW_CNT = 0, DW_SUM = 16, DW_SUM2 = 32, DW_SUM3 = 48 };        // wsl[]: 16 slots each
 
 struct DtGrid {
@@ -463,11 +484,14 @@ __device__ __forceinline__ int dt_incl_scan(int v) {
     return v;
 }
 
-template <bool GLOBAL, int WAVES = kDtWaves, bool ARENA_OUT = false>
-__global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) void delaunay_kernel(const DtArgs a) {
+template <bool GLOBAL, int WAVES = kDtWaves, bool ARENA_OUT = false, bool PARTS = false>
+__global__ __launch_bounds__(WAVES *kWave, PARTS ? 1 : ((ARENA_OUT && WAVES == 4) ? 3 : 4)) void delaunay_kernel(const DtArgs a) {
+    static_assert(!PARTS || (!GLOBAL && !ARENA_OUT), "the PARTS variant keeps a frame in every part's LDS");
     constexpr int BLOCK = WAVES * kWave;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int64_t f = blockIdx.x;
+    const int64_t f = PARTS ? (int64_t)(blockIdx.x / (unsigned)a.parts) : (int64_t)blockIdx.x;
+    const int part = PARTS ? (int)(blockIdx.x % (unsigned)a.parts) : 0;
+    const int64_t hslice = PARTS ? (int64_t)blockIdx.x : f;          // (every part sorts the points its own way: caches of its own)
     const int n_in = a.pts_cnt[f];
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
     const DtPlan L = dt_plan(a.max_pts, GLOBAL, WAVES, ARENA_OUT);
@@ -486,7 +510,7 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
     int *wsl = reinterpret_cast<int *>(small + L.wsl);
     uint8_t *aff = reinterpret_cast<uint8_t *>(small + L.aff);
     const size_t hint_pts = (size_t)((a.max_pts + 7) & ~7);
-    uint32_t *hints = (kDtHintsOn<GLOBAL> && a.hints) ? a.hints + (size_t)f * ((size_t)(kDtHintK + 3) * hint_pts) : nullptr;
+    uint32_t *hints = (kDtHintsOn<GLOBAL> && a.hints) ? a.hints + (size_t)hslice * ((size_t)(kDtHintK + 3) * hint_pts) : nullptr;
     uint32_t *start = hints ? hints + (size_t)(kDtHintK + 1) * hint_pts : nullptr;               // one known triangle per point: its star starts there
     uint32_t *inv = (hints && a.seed_tri) ? hints + (size_t)kDtHintK * hint_pts : nullptr;       // position in u/v -> sorted index (seeds only)
     uint32_t *order = (hints && kDtColour && !GLOBAL) ? hints + (size_t)(kDtHintK + 2) * hint_pts : nullptr; // the order in which the points are taken
@@ -496,9 +520,14 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
         const int n_words = kDtHintK * min(n_in, (int)hint_pts);
         uint4 ones; ones.x = ones.y = ones.z = ones.w = 0xFFFFFFFFu;
         for (int k = tid; k < (n_words + 3) / 4; k += BLOCK) reinterpret_cast<uint4 *>(hints)[k] = ones;
-        if (inv) for (int k = tid; k < min(n_in, (int)hint_pts); k += BLOCK) inv[k] = 0xFFFFFFFFu;
         for (int k = tid; k < min(n_in, (int)hint_pts); k += BLOCK) start[k] = 0xFFFFFFFFu;
+        if (inv) for (int k = tid; k < min(n_in, (int)hint_pts); k += BLOCK) inv[k] = 0xFFFFFFFFu;
     }
+    // "in x's star, after `key` comes ...": slot key mod kDtHintK of x's cache; x's known triangle
+    auto hint_put = [&](uint32_t x, uint32_t key, uint32_t val) { __hip_atomic_store(hints + (size_t)x * kDtHintK + (key % kDtHintK), val, __ATOMIC_RELAXED, kDtScope); };
+    auto hint_get = [&](uint32_t x, uint32_t key) -> uint32_t { return __hip_atomic_load(hints + (size_t)x * kDtHintK + (key % kDtHintK), __ATOMIC_RELAXED, kDtScope); };
+    auto start_put = [&](uint32_t x, uint32_t val) { __hip_atomic_store(start + x, val, __ATOMIC_RELAXED, kDtScope); };
+    auto start_get = [&](uint32_t x) -> uint32_t { return __hip_atomic_load(start + x, __ATOMIC_RELAXED, kDtScope); };
 
     auto decline = [&](int why, int n_used) {
         if (tid == 0) { a.tri_cnt[f] = 0; a.status[f] = MVOSR_DT_DEGENERATE | (why << 8); if (a.n_used) a.n_used[f] = n_used; }
@@ -586,6 +615,10 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
         G.lo_u = lo_u; G.lo_v = lo_v; G.ix = fx / W; G.iy = fy / H; G.sx = W / fx; G.sy = H / fy; G.cs = cs;
     }
     const int ncell = G.gx * G.gy;
+    // PARTS: the part a cell's stars belong to — a strip of cell columns, so that every part has its share of the long top and
+    // bottom hulls (their stars are the long ones: bands of cell rows left the first and the last part with twice the others'
+    // time: 277 against 227 us per launch of a 2000-point frame in eight parts)
+    auto part_of = [&](int c) -> int { return min(a.parts - 1, (int)(((int64_t)(c % G.gx) * a.parts) / G.gx)); };
     DT_STAMP(1);
     DT_STAMP(48);
     for (int c = tid - 1; c <= ncell; c += BLOCK) cs[c] = 0u;          // (from cs[-1] on)
@@ -665,6 +698,14 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
         const int32_t *st = a.seed_tri + 3 * a.seed_off[f];
         const int ns = a.seed_cnt[f];
         if (carry) {
+            if constexpr (PARTS) {
+                // 2: the star belongs to another part (neither walked nor carried here)
+                for (int c = tid; c < ncell; c += BLOCK) {
+                    const int b = c ? (int)cs[c - 1] : 0, e = (int)cs[c];
+                    const uint8_t v_ = part_of(c) == part ? 0 : 2;
+                    for (int j = b; j < e; ++j) aff[j] = v_;
+                }
+            } else
             for (int j = tid; j < n; j += BLOCK) aff[j] = 0;
             __syncthreads();
             // a seed row that lost a vertex: its other vertices' stars change.  (Four rows at a time: their twelve ids, then their
@@ -688,9 +729,9 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
                     if (ps[q][0] == 0xFFFFFFFEu || ps[q][1] == 0xFFFFFFFEu || ps[q][2] == 0xFFFFFFFEu) continue;     // (an id out of range: not a row of this frame)
                     const bool ka = ps[q][0] < (uint32_t)n, kb = ps[q][1] < (uint32_t)n, kc = ps[q][2] < (uint32_t)n;
                     if (ka && kb && kc) continue;
-                    if (ka) aff[ps[q][0]] = 1;
-                    if (kb) aff[ps[q][1]] = 1;
-                    if (kc) aff[ps[q][2]] = 1;
+                    if (ka && (!PARTS || aff[ps[q][0]] != 2)) aff[ps[q][0]] = 1;
+                    if (kb && (!PARTS || aff[ps[q][1]] != 2)) aff[ps[q][1]] = 1;
+                    if (kc && (!PARTS || aff[ps[q][2]] != 2)) aff[ps[q][2]] = 1;
                 }
             }
             __syncthreads();
@@ -753,8 +794,8 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
             if (pa >= (uint32_t)n || pb >= (uint32_t)n || pc >= (uint32_t)n) continue;          // a vertex that is not kept (all ones)
             bool ha = true, hb = true, hc = true;
             if (carry) {
-                ha = aff[pa] != 0; hb = aff[pb] != 0; hc = aff[pc] != 0;
-                if (!ha) {                                   // ra is the row's smallest id: its owner, and the ranks keep the order
+                ha = aff[pa] == 1; hb = aff[pb] == 1; hc = aff[pc] == 1;
+                if (aff[pa] == 0) {                                   // ra is the row's smallest id: its owner, and the ranks keep the order
                     const int idx = r - (int)(a.seed_info[off + ra] >> 16);
                     if (idx >= 0 && idx < (int)(od[oid[pa]] & 63u)) arena[astart[oid[pa]] + idx] = ((uint32_t)oid[pb] << 16) | (uint32_t)oid[pc];
                     else atomicOr(&misc[DM_FLAGS], (int)DT_WHY_ROWS);
@@ -766,16 +807,16 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
             if (!(cr != 0.0)) continue;
             if (cr < 0.0) { const uint32_t t = pb; pb = pc; pc = t; const bool tb = hb; hb = hc; hc = tb; }   // (pa, pb, pc) counter-clockwise now
             if (ha) {
-                __hip_atomic_store(hints + (size_t)pa * kDtHintK + (pb % kDtHintK), (pb << 16) | pc, __ATOMIC_RELAXED, kDtScope);
-                __hip_atomic_store(start + pa, (pb << 16) | pc, __ATOMIC_RELAXED, kDtScope);
+                hint_put(pa, pb, (pb << 16) | pc);
+                start_put(pa, (pb << 16) | pc);
             }
             if (hb) {
-                __hip_atomic_store(hints + (size_t)pb * kDtHintK + (pc % kDtHintK), (pc << 16) | pa, __ATOMIC_RELAXED, kDtScope);
-                __hip_atomic_store(start + pb, (pc << 16) | pa, __ATOMIC_RELAXED, kDtScope);
+                hint_put(pb, pc, (pc << 16) | pa);
+                start_put(pb, (pc << 16) | pa);
             }
             if (hc) {
-                __hip_atomic_store(hints + (size_t)pc * kDtHintK + (pa % kDtHintK), (pa << 16) | pb, __ATOMIC_RELAXED, kDtScope);
-                __hip_atomic_store(start + pc, (pa << 16) | pb, __ATOMIC_RELAXED, kDtScope);
+                hint_put(pc, pa, (pa << 16) | pb);
+                start_put(pc, (pa << 16) | pb);
             }
         }
         __syncthreads();
@@ -795,9 +836,10 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
         for (int c = tid; c < ncell; c += BLOCK) {
             const int cx = c % G.gx, cy = c / G.gx, col = (cx & 1) | ((cy & 1) << 1);
             const int b = c ? (int)cs[c - 1] : 0, e = (int)cs[c];
+            if (PARTS && part_of(c) != part) continue;     // (the stars of this part's strip of cells only)
             int k = 0;                                        // (with carry: only the points whose star is walked)
             for (int j = b; j < e; ++j) {
-                if (carry && !aff[j]) continue;
+                if (carry && aff[j] != 1) continue;
                 atomicAdd(&ccnt[4 * min(k, 3) + col], 1);
                 ++k;
             }
@@ -814,9 +856,10 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
         for (int c = tid; c < ncell; c += BLOCK) {
             const int cx = c % G.gx, cy = c / G.gx, col = (cx & 1) | ((cy & 1) << 1);
             const int b = c ? (int)cs[c - 1] : 0, e = (int)cs[c];
+            if (PARTS && part_of(c) != part) continue;
             int k = 0;
             for (int j = b; j < e; ++j) {
-                if (carry && !aff[j]) continue;
+                if (carry && aff[j] != 1) continue;
                 const int at = atomicAdd(&ccnt[4 * min(k, 3) + col], 1);
                 __hip_atomic_store(order + at, (uint32_t)j, __ATOMIC_RELAXED, kDtScope);
                 ++k;
@@ -883,7 +926,7 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
 #if MVOSR_DT_HINT_START
             if constexpr (kDtHintsOn<GLOBAL>) {
                 if (hints && i >= 0) {
-                    const uint32_t h = __hip_atomic_load(start + i, __ATOMIC_RELAXED, kDtScope);
+                    const uint32_t h = start_get((uint32_t)i);
                     const int from = (int)(h >> 16), to = (int)(h & 0xFFFFu);
                     if (h != 0xFFFFFFFFu && from < n && to < n && from != to && from != i && to != i) {
                         mode = 1; q0 = from; iq = from; nn_level = 0;
@@ -1108,13 +1151,11 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
                         if (hints) {
                             // counter-clockwise walk: (p, iq, accept) is the triangle; clockwise: (p, accept, iq)
                             const uint32_t a_ = (uint32_t)(sgn > 0.0 ? iq : accept), c_ = (uint32_t)(sgn > 0.0 ? accept : iq);
-                            __hip_atomic_store(hints + (size_t)a_ * kDtHintK + (c_ % kDtHintK), (c_ << 16) | (uint32_t)i,
-                                               __ATOMIC_RELAXED, kDtScope);        // in a's star: after c comes p
-                            __hip_atomic_store(hints + (size_t)c_ * kDtHintK + ((uint32_t)i % kDtHintK), ((uint32_t)i << 16) | a_,
-                                               __ATOMIC_RELAXED, kDtScope);        // in c's star: after p comes a
+                            hint_put(a_, c_, (c_ << 16) | (uint32_t)i);                  // in a's star: after c comes p
+                            hint_put(c_, (uint32_t)i, ((uint32_t)i << 16) | a_);         // in c's star: after p comes a
 #if MVOSR_DT_HINT_START
-                            __hip_atomic_store(start + a_, (c_ << 16) | (uint32_t)i, __ATOMIC_RELAXED, kDtScope);
-                            __hip_atomic_store(start + c_, ((uint32_t)i << 16) | a_, __ATOMIC_RELAXED, kDtScope);
+                            start_put(a_, (c_ << 16) | (uint32_t)i);
+                            start_put(c_, ((uint32_t)i << 16) | a_);
 #endif
                         }
                     }
@@ -1122,7 +1163,7 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
 #ifdef MVOSR_STAMPS
                     ++n_by_search;
                     if (hints && sgn > 0.0) {       // did the hint arrive while the search ran?
-                        const uint32_t h_ = __hip_atomic_load(hints + (size_t)i * kDtHintK + ((uint32_t)iq % kDtHintK), __ATOMIC_RELAXED, kDtScope);
+                        const uint32_t h_ = hint_get((uint32_t)i, (uint32_t)iq);
                         if ((h_ >> 16) == (uint32_t)iq) atomicAdd(&misc[61], 1);
                         else if (h_ != 0xFFFFFFFFu) atomicAdd(&misc[62], 1);      // the slot holds another neighbour's hint
                     }
@@ -1152,8 +1193,7 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
                         int nxt = -1;
                         if constexpr (kDtHintsOn<GLOBAL>) {
                             if (go && hints && sgn > 0.0 && chain < kDtHintChain) {
-                                const uint32_t h = __hip_atomic_load(hints + (size_t)i * kDtHintK + ((uint32_t)iq % kDtHintK),
-                                                                     __ATOMIC_RELAXED, kDtScope);
+                                const uint32_t h = hint_get((uint32_t)i, (uint32_t)iq);
                                 if ((h >> 16) == (uint32_t)iq && (int)(h & 0xFFFFu) < n) nxt = (int)(h & 0xFFFFu);
                             }
                         }
@@ -1216,9 +1256,9 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
 #ifdef MVOSR_STAMPS
     DT_NOTE(10, misc[48]); DT_NOTE(11, misc[49]); DT_NOTE(12, misc[50]); DT_NOTE(13, misc[51]);
     DT_NOTE(26, misc[61]); DT_NOTE(27, misc[62]); DT_NOTE(28, misc[63]);
-    if (tid == 0 && a.stamps) for (int k = 0; k < 16; ++k) a.stamps[64 * f + 32 + k] = (unsigned long long)misc[24 + k];
+    if (tid == 0 && a.stamps) for (int k = 0; k < 16; ++k) a.stamps[64 * (PARTS ? (int64_t)blockIdx.x : f) + 32 + k] = (unsigned long long)misc[24 + k];
     DT_NOTE(29, misc[40]); DT_NOTE(30, misc[41]); DT_NOTE(31, misc[42]); DT_NOTE(7, misc[43]); DT_NOTE(8, misc[44]); DT_NOTE(14, misc[45]);
-    if (tid == 0 && a.stamps) for (int k = 52; k < 61; ++k) a.stamps[64 * f + 16 + (k - 52)] = (unsigned long long)misc[k];
+    if (tid == 0 && a.stamps) for (int k = 52; k < 61; ++k) a.stamps[64 * (PARTS ? (int64_t)blockIdx.x : f) + 16 + (k - 52)] = (unsigned long long)misc[k];
 #endif
 
     // The two passes below work in GROUPS of 16 lanes (a DPP row): a completion has a few dozen candidates at most, so
@@ -1321,12 +1361,46 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
     DT_STAMP(5);
     DT_NOTE(9, misc[DM_NHARD]);
 
+    // PARTS: this part's stars — the `od` words and row starts of its band's points, its arena — to the frame's meeting place;
+    // the last part to arrive goes on and writes the rows from there
+    const uint16_t *OD = od;
+    const uint32_t *AR = arena;
+    const uint32_t *ST32 = nullptr;
+    int part_flags = 0;
+    if constexpr (PARTS) {
+        const DtPartsPlan PP = dt_parts_plan(a.max_pts, a.parts & 0xFF);
+        char *pg = a.pg + (size_t)f * PP.total;
+        uint32_t *g_head = a.ph + 16 * f;
+        uint16_t *g_od = reinterpret_cast<uint16_t *>(pg + PP.od);
+        uint32_t *g_start = reinterpret_cast<uint32_t *>(pg + PP.start);
+        uint32_t *g_arena = reinterpret_cast<uint32_t *>(pg + PP.arena);
+        const uint32_t abase = (uint32_t)part * (uint32_t)L.arena_cap;
+        const int used = min(misc[DM_ARENA], L.arena_cap);
+        for (int k = tid; k < used; k += BLOCK) g_arena[abase + k] = arena[k];
+        for (int c = tid; c < ncell; c += BLOCK) {
+            const int b = c ? (int)cs[c - 1] : 0, e = (int)cs[c];
+            if (part_of(c) != part) continue;
+            for (int j = b; j < e; ++j) { const int o = oid[j]; g_od[o] = od[o]; g_start[o] = abase + astart[o]; }
+        }
+        if (tid == 0 && misc[DM_FLAGS]) atomicOr(&g_head[1], (uint32_t)misc[DM_FLAGS]);
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) misc[DM_TICKET] = (int)atomicAdd(&g_head[0], 1u);
+        __syncthreads();
+        if (misc[DM_TICKET] != a.parts - 1) return;
+        __threadfence();
+        part_flags = (int)__hip_atomic_load(&g_head[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) { g_head[0] = 0u; g_head[1] = 0u; }            // (for the next launch: every part of this one has been here)
+        OD = g_od; AR = g_arena; ST32 = g_start;
+    }
+    auto start_of = [&](int o) -> int { if constexpr (PARTS) return (int)ST32[o]; else return (int)astart[o]; };
+
     // ---- rows in point order: block prefix over the points' row counts; Euler's relation
     {
         const int pper = (n + BLOCK - 1) / BLOCK;
         const int o0 = tid * pper, o1 = min(n, o0 + pper);
         int mine = 0, sdeg = 0, hull = 0;
-        for (int o = o0; o < o1; ++o) { const int d = od[o]; mine += d & 63; sdeg += (d >> 6) & 63; hull += (d >> 15) & 1; }
+        for (int o = o0; o < o1; ++o) { const int d = OD[o]; mine += d & 63; sdeg += (d >> 6) & 63; hull += (d >> 15) & 1; }
         const int incl = dt_incl_scan(mine);
         const int wdeg = wave_sum(sdeg), whull = wave_sum(hull);
         if (lane == kWave - 1) wsl[DW_SUM + w] = incl;
@@ -1339,7 +1413,7 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
             if (i < w) base += c;
             total += c; tdeg += wsl[DW_SUM2 + i]; thull += wsl[DW_SUM3 + i];
         }
-        int why = misc[DM_FLAGS];
+        int why = PARTS ? part_flags : misc[DM_FLAGS];
         if (total != 2 * n - 2 - thull || tdeg != 3 * total) why |= DT_WHY_EULER;
         if (why) { decline(why, n); return; }
         int32_t *rows = a.tri + 3 * a.tri_off[f];
@@ -1351,15 +1425,15 @@ __global__ __launch_bounds__(WAVES *kWave, (ARENA_OUT && WAVES == 4) ? 3 : 4) vo
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int o = min(ob + q, o1 - 1);
-                ks[q] = ob + q < o1 ? (od[o] & 63) : 0;
-                sts[q] = astart[o];
+                ks[q] = ob + q < o1 ? (OD[o] & 63) : 0;
+                sts[q] = start_of(o);
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int o = ob + q;
                 if (o >= o1) break;
-                if (a.info_out && !gk) a.info_out[off + o] = (uint32_t)od[o] | ((uint32_t)at << 16);    // (no keep mask: rank o = position o)
-                const uint32_t *src = arena + sts[q];
+                if (a.info_out && !gk) a.info_out[off + o] = (uint32_t)OD[o] | ((uint32_t)at << 16);    // (no keep mask: rank o = position o)
+                const uint32_t *src = AR + sts[q];
                 for (int j = 0; j < ks[q]; j += 4) {
                     uint32_t key[4];
 #pragma unroll
@@ -1385,6 +1459,14 @@ using namespace mvosr;
 #ifdef MVOSR_STAMPS
 extern "C" void mvosr_debug_dt_stamps(void *dptr) { g_dt_stamps = reinterpret_cast<unsigned long long *>(dptr); }
 #endif
+
+// (MVOSR_DT_PARTS=0: the per-frame launch as one workgroup, for A/B runs and the tests that compare the two)
+static int dt_parts_env() {          // 0: off, n: that many parts, -1: by the frame's size
+    const char *e = getenv("MVOSR_DT_PARTS");
+    if (!e) return -1;
+    const int v = atoi(e);
+    return v < 0 ? -1 : (v > kDtPartsMax ? kDtPartsMax : v);
+}
 
 static int dt_lds_points() {
     int lo = 3, hi = 65535;
@@ -1475,7 +1557,7 @@ extern "C" int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const i
     a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
     a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.max_pts = max_pts; a.ws = nullptr; a.aws = nullptr; a.hints = nullptr;
     a.seed_off = seed_off; a.seed_tri = seed_tri; a.seed_cnt = seed_cnt;
-    a.seed_info = seed_info; a.info_out = info_out;
+    a.seed_info = seed_info; a.info_out = info_out; a.parts = 1; a.pg = nullptr; a.ph = nullptr;
 #ifdef MVOSR_STAMPS
     a.stamps = g_dt_stamps;
 #endif
@@ -1503,6 +1585,34 @@ extern "C" int mvosr_delaunay_batch_ex(mvosr_ctx *ctx, int64_t n_frames, const i
     // lanes per frame are what shortens the call (900 points: 0.96 against 1.26 ms per frame call).
     int waves = kDtWaves, per_cu = 1;
     bool arena_out = false;
+    // A launch of a few frames (the per-frame call of /root/reference/src/main.py:110-113: ONE) leaves 255 CUs idle and lasts as long as
+    // one frame on one CU (276 us at 2000 points, 95 % of it the stars): several workgroups per frame instead, each with the
+    // whole frame in its LDS and a strip of the cells to build the stars of — four wavefronts, at most a star per lane —, the last one to
+    // finish writing the rows (the PARTS instantiation)
+    if (kDtHintK > 0 && kDtColour && n_frames <= kDtPartsMaxFrames && max_pts >= 2 * kDtPartsPoints && dt_parts_env() &&
+        dt_plan(max_pts, false, 4).total <= 160u * 1024u) {
+        const int parts = dt_parts_env() > 0 ? dt_parts_env() : min(kDtPartsMax, (max_pts + kDtPartsPoints - 1) / kDtPartsPoints);
+        const DtPlan LQ = dt_plan(max_pts, false, 4);
+        const size_t plds = (size_t)LQ.total;
+        const DtPartsPlan PP = dt_parts_plan(max_pts, parts);
+        const size_t hint_bytes = ((size_t)n_frames * parts * (size_t)(kDtHintK + 3) * (size_t)((max_pts + 7) & ~7) * sizeof(uint32_t) + 255) & ~(size_t)255;
+        void *ws = nullptr;
+        if ((rc = ctx_workspace_bytes(ctx, hint_bytes + (size_t)n_frames * PP.total, &ws))) return rc;
+        a.hints = reinterpret_cast<uint32_t *>(ws);
+        a.pg = reinterpret_cast<char *>(ws) + hint_bytes;
+        a.parts = parts;
+        if (!ctx->dt_parts_head) {
+            hipError_t eh = hipMalloc(reinterpret_cast<void **>(&ctx->dt_parts_head), 16 * sizeof(unsigned int) * kDtPartsMaxFrames);
+            if (eh == hipSuccess) eh = hipMemset(ctx->dt_parts_head, 0, 16 * sizeof(unsigned int) * kDtPartsMaxFrames);
+            if (eh != hipSuccess) return set_hip_error("delaunay_batch: the parts' counters", eh);
+        }
+        a.ph = ctx->dt_parts_head;
+        const void *kp = reinterpret_cast<const void *>(delaunay_kernel<false, 4, false, true>);
+        hipError_t e2 = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+        if (e2 != hipSuccess) return set_hip_error("hipFuncSetAttribute(delaunay_kernel)", e2);
+        hipLaunchKernelGGL((delaunay_kernel<false, 4, false, true>), dim3((unsigned)(n_frames * parts)), dim3(4 * kWave), plds, ctx_stream(ctx), a);
+        return check_launch("delaunay_kernel (parts)");
+    }
     if (kDtSmallLadder && n_frames >= kDtLadderMinFrames) dt_ladder(max_pts, waves, arena_out, per_cu);
     // A launch of a few frames (the per-frame call of /root/reference/src/main.py:110-113: ONE) leaves most CUs idle and its length is
     // one frame's: sixteen wavefronts per frame — four per SIMD instead of two: the lanes' dependent steps overlap, and a

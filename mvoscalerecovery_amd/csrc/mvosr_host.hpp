@@ -44,6 +44,9 @@ struct mvosr_ctx {
     size_t ws_dense_len;
     void *ws_bytes;               // generic grow-only scratch (the Delaunay kernel's per-frame arrays beyond the LDS capacity)
     size_t ws_bytes_len;
+    // delaunay_kernel's PARTS launches (a few frames, several workgroups each): per frame an arrival counter and the parts'
+    // decline flags (16 words a frame; zero between launches: the last part to arrive resets them), allocated on first use
+    unsigned int *dt_parts_head;
     // optional per-call kernel timing (mvosr_ctx_profile): start / between the two kernels / end
     int prof_on;
     int prof_calls;

@@ -22,7 +22,8 @@ d_u, d_v = ctx.to_device(np.ascontiguousarray(uv[:, 0])), ctx.to_device(np.ascon
 d_off, d_cnt, d_toff = ctx.to_device(off), ctx.to_device(cnt), ctx.to_device(2 * off)
 d_tri = ctx.empty((2 * F * n, 3), np.int32)
 d_tcnt, d_st, d_used = ctx.zeros(F, np.int32), ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
-d_stamps = ctx.zeros((F, 64), np.uint64)
+ROWS = int(os.environ.get("DT_PART_ROWS", "0"))       # PARTS launches (a few frames): a row of stamps per part
+d_stamps = ctx.zeros((max(F, F * ROWS), 64), np.uint64)
 ctx.lib.mvosr_debug_dt_stamps.argtypes = [C.c_void_p]
 ctx.lib.mvosr_debug_dt_stamps(d_stamps.ptr)
 d_info = ctx.zeros(F * n, np.uint32)
@@ -48,6 +49,12 @@ if os.environ.get("DT_SEEDED"):
     ctx.sync()
     print("second triangulation over %.0f %% of the points, %s%s:" % (100 * KEEP, "seeded" if seeded else "not seeded", ", untouched stars carried over" if (seeded and CARRY) else ""))
 s = d_stamps.download().astype(np.float64)
+if ROWS:
+    s = s[s[:, 0] > 0]
+    t0 = s[:, 0].min()
+    for r in range(len(s)):
+        print("  part %2d: start %7.0f  setup %7.0f  phase 1 %8.0f  tail %7.0f  end %8.0f | loop iterations %4.0f  lanes busy %5.1f %%  wide scans %4.0f (row passes %4.0f)  hard %2.0f" % (
+            r, s[r, 0] - t0, s[r, 2] - s[r, 0], s[r, 3] - s[r, 2], max(s[r, 6], s[r, 5]) - s[r, 3], max(s[r, 6], s[r, 5]) - t0, s[r, 12] / 256.0, 100.0 * s[r, 13] / max(s[r, 12], 1), s[r, 31], s[r, 7], s[r, 9]))
 d = np.diff(s[:, :7], axis=1)
 tot = s[:, 6] - s[:, 0]
 names = ["load + bbox + grid dims", "zero + count / scan / scatter", "phase 1 (one lane per point)", "(barrier)", "phase 2 (hard points, groups)", "prefix + Euler + rows out"]

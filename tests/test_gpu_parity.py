@@ -506,6 +506,70 @@ def test_delaunay_few_frames_up_to_the_lds_limit(gpu):
             b.free()
 
 
+def test_delaunay_parts_variant_equals_one_workgroup(gpu, monkeypatch):
+    """Launches of up to 16 frames (the per-frame call: one) run several workgroups per frame — each with the whole frame in its
+    LDS and a strip of the cells' stars to build, the last one to arrive writing the rows (delaunay_kernel's PARTS
+    instantiation): first triangulation, seeded second with carried stars, declined frames — the same rows, counts, statuses and
+    seed words as the one-workgroup launch (MVOSR_DT_PARTS=0) and as SciPy; 16 frames take it, 17 do not, and both agree."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import _lib, packing, synth
+    rng = np.random.default_rng(515)
+
+    def run(sets, keep_frac):
+        F = len(sets)
+        cnt = np.array([len(q) for q in sets], dtype=np.int32)
+        off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+        uv = np.concatenate(sets)
+        keep = np.where(np.random.default_rng(9).uniform(size=len(uv)) < keep_frac, 1, -1).astype(np.int32)
+        d_u, d_v = gpu.to_device(np.ascontiguousarray(uv[:, 0])), gpu.to_device(np.ascontiguousarray(uv[:, 1]))
+        d_off, d_cnt, d_toff, d_keep = gpu.to_device(off), gpu.to_device(cnt), gpu.to_device(2 * off), gpu.to_device(keep)
+        rows = int(2 * cnt.sum())
+        t1, t2 = gpu.empty((rows, 3), np.int32), gpu.empty((rows, 3), np.int32)
+        c1, c2, s1, s2, used = (gpu.zeros(F, np.int32) for _ in range(5))
+        info = gpu.zeros(int(cnt.sum()), np.uint32)
+        n_max = int(cnt.max())
+        _lib.check(gpu.lib.mvosr_delaunay_batch_ex(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n_max, d_toff.ptr, t1.ptr, c1.ptr,
+                                                   None, s1.ptr, None, None, None, None, info.ptr), "first")
+        _lib.check(gpu.lib.mvosr_delaunay_batch_ex(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr, t2.ptr, c2.ptr,
+                                                   used.ptr, s2.ptr, d_toff.ptr, t1.ptr, c1.ptr, info.ptr, None), "second")
+        out = dict(t1=t1.download(), t2=t2.download(), c1=c1.download(), c2=c2.download(), s1=s1.download(), s2=s2.download(),
+                   used=used.download(), info=info.download(), off=off, cnt=cnt, keep=keep)
+        for b in (d_u, d_v, d_off, d_cnt, d_toff, d_keep, t1, t2, c1, c2, s1, s2, used, info):
+            b.free()
+        return out
+
+    top = int(gpu.lib.mvosr_delaunay_lds_points())
+    dup = synth.synth_frame(5, 700, base_seed=77)[1].copy(); dup[3] = dup[400]
+    line = np.stack([np.arange(600.0), 2.0 * np.arange(600.0)], axis=1)
+    cases = [([synth.synth_frame(1, 2000, base_seed=515)[1]], 0.95),
+             ([synth.synth_frame(2, 900, base_seed=515)[1]], 0.85),
+             ([synth.synth_frame(3, 4000, base_seed=515)[1]], 0.9),
+             ([np.ascontiguousarray(rng.uniform(0, 1, (top, 2)) * [1241.0, 376.0])], 0.9),
+             ([synth.synth_frame(10 + i, int(m), base_seed=515)[1] for i, m in enumerate((2000, 1700, 520, 300, 12, 3, 2))] + [dup, line], 0.8),
+             ([synth.synth_frame(40 + i, int(m), base_seed=515)[1] for i, m in enumerate(rng.integers(600, 1500, 16))], 0.9),
+             ([synth.synth_frame(70 + i, int(m), base_seed=515)[1] for i, m in enumerate(rng.integers(600, 1500, 17))], 0.9)]
+    for sets, frac in cases:
+        monkeypatch.delenv("MVOSR_DT_PARTS", raising=False)
+        a = run(sets, frac)
+        monkeypatch.setenv("MVOSR_DT_PARTS", "0")
+        b = run(sets, frac)
+        for k in ("c1", "c2", "s1", "s2", "used"):
+            assert np.array_equal(a[k], b[k]), (k, [len(q) for q in sets])
+        for f, q in enumerate(sets):
+            lo = int(2 * a["off"][f])
+            assert np.array_equal(a["t1"][lo:lo + a["c1"][f]], b["t1"][lo:lo + b["c1"][f]]), f
+            assert np.array_equal(a["t2"][lo:lo + a["c2"][f]], b["t2"][lo:lo + b["c2"][f]]), f
+            if a["s1"][f] == 0:
+                o = int(a["off"][f])
+                assert np.array_equal(a["info"][o:o + len(q)], b["info"][o:o + len(q)]), f
+                assert np.array_equal(a["t1"][lo:lo + a["c1"][f]], packing.canonical_rows(Delaunay(q).simplices)), f
+            kept = a["keep"][a["off"][f]:a["off"][f] + len(q)] >= 0
+            if a["s2"][f] == 0:
+                assert np.array_equal(a["t2"][lo:lo + a["c2"][f]], packing.canonical_rows(Delaunay(q[kept]).simplices)), f
+        assert (a["s1"][:min(4, len(sets))] == 0).all()
+    monkeypatch.delenv("MVOSR_DT_PARTS", raising=False)
+
+
 @pytest.mark.parametrize("n_max", [40, 470, 530, 1000, 1120, 1140, 1500, 2000, 2160, 2180, 2500, 3300, 3320])
 def test_delaunay_small_frame_variants(gpu, n_max):
     """The launcher's instantiations by the batch's largest frame: two wavefronts per frame while eight frames' arrays fit a
