@@ -493,6 +493,9 @@ def latency_leg(args, device, sizes, seed, frames=100):
         t = np.array(t) * 1e3
         out[name] = {"median_ms": float(np.median(t)), "p90_ms": float(np.percentile(t, 90)),
                      "hip_malloc_calls": a1["hip_malloc"] - a0["hip_malloc"], "hip_host_malloc_calls": a1["host_malloc"] - a0["host_malloc"]}
+        if name == "gpu_exact":       # (frames the one-SciPy-call path handed back to the host's path; exact levels it computed on demand)
+            out[name]["redone_on_host"] = int(getattr(est, "single_fast_redone", 0))
+            out[name]["levels_on_demand"] = int(getattr(est, "single_fast_levels", 0))
     # the estimator the reference's drivers import, device-resident (one frame per call: /root/reference/src/main.py:113)
     from mvoscalerecovery_amd.rescale import ScaleEstimator as RescaleEstimator
     est = RescaleEstimator(ABS_REF, window_size=WINDOW, device=device, delaunay_workers=0, triangulation="gpu", ransac_seed=2024)

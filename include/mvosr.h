@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MVOSR_ABI_VERSION 10
+#define MVOSR_ABI_VERSION 11
 
 /* error codes (function return values) */
 enum mvosr_err {
@@ -345,6 +345,15 @@ void mvosr_default_params(mvosr_params *p, double absolute_reference);
 /* or-ed into waves_per_frame: ONLY the frames of the range with a non-zero exact_mask byte are (re)done, in the exact mode;
  * every other frame's outputs stay as they are (the host asks for the neighbours of a frame that raised, once it knows). */
 #define MVOSR_WAVES_EXACT_MASKED 0x200
+/* or-ed into waves_per_frame: the product (HOT) kernels and the road model ONLY, whatever outputs are asked for (selected,
+ * vote_counters: written; per-triangle outputs: refused) — no exact pass, no exact_mask.  A frame the exact pass would have
+ * redone (its level may decide its result in the last bit, or IS its result) is left with status MVOSR_ST_REDO and no result:
+ * the caller redoes it.  Every other frame's raw_scale, status, counts and selected are final; its height_level is the kernel's
+ * own fixed-order sum (equal to NumPy's to ~1e-16 relative, not bit for bit).  The per-frame call of the reference-exact
+ * estimator runs this way on stand-in rows and asks SciPy for the second triangulation only when a frame comes back
+ * MVOSR_ST_REDO or its exact level is read (mvoscalerecovery_amd/scale_calculator.py). */
+#define MVOSR_WAVES_HOT_ONLY 0x400
+#define MVOSR_ST_REDO (-2)
 int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *b,
                       const mvosr_outputs *o, int waves_per_frame,
                       int64_t first_frame, int64_t n_launch);

@@ -13,10 +13,12 @@ import os
 import numpy as np
 
 LIB_PATH = os.environ.get("MVOSR_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")   # (override: A/B builds in profiles/)
-ABI_VERSION = 10
+ABI_VERSION = 11
 VOTE_REFERENCE, VOTE_FIXED = 0, 1          # mvosr_params.vote_mode
 WAVES_EXACT = 0x100                        # MVOSR_WAVES_EXACT, or-ed into waves_per_frame
 WAVES_EXACT_MASKED = 0x200                 # MVOSR_WAVES_EXACT_MASKED: only the frames of mvosr_batch.exact_mask, in the exact mode
+WAVES_HOT_ONLY = 0x400                     # MVOSR_WAVES_HOT_ONLY: product kernels only; frames the exact pass would redo come back ST_REDO
+ST_REDO = -2                               # MVOSR_ST_REDO
 MARK_NOW, MARK_IDLE, MARK_UPLOAD = 1, 2, 3 # mvosr_block_mark
 TRI2_SURVIVORS, TRI2_FEATURES = 0, 1      # mvosr_batch.tri2_ids
 N_COUNTS = 8

@@ -852,6 +852,7 @@ constexpr int kRoadWaves = 4;          // frames (wavefronts) per workgroup
 constexpr int kTrash = 175;            // histogram slot for values that are not binned (bins are 0..168)
 constexpr int kStPending = -1;         // scale kernel -> road kernel: "road model still to run"
 constexpr int kStRedo = -2;            // HOT scale kernel -> EXACT pass: "needs height_level in NumPy's summation order"
+static_assert(kStRedo == MVOSR_ST_REDO, "include/mvosr.h");
 constexpr int kMaxVoteRows = 32765;    // a 16-bit biased vote counter stays in [1, 0xFFFE] whatever the rows say while a vertex has at most this many
 
 struct RoadArgs {
@@ -2534,6 +2535,7 @@ static inline KArgs &kargs_of(DenseArgs &a) { return a.k; }
 
 // set by mvosr_scale_batch around its HOT dispatch: the exact pass over the redo list is left to the caller
 static thread_local bool g_defer_exact = false;
+static thread_local bool g_hot_only = false;      // MVOSR_WAVES_HOT_ONLY: no exact_mask frames on the redo list either
 
 template <class Args>
 static int launch_modes(mvosr_ctx *ctx, void (*k_hot)(const Args), void (*k_exact)(const Args), void (*k_full)(const Args),
@@ -2564,7 +2566,7 @@ static int launch_modes(mvosr_ctx *ctx, void (*k_hot)(const Args), void (*k_exac
     if (e != hipSuccess) return set_hip_error("hipMemsetAsync(redo list)", e);
     hipLaunchKernelGGL(k_hot, dim3((unsigned)nl), dim3(threads_hot), lds_hot, ctx_stream(ctx), args);
     if ((rc = check_launch(name))) return rc;
-    if ((rc = launch_append_mask(ctx, kargs_of(args), nl, true))) return rc;
+    if (!g_hot_only && (rc = launch_append_mask(ctx, kargs_of(args), nl, true))) return rc;
     if (g_defer_exact) return MVOSR_OK;           // mvosr_scale_batch runs ONE exact pass, after the road model has added its frames to the list
     kargs_of(args).redo_pass = 1;
     const unsigned grid = (unsigned)(nl < (int64_t)kRedoGrid ? nl : (int64_t)kRedoGrid);
@@ -2759,7 +2761,10 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     if (rc) return rc;
     const bool want_exact = (waves_per_frame & MVOSR_WAVES_EXACT) != 0;
     const bool want_masked = (waves_per_frame & MVOSR_WAVES_EXACT_MASKED) != 0;
-    waves_per_frame &= ~(MVOSR_WAVES_EXACT | MVOSR_WAVES_EXACT_MASKED);
+    const bool hot_only = (waves_per_frame & MVOSR_WAVES_HOT_ONLY) != 0;
+    waves_per_frame &= ~(MVOSR_WAVES_EXACT | MVOSR_WAVES_EXACT_MASKED | MVOSR_WAVES_HOT_ONLY);
+    if (hot_only && (want_exact || want_masked)) return set_error(MVOSR_ERR_ARG, "scale_batch: MVOSR_WAVES_HOT_ONLY excludes the exact flags");
+    if (hot_only && (o->tri_normals || o->tri_pitch_deg || o->tri_heights)) return set_error(MVOSR_ERR_ARG, "scale_batch: MVOSR_WAVES_HOT_ONLY has no per-triangle outputs");
     if (!b->x || !b->y || !b->z || !b->v || !b->tri1_off || !b->tri2_off || !b->tri2)
         return set_error(MVOSR_ERR_ARG, "scale_batch: missing input plane / triangulation");
     if (!o->raw_scale || !o->height || !o->height_level || !o->status)
@@ -2779,7 +2784,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     int32_t *redo2 = ka.redo + b->n_frames + 1; // a second list: frames the road model ends on the fallback level
     // FULL: per-triangle debug outputs; EXACT: stage outputs requested (height_level bit-equal to NumPy's for every
     // frame); HOT: the product path + its exact pass over the frames that need it
-    const int mode = (o->tri_normals || o->tri_pitch_deg || o->tri_heights) ? MODE_FULL
+    const int mode = hot_only ? MODE_HOT : (o->tri_normals || o->tri_pitch_deg || o->tri_heights) ? MODE_FULL
                      : ((o->selected || o->vote_counters || want_exact) ? MODE_EXACT : MODE_HOT);
     const int waves = pick_waves(waves_per_frame, b->max_feat);
     RoadArgs ra;
@@ -2810,7 +2815,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
         if (!b->standin_keep || !b->standin_rows || !b->standin_cnt || !b->standin_status || !b->tri2_cnt || b->tri2_ids != MVOSR_TRI2_SURVIVORS)
             return set_error(MVOSR_ERR_ARG, "scale_batch: stand-in rows need standin_keep/_rows/_cnt/_status, tri2_cnt and survivor-numbered rows");
         if (dense) return set_error(MVOSR_ERR_TOO_LARGE, "scale_batch: stand-in rows are for frames that fit the LDS-resident kernels");
-        if (!(want_masked || (mode == MODE_HOT && !(debug_skip_env() & (16 | 512)))))
+        if (!(want_masked || hot_only || (mode == MODE_HOT && !(debug_skip_env() & (16 | 512)))))
             return set_error(MVOSR_ERR_ARG, "scale_batch: stand-in rows need the HOT mode (no stage outputs, no EXACT-for-all)");
     }
     auto standin_rows = [&](const int32_t *list) {
@@ -2833,15 +2838,17 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     // HOT: ONE exact pass per call (round 5; two before: one behind the HOT kernel, one behind the road model).  The HOT kernel
     // and the exact mask put their frames on the redo list; the road model runs over every other frame and APPENDS the frames that
     // end on the fallback level (:334-335; rare) to the same list; then the EXACT variant over the list, then the road model over it.
-    const bool fold = mode == MODE_HOT && !(debug_skip_env() & 16) && !(debug_skip_env() & 512);
+    const bool fold = mode == MODE_HOT && (hot_only || (!(debug_skip_env() & 16) && !(debug_skip_env() & 512)));
     if (by_class) {
         if ((rc = launch_scale_classes(ctx, ka, n_launch))) return rc;
-        if ((rc = launch_append_mask(ctx, ka, n_launch, true))) return rc;
+        if (!hot_only && (rc = launch_append_mask(ctx, ka, n_launch, true))) return rc;
         if (!fold && (rc = dispatch_scale(ctx, ka, waves, n_launch, kModeExactList))) return rc;
     } else {
         g_defer_exact = fold;
+        g_hot_only = hot_only;
         rc = dense ? launch_scale_dense(ctx, ka, n_launch, mode, false) : dispatch_scale(ctx, ka, waves, n_launch, mode);
         g_defer_exact = false;
+        g_hot_only = false;
         if (rc) return rc;
     }
     if (pev && (ee = hipEventRecord(pev[1], ctx_stream(ctx))) != hipSuccess) return set_hip_error("hipEventRecord(profile)", ee);
@@ -2851,6 +2858,7 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
         if (fold) {
             ra.level_redo = ka.redo;
             if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc;
+            if (hot_only) return MVOSR_OK;            // (the list's frames stay MVOSR_ST_REDO: the caller's)
             if (standin && (rc = standin_rows(ka.redo))) return rc;          // SciPy's own rows for the frames the exact pass redoes
             if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, kModeExactList, false) : dispatch_scale(ctx, ka, waves, n_launch, kModeExactList))) return rc;
             ra.level_redo = nullptr; ra.list = ka.redo;

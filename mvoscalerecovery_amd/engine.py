@@ -138,6 +138,7 @@ class DeviceBatch:
         self.n_frames = pf.n_frames
         self.max_feat = pf.max_feat
         self._feat_cnt_host = np.ascontiguousarray(pf.feat_cnt, dtype=np.int32)
+        self._feat_off_host = np.ascontiguousarray(pf.feat_off, dtype=np.int64)
         self.total_padded = pf.total_padded
         self.n_tri1 = int(pf.tri1_off[-1]) if pf.tri1_off is not None else 0
         self.n_tri2 = int(pf.tri2_off[-1]) if (with_tri2 and pf.tri2_off is not None) else 0
@@ -178,12 +179,14 @@ class DeviceBatch:
             self.set_tri2(pf)
         self._struct = None
 
-    def triangulate(self, engine, standin=False):
+    def triangulate(self, engine, standin=False, tri1_rows=None):
         """Delaunay #1 -> depth-order vote -> Delaunay #2 over the survivors (/root/reference/src/scale_calculator.py:
         257-267), three launches on the context's stream; rows, counters and counts stay in HBM.  ``standin`` (reference vote
         only; HOT launches without stage outputs, frames that fit the LDS-resident kernels): the second triangulation by the fast
         canonical-row kernel as a stand-in — its rows reach the result only through rounding, and mvosr_scale_batch replaces them
-        with SciPy's own (Qhull's replay over its exact pass's list) for exactly the frames in which rounding can decide."""
+        with SciPy's own (Qhull's replay over its exact pass's list) for exactly the frames in which rounding can decide.
+        ``tri1_rows`` (reference vote; the per-frame call): SciPy's rows of the first triangulation, one array per frame, computed
+        on the host — one replay of Qhull's run is 20 ms on the device whatever the frame count, SciPy's call 2.6."""
         ctx, lib, b = self.ctx, self.ctx.lib, self.bufs
         assert self.device_triangulation
         self.info.invalidate()
@@ -192,9 +195,21 @@ class DeviceBatch:
         if getattr(engine, "check_triangle", "reference") == "reference":
             # the reference's vote reads the ROTATION of every row (:113-115): SciPy's rows themselves, order and rotation, from
             # the kernel that replays Qhull's insertion order (mvosr_delaunay_qhull_batch)
-            _lib.check(lib.mvosr_delaunay_qhull_batch(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
-                                                      None, int(self.max_feat), b["tri_off"].ptr, b["tri1"].ptr, b["tri1_cnt"].ptr, None,
-                                                      b["dt1_status"].ptr, None), "mvosr_delaunay_qhull_batch (first triangulation)")
+            if tri1_rows is not None:
+                assert len(tri1_rows) == self.n_frames
+                cnt1 = np.zeros(max(self.n_frames, 1), dtype=np.int32)
+                for f, rows in enumerate(tri1_rows):              # (a frame's rows start at twice its feature offset)
+                    rows = np.ascontiguousarray(rows, dtype=np.int32)
+                    assert len(rows) <= 2 * int(self._feat_cnt_host[f])
+                    cnt1[f] = len(rows)
+                    if len(rows):
+                        _lib.check(lib.mvosr_memcpy_h2d(ctx.handle, b["tri1"].ptr + 12 * 2 * int(self._feat_off_host[f]), _lib.addr(rows), rows.nbytes), "h2d (tri1 rows)")
+                b["tri1_cnt"].upload(cnt1)
+                b["dt1_status"].upload(np.zeros(max(self.n_frames, 1), dtype=np.int32))
+            else:
+                _lib.check(lib.mvosr_delaunay_qhull_batch(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
+                                                          None, int(self.max_feat), b["tri_off"].ptr, b["tri1"].ptr, b["tri1_cnt"].ptr, None,
+                                                          b["dt1_status"].ptr, None), "mvosr_delaunay_qhull_batch (first triangulation)")
             o = _lib.Outputs()
             o.vote_counters = b["vote_counters"].ptr
             bs = self.struct()
@@ -381,14 +396,15 @@ class ScaleEngine:
         self.check_triangle = param_kw.get("check_triangle", "reference")
         self.params = make_params(absolute_reference, **param_kw)
 
-    def scale_batch(self, batch: DeviceBatch, out: DeviceOutputs, waves=0, first=0, count=0, exact=False, masked=False):
+    def scale_batch(self, batch: DeviceBatch, out: DeviceOutputs, waves=0, first=0, count=0, exact=False, masked=False, hot_only=False):
         """``exact``: every frame of the range in the exact mode; ``masked``: ONLY the frames of the batch's exact mask, in
-        the exact mode — the other frames' outputs stay as they are."""
+        the exact mode — the other frames' outputs stay as they are; ``hot_only``: the product kernels only (MVOSR_WAVES_HOT_ONLY):
+        frames the exact pass would redo come back with status ``_lib.ST_REDO``."""
         b, o = batch.struct(), out.struct()
         out.invalidate()
         if getattr(batch, "_marked", False):
             batch.mark(False)
-        flags = (_lib.WAVES_EXACT if exact else 0) | (_lib.WAVES_EXACT_MASKED if masked else 0)
+        flags = (_lib.WAVES_EXACT if exact else 0) | (_lib.WAVES_EXACT_MASKED if masked else 0) | (_lib.WAVES_HOT_ONLY if hot_only else 0)
         _lib.check(self.lib.mvosr_scale_batch(self.ctx.handle, C.byref(self.params), C.byref(b), C.byref(o),
                                               int(waves) | flags, int(first), int(count)), "mvosr_scale_batch")
 

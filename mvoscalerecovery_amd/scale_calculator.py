@@ -132,6 +132,27 @@ class ScaleEstimator:
             self.scale_queue.popleft()
         return out[0]
 
+    # ``height_level`` (:217,:241) as the reference leaves it on the estimator: NumPy's own double.  The per-frame call of the
+    # reference-exact device path (``_single_exact_fast``) knows it only in the kernel's summation order — equal to ~1e-16
+    # relative, not bit for bit — and leaves a thunk instead: whoever READS the attribute (the caller; the next frame's
+    # "no enough feature for triangulation" branch, :421) gets the exact value, computed then (one more SciPy call).
+    def _get_height_level(self):
+        d = self.__dict__
+        thunk = d.get("_level_thunk")
+        if thunk is not None:
+            d["_level_thunk"] = None
+            d["_level_value"] = thunk()
+        try:
+            return d["_level_value"]
+        except KeyError:
+            raise AttributeError("'ScaleEstimator' object has no attribute 'height_level'") from None
+
+    def _set_height_level(self, value):
+        self.__dict__["_level_value"] = value
+        self.__dict__["_level_thunk"] = None
+
+    height_level = property(_get_height_level, _set_height_level)
+
     def scale_calculation(self, feature3d, feature2d, img=None):
         """scale_calculator.py:411-423: returns (filtered scale, std)."""
         scales, stds = self.scale_calculation_batch([feature3d], [feature2d], _single=True)
@@ -285,7 +306,13 @@ class ScaleEstimator:
             # host: ~3 us per point and triangulation (SciPy), spread over the pool's workers — the break-even count of frames
             w = max(1, packing.resolve_workers(self.delaunay_workers))
             few_exact = F < max(self.GPU_EXACT_MIN_FRAMES, int(3.7 * w))
-        if self.triangulation == "gpu" and tri1s is None and tri2s is None and not few_exact:
+        fast = None
+        if few_exact and stage and F == 1 and tri1s is None and tri2s is None and self.GPU_EXACT_SINGLE_FAST:
+            fast = self._single_exact_fast(feature3ds, feature2ds)
+        lazy_level = None
+        if fast is not None:
+            raw, status, level, counts, host_errors, last, lazy_level = fast
+        elif self.triangulation == "gpu" and tri1s is None and tri2s is None and not few_exact:
             raw, status, level, counts, host_errors, last = self._stream_gpu(feature3ds, feature2ds, stage)
         elif tri1s is None and tri2s is None and not _single and F > self.PIPELINE_CHUNK:
             raw, status, level, counts, host_errors, last = self._stream_chunks(feature3ds, feature2ds)
@@ -299,6 +326,8 @@ class ScaleEstimator:
             self._chunk_free(last)
             return raw, status, level, host_errors
         filtered, stds, n_ok, raise_late = self._push(raw, status, level, host_errors, _single)
+        if lazy_level is not None and n_ok:
+            self.__dict__["_level_thunk"] = lazy_level          # (the value _push stored is the kernel's own sum: see height_level)
         if n_ok and stage:
             self._store_flat_feature(last["pf"], last["out"], feature3ds, feature2ds, last["masks"], n_ok - 1, status[n_ok - 1])
         elif n_ok:
@@ -468,6 +497,7 @@ class ScaleEstimator:
     GPU_EXACT_TWO_CONTEXTS = True   # check_triangle="reference": the chunks of a call alternate between two contexts (see _stream_gpu)
     GPU_EXACT_STANDIN = True    # check_triangle="reference": the second triangulation by the fast kernel as a stand-in; Qhull's own rows only for
                                 # the frames of the exact pass (engine.DeviceBatch.triangulate); False: Qhull's replay for every frame
+    GPU_EXACT_SINGLE_FAST = True    # check_triangle="reference", ONE frame per call: SciPy for the first triangulation only (see _single_exact_fast)
     GPU_EXACT_MIN_FRAMES = 8    # ... calls of fewer frames (or fewer than ~3.7 per Delaunay worker) take SciPy's triangulations (same rows, lower latency)
     GPU_EXACT_CHUNK = 16384     # check_triangle="reference" (the Qhull-rows kernel): frames per chunk, at most ...
     GPU_EXACT_CHUNK_POINTS = 33000000   # ... and features per chunk (~0.75 KB each on the device: 25 GB at the cap)
@@ -479,7 +509,7 @@ class ScaleEstimator:
                                         check_triangle=self.check_triangle)
         return self._engine2
 
-    def _chunk_gpu(self, f3s, f2s, stage, tables=False, eng=None):
+    def _chunk_gpu(self, f3s, f2s, stage, tables=False, eng=None, single_exact=False):
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
         ONE upload -> Delaunay #1, vote, Delaunay #2, scale kernel, road model, the exact re-runs known in advance and
         the download of the results, all queued; nothing is waited for here (``_chunk_gpu_finish`` does)."""
@@ -508,9 +538,27 @@ class ScaleEstimator:
             if blk is not None:
                 blk.free()
             return st
+        tri1_rows = None
+        if single_exact:
+            # the per-frame call of the reference-exact path: SciPy's own first triangulation (:257) from the host — the vote
+            # reads the rotation of its rows
+            tri1_rows = []
+            try:
+                for f2 in f2s:
+                    f2 = np.asarray(f2, dtype=np.float64)
+                    pts = f2[f2[:, 1] > self.vanish]                              # :252-254
+                    if len(pts) < 5:
+                        raise ValueError("too few points for the device path")
+                    tri1_rows.append(packing.delaunay_simplices(pts))
+            except Exception:              # (QhullError, tiny frames: the host's path deals with them as the reference does)
+                st["gpu"] = False
+                if blk is not None:
+                    blk.free()
+                return st
+        st["tri1_rows"] = tri1_rows
         db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk)
         try:
-            db.triangulate(eng, standin=self.GPU_EXACT_STANDIN and not stage)
+            db.triangulate(eng, standin=self.GPU_EXACT_STANDIN and (single_exact or not stage), tri1_rows=tri1_rows)
         except _lib.MvosrAllocError:
             # the triangulation kernels' workspace (frames x largest frame) did not fit next to whatever else lives on the
             # device: nothing was launched — this chunk takes the host's triangulations (MVOSR_ERR_ALLOC)
@@ -519,7 +567,8 @@ class ScaleEstimator:
             self.alloc_fallbacks = getattr(self, "alloc_fallbacks", 0) + 1
             return st
         out = DeviceOutputs(ctx, db, counts=True, stage=stage)
-        eng.scale_batch(db, out)                  # (the frames whose level a later step reads are on the batch's exact mask)
+        st["hot_only"] = bool(single_exact and getattr(db, "standin", False))
+        eng.scale_batch(db, out, hot_only=st["hot_only"])      # (the frames whose level a later step reads are on the batch's exact mask)
         out.prefetch()
         db.prefetch_info()
         db.mark()                     # the chunk's last launch is queued: its blocks' next users need not wait for later chunks
@@ -667,6 +716,51 @@ class ScaleEstimator:
             host_errors.update({a + f: e for f, e in r[4].items()})
         return raw, status, level, counts, host_errors, ps
 
+    def _single_exact_fast(self, feature3ds, feature2ds):
+        """ONE frame of the reference-exact path (the per-frame call of /root/reference/src/main.py:110-113) with ONE SciPy call
+        instead of two: the first triangulation by SciPy on the host (the vote reads its rows' rotation, :113-115; a replay of
+        Qhull's run on the device is 20 ms per frame however few the frames), the vote on the device, the second triangulation by
+        the fast kernel as a stand-in (its rows reach the result only through rounding), the product kernels alone
+        (MVOSR_WAVES_HOT_ONLY).  A frame in which rounding could decide — or whose level IS its result, or which raises, or whose
+        point set the fast kernel declines — comes back marked and takes the host's path (SciPy's second triangulation, exact
+        mode) as before.  ``height_level`` of a frame that went through is known in the kernel's summation order only: the
+        estimator gets a thunk that computes NumPy's own double when it is read.  Returns None when the frame is not for this
+        path, else (raw, status, level, counts, host_errors, state, thunk or None)."""
+        f3, f2 = feature3ds[0], feature2ds[0]
+        cap = min(int(self.engine.lib.mvosr_max_lds_features()), int(self.engine.lib.mvosr_delaunay_lds_points()))
+        if not (isinstance(f3, np.ndarray) and isinstance(f2, np.ndarray) and f2.ndim == 2 and 8 <= len(f2) <= cap):
+            return None
+        raw_in = np.array(f3, dtype=np.float64, copy=True)          # (before the in-place remap, :414: what the thunk re-runs)
+        f2_in = np.array(f2, dtype=np.float64, copy=True)
+        st = self._chunk_gpu([f3], [f2], True, single_exact=True)
+        went = bool(st["gpu"] and st.get("hot_only"))
+        raw, status, level, counts, host_errors = self._chunk_gpu_finish(st, [f3], [f2], keep=True)
+        if not went or self.last_declined or host_errors:
+            return raw, status, level, counts, host_errors, st, None          # (the host's path ran: everything exact)
+        if int(status[0]) not in (K.ST_MODE, K.ST_RIGHT, K.ST_MEDIAN):
+            # marked (_lib.ST_REDO), or a status whose level is read at once: the frame again, through the host's path
+            self._chunk_free(st)
+            sub = self._chunk_begin([f3], [f2], 0, tri1s=st["tri1_rows"], _remapped=st["remapped"])
+            self._chunk_vote(sub, None, 0)
+            raw, status, level, counts, host_errors = self._chunk_scale(sub, None, True, keep=True)
+            self.single_fast_redone = getattr(self, "single_fast_redone", 0) + 1
+            return raw, status, level, counts, host_errors, sub, None
+
+        rows1 = st["tri1_rows"]
+
+        def exact_level():
+            keep = self.mutate_inputs
+            self.mutate_inputs = False                  # (a private copy: nothing of the caller's to remap)
+            try:
+                sub = self._chunk_begin([raw_in], [f2_in], 0, tri1s=rows1, _exact_all=True)
+                self._chunk_vote(sub, None, 0)
+                _, _, lvl, _, _ = self._chunk_scale(sub, None, False)
+            finally:
+                self.mutate_inputs = keep
+            self.single_fast_levels = getattr(self, "single_fast_levels", 0) + 1
+            return lvl[0]
+        return raw, status, level, counts, host_errors, st, exact_level
+
     def _flat_feature_of(self, feature3d, feature2d, st):
         """``self.flat_feature`` / ``flat_feature_2d`` after a batch: the selected points of its last processed frame
         (:275-276,:416), by running that one frame again with the stage outputs.  With ``mutate_inputs`` the
@@ -715,16 +809,18 @@ class ScaleEstimator:
         # there is none
         sets_level = status[:err_at] != K.ST_TOO_FEW
         last_setter = np.maximum.accumulate(np.where(sets_level, np.arange(err_at), -1)) if err_at else np.zeros(0, dtype=np.int64)
-        before = getattr(self, "height_level", None)
+        before = []                  # (read only if a frame needs it: reading resolves a pending exact level — see height_level)
         for f in np.nonzero(~sets_level)[0]:
             g = int(last_setter[f])
-            lvl = level[g] if g >= 0 else before
+            if g < 0 and not before:
+                before.append(getattr(self, "height_level", None))
+            lvl = level[g] if g >= 0 else before[0]
             if lvl is None:
                 err_at, err = int(f), AttributeError("'ScaleEstimator' object has no attribute 'height_level'")
                 break
             with np.errstate(all="ignore"):
                 raw[f] = np.float64(self.absolute_reference) / np.float64(lvl)
-        cur_level = before
+        cur_level = None             # (None: no frame of the run set a level — the estimator's stays)
         if err_at and last_setter[err_at - 1] >= 0:
             cur_level = level[int(last_setter[err_at - 1])]                   # :241 of the last frame that reached it
         n_ok = err_at

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-frame calls of the device-resident estimators, for a kernel trace of ONE frame's chain:
-   rocprofv3 --kernel-trace -d gpurun_out/lat -o lat -- python3 profiles/latency_probe.py [rescale|scale] [frames] [features]
+   rocprofv3 --kernel-trace -d gpurun_out/lat -o lat -- python3 profiles/latency_probe.py [rescale|scale|exact] [frames] [features]
 prints the median wall time per call; profiles/sum_kernel_trace.py on the trace gives each kernel's share of it."""
 import os
 import sys
@@ -20,6 +20,10 @@ def main():
     if which == "rescale":
         from mvoscalerecovery_amd.rescale import ScaleEstimator
         est = ScaleEstimator(1.75, window_size=5, device=0, delaunay_workers=0, triangulation="gpu", ransac_seed=2024)
+    elif which == "exact":            # the default construction: the reference's result (one SciPy call per frame since round 5)
+        from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+        est = ScaleEstimator(1.75, window_size=5, device=0, delaunay_workers=0, triangulation="gpu", check_triangle="reference")
+        est.GPU_EXACT_SINGLE_FAST = os.environ.get("SINGLE_FAST", "1") == "1"
     else:
         from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
         est = ScaleEstimator(1.75, window_size=5, device=0, delaunay_workers=0, triangulation="gpu")
@@ -32,6 +36,8 @@ def main():
         est.scale_calculation(a, f2)
         t.append(time.perf_counter() - t0)
     t = np.array(t) * 1e3
+    if which == "exact":
+        print("   frames redone through the host's path: %d, exact levels computed on demand: %d" % (getattr(est, "single_fast_redone", 0), getattr(est, "single_fast_levels", 0)))
     print("%s: %d per-frame calls of %d features: median %.3f ms, p10 %.3f, p90 %.3f" % (which, frames, n, np.median(t), np.percentile(t, 10), np.percentile(t, 90)))
 
 

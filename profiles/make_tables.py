@@ -82,7 +82,7 @@ def render(tag):
             la = b["latency"]
             extra = (", `rescale` estimator device-resident %.2f ms" % la["rescale_gpu"]["median_ms"]) if "rescale_gpu" in la else ""
             if "gpu_exact" in la:
-                extra += ", `check_triangle=\"reference\"` with `triangulation=\"gpu\"` %.2f ms (a single frame takes SciPy's triangulations: the device chain is 37 ms)" % la["gpu_exact"]["median_ms"]
+                extra += ", `check_triangle=\"reference\"` with `triangulation=\"gpu\"` %.2f ms (the DEFAULT construction, the reference's result: SciPy for the first triangulation only, the second by the fast kernel as a stand-in — the device's replay of Qhull is 20 ms per triangulation for a single frame)" % la["gpu_exact"]["median_ms"]
             rows.append(("per-frame `scale_calculation` latency, 2000 features", "SciPy triangulations %.2f ms, device triangulations %.2f ms%s (median; 0 allocations per call)" % (la["scipy"]["median_ms"], la["gpu"]["median_ms"], extra), "`latency` in the bench line"))
         cb = b.get("cpu_baseline")
         if cb:

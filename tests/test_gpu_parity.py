@@ -2715,9 +2715,63 @@ def test_default_construction_is_the_fast_exact_path(gpu, monkeypatch):
     r, rd = ref.scale_calculation_batch([f[0].copy() for f in frames], [f[1] for f in frames])
     assert np.array_equal(s, r) and np.array_equal(sd, rd)
     one = ScaleEstimator(1.75, window_size=5, delaunay_workers=0)
-    host_frames.clear()
+    calls = []
+    real_delaunay = packing.delaunay_simplices
+    monkeypatch.setattr(packing, "delaunay_simplices", lambda pts: (calls.append(len(pts)), real_delaunay(pts))[1])
     assert one.scale_calculation(frames[0][0].copy(), frames[0][1]) == (r[0], rd[0])          # per-frame: SciPy's rows, same numbers
-    assert sum(host_frames) >= 1
+    assert len(calls) >= 1                                                                    # (the first triangulation at least: the vote reads its rows' rotation)
+
+
+def test_per_frame_call_of_the_exact_path_one_scipy_call(gpu, monkeypatch):
+    """The per-frame call of the default estimator (triangulation "gpu", check_triangle "reference"): SciPy for the FIRST
+    triangulation only, the second by the fast kernel as a stand-in under the product kernels (MVOSR_WAVES_HOT_ONLY); frames in
+    which rounding could decide are redone through the host's path.  A sequence against the oracle, frame by frame: scales, stds,
+    the window, flat_feature, the in-place remap — and height_level, which the fast path knows only in the kernel's summation
+    order: reading the attribute gives NumPy's own double (one more SciPy call, then), and so does the next frame's "no enough
+    feature for triangulation" branch (:263-270, :421), which reads it internally."""
+    from mvoscalerecovery_amd import packing, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    monkeypatch.delenv("MVOSR_TRIANGULATION")
+    est = ScaleEstimator(1.75, window_size=5, delaunay_workers=0)
+    assert (est.triangulation, est.check_triangle) == ("gpu", "reference")
+    ref = so.OracleScaleEstimator(1.75, window_size=5)
+    calls = []
+    real_delaunay = packing.delaunay_simplices
+    monkeypatch.setattr(packing, "delaunay_simplices", lambda pts: (calls.append(len(pts)), real_delaunay(pts))[1])
+    rng = np.random.default_rng(11)
+    with pytest.raises(AttributeError):
+        est.height_level
+    n_frames, fast, reads = 36, 0, 0
+    for i in range(n_frames):
+        f3, f2 = synth.synth_frame(i, int(rng.integers(300, 2001)), base_seed=1212, upper_fraction=0.1)
+        if i in (7, 19):                                 # exactly three features below the vanishing row: the previous frame's level
+            f2 = f2.copy()
+            low = np.nonzero(f2[:, 1] > est.vanish)[0]
+            f2[low[3:], 1] = est.vanish - 5.0
+        a3 = f3.copy()
+        calls.clear()
+        before_levels = getattr(est, "single_fast_levels", 0)
+        s, sd = est.scale_calculation(a3, f2)
+        rs, rsd = ref.scale_calculation(f3.copy(), f2)
+        assert (s, sd) == (rs, rsd), i
+        assert np.array_equal(a3, so.remap(f3)), i
+        assert list(est.scale_queue) == list(ref.scale_queue), i
+        if ref.flat_feature is None:
+            assert est.flat_feature is None
+        else:
+            assert np.array_equal(est.flat_feature, ref.flat_feature) and np.array_equal(est.flat_feature_2d, ref.flat_feature_2d), i
+        went_fast = est.__dict__.get("_level_thunk") is not None
+        if went_fast:
+            fast += 1
+            assert len(calls) == 1 + (getattr(est, "single_fast_levels", 0) - before_levels), (i, calls)     # ONE triangulation on the host (+ one if the frame before had to be finished)
+        if i % 3 == 0 or i in (6, 18):                   # read on some frames, not on others (6, 18: read by hand; 5 / 17 .. by the three-feature frame)
+            assert est.height_level == ref.height_level, i
+            reads += 1
+            assert est.__dict__.get("_level_thunk") is None
+    assert fast >= n_frames - 8, fast                      # (almost every frame takes the fast path)
+    assert est.height_level == ref.height_level
+    assert getattr(est, "single_fast_levels", 0) >= 1
 
 
 def test_qhull_rows_kernel_hostile_inputs_are_declined(gpu):
