@@ -2774,6 +2774,40 @@ def test_per_frame_call_of_the_exact_path_one_scipy_call(gpu, monkeypatch):
     assert getattr(est, "single_fast_levels", 0) >= 1
 
 
+def test_per_frame_exact_path_on_the_fuzz_frames(gpu, monkeypatch):
+    """The frame-level fuzz set (duplicates, tied depths, walls, tiny frames, negative heights, the level at zero) through the
+    per-frame call of the default estimator, one frame after the other on ONE estimator: what each call returns or raises, the
+    window and height_level after it — the one-SciPy-call path (frames it cannot finish come back marked and take the host's
+    path) against the two-SciPy-call path, and the first 60 against the reference's own results (tests/golden/frame_fuzz.npz)."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    monkeypatch.delenv("MVOSR_TRIANGULATION")
+    a = ScaleEstimator(1.75, window_size=5, delaunay_workers=0)
+    b = ScaleEstimator(1.75, window_size=5, delaunay_workers=0)
+    assert (a.triangulation, a.check_triangle, a.GPU_EXACT_SINGLE_FAST) == ("gpu", "reference", True)
+    b.GPU_EXACT_SINGLE_FAST = False
+
+    def eq(p, q):
+        if p is None or q is None or isinstance(p, str):
+            return p == q
+        return np.array_equal(np.asarray(p, dtype=np.float64), np.asarray(q, dtype=np.float64), equal_nan=True)
+
+    fast = 0
+    for i in list(range(150)) + list(range(400, 440)):
+        f3, f2 = synth.fuzz_frame(i)
+        outs = []
+        for est in (a, b):
+            try:
+                outs.append(("ok", est.scale_calculation(f3.copy(), f2)))
+            except Exception as exc:                     # noqa: BLE001
+                outs.append(("raised", type(exc).__name__))
+        fast += a.__dict__.get("_level_thunk") is not None
+        assert outs[0][0] == outs[1][0] and eq(outs[0][1], outs[1][1]), (i, outs)
+        assert eq(list(a.scale_queue), list(b.scale_queue)), i
+        assert eq(getattr(a, "height_level", None), getattr(b, "height_level", None)), i
+    assert fast >= 40 and getattr(a, "single_fast_redone", 0) >= 20          # both routes were taken
+
+
 def test_qhull_rows_kernel_hostile_inputs_are_declined(gpu):
     """NaN / infinite / huge / identical / collinear sites, a mask that keeps fewer than three points: the kernel declines (status
     != 0, no rows) — it neither hangs nor writes outside its frame — and the sets around them are untouched."""
