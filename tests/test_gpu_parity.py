@@ -1115,11 +1115,17 @@ def test_road_long_lists_kernel(gpu):
         assert stats[k, 2] == c["skew"], (k, stats[k, 2], c["skew"])
 
 
-def test_frame_fuzz_through_drop_in(gpu):
+@pytest.mark.parametrize("default_construction", [False, True])
+def test_frame_fuzz_through_drop_in(gpu, monkeypatch, default_construction):
     """The drop-in class on the 400 adversarial frames of tests/golden/frame_fuzz.npz: the scale the
-    reference returned (bit-equal, also where it is ref/height_level) or the exception it raised."""
+    reference returned (bit-equal, also where it is ref/height_level) or the exception it raised.  ``default_construction``:
+    as the reference's drivers construct it — device triangulations, the reference's vote; per frame: SciPy for the first
+    triangulation only — instead of the suite's host-SciPy setting."""
     from mvoscalerecovery_amd import constants as K, synth
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    if default_construction:
+        monkeypatch.delenv("MVOSR_TRIANGULATION")
+        assert ScaleEstimator(1.75, window_size=5, device=gpu.device).check_triangle == "reference"
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_fuzz.npz"))
     names = list(z["exception_names"])
     seen = set()
@@ -2778,7 +2784,8 @@ def test_per_frame_exact_path_on_the_fuzz_frames(gpu, monkeypatch):
     """The frame-level fuzz set (duplicates, tied depths, walls, tiny frames, negative heights, the level at zero) through the
     per-frame call of the default estimator, one frame after the other on ONE estimator: what each call returns or raises, the
     window and height_level after it — the one-SciPy-call path (frames it cannot finish come back marked and take the host's
-    path) against the two-SciPy-call path, and the first 60 against the reference's own results (tests/golden/frame_fuzz.npz)."""
+    path) against the two-SciPy-call path (the reference's own results for these frames, on fresh estimators:
+    test_frame_fuzz_through_drop_in[True])."""
     from mvoscalerecovery_amd import synth
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
     monkeypatch.delenv("MVOSR_TRIANGULATION")
