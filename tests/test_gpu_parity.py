@@ -1571,13 +1571,19 @@ def test_seq200_golden_through_driver(gpu):
     np.testing.assert_array_equal(res1["scales"], z["scales"][:25])
 
 
-def test_main_offline_files_golden(gpu, tmp_path):
+@pytest.mark.parametrize("default_construction", [False, True])
+def test_main_offline_files_golden(gpu, tmp_path, monkeypatch, default_construction):
     """What /root/reference/src/main_offline.py itself writes for the synthetic 200-frame dict (scales.txt, path.txt:
     tests/golden/seq200_main_offline.npz), reproduced by the drop-in estimator behind the build's driver — frame at a
-    time, batched (streaming) and sharded-driver (one rank) — value for value."""
+    time, batched (streaming) and sharded-driver (one rank) — value for value.  ``default_construction``: the estimator as the
+    reference's drivers construct it (device triangulations and the reference's vote: Qhull's replay for the batches, one SciPy
+    call per frame for the frame-at-a-time run) instead of the suite's host-SciPy setting."""
     import zlib
     from mvoscalerecovery_amd import offline, synth
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    if default_construction:
+        monkeypatch.delenv("MVOSR_TRIANGULATION")
+        assert ScaleEstimator(1.75, window_size=5).check_triangle == "reference"
     z, meta = load_npz("seq200_main_offline.npz")
     data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
     for k, runner in enumerate((offline.run_sequence, offline.run_sequence_batched, offline.run_sequence_sharded)):
