@@ -593,7 +593,7 @@ template <typename FID, int G, int TAB> __device__ __forceinline__ int qh_run(co
         auto pos2id = [&](int pos) { return pos >= 4 || perm0 == 0 ? pos + 1 : (pos == 0 ? perm0 : (pos < perm0 ? pos : pos + 1)); };
         int pos = 0, step = 0;
 #ifdef MVOSR_QH_STAMPS
-        unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // 0..6 sections; 8..10 / 11..13: partition + placement clocks / insertions with S = 0, 1..64, more
         unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
         while (true) {
@@ -770,6 +770,9 @@ template <typename FID, int G, int TAB> __device__ __forceinline__ int qh_run(co
                 qh_lds_sync();
             }
             QH_STAMP(3);
+#ifdef MVOSR_QH_STAMPS
+            const unsigned long long t_part0 = t_last;
+#endif
             // (e) qh_partitionvisible: the visible facets' points, in list order, to the cone
             int S = 0;
             {
@@ -854,6 +857,9 @@ template <typename FID, int G, int TAB> __device__ __forceinline__ int qh_run(co
                 qh_lds_sync();
             }
             QH_STAMP(5);
+#ifdef MVOSR_QH_STAMPS
+            { const int c_ = S == 0 ? 0 : (S <= 64 ? 1 : 2); acc[8 + c_] += t_last - t_part0; acc[11 + c_] += 1; }
+#endif
             // (f) the cone's facet records; the visible facets die
             for (int jb = 0; jb < m; jb += G) {
                 const int j = jb + lane;
@@ -874,7 +880,7 @@ template <typename FID, int G, int TAB> __device__ __forceinline__ int qh_run(co
             QH_STAMP(6);
         }
 #ifdef MVOSR_QH_STAMPS
-        if (a.stamps && f == 0 && lane == 0) { for (int k = 0; k < 8; ++k) a.stamps[k] = acc[k]; a.stamps[8] = (unsigned long long)step; }
+        if (a.stamps && f == 0 && lane == 0) { for (int k = 0; k < 8; ++k) a.stamps[k] = acc[k]; a.stamps[8] = (unsigned long long)step; for (int k = 8; k < 14; ++k) a.stamps[k + 8] = acc[k]; }
 #endif
         // ---- 4. SciPy's rows: lower facets in list order; vertices by decreasing vertex id, first two swapped unless top ----
         const int64_t toff = a.tri_off[f];

@@ -19,7 +19,7 @@ def main():
     ctx = _lib.Context(0)
     lib = ctx.lib
     lib.mvosr_debug_qh_stamps.argtypes = [C.c_void_p]
-    d_stamps = ctx.zeros(16, np.uint64)
+    d_stamps = ctx.zeros(32, np.uint64)
     lib.mvosr_debug_qh_stamps(d_stamps.ptr)
     pool = [synth.synth_frame(s, n, base_seed=999)[1] for s in range(min(frames, 256))]
     sets = [pool[s % len(pool)] for s in range(frames)]
@@ -40,6 +40,15 @@ def main():
     print("%d resident frames of %d points; frame 0: %d insertions, %.0f clocks per insertion" % (frames, n, steps, tot / max(steps, 1)))
     for k in range(7):
         print("  %-20s %5.1f %%  %8.0f clocks per insertion" % (NAMES[k], 100.0 * st[k] / tot, st[k] / max(steps, 1)))
+    by_size(st)
+
+
+def by_size(st):
+    names = ["no points to place", "1..64 points", "more than 64"]
+    for c in range(3):
+        n = float(st[19 + c])
+        if n:
+            print("  partition + placement, %-20s %6.0f insertions, %8.0f clocks each (%4.1f %% of the run)" % (names[c], n, st[16 + c] / n, 100.0 * st[16 + c] / max(float(st[:7].sum()), 1.0)))
 
 
 if __name__ == "__main__":
