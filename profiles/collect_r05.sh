@@ -12,6 +12,11 @@ timeout 900 python bench.py --features 20000 > $OUT/r05_bench_dense.json 2> $OUT
 QH_FRAMES=512,4096,16384 timeout 300 python profiles/qhull_gpu_check.py 2048 2000 > $OUT/r05_qhull_check.txt 2>&1
 QH_FRAMES=8192,32768 timeout 300 python profiles/qhull_gpu_check.py 2048 0 | tail -2 >> $OUT/r05_qhull_check.txt 2>&1
 timeout 300 python profiles/e2e_exact_probe.py 32768 2000 > $OUT/r05_e2e_exact_probe.txt 2>&1
+# per-frame calls: the three estimators' chains (median wall time), the one-frame triangulation launches with and without PARTS
+: > $OUT/r05_latency_probe.txt
+for w in rescale scale exact; do timeout 120 python profiles/latency_probe.py $w 200 2000 >> $OUT/r05_latency_probe.txt 2>&1; done
+SINGLE_FAST=0 timeout 120 python profiles/latency_probe.py exact 200 2000 | sed 's/^exact:/exact (two SciPy calls, the path before):/' >> $OUT/r05_latency_probe.txt 2>&1
+for n in 900 2000 4000; do timeout 60 python profiles/dt_parts_probe.py $n | grep MVOSR >> $OUT/r05_latency_probe.txt 2>&1; MVOSR_DT_PARTS=0 timeout 60 python profiles/dt_parts_probe.py $n | grep MVOSR >> $OUT/r05_latency_probe.txt 2>&1; done
 : > $OUT/r05_delaunay_bench.jsonl
 for a in "" "--seeded --keep 0.95" "--seeded --keep 0.85" "--points 900 --sets 8192" "--points 900 --sets 8192 --seeded --keep 0.95" \
          "--ragged 300:1500 --sets 8192" "--ragged 300:1500 --sets 8192 --seeded --keep 0.95"; do

@@ -42,6 +42,6 @@ for name, fn in (("first", first), ("seeded second (95 % kept, carried stars)", 
         fn()
     ctx.sync()
     dt = (time.perf_counter() - t0) / 200
-    print("MVOSR_DT_PARTS=%s NOHINT=%s  %d points, %s: %.1f us per launch (status %d, rows %d)" % (
-        os.environ.get("MVOSR_DT_PARTS", "auto"), os.environ.get("MVOSR_DT_NOHINT", "-"), n, name, dt * 1e6,
+    print("MVOSR_DT_PARTS=%s  %d points, %s: %.1f us per launch (status %d, rows %d)" % (
+        os.environ.get("MVOSR_DT_PARTS", "auto"), n, name, dt * 1e6,
         int((st if fn is first else st2).download()[0]), int((tc if fn is first else tc2).download()[0])))
