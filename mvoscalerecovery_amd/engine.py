@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -66,6 +68,7 @@ def frame_tables(feature3ds, feature2ds, remap_in_place=False):
     return tables
 
 
+STANDIN_SEEDED = os.environ.get("MVOSR_STANDIN_SEEDED", "1") == "1"   # the stand-in second triangulation seeded with the first one's rows (Qhull's: any row form seeds)
 UPLOAD_PIECES = 4              # pieces a chunk's upload is cut into (pack_upload_native) ...
 UPLOAD_PIECE_FRAMES = 256      # ... of at least that many frames
 
@@ -218,7 +221,8 @@ class DeviceBatch:
                 _lib.check(lib.mvosr_delaunay_batch_ex(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
                                                        b["vote_counters"].ptr, int(self.max_feat), b["tri_off"].ptr, b["tri2"].ptr,
                                                        b["tri2_cnt"].ptr, b["n2_expected"].ptr, b["dt2_status"].ptr,
-                                                       None, None, None, None, None), "mvosr_delaunay_batch_ex (stand-in second triangulation)")
+                                                       *((b["tri_off"].ptr, b["tri1"].ptr, b["tri1_cnt"].ptr) if STANDIN_SEEDED else (None, None, None)),
+                                                       None, None), "mvosr_delaunay_batch_ex (stand-in second triangulation)")
                 self.standin = True
                 self._struct = None
                 return
