@@ -1618,6 +1618,25 @@ def test_seq4541_golden_batched(gpu):
     np.testing.assert_array_equal(res["pitchs"], z["pitchs"])
 
 
+def test_seq4541_golden_frame_at_a_time_default_construction(gpu, monkeypatch):
+    """Config C3 as the reference's online loop runs it (/root/reference/src/main.py:110-113): the 4541-frame golden through the
+    frame-at-a-time driver with the estimator as the drivers construct it — per frame ONE SciPy call, the second triangulation by
+    the fast kernel as a stand-in, the product kernels alone: every filtered scale equals the reference's."""
+    from mvoscalerecovery_amd import offline, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    monkeypatch.delenv("MVOSR_TRIANGULATION")
+    z, meta = load_npz("seq4541.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, delaunay_workers=0)
+    assert (est.triangulation, est.check_triangle, est.GPU_EXACT_SINGLE_FAST) == ("gpu", "reference", True)
+    res = offline.run_sequence(data, est)
+    assert np.array_equal(res["kinds"], z["kinds"])
+    np.testing.assert_array_equal(res["scales"], z["scales"])
+    np.testing.assert_array_equal(res["error"], z["error"])
+    np.testing.assert_array_equal(res["pitchs"], z["pitchs"])
+    assert getattr(est, "single_fast_redone", 0) <= 0.05 * meta["n_frames"]       # (the one-SciPy-call path carried the sequence)
+
+
 def test_rccl_gather_and_gpu_median_world1(gpu, tmp_path):
     """The multi-GPU step on one GPU: torch.distributed `nccl` (= RCCL) group of size 1, all-gather of
     device tensors, window-median kernel on the stream torch and the context share."""
