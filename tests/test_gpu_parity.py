@@ -553,8 +553,10 @@ def test_delaunay_parts_variant_equals_one_workgroup(gpu, monkeypatch):
         a = run(sets, frac)
         monkeypatch.setenv("MVOSR_DT_PARTS", "0")
         b = run(sets, frac)
-        for k in ("c1", "c2", "s1", "s2", "used"):
+        for k in ("c1", "c2", "used"):
             assert np.array_equal(a[k], b[k]), (k, [len(q) for q in sets])
+        for k in ("s1", "s2"):               # (the code; the reason bits above it say which of a declined frame's failing tests fired first)
+            assert np.array_equal(a[k] & 0xFF, b[k] & 0xFF), (k, [len(q) for q in sets])
         for f, q in enumerate(sets):
             lo = int(2 * a["off"][f])
             assert np.array_equal(a["t1"][lo:lo + a["c1"][f]], b["t1"][lo:lo + b["c1"][f]]), f
