@@ -27,8 +27,12 @@ def run(ctx, sets, keep):
                                                None, s1.ptr, None, None, None, None, info.ptr), "first")
     _lib.check(ctx.lib.mvosr_delaunay_batch_ex(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr, t2.ptr, c2.ptr,
                                                None, s2.ptr, d_toff.ptr, t1.ptr, c1.ptr, info.ptr, None), "second")
-    out = [x.download() for x in (t1, t2, c1, c2, s1, s2, info)]
-    for b in (d_u, d_v, d_off, d_cnt, d_toff, d_keep, t1, t2, c1, c2, s1, s2, info):
+    # ... and seeded without the per-point words (no carried stars: the exact path's stand-in, seeded with Qhull's rows)
+    t3, c3, s3 = ctx.empty((rows, 3), np.int32), ctx.zeros(F, np.int32), ctx.zeros(F, np.int32)
+    _lib.check(ctx.lib.mvosr_delaunay_batch_seeded(ctx.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr, t3.ptr, c3.ptr,
+                                                   None, s3.ptr, d_toff.ptr, t1.ptr, c1.ptr), "second, seeds only")
+    out = [x.download() for x in (t1, t2, c1, c2, s1, s2, info, t3, c3, s3)]
+    for b in (d_u, d_v, d_off, d_cnt, d_toff, d_keep, t1, t2, c1, c2, s1, s2, info, t3, c3, s3):
         b.free()
     return out, off
 
@@ -57,6 +61,8 @@ def main():
         for f in range(F):
             lo = int(2 * off[f])
             same = same and np.array_equal(a[0][lo:lo + a[2][f]], c[0][lo:lo + c[2][f]]) and np.array_equal(a[1][lo:lo + a[3][f]], c[1][lo:lo + c[3][f]])
+            # (seeds only: the same rows as with carried stars, in both launch shapes)
+            same = same and a[8][f] == c[8][f] == a[3][f] and np.array_equal(a[7][lo:lo + a[8][f]], a[1][lo:lo + a[3][f]]) and np.array_equal(c[7][lo:lo + c[8][f]], a[1][lo:lo + a[3][f]])
             if a[4][f] == 0:
                 same = same and np.array_equal(a[6][off[f]:off[f] + len(sets[f])], c[6][off[f]:off[f] + len(sets[f])])
         if not same:
