@@ -347,6 +347,26 @@ def test_product_fails_loudly_without_gpu():
         ScaleEstimator(1.75, window_size=5)
 
 
+def test_height_level_attribute_is_exact_on_read():
+    """``ScaleEstimator.height_level`` (/root/reference/src/scale_calculator.py:217,:241 leave it on the estimator): a plain
+    attribute to its users — AttributeError before the first frame, what was assigned afterwards — whose value may be PENDING
+    after a per-frame call of the reference-exact path (known in the kernel's summation order only): the pending computation
+    runs once, when the attribute is read, and a later assignment replaces it unread.  (Host logic only: no device.)"""
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    est = ScaleEstimator.__new__(ScaleEstimator)
+    with pytest.raises(AttributeError, match="height_level"):
+        est.height_level
+    assert getattr(est, "height_level", None) is None and not hasattr(est, "height_level")
+    est.height_level = 1.5
+    assert est.height_level == 1.5 and hasattr(est, "height_level")
+    calls = []
+    est.__dict__["_level_thunk"] = lambda: (calls.append(1), 2.25)[1]
+    assert est.height_level == 2.25 and est.height_level == 2.25 and calls == [1]
+    est.__dict__["_level_thunk"] = lambda: (calls.append(2), 9.0)[1]
+    est.height_level = 3.0                                  # the next frame's level: the pending one is never computed
+    assert est.height_level == 3.0 and calls == [1]
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "mvoscalerecovery_amd")
     for fn in os.listdir(pkg):
