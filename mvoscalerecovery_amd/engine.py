@@ -343,6 +343,8 @@ class DeviceOutputs:
                 zero = True
         if stage:
             spec += [("vote_counters", batch.total_padded, np.int32), ("selected", batch.total_padded, np.uint8)]
+            if F == 1:                   # (the per-frame call: the window median of its one raw scale travels with the results)
+                spec.append(("filtered", 1, np.float64))
             zero = True
         if per_triangle:
             t2 = max(batch.n_tri2, 1)

@@ -325,7 +325,11 @@ class ScaleEstimator:
         if _raw_only:
             self._chunk_free(last)
             return raw, status, level, host_errors
-        filtered, stds, n_ok, raise_late = self._push(raw, status, level, host_errors, _single)
+        hint = None
+        if stage and F == 1 and isinstance(last, dict) and last.get("filtered_queue") is not None and last.get("out") is not None \
+                and "filtered" in last["out"].bufs and last["filtered_queue"] == list(self.scale_queue):
+            hint = last["out"].get("filtered")
+        filtered, stds, n_ok, raise_late = self._push(raw, status, level, host_errors, _single, filtered_hint=hint)
         if lazy_level is not None and n_ok:
             self.__dict__["_level_thunk"] = lazy_level          # (the value _push stored is the kernel's own sum: see height_level)
         if n_ok and stage:
@@ -569,6 +573,12 @@ class ScaleEstimator:
         out = DeviceOutputs(ctx, db, counts=True, stage=stage)
         st["hot_only"] = bool(single_exact and getattr(db, "standin", False))
         eng.scale_batch(db, out, hot_only=st["hot_only"])      # (the frames whose level a later step reads are on the batch's exact mask)
+        if stage and pf.n_frames == 1 and "filtered" in out.bufs:
+            # the per-frame call: the window median (:396-400) of this frame's raw scale over the estimator's queue, queued behind the
+            # kernels that produce it — its result arrives with theirs instead of costing an upload, a launch and a download after them
+            # (64 us per call).  Used when the frame turns out to be an ordinary one (_push decides).
+            eng.window_median(out.bufs["raw_scale"].ptr, 1, self.window_size, list(self.scale_queue), out.bufs["filtered"].ptr)
+            st["filtered_queue"] = list(self.scale_queue)
         out.prefetch()
         db.prefetch_info()
         db.mark()                     # the chunk's last launch is queued: its blocks' next users need not wait for later chunks
@@ -625,7 +635,7 @@ class ScaleEstimator:
                 self._chunk_vote(one, None, 0)
                 self._chunk_scale(one, None, True, keep=True)
                 self._chunk_free(st)
-                st.update(out=one["out"], dbatch=one["dbatch"], masks=one["masks"], pf=one["pf"])
+                st.update(out=one["out"], dbatch=one["dbatch"], masks=one["masks"], pf=one["pf"], filtered_queue=None)
         if not keep:
             self._chunk_free(st)
         return raw, status, level, counts, host_errors
@@ -791,7 +801,7 @@ class ScaleEstimator:
         finally:
             self.mutate_inputs = mutate
 
-    def _push(self, raw, status, level, host_errors, single=False):
+    def _push(self, raw, status, level, host_errors, single=False, filtered_hint=None):
         """The cross-frame half of scale_calculation for a run of frames (:396-400, :413-422): window
         median over the raw scales up to the first frame at which the reference would have raised,
         queue update, ``height_level`` of the last good frame.  Returns ``(filtered, stds, n_ok,
@@ -825,7 +835,10 @@ class ScaleEstimator:
             cur_level = level[int(last_setter[err_at - 1])]                   # :241 of the last frame that reached it
         n_ok = err_at
         stds = np.where((status[:n_ok] == K.ST_NO_FLAT) | (status[:n_ok] == K.ST_TOO_FEW), 100, 1).astype(np.float64)   # :413,:333-354
-        filtered = self.engine.window_median_host(raw[:n_ok], self.window_size, list(self.scale_queue))   # :396-400
+        if filtered_hint is not None and F == 1 and n_ok == 1 and status[0] != K.ST_TOO_FEW:
+            filtered = np.array(filtered_hint, dtype=np.float64, copy=True)             # (computed on the device behind the frame's kernels)
+        else:
+            filtered = self.engine.window_median_host(raw[:n_ok], self.window_size, list(self.scale_queue))   # :396-400
         # (the deque after n_ok appends with popleft beyond window_size: its last window_size entries — no loop over the run)
         tail = list(self.scale_queue) + [s for s in raw[max(0, n_ok - self.window_size):n_ok]]
         self.scale_queue.clear()
