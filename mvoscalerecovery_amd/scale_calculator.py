@@ -309,6 +309,9 @@ class ScaleEstimator:
         fast = None
         if few_exact and stage and F == 1 and tri1s is None and tri2s is None and self.GPU_EXACT_SINGLE_FAST:
             fast = self._single_exact_fast(feature3ds, feature2ds)
+        if fast is None and stage and F == 1 and tri1s is None and tri2s is None and self.GPU_SINGLE_HOT and \
+                self.triangulation == "gpu" and self.check_triangle == "fixed":
+            fast = self._single_exact_fast(feature3ds, feature2ds, fixed=True)
         lazy_level = None
         if fast is not None:
             raw, status, level, counts, host_errors, last, lazy_level = fast
@@ -501,6 +504,7 @@ class ScaleEstimator:
     GPU_EXACT_TWO_CONTEXTS = True   # check_triangle="reference": the chunks of a call alternate between two contexts (see _stream_gpu)
     GPU_EXACT_STANDIN = True    # check_triangle="reference": the second triangulation by the fast kernel as a stand-in; Qhull's own rows only for
                                 # the frames of the exact pass (engine.DeviceBatch.triangulate); False: Qhull's replay for every frame
+    GPU_SINGLE_HOT = True           # check_triangle="fixed", ONE frame per call: the product kernels only, height_level exact when read (see _single_exact_fast)
     GPU_EXACT_SINGLE_FAST = True    # check_triangle="reference", ONE frame per call: SciPy for the first triangulation only (see _single_exact_fast)
     GPU_EXACT_MIN_FRAMES = 8    # ... calls of fewer frames (or fewer than ~3.7 per Delaunay worker) take SciPy's triangulations (same rows, lower latency)
     GPU_EXACT_CHUNK = 16384     # check_triangle="reference" (the Qhull-rows kernel): frames per chunk, at most ...
@@ -513,7 +517,7 @@ class ScaleEstimator:
                                         check_triangle=self.check_triangle)
         return self._engine2
 
-    def _chunk_gpu(self, f3s, f2s, stage, tables=False, eng=None, single_exact=False):
+    def _chunk_gpu(self, f3s, f2s, stage, tables=False, eng=None, single_exact=False, hot_only=False):
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
         ONE upload -> Delaunay #1, vote, Delaunay #2, scale kernel, road model, the exact re-runs known in advance and
         the download of the results, all queued; nothing is waited for here (``_chunk_gpu_finish`` does)."""
@@ -571,7 +575,7 @@ class ScaleEstimator:
             self.alloc_fallbacks = getattr(self, "alloc_fallbacks", 0) + 1
             return st
         out = DeviceOutputs(ctx, db, counts=True, stage=stage)
-        st["hot_only"] = bool(single_exact and getattr(db, "standin", False))
+        st["hot_only"] = bool((single_exact and getattr(db, "standin", False)) or hot_only)
         eng.scale_batch(db, out, hot_only=st["hot_only"])      # (the frames whose level a later step reads are on the batch's exact mask)
         if stage and pf.n_frames == 1 and "filtered" in out.bufs:
             # the per-frame call: the window median (:396-400) of this frame's raw scale over the estimator's queue, queued behind the
@@ -726,7 +730,7 @@ class ScaleEstimator:
             host_errors.update({a + f: e for f, e in r[4].items()})
         return raw, status, level, counts, host_errors, ps
 
-    def _single_exact_fast(self, feature3ds, feature2ds):
+    def _single_exact_fast(self, feature3ds, feature2ds, fixed=False):
         """ONE frame of the reference-exact path (the per-frame call of /root/reference/src/main.py:110-113) with ONE SciPy call
         instead of two: the first triangulation by SciPy on the host (the vote reads its rows' rotation, :113-115; a replay of
         Qhull's run on the device is 20 ms per frame however few the frames), the vote on the device, the second triangulation by
@@ -735,36 +739,45 @@ class ScaleEstimator:
         point set the fast kernel declines — comes back marked and takes the host's path (SciPy's second triangulation, exact
         mode) as before.  ``height_level`` of a frame that went through is known in the kernel's summation order only: the
         estimator gets a thunk that computes NumPy's own double when it is read.  Returns None when the frame is not for this
-        path, else (raw, status, level, counts, host_errors, state, thunk or None)."""
+        path, else (raw, status, level, counts, host_errors, state, thunk or None).  ``fixed`` (check_triangle="fixed": both
+        triangulations are the device's own, no SciPy): the same arrangement for the sake of the product kernels alone — the exact
+        mode's level in NumPy's pairwise order is 107 us of a 0.8 ms call."""
         f3, f2 = feature3ds[0], feature2ds[0]
         cap = min(int(self.engine.lib.mvosr_max_lds_features()), int(self.engine.lib.mvosr_delaunay_lds_points()))
         if not (isinstance(f3, np.ndarray) and isinstance(f2, np.ndarray) and f2.ndim == 2 and 8 <= len(f2) <= cap):
             return None
         raw_in = np.array(f3, dtype=np.float64, copy=True)          # (before the in-place remap, :414: what the thunk re-runs)
         f2_in = np.array(f2, dtype=np.float64, copy=True)
-        st = self._chunk_gpu([f3], [f2], True, single_exact=True)
+        st = self._chunk_gpu([f3], [f2], True, single_exact=not fixed, hot_only=fixed)
         went = bool(st["gpu"] and st.get("hot_only"))
         raw, status, level, counts, host_errors = self._chunk_gpu_finish(st, [f3], [f2], keep=True)
         if not went or self.last_declined or host_errors:
             return raw, status, level, counts, host_errors, st, None          # (the host's path ran: everything exact)
-        if int(status[0]) not in (K.ST_MODE, K.ST_RIGHT, K.ST_MEDIAN):
+        sets_level = int(status[0]) in (K.ST_MODE, K.ST_RIGHT, K.ST_MEDIAN)
+        if fixed and int(status[0]) in (K.ST_TOO_FEW, K.ST_ERR_SINGULAR, K.ST_ERR_MASK, K.ST_ERR_EMPTY):
+            return raw, status, level, counts, host_errors, st, None          # (final as it is: no level of this frame is read)
+        if not sets_level:
             # marked (_lib.ST_REDO), or a status whose level is read at once: the frame again, through the host's path
             self._chunk_free(st)
-            sub = self._chunk_begin([f3], [f2], 0, tri1s=st["tri1_rows"], _remapped=st["remapped"])
+            sub = self._chunk_begin([f3], [f2], 0, tri1s=st.get("tri1_rows"), _remapped=st["remapped"])
             self._chunk_vote(sub, None, 0)
             raw, status, level, counts, host_errors = self._chunk_scale(sub, None, True, keep=True)
             self.single_fast_redone = getattr(self, "single_fast_redone", 0) + 1
             return raw, status, level, counts, host_errors, sub, None
 
-        rows1 = st["tri1_rows"]
+        rows1 = st.get("tri1_rows")
 
         def exact_level():
             keep = self.mutate_inputs
             self.mutate_inputs = False                  # (a private copy: nothing of the caller's to remap)
             try:
-                sub = self._chunk_begin([raw_in], [f2_in], 0, tri1s=rows1, _exact_all=True)
-                self._chunk_vote(sub, None, 0)
-                _, _, lvl, _, _ = self._chunk_scale(sub, None, False)
+                if fixed:               # (the device's own triangulations again, the frame on the exact mask this time)
+                    _, _, lvl, _, _, ps = self._stream_gpu([raw_in], [f2_in], False)
+                    self._chunk_free(ps)
+                else:
+                    sub = self._chunk_begin([raw_in], [f2_in], 0, tri1s=rows1, _exact_all=True)
+                    self._chunk_vote(sub, None, 0)
+                    _, _, lvl, _, _ = self._chunk_scale(sub, None, False)
             finally:
                 self.mutate_inputs = keep
             self.single_fast_levels = getattr(self, "single_fast_levels", 0) + 1

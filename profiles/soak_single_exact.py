@@ -18,9 +18,11 @@ def main():
     F = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     lo = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     hi = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
-    a = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu", check_triangle="reference")
-    b = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu", check_triangle="reference")
+    mode = os.environ.get("SOAK_MODE", "reference")            # "fixed": the explicit speed mode's per-frame call (product kernels only)
+    a = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu", check_triangle=mode)
+    b = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu", check_triangle=mode)
     b.GPU_EXACT_SINGLE_FAST = False
+    b.GPU_SINGLE_HOT = False
     rng = np.random.default_rng(77)
     bad = fast = 0
     ta = tb = 0.0
@@ -50,9 +52,11 @@ def main():
 def fuzz(count=480):
     """The frame-level fuzz set (duplicates, tied depths, walls, tiny frames, the level at zero ...): what each call returns or
     raises, the window and height_level after it, on the two paths."""
-    a = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu", check_triangle="reference")
-    b = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu", check_triangle="reference")
+    mode = os.environ.get("SOAK_MODE", "reference")
+    a = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu", check_triangle=mode)
+    b = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu", check_triangle=mode)
     b.GPU_EXACT_SINGLE_FAST = False
+    b.GPU_SINGLE_HOT = False
     bad = raised = fast = 0
     for i in range(count):
         f3, f2 = synth.fuzz_frame(i)
