@@ -2842,6 +2842,49 @@ def test_per_frame_exact_path_on_the_fuzz_frames(gpu, monkeypatch):
     assert fast >= 40 and getattr(a, "single_fast_redone", 0) >= 20          # both routes were taken
 
 
+def test_per_frame_call_of_the_speed_mode_product_kernels_only(gpu):
+    """check_triangle="fixed" per frame: the product kernels alone (MVOSR_WAVES_HOT_ONLY), the window median queued behind them,
+    height_level exact when read — against the same estimator on the exact mode (GPU_SINGLE_HOT off) and, for the ordinary frames,
+    against the fixed-mode oracle: scales, stds, the window, flat_feature, height_level; the fuzz frames (errors, tiny frames,
+    levels at zero) among them."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    a = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu")
+    b = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu")
+    assert a.check_triangle == "fixed" and a.GPU_SINGLE_HOT
+    b.GPU_SINGLE_HOT = False
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+
+    def eq(p, q):
+        if p is None or q is None or isinstance(p, str):
+            return p == q
+        return np.array_equal(np.asarray(p, dtype=np.float64), np.asarray(q, dtype=np.float64), equal_nan=True)
+
+    rng = np.random.default_rng(5)
+    pending = 0
+    for i in range(40):
+        f3, f2 = synth.synth_frame(i, int(rng.integers(300, 2001)), base_seed=2323, upper_fraction=0.1)
+        ra, rb, rr = a.scale_calculation(f3.copy(), f2), b.scale_calculation(f3.copy(), f2), ref.scale_calculation(f3.copy(), f2)
+        assert ra == rb == rr, i
+        assert list(a.scale_queue) == list(b.scale_queue) == list(ref.scale_queue)
+        assert np.array_equal(a.flat_feature, ref.flat_feature)
+        pending += a.__dict__.get("_level_thunk") is not None
+        if i % 4 == 0:
+            assert a.height_level == b.height_level == ref.height_level, i
+    assert pending >= 30
+    for i in list(range(60)) + list(range(400, 420)):
+        f3, f2 = synth.fuzz_frame(i)
+        outs = []
+        for est in (a, b):
+            try:
+                outs.append(("ok", est.scale_calculation(f3.copy(), f2)))
+            except Exception as exc:                     # noqa: BLE001
+                outs.append(("raised", type(exc).__name__))
+        assert outs[0][0] == outs[1][0] and eq(outs[0][1], outs[1][1]), (i, outs)
+        assert eq(list(a.scale_queue), list(b.scale_queue)) and eq(getattr(a, "height_level", None), getattr(b, "height_level", None)), i
+
+
 def test_qhull_rows_kernel_hostile_inputs_are_declined(gpu):
     """NaN / infinite / huge / identical / collinear sites, a mask that keeps fewer than three points: the kernel declines (status
     != 0, no rows) — it neither hangs nor writes outside its frame — and the sets around them are untouched."""
