@@ -86,7 +86,7 @@ def good_bits(edge_potential=EDGE_POTENTIAL, prob_threshold=0.6):
 
 class ScaleEstimator:
     def __init__(self, absolute_reference, window_size=6, device=0, ransac_seed=None, sampler=None,
-                 delaunay_workers=None, verbose=False, triangulation="scipy", sampling=None):
+                 delaunay_workers=None, verbose=False, triangulation=None, sampling=None):
         # reference attributes (rescale.py:24-35)
         self.absolute_reference = absolute_reference
         self.camera_pitch = 0
@@ -114,6 +114,11 @@ class ScaleEstimator:
         # device-resident.  sampling "host": the triples are drawn here with Python's random, by LIST POSITION in SciPy's row
         # order (replays a recorded reference run); "device": the kernel's counter-based sequence over rows in canonical
         # form (the default — and the only choice — with "gpu").
+        # No triangulation given (the reference's own construction, /root/reference/src/main.py:55): the device-resident path
+        # (round 5; the reference's RANSAC is unseeded, so no realisation of its draws is THE result — DESIGN.md §3.4 —;
+        # MVOSR_TRIANGULATION=scipy restores the host default, and a host `sampler` or sampling="host" implies it).
+        if triangulation is None:
+            triangulation = "scipy" if (sampler is not None or sampling == "host") else os.environ.get("MVOSR_TRIANGULATION", "gpu")
         if triangulation not in ("scipy", "gpu"):
             raise ValueError("triangulation must be 'scipy' or 'gpu'")
         if sampling is None:

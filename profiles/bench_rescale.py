@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8, help="frames of the pool timed through the NumPy oracle")
     args = ap.parse_args()
 
-    est = rescale.ScaleEstimator(1.75, window_size=5, ransac_seed=7, delaunay_workers=0)
+    est = rescale.ScaleEstimator(1.75, window_size=5, ransac_seed=7, delaunay_workers=0, triangulation="scipy")
     ctx, lib = est.ctx, est.ctx.lib
     frames = [synth.synth_frame(i, args.features, base_seed=4242) for i in range(args.pool)]
     t0 = time.perf_counter()

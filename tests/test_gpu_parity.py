@@ -2885,6 +2885,24 @@ def test_per_frame_call_of_the_speed_mode_product_kernels_only(gpu):
         assert eq(list(a.scale_queue), list(b.scale_queue)) and eq(getattr(a, "height_level", None), getattr(b, "height_level", None)), i
 
 
+def test_rescale_default_construction_is_device_resident(gpu, monkeypatch):
+    """rescale.ScaleEstimator(absolute_reference, window_size) as /root/reference/src/main.py:20,55 constructs it: the
+    device-resident path (both triangulations, the vote, flat selection and RANSAC on the device; the counter-based sampler);
+    MVOSR_TRIANGULATION=scipy (this suite's setting), a host sampler or sampling="host" give the host path as before."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    assert ScaleEstimator(1.75, window_size=5, delaunay_workers=0).triangulation == "scipy"          # (conftest's setting)
+    monkeypatch.delenv("MVOSR_TRIANGULATION")
+    est = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, ransac_seed=7)
+    assert (est.triangulation, est.sampling) == ("gpu", "device")
+    assert ScaleEstimator(1.75, window_size=5, delaunay_workers=0, sampling="host").triangulation == "scipy"
+    assert ScaleEstimator(1.75, window_size=5, delaunay_workers=0, sampler=lambda n, k: list(range(k))).triangulation == "scipy"
+    explicit = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, ransac_seed=7, triangulation="gpu")
+    for i in range(8):
+        f3, f2 = synth.synth_frame(i, 600 + 150 * i, base_seed=515)
+        assert est.scale_calculation(f3, f2) == explicit.scale_calculation(f3, f2), i
+
+
 def test_qhull_rows_kernel_hostile_inputs_are_declined(gpu):
     """NaN / infinite / huge / identical / collinear sites, a mask that keeps fewer than three points: the kernel declines (status
     != 0, no rows) — it neither hangs nor writes outside its frame — and the sets around them are untouched."""
