@@ -39,13 +39,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                 insertion order — the reference's result, bit for bit, with nothing on the host but packing;
   e2e_rescale   the estimator the reference's drivers really import (rescale.ScaleEstimator, /root/reference/src/main.py:20),
                 device-resident (Delaunay x2, GraphChecker vote, flat_selection + RANSAC plane; slew limiter + window median: a C
-                loop on the host) from per-frame arrays; one declared deviation, in the sampler (DESIGN.md §3.4);
+                loop on the host) from per-frame arrays; no declared deviation (DESIGN.md §3.4);
   latency       per-frame latency of the drop-in scale_calculation call in the reference's loop shape.
 """
 from __future__ import annotations
 
 import os as _os
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # this process owns more than four streams (torch's, two contexts with an upload stream each): ROCm's default of four hardware queues would make them share
+_os.environ.setdefault("MVOSR_HW_QUEUES", "8"); _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # this process owns more than four streams (torch's, two contexts with an upload stream each): ROCm's default of four hardware queues would make them share
 _os.environ.setdefault("MVOSR_AFFINITY", "1")     # the end-to-end legs pin this process to the CPUs of the device's NUMA node (opt-in in the library)
 import argparse
 import ctypes as C
@@ -351,7 +351,7 @@ def e2e_rescale_leg(args, device, sizes, seed, n_frames):
             "what": "rescale.ScaleEstimator(triangulation='gpu').scale_calculation_batch on a list of per-frame arrays: the "
                     "estimator /root/reference/src/main.py:20 imports, every stage on the device (Delaunay x2, GraphChecker vote, "
                     "flat_selection + 100-hypothesis RANSAC plane on the device; slew limiter + window median in C on the host); deterministic stages "
-                    "without a deviation, one declared deviation in the sampler (a triple naming one vertex twice is drawn again)"}
+                    "without a deviation; the sampler spends an iteration on a triple naming one vertex twice, as the reference does (zero inliers)"}
 
 
 def e2e_gpu_leg(args, device, sizes, seed, n_frames, exact=False):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MVOSR_ABI_VERSION 11
+#define MVOSR_ABI_VERSION 12
 
 /* error codes (function return values) */
 enum mvosr_err {
@@ -248,6 +248,11 @@ int mvosr_ctx_sync(mvosr_ctx *ctx);
  * need 24 more bytes per feature, allocated at their first launch).  mvosr_scale_batch grows it on demand
  * with hipMalloc; call this first if the launches must not allocate (e.g. under graph capture). */
 int mvosr_ctx_reserve(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat);
+/* Cap, in bytes, on the grow-only workspace of the triangulation kernels (mvosr_delaunay_*_batch: per-frame state beyond LDS —
+ * ~0.55 KB per point of frames x largest frame for the Qhull replay): a launch that would need more returns MVOSR_ERR_ALLOC
+ * without launching anything, exactly as when the device cannot satisfy the request, and the drop-in sends that chunk through
+ * the host's triangulations.  For hosts that share the device with another tenant's allocations.  0 (default): no cap. */
+int mvosr_ctx_workspace_limit(mvosr_ctx *ctx, int64_t bytes);
 /* Per-call kernel timing of mvosr_scale_batch with HIP events on the launch stream: after
  * mvosr_ctx_profile(ctx, 1) every call (up to 64) records an event before the scale kernel, between
  * the two kernels and after the road-model kernel; mvosr_ctx_profile_read returns the two

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 LIB_PATH = os.environ.get("MVOSR_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvosr.so")   # (override: A/B builds in profiles/)
-ABI_VERSION = 11
+ABI_VERSION = 12
 VOTE_REFERENCE, VOTE_FIXED = 0, 1          # mvosr_params.vote_mode
 WAVES_EXACT = 0x100                        # MVOSR_WAVES_EXACT, or-ed into waves_per_frame
 WAVES_EXACT_MASKED = 0x200                 # MVOSR_WAVES_EXACT_MASKED: only the frames of mvosr_batch.exact_mask, in the exact mode
@@ -93,6 +93,7 @@ SYMBOLS = {
     "mvosr_ctx_stream": (_P, [_P]),
     "mvosr_ctx_sync": (C.c_int, [_P]),
     "mvosr_ctx_reserve": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "mvosr_ctx_workspace_limit": (C.c_int, [_P, C.c_int64]),
     "mvosr_ctx_profile": (C.c_int, [_P, C.c_int]),
     "mvosr_ctx_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mvosr_ctx_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -182,9 +183,20 @@ def load():
             "(or `make -C mvoscalerecovery_amd/csrc`). There is no CPU fallback." % LIB_PATH)
     # A context owns a compute and an upload stream, the exact device path runs two contexts, a host application (torch) has streams of
     # its own: beyond ROCm's default of four hardware queues per process streams SHARE a queue and stop overlapping (measured: the
-    # exact path's two contexts 78 k instead of 94 k frames/s inside bench.py).  A default only — it takes effect if the HIP runtime
-    # has not been initialised yet, and an explicit setting of the variable wins.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # exact path's two contexts 78 k instead of 94 k frames/s inside bench.py).  The variable that lifts the limit is the HOST
+    # APPLICATION's (it is read when the HIP runtime initialises and is inherited by child processes): this binding sets it only when
+    # asked to — MVOSR_HW_QUEUES=<n> (bench.py opts in with 8, like MVOSR_AFFINITY) — and says so when the request comes too late.
+    want = os.environ.get("MVOSR_HW_QUEUES", "").strip()
+    if want.isdigit() and int(want) > 0 and "GPU_MAX_HW_QUEUES" not in os.environ:
+        import sys
+        import warnings
+        torch = sys.modules.get("torch")
+        if torch is not None and getattr(getattr(torch, "cuda", None), "is_initialized", lambda: False)():
+            warnings.warn("mvoscalerecovery_amd: MVOSR_HW_QUEUES=%s asked for after the HIP runtime was initialised (torch.cuda is up): "
+                          "GPU_MAX_HW_QUEUES has no effect any more; set it in the environment of the process instead" % want,
+                          RuntimeWarning, stacklevel=2)
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = want
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as exc:
@@ -519,6 +531,10 @@ class Context:
 
     def trim(self):
         check(self.lib.mvosr_ctx_trim(self.handle), "mvosr_ctx_trim")
+
+    def workspace_limit(self, nbytes):
+        """Cap the triangulation kernels' grow-only workspace (0: none): chunks that would need more take the host's triangulations."""
+        check(self.lib.mvosr_ctx_workspace_limit(self.handle, int(nbytes)), "mvosr_ctx_workspace_limit")
 
     def sync(self):
         check(self.lib.mvosr_ctx_sync(self.handle), "mvosr_ctx_sync")

@@ -72,7 +72,8 @@ int ctx_workspace_bytes(mvosr_ctx *ctx, size_t bytes, void **ptr) {
         if (ctx->ws_bytes) (void)hipFree(ctx->ws_bytes);
         ctx->ws_bytes = nullptr; ctx->ws_bytes_len = 0;
         const size_t want = bytes + bytes / 4;
-        hipError_t e = getenv("MVOSR_TEST_FAIL_ALLOC") ? hipErrorOutOfMemory : hipMalloc(&ctx->ws_bytes, want);      // (test hook: tests/test_gpu_parity.py)
+        // (mvosr_ctx_workspace_limit: a request beyond the caller's cap is refused like one the device cannot satisfy)
+        hipError_t e = (ctx->ws_bytes_limit && want > ctx->ws_bytes_limit) ? hipErrorOutOfMemory : hipMalloc(&ctx->ws_bytes, want);
         if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
             (void)hipGetLastError();
             ctx->ws_bytes = nullptr;
@@ -399,7 +400,7 @@ int mvosr_ctx_create(int device, mvosr_ctx **out) {
     ctx->prof_on = 0; ctx->prof_calls = 0;
     for (int i = 0; i < 2; ++i) ctx->ws_dense[i] = nullptr;
     ctx->ws_dense_len = 0;
-    ctx->ws_bytes = nullptr; ctx->ws_bytes_len = 0;
+    ctx->ws_bytes = nullptr; ctx->ws_bytes_len = 0; ctx->ws_bytes_limit = 0;
     ctx->dt_parts_head = nullptr;
     for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) ctx->prof_ev[i][j] = nullptr;
     ctx->ws_ysel = nullptr; ctx->ws_ysel_len = 0; ctx->ws_nsel = nullptr; ctx->ws_nsel_len = 0;
@@ -504,6 +505,18 @@ int mvosr_ctx_reserve(mvosr_ctx *ctx, int64_t n_frames, int64_t total_feat) {
     double *a = nullptr;
     int32_t *b = nullptr;
     return ctx_workspace(ctx, n_frames, total_feat, &a, &b);
+}
+
+int mvosr_ctx_workspace_limit(mvosr_ctx *ctx, int64_t bytes) {
+    if (!ctx || bytes < 0) return set_error(MVOSR_ERR_ARG, "ctx_workspace_limit: bad argument");
+    ctx->ws_bytes_limit = (size_t)bytes;
+    if (bytes && ctx->ws_bytes_len > (size_t)bytes) {           // (a workspace beyond the new cap goes back to the device now)
+        HIP_TRY(hipSetDevice(ctx->device));
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->ws_bytes) (void)hipFree(ctx->ws_bytes);
+        ctx->ws_bytes = nullptr; ctx->ws_bytes_len = 0;
+    }
+    return MVOSR_OK;
 }
 
 int mvosr_malloc(mvosr_ctx *ctx, size_t bytes, void **dptr) {

@@ -248,7 +248,7 @@ constexpr int kDtPartsMaxFrames = 16;      // launches of up to this many frames
 constexpr int kDtPartsPoints = 128;        // points per part (four wavefronts: at most a star per lane)
 constexpr int kDtPartsMax = 16;
 
-enum { DM_FLAGS = 0, DM_ARENA = 1, DM_VQ = 2, DM_NHARD = 3, DM_NEXT = 4, DM_TICKET = 5 };
+enum { DM_FLAGS = 0, DM_ARENA = 1, DM_VQ = 2, DM_NHARD = 3, DM_NEXT = 4, DM_TICKET = 5, DM_PFLAGS = 6 };
 enum { DW_CNT = 0, DW_SUM = 16, DW_SUM2 = 32, DW_SUM3 = 48 };        // wsl[]: 16 slots each
 
 struct DtGrid {
@@ -1389,8 +1389,13 @@ __global__ __launch_bounds__(WAVES *kWave, PARTS ? 1 : ((ARENA_OUT && WAVES == 4
         __syncthreads();
         if (misc[DM_TICKET] != a.parts - 1) return;
         __threadfence();
-        part_flags = (int)__hip_atomic_load(&g_head[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) { g_head[0] = 0u; g_head[1] = 0u; }            // (for the next launch: every part of this one has been here)
+        // (one thread reads the parts' flags, every wavefront takes them from LDS, and only then are they reset for the next launch:
+        // a wavefront that loaded them itself could come after thread 0's store, see zero, and go on with a frame the others decline)
+        if (tid == 0) misc[DM_PFLAGS] = (int)__hip_atomic_load(&g_head[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        part_flags = misc[DM_PFLAGS];
+        __syncthreads();
+        if (tid == 0) { g_head[0] = 0u; g_head[1] = 0u; }            // (every part of this launch has been here)
         OD = g_od; AR = g_arena; ST32 = g_start;
     }
     auto start_of = [&](int o) -> int { if constexpr (PARTS) return (int)ST32[o]; else return (int)astart[o]; };

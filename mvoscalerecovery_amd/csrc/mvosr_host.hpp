@@ -44,6 +44,7 @@ struct mvosr_ctx {
     size_t ws_dense_len;
     void *ws_bytes;               // generic grow-only scratch (the Delaunay kernel's per-frame arrays beyond the LDS capacity)
     size_t ws_bytes_len;
+    size_t ws_bytes_limit;        // mvosr_ctx_workspace_limit: 0 = none
     // delaunay_kernel's PARTS launches (a few frames, several workgroups each): per frame an arrival counter and the parts'
     // decline flags (16 words a frame; zero between launches: the last part to arrive resets them), allocated on first use
     unsigned int *dt_parts_head;

@@ -869,6 +869,8 @@ struct RoadArgs {
                                  // here ([0] = count): height_level becomes their result, so it must be NumPy's own double first
     const int32_t *list;         // process the frames list[1 .. list[0]] (grid-strided) instead of first_frame + index
     int wide;                    // one WORKGROUP per frame (dense batches: long lists, few frames)
+    const uint8_t *listed_mask = nullptr;   // with level_redo: frames whose byte is set are ON that list already (append_mask_kernel put
+                                 // them there behind the HOT kernel) — marked for the exact pass, not appended a second time
 };
 
 // bin of y against the workgroup's table edges[k] = {edge k, edge k+1} (same doubles as bin_edge)
@@ -1234,7 +1236,12 @@ __global__ __launch_bounds__(kRoadWaves *kWave, (LIST ? 1 : 4)) void road_model_
     if (WW > 1 && wave_id() != 0) return;                               // wavefront 0 holds the frame's result
     if (R.status == MVOSR_ST_LEVEL && a.level_redo) {
         // the frame's height IS height_level, which the HOT scale kernel summed in its own order: the EXACT pass redoes it
-        if (lane_id() == 0) { a.level_redo[1 + atomicAdd(a.level_redo, 1)] = (int32_t)f; a.o.status[f] = kStRedo; }
+        // (a frame of the exact mask is on the list already: a second entry would run two workgroups of the exact pass on one frame —
+        // its list is compacted in place — and could push the list beyond its n_frames + 1 slots)
+        if (lane_id() == 0) {
+            if (!(a.listed_mask && a.listed_mask[f])) a.level_redo[1 + atomicAdd(a.level_redo, 1)] = (int32_t)f;
+            a.o.status[f] = kStRedo;
+        }
         return;
     }
     if (lane_id() == 0) {
@@ -2857,7 +2864,9 @@ int mvosr_scale_batch(mvosr_ctx *ctx, const mvosr_params *p, const mvosr_batch *
     if (!(debug_skip_env() & 16)) {
         if (fold) {
             ra.level_redo = ka.redo;
+            ra.listed_mask = hot_only ? nullptr : b->exact_mask;    // (hot_only: append_mask_kernel did not run)
             if ((rc = launch_road(ctx, ra, ctx_stream(ctx)))) return rc;
+            ra.listed_mask = nullptr;
             if (hot_only) return MVOSR_OK;            // (the list's frames stay MVOSR_ST_REDO: the caller's)
             if (standin && (rc = standin_rows(ka.redo))) return rc;          // SciPy's own rows for the frames the exact pass redoes
             if ((rc = dense ? launch_scale_dense(ctx, ka, n_launch, kModeExactList, false) : dispatch_scale(ctx, ka, waves, n_launch, kModeExactList))) return rc;

@@ -160,25 +160,23 @@ __host__ __device__ __forceinline__ uint64_t rs_mix64(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
-constexpr int kRsDrawAttempts = 16;
-// Hypothesis h of a frame: three distinct list positions, uniform — drawn again (the next three values of the hypothesis' own
-// stream) while two of them name the SAME VERTEX.  The list repeats every vertex once per kept triangle (rescale.py:101), so
-// 0.5-2 % of the reference's samples are such rank-deficient triples; its SVD then returns a null vector that rounding noise
-// picks from the pencil of planes through two points (LAPACK's bidiagonalisation of a rank-2 matrix) — nothing a restatement
-// can reproduce or a test can pin.  The product's sequence simply does not contain them.
+// Hypothesis h of a frame: three distinct list positions, uniform (ransac.py:10, random.sample over the list).  The list repeats
+// every vertex once per kept triangle (rescale.py:101), so 0.5-2 % of the samples name one VERTEX twice.  The reference spends
+// the iteration on such a sample (ransac.py:8-21): its SVD of the rank-2 matrix returns a plane that rounding noise picks from
+// the pencil through two points.  Here the iteration is spent as well — the sample is NOT drawn again (rounds 4-5 did, a
+// declared deviation that inflated the iteration budget) —: the cross product of a repeated vertex is exactly zero, the model
+// NaN, the hypothesis counts zero inliers and can never be the best — what the id_triples path has always done with such a
+// triple (pinned against the reference's own run on such triples: tests/golden/rescale.npz frame 26).
 __device__ __forceinline__ void rs_draw3(uint64_t key, int h, int M, const uint16_t *L, int &v0, int &v1, int &v2) {
     const uint64_t hk = rs_mix64(key + (uint64_t)h);
-    for (int att = 0; att < kRsDrawAttempts; ++att) {
-        const uint64_t r0 = rs_mix64(hk + (uint64_t)(3 * att)), r1 = rs_mix64(hk + (uint64_t)(3 * att + 1)), r2 = rs_mix64(hk + (uint64_t)(3 * att + 2));
-        const int i0 = (int)__umul64hi(r0, (uint64_t)M);                          // uniform on [0, M) up to M / 2^64
-        int i1 = (int)__umul64hi(r1, (uint64_t)(M - 1)); if (i1 >= i0) ++i1;       // ... on the M - 1 other positions
-        int i2 = (int)__umul64hi(r2, (uint64_t)(M - 2));
-        const int lo = min(i0, i1), hi = max(i0, i1);
-        if (i2 >= lo) ++i2;
-        if (i2 >= hi) ++i2;
-        v0 = L[i0]; v1 = L[i1]; v2 = L[i2];
-        if (v0 != v1 && v0 != v2 && v1 != v2) return;
-    }
+    const uint64_t r0 = rs_mix64(hk), r1 = rs_mix64(hk + 1ull), r2 = rs_mix64(hk + 2ull);
+    const int i0 = (int)__umul64hi(r0, (uint64_t)M);                          // uniform on [0, M) up to M / 2^64
+    int i1 = (int)__umul64hi(r1, (uint64_t)(M - 1)); if (i1 >= i0) ++i1;       // ... on the M - 1 other positions
+    int i2 = (int)__umul64hi(r2, (uint64_t)(M - 2));
+    const int lo = min(i0, i1), hi = max(i0, i1);
+    if (i2 >= lo) ++i2;
+    if (i2 >= hi) ++i2;
+    v0 = L[i0]; v1 = L[i1]; v2 = L[i2];
 }
 
 #ifndef MVOSR_FLAT_DEV_WAVES

@@ -27,6 +27,12 @@ def delaunay_simplices(points2d):
     return np.ascontiguousarray(Delaunay(points2d).simplices, dtype=np.int32)
 
 
+def qhull_rows_host_or_none():
+    """The host replay of Qhull's run (``qhull_rows_host``) as a callable ``points -> rows or None``, or ``None`` when the
+    helper library does not carry it."""
+    return None
+
+
 def _delaunay_job(points2d):
     try:
         return delaunay_simplices(points2d)

@@ -29,10 +29,11 @@ tested, the estimator does not use it).  No host step between the device stages.
 the vote's edge potential is symmetric, so its mask is a function of the triangle SET (graph.py:18-36,124-145);
 flat_selection keeps a set of triangles (rescale.py:75-96); only the order of its point list (:101) follows the rows,
 and the RANSAC draws list positions uniformly (ransac.py:10) — here from a counter-based sequence keyed by
-``ransac_seed`` (None: OS entropy, the reference's behaviour).  ONE DECLARED DEVIATION, in the sampler: a draw that names one
-vertex twice (the list repeats vertices: 0.5-2 % of the reference's draws; its SVD of such a rank-deficient sample returns a
-plane picked by rounding noise and the iteration is spent) is drawn again — DESIGN.md §3.4; the scale distribution is compared
-with the unseeded reference's in tests/test_gpu_parity.py.  ``triangulation="scipy", sampling="device"`` runs the
+``ransac_seed`` (None: OS entropy, the reference's behaviour).  A draw that names one vertex twice (the list repeats vertices:
+0.5-2 % of the reference's draws) spends its iteration, as in the reference (ransac.py:8-21), and counts zero inliers — the
+reference's SVD of such a rank-2 sample returns a plane picked by rounding noise, which its own recorded run shows losing to every
+real hypothesis (tests/golden/rescale.npz frame 26); rounds 4-5 drew such a sample again (a declared deviation: gone).  The scale
+distribution is compared with the unseeded reference's in tests/test_gpu_rescale.py.  ``triangulation="scipy", sampling="device"`` runs the
 same kernels on SciPy's triangulations brought to the same row form, with bit-identical results.
 """
 from __future__ import annotations
@@ -93,9 +94,8 @@ class ScaleEstimator:
         self.scale = 1
         self.inliers = None
         self.scale_queue = deque()
-        if not (1 <= int(window_size) <= 64):
-            # (the reference takes any window — np.median of an empty deque is nan for 0 —; the C loop's ring buffer holds 64)
-            raise ValueError("window_size must be between 1 and 64 (mvosr_slew_median_host's ring buffer), got %r" % (window_size,))
+        # (the reference takes any window; mvosr_slew_median_host's ring buffer holds 64 — other windows walk the recurrence in Python,
+        # _push_device)
         self.window_size = window_size
         self.vanish = VANISH
         # build-side state
@@ -378,7 +378,7 @@ class ScaleEstimator:
         if tables is not None:
             pf, blk = pack_upload_native(ctx, f3s, f2s, self.vanish, None, tables=tables)             # rescale.py:115-117
             self._trace("packed", -1, len(f3s))
-            if pf.max_feat > self._max_points():
+            if pf.max_feat > self._max_points():           # (_stream_device cuts the stream before such a frame: a direct caller's)
                 blk.free()
                 self._refuse_oversized(pf, frame_base)
             db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk)
@@ -425,15 +425,30 @@ class ScaleEstimator:
         if tr is not None:
             tr.append((what, chunk, frames, time.perf_counter() - getattr(self, "_trace_t0", 0.0)))
 
-    def _refuse_oversized(self, pf, frame_base):
+    def _oversized_error(self, frame, count):
         """flat_selection + RANSAC hold a frame's survivors, heights and flags in ONE workgroup's LDS: a frame beyond that has no
-        kernel here (the reference takes any size — /root/reference/src/rescale.py:113-148 — at seconds per frame).  Said up
-        front, with the frame named, instead of a library error from the middle of the host path."""
+        kernel here (the reference takes any size — /root/reference/src/rescale.py:113-148 — at seconds per frame).  Said with the
+        frame named, instead of a library error from the middle of the host path."""
+        return ValueError("rescale.ScaleEstimator: frame %d has %d features below the vanishing row; the device-resident path takes at "
+                          "most %d per frame (one workgroup's LDS).  Thin the frame, or use scale_calculator.ScaleEstimator, whose "
+                          "dense kernels take any size." % (frame, count, self._max_points()))
+
+    def _refuse_oversized(self, pf, frame_base):
         cnt = np.asarray(pf.feat_cnt)
-        f = int(np.argmax(cnt))
-        raise ValueError("rescale.ScaleEstimator: frame %d has %d features below the vanishing row; the device-resident path takes at "
-                         "most %d per frame (one workgroup's LDS).  Thin the frame, or use scale_calculator.ScaleEstimator, whose "
-                         "dense kernels take any size." % (frame_base - self._frame_counter + f, int(cnt[f]), self._max_points()))
+        f = int(np.argmax(cnt > self._max_points()))
+        raise self._oversized_error(frame_base - self._frame_counter + f, int(cnt[f]))
+
+    def _first_oversized(self, feature2ds, lens, a):
+        """Index (within the call) of the first frame of ``feature2ds[a:a + len(lens)]`` with more features below the vanishing row
+        than the device path takes, and that count — or None.  ``lens``: the frames' sizes (an upper bound of that count, so the
+        frames are looked at only where a size exceeds the limit: never, in an ordinary call)."""
+        cap = self._max_points()
+        for j in np.nonzero(np.asarray(lens) > cap)[0]:
+            f2 = np.asarray(feature2ds[a + int(j)], dtype=np.float64)
+            below = int(np.count_nonzero(f2[:, 1] > self.vanish)) if f2.ndim == 2 and f2.size else 0
+            if below > cap:
+                return a + int(j), below
+        return None
 
     def _resident_frames(self, max_pts):
         """Frames the triangulation kernel works on at a time (mvosr_delaunay_frames_per_cu x CUs)."""
@@ -542,6 +557,14 @@ class ScaleEstimator:
         base = self._frame_counter
         self.last_declined = 0
         results, bounds = [], []
+        # A frame the device path has no kernel for (_oversized_error) ends the run like every other error (_push_device): the frames
+        # before it go through the slew limiter, the window and the sample counter, nothing queued is dropped, then the exception —
+        # what the reference's per-frame loop would have left behind.
+        oversized = None
+        if self.triangulation != "gpu":
+            oversized = self._first_oversized(feature2ds, [len(x) for x in feature2ds], 0)
+            if oversized is not None:
+                F = oversized[0]
         if self.triangulation == "gpu":
             C_ = int(min(self.GPU_CHUNK, max(512, -(-F // 4))))
             mean_pts = max(1, sum(len(x) for x in feature3ds[:64]) // min(F, 64))
@@ -557,6 +580,14 @@ class ScaleEstimator:
                 b = min(F, a + (ramp[len(bounds)] if len(bounds) < len(ramp) else C_))
                 tb = frame_tables(feature3ds[a:b], feature2ds[a:b])          # (sizes from the packer's pointer tables: one C loop)
                 lens = tb[2].astype(np.int64) if tb is not None else np.fromiter((len(x) for x in feature3ds[a:b]), dtype=np.int64, count=b - a)
+                if oversized is None:
+                    oversized = self._first_oversized(feature2ds, lens, a)
+                    if oversized is not None:
+                        F = oversized[0]                   # (the stream ends before that frame)
+                        if a >= F:
+                            break
+                        b, lens = min(b, F), lens[:F - a]
+                        tb = tuple(t[:F - a] for t in tb) if tb is not None else None
                 b = min(b, a + max(int(np.searchsorted(np.cumsum(lens), self.GPU_CHUNK_POINTS, side="right")), 1))
                 while b - a > 1 and (b - a) * int(lens[:b - a].max()) > 2 * self.GPU_CHUNK_POINTS:     # (workspace = frames x largest frame)
                     b = a + max(1, (b - a) // 2)
@@ -581,11 +612,13 @@ class ScaleEstimator:
                                                       None if id_triples is None else id_triples[pa:pb], stage))
         else:
             C_ = 2048
-            for a in range(0, F, C_):
+            for a in range(0, F, C_):          # (F: the frames before the first oversized one)
                 b = min(F, a + C_)
                 bounds.append((a, b))
                 results.append(self._chunk_dev_host(feature3ds[a:b], feature2ds[a:b], base + a, None,
                                                     None if id_triples is None else id_triples[a:b], stage))
+        if oversized is not None and not results:
+            raise self._oversized_error(*oversized)
         cat = lambda k: np.concatenate([r[k] for r in results])
         raw, status, level = cat("raw_scale"), cat("status"), cat("height_level")
         host_errors = {}
@@ -596,7 +629,15 @@ class ScaleEstimator:
         if stage:
             for k in ("valid", "tris2", "tri_flags"):
                 self.last[k] = [x for r in results for x in r["stage"][k]]
+        if oversized is not None:
+            host_errors = dict(host_errors)
+            host_errors[F] = self._oversized_error(*oversized)
+            raw = np.concatenate([raw, [np.nan]])
+            status = np.concatenate([status, np.array([K.ST_ERR_EMPTY], dtype=status.dtype)])
+            level = np.concatenate([level, [np.nan]])
         if not push:
+            if oversized is not None:
+                raise host_errors[F]
             return raw, status, level, host_errors
         return self._push_device(raw, status, level, host_errors)
 
@@ -641,13 +682,34 @@ class ScaleEstimator:
             ap = np.ascontiguousarray(status[:n_ok] == 0, dtype=np.int32)
             pushed, filtered = np.empty(n_ok, np.float64), np.empty(n_ok, np.float64)
             q = np.ascontiguousarray(np.asarray(list(self.scale_queue), dtype=np.float64))
-            _lib.check(ctx.lib.mvosr_slew_median_host(_lib.addr(r), _lib.addr(ap), n_ok, SLEW, float(self.scale), int(self.window_size),
-                                                      _lib.addr(q) if q.size else None, int(q.size), _lib.addr(pushed),
-                                                      _lib.addr(filtered), None), "mvosr_slew_median_host")
-            self.scale = float(pushed[-1])                                                  # :169-174
-            tail = list(self.scale_queue) + list(pushed[max(0, n_ok - self.window_size):])
-            self.scale_queue.clear()
-            self.scale_queue.extend(tail[-self.window_size:])                               # :175-177
+            if 1 <= int(self.window_size) <= 64 and q.size <= 64:
+                _lib.check(ctx.lib.mvosr_slew_median_host(_lib.addr(r), _lib.addr(ap), n_ok, SLEW, float(self.scale), int(self.window_size),
+                                                          _lib.addr(q) if q.size else None, int(q.size), _lib.addr(pushed),
+                                                          _lib.addr(filtered), None), "mvosr_slew_median_host")
+                self.scale = float(pushed[-1])                                              # :169-174
+                tail = list(self.scale_queue) + list(pushed[max(0, n_ok - self.window_size):])
+                self.scale_queue.clear()
+                self.scale_queue.extend(tail[-self.window_size:])                           # :175-177
+            else:
+                # a window the C loop's ring buffer does not hold (the reference takes any: 0 gives the median of an empty deque,
+                # nan): the same recurrence, frame by frame, as the reference writes it (:169-178)
+                with np.errstate(all="ignore"):
+                    for i in range(n_ok):
+                        if ap[i]:
+                            if r[i] - self.scale > SLEW:
+                                self.scale += SLEW
+                            elif r[i] - self.scale < -SLEW:
+                                self.scale -= SLEW
+                            else:
+                                self.scale = float(r[i])
+                        self.scale_queue.append(self.scale)
+                        if len(self.scale_queue) > self.window_size:
+                            self.scale_queue.popleft()
+                        pushed[i] = self.scale
+                        import warnings
+                        with warnings.catch_warnings():
+                            warnings.simplefilter("ignore")
+                            filtered[i] = np.median(self.scale_queue)
             self.height_level = level[n_ok - 1]                                             # :92
         self._frame_counter += n_ok + (1 if n_ok < F else 0)
         if n_ok < F:

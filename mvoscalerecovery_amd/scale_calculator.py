@@ -100,6 +100,15 @@ class ScaleEstimator:
         if delaunay_workers is None or delaunay_workers > 1:
             packing.start_pool(delaunay_workers)    # fork the host stage's workers BEFORE the GPU runtime starts its threads
         self.engine = ScaleEngine(absolute_reference, device=device, camera_pitch=self.camera_pitch, check_triangle=check_triangle)
+        # The replay of Qhull's run (device kernel and host C form) reproduces ONE Qhull build's decisions; the reference floats with
+        # whatever Qhull the installed SciPy bundles (:12,:257,:266).  Once per process and device the two are compared on fixed point
+        # sets (selfcheck.py); on any difference this estimator takes the host path — by construction this box's reference.
+        self.qhull_selfcheck = None
+        if triangulation == "gpu" and check_triangle == "reference":
+            from . import selfcheck
+            self.qhull_selfcheck = selfcheck.run(self.engine.ctx, host_replay=packing.qhull_rows_host_or_none())
+            if not self.qhull_selfcheck["ok"]:
+                self.triangulation = "scipy"
         self.last_declined = 0                      # frames of the last device-triangulation chunk that went to the host's Qhull
         self.last_status = None
         self.last_counts = None

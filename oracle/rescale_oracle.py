@@ -127,14 +127,20 @@ def count_inliers(m, pts, threshold):
     return int(np.sum(np.abs(pts @ m[:3] + m[3]) < threshold))
 
 
-def run_ransac(pts, triples, threshold=RANSAC_THRESHOLD, goal_fraction=RANSAC_GOAL):
+def run_ransac(pts, triples, threshold=RANSAC_THRESHOLD, goal_fraction=RANSAC_GOAL, repeated_counts_zero=False):
     """ransac.py:3-23 with the sample sequence given: `triples` (H,3) row indices, consumed in order;
-    stops at the first improvement that exceeds the goal.  Returns (model, best_count, n_used)."""
+    stops at the first improvement that exceeds the goal.  Returns (model, best_count, n_used).
+    `repeated_counts_zero` (the device-resident sampler's rule): a sample holding one point twice spends its iteration with
+    zero inliers — the reference's SVD of such a rank-2 sample returns a plane that rounding noise picks from the pencil through
+    two points (the reference's own run on such samples: tests/golden/rescale.npz frame 26 — never the best plane there)."""
     goal = pts.shape[0] * goal_fraction
     best_ic, best_m, used = 0, None, 0
     for t in triples:
         used += 1
-        m = estimate_plane(pts[list(t)])
+        p3 = pts[list(t)]
+        if repeated_counts_zero and (np.array_equal(p3[0], p3[1]) or np.array_equal(p3[0], p3[2]) or np.array_equal(p3[1], p3[2])):
+            continue
+        m = estimate_plane(p3)
         ic = count_inliers(m, pts, threshold)
         if ic > best_ic:
             best_ic, best_m = ic, m
@@ -198,36 +204,30 @@ def mix64(x):
     return x ^ (x >> 31)
 
 
-DRAW_ATTEMPTS = 16
-
-
 def device_triples(seed, frame_counter, ids, n_hyp=RANSAC_ITERATIONS):
     """The list positions hypothesis h = 0..n_hyp-1 of frame `frame_counter` draws under key `seed` from the point list whose
     vertex ids are `ids` (an int m: a list of m distinct points): three distinct positions, uniform — the reference draws
-    them with random.sample from OS entropy, /root/reference/src/thirdparty/Ransac/ransac.py:6,10 — drawn again while two
-    of them name the same vertex (the list repeats vertices, /root/reference/src/rescale.py:101; the reference's SVD of such
-    a rank-deficient sample returns a plane that rounding noise picks: the product's sequence leaves those samples out)."""
+    them with random.sample from OS entropy, /root/reference/src/thirdparty/Ransac/ransac.py:6,10.  ONE draw per hypothesis:
+    a sample that names one vertex twice (the list repeats vertices, /root/reference/src/rescale.py:101) spends its
+    iteration, as in the reference (ransac.py:8-21)."""
     ids = np.arange(ids) if np.isscalar(ids) else np.asarray(ids)
     m = len(ids)
     key = mix64((seed ^ ((frame_counter * 0xD1B54A32D192ED03) & _M64)) & _M64)
     out = np.zeros((n_hyp, 3), dtype=np.int64)
     for h in range(n_hyp):
         hk = mix64((key + h) & _M64)
-        for att in range(DRAW_ATTEMPTS):
-            r = [mix64((hk + 3 * att + k) & _M64) for k in range(3)]
-            i0 = (r[0] * m) >> 64
-            i1 = (r[1] * (m - 1)) >> 64
-            if i1 >= i0:
-                i1 += 1
-            i2 = (r[2] * (m - 2)) >> 64
-            lo, hi = min(i0, i1), max(i0, i1)
-            if i2 >= lo:
-                i2 += 1
-            if i2 >= hi:
-                i2 += 1
-            out[h] = (i0, i1, i2)
-            if len({int(ids[i0]), int(ids[i1]), int(ids[i2])}) == 3:
-                break
+        r = [mix64((hk + k) & _M64) for k in range(3)]
+        i0 = (r[0] * m) >> 64
+        i1 = (r[1] * (m - 1)) >> 64
+        if i1 >= i0:
+            i1 += 1
+        i2 = (r[2] * (m - 2)) >> 64
+        lo, hi = min(i0, i1), max(i0, i1)
+        if i2 >= lo:
+            i2 += 1
+        if i2 >= hi:
+            i2 += 1
+        out[h] = (i0, i1, i2)
     return out
 
 
@@ -286,7 +286,7 @@ class OracleRescaleEstimator:
                 triples = device_triples(self.device_seed, self.frame_counter, self.last["flat"].ids)
             else:
                 triples = self.sampler(pts.shape[0])
-            m, ic, used = run_ransac(np.array(pts), triples)
+            m, ic, used = run_ransac(np.array(pts), triples, repeated_counts_zero=self.device_seed is not None)
             self.last.update(model=m, best_ic=ic, used=used)
             scale = scale_from_model(m, self.absolute_reference)
             if scale - self.scale > SLEW:                          # :169-174

@@ -11,16 +11,24 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# The suite's un-parametrised ScaleEstimator(...) constructions are the host-SciPy baseline every device path is compared with
-# (rounds 1-4 wrote them when that was the default).  Since round 5 the default is the fast exact path (triangulation="gpu" with
-# the reference's vote); here the baseline stays what it was, and the default itself has its own test
-# (tests/test_gpu_parity.py::test_default_construction_is_the_fast_exact_path).
-os.environ.setdefault("MVOSR_TRIANGULATION", "scipy")
+# Constructions in this suite say which path they mean: triangulation="scipy" is the host-SciPy baseline every device path is compared
+# with; a ScaleEstimator(...) without the keyword is the shipped default.  (Round 5 ran the suite under MVOSR_TRIANGULATION=scipy and
+# un-set it where the default was meant: a new test that forgot would have tested the old path silently — ADVICE r5.)
+os.environ.pop("MVOSR_TRIANGULATION", None)
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """The device context every -m gpu test runs on: raises loudly if libmvosr.so / the GPU is missing."""
+    from mvoscalerecovery_amd import _lib
+    ctx = _lib.default_context(0)
+    assert "gfx950" in ctx.name
+    return ctx
 
 
 def load_json(name):

