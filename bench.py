@@ -188,6 +188,19 @@ def launch_ranks(args, argv):
 TILE_ABOVE = [1 << 30]
 
 
+SNAP = [0.0]          # --workload gridded: pixel coordinates rounded to this grid (0.25 px)
+
+
+def _synth(synth, i, n, base_seed):
+    """A synthetic frame of the workload; ``--workload gridded``: its pixel coordinates snapped to a quarter-pixel grid — collinear and
+    cocircular sites by construction (what a detector with sub-pixel refinement to 1/4 px hands over): the regime in which Qhull
+    merges facets and the replay DECLINES to the host's SciPy (VERDICT r5 #3)."""
+    f3, f2 = synth.synth_frame(i, n, base_seed=base_seed)
+    if SNAP[0] > 0.0:
+        f2 = np.ascontiguousarray(np.round(f2 / SNAP[0]) * SNAP[0])
+    return f3, f2
+
+
 def frame_sizes(args, pool):
     if args.workload == "kitti":
         # configs[2]: per-frame feature counts after the VO's masks, a few hundred to ~1500 (SURVEY §8: C3)
@@ -202,7 +215,7 @@ def build_pool(ctx, engine, sizes, seed):
     from mvoscalerecovery_amd import packing, synth
     from mvoscalerecovery_amd.engine import DeviceBatch, DeviceOutputs
     pool = len(sizes)
-    frames = [synth.synth_frame(i, sizes[i], base_seed=seed) for i in range(pool)]
+    frames = [_synth(synth, i, sizes[i], base_seed=seed) for i in range(pool)]
     pf = packing.pack_features([f[0] for f in frames], [f[1] for f in frames])
     t0 = time.perf_counter()
     packing.attach_tri1(pf, None, None)
@@ -251,7 +264,7 @@ def prepare_cpu_legs(sizes, seed, sample=24):
     from oracle import scale_oracle as so
     jobs = []
     for i in range(min(sample, len(sizes))):
-        f3, f2 = synth.synth_frame(i, sizes[i], base_seed=seed)
+        f3, f2 = _synth(synth, i, sizes[i], base_seed=seed)
         r = so.frame_raw_scale(f3, f2, ABS_REF)
         jobs.append((f3, f2, np.ascontiguousarray(r.tri1, dtype=np.int32), np.ascontiguousarray(r.tri2, dtype=np.int32), r.raw_scale, r.status))
     _ALL_CORES_JOBS = [j[:4] for j in jobs]
@@ -293,7 +306,7 @@ def e2e_leg(args, device, sizes, seed, budget_frames):
     from mvoscalerecovery_amd import packing, synth
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
     n = min(budget_frames, 4096)
-    frames = [synth.synth_frame(100000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(n)]
+    frames = [_synth(synth, 100000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(n)]
     est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="scipy")
     nw = min(64, max(8, n // 8))
     est.scale_calculation_batch([f[0] for f in frames[:nw]], [f[1] for f in frames[:nw]])         # warm-up (pool, workspaces)
@@ -316,7 +329,7 @@ def _e2e_frames(sizes, seed, n_frames):
     key = (tuple(sizes[:8]), len(sizes), seed, n_frames)
     if key not in _E2E_FRAMES:
         npool = min(n_frames, 4096 if max(sizes) <= 6000 else 16)
-        pool = [synth.synth_frame(200000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(npool)]
+        pool = [_synth(synth, 200000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(npool)]
         _E2E_FRAMES.clear()
         _E2E_FRAMES[key] = (pool, [pool[i % npool][0] for i in range(n_frames)], [pool[i % npool][1] for i in range(n_frames)])
     return _E2E_FRAMES[key]
@@ -354,6 +367,21 @@ def e2e_rescale_leg(args, device, sizes, seed, n_frames):
                     "without a deviation; the sampler spends an iteration on a triple naming one vertex twice, as the reference does (zero inliers)"}
 
 
+def _selfcheck_record(est):
+    """What guards the reference-exact device path on this box: the installed SciPy's version and the first-use comparison of the Qhull
+    replay (device kernel and host C form) with it (mvoscalerecovery_amd/selfcheck.py)."""
+    sc = getattr(est, "qhull_selfcheck", None)
+    if not sc:
+        return None
+    rec = {"ok": bool(sc.get("ok")), "skipped": bool(sc.get("skipped")), "scipy": sc.get("scipy"), "numpy": sc.get("numpy"),
+           "replayed": sc.get("replayed"), "runs": est.triangulation}
+    for side in ("device", "host"):
+        if side in sc:
+            rec[side] = {k: sc[side][k] for k in ("sets", "compared", "declined")}
+            rec[side]["different"] = len(sc[side]["different"])
+    return rec
+
+
 def e2e_gpu_leg(args, device, sizes, seed, n_frames, exact=False):
     """The batch call end to end with BOTH TRIANGULATIONS BUILT ON THE DEVICE (triangulation="gpu", which selects
     check_triangle="fixed": DESIGN.md §3.5): C packer -> one upload per chunk -> Delaunay #1 -> vote -> Delaunay #2 ->
@@ -363,8 +391,10 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames, exact=False):
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
     pool, f3s, f2s = _e2e_frames(sizes, seed, n_frames)
     npool = len(pool)
-    est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="gpu", delaunay_workers=0,
-                         check_triangle="reference" if exact else "fixed")
+    # (the exact leg keeps the Delaunay worker pool — forked in main() before the GPU runtime started —: frames the replay declines are
+    # triangulated there, under the GPU's queued chunks)
+    est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="gpu",
+                         delaunay_workers=None if (exact or SNAP[0] > 0.0) else 0, check_triangle="reference" if exact else "fixed")
     for _ in range(2):                                                        # warm-up: kernels, allocator caches (same sizes as the timed call)
         est.scale_calculation_batch(f3s, f2s)
     ctx = est.engine.ctx
@@ -408,7 +438,8 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames, exact=False):
         dt_alone = None
     return {"value": n_frames / dt, "unit": "frames/s", "frames": n_frames, "distinct_frames": npool,
             "timed_calls_frames_per_s": [n_frames / t for t in times],
-            "declined_last_chunk": int(est.last_declined), "delaunay_kernel": dt_alone,
+            "declined_total": int(est.declined_total), "declined_fraction": float(est.declined_total) / max(n_frames, 1),
+            "qhull_selfcheck": _selfcheck_record(est), "delaunay_kernel": dt_alone,
             "hip_malloc_calls_in_timed_call": a1["hip_malloc"] - a0["hip_malloc"], "hip_host_malloc_calls_in_timed_call": a1["host_malloc"] - a0["host_malloc"],
             "what": ("ScaleEstimator(triangulation='gpu', check_triangle='reference').scale_calculation_batch on a list of per-frame arrays: "
                      "the C packer, one upload per chunk, Qhull's rows #1 (insertion order replayed on the device) / the reference's vote / "
@@ -433,7 +464,7 @@ def e2e_sharded_leg(args, device, rank, world, sizes, seed, per_rank):
     from mvoscalerecovery_amd.rescale import ScaleEstimator as RescaleEstimator
     multi = dist.is_available() and dist.is_initialized()
     out = {}
-    pool = [synth.synth_frame(400000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(min(1024, per_rank))]
+    pool = [_synth(synth, 400000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(min(1024, per_rank))]
     motion = np.array([1, 0, 0, 0.01, 0, 1, 0, -0.02, 0, 0, 1, 0.9997], dtype=np.float64)
     for name, make, frames_rank in (
             ("scale_fixed", lambda: ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, mutate_inputs=False, triangulation="gpu", delaunay_workers=0), per_rank),
@@ -476,7 +507,7 @@ def latency_leg(args, device, sizes, seed, frames=100):
     scale_calculation per frame — with SciPy's triangulations (the default, bit-exact path) and with the device's."""
     from mvoscalerecovery_amd import synth
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
-    fr = [synth.synth_frame(300000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(frames)]
+    fr = [_synth(synth, 300000 + i, sizes[i % len(sizes)], base_seed=seed) for i in range(frames)]
     out = {}
     for name, kw in (("scipy", {"triangulation": "scipy"}), ("gpu", {"triangulation": "gpu"}), ("gpu_exact", {"triangulation": "gpu", "check_triangle": "reference"})):
         est = ScaleEstimator(ABS_REF, window_size=WINDOW, device=device, delaunay_workers=0, **kw)
@@ -494,6 +525,10 @@ def latency_leg(args, device, sizes, seed, frames=100):
         out[name] = {"median_ms": float(np.median(t)), "p90_ms": float(np.percentile(t, 90)),
                      "hip_malloc_calls": a1["hip_malloc"] - a0["hip_malloc"], "hip_host_malloc_calls": a1["host_malloc"] - a0["host_malloc"]}
         if name == "gpu_exact":       # (frames the one-SciPy-call path handed back to the host's path; exact levels it computed on demand)
+            from mvoscalerecovery_amd import packing as _pk
+            out[name]["qhull_selfcheck"] = _selfcheck_record(est)
+            out[name]["host_replay"] = bool(getattr(est, "_host_replay", False))
+            out[name]["host_replay_declined_to_scipy"] = int(getattr(_pk.delaunay_simplices_fast, "declined", 0))
             out[name]["redone_on_host"] = int(getattr(est, "single_fast_redone", 0))
             out[name]["levels_on_demand"] = int(getattr(est, "single_fast_levels", 0))
     # the estimator the reference's drivers import, device-resident (one frame per call: /root/reference/src/main.py:113)
@@ -522,8 +557,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (0: 65536, or 3072 for dense frames)")
     ap.add_argument("--features", type=int, default=2000)
-    ap.add_argument("--workload", choices=("c2", "kitti"), default="c2",
-                    help="c2: every frame has --features features (configs[1]); kitti: 300-1500 per frame (configs[2]'s sizes)")
+    ap.add_argument("--workload", choices=("c2", "kitti", "gridded"), default="c2",
+                    help="c2: every frame has --features features (configs[1]); kitti: 300-1500 per frame (configs[2]'s sizes); "
+                         "gridded: c2's frames with pixel coordinates rounded to 1/4 px (sites in degenerate position: the decline path)")
     ap.add_argument("--pool", type=int, default=0, help="unique synthetic frames tiled to --frames (0: 1024, or 32 for dense frames)")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts per frame (0 = auto)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: more ranks than GPUs (gloo, devices shared round-robin)")
@@ -545,6 +581,8 @@ def main():
     args = ap.parse_args()
     if args.tile_above > 0:
         TILE_ABOVE[0] = args.tile_above
+    if args.workload == "gridded":
+        SNAP[0] = 0.25
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
@@ -553,7 +591,7 @@ def main():
         print("bench.py: WORLD_SIZE=%s but --gpus %d" % (env_world, args.gpus), file=sys.stderr)
         sys.exit(2)
 
-    dense_cfg = args.features > 6000 and args.workload == "c2"
+    dense_cfg = args.features > 6000 and args.workload in ("c2", "gridded")
     pool_n = args.pool or (32 if dense_cfg else 1024)
     frames_req = args.frames or (3072 if dense_cfg else 65536)
     pool_n = min(pool_n, frames_req)
@@ -798,6 +836,9 @@ def main():
                      "scale_frames_dense_feat_kernel" if pf_pool.tri2_ids else "scale_frames_dense_kernel")
         wl = ("synthetic %d-feature / ~%d-triangle frames (T1~%d, T2~%d)" % (args.features, round(t1_mean + t2_mean), round(t1_mean), round(t2_mean))
               if args.workload == "c2" else
+              "synthetic %d-feature frames with pixel coordinates rounded to 1/4 px (collinear / cocircular sites: Qhull merges facets, the "
+              "device triangulations decline such frames to the host's SciPy; T1~%d, T2~%d)" % (args.features, round(t1_mean), round(t2_mean))
+              if args.workload == "gridded" else
               "synthetic KITTI-sized frames, 300-1500 features each (mean %.0f; T1~%d, T2~%d)" % (n_mean, round(t1_mean), round(t2_mean)))
         line = {
             "metric": "frames/sec scale-recovery, KITTI-00 flow (~2k feats/frame), 1/2/4/8 GPU",
@@ -890,7 +931,18 @@ def main():
                 line["e2e_gpu_exact"] = e2e_gpu_leg(args, local, sizes, 2024, 1024, exact=True)
             except Exception as exc:                                    # noqa: BLE001
                 line["e2e_gpu_exact"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-        if n_gpus == 1 and not args.no_e2e and not dense:
+        if n_gpus == 1 and not args.no_e2e and not dense and args.workload == "gridded":
+            # the decline path: a quarter of these frames goes to the host's SciPy (worker pool), the rest stays on the device
+            for key, kw in (("e2e_gpu_exact", {"exact": True}), ("e2e_gpu_triangulation", {})):
+                try:
+                    line[key] = e2e_gpu_leg(args, local, sizes, 2024, 4096, **kw)
+                except Exception as exc:                                    # noqa: BLE001
+                    line[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                line["e2e"] = e2e_leg(args, local, sizes, 2024, 2048)
+            except Exception as exc:                                    # noqa: BLE001
+                line["e2e"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        elif n_gpus == 1 and not args.no_e2e and not dense:
             try:
                 line["e2e"] = e2e_leg(args, local, sizes, 2024, 4096)
             except Exception as exc:                                    # noqa: BLE001

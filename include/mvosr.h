@@ -637,6 +637,19 @@ int mvosr_delaunay_qhull_batch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *
                                const double *u, const double *v, const int32_t *keep, int max_pts, const int64_t *tri_off,
                                int32_t *tri, int32_t *tri_cnt, int32_t *n_used, int32_t *status, int32_t *order_out);
 int mvosr_delaunay_qhull_max_points(void);
+/*
+ * The same replay for ONE point set on the HOST (plain C, no device, no context; thread-safe: per-thread workspace) — replaces the
+ * reference's scipy.spatial.Delaunay call for the first triangulation of a per-frame scale_calculation
+ * (/root/reference/src/scale_calculator.py:257 from src/main.py:110-113): one frame on the device is a chain of ~n dependent
+ * insertions (20 ms at 2000 points); SciPy is 2.6 ms; this loop, which skips what Qhull does for inputs that are not in general
+ * position and what SciPy builds around the rows, is several times faster.  points: n_points rows of (x, y), stride_doubles apart
+ * (2 for a C-contiguous (n, 2) array); rows: room for rows_cap (>= 2 n_points) int32 triples; *n_rows: rows written; order
+ * (optional, n_points): the step at which a site became a vertex.  Returns 0 (rows = SciPy's simplices, bit for bit), > 0: declined
+ * — a decision inside a roundoff guard band, fewer than 3 points; the reason code as in the batch kernel's status >> 8; the
+ * caller asks SciPy —, < 0: MVOSR_ERR_ARG / MVOSR_ERR_ALLOC.
+ */
+int mvosr_qhull_rows_host(const double *points, int64_t n_points, int64_t stride_doubles, int32_t *rows, int64_t rows_cap,
+                          int32_t *n_rows, int32_t *order);
 
 /* LDS bytes the fused kernel requests for a frame of n features (host-side planning). */
 size_t mvosr_lds_bytes(int n_features);

@@ -145,6 +145,7 @@ SYMBOLS = {
     "mvosr_delaunay_batch_ex": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mvosr_delaunay_qhull_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "mvosr_delaunay_qhull_max_points": (C.c_int, []),
+    "mvosr_qhull_rows_host": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P]),
     "mvosr_delaunay_max_points": (C.c_int, []),
     "mvosr_delaunay_lds_points": (C.c_int, []),
     "mvosr_delaunay_frames_per_cu": (C.c_int, [C.c_int]),

@@ -27,15 +27,45 @@ def delaunay_simplices(points2d):
     return np.ascontiguousarray(Delaunay(points2d).simplices, dtype=np.int32)
 
 
-def qhull_rows_host_or_none():
-    """The host replay of Qhull's run (``qhull_rows_host``) as a callable ``points -> rows or None``, or ``None`` when the
-    helper library does not carry it."""
-    return None
+def qhull_rows_host(points2d):
+    """``mvosr_qhull_rows_host``: SciPy's ``Delaunay(points).simplices`` — set, order and rotation — by the C replay of Qhull's
+    run on the host (csrc/mvosr_qhull_host.c), or ``None`` where it declines (a decision inside a roundoff guard band: the caller
+    asks SciPy).  One point set, ~0.2 us per point."""
+    from . import _lib
+    lib = _lib.load()
+    p = np.ascontiguousarray(points2d, dtype=np.float64)
+    if p.ndim != 2 or p.shape[1] != 2:
+        raise ValueError("points must be (n, 2)")
+    n = p.shape[0]
+    rows = np.empty((2 * n + 8, 3), dtype=np.int32)
+    cnt = np.zeros(1, dtype=np.int32)
+    rc = lib.mvosr_qhull_rows_host(_lib.addr(p), n, 2, _lib.addr(rows), rows.shape[0], _lib.addr(cnt), None)
+    qhull_rows_host.last_reason = int(rc)
+    if rc < 0:
+        _lib.check(rc, "mvosr_qhull_rows_host")
+    if rc != 0:
+        return None
+    return rows[:int(cnt[0])]
 
 
-def _delaunay_job(points2d):
-    try:
+def delaunay_simplices_fast(points2d):
+    """The first triangulation of a per-frame call (:257): the host replay where it accepts the set, SciPy otherwise — the same
+    rows either way (selfcheck.py holds the replay to the installed SciPy)."""
+    rows = qhull_rows_host(points2d)
+    if rows is None:
+        delaunay_simplices_fast.declined = getattr(delaunay_simplices_fast, "declined", 0) + 1
         return delaunay_simplices(points2d)
+    return rows
+
+
+def qhull_rows_host_or_none():
+    """The host replay (``qhull_rows_host``) as a callable ``points -> rows or None`` for the self-check."""
+    return qhull_rows_host
+
+
+def _delaunay_job(points2d, fast=False):
+    try:
+        return delaunay_simplices_fast(points2d) if fast else delaunay_simplices(points2d)
     except Exception as exc:  # QhullError etc.: re-raised in frame order by the caller
         return exc
 
@@ -257,12 +287,13 @@ _atexit.register(shutdown_pool)
 
 def _delaunay_shm_job(job):
     """Worker: triangulate the listed point sets of the input segment, write the rows to the output segment."""
-    in_name, out_name, items = job
+    in_name, out_name, items = job[:3]
+    fast = bool(job[3]) if len(job) > 3 else False
     pin, pout = _shm_attach(in_name, (in_name, out_name)), _shm_attach(out_name, (in_name, out_name))
     results = []
     for in_off, n, out_off, cap in items:
         pts = np.ndarray((n, 2), dtype=np.float64, buffer=pin.buf, offset=16 * in_off)
-        r = _delaunay_job(pts)
+        r = _delaunay_job(pts, fast)
         if isinstance(r, Exception):
             results.append(r)
         elif r.shape[0] > cap:
@@ -331,15 +362,16 @@ class _DelaunayHandle:
         return self._done
 
 
-def delaunay_submit(point_sets, workers=0, slot=0):
+def delaunay_submit(point_sets, workers=0, slot=0, fast=False):
     """Start triangulating many point sets on the process pool and return at once (a handle with ``get()``): the host
     stage that bounds end-to-end throughput (SURVEY.md §7 hard part 1) runs while the caller packs, uploads and
     launches the GPU stages of other chunks.  ``slot`` names the pair of shared-memory segments the call uses — calls
-    that are in flight at the same time need different slots."""
+    that are in flight at the same time need different slots.  ``fast``: the C replay of Qhull's run (:func:`qhull_rows_host`) where it
+    accepts a set, SciPy otherwise — the same rows (the default estimator's few-frames path; ``triangulation="scipy"`` never asks)."""
     n = len(point_sets)
     workers = resolve_workers(workers)
     if not (workers and workers > 1 and n > 1):
-        return _DelaunayHandle(n, done=[_delaunay_job(p) for p in point_sets])
+        return _DelaunayHandle(n, done=[_delaunay_job(p, fast) for p in point_sets])
     pool = _get_pool(int(workers))
     counts = np.array([len(p) for p in point_sets], dtype=np.int64)
     in_off = np.concatenate([[0], np.cumsum(counts)])
@@ -352,7 +384,7 @@ def delaunay_submit(point_sets, workers=0, slot=0):
         allpts[in_off[f]:in_off[f + 1]] = p
     per_job = max(1, min(16, n // (int(workers) * 4)))
     jobs = [(pin.path, pout.path, [(int(in_off[f]), int(counts[f]), int(out_off[f]), int(caps[f]))
-                                    for f in range(j, min(n, j + per_job))]) for j in range(0, n, per_job)]
+                                    for f in range(j, min(n, j + per_job))], bool(fast)) for j in range(0, n, per_job)]
     rows = np.ndarray((int(out_off[-1]), 3), dtype=np.int32, buffer=pout.buf)
     return _DelaunayHandle(n, async_result=pool.map_async(_delaunay_shm_job, jobs), rows=rows, out_off=out_off)
 
@@ -482,13 +514,13 @@ def _pack_tris(tris):
     return off, flat
 
 
-def submit_tri1(pf: PackedFrames, workers=0, slot=0):
+def submit_tri1(pf: PackedFrames, workers=0, slot=0, fast=False):
     """Start the first triangulation of every frame (SciPy on the packed (u,v)); finish with :func:`attach_tri1`."""
     pts = []
     for f in range(pf.n_frames):
         s = pf.frame_slice(f)
         pts.append(np.stack([pf.u[s], pf.v[s]], axis=1))
-    return delaunay_submit(pts, workers, slot)
+    return delaunay_submit(pts, workers, slot, fast)
 
 
 def attach_tri1(pf: PackedFrames, tri1s=None, workers=0):
@@ -533,7 +565,7 @@ def survivor_points(pf: PackedFrames, valid_masks):
     return pts
 
 
-def submit_tri2(pf: PackedFrames, valid_masks, workers=0, slot=1):
+def submit_tri2(pf: PackedFrames, valid_masks, workers=0, slot=1, fast=False):
     """Start the second triangulation of every frame: SciPy over the features with ``valid_masks[f]`` (the vote result
     that came back from the GPU, in the PACKED order).  For frames that :func:`apply_locality_order` permuted, Delaunay
     still runs on the survivors in their original order — the reference's exact call.  Finish with :func:`attach_tri2`."""
@@ -550,7 +582,7 @@ def submit_tri2(pf: PackedFrames, valid_masks, workers=0, slot=1):
         # <= 3 features below the vanishing row: the reference never makes the second call (:263-270)
         pts.append(np.stack([u[m], v[m]], axis=1) if len(m) > 3 else None)
     todo = [f for f, p in enumerate(pts) if p is not None]
-    return _Tri2Handle(todo, delaunay_submit([pts[f] for f in todo], workers, slot), pf.n_frames)
+    return _Tri2Handle(todo, delaunay_submit([pts[f] for f in todo], workers, slot, fast), pf.n_frames)
 
 
 def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0, feature_ids=False):

@@ -109,7 +109,13 @@ class ScaleEstimator:
             self.qhull_selfcheck = selfcheck.run(self.engine.ctx, host_replay=packing.qhull_rows_host_or_none())
             if not self.qhull_selfcheck["ok"]:
                 self.triangulation = "scipy"
+        # the default estimator's own host triangulations (the per-frame call's first one, a handful of frames, the last frame's
+        # flat_feature) by the C replay of Qhull's run where it accepts the set (packing.delaunay_simplices_fast) — held to the installed
+        # SciPy by the self-check above; GPU_EXACT_HOST_REPLAY = False: SciPy, as in round 5
+        self._host_replay = bool(self.GPU_EXACT_HOST_REPLAY and self.triangulation == "gpu" and self.check_triangle == "reference"
+                                 and packing.qhull_rows_host_or_none() is not None)
         self.last_declined = 0                      # frames of the last device-triangulation chunk that went to the host's Qhull
+        self.declined_total = 0                     # ... of the last call, all chunks
         self.last_status = None
         self.last_counts = None
         self.last_raw_scale = None
@@ -307,14 +313,17 @@ class ScaleEstimator:
         if F == 0:
             return np.zeros(0), np.zeros(0)
         stage = bool(_single)
+        self.declined_total = 0
         # (the Qhull-rows kernel is a chain of dependent insertions: ~20 ms per 2000-point triangulation however few the frames —
         # a handful of frames, the per-frame call of /root/reference/src/main.py:113 among them, is quicker through SciPy: 6 ms)
         few_exact = False
         if self.check_triangle == "reference" and self.triangulation == "gpu":
             # device: two chains of n dependent insertions, ~11 us each, whatever the frame count (up to ~4 000 frames);
             # host: ~3 us per point and triangulation (SciPy), spread over the pool's workers — the break-even count of frames
+            # (with the host replay of Qhull's run instead of SciPy — ~3 x faster — the break-even moves accordingly)
             w = max(1, packing.resolve_workers(self.delaunay_workers))
-            few_exact = F < max(self.GPU_EXACT_MIN_FRAMES, int(3.7 * w))
+            per_worker, least = (10.0, 2.5 * self.GPU_EXACT_MIN_FRAMES) if self._host_replay else (3.7, self.GPU_EXACT_MIN_FRAMES)
+            few_exact = F < max(int(least), int(per_worker * w))
         fast = None
         if few_exact and stage and F == 1 and tri1s is None and tri2s is None and self.GPU_EXACT_SINGLE_FAST:
             fast = self._single_exact_fast(feature3ds, feature2ds)
@@ -329,7 +338,7 @@ class ScaleEstimator:
         elif tri1s is None and tri2s is None and not _single and F > self.PIPELINE_CHUNK:
             raw, status, level, counts, host_errors, last = self._stream_chunks(feature3ds, feature2ds)
         else:
-            st = self._chunk_begin(feature3ds, feature2ds, 0, tri1s)
+            st = self._chunk_begin(feature3ds, feature2ds, 0, tri1s, _fast=self._host_replay)
             self._chunk_vote(st, tri2s, 0)
             raw, status, level, counts, host_errors = self._chunk_scale(st, tri2s, stage, keep=True)
             last = st
@@ -353,7 +362,7 @@ class ScaleEstimator:
         return filtered, stds
 
     # -- one chunk of frames through the stages; the Delaunay calls are submitted to the pool and collected later
-    def _chunk_begin(self, f3s, f2s, k, tri1s=None, _packed=None, _remapped=False, _exact_all=False):
+    def _chunk_begin(self, f3s, f2s, k, tri1s=None, _packed=None, _remapped=False, _exact_all=False, _fast=False, _eng=None):
         """Vanishing-row filter + packing (:252-254) and the start of the first triangulation (:257), on the host."""
         if _packed is not None:
             pf = _packed                                               # (packed — and the caller's arrays remapped — already)
@@ -371,15 +380,21 @@ class ScaleEstimator:
         if tri1s is not None:
             h1 = tri1s
         else:
-            h1 = packing.submit_tri1(pf, self.delaunay_workers, slot=k % 4)
-        st = {"pf": pf, "h1": h1, "n": len(f3s), "out": None, "dbatch": None, "masks": None, "exact_all": bool(_exact_all)}
-        if _remapped:
+            h1 = packing.submit_tri1(pf, self.delaunay_workers, slot=k % 4, fast=_fast)
+        # (_fast: the host replay of Qhull's run instead of SciPy where it accepts the set — the default estimator's own host steps;
+        # an estimator constructed with triangulation="scipy" never sets it)
+        st = {"pf": pf, "h1": h1, "n": len(f3s), "out": None, "dbatch": None, "masks": None, "exact_all": bool(_exact_all),
+              "fast": bool(_fast)}
+        if _eng is not None:
+            st["eng"] = _eng
+        elif _remapped:
             st["eng"] = self._plain_engine()
         return st
 
     def _chunk_vote(self, st, tri2s, k):
         """First triangulation in, vote on the GPU (:151-167), start of the second triangulation (:266)."""
-        eng, ctx, pf = st.get("eng") or self.engine, self.engine.ctx, st["pf"]
+        eng = st.get("eng") or self.engine
+        ctx, pf = eng.ctx, st["pf"]
         packing.attach_tri1(pf, st["h1"], self.delaunay_workers)
         cap = int(ctx.lib.mvosr_max_lds_features())
         st["dense"] = pf.max_feat > cap
@@ -399,7 +414,7 @@ class ScaleEstimator:
                     print('feature rejected ', int(np.sum(~m)))
                     print('feature left     ', int(np.sum(m)))
             vote_out.free()
-            st["h2"] = packing.submit_tri2(pf, st["masks"], self.delaunay_workers, slot=4 + k % 4)
+            st["h2"] = packing.submit_tri2(pf, st["masks"], self.delaunay_workers, slot=4 + k % 4, fast=st.get("fast", False))
         else:
             if any(p is not None for p in (pf.extra.get("perm") or [])):
                 raise ValueError("precomputed tri2s for dense (re-ordered) frames need the vote mask: pass tri1s only")
@@ -407,7 +422,8 @@ class ScaleEstimator:
 
     def _chunk_scale(self, st, tri2s, stage, keep=False):
         """Second triangulation in, the fused GPU stages (:225-248, :324-354, :419), results to the host."""
-        eng, ctx, pf = st.get("eng") or self.engine, self.engine.ctx, st["pf"]
+        eng = st.get("eng") or self.engine
+        ctx, pf = eng.ctx, st["pf"]
         # dense frames: rows renumbered over the features, so that the kernel need not compact (less HBM traffic)
         packing.attach_tri2(pf, st["h2"], st["masks"], self.delaunay_workers,
                             feature_ids=(st["masks"] is not None and st["dense"]))
@@ -515,6 +531,7 @@ class ScaleEstimator:
                                 # the frames of the exact pass (engine.DeviceBatch.triangulate); False: Qhull's replay for every frame
     GPU_SINGLE_HOT = True           # check_triangle="fixed", ONE frame per call: the product kernels only, height_level exact when read (see _single_exact_fast)
     GPU_EXACT_SINGLE_FAST = True    # check_triangle="reference", ONE frame per call: SciPy for the first triangulation only (see _single_exact_fast)
+    GPU_EXACT_HOST_REPLAY = True    # check_triangle="reference" with triangulation="gpu": the estimator's host-side triangulations by mvosr_qhull_rows_host
     GPU_EXACT_MIN_FRAMES = 8    # ... calls of fewer frames (or fewer than ~3.7 per Delaunay worker) take SciPy's triangulations (same rows, lower latency)
     GPU_EXACT_CHUNK = 16384     # check_triangle="reference" (the Qhull-rows kernel): frames per chunk, at most ...
     GPU_EXACT_CHUNK_POINTS = 33000000   # ... and features per chunk (~0.75 KB each on the device: 25 GB at the cap)
@@ -525,6 +542,20 @@ class ScaleEstimator:
             self._engine2 = ScaleEngine(self.absolute_reference, ctx=_lib.Context(self.engine.ctx.device), camera_pitch=self.camera_pitch,
                                         check_triangle=self.check_triangle)
         return self._engine2
+
+    GPU_REDO_CONTEXT = True         # streamed batches: the host-path re-run of declined frames on a context of its own (see _chunk_gpu_finish)
+
+    def _redo_engine(self, remapped):
+        """The engine (on a third context: own streams, workspace, caches) for the re-runs of frames a device triangulation declined;
+        ``remapped``: the caller's arrays hold the remapped values already (:414), the engine's remap is the identity."""
+        if getattr(self, "_redo_ctx", None) is None:
+            self._redo_ctx = _lib.Context(self.engine.ctx.device)
+            self._redo_engines = {}
+        key = bool(remapped)
+        if key not in self._redo_engines:
+            self._redo_engines[key] = ScaleEngine(self.absolute_reference, ctx=self._redo_ctx,
+                                                  camera_pitch=0.0 if remapped else self.camera_pitch, check_triangle=self.check_triangle)
+        return self._redo_engines[key]
 
     def _chunk_gpu(self, f3s, f2s, stage, tables=False, eng=None, single_exact=False, hot_only=False):
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
@@ -566,7 +597,7 @@ class ScaleEstimator:
                     pts = f2[f2[:, 1] > self.vanish]                              # :252-254
                     if len(pts) < 5:
                         raise ValueError("too few points for the device path")
-                    tri1_rows.append(packing.delaunay_simplices(pts))
+                    tri1_rows.append(packing.delaunay_simplices_fast(pts) if self._host_replay else packing.delaunay_simplices(pts))
             except Exception:              # (QhullError, tiny frames: the host's path deals with them as the reference does)
                 st["gpu"] = False
                 if blk is not None:
@@ -618,9 +649,15 @@ class ScaleEstimator:
         raw, status, level, counts = out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts")
         host_errors = {}
         self.last_declined = len(redo)
+        self.declined_total += len(redo)
         if len(redo):
-            # (every frame of the small re-run in the exact mode: a declined frame's level may be the one a later frame reads)
-            sub = self._chunk_begin([f3s[f] for f in redo], [f2s[f] for f in redo], 0, _remapped=st["remapped"], _exact_all=True)
+            # (every frame of the small re-run in the exact mode: a declined frame's level may be the one a later frame reads).
+            # On a context of its own in a streamed batch: the re-run's small launches are waited for, and on the chunk's stream they
+            # would queue behind the chunks already launched — every chunk with one declined frame drained the pipeline (round 5:
+            # 72 declined frames in 16 384 took a call from 53 k to 30 k frames/s).  The SciPy calls go to the worker pool when the
+            # estimator has one (delaunay_workers), so the cost of a declined frame is 7 ms / workers under the GPU's queued work.
+            sub = self._chunk_begin([f3s[f] for f in redo], [f2s[f] for f in redo], 0, _remapped=st["remapped"], _exact_all=True,
+                                    _eng=None if stage or not self.GPU_REDO_CONTEXT else self._redo_engine(st["remapped"]))
             self._chunk_vote(sub, None, 0)
             r_raw, r_status, r_level, r_counts, r_err = self._chunk_scale(sub, None, False)
             raw[redo], status[redo], level[redo], counts[redo] = r_raw, r_status, r_level, r_counts
@@ -640,6 +677,7 @@ class ScaleEstimator:
                     level = np.array(level, copy=True)
                     level[late] = l_level
                     self.last_declined += len(late)
+                    self.declined_total += len(late)
         if stage:
             c = db.bufs["vote_counters"].download()
             st["masks"] = [c[pf.frame_slice(f)] >= 0 for f in range(pf.n_frames)]
@@ -768,7 +806,7 @@ class ScaleEstimator:
         if not sets_level:
             # marked (_lib.ST_REDO), or a status whose level is read at once: the frame again, through the host's path
             self._chunk_free(st)
-            sub = self._chunk_begin([f3], [f2], 0, tri1s=st.get("tri1_rows"), _remapped=st["remapped"])
+            sub = self._chunk_begin([f3], [f2], 0, tri1s=st.get("tri1_rows"), _remapped=st["remapped"], _fast=self._host_replay)
             self._chunk_vote(sub, None, 0)
             raw, status, level, counts, host_errors = self._chunk_scale(sub, None, True, keep=True)
             self.single_fast_redone = getattr(self, "single_fast_redone", 0) + 1
@@ -784,7 +822,7 @@ class ScaleEstimator:
                     _, _, lvl, _, _, ps = self._stream_gpu([raw_in], [f2_in], False)
                     self._chunk_free(ps)
                 else:
-                    sub = self._chunk_begin([raw_in], [f2_in], 0, tri1s=rows1, _exact_all=True)
+                    sub = self._chunk_begin([raw_in], [f2_in], 0, tri1s=rows1, _exact_all=True, _fast=self._host_replay)
                     self._chunk_vote(sub, None, 0)
                     _, _, lvl, _, _ = self._chunk_scale(sub, None, False)
             finally:
@@ -812,7 +850,7 @@ class ScaleEstimator:
                 self._store_flat_feature(one["pf"], one["out"], [f3], [f2], one["masks"], 0, status[0])
                 self._chunk_free(one)
                 return
-            one = self._chunk_begin([f3], [f2], 0)
+            one = self._chunk_begin([f3], [f2], 0, _fast=self._host_replay)
             one["eng"] = self._plain_engine() if mutate else self.engine
             self._chunk_vote(one, None, 0)
             _, status, _, _, _ = self._chunk_scale(one, None, True, keep=True)
