@@ -436,8 +436,27 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames, exact=False):
             b.free()
     else:
         dt_alone = None
+    roof = None
+    if exact and dt_alone is not None and n == 2000:
+        # The default path's dominant kernel priced like the headline's (VERDICT r5 #2a).  Its roof is VECTOR INSTRUCTION ISSUE, not HBM
+        # (a chain of dependent insertions; HBM at ~9 % of the peak): achieved = the VALU wave-instructions one set costs (rocprofv3
+        # SQ_INSTS_VALU of this kernel on these sizes: profiles/qhull_counters.json, re-collected per round) x the sets/s measured HERE
+        # with HIP events; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per 64-lane instruction.
+        try:
+            qc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "qhull_counters.json")))
+            peak = 256 * 4 * 2.4e9 / 4.0
+            ach = qc["valu_wave_instructions_per_set"] * dt_alone["sets_per_s"]
+            roof = {"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "wave-instructions/s", "frac": ach / peak,
+                    "kernel": "qhull_rows_kernel<unsigned short, 64, 64, false>", "kernel_ms": dt_alone["kernel_ms"], "sets_per_launch": F,
+                    "valu_per_insertion": qc["valu_wave_instructions_per_set"] / qc["insertions_per_set"],
+                    "salu_per_insertion": qc["salu_instructions_per_set"] / qc["insertions_per_set"],
+                    "hbm_bytes_per_set": qc["fetch_bytes_per_set"] + qc["write_bytes_per_set"],
+                    "hbm_frac_of_8TBps": (qc["fetch_bytes_per_set"] + qc["write_bytes_per_set"]) * dt_alone["sets_per_s"] / 8e12,
+                    "counters_from": "profiles/qhull_counters.json (%s)" % qc.get("tag")}
+        except Exception as exc:                                        # noqa: BLE001
+            roof = {"error": "%s: %s" % (type(exc).__name__, exc)}
     return {"value": n_frames / dt, "unit": "frames/s", "frames": n_frames, "distinct_frames": npool,
-            "timed_calls_frames_per_s": [n_frames / t for t in times],
+            "timed_calls_frames_per_s": [n_frames / t for t in times], "roofline": roof,
             "declined_total": int(est.declined_total), "declined_fraction": float(est.declined_total) / max(n_frames, 1),
             "qhull_selfcheck": _selfcheck_record(est), "delaunay_kernel": dt_alone,
             "hip_malloc_calls_in_timed_call": a1["hip_malloc"] - a0["hip_malloc"], "hip_host_malloc_calls_in_timed_call": a1["host_malloc"] - a0["host_malloc"],

@@ -684,6 +684,32 @@ template <typename FID, int G, int TAB> __device__ __forceinline__ int qh_run(co
             if (S_::any(copl)) return QH_COPLANAR_HORIZON;
             if (S_::any(bad)) return QH_BAND;
             QH_STAMP(1);
+            // The visible facets' points (what (e) partitions) are known as soon as the visible list is: their ids (a load from the
+            // arena) and then their coordinates (a dependent load) are two of an insertion's ~8 memory round trips.  The first chunk's
+            // ids can be asked for HERE, under the cone's own loads, and their coordinates before the matching, which is LDS work only:
+            // (e) then starts with its operands in registers.  MEASURED (round 6, same box, -DMVOSR_QH_PREFETCH against without): 34.75 /
+            // 34.94 against 34.86 / 34.84 ms per launch of 4 096 sets, 126.41 / 125.74 against 126.56 / 126.04 for 16 384 — nothing, like
+            // round 5's variant that only touched the sectors (LABNOTES §9.15): at four wavefronts per SIMD a wavefront's own round trips
+            // are hidden behind the others' instructions already.  Off by default; the prefix sum alone stays here.
+            int S = 0;
+            {
+                if (lane == 0) {
+                    uint32_t c = 0;
+                    for (int e = 0; e < nvis; ++e) { L.viscum[e] = c; c += L.viscnt[e] + (L.visbest[e] != kQhNone ? 1u : 0u); }
+                    L.viscum[nvis] = c;
+                }
+                qh_lds_sync();
+                S = (int)L.viscum[nvis];
+            }
+            if (atop + (uint32_t)S > P.acap) return QH_ARENA_FULL;
+#ifdef MVOSR_QH_PREFETCH
+            int q_pre = 0, e_pre = 0;
+            if (lane < S) {
+                while (e_pre + 1 < nvis && (int)L.viscum[e_pre + 1] <= lane) ++e_pre;
+                const int r = lane - (int)L.viscum[e_pre];
+                q_pre = r < (int)L.viscnt[e_pre] ? arena[L.visoff[e_pre] + r] : L.visbest[e_pre];
+            }
+#endif
             // (c) qh_makenewfacets: for each visible facet in order, for each horizon neighbour in order, a facet (apex first)
             int m = 0;
             for (int e = lane; e < nvis; e += G) L.visrep[e] = kQhNone;
@@ -735,6 +761,10 @@ template <typename FID, int G, int TAB> __device__ __forceinline__ int qh_run(co
             if (S_::any(gauss)) return QH_GAUSS;
             if (S_::any(notconv)) return QH_NOT_CONVEX;
             if (m < 3) return QH_OPEN_CONE;
+#ifdef MVOSR_QH_PREFETCH
+            double x_pre = 0.0, y_pre = 0.0, z_pre = 0.0;
+            if (lane < S) { x_pre = X[q_pre]; y_pre = Y[q_pre]; z_pre = Z[q_pre]; }
+#endif
             QH_STAMP(2);
             // (d) qh_matchnewfacets: neighbour 1 shares the ridge {apex, b}, neighbour 2 the ridge {apex, a};
             //     qh_sharpnewfacets: the cone's normals in more than one orthant
@@ -774,17 +804,6 @@ template <typename FID, int G, int TAB> __device__ __forceinline__ int qh_run(co
             const unsigned long long t_part0 = t_last;
 #endif
             // (e) qh_partitionvisible: the visible facets' points, in list order, to the cone
-            int S = 0;
-            {
-                if (lane == 0) {
-                    uint32_t c = 0;
-                    for (int e = 0; e < nvis; ++e) { L.viscum[e] = c; c += L.viscnt[e] + (L.visbest[e] != kQhNone ? 1u : 0u); }
-                    L.viscum[nvis] = c;
-                }
-                qh_lds_sync();
-                S = (int)L.viscum[nvis];
-            }
-            if (atop + (uint32_t)S > P.acap) return QH_ARENA_FULL;
             {
                 // targets: a directed walk per point; from the first point that ends below its best facet on a sharp cone,
                 // a linear scan (qh.findbestnew stays set for the rest of this insertion)
@@ -795,6 +814,12 @@ template <typename FID, int G, int TAB> __device__ __forceinline__ int qh_run(co
                     const bool valid = i < S;
                     int q = 0, start = 0;
                     double x = 0.0, y = 0.0, z = 0.0;
+#ifdef MVOSR_QH_PREFETCH
+                    if (valid && base == 0) {
+                        q = q_pre; x = x_pre; y = y_pre; z = z_pre;
+                        start = L.visrep[e_pre] == kQhNone ? 0 : L.visrep[e_pre];
+                    } else
+#endif
                     if (valid) {
                         int e = 0;
                         while (e + 1 < nvis && (int)L.viscum[e + 1] <= i) ++e;

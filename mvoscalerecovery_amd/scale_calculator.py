@@ -323,7 +323,7 @@ class ScaleEstimator:
             # (with the host replay of Qhull's run instead of SciPy — ~3 x faster — the break-even moves accordingly)
             w = max(1, packing.resolve_workers(self.delaunay_workers))
             per_worker, least = (10.0, 2.5 * self.GPU_EXACT_MIN_FRAMES) if self._host_replay else (3.7, self.GPU_EXACT_MIN_FRAMES)
-            few_exact = F < max(int(least), int(per_worker * w))
+            few_exact = F < max(int(least), int(per_worker * w)) and not self.GPU_EXACT_FORCE_DEVICE
         fast = None
         if few_exact and stage and F == 1 and tri1s is None and tri2s is None and self.GPU_EXACT_SINGLE_FAST:
             fast = self._single_exact_fast(feature3ds, feature2ds)
@@ -532,6 +532,7 @@ class ScaleEstimator:
     GPU_SINGLE_HOT = True           # check_triangle="fixed", ONE frame per call: the product kernels only, height_level exact when read (see _single_exact_fast)
     GPU_EXACT_SINGLE_FAST = True    # check_triangle="reference", ONE frame per call: SciPy for the first triangulation only (see _single_exact_fast)
     GPU_EXACT_HOST_REPLAY = True    # check_triangle="reference" with triangulation="gpu": the estimator's host-side triangulations by mvosr_qhull_rows_host
+    GPU_EXACT_FORCE_DEVICE = False  # (tests) the device replay however few the frames
     GPU_EXACT_MIN_FRAMES = 8    # ... calls of fewer frames (or fewer than ~3.7 per Delaunay worker) take SciPy's triangulations (same rows, lower latency)
     GPU_EXACT_CHUNK = 16384     # check_triangle="reference" (the Qhull-rows kernel): frames per chunk, at most ...
     GPU_EXACT_CHUNK_POINTS = 33000000   # ... and features per chunk (~0.75 KB each on the device: 25 GB at the cap)

@@ -15,5 +15,6 @@ for f in mvosr_kernels mvosr_rescale mvosr_delaunay mvosr_qhull mvosr_capi; do
   fi
 done
 wait
+cp mvosr_qhull_host.o $R/profiles/ab/obj_$NAME/mvosr_qhull_host.o      # (plain C, no flags of interest: from the product build)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $R/profiles/ab/obj_$NAME/*.o -o $R/profiles/ab/libmvosr_$NAME.so
 echo built $R/profiles/ab/libmvosr_$NAME.so

@@ -24,6 +24,8 @@ def main():
         from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
         est = ScaleEstimator(1.75, window_size=5, device=0, delaunay_workers=0, triangulation="gpu", check_triangle="reference")
         est.GPU_EXACT_SINGLE_FAST = os.environ.get("SINGLE_FAST", "1") == "1"
+        if os.environ.get("HOST_REPLAY", "1") != "1":     # the first triangulation by SciPy, as in round 5 (A/B of mvosr_qhull_rows_host)
+            est._host_replay = False
     else:
         from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
         est = ScaleEstimator(1.75, window_size=5, device=0, delaunay_workers=0, triangulation="gpu")

@@ -56,6 +56,20 @@ def main():
                   "dependent steps (WAIT_ANY above) with the VALU pipe ~50 %% busy at four wavefronts per SIMD (SQ_ACTIVE_INST_VALU x 4 waves / launch time)."
                   % (fetch / frames / 1e6, 2 * fetch / frames / 1e6, write / frames / 1e6, alg / 1e3, fetch / frames / 1997.0 / 1e3,
                      rate / 1e3, fetch / frames * rate / 1e12, write / frames * rate / 1e12, 100.0 * (fetch + write) / frames * rate / 8e12)]
+    # the counters bench.py prices e2e_gpu_exact's roofline record with (instruction counts of a run are a property of the point sets and
+    # the kernel source, not of the box: the bench multiplies them with the rate it measures live)
+    import json
+    if "SQ_INSTS_VALU" in med:
+        rec = {"tag": tag, "sets": frames, "points_per_set": pts, "insertions_per_set": 1997,
+               "valu_wave_instructions_per_set": med["SQ_INSTS_VALU"] / frames, "salu_instructions_per_set": med.get("SQ_INSTS_SALU", 0) / frames,
+               "lds_instructions_per_set": med.get("SQ_INSTS_LDS", 0) / frames,
+               "vmem_rd_per_set": med.get("SQ_INSTS_VMEM_RD", 0) / frames, "vmem_wr_per_set": med.get("SQ_INSTS_VMEM_WR", 0) / frames,
+               "fetch_bytes_per_set": med.get("FETCH_SIZE", 0) * 1024 / frames, "write_bytes_per_set": med.get("WRITE_SIZE", 0) * 1024 / frames,
+               "wait_any_share_of_wave_cycles": med.get("SQ_WAIT_ANY", 0) / med["SQ_WAVE_CYCLES"] if med.get("SQ_WAVE_CYCLES") else None,
+               "kernel_ms_rocprof_max": float(rows[0]["MaxNs"]) / 1e6,
+               "method": "rocprofv3 --pmc, separate passes, median over the launches of %d sets (profiles/qhull_gpu_check.py); FETCH_SIZE uncorrected "
+                         "(32- and 64-byte requests)" % frames}
+        json.dump(rec, open(os.path.join(HERE, "qhull_counters.json"), "w"), indent=1)
     open(os.path.join(HERE, tag + "_qhull_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 

@@ -116,7 +116,7 @@ def test_chunk_boundary_fuzz_of_the_cross_frame_state(gpu, mode):
         f3s, f2s = [f[0].copy() for f in frames], [f[1].copy() for f in frames]
         if mode == "gpu_exact":            # device triangulations with the reference's vote: stand-in second triangulation, masked relaunches
             est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle="reference", delaunay_workers=0)
-            est.GPU_EXACT_CHUNK, est.GPU_EXACT_MIN_FRAMES = chunk, 1
+            est.GPU_EXACT_CHUNK, est.GPU_EXACT_FORCE_DEVICE = chunk, True
         else:
             est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation=mode, delaunay_workers=4)
         est.GPU_CHUNK, est.GPU_RAMP, est.PIPELINE_CHUNK, est.GPU_MIN_CHUNK = chunk, False, chunk, 1
@@ -729,6 +729,8 @@ def test_workspace_allocation_failure_takes_the_host_path(gpu, tmp_path):
         frames = [synth.synth_frame(i, 500 + 7 * i, base_seed=31) for i in range(40)]
         f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
         ctx = _lib.default_context(0)
+        from mvoscalerecovery_amd import selfcheck
+        assert selfcheck.run(ctx)["ok"]                                     # (the first-use check of the Qhull replay, before the cap)
         ctx.workspace_limit(1)
         rc = ctx.lib.mvosr_delaunay_qhull_batch(ctx.handle, 1, None, None, None, None, None, 10, None, None, None, None, None, None)
         assert rc == -2                                                     # (argument check comes first)

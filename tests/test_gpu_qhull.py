@@ -139,7 +139,7 @@ def test_dense_frames_reference_exact_on_the_device(gpu, monkeypatch):
     t2 = packing.delaunay_gpu(gpu, [low], [keep], rows="qhull")[0]
     assert np.array_equal(t2, z["tri2"].astype(np.int32))                           # and, over the vote's survivors, its second
     est = ScaleEstimator(meta["abs_ref"], window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle="reference", delaunay_workers=0)
-    est.GPU_EXACT_MIN_FRAMES = 1
+    est.GPU_EXACT_FORCE_DEVICE = True                                                 # (four frames: the host replay would be quicker)
     host_calls = []
     real_attach = packing.attach_tri1
     monkeypatch.setattr(packing, "attach_tri1", lambda pf, *a, **k: (host_calls.append(pf.n_frames), real_attach(pf, *a, **k))[1])
