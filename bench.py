@@ -188,7 +188,7 @@ def launch_ranks(args, argv):
 TILE_ABOVE = [1 << 30]
 
 
-SNAP = [0.0]          # --workload gridded: pixel coordinates rounded to this grid (0.25 px)
+SNAP = [0.0, 1.0]     # --workload gridded: pixel coordinates rounded to this grid (0.25 px) in this fraction of the frames (--snap-fraction)
 
 
 def _synth(synth, i, n, base_seed):
@@ -196,7 +196,7 @@ def _synth(synth, i, n, base_seed):
     cocircular sites by construction (what a detector with sub-pixel refinement to 1/4 px hands over): the regime in which Qhull
     merges facets and the replay DECLINES to the host's SciPy (VERDICT r5 #3)."""
     f3, f2 = synth.synth_frame(i, n, base_seed=base_seed)
-    if SNAP[0] > 0.0:
+    if SNAP[0] > 0.0 and ((i * 2654435761) % (1 << 32)) / float(1 << 32) < SNAP[1]:
         f2 = np.ascontiguousarray(np.round(f2 / SNAP[0]) * SNAP[0])
     return f3, f2
 
@@ -579,6 +579,9 @@ def main():
     ap.add_argument("--workload", choices=("c2", "kitti", "gridded"), default="c2",
                     help="c2: every frame has --features features (configs[1]); kitti: 300-1500 per frame (configs[2]'s sizes); "
                          "gridded: c2's frames with pixel coordinates rounded to 1/4 px (sites in degenerate position: the decline path)")
+    ap.add_argument("--snap-fraction", type=float, default=1.0,
+                    help="--workload gridded: the share of the frames whose coordinates are snapped (1.0: all; 0.005: the decline rate "
+                         "ordinary data showed before round 5's restatements — the cost of a FEW declined frames per chunk)")
     ap.add_argument("--pool", type=int, default=0, help="unique synthetic frames tiled to --frames (0: 1024, or 32 for dense frames)")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts per frame (0 = auto)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: more ranks than GPUs (gloo, devices shared round-robin)")
@@ -601,7 +604,7 @@ def main():
     if args.tile_above > 0:
         TILE_ABOVE[0] = args.tile_above
     if args.workload == "gridded":
-        SNAP[0] = 0.25
+        SNAP[0], SNAP[1] = 0.25, float(args.snap_fraction)
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
@@ -855,8 +858,8 @@ def main():
                      "scale_frames_dense_feat_kernel" if pf_pool.tri2_ids else "scale_frames_dense_kernel")
         wl = ("synthetic %d-feature / ~%d-triangle frames (T1~%d, T2~%d)" % (args.features, round(t1_mean + t2_mean), round(t1_mean), round(t2_mean))
               if args.workload == "c2" else
-              "synthetic %d-feature frames with pixel coordinates rounded to 1/4 px (collinear / cocircular sites: Qhull merges facets, the "
-              "device triangulations decline such frames to the host's SciPy; T1~%d, T2~%d)" % (args.features, round(t1_mean), round(t2_mean))
+              "synthetic %d-feature frames, %.1f %% of them with pixel coordinates rounded to 1/4 px (collinear / cocircular sites: Qhull merges "
+              "facets, the device triangulations decline such frames to the host's SciPy; T1~%d, T2~%d)" % (args.features, 100 * SNAP[1], round(t1_mean), round(t2_mean))
               if args.workload == "gridded" else
               "synthetic KITTI-sized frames, 300-1500 features each (mean %.0f; T1~%d, T2~%d)" % (n_mean, round(t1_mean), round(t2_mean)))
         line = {
@@ -954,7 +957,7 @@ def main():
             # the decline path: a quarter of these frames goes to the host's SciPy (worker pool), the rest stays on the device
             for key, kw in (("e2e_gpu_exact", {"exact": True}), ("e2e_gpu_triangulation", {})):
                 try:
-                    line[key] = e2e_gpu_leg(args, local, sizes, 2024, 4096, **kw)
+                    line[key] = e2e_gpu_leg(args, local, sizes, 2024, 4096 if SNAP[1] > 0.2 else 16384, **kw)
                 except Exception as exc:                                    # noqa: BLE001
                     line[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             try:

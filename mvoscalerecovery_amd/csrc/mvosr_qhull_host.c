@@ -38,16 +38,22 @@ enum {  /* decline reasons (return value; 0 = rows written) — the device kerne
 #define QHH_ERR_ALLOC (-5)   /* MVOSR_ERR_ALLOC */
 #define QHH_ERR_ARG (-2)     /* MVOSR_ERR_ARG */
 
-typedef struct {
-    double n0, n1, n2, off, fdist;
-    int32_t v[3];        /* vertex ids, newest first */
+/* A facet in two halves: what a distance test and a walk touch — the plane, the neighbours, the visit stamp, the flags, the vertices —
+ * is ONE 64-byte cache line; list links and the outside set live apart (a run is ~100 000 distance tests against ~30 000 list edits) */
+typedef struct __attribute__((aligned(64))) {
+    double n0, n1, n2, off;
     int32_t nb[3];       /* neighbour i is opposite vertex i */
+    uint32_t visit;
+    int32_t v[3];        /* vertex ids, newest first */
+    uint8_t top, upper, visible, isnew;
+} qh_facet;
+typedef struct {
+    double fdist;
     int32_t prev, next;  /* the facet list: order is part of the algorithm */
     int32_t out_first, out_last;   /* outside set: a doubly linked list through the points (a point is in one set at most) */
     int32_t replace;
-    uint32_t visit;
-    uint8_t top, upper, visible, isnew, has_out, pad[3];
-} qh_facet;
+    uint8_t has_out, pad[3];
+} qh_cold;
 
 typedef struct {
     int n, m;                       /* sites; points including the one at infinity */
@@ -56,6 +62,7 @@ typedef struct {
     int32_t *vpoint;                /* vertex id (from 1) -> point */
     int nvert;
     qh_facet *F;
+    qh_cold *C;
     int ncap, nused, free_head;     /* facet slots: [0] is the list's tail sentinel; dead facets are reused */
     int head, facet_next;
     uint32_t visit_id;
@@ -86,67 +93,69 @@ static void *ws_get(int slot, size_t bytes) {
 
 /* ---- list plumbing ---- */
 static inline void fl_append(qh_state *S, int f) {
-    qh_facet *F = S->F;
+    qh_cold *C = S->C;
     const int t = 0;
-    F[f].prev = F[t].prev;
-    F[f].next = t;
-    if (F[t].prev >= 0) F[F[t].prev].next = f; else S->head = f;
-    F[t].prev = f;
+    C[f].prev = C[t].prev;
+    C[f].next = t;
+    if (C[t].prev >= 0) C[C[t].prev].next = f; else S->head = f;
+    C[t].prev = f;
     if (S->facet_next == t) S->facet_next = f;
 }
 static inline void fl_remove(qh_state *S, int f) {
-    qh_facet *F = S->F;
-    if (f == S->facet_next) S->facet_next = F[f].next;
-    if (F[f].prev >= 0) F[F[f].prev].next = F[f].next; else S->head = F[f].next;
-    F[F[f].next].prev = F[f].prev;
-    F[f].prev = F[f].next = -1;
+    qh_cold *C = S->C;
+    if (f == S->facet_next) S->facet_next = C[f].next;
+    if (C[f].prev >= 0) C[C[f].prev].next = C[f].next; else S->head = C[f].next;
+    C[C[f].next].prev = C[f].prev;
+    C[f].prev = C[f].next = -1;
 }
 static inline void fl_prepend(qh_state *S, int f, int before) {
-    qh_facet *F = S->F;
-    F[f].prev = F[before].prev;
-    F[f].next = before;
-    if (F[before].prev >= 0) F[F[before].prev].next = f; else S->head = f;
-    F[before].prev = f;
+    qh_cold *C = S->C;
+    C[f].prev = C[before].prev;
+    C[f].next = before;
+    if (C[before].prev >= 0) C[C[before].prev].next = f; else S->head = f;
+    C[before].prev = f;
 }
 
 static int facet_new(qh_state *S) {
     int f;
     if (S->free_head >= 0) {
         f = S->free_head;
-        S->free_head = S->F[f].next;
+        S->free_head = S->C[f].next;
     } else {
         if (S->nused >= S->ncap) return -1;
         f = S->nused++;
     }
     qh_facet *q = &S->F[f];
-    q->prev = q->next = -1;
-    q->out_first = q->out_last = -1;
-    q->has_out = 0;
-    q->fdist = 0.0;
-    q->visible = 0; q->isnew = 0; q->visit = 0; q->replace = -1; q->upper = 0; q->top = 0;
+    qh_cold *c = &S->C[f];
+    c->prev = c->next = -1;
+    c->out_first = c->out_last = -1;
+    c->has_out = 0;
+    c->fdist = 0.0;
+    c->replace = -1;
+    q->visible = 0; q->isnew = 0; q->visit = 0; q->upper = 0; q->top = 0;
     q->nb[0] = q->nb[1] = q->nb[2] = -1;
     return f;
 }
 
 /* ---- outside sets ---- */
-static inline void out_append(qh_state *S, qh_facet *f, int p) {
+static inline void out_append(qh_state *S, qh_cold *f, int p) {
     S->onext[p] = -1; S->oprev[p] = f->out_last;
     if (f->out_last >= 0) S->onext[f->out_last] = p; else f->out_first = p;
     f->out_last = p;
 }
-static inline void out_insert_before_last(qh_state *S, qh_facet *f, int p) {
+static inline void out_insert_before_last(qh_state *S, qh_cold *f, int p) {
     const int l = f->out_last, pl = S->oprev[l];
     S->onext[p] = l; S->oprev[p] = pl;
     S->oprev[l] = p;
     if (pl >= 0) S->onext[pl] = p; else f->out_first = p;
 }
-static inline int out_pop(qh_state *S, qh_facet *f) {
+static inline int out_pop(qh_state *S, qh_cold *f) {
     const int p = f->out_last, pl = S->oprev[p];
     f->out_last = pl;
     if (pl >= 0) S->onext[pl] = -1; else f->out_first = -1;
     return p;
 }
-static inline void add_outside(qh_state *S, qh_facet *f, int p, double d) {
+static inline void add_outside(qh_state *S, qh_cold *f, int p, double d) {
     if (f->out_first < 0) { f->out_first = f->out_last = -1; out_append(S, f, p); f->fdist = d; f->has_out = 1; }
     else if (f->fdist < d) { out_append(S, f, p); f->fdist = d; }
     else out_insert_before_last(S, f, p);
@@ -281,6 +290,7 @@ static int find_best_horizon(qh_state *S, int p, int start, double *bestd_io) {
 
 static int find_best_new(qh_state *S, int p, int start, double *dout) {
     qh_facet *F = S->F;
+    const qh_cold *C = S->C;
     const uint32_t vid = ++S->visit_id;
     int best = -1;
     double bestd = -QH_BIG;
@@ -296,7 +306,7 @@ static int find_best_new(qh_state *S, int p, int start, double *dout) {
                 if (d >= S->distoutside) { *dout = d; return f; }
                 bestd = d;
             }
-            f = F[f].next;
+            f = C[f].next;
         }
     }
     best = find_best_horizon(S, p, best >= 0 ? best : start, &bestd);
@@ -308,9 +318,10 @@ static int find_best_new(qh_state *S, int p, int start, double *dout) {
 
 static int cone_is_sharp(const qh_state *S) {
     const qh_facet *F = S->F;
+    const qh_cold *C = S->C;
     int f = S->newlist;
     const int q0 = F[f].n0 > 0, q1 = F[f].n1 > 0, q2 = F[f].n2 > 0;
-    for (f = F[f].next; f != 0; f = F[f].next)
+    for (f = C[f].next; f != 0; f = C[f].next)
         if (q0 != (F[f].n0 > 0) || q1 != (F[f].n1 > 0) || q2 != (F[f].n2 > 0)) return 1;
     return 0;
 }
@@ -359,6 +370,7 @@ static int qh_run(qh_state *S) {
     const int m = S->m;
     double *xs = S->x, *ys = S->y, *zs = S->z;
     qh_facet *F = S->F;
+    qh_cold *C = S->C;
     /* 2. extreme points per coordinate (first strict maximum / minimum in input order, maximum tested first), ranges */
     int maxpoints[6];
     double maxabs = 0.0, maxwidth = 0.0, maxsum = 0.0, zlow = 0.0, zhigh = 0.0;
@@ -436,7 +448,7 @@ static int qh_run(qh_state *S) {
     for (int i = 0; i < 4; ++i) S->vpoint[i + 1] = simplex[i];
     S->nvert = 5;
     S->visit_id = 0;
-    F[0].prev = -1; F[0].next = -1; F[0].out_first = F[0].out_last = -1; F[0].has_out = 0; F[0].isnew = 0; F[0].visit = 0; F[0].upper = 1;
+    C[0].prev = -1; C[0].next = -1; C[0].out_first = C[0].out_last = -1; C[0].has_out = 0; F[0].isnew = 0; F[0].visit = 0; F[0].upper = 1;
     S->nused = 1; S->free_head = -1;
     S->head = 0; S->facet_next = 0;
     int fs[4];
@@ -483,10 +495,11 @@ static int qh_run(qh_state *S) {
             if (p == simplex[0] || p == simplex[1] || p == simplex[2] || p == simplex[3]) continue;
             pointset[np++] = p;
         }
-        for (int f = S->head; f != 0; f = F[f].next) {
+        for (int f = S->head; f != 0; f = C[f].next) {
             int nrest = 0, best = -1;
             double bestd = 0.0;
-            qh_facet *q = &F[f];
+            const qh_facet *q = &F[f];
+            qh_cold *qc = &C[f];
             for (int i = 0; i < np; ++i) {
                 const int p = pointset[i];
                 const double d = dist_pf(S, p, q);
@@ -495,11 +508,11 @@ static int qh_run(qh_state *S) {
                     if (d > -S->guard && d > S->distoutside - 2 * S->guard) return QHH_INITIAL_ROUNDOFF;
                 } else {
                     if (best < 0) { best = p; bestd = d; }
-                    else if (d > bestd) { out_append(S, q, best); best = p; bestd = d; }
-                    else out_append(S, q, p);
+                    else if (d > bestd) { out_append(S, qc, best); best = p; bestd = d; }
+                    else out_append(S, qc, p);
                 }
             }
-            if (best >= 0) { out_append(S, q, best); q->fdist = bestd; q->has_out = 1; }
+            if (best >= 0) { out_append(S, qc, best); qc->fdist = bestd; qc->has_out = 1; }
             np = nrest;
         }
         if (np) return QHH_INSIDE_SIMPLEX;
@@ -508,8 +521,8 @@ static int qh_run(qh_state *S) {
     {
         int best = -1;
         double bestd = -QH_BIG;
-        for (int f = S->head; f != 0; f = F[f].next)
-            if (F[f].has_out && F[f].fdist > bestd) { best = f; bestd = F[f].fdist; }
+        for (int f = S->head; f != 0; f = C[f].next)
+            if (C[f].has_out && C[f].fdist > bestd) { best = f; bestd = C[f].fdist; }
         S->facet_next = S->head;
         if (best >= 0) {
             fl_remove(S, best);
@@ -521,14 +534,14 @@ static int qh_run(qh_state *S) {
     uint32_t ridge_generation = 0;
     for (;;) {
         int f = S->facet_next;
-        while (f != 0 && F[f].out_first < 0) { F[f].has_out = 0; f = F[f].next; }
+        while (f != 0 && C[f].out_first < 0) { C[f].has_out = 0; f = C[f].next; }
         S->facet_next = f;
         if (f == 0) break;
-        const int p = out_pop(S, &F[f]);
+        const int p = out_pop(S, &C[f]);
         /* the visible facets, breadth first in neighbour order */
         fl_remove(S, f);
         fl_append(S, f);
-        F[f].visible = 1; F[f].replace = -1;
+        F[f].visible = 1; C[f].replace = -1;
         int nvis = 0;
         S->visible[nvis++] = f;
         const uint32_t vid = ++S->visit_id;
@@ -544,7 +557,7 @@ static int qh_run(qh_state *S) {
                     if (d < S->guard) return QHH_VISIBILITY_ROUNDOFF;
                     fl_remove(S, g);
                     fl_append(S, g);
-                    F[g].visible = 1; F[g].replace = -1;
+                    F[g].visible = 1; C[g].replace = -1;
                     if (nvis >= S->listcap) return QHH_ROWS_OVERFLOW;
                     S->visible[nvis++] = g;
                 } else if (d >= -S->guard) return QHH_COPLANAR_HORIZON;
@@ -575,7 +588,7 @@ static int qh_run(qh_state *S) {
                 S->newf[nnew++] = nf;
                 last = nf;
             }
-            if (last >= 0) F[vis].replace = last;
+            if (last >= 0) C[vis].replace = last;
         }
         if (!nnew) return QHH_OPEN_CONE;
         S->newlist = S->newf[0];
@@ -618,25 +631,25 @@ static int qh_run(qh_state *S) {
         S->findbestnew = 0; S->notsharp = 0;
         for (int i = 0; i < nvis; ++i) {
             const int vis = S->visible[i];
-            if (F[vis].out_first < 0) continue;
-            const int start = F[vis].replace >= 0 ? F[vis].replace : S->newlist;
-            int q = F[vis].out_first;
+            if (C[vis].out_first < 0) continue;
+            const int start = C[vis].replace >= 0 ? C[vis].replace : S->newlist;
+            int q = C[vis].out_first;
             while (q >= 0) {
                 const int qn = S->onext[q];
                 double d;
                 const int g = partition_point(S, q, start, &d);
                 if (g < 0) return S->why;
-                if (F[g].out_first < 0 && !F[g].isnew) { fl_remove(S, g); fl_append(S, g); }   /* an old facet takes a point */
-                add_outside(S, &F[g], q, d);
+                if (C[g].out_first < 0 && !F[g].isnew) { fl_remove(S, g); fl_append(S, g); }   /* an old facet takes a point */
+                add_outside(S, &C[g], q, d);
                 q = qn;
             }
-            F[vis].out_first = F[vis].out_last = -1;
+            C[vis].out_first = C[vis].out_last = -1;
         }
         for (int i = 0; i < nvis; ++i) {
             const int vis = S->visible[i];
             fl_remove(S, vis);
             F[vis].visible = 0;
-            F[vis].next = S->free_head;       /* (free list through `next`) */
+            C[vis].next = S->free_head;       /* (free list through `next`) */
             S->free_head = vis;
         }
         for (int i = 0; i < nnew; ++i) F[S->newf[i]].isnew = 0;
@@ -647,8 +660,9 @@ static int qh_run(qh_state *S) {
 /* rows: SciPy's — lower facets in list order; vertices by decreasing vertex id, first two swapped when NOT top-oriented */
 static int emit_rows(const qh_state *S, int32_t *rows, int rows_cap) {
     const qh_facet *F = S->F;
+    const qh_cold *C = S->C;
     int t = 0;
-    for (int f = S->head; f != 0; f = F[f].next) {
+    for (int f = S->head; f != 0; f = C[f].next) {
         if (F[f].upper) continue;
         if (t >= rows_cap) return -1;
         const int a = S->vpoint[F[f].v[0]], b = S->vpoint[F[f].v[1]], c = S->vpoint[F[f].v[2]];
@@ -676,11 +690,15 @@ int mvosr_qhull_rows_host(const double *points, int64_t n_points, int64_t stride
     S.x = (double *)ws_get(0, sizeof(double) * 3 * (size_t)m);
     S.onext = (int32_t *)ws_get(1, sizeof(int32_t) * 2 * (size_t)m);
     S.vpoint = (int32_t *)ws_get(2, sizeof(int32_t) * ((size_t)m + 8));
-    S.F = (qh_facet *)ws_get(3, sizeof(qh_facet) * (size_t)S.ncap);
+    {
+        char *raw = (char *)ws_get(3, sizeof(qh_facet) * (size_t)S.ncap + 64);
+        S.F = raw ? (qh_facet *)(((uintptr_t)raw + 63) & ~(uintptr_t)63) : NULL;
+    }
+    S.C = (qh_cold *)ws_get(7, sizeof(qh_cold) * (size_t)S.ncap);
     S.visible = (int32_t *)ws_get(4, sizeof(int32_t) * 3 * (size_t)S.listcap);
     S.ridge_nf = (int32_t *)ws_get(5, sizeof(int32_t) * 2 * ((size_t)m + 8));
     S.ridge_k = (uint8_t *)ws_get(6, (size_t)m + 8);
-    if (!S.x || !S.onext || !S.vpoint || !S.F || !S.visible || !S.ridge_nf || !S.ridge_k) return QHH_ERR_ALLOC;
+    if (!S.x || !S.onext || !S.vpoint || !S.F || !S.C || !S.visible || !S.ridge_nf || !S.ridge_k) return QHH_ERR_ALLOC;
     S.y = S.x + m; S.z = S.y + m;
     S.oprev = S.onext + m;
     S.newf = S.visible + S.listcap; S.stack = S.newf + S.listcap;

@@ -20,12 +20,36 @@ for s, e, _ in rows[1:]:
         cur_e = max(cur_e, e)
 busy += cur_e - cur_s
 print("kernels %d, span %.2f ms, busy %.2f ms (%.1f %%)" % (len(rows), (t1 - t0) / 1e6, busy / 1e6, 100.0 * busy / (t1 - t0)))
+def short(k):
+    """A kernel's name without its argument list ('(anonymous namespace)::' is not one)."""
+    k = k.replace("(anonymous namespace)::", "")
+    return k.split("(")[0][-62:]
+
+
 per = defaultdict(lambda: [0, 0])
 for s, e, k in rows:
-    per[k.split("(")[0][-60:]][0] += e - s; per[k.split("(")[0][-60:]][1] += 1
+    per[short(k)][0] += e - s; per[short(k)][1] += 1
 for k, (t, c) in sorted(per.items(), key=lambda kv: -kv[1][0])[:10]:
     print("  %-62s %8.2f ms  %5d launches" % (k, t / 1e6, c))
 gaps.sort(reverse=True)
 print("idle %.2f ms in %d gaps; the largest (us, at ms):" % (sum(g for g, _ in gaps) / 1e6, len(gaps)), ", ".join("%.0f@%.1f" % (g / 1e3, a / 1e6) for g, a in gaps[:12]))
 small = sum(g for g, _ in gaps if g < 50e3)
 print("gaps below 50 us: %.2f ms in total" % (small / 1e6))
+
+# the exact path (VERDICT r5 #6): where a call's time goes around the Qhull replay — the head before the first replay starts (pack +
+# upload of the first chunk), the union of the big replays (the machine's real work), the tail after the last big replay ends (vote,
+# stand-in triangulation, product kernels, the list replay of the exact pass's frames: one wavefront per frame, a whole run long)
+rep = [(s_, e_) for s_, e_, k in rows if "qhull_rows_kernel" in k]
+if rep:
+    big = [r for r in rep if r[1] - r[0] > 0.5 * max(e_ - s_ for s_, e_ in rep)]
+    lst = [r for r in rep if r not in big]
+    u, cs, ce = 0, big[0][0], big[0][1]
+    for s_, e_ in sorted(big)[1:]:
+        if s_ > ce:
+            u += ce - cs; cs, ce = s_, e_
+        else:
+            ce = max(ce, e_)
+    u += ce - cs
+    print("qhull replay: %d big launches (union %.2f ms, sum %.2f ms), %d list launches (sum %.2f ms); head before the first replay %.2f ms, "
+          "tail after the last big replay %.2f ms" % (len(big), u / 1e6, sum(e_ - s_ for s_, e_ in big) / 1e6, len(lst), sum(e_ - s_ for s_, e_ in lst) / 1e6,
+                                                     (min(s_ for s_, _ in big) - t0) / 1e6, (t1 - max(e_ for _, e_ in big)) / 1e6))

@@ -70,10 +70,17 @@ def render(tag):
             e = b["e2e_gpu_exact"]
             dk = e.get("delaunay_kernel") or {}
             extra = "; KITTI-sized frames (300-1500 features): %s" % k(kt["e2e_gpu_exact"]["value"]) if (kt and "value" in kt.get("e2e_gpu_exact", {})) else ""
+            declined = ("declined to the host in the whole call: %d" % e["declined_total"]) if "declined_total" in e else ("declined to the host in the last chunk: %d" % e.get("declined_last_chunk", 0))
+            sc = e.get("qhull_selfcheck") or {}
+            guard = ("; first-use self-check of the replay against the installed SciPy %s: %s (device %d / host replay %d sets compared, 0 different)"
+                     % (sc.get("scipy"), "passed" if sc.get("ok") else "FAILED", (sc.get("device") or {}).get("compared", 0), (sc.get("host") or {}).get("compared", 0))) if sc else ""
+            rf = e.get("roofline") or {}
+            roof = ("; its roof is vector instruction issue: %.0f VALU + %.0f scalar instructions per insertion, **%.2f of the VALU issue peak** (%.2e of %.2e wave-instructions/s), HBM at %.0f %% of 8 TB/s"
+                    % (rf["valu_per_insertion"], rf["salu_per_insertion"], rf["frac"], rf["achieved"], rf["peak"], 100 * rf["hbm_frac_of_8TBps"])) if "frac" in rf else ""
             rows.append(("end to end, `scale_calculator.ScaleEstimator(...)` as the reference constructs it (= `triangulation=\"gpu\", check_triangle=\"reference\"`, the default since round 5) — **the reference's result, bit for bit, both triangulations on the device** (Qhull's rows by `qhull_rows_kernel`)",
-                         "**%s frames/s** at 2000 features (%d frames, %s distinct; declined to the host in the last chunk: %d)%s; `qhull_rows_kernel` alone: %s sets/s (%d resident sets of %d points)"
-                         % (k(e["value"]), e["frames"], e.get("distinct_frames", "all"), e.get("declined_last_chunk", 0), extra,
-                            k(dk.get("sets_per_s", float("nan"))), dk.get("sets", 0), dk.get("points_per_set", 0)), "`e2e_gpu_exact` in the bench line"))
+                         "**%s frames/s** at 2000 features (%d frames, %s distinct; %s)%s; `qhull_rows_kernel` alone: %s sets/s (%d resident sets of %d points)%s%s"
+                         % (k(e["value"]), e["frames"], e.get("distinct_frames", "all"), declined, extra,
+                            k(dk.get("sets_per_s", float("nan"))), dk.get("sets", 0), dk.get("points_per_set", 0), roof, guard), "`e2e_gpu_exact` in the bench line"))
         if "two_streams" in b and "ms_per_step" in b["two_streams"]:
             t2 = b["two_streams"]
             rows.append(("the headline steps alternating between two streams (road model of step k under the scale kernel of step k+1)",
@@ -82,7 +89,12 @@ def render(tag):
             la = b["latency"]
             extra = (", `rescale` estimator device-resident %.2f ms" % la["rescale_gpu"]["median_ms"]) if "rescale_gpu" in la else ""
             if "gpu_exact" in la:
-                extra += ", `check_triangle=\"reference\"` with `triangulation=\"gpu\"` %.2f ms (the DEFAULT construction, the reference's result: SciPy for the first triangulation only, the second by the fast kernel as a stand-in — the device's replay of Qhull is 20 ms per triangulation for a single frame)" % la["gpu_exact"]["median_ms"]
+                if la["gpu_exact"].get("host_replay"):
+                    extra += (", `check_triangle=\"reference\"` with `triangulation=\"gpu\"` **%.2f ms** (the DEFAULT construction, the reference's result: the first triangulation by the host replay of Qhull's run `mvosr_qhull_rows_host` — SciPy's own rows, "
+                              "held to the installed SciPy by the first-use self-check; %d of the calls' sets declined to SciPy —, the second by the fast kernel as a stand-in; round 5, with SciPy for the first triangulation: 3.3 ms)"
+                              % (la["gpu_exact"]["median_ms"], la["gpu_exact"].get("host_replay_declined_to_scipy", 0)))
+                else:
+                    extra += ", `check_triangle=\"reference\"` with `triangulation=\"gpu\"` %.2f ms (the DEFAULT construction, the reference's result: SciPy for the first triangulation only, the second by the fast kernel as a stand-in — the device's replay of Qhull is 20 ms per triangulation for a single frame)" % la["gpu_exact"]["median_ms"]
             rows.append(("per-frame `scale_calculation` latency, 2000 features", "SciPy triangulations %.2f ms, device triangulations %.2f ms%s (median; 0 allocations per call)" % (la["scipy"]["median_ms"], la["gpu"]["median_ms"], extra), "`latency` in the bench line"))
         cb = b.get("cpu_baseline")
         if cb:
@@ -102,6 +114,26 @@ def render(tag):
                         k(dn.get("e2e_gpu_triangulation", {}).get("value", float("nan"))),
                         (", the reference's result with device triangulations (`qhull_rows_kernel<uint32_t>`) **%s**" % k(ex["value"])) if "value" in ex else ""),
                      "`profiles/%s_bench_dense.json`" % tag))
+    gr = load_line(tag + "_bench_gridded.json")
+    if gr:
+        ex, fx, ho = gr.get("e2e_gpu_exact", {}), gr.get("e2e_gpu_triangulation", {}), gr.get("e2e", {})
+        if "value" in ex:
+            rows.append(("the decline path (`--workload gridded`: 2000-feature frames with pixel coordinates rounded to 1/4 px — collinear and cocircular sites, where Qhull merges facets and both device triangulations DECLINE to the host's SciPy)",
+                         "the default estimator end to end **%s frames/s** with %.1f %% of the frames declined (%d of %d; triangulated by SciPy on the worker pool under the GPU's queued chunks, re-run on a context of their own), 0 rows different from SciPy by construction; "
+                         "the fixed-mode estimator %s (declined %.1f %%); host SciPy for every frame: %s"
+                         % (k(ex["value"]), 100 * ex.get("declined_fraction", 0), ex.get("declined_total", 0), ex["frames"], k(fx.get("value", float("nan"))), 100 * fx.get("declined_fraction", 0), k(ho.get("value", float("nan")))),
+                         "`profiles/%s_bench_gridded.json`" % tag))
+    g5 = load_line(tag + "_bench_gridded_0005.json")
+    if g5 and "value" in g5.get("e2e_gpu_exact", {}):
+        ex = g5["e2e_gpu_exact"]
+        rows.append(("... a FEW declined frames per chunk (`--workload gridded --snap-fraction 0.005`; round 5: 72 declined frames in 16 384 took the call from 53 k to 30 k frames/s, re-run in the chunk's epilogue on the chunk's own stream)",
+                     "the default estimator end to end **%s frames/s** with %d of %d frames declined (%.2f %%): the re-runs on a context of their own, their SciPy calls on the worker pool, under the GPU's queued chunks"
+                     % (k(ex["value"]), ex.get("declined_total", 0), ex["frames"], 100 * ex.get("declined_fraction", 0)), "`profiles/%s_bench_gridded_0005.json`" % tag))
+    for nm, what in (("share2", "`bench.py --gpus 2 --share-gpu` (two ranks sharing this one GPU over gloo: the N-rank code path as a dry run, not a scaling number)"),
+                     ("share2_c4", "`bench.py --gpus 2 --share-gpu --c4 --total-frames 100000` (configs[3]'s split, two ranks on one GPU, dry run)")):
+        sh = load_line(tag + "_bench_%s.json" % nm)
+        if sh:
+            rows.append((what, "ran: %s frames/s whole-job, %d ranks, scaling \"%s\", one collective per step" % (k(sh["value"]), sh["n_gpus"], sh["scaling"]), "`profiles/%s_bench_%s.json`" % (tag, nm)))
     if c4:
         rows.append(("BASELINE configs[3] literally on ONE GPU (`bench.py --c4 --total-frames 1000000 --gpus 1`: %.0f GB resident)" % (c4["roofline"]["algorithmic_bytes_per_launch"] / 1e9),
                      "%s frames/s, %.1f ms per step of 1 000 000 frames, kernel %.3f of 8 TB/s" % (k(c4["value"]), c4["ms_per_step"], c4["roofline"]["frac"]), "`profiles/%s_bench_c4_1gpu.json`" % tag))

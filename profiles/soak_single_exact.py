@@ -20,7 +20,9 @@ def main():
     hi = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
     mode = os.environ.get("SOAK_MODE", "reference")            # "fixed": the explicit speed mode's per-frame call (product kernels only)
     a = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu", check_triangle=mode)
-    b = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu", check_triangle=mode)
+    # (reference mode, round 6: the comparator is the host-SciPy estimator itself — two scipy.spatial.Delaunay calls per frame, no
+    # replay of Qhull's run anywhere — so that the soak also holds mvosr_qhull_rows_host to SciPy on every frame)
+    b = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="scipy" if mode == "reference" else "gpu", check_triangle=mode)
     b.GPU_EXACT_SINGLE_FAST = False
     b.GPU_SINGLE_HOT = False
     rng = np.random.default_rng(77)
@@ -54,7 +56,9 @@ def fuzz(count=480):
     raises, the window and height_level after it, on the two paths."""
     mode = os.environ.get("SOAK_MODE", "reference")
     a = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu", check_triangle=mode)
-    b = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="gpu", check_triangle=mode)
+    # (reference mode, round 6: the comparator is the host-SciPy estimator itself — two scipy.spatial.Delaunay calls per frame, no
+    # replay of Qhull's run anywhere — so that the soak also holds mvosr_qhull_rows_host to SciPy on every frame)
+    b = ScaleEstimator(1.75, window_size=5, delaunay_workers=0, triangulation="scipy" if mode == "reference" else "gpu", check_triangle=mode)
     b.GPU_EXACT_SINGLE_FAST = False
     b.GPU_SINGLE_HOT = False
     bad = raised = fast = 0
