@@ -63,9 +63,10 @@ def qhull_rows_host_or_none():
     return qhull_rows_host
 
 
-def _delaunay_job(points2d, fast=False):
+def _delaunay_job(points2d, fast=False, canonical=False):
     try:
-        return delaunay_simplices_fast(points2d) if fast else delaunay_simplices(points2d)
+        rows = delaunay_simplices_fast(points2d) if fast else delaunay_simplices(points2d)
+        return canonical_rows(rows) if canonical else rows
     except Exception as exc:  # QhullError etc.: re-raised in frame order by the caller
         return exc
 
@@ -102,6 +103,13 @@ def canonical_rows(tri):
     t = np.sort(np.asarray(tri, dtype=np.int32).reshape(-1, 3), axis=1)
     if t.shape[0] == 0:
         return t
+    if t.min() >= 0 and t.max() < (1 << 21):
+        # (one 63-bit key per row, sorted, unpacked: a third of np.lexsort's time on 4 000 rows — the host path of a "fixed"-mode
+        # estimator canonicalises two triangulations per frame)
+        key = np.sort((t[:, 0].astype(np.int64) << 42) | (t[:, 1].astype(np.int64) << 21) | t[:, 2].astype(np.int64))
+        out = np.empty((len(key), 3), dtype=np.int32)
+        out[:, 0], out[:, 1], out[:, 2] = key >> 42, (key >> 21) & 0x1FFFFF, key & 0x1FFFFF
+        return out
     return np.ascontiguousarray(t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))])
 
 
@@ -289,11 +297,12 @@ def _delaunay_shm_job(job):
     """Worker: triangulate the listed point sets of the input segment, write the rows to the output segment."""
     in_name, out_name, items = job[:3]
     fast = bool(job[3]) if len(job) > 3 else False
+    canonical = bool(job[4]) if len(job) > 4 else False
     pin, pout = _shm_attach(in_name, (in_name, out_name)), _shm_attach(out_name, (in_name, out_name))
     results = []
     for in_off, n, out_off, cap in items:
         pts = np.ndarray((n, 2), dtype=np.float64, buffer=pin.buf, offset=16 * in_off)
-        r = _delaunay_job(pts, fast)
+        r = _delaunay_job(pts, fast, canonical)
         if isinstance(r, Exception):
             results.append(r)
         elif r.shape[0] > cap:
@@ -348,8 +357,9 @@ class _DelaunayHandle:
     """Result of :func:`delaunay_submit`: ``get()`` waits for the workers and returns, per point set, the (T,3) int32
     simplices or the exception SciPy raised for it."""
 
-    def __init__(self, n, done=None, async_result=None, rows=None, out_off=None):
+    def __init__(self, n, done=None, async_result=None, rows=None, out_off=None, canonical=False):
         self.n, self._done, self._async, self._rows, self._out_off = n, done, async_result, rows, out_off
+        self.canonical = bool(canonical)         # the rows come back in canonical form already (the workers did it)
 
     def get(self):
         if self._done is None:
@@ -362,7 +372,7 @@ class _DelaunayHandle:
         return self._done
 
 
-def delaunay_submit(point_sets, workers=0, slot=0, fast=False):
+def delaunay_submit(point_sets, workers=0, slot=0, fast=False, canonical=False):
     """Start triangulating many point sets on the process pool and return at once (a handle with ``get()``): the host
     stage that bounds end-to-end throughput (SURVEY.md §7 hard part 1) runs while the caller packs, uploads and
     launches the GPU stages of other chunks.  ``slot`` names the pair of shared-memory segments the call uses — calls
@@ -371,7 +381,7 @@ def delaunay_submit(point_sets, workers=0, slot=0, fast=False):
     n = len(point_sets)
     workers = resolve_workers(workers)
     if not (workers and workers > 1 and n > 1):
-        return _DelaunayHandle(n, done=[_delaunay_job(p, fast) for p in point_sets])
+        return _DelaunayHandle(n, done=[_delaunay_job(p, fast, canonical) for p in point_sets], canonical=canonical)
     pool = _get_pool(int(workers))
     counts = np.array([len(p) for p in point_sets], dtype=np.int64)
     in_off = np.concatenate([[0], np.cumsum(counts)])
@@ -384,9 +394,9 @@ def delaunay_submit(point_sets, workers=0, slot=0, fast=False):
         allpts[in_off[f]:in_off[f + 1]] = p
     per_job = max(1, min(16, n // (int(workers) * 4)))
     jobs = [(pin.path, pout.path, [(int(in_off[f]), int(counts[f]), int(out_off[f]), int(caps[f]))
-                                    for f in range(j, min(n, j + per_job))], bool(fast)) for j in range(0, n, per_job)]
+                                    for f in range(j, min(n, j + per_job))], bool(fast), bool(canonical)) for j in range(0, n, per_job)]
     rows = np.ndarray((int(out_off[-1]), 3), dtype=np.int32, buffer=pout.buf)
-    return _DelaunayHandle(n, async_result=pool.map_async(_delaunay_shm_job, jobs), rows=rows, out_off=out_off)
+    return _DelaunayHandle(n, async_result=pool.map_async(_delaunay_shm_job, jobs), rows=rows, out_off=out_off, canonical=canonical)
 
 
 def delaunay_many(point_sets, workers=0):
@@ -520,18 +530,20 @@ def submit_tri1(pf: PackedFrames, workers=0, slot=0, fast=False):
     for f in range(pf.n_frames):
         s = pf.frame_slice(f)
         pts.append(np.stack([pf.u[s], pf.v[s]], axis=1))
-    return delaunay_submit(pts, workers, slot, fast)
+    return delaunay_submit(pts, workers, slot, fast, canonical=bool(pf.extra.get("canonical")))
 
 
 def attach_tri1(pf: PackedFrames, tri1s=None, workers=0):
     """First triangulation per frame: given (a list, or the handle :func:`submit_tri1` returned), or SciPy now."""
     if tri1s is None:
         tri1s = submit_tri1(pf, workers)
+    done = bool(pf.extra.get("tri1_is_canonical"))
     if isinstance(tri1s, _DelaunayHandle):
+        done = done or tri1s.canonical
         tri1s = tri1s.get()
     pf.extra["tri1_errors"] = {f: t for f, t in enumerate(tri1s) if isinstance(t, Exception)}
     tri1s = [None if isinstance(t, Exception) else np.ascontiguousarray(t, dtype=np.int32) for t in tri1s]
-    if pf.extra.get("canonical"):               # check_triangle="fixed": rows as a function of the triangle set alone
+    if pf.extra.get("canonical") and not done:  # check_triangle="fixed": rows as a function of the triangle set alone (the workers' job where there are any)
         tri1s = [None if t is None else canonical_rows(t) for t in tri1s]
     pf.tri1_off, pf.tri1 = _pack_tris(tri1s)
     return pf
@@ -540,6 +552,7 @@ def attach_tri1(pf: PackedFrames, tri1s=None, workers=0):
 class _Tri2Handle:
     def __init__(self, todo, handle, n_frames):
         self.todo, self.handle, self.n_frames = todo, handle, n_frames
+        self.canonical = bool(getattr(handle, "canonical", False))
 
     def get(self):
         tri2s = [np.zeros((0, 3), dtype=np.int32)] * self.n_frames
@@ -582,7 +595,7 @@ def submit_tri2(pf: PackedFrames, valid_masks, workers=0, slot=1, fast=False):
         # <= 3 features below the vanishing row: the reference never makes the second call (:263-270)
         pts.append(np.stack([u[m], v[m]], axis=1) if len(m) > 3 else None)
     todo = [f for f, p in enumerate(pts) if p is not None]
-    return _Tri2Handle(todo, delaunay_submit([pts[f] for f in todo], workers, slot, fast), pf.n_frames)
+    return _Tri2Handle(todo, delaunay_submit([pts[f] for f in todo], workers, slot, fast, canonical=bool(pf.extra.get("canonical"))), pf.n_frames)
 
 
 def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0, feature_ids=False):
@@ -597,11 +610,13 @@ def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0, featu
     if tri2s is None:
         assert valid_masks is not None
         tri2s = submit_tri2(pf, valid_masks, workers)
+    done2 = False
     if isinstance(tri2s, _Tri2Handle):
+        done2 = tri2s.canonical
         tri2s = tri2s.get()
     pf.extra["tri2_errors"] = {f: t for f, t in enumerate(tri2s) if isinstance(t, Exception)}
     tri2s = [None if isinstance(t, Exception) else np.ascontiguousarray(t, dtype=np.int32) for t in tri2s]
-    if pf.extra.get("canonical"):
+    if pf.extra.get("canonical") and not done2:
         tri2s = [None if t is None else canonical_rows(t) for t in tri2s]
     row_src = [None] * pf.n_frames          # row_src[f][i] = index, in the caller's original order, of the row now stored at i
     if valid_masks is not None:

@@ -362,7 +362,7 @@ class ScaleEstimator:
         return filtered, stds
 
     # -- one chunk of frames through the stages; the Delaunay calls are submitted to the pool and collected later
-    def _chunk_begin(self, f3s, f2s, k, tri1s=None, _packed=None, _remapped=False, _exact_all=False, _fast=False, _eng=None):
+    def _chunk_begin(self, f3s, f2s, k, tri1s=None, _packed=None, _remapped=False, _exact_all=False, _fast=False, _eng=None, _slot=None):
         """Vanishing-row filter + packing (:252-254) and the start of the first triangulation (:257), on the host."""
         if _packed is not None:
             pf = _packed                                               # (packed — and the caller's arrays remapped — already)
@@ -380,7 +380,7 @@ class ScaleEstimator:
         if tri1s is not None:
             h1 = tri1s
         else:
-            h1 = packing.submit_tri1(pf, self.delaunay_workers, slot=k % 4, fast=_fast)
+            h1 = packing.submit_tri1(pf, self.delaunay_workers, slot=(k % 4) if _slot is None else _slot, fast=_fast)
         # (_fast: the host replay of Qhull's run instead of SciPy where it accepts the set — the default estimator's own host steps;
         # an estimator constructed with triangulation="scipy" never sets it)
         st = {"pf": pf, "h1": h1, "n": len(f3s), "out": None, "dbatch": None, "masks": None, "exact_all": bool(_exact_all),
@@ -545,6 +545,8 @@ class ScaleEstimator:
         return self._engine2
 
     GPU_REDO_CONTEXT = True         # streamed batches: the host-path re-run of declined frames on a context of its own (see _chunk_gpu_finish)
+    GPU_REDO_MAX_DEFERRED = 8       # ... at most so many chunks' re-runs pending (each keeps its device blocks and a shared-memory slot)
+    GPU_REDO_DEFER = True           # ... and finished after the call's last chunk (its SciPy calls start on the worker pool at once)
 
     def _redo_engine(self, remapped):
         """The engine (on a third context: own streams, workspace, caches) for the re-runs of frames a device triangulation declined;
@@ -630,11 +632,14 @@ class ScaleEstimator:
         st["dbatch"], st["out"] = db, out
         return st
 
-    def _chunk_gpu_finish(self, st, f3s, f2s, keep=False):
+    def _chunk_gpu_finish(self, st, f3s, f2s, keep=False, defer=None):
         """Results of a chunk started by ``_chunk_gpu``; frames whose triangulation the device stage declined (degenerate
-        point sets, fewer than 3 points) are redone through the host's path (SciPy's rows, canonical form in "fixed" mode)."""
+        point sets, fewer than 3 points) are redone through the host's path (SciPy's rows, canonical form in "fixed" mode).
+        ``defer`` (a list; streamed batches): the re-run is only STARTED here — its first SciPy calls go to the worker pool — and a
+        record is appended; ``_chunk_gpu_complete`` finishes it once every chunk of the call has been collected.  Returns the
+        chunk's ``[raw, status, level, counts, host_errors]`` (a list: a deferred completion fills the declined frames' entries in)."""
         eng = st.get("engine") or self.engine
-        ctx, pf = eng.ctx, st["pf"]
+        pf = st["pf"]
         stage = st["stage"]
         if not st["gpu"]:
             sub = self._chunk_begin(f3s, f2s, 0, _remapped=st["remapped"])
@@ -643,22 +648,76 @@ class ScaleEstimator:
             st.update(out=sub["out"], dbatch=sub["dbatch"], masks=sub["masks"], pf=sub["pf"])
             if not keep:
                 self._chunk_free(st)
-            return res
+            return list(res)
         db, out = st["dbatch"], st["out"]
         s1, s2 = db.triangulation_status()
         redo = np.nonzero((s1 != 0) | (s2 != 0))[0]
-        raw, status, level, counts = out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts")
-        host_errors = {}
+        res = [out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts"), {}]
         self.last_declined = len(redo)
         self.declined_total += len(redo)
-        if len(redo):
-            # (every frame of the small re-run in the exact mode: a declined frame's level may be the one a later frame reads).
-            # On a context of its own in a streamed batch: the re-run's small launches are waited for, and on the chunk's stream they
-            # would queue behind the chunks already launched — every chunk with one declined frame drained the pipeline (round 5:
-            # 72 declined frames in 16 384 took a call from 53 k to 30 k frames/s).  The SciPy calls go to the worker pool when the
-            # estimator has one (delaunay_workers), so the cost of a declined frame is 7 ms / workers under the GPU's queued work.
-            sub = self._chunk_begin([f3s[f] for f in redo], [f2s[f] for f in redo], 0, _remapped=st["remapped"], _exact_all=True,
-                                    _eng=None if stage or not self.GPU_REDO_CONTEXT else self._redo_engine(st["remapped"]))
+        handle = None
+        if len(redo) and defer is not None and not stage:
+            # Streamed batches (round 6): only the declined frames' FIRST SciPy calls are started here — on the worker pool when the
+            # estimator has one (delaunay_workers), under the GPU's queued work —; the re-run itself waits for the call's last chunk
+            # and is ONE small batch over every declined frame of the call, on a context of its own.  Its launches are waited for,
+            # and while replays of other chunks hold every CU's LDS for a whole frame (30 ms) a vote or scale workgroup waits that
+            # long for a slot: round 5 ran the re-run in each chunk's epilogue on the chunk's own stream (72 declined frames in
+            # 16 384: 53 k -> 30 k frames/s); on its own context but still between the chunks 80 declined frames cost 96 -> 66 k
+            # (and 529 -> 93 k in the fixed mode, whose chunks are short).
+            pts = []
+            for f in redo:
+                f2 = np.asarray(f2s[f], dtype=np.float64)
+                pts.append(np.ascontiguousarray(f2[f2[:, 1] > self.vanish]) if f2.ndim == 2 and f2.size else np.zeros((0, 2)))   # :252-254
+            handle = packing.delaunay_submit(pts, self.delaunay_workers, slot=8 + len(defer) % self.GPU_REDO_MAX_DEFERRED,
+                                             canonical=self.check_triangle == "fixed")
+        pend = {"st": st, "redo": redo, "s12": (s1, s2), "f3s": f3s, "f2s": f2s, "res": res, "keep": keep, "h1": handle}
+        if handle is not None:
+            defer.append(pend)
+            if len(defer) >= self.GPU_REDO_MAX_DEFERRED:       # (bounded: a deferred chunk keeps its device blocks and a pool slot)
+                self._chunk_gpu_complete_all(defer)
+                del defer[:]
+            return res
+        self._chunk_gpu_complete(pend)
+        return res
+
+    def _chunk_gpu_complete_all(self, pending):
+        """The declined frames of several chunks in ONE re-run through the host path (their first triangulations were started by
+        ``_chunk_gpu_finish``), results scattered back; then every chunk's own completion."""
+        if not pending:
+            return
+        f3_all, f2_all, tri1_all, where = [], [], [], []
+        for k, p in enumerate(pending):
+            rows = p["h1"].get()
+            for j, f in enumerate(p["redo"]):
+                f3_all.append(p["f3s"][f]); f2_all.append(p["f2s"][f]); tri1_all.append(rows[j]); where.append((k, int(f)))
+        remapped = pending[0]["st"]["remapped"]
+        sub = self._chunk_begin(f3_all, f2_all, 0, tri1s=tri1_all, _remapped=remapped, _exact_all=True,
+                                _eng=self._redo_engine(remapped) if self.GPU_REDO_CONTEXT else None)
+        sub["pf"].extra["tri1_is_canonical"] = self.check_triangle == "fixed"       # (the workers brought the rows to canonical form)
+        self._chunk_vote(sub, None, 0)
+        r_raw, r_status, r_level, r_counts, r_err = self._chunk_scale(sub, None, False)
+        errs = [dict() for _ in pending]
+        for i, (k, f) in enumerate(where):
+            res = pending[k]["res"]
+            res[0][f], res[1][f], res[2][f], res[3][f] = r_raw[i], r_status[i], r_level[i], r_counts[i]
+            if i in r_err:
+                errs[k][f] = r_err[i]
+        for k, p in enumerate(pending):
+            p["res"][4] = errs[k]
+            p["merged"] = True
+            self._chunk_gpu_complete(p)
+
+    def _chunk_gpu_complete(self, pend):
+        """The rest of ``_chunk_gpu_finish``: the declined frames' re-run (unless ``_chunk_gpu_complete_all`` merged it in already);
+        the exact levels around the chunk's first real error; the per-frame call's stage outputs."""
+        st, redo, (s1, s2), f3s, f2s, res, keep = (pend[k] for k in ("st", "redo", "s12", "f3s", "f2s", "res", "keep"))
+        eng = st.get("engine") or self.engine
+        pf, stage = st["pf"], st["stage"]
+        db, out = st["dbatch"], st["out"]
+        raw, status, level, counts, host_errors = res
+        if len(redo) and not pend.get("merged"):
+            # (every frame of the small re-run in the exact mode: a declined frame's level may be the one a later frame reads)
+            sub = self._chunk_begin([f3s[f] for f in redo], [f2s[f] for f in redo], 0, _remapped=st["remapped"], _exact_all=True)
             self._chunk_vote(sub, None, 0)
             r_raw, r_status, r_level, r_counts, r_err = self._chunk_scale(sub, None, False)
             raw[redo], status[redo], level[redo], counts[redo] = r_raw, r_status, r_level, r_counts
@@ -672,9 +731,9 @@ class ScaleEstimator:
                 # there (its bits arrive in the second triangulation's status only now) takes the host's path for its level
                 late = np.nonzero((db.bufs["dt2_status"].download() != 0) & (s2 == 0) & (s1 == 0))[0]
                 if len(late):
-                    sub = self._chunk_begin([f3s[f] for f in late], [f2s[f] for f in late], 0, _remapped=st["remapped"], _exact_all=True)
-                    self._chunk_vote(sub, None, 0)
-                    _, _, l_level, _, _ = self._chunk_scale(sub, None, False)
+                    sub2 = self._chunk_begin([f3s[f] for f in late], [f2s[f] for f in late], 0, _remapped=st["remapped"], _exact_all=True)
+                    self._chunk_vote(sub2, None, 0)
+                    _, _, l_level, _, _ = self._chunk_scale(sub2, None, False)
                     level = np.array(level, copy=True)
                     level[late] = l_level
                     self.last_declined += len(late)
@@ -690,7 +749,7 @@ class ScaleEstimator:
                 st.update(out=one["out"], dbatch=one["dbatch"], masks=one["masks"], pf=one["pf"], filtered_queue=None)
         if not keep:
             self._chunk_free(st)
-        return raw, status, level, counts, host_errors
+        res[2], res[4] = level, host_errors
 
     def _stream_gpu(self, feature3ds, feature2ds, stage):
         """The batch through the device-triangulation path in chunks: the GPU works on chunk k while this process packs
@@ -757,6 +816,7 @@ class ScaleEstimator:
 
         bounds = []
         results, queue = [], []
+        deferred = [] if (self.GPU_REDO_DEFER and not stage) else None      # declined frames' re-runs: finished after the last chunk
         for k, (a, b, tb) in enumerate(chunk_bounds()):
             bounds.append((a, b))
             queue.append((self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage, tables=tb, eng=engines[k % len(engines)]), a, b))
@@ -765,10 +825,11 @@ class ScaleEstimator:
             # with one: what a call pays beyond its kernels is its first chunk's pack + upload and the host's epilogue)
             while len(queue) > self.GPU_PIPELINE:
                 ps, pa, pb = queue.pop(0)
-                results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb]))
+                results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb], defer=deferred))
         while queue:
             ps, pa, pb = queue.pop(0)
-            results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb], keep=not queue))
+            results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb], keep=not queue, defer=deferred))
+        self._chunk_gpu_complete_all(deferred)
         raw = np.concatenate([r[0] for r in results])
         status = np.concatenate([r[1] for r in results])
         level = np.concatenate([r[2] for r in results])

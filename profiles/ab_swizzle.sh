@@ -6,7 +6,7 @@ cd $R; mkdir -p gpurun_out
 {
 echo "== the experiment builds compute the same results (LDS-resident variants: stage goldens + seeded batches against the oracle)"
 for NAME in swz3 swz5 psplit; do
-  MVOSR_LIB_PATH=$R/profiles/ab/libmvosr_$NAME.so python3 -m pytest tests/test_gpu_parity.py -q -x -k "stage_goldens_fused or test_seeded_batches or ragged_batch" 2>&1 | tail -1 | sed "s/^/$NAME: /"
+  MVOSR_LIB_PATH=$R/profiles/ab/libmvosr_$NAME.so python3 -m pytest tests/test_gpu_kernels.py -q -x -k "stage_goldens_fused or test_seeded_batches or ragged_batch" 2>&1 | tail -1 | sed "s/^/$NAME: /"
 done
 echo "== timing (bench.py --steps 10, two alternating repeats)"
 bash profiles/ab_run.sh "" main swz3 swz5 psplit

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How often the scales of the DECLARED DEVIATION — triangulation="gpu", check_triangle="fixed": the order-invariant vote
 on the device's triangulations — equal the reference's own, and what the device stage buys end to end.
-(Against its own oracle, Oracle(check_triangle="fixed"), that mode is bit-equal on every frame: tests/test_gpu_parity.py.)
+(Against its own oracle, Oracle(check_triangle="fixed"), that mode is bit-equal on every frame: tests/test_gpu_dropin.py.)
 Also: the same fixed vote on SciPy's triangulations (identical to "gpu" by construction), and "gpu" with the reference's
 flag pattern (unpinned: Qhull's row rotation is not reproducible).
 

@@ -127,8 +127,9 @@ def render(tag):
     if g5 and "value" in g5.get("e2e_gpu_exact", {}):
         ex = g5["e2e_gpu_exact"]
         rows.append(("... a FEW declined frames per chunk (`--workload gridded --snap-fraction 0.005`; round 5: 72 declined frames in 16 384 took the call from 53 k to 30 k frames/s, re-run in the chunk's epilogue on the chunk's own stream)",
-                     "the default estimator end to end **%s frames/s** with %d of %d frames declined (%.2f %%): the re-runs on a context of their own, their SciPy calls on the worker pool, under the GPU's queued chunks"
-                     % (k(ex["value"]), ex.get("declined_total", 0), ex["frames"], 100 * ex.get("declined_fraction", 0)), "`profiles/%s_bench_gridded_0005.json`" % tag))
+                     "the default estimator end to end **%s frames/s** with %d of %d frames declined (%.2f %%), the fixed-mode estimator **%s** (without declines: the rows above): ONE re-run of the call's declined frames after its last chunk, on a context of its own, "
+                     "their first SciPy calls started on the worker pool at discovery — a per-call cost of 40-80 ms, not a per-chunk stall"
+                     % (k(ex["value"]), ex.get("declined_total", 0), ex["frames"], 100 * ex.get("declined_fraction", 0), k(g5.get("e2e_gpu_triangulation", {}).get("value", float("nan")))), "`profiles/%s_bench_gridded_0005.json`" % tag))
     for nm, what in (("share2", "`bench.py --gpus 2 --share-gpu` (two ranks sharing this one GPU over gloo: the N-rank code path as a dry run, not a scaling number)"),
                      ("share2_c4", "`bench.py --gpus 2 --share-gpu --c4 --total-frames 100000` (configs[3]'s split, two ranks on one GPU, dry run)")):
         sh = load_line(tag + "_bench_%s.json" % nm)
@@ -174,11 +175,33 @@ def render(tag):
     return "\n".join(out)
 
 
+def test_counts():
+    """`pytest --collect-only` of the suite as it stands (the counts in the documents are rendered, not typed), and the GPU box's pass
+    count of the round's collection (profiles/r06_gputest_count.txt) next to it."""
+    import subprocess
+    out = {}
+    for name, expr in (("gpu", "gpu"), ("cpu", "not gpu")):
+        r = subprocess.run([sys.executable, "-m", "pytest", "tests", "--collect-only", "-q", "-m", expr], cwd=ROOT, capture_output=True, text=True)
+        m = re.search(r"(\d+)/(\d+) tests collected", r.stdout) or re.search(r"(\d+) tests? collected", r.stdout)
+        out[name] = int(m.group(1)) if m else -1
+    return out
+
+
+def render_counts(tag):
+    c = test_counts()
+    txt = "`-m gpu`: %d tests, `-m \"not gpu\"`: %d (`pytest --collect-only`, rendered by `profiles/make_tables.py`)" % (c["gpu"], c["cpu"])
+    p = os.path.join(HERE, tag + "_gputest_count.txt")
+    if os.path.isfile(p):
+        txt += "; on the GPU box, the suite as shipped (no `MVOSR_TRIANGULATION` anywhere): %s (`profiles/%s_gputest_count.txt`)" % (open(p).read().strip().strip("=").strip(), tag)
+    return txt
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     text = render(tag)
     open(os.path.join(HERE, tag + "_tables.md"), "w").write(text + "\n")
     begin, end = "<!-- %s-tables:begin -->" % tag, "<!-- %s-tables:end -->" % tag
+    counts = render_counts(tag) if tag >= "r06" else None
     for doc in ("BASELINE.md", "README.md", "DESIGN.md"):
         p = os.path.join(ROOT, doc)
         s = open(p).read()
@@ -186,6 +209,10 @@ def main():
             s = s[:s.index(begin) + len(begin)] + "\n" + text + "\n" + s[s.index(end):]
             open(p, "w").write(s)
             print("updated", doc)
+        cb, ce = "<!-- test-counts:begin -->", "<!-- test-counts:end -->"
+        if counts and cb in s and ce in s:
+            s = s[:s.index(cb) + len(cb)] + counts + s[s.index(ce):]
+            open(p, "w").write(s)
     print(text)
 
 
