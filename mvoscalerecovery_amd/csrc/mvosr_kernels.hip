@@ -2984,3 +2984,14 @@ int mvosr_window_median_blocked(mvosr_ctx *ctx, const double *blocks, int64_t n,
 }
 
 }  // extern "C"
+
+#ifdef MVOSR_ABLATE
+// diagnostic builds only (profiles/ab_build.sh ... -DMVOSR_ABLATE): the exact pass's list of the context's last mvosr_scale_batch —
+// out[0] = how many frames, out[1..] = which (profiles/redo_list_census.py)
+extern "C" int mvosr_debug_redo_list(mvosr_ctx *ctx, int64_t n_frames, int32_t *out, int cap) {
+    if (!ctx || !out || cap < 1 || !ctx->ws_nsel) return MVOSR_ERR_ARG;
+    (void)hipStreamSynchronize(ctx_stream(ctx));
+    const hipError_t e = hipMemcpy(out, ctx->ws_nsel + n_frames, sizeof(int32_t) * (size_t)cap, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? MVOSR_OK : MVOSR_ERR_HIP;
+}
+#endif

@@ -28,6 +28,9 @@
 
 #define QH_EPS 2.220446049250313e-16
 #define QH_BIG 1.797e308
+#define PX(p) pt[4 * (size_t)(p)]
+#define PY(p) pt[4 * (size_t)(p) + 1]
+#define PZ(p) pt[4 * (size_t)(p) + 2]
 
 enum {  /* decline reasons (return value; 0 = rows written) — the device kernel's list, mvosr_qhull.hip */
     QHH_OK = 0, QHH_FEW_POINTS = 1, QHH_ZERO_WIDTH = 2, QHH_FLAT_SIMPLEX = 3, QHH_NARROW_SIMPLEX = 4, QHH_ONE_EXTREME = 5,
@@ -57,7 +60,7 @@ typedef struct {
 
 typedef struct {
     int n, m;                       /* sites; points including the one at infinity */
-    double *x, *y, *z;
+    double *pt;                     /* one 32-byte record per point: x, y, lifted z, pad (a distance test touches one line of it) */
     int32_t *onext, *oprev;         /* outside-set links per point */
     int32_t *vpoint;                /* vertex id (from 1) -> point */
     int nvert;
@@ -163,14 +166,15 @@ static inline void add_outside(qh_state *S, qh_cold *f, int p, double d) {
 
 /* ---- geometry, in Qhull's order of operations ---- */
 static inline double dist_pf(const qh_state *S, int p, const qh_facet *f) {
-    return ((f->off + S->x[p] * f->n0) + S->y[p] * f->n1) + S->z[p] * f->n2;
+    const double *pt = S->pt;
+    return ((f->off + PX(p) * f->n0) + PY(p) * f->n1) + PZ(p) * f->n2;
 }
 
 static int set_plane(qh_state *S, qh_facet *f) {
-    const double *x = S->x, *y = S->y, *z = S->z;
+    const double *pt = S->pt;
     const int p0 = S->vpoint[f->v[0]], p1 = S->vpoint[f->v[1]], p2 = S->vpoint[f->v[2]];
-    const double dx1 = x[p1] - x[p0], dy1 = y[p1] - y[p0], dz1 = z[p1] - z[p0];
-    const double dx2 = x[p2] - x[p0], dy2 = y[p2] - y[p0], dz2 = z[p2] - z[p0];
+    const double dx1 = PX(p1) - PX(p0), dy1 = PY(p1) - PY(p0), dz1 = PZ(p1) - PZ(p0);
+    const double dx2 = PX(p2) - PX(p0), dy2 = PY(p2) - PY(p0), dz2 = PZ(p2) - PZ(p0);
     double n0 = dy2 * dz1 - dz2 * dy1;
     double n1 = dx1 * dz2 - dz1 * dx2;
     double n2 = dx2 * dy1 - dy2 * dx1;
@@ -179,13 +183,13 @@ static int set_plane(qh_state *S, qh_facet *f) {
     if (!f->top) norm = -norm;
     n0 = n0 / norm; n1 = n1 / norm; n2 = n2 / norm;
     f->n0 = n0; f->n1 = n1; f->n2 = n2;
-    f->off = -((x[p0] * n0 + y[p0] * n1) + z[p0] * n2);
+    f->off = -((PX(p0) * n0 + PY(p0) * n1) + PZ(p0) * n2);
     int gauss = 0;
     {
-        double d = f->off + ((x[p2] * n0 + y[p2] * n1) + z[p2] * n2);
+        double d = f->off + ((PX(p2) * n0 + PY(p2) * n1) + PZ(p2) * n2);
         if (d > S->distround || d < -S->distround) gauss = 1;
         else {
-            d = f->off + ((x[p1] * n0 + y[p1] * n1) + z[p1] * n2);
+            d = f->off + ((PX(p1) * n0 + PY(p1) * n1) + PZ(p1) * n2);
             if (d > S->distround || d < -S->distround) gauss = 1;
         }
     }
@@ -218,9 +222,9 @@ static int set_plane(qh_state *S, qh_facet *f) {
         norm = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
         n0 = n0 / norm; n1 = n1 / norm; n2 = n2 / norm;
         f->n0 = n0; f->n1 = n1; f->n2 = n2;
-        double off = -(x[p0] * n0);
-        off -= y[p0] * n1;
-        off -= z[p0] * n2;
+        double off = -(PX(p0) * n0);
+        off -= PY(p0) * n1;
+        off -= PZ(p0) * n2;
         f->off = off;
     }
     f->upper = n2 > -S->anground * 2.0;
@@ -228,19 +232,19 @@ static int set_plane(qh_state *S, qh_facet *f) {
 }
 
 static double det_of(const qh_state *S, int apex, const int *pts, int dim, int *near) {
-    const double *x = S->x, *y = S->y, *z = S->z;
+    const double *pt = S->pt;
     if (dim == 2) {
         const int a = pts[0], b = pts[1];
-        const double r00 = x[a] - x[apex], r01 = y[a] - y[apex];
-        const double r10 = x[b] - x[apex], r11 = y[b] - y[apex];
+        const double r00 = PX(a) - PX(apex), r01 = PY(a) - PY(apex);
+        const double r10 = PX(b) - PX(apex), r11 = PY(b) - PY(apex);
         const double det = r00 * r11 - r01 * r10;
         *near = fabs(det) < 10 * S->nearzero[1];
         return det;
     }
     const int a = pts[0], b = pts[1], c = pts[2];
-    const double a1 = x[a] - x[apex], a2 = y[a] - y[apex], a3 = z[a] - z[apex];
-    const double b1 = x[b] - x[apex], b2 = y[b] - y[apex], b3 = z[b] - z[apex];
-    const double c1 = x[c] - x[apex], c2 = y[c] - y[apex], c3 = z[c] - z[apex];
+    const double a1 = PX(a) - PX(apex), a2 = PY(a) - PY(apex), a3 = PZ(a) - PZ(apex);
+    const double b1 = PX(b) - PX(apex), b2 = PY(b) - PY(apex), b3 = PZ(b) - PZ(apex);
+    const double c1 = PX(c) - PX(apex), c2 = PY(c) - PY(apex), c3 = PZ(c) - PZ(apex);
     const double det = (a1 * (b2 * c3 - b3 * c2) - b1 * (a2 * c3 - a3 * c2)) + c1 * (a2 * b3 - a3 * b2);
     *near = fabs(det) < 10 * S->nearzero[2];
     return det;
@@ -368,24 +372,25 @@ static int partition_point(qh_state *S, int p, int start, double *dout) {
 /* ---- the run ---- */
 static int qh_run(qh_state *S) {
     const int m = S->m;
-    double *xs = S->x, *ys = S->y, *zs = S->z;
+    double *pt = S->pt;
     qh_facet *F = S->F;
     qh_cold *C = S->C;
     /* 2. extreme points per coordinate (first strict maximum / minimum in input order, maximum tested first), ranges */
     int maxpoints[6];
     double maxabs = 0.0, maxwidth = 0.0, maxsum = 0.0, zlow = 0.0, zhigh = 0.0;
     for (int k = 0; k < 3; ++k) {
-        const double *c = k == 0 ? xs : (k == 1 ? ys : zs);
+        const double *c = pt + k;          /* coordinate k of point i: c[4 i] */
         int lo = 0, hi = 0;
         for (int i = 0; i < m; ++i) {
-            if (c[hi] < c[i]) hi = i;
-            else if (c[lo] > c[i]) lo = i;
+            if (c[4 * (size_t)hi] < c[4 * (size_t)i]) hi = i;
+            else if (c[4 * (size_t)lo] > c[4 * (size_t)i]) lo = i;
         }
         double maxcoord;
-        if (k == 2) { zlow = c[lo]; zhigh = c[hi]; maxcoord = maxabs; }
+        const double clo = c[4 * (size_t)lo], chi = c[4 * (size_t)hi];
+        if (k == 2) { zlow = clo; zhigh = chi; maxcoord = maxabs; }
         else {
-            maxcoord = c[hi] > -c[lo] ? c[hi] : -c[lo];
-            if (c[hi] - c[lo] > maxwidth) maxwidth = c[hi] - c[lo];
+            maxcoord = chi > -clo ? chi : -clo;
+            if (chi - clo > maxwidth) maxwidth = chi - clo;
         }
         if (maxcoord > maxabs) maxabs = maxcoord;
         maxsum += maxcoord;
@@ -397,7 +402,7 @@ static int qh_run(qh_state *S) {
     {
         const double scale = maxabs / (zhigh - zlow);
         const double shift = 0.0 - zlow * scale;
-        for (int i = 0; i < m; ++i) zs[i] = zs[i] * scale + shift;
+        for (int i = 0; i < m; ++i) PZ(i) = PZ(i) * scale + shift;
     }
     /* 4. roundoff constants */
     {
@@ -418,8 +423,8 @@ static int qh_run(qh_state *S) {
         int maxx = -1, minx = -1;
         for (int k = 0; k < 6; ++k) {
             const int p = maxpoints[k];
-            if (maxc < xs[p]) { maxc = xs[p]; maxx = p; }
-            if (minc > xs[p]) { minc = xs[p]; minx = p; }
+            if (maxc < PX(p)) { maxc = PX(p); maxx = p; }
+            if (minc > PX(p)) { minc = PX(p); minx = p; }
         }
         simplex[ns++] = minx;
         if (maxx != minx) simplex[ns++] = maxx;
@@ -467,7 +472,7 @@ static int qh_run(qh_state *S) {
         }
         for (int i = 0; i < 4; ++i) { int c = 0; for (int j = 0; j < 4; ++j) if (j != i) F[fs[i]].nb[c++] = fs[j]; }
         double cx = 0.0, cy = 0.0, cz = 0.0;
-        for (int j = 0; j < 4; ++j) { const int p = S->vpoint[verts[j]]; cx += xs[p]; cy += ys[p]; cz += zs[p]; }
+        for (int j = 0; j < 4; ++j) { const int p = S->vpoint[verts[j]]; cx += PX(p); cy += PY(p); cz += PZ(p); }
         cx = cx / 4; cy = cy / 4; cz = cz / 4;
         int rc = set_plane(S, &F[fs[0]]);
         if (rc) return rc;
@@ -687,7 +692,10 @@ int mvosr_qhull_rows_host(const double *points, int64_t n_points, int64_t stride
     /* a run creates ~5.6 facets per point and keeps ~2 alive: slots are reused, 4 n + 64 never ran out on 60 000 sets (else: declined) */
     S.ncap = 4 * m + 64;
     S.listcap = 2 * m + 64;
-    S.x = (double *)ws_get(0, sizeof(double) * 3 * (size_t)m);
+    {
+        char *raw = (char *)ws_get(0, sizeof(double) * 4 * (size_t)m + 64);
+        S.pt = raw ? (double *)(((uintptr_t)raw + 63) & ~(uintptr_t)63) : NULL;
+    }
     S.onext = (int32_t *)ws_get(1, sizeof(int32_t) * 2 * (size_t)m);
     S.vpoint = (int32_t *)ws_get(2, sizeof(int32_t) * ((size_t)m + 8));
     {
@@ -698,8 +706,8 @@ int mvosr_qhull_rows_host(const double *points, int64_t n_points, int64_t stride
     S.visible = (int32_t *)ws_get(4, sizeof(int32_t) * 3 * (size_t)S.listcap);
     S.ridge_nf = (int32_t *)ws_get(5, sizeof(int32_t) * 2 * ((size_t)m + 8));
     S.ridge_k = (uint8_t *)ws_get(6, (size_t)m + 8);
-    if (!S.x || !S.onext || !S.vpoint || !S.F || !S.C || !S.visible || !S.ridge_nf || !S.ridge_k) return QHH_ERR_ALLOC;
-    S.y = S.x + m; S.z = S.y + m;
+    if (!S.pt || !S.onext || !S.vpoint || !S.F || !S.C || !S.visible || !S.ridge_nf || !S.ridge_k) return QHH_ERR_ALLOC;
+    double *pt = S.pt;
     S.oprev = S.onext + m;
     S.newf = S.visible + S.listcap; S.stack = S.newf + S.listcap;
     S.ridge_gen = S.ridge_nf + (m + 8);
@@ -711,11 +719,11 @@ int mvosr_qhull_rows_host(const double *points, int64_t n_points, int64_t stride
             const double px = points[(size_t)i * (size_t)stride_doubles], py = points[(size_t)i * (size_t)stride_doubles + 1];
             if (!(px == px) || !(py == py) || fabs(px) > 1e150 || fabs(py) > 1e150) return QHH_ZERO_WIDTH;   /* NaN / inf / overflowing squares */
             const double pz = px * px + py * py;
-            S.x[i] = px; S.y[i] = py; S.z[i] = pz;
+            PX(i) = px; PY(i) = py; PZ(i) = pz; pt[4 * (size_t)i + 3] = 0.0;
             sx += px; sy += py;
             if (pz > maxb) maxb = pz;
         }
-        S.x[n] = sx / n; S.y[n] = sy / n; S.z[n] = maxb * 1.1;
+        PX(n) = sx / n; PY(n) = sy / n; PZ(n) = maxb * 1.1; pt[4 * (size_t)n + 3] = 0.0;
     }
     const int rc = qh_run(&S);
     if (rc) return rc;

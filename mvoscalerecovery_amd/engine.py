@@ -25,19 +25,23 @@ def make_params(absolute_reference, camera_pitch=K.CAMERA_PITCH, pitch_threshold
                        _lib.VOTE_FIXED if check_triangle == "fixed" else _lib.VOTE_REFERENCE)
 
 
-def exact_mask_of(feat_cnt, everything=False):
+def exact_mask_of(feat_cnt, everything=False, lazy_last=False):
     """mvosr_batch.exact_mask for a chunk: the frames whose ``height_level`` a LATER step reads get it summed in NumPy's own
     order by the product launch itself — the last frame of the chunk that sets a level (the next chunk, or the caller, may
     read it: a frame with exactly three features below the vanishing row divides by the level an earlier frame left,
     /root/reference/src/scale_calculator.py:263-270,:420-422; a frame that raises leaves the estimator at it) and every frame
-    directly followed by such a three-feature frame.  ``everything``: all frames (small re-run batches)."""
+    directly followed by such a three-feature frame.  ``everything``: all frames (small re-run batches).  ``lazy_last``: WITHOUT the
+    chunk's last level-setting frame — its exact level is computed only if somebody turns out to read it (the next chunk's head, the
+    caller: scale_calculator._stream_gpu); on ordinary data that one frame was the exact pass's whole list, i.e. a 23 ms replay of
+    Qhull's run per chunk for a number nobody looked at."""
     cnt = np.asarray(feat_cnt)
     if everything:
         return np.ones(len(cnt), dtype=np.uint8)
     m = np.zeros(len(cnt), dtype=np.uint8)
     ok = np.nonzero(cnt > 3)[0]
     if len(ok):
-        m[ok[-1]] = 1
+        if not lazy_last:
+            m[ok[-1]] = 1
         nxt = ok[ok + 1 < len(cnt)]
         m[nxt[cnt[nxt + 1] == 3]] = 1
     return m
@@ -73,7 +77,7 @@ UPLOAD_PIECES = 4              # pieces a chunk's upload is cut into (pack_uploa
 UPLOAD_PIECE_FRAMES = 256      # ... of at least that many frames
 
 
-def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=0, tables=None):
+def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=0, tables=None, lazy_last=False):
     """The batch path's front end without a Python loop over the frames' CONTENTS: the C packer (mvosr_pack_count /
     mvosr_pack_fill, a few host threads) applies the vanishing-row filter (/root/reference/src/scale_calculator.py:252-254)
     and writes the planes x|y|z|v|u straight into page-locked staging memory, which one asynchronous copy moves into a
@@ -118,7 +122,7 @@ def pack_upload_native(ctx, feature3ds, feature2ds, vanish, remap=None, threads=
             lo, hi = int(off[a]), (int(off[b]) if b < F else int(total))
             blk.commit_ranges(stage, [(blk[k].offset + 8 * lo, 8 * (hi - lo)) for k in ("x", "y", "z", "v", "u")])
     cnt = np.array(cnt_view, dtype=np.int32, copy=True)
-    sv("exact_mask")[:] = exact_mask_of(cnt)
+    sv("exact_mask")[:] = exact_mask_of(cnt, lazy_last=lazy_last)
     if n_pieces > 1:
         head, tail = blk["feat_off"].offset, blk["tri_off"].offset
         blk.commit_ranges(stage, [(head, blk["x"].offset - head), (tail, blk.nbytes - tail)], last=True)
@@ -133,7 +137,8 @@ class DeviceBatch:
     """HBM-resident image of a packed batch: ONE device block per upload (features + first triangulation; second
     triangulation + tile index), each filled by one staged asynchronous copy (``_lib.DeviceBlock``)."""
 
-    def __init__(self, ctx: _lib.Context, pf: PackedFrames, with_tri2=True, device_triangulation=False, uploaded=None, exact_all=False):
+    def __init__(self, ctx: _lib.Context, pf: PackedFrames, with_tri2=True, device_triangulation=False, uploaded=None, exact_all=False,
+                 lazy_last=False):
         """``device_triangulation``: both triangulations will be BUILT on the device (:meth:`triangulate`) — the pixel
         column ``u`` travels too, and rows, row counts, vote counters and survivor counts get device buffers that the
         stages hand to each other; nothing of them visits the host."""
@@ -155,7 +160,7 @@ class DeviceBatch:
             self.bufs.update(uploaded.views)
         else:
             arrays = {"feat_off": (pf.feat_off, np.int64), "feat_cnt": (pf.feat_cnt, np.int32),
-                      "exact_mask": (exact_mask_of(pf.feat_cnt, exact_all) if pf.n_frames else np.zeros(1, np.uint8), np.uint8)}
+                      "exact_mask": (exact_mask_of(pf.feat_cnt, exact_all, lazy_last) if pf.n_frames else np.zeros(1, np.uint8), np.uint8)}
             for name in ("x", "y", "z", "v"):
                 arrays[name] = (getattr(pf, name), np.float64)
             if pf.tri1_off is not None and not device_triangulation:

@@ -334,7 +334,25 @@ class ScaleEstimator:
         if fast is not None:
             raw, status, level, counts, host_errors, last, lazy_level = fast
         elif self.triangulation == "gpu" and tri1s is None and tri2s is None and not few_exact:
-            raw, status, level, counts, host_errors, last = self._stream_gpu(feature3ds, feature2ds, stage)
+            lazy_last = bool(self.GPU_EXACT_LAZY_LEVEL and self.check_triangle == "reference" and not stage)
+            raw, status, level, counts, host_errors, last = self._stream_gpu(feature3ds, feature2ds, stage, lazy_last=lazy_last,
+                                                                             eager_final=bool(_raw_only))
+            if lazy_last and self._lazy_levels and not _raw_only:
+                # the level the estimator is left with (:241 of the last frame that reached it) when that frame is one of those: NumPy's
+                # own double when somebody READS it (height_level is a property: the caller, or the next call's three-feature frame)
+                bad_ = np.isin(status, K.ERROR_STATUSES)
+                for f in host_errors:
+                    bad_[f] = True
+                end_ = int(np.argmax(bad_)) if bad_.any() else len(status)
+                setters_ = np.nonzero(status[:end_] != K.ST_TOO_FEW)[0]
+                if len(setters_) and int(setters_[-1]) in self._lazy_levels and end_ == len(status):
+                    g_ = int(setters_[-1])
+                    f3c, f2c = np.array(feature3ds[g_], dtype=np.float64, copy=True), np.array(feature2ds[g_], dtype=np.float64, copy=True)
+                    remapped_ = bool(self.mutate_inputs)
+
+                    def lazy_level(f3c=f3c, f2c=f2c, remapped_=remapped_):
+                        self.lazy_levels_on_read = getattr(self, "lazy_levels_on_read", 0) + 1
+                        return self._exact_level_of(f3c, f2c, remapped_)
         elif tri1s is None and tri2s is None and not _single and F > self.PIPELINE_CHUNK:
             raw, status, level, counts, host_errors, last = self._stream_chunks(feature3ds, feature2ds)
         else:
@@ -560,7 +578,7 @@ class ScaleEstimator:
                                                   camera_pitch=0.0 if remapped else self.camera_pitch, check_triangle=self.check_triangle)
         return self._redo_engines[key]
 
-    def _chunk_gpu(self, f3s, f2s, stage, tables=False, eng=None, single_exact=False, hot_only=False):
+    def _chunk_gpu(self, f3s, f2s, stage, tables=False, eng=None, single_exact=False, hot_only=False, lazy_last=False, host_exact=False):
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
         ONE upload -> Delaunay #1, vote, Delaunay #2, scale kernel, road model, the exact re-runs known in advance and
         the download of the results, all queued; nothing is waited for here (``_chunk_gpu_finish`` does)."""
@@ -573,7 +591,7 @@ class ScaleEstimator:
         blk = None
         if native:
             remap = (eng.params.cos_pitch, eng.params.sin_pitch) if self.mutate_inputs else None
-            pf, blk = pack_upload_native(ctx, f3s, f2s, self.vanish, remap, tables=tables)     # (:252-254, and :414 on the caller's arrays)
+            pf, blk = pack_upload_native(ctx, f3s, f2s, self.vanish, remap, tables=tables, lazy_last=lazy_last)     # (:252-254, and :414 on the caller's arrays)
         else:
             pf = packing.pack_features(f3s, f2s, self.vanish)          # raw values, packed BEFORE the in-place remap below
             if self.mutate_inputs:
@@ -607,7 +625,7 @@ class ScaleEstimator:
                     blk.free()
                 return st
         st["tri1_rows"] = tri1_rows
-        db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk)
+        db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk, lazy_last=lazy_last)
         try:
             db.triangulate(eng, standin=self.GPU_EXACT_STANDIN and (single_exact or not stage), tri1_rows=tri1_rows)
         except _lib.MvosrAllocError:
@@ -619,7 +637,15 @@ class ScaleEstimator:
             return st
         out = DeviceOutputs(ctx, db, counts=True, stage=stage)
         st["hot_only"] = bool((single_exact and getattr(db, "standin", False)) or hot_only)
-        eng.scale_batch(db, out, hot_only=st["hot_only"])      # (the frames whose level a later step reads are on the batch's exact mask)
+        # host_exact (batches of the reference-exact path with a stand-in second triangulation): the product kernels alone, and the
+        # few frames the exact pass would have redone — they come back MVOSR_ST_REDO — or whose level a later step reads (the exact
+        # mask) go through the HOST path with the call's declined frames (_chunk_gpu_finish): on the device their Qhull rows are one
+        # wavefront per frame for a whole run — 23 ms at the end of EVERY chunk for a handful of frames, the bulk of a call's tail
+        st["host_exact"] = bool(host_exact and getattr(db, "standin", False) and not stage)
+        if st["host_exact"]:
+            from .engine import exact_mask_of
+            st["exact_mask_host"] = exact_mask_of(pf.feat_cnt, lazy_last=lazy_last)
+        eng.scale_batch(db, out, hot_only=st["hot_only"] or st["host_exact"])      # (else: the frames whose level a later step reads are on the batch's exact mask)
         if stage and pf.n_frames == 1 and "filtered" in out.bufs:
             # the per-frame call: the window median (:396-400) of this frame's raw scale over the estimator's queue, queued behind the
             # kernels that produce it — its result arrives with theirs instead of costing an upload, a launch and a download after them
@@ -655,6 +681,30 @@ class ScaleEstimator:
         res = [out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts"), {}]
         self.last_declined = len(redo)
         self.declined_total += len(redo)
+        if st.get("host_exact"):
+            # the exact pass's frames of this chunk: listed by the kernels themselves (a flat triangle within the guard band of the
+            # level, a pitch inside the 1e-9 band, a level that is the result) or on the exact mask
+            extra = np.nonzero((res[1] == _lib.ST_REDO) | (st["exact_mask_host"] != 0))[0]
+            extra = extra[~np.isin(extra, redo)]
+            if len(extra) > self.GPU_EXACT_HOST_REDO_MAX:
+                # many of them (adversarial data): the device's exact pass after all — one masked relaunch (Qhull's rows by the list
+                # kernel, the EXACT variant, the road model), waited for
+                mask = np.zeros(pf.n_frames, dtype=np.uint8)
+                mask[extra] = 1
+                db.set_exact_mask(mask)
+                eng.scale_batch(db, out, masked=True)
+                eng.ctx.sync()
+                new = [out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts")]
+                for k in range(4):
+                    res[k][extra] = new[k][extra]
+                db.info.invalidate()                             # (the statuses read above are the block's cached copy)
+                s2n = db.bufs["dt2_status"].download()
+                late = extra[(s2n[extra] != 0)]                  # (Qhull's replay declined one there: the host's path, below)
+                redo = np.union1d(redo, late).astype(redo.dtype) if len(late) else redo
+                self.exact_redone_on_device = getattr(self, "exact_redone_on_device", 0) + len(extra)
+            elif len(extra):
+                redo = np.union1d(redo, extra).astype(redo.dtype)
+                self.exact_redone_on_host = getattr(self, "exact_redone_on_host", 0) + len(extra)
         handle = None
         if len(redo) and defer is not None and not stage:
             # Streamed batches (round 6): only the declined frames' FIRST SciPy calls are started here — on the worker pool when the
@@ -669,7 +719,7 @@ class ScaleEstimator:
                 f2 = np.asarray(f2s[f], dtype=np.float64)
                 pts.append(np.ascontiguousarray(f2[f2[:, 1] > self.vanish]) if f2.ndim == 2 and f2.size else np.zeros((0, 2)))   # :252-254
             handle = packing.delaunay_submit(pts, self.delaunay_workers, slot=8 + len(defer) % self.GPU_REDO_MAX_DEFERRED,
-                                             canonical=self.check_triangle == "fixed")
+                                             fast=self._host_replay, canonical=self.check_triangle == "fixed")
         pend = {"st": st, "redo": redo, "s12": (s1, s2), "f3s": f3s, "f2s": f2s, "res": res, "keep": keep, "h1": handle}
         if handle is not None:
             defer.append(pend)
@@ -691,7 +741,7 @@ class ScaleEstimator:
             for j, f in enumerate(p["redo"]):
                 f3_all.append(p["f3s"][f]); f2_all.append(p["f2s"][f]); tri1_all.append(rows[j]); where.append((k, int(f)))
         remapped = pending[0]["st"]["remapped"]
-        sub = self._chunk_begin(f3_all, f2_all, 0, tri1s=tri1_all, _remapped=remapped, _exact_all=True,
+        sub = self._chunk_begin(f3_all, f2_all, 0, tri1s=tri1_all, _remapped=remapped, _exact_all=True, _fast=self._host_replay,
                                 _eng=self._redo_engine(remapped) if self.GPU_REDO_CONTEXT else None)
         sub["pf"].extra["tri1_is_canonical"] = self.check_triangle == "fixed"       # (the workers brought the rows to canonical form)
         self._chunk_vote(sub, None, 0)
@@ -717,7 +767,8 @@ class ScaleEstimator:
         raw, status, level, counts, host_errors = res
         if len(redo) and not pend.get("merged"):
             # (every frame of the small re-run in the exact mode: a declined frame's level may be the one a later frame reads)
-            sub = self._chunk_begin([f3s[f] for f in redo], [f2s[f] for f in redo], 0, _remapped=st["remapped"], _exact_all=True)
+            sub = self._chunk_begin([f3s[f] for f in redo], [f2s[f] for f in redo], 0, _remapped=st["remapped"], _exact_all=True,
+                                    _fast=self._host_replay)
             self._chunk_vote(sub, None, 0)
             r_raw, r_status, r_level, r_counts, r_err = self._chunk_scale(sub, None, False)
             raw[redo], status[redo], level[redo], counts[redo] = r_raw, r_status, r_level, r_counts
@@ -729,6 +780,7 @@ class ScaleEstimator:
             if self._masked_launched and getattr(db, "standin", False):
                 # stand-in rows: the masked relaunch asked Qhull's replay for the rows of its one or two frames; a frame it declined
                 # there (its bits arrive in the second triangulation's status only now) takes the host's path for its level
+                db.info.invalidate()                # (s1 / s2 came from the block's cached copy: the relaunch wrote new bits)
                 late = np.nonzero((db.bufs["dt2_status"].download() != 0) & (s2 == 0) & (s1 == 0))[0]
                 if len(late):
                     sub2 = self._chunk_begin([f3s[f] for f in late], [f2s[f] for f in late], 0, _remapped=st["remapped"], _exact_all=True)
@@ -751,10 +803,33 @@ class ScaleEstimator:
             self._chunk_free(st)
         res[2], res[4] = level, host_errors
 
-    def _stream_gpu(self, feature3ds, feature2ds, stage):
+    GPU_EXACT_FIRST_CHUNK = 4096    # check_triangle="reference", two contexts: frames of a call's first chunk (0: a full chunk; 4096 = one round of resident wavefronts: profiles/r06_exact_first_chunk_ab.txt)
+    GPU_EXACT_HOST_REDO = True      # check_triangle="reference" batches: the exact pass's few frames through the host path (see _chunk_gpu)
+    GPU_EXACT_HOST_REDO_MAX = 64    # ... up to so many per chunk; more: the device's exact pass (one masked relaunch)
+    GPU_EXACT_LAZY_LEVEL = True     # check_triangle="reference" batches: a chunk's last frame is not on the exact mask (see _stream_gpu)
+
+    def _exact_level_of(self, f3, f2, remapped):
+        """NumPy's own ``height_level`` (:239-241) of ONE frame: Qhull's rows (the host replay, SciPy where it declines), every stage in
+        the exact mode."""
+        sub = self._chunk_begin([f3], [f2], 0, _remapped=remapped, _exact_all=True, _fast=self._host_replay)
+        self._chunk_vote(sub, None, 0)
+        _, _, lvl, _, _ = self._chunk_scale(sub, None, False)
+        return lvl[0]
+
+    def _stream_gpu(self, feature3ds, feature2ds, stage, lazy_last=False, eager_final=False):
         """The batch through the device-triangulation path in chunks: the GPU works on chunk k while this process packs
-        chunk k+1 (every launch and copy of a chunk is asynchronous)."""
+        chunk k+1 (every launch and copy of a chunk is asynchronous).
+
+        ``lazy_last`` (round 6; the reference-exact path's batches): a chunk's last level-setting frame is NOT put on the exact mask.
+        Its level in NumPy's summation order is read by a later step only if the next chunk starts with a three-feature frame
+        (:263-270, :420-422) or the caller looks at ``est.height_level`` — and on ordinary data that one frame was the exact pass's
+        whole list: Qhull's rows for it are a chain of ~n insertions on ONE wavefront, 23 ms at the end of every chunk, the bulk of a
+        call's exposed tail.  Now the frames concerned are remembered (``self._lazy_levels``); the ones a three-feature frame of the
+        call reads are finished here, exactly (the host path, one frame each); the call's last one is left to ``height_level``'s
+        reader (scale_calculation_batch).  ``eager_final`` (raw_scale_batch: the levels leave this estimator — another rank's first
+        frame may read this block's last one): the call's final chunk keeps its mask."""
         F = len(feature3ds)
+        self._lazy_levels = set()
         # Larger chunks leave fewer launch tails (32 768 frames of 2000 features: 347 k frames/s in chunks of 2048, 356 k in
         # chunks of 4096; 900 features: 710 k / 756 k, and with the short first chunks 764 k / 807 k in chunks of 4096 / 8192 —
         # profiles/e2e_chunk_sweep.py; the points cap keeps 2000-feature frames at 5000 per chunk), but a call that is ONE chunk packs,
@@ -784,6 +859,11 @@ class ScaleEstimator:
         # the first chunks are short (C/8, C/4, C/2): the GPU starts after the pack + upload of 1/8 chunk instead of a whole
         # one, and the host, which prepares a frame in less time than the GPU spends on it, is ahead from then on
         ramp = [int(C * x) for x in self.GPU_RAMP_FRACTIONS] if (self.GPU_RAMP and not exact and C >= 2048 and F >= 3 * C) else []
+        if exact and len(engines) == 2 and self.GPU_EXACT_FIRST_CHUNK and C >= 2 * self.GPU_EXACT_FIRST_CHUNK and self.GPU_EXACT_HOST_REDO:
+            # the exact path's head: nothing runs before the first chunk is packed and uploaded (16 ms for 8 192 frames of 2000 features).
+            # A short first chunk was a loss while every chunk ended in a 23 ms list replay (LABNOTES 9.14); with the exact pass's
+            # frames on the host (host_exact) a chunk has no such tail, and the short chunk's replay runs under the next one's.
+            ramp = [int(self.GPU_EXACT_FIRST_CHUNK)]
 
         from .engine import frame_tables
 
@@ -816,18 +896,23 @@ class ScaleEstimator:
 
         bounds = []
         results, queue = [], []
+        self._chunk_states = []
         deferred = [] if (self.GPU_REDO_DEFER and not stage) else None      # declined frames' re-runs: finished after the last chunk
         for k, (a, b, tb) in enumerate(chunk_bounds()):
             bounds.append((a, b))
-            queue.append((self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage, tables=tb, eng=engines[k % len(engines)]), a, b))
+            queue.append((self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage, tables=tb, eng=engines[k % len(engines)],
+                                          lazy_last=lazy_last and not (eager_final and b == F),
+                                          host_exact=exact and not stage and self.GPU_EXACT_HOST_REDO and self.GPU_EXACT_STANDIN), a, b))
             # GPU_PIPELINE chunks stay queued behind the one whose results are collected: this process packs and uploads
             # the next chunk meanwhile (the kernel timeline shows the GPU 98 % busy between a call's first and last chunk
             # with one: what a call pays beyond its kernels is its first chunk's pack + upload and the host's epilogue)
             while len(queue) > self.GPU_PIPELINE:
                 ps, pa, pb = queue.pop(0)
+                self._chunk_states.append((ps, pa, pb))
                 results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb], defer=deferred))
         while queue:
             ps, pa, pb = queue.pop(0)
+            self._chunk_states.append((ps, pa, pb))
             results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb], keep=not queue, defer=deferred))
         self._chunk_gpu_complete_all(deferred)
         raw = np.concatenate([r[0] for r in results])
@@ -837,6 +922,35 @@ class ScaleEstimator:
         host_errors = {}
         for (a, _), r in zip(bounds, results):
             host_errors.update({a + f: e for f, e in r[4].items()})
+        if lazy_last:
+            # the frames whose level is the product kernels' own sum although a later chunk might read it: every chunk's last frame
+            # with more than three features below the vanishing row, unless the mask held it for another reason or an exact pass
+            # redid it anyway (a re-run, a level that is the result).  A three-feature frame of THIS call that reads one: finished now.
+            lazy = set()
+            for (a, b), (ps_, _, _) in zip(bounds, self._chunk_states):
+                cnt = np.asarray(ps_["pf"].feat_cnt) if ps_.get("gpu") else None
+                if cnt is not None and not (eager_final and b == F):
+                    ok = np.nonzero(cnt > 3)[0]
+                    if len(ok) and not (ok[-1] + 1 < len(cnt) and cnt[ok[-1] + 1] == 3):
+                        lazy.add(a + int(ok[-1]))
+            bad = np.isin(status, K.ERROR_STATUSES)
+            for f in host_errors:
+                bad[f] = True
+            end = int(np.argmax(bad)) if bad.any() else len(status)
+            sets_level = status[:end] != K.ST_TOO_FEW
+            last_setter = np.maximum.accumulate(np.where(sets_level, np.arange(end), -1)) if end else np.zeros(0, dtype=np.int64)
+            need = {int(last_setter[f]) for f in np.nonzero(~sets_level)[0] if int(last_setter[f]) in lazy}
+            if end < len(status) and end and int(last_setter[end - 1]) in lazy:
+                need.add(int(last_setter[end - 1]))          # a frame raises: the estimator keeps the level of the last frame before it (:241)
+            need = sorted(need)
+            if need:
+                level = np.array(level, copy=True)
+                for g in need:
+                    level[g] = self._exact_level_of(feature3ds[g], feature2ds[g], bool(self.mutate_inputs))
+                    lazy.discard(g)
+                self.lazy_levels_finished = getattr(self, "lazy_levels_finished", 0) + len(need)
+            self._lazy_levels = lazy
+        self._chunk_states = []
         return raw, status, level, counts, host_errors, ps
 
     def _single_exact_fast(self, feature3ds, feature2ds, fixed=False):

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""A/B of the exact path's chunk size with the exact pass's frames on the host (no list replay per chunk any more): GPU_EXACT_CHUNK
+(halved per context) x GPU_EXACT_FIRST_CHUNK, calls of 16 384 / 65 536 frames."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvoscalerecovery_amd import synth                                     # noqa: E402
+from mvoscalerecovery_amd.scale_calculator import ScaleEstimator            # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+pool = [synth.synth_frame(200000 + i, N, base_seed=2024) for i in range(4096)]
+est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=0)
+for F in (16384, 65536):
+    f3, f2 = [pool[i % 4096][0] for i in range(F)], [pool[i % 4096][1] for i in range(F)]
+    for chunk, first in ((16384, 4096), (8192, 4096), (8192, 0), (24576, 4096), (16384, 4096)):
+        est.GPU_EXACT_CHUNK, est.GPU_EXACT_FIRST_CHUNK = chunk, first
+        est.scale_calculation_batch(f3, f2)
+        t = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            est.scale_calculation_batch(f3, f2)
+            t.append(time.perf_counter() - t0)
+        print("%d features, %6d frames, GPU_EXACT_CHUNK %5d (per context %5d), first %4d: %.1f ms = %.1f k frames/s"
+              % (N, F, chunk, chunk // 2, first, 1e3 * sorted(t)[1], F / sorted(t)[1] / 1e3), flush=True)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the HOST spends a per-frame call: cProfile over 300 calls.   python profiles/latency_cprofile.py [rescale|scale] [features]"""
+"""Where the HOST spends a per-frame call: cProfile over 300 calls.   python profiles/latency_cprofile.py [rescale|scale|exact] [features]"""
 import cProfile
 import os
 import pstats
@@ -14,6 +14,9 @@ fr = [synth.synth_frame(300000 + i, n, base_seed=2024) for i in range(100)]
 if which == "rescale":
     from mvoscalerecovery_amd.rescale import ScaleEstimator
     est = ScaleEstimator(1.75, window_size=5, device=0, delaunay_workers=0, triangulation="gpu", ransac_seed=2024)
+elif which == "exact":                 # the default construction: the reference's result
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    est = ScaleEstimator(1.75, window_size=5, device=0, delaunay_workers=0)
 else:
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
     est = ScaleEstimator(1.75, window_size=5, device=0, delaunay_workers=0, triangulation="gpu")

@@ -109,3 +109,24 @@ def test_threads_share_nothing():
     for k, g in enumerate(got):
         w = want[k % 64]
         assert (g is None) == (w is None) and (g is None or np.array_equal(g, w))
+
+
+def test_sanitizers(tmp_path):
+    """The C replay under AddressSanitizer + UBSan on 3 000 point sets, hostile ones included (tests/native/qhull_host_sanitize.c):
+    no report, no out-of-range row, a too-small rows buffer declined."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "san")
+    build = subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                            os.path.join(root, "tests", "native", "qhull_host_sanitize.c"),
+                            os.path.join(root, "mvoscalerecovery_amd", "csrc", "mvosr_qhull_host.c"), "-lm", "-o", exe], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("no sanitizer runtime: " + build.stderr[-200:])
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert run.returncode == 0 and "sanitizer run: ok" in run.stdout and "errors 0" in run.stdout, run.stdout[-500:] + run.stderr[-3000:]
+    assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr[-3000:]
