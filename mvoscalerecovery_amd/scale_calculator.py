@@ -686,7 +686,9 @@ class ScaleEstimator:
             # level, a pitch inside the 1e-9 band, a level that is the result) or on the exact mask
             extra = np.nonzero((res[1] == _lib.ST_REDO) | (st["exact_mask_host"] != 0))[0]
             extra = extra[~np.isin(extra, redo)]
-            if len(extra) > self.GPU_EXACT_HOST_REDO_MAX:
+            # (the host's route costs two replays of Qhull's run per frame, ~1.7 ms, spread over the Delaunay workers; the device's one
+            # masked relaunch, ~25 ms and a wait, however many frames)
+            if len(extra) > min(self.GPU_EXACT_HOST_REDO_MAX, 16 * max(1, packing.resolve_workers(self.delaunay_workers))):
                 # many of them (adversarial data): the device's exact pass after all — one masked relaunch (Qhull's rows by the list
                 # kernel, the EXACT variant, the road model), waited for
                 mask = np.zeros(pf.n_frames, dtype=np.uint8)
@@ -805,7 +807,7 @@ class ScaleEstimator:
 
     GPU_EXACT_FIRST_CHUNK = 4096    # check_triangle="reference", two contexts: frames of a call's first chunk (0: a full chunk; 4096 = one round of resident wavefronts: profiles/r06_exact_first_chunk_ab.txt)
     GPU_EXACT_HOST_REDO = True      # check_triangle="reference" batches: the exact pass's few frames through the host path (see _chunk_gpu)
-    GPU_EXACT_HOST_REDO_MAX = 64    # ... up to so many per chunk; more: the device's exact pass (one masked relaunch)
+    GPU_EXACT_HOST_REDO_MAX = 64    # ... up to so many per chunk (16 per Delaunay worker at most); more: the device's exact pass (one masked relaunch)
     GPU_EXACT_LAZY_LEVEL = True     # check_triangle="reference" batches: a chunk's last frame is not on the exact mask (see _stream_gpu)
 
     def _exact_level_of(self, f3, f2, remapped):
