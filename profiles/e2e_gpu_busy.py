@@ -41,8 +41,9 @@ print("gaps below 50 us: %.2f ms in total" % (small / 1e6))
 # stand-in triangulation, product kernels, the list replay of the exact pass's frames: one wavefront per frame, a whole run long)
 rep = [(s_, e_) for s_, e_, k in rows if "qhull_rows_kernel" in k]
 if rep:
-    big = [r for r in rep if r[1] - r[0] > 0.5 * max(e_ - s_ for s_, e_ in rep)]
-    lst = [r for r in rep if r not in big]
+    # (the list walk is the instantiation whose last template argument is true)
+    lst = [(s_, e_) for s_, e_, k in rows if "qhull_rows_kernel" in k and k.replace(" ", "").split("(")[0].rstrip(">").endswith(",true")]
+    big = [r for r in rep if r not in lst]
     u, cs, ce = 0, big[0][0], big[0][1]
     for s_, e_ in sorted(big)[1:]:
         if s_ > ce:

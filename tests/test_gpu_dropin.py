@@ -920,3 +920,24 @@ def test_per_frame_call_of_the_speed_mode_product_kernels_only(gpu):
                 outs.append(("raised", type(exc).__name__))
         assert outs[0][0] == outs[1][0] and eq(outs[0][1], outs[1][1]), (i, outs)
         assert eq(list(a.scale_queue), list(b.scale_queue)) and eq(getattr(a, "height_level", None), getattr(b, "height_level", None)), i
+
+
+def test_host_replay_in_the_delaunay_workers(gpu):
+    """A handful of frames through the default estimator WITH a worker pool: both triangulations by the host replay of Qhull's run
+    (mvosr_qhull_rows_host) inside the forked Delaunay workers — libmvosr.so is loaded there without touching the GPU — and the
+    oracle's numbers; a set the replay declines (quarter-pixel grid) takes SciPy in the same worker."""
+    from mvoscalerecovery_amd import packing, synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    frames = [synth.synth_frame(i, 400 + 90 * i, base_seed=777, upper_fraction=0.1) for i in range(12)]
+    f3, f2 = frames[5]
+    frames[5] = (f3, np.ascontiguousarray(np.round(f2 * 4) / 4))
+    est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=3)
+    assert est._host_replay and packing._pool is not None
+    ref = so.OracleScaleEstimator(1.75, window_size=5)
+    want = [ref.scale_calculation(a.copy(), b.copy()) for a, b in frames]
+    got = est.scale_calculation_batch([f[0] for f in frames], [f[1] for f in frames])
+    assert [w[0] for w in want] == list(got[0]) and [w[1] for w in want] == list(got[1])
+    rows = packing.delaunay_submit([f[1][f[1][:, 1] > 185] for f in frames], 3, slot=3, fast=True).get()
+    for f, r in zip(frames, rows):
+        assert np.array_equal(r, packing.delaunay_simplices(f[1][f[1][:, 1] > 185]))
