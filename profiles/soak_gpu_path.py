@@ -34,6 +34,8 @@ while time.time() < t_end:
     g.GPU_CHUNK = 2048 if big else int(rng.integers(16, 256))
     if EXACT:
         g.GPU_EXACT_CHUNK = int(rng.choice([64, 300, 16384]))
+        if rng.uniform() < 0.5:
+            g.GPU_MIN_CHUNK = 16        # (chunk boundaries everywhere in half of the batches)
     h = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="scipy", check_triangle=MODE, delaunay_workers=8)
     try:
         sg = g.scale_calculation_batch(f3, f2); eg = None
@@ -45,6 +47,10 @@ while time.time() < t_end:
         sh, eh = None, type(exc).__name__
     ok = eg == eh and (sg is None or (np.array_equal(sg[0], sh[0], equal_nan=True) and np.array_equal(sg[1], sh[1])))
     ok = ok and np.array_equal(np.asarray(g.last_raw_scale), np.asarray(h.last_raw_scale), equal_nan=True)
+    if eg is None:                  # the level the estimator is left with (round 6: computed when read, for the exact path's batches)
+        lg, lh = getattr(g, "height_level", None), getattr(h, "height_level", None)
+        ok = ok and (lg == lh or (lg is not None and lh is not None and np.isnan(lg) and np.isnan(lh)))
+
     bad += 0 if ok else 1
     if not ok:
         print("MISMATCH batch seed=%d F=%d chunk=%d: %s / %s" % (seed, F, g.GPU_CHUNK, eg, eh))
