@@ -86,6 +86,7 @@ struct QhArgs {
     unsigned long long *stamps;
     int32_t *redo;               // packed kernels: frames that overflowed a table ([0] = how many), for the list kernel
     const int32_t *list;         // null, or: list[0] frames list[1..] (a redo list of the scale kernels), walked by a persistent grid
+    const int32_t *launch_order; // null, or: workgroup b runs frame launch_order[b] — the largest frames first (qh_order_kernel)
     char *ws; size_t ws_stride; int cap_pts;      // per-frame slice, laid out by QhPlan for cap_pts = max_pts + 1 points
 };
 
@@ -951,8 +952,9 @@ __global__ __launch_bounds__(64, (G == 16 ? 2 : 4)) void qhull_rows_kernel(const
         }
         return;
     } else {
-        const int64_t f = (int64_t)blockIdx.x * (64 / G) + Sg<G>::sub();
+        int64_t f = (int64_t)blockIdx.x * (64 / G) + Sg<G>::sub();
         if (f >= a.n_frames) return;
+        if (G == 64 && a.launch_order) f = (int64_t)a.launch_order[f];
         int nrows = 0;
         const int why = qh_run<FID, G, TAB>(a, L, f, f, nrows);
         if (Sg<G>::sl() == 0) {
@@ -968,10 +970,38 @@ __global__ __launch_bounds__(64, (G == 16 ? 2 : 4)) void qhull_rows_kernel(const
     }
 }
 
+// Launch order of a ragged batch: a replay is a chain of ~n insertions, so a wavefront's life is proportional to its frame's points,
+// and a launch of more frames than the machine holds wavefronts (16 per CU) ends when its LAST-started long frame ends.  Workgroups are
+// dispatched in index order: frames sorted by size, largest first (64 size classes, one counting sort by one workgroup; the order inside
+// a class is whatever the atomics give — every frame's rows are its own), leave the short frames for the tail.
+constexpr int kQhOrderThreads = 1024, kQhOrderClasses = 64;
+__global__ __launch_bounds__(kQhOrderThreads) void qh_order_kernel(const int32_t *pts_cnt, int64_t n_frames, int max_pts, int32_t *order) {
+    __shared__ int cnt[kQhOrderClasses], base[kQhOrderClasses];
+    const int tid = threadIdx.x;
+    if (tid < kQhOrderClasses) cnt[tid] = 0;
+    __syncthreads();
+    auto cls = [&](int n) { const int c = (int)(((int64_t)max(n, 0) * kQhOrderClasses) / ((int64_t)max_pts + 1)); return kQhOrderClasses - 1 - min(c, kQhOrderClasses - 1); };
+    for (int64_t f = tid; f < n_frames; f += kQhOrderThreads) atomicAdd(&cnt[cls(pts_cnt[f])], 1);
+    __syncthreads();
+    if (tid == 0) { int b = 0; for (int c = 0; c < kQhOrderClasses; ++c) { base[c] = b; b += cnt[c]; } }
+    __syncthreads();
+    for (int64_t f = tid; f < n_frames; f += kQhOrderThreads) order[atomicAdd(&base[cls(pts_cnt[f])], 1)] = (int32_t)f;
+}
+
 // Lanes per frame of the product launch: 64.  The packed instantiations (two / four frames per wavefront) are measured A/B
 // variants of builds with -DMVOSR_ABLATE (env MVOSR_QH_GROUP = 32 | 16): rows identical, but a packed wavefront's insertion is
 // the LONGEST of its frames' steps (52.7 k clocks for four frames against 27.5 k for one, alone on a SIMD) and 20 KB of LDS
 // leave two wavefronts per SIMD: 113 k sets/s (G = 16), 103 k (G = 32) against 129 k (LABNOTES §9.8).
+// MVOSR_QH_NO_ORDER=1 (diagnostic builds, -DMVOSR_ABLATE): frames in index order, as before round 6
+bool qh_no_order() {
+#ifdef MVOSR_ABLATE
+    static const bool v = [] { const char *e = getenv("MVOSR_QH_NO_ORDER"); return e && e[0] == '1'; }();
+    return v;
+#else
+    return false;
+#endif
+}
+
 int qh_group() {
 #ifdef MVOSR_ABLATE
     static const int g = [] {
@@ -1009,6 +1039,7 @@ static int qh_launch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, c
     QhArgs a;
     a.n_frames = n_frames; a.pts_off = pts_off; a.pts_cnt = pts_cnt; a.u = u; a.v = v; a.keep = keep; a.tri_off = tri_off; a.tri = tri;
     a.tri_cnt = tri_cnt; a.n_used = n_used; a.status = status; a.order_out = order_out; a.list = list; a.redo = nullptr;
+    a.launch_order = nullptr;
     a.cap_pts = max_pts + 1;
 #ifdef MVOSR_QH_STAMPS
     a.stamps = g_qh_stamps;
@@ -1020,10 +1051,19 @@ static int qh_launch(mvosr_ctx *ctx, int64_t n_frames, const int64_t *pts_off, c
     const int64_t slices = list ? (int64_t)(list_blocks < n_frames ? list_blocks : n_frames) : n_frames;
     const int group = (list || wide) ? 64 : qh_group();
     const size_t redo_bytes = group < 64 ? (((size_t)n_frames + 1) * sizeof(int32_t) + 255) & ~(size_t)255 : 0;
+    // (a launch that holds more frames than the machine holds wavefronts — 16 per CU — and is not a list walk: largest frames first)
+    const bool ordered = !list && group == 64 && n_frames > (int64_t)16 * ctx->n_cu && n_frames < 0x7fffffff && !qh_no_order();
+    const size_t order_bytes = ordered ? ((size_t)n_frames * sizeof(int32_t) + 255) & ~(size_t)255 : 0;
     void *ws = nullptr;
-    if ((rc = ctx_workspace_bytes(ctx, (size_t)slices * P.total + redo_bytes, &ws))) return rc;
+    if ((rc = ctx_workspace_bytes(ctx, (size_t)slices * P.total + redo_bytes + order_bytes, &ws))) return rc;
     a.ws = reinterpret_cast<char *>(ws);
     hipStream_t st = ctx_stream(ctx);
+    if (ordered) {
+        int32_t *ord = reinterpret_cast<int32_t *>(a.ws + (size_t)slices * P.total + redo_bytes);
+        hipLaunchKernelGGL(qh_order_kernel, dim3(1), dim3(kQhOrderThreads), 0, st, pts_cnt, n_frames, max_pts, ord);
+        if ((rc = check_launch("qh_order_kernel"))) return rc;
+        a.launch_order = ord;
+    }
     // (the list walk is an instantiation of its own: the loop around the run cost the product kernel registers — spills in its hot loop)
     if (list) {
         if (wide) hipLaunchKernelGGL((qhull_rows_kernel<uint32_t, 64, 64, true>), dim3((unsigned)slices), dim3(64), 0, st, a);

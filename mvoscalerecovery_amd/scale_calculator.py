@@ -865,7 +865,13 @@ class ScaleEstimator:
             # the exact path's head: nothing runs before the first chunk is packed and uploaded (16 ms for 8 192 frames of 2000 features).
             # A short first chunk was a loss while every chunk ended in a 23 ms list replay (LABNOTES 9.14); with the exact pass's
             # frames on the host (host_exact) a chunk has no such tail, and the short chunk's replay runs under the next one's.
-            ramp = [int(self.GPU_EXACT_FIRST_CHUNK)]
+            # Not for RAGGED frames: the replay launches its frames largest first (qh_order_kernel), which packs a launch of two rounds
+            # of wavefronts well — and a one-round first chunk of ragged frames lasts as long as its longest frame with most of the
+            # machine idle: 238 -> 201 k frames/s at 300-1500 features, 110 -> 116 k at 2000, 245 -> 259 k at 900 (profiles/
+            # r06_exact_first_chunk_ab.txt).  Ragged: the largest of the call's first frames has more than 1.3 x their mean.
+            head = np.fromiter((len(x) for x in feature3ds[:256]), dtype=np.int64, count=min(F, 256))
+            if head.max() <= 1.3 * max(head.mean(), 1.0):
+                ramp = [int(self.GPU_EXACT_FIRST_CHUNK)]
 
         from .engine import frame_tables
 

@@ -8,12 +8,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvoscalerecovery_amd import synth                                     # noqa: E402
 from mvoscalerecovery_amd.scale_calculator import ScaleEstimator            # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-pool = [synth.synth_frame(200000 + i, N, base_seed=2024) for i in range(4096)]
+import numpy as np                                                          # noqa: E402
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000                         # 0: ragged 300-1500 (config C3's sizes)
+rng = np.random.default_rng(4541)
+sizes = [int(v) for v in rng.integers(300, 1501, 1024)] if N == 0 else [N]
+pool = [synth.synth_frame(200000 + i, sizes[i % len(sizes)], base_seed=2024) for i in range(4096)]
 est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, delaunay_workers=0)
-for F in (16384, 32768, 65536):
+for F in (16384, 65536):
     f3, f2 = [pool[i % 4096][0] for i in range(F)], [pool[i % 4096][1] for i in range(F)]
-    for first in (0, 1024, 2048, 4096, 0, 2048):
+    for first in (0, 4096, 0, 4096):
         est.GPU_EXACT_FIRST_CHUNK = first
         est.scale_calculation_batch(f3, f2)
         t = []
