@@ -168,6 +168,35 @@ class ScaleEstimator:
 
     height_level = property(_get_height_level, _set_height_level)
 
+    # ``flat_feature`` / ``flat_feature_2d`` (:275-276, :416) after a BATCH are the selected points of its last processed frame: one
+    # more run of that frame with the stage outputs (the host path: ~3 ms — 5 % of a 32 768-frame call of the fixed mode, a quarter
+    # of a 1 000-frame one).  Nobody in the reference's drivers reads them (src/main.py:117-123 is dead code): they are produced when
+    # somebody does.  A per-frame call sets them at once, as before.
+    def _flat_pending(self):
+        d = self.__dict__
+        thunk = d.get("_flat_thunk")
+        if thunk is not None:
+            d["_flat_thunk"] = None
+            thunk()
+
+    def _get_flat_feature(self):
+        self._flat_pending()
+        return self.__dict__.get("_flat_value")
+
+    def _set_flat_feature(self, value):
+        self.__dict__["_flat_thunk"] = None
+        self.__dict__["_flat_value"] = value
+
+    def _get_flat_feature_2d(self):
+        self._flat_pending()
+        return self.__dict__.get("_flat2d_value")
+
+    def _set_flat_feature_2d(self, value):
+        self.__dict__["_flat2d_value"] = value
+
+    flat_feature = property(_get_flat_feature, _set_flat_feature)
+    flat_feature_2d = property(_get_flat_feature_2d, _set_flat_feature_2d)
+
     def scale_calculation(self, feature3d, feature2d, img=None):
         """scale_calculator.py:411-423: returns (filtered scale, std)."""
         scales, stds = self.scale_calculation_batch([feature3d], [feature2d], _single=True)
@@ -373,6 +402,11 @@ class ScaleEstimator:
             self.__dict__["_level_thunk"] = lazy_level          # (the value _push stored is the kernel's own sum: see height_level)
         if n_ok and stage:
             self._store_flat_feature(last["pf"], last["out"], feature3ds, feature2ds, last["masks"], n_ok - 1, status[n_ok - 1])
+        elif n_ok and self.LAZY_FLAT_FEATURE and status[n_ok - 1] not in (K.ST_NO_FLAT, K.ST_TOO_FEW):
+            f3c = np.array(feature3ds[n_ok - 1], dtype=np.float64, copy=True)          # (after the in-place remap, if any: :414)
+            f2c = np.array(feature2ds[n_ok - 1], dtype=np.float64, copy=True)
+            st_, mut_ = status[n_ok - 1], bool(self.mutate_inputs)
+            self.__dict__["_flat_thunk"] = lambda: self._flat_feature_of(f3c, f2c, st_, mutate=mut_)
         elif n_ok:
             self._flat_feature_of(feature3ds[n_ok - 1], feature2ds[n_ok - 1], status[n_ok - 1])
         self._chunk_free(last)
@@ -1015,7 +1049,9 @@ class ScaleEstimator:
             return lvl[0]
         return raw, status, level, counts, host_errors, st, exact_level
 
-    def _flat_feature_of(self, feature3d, feature2d, st):
+    LAZY_FLAT_FEATURE = True        # after a batch: flat_feature / flat_feature_2d when they are read (see the properties)
+
+    def _flat_feature_of(self, feature3d, feature2d, st, mutate=None):
         """``self.flat_feature`` / ``flat_feature_2d`` after a batch: the selected points of its last processed frame
         (:275-276,:416), by running that one frame again with the stage outputs.  With ``mutate_inputs`` the
         caller's array already holds the remapped values (:414), so the re-run uses the identity remap."""
@@ -1024,7 +1060,9 @@ class ScaleEstimator:
             return
         f3 = np.array(feature3d, dtype=np.float64, copy=True)
         f2 = np.asarray(feature2d, dtype=np.float64)
-        mutate, self.mutate_inputs = self.mutate_inputs, False
+        keep_mutate = self.mutate_inputs
+        mutate = keep_mutate if mutate is None else mutate             # (were the frame's values remapped in place when it was processed?)
+        self.mutate_inputs = False
         try:
             if self.triangulation == "gpu" and not mutate and self.check_triangle == "fixed":
                 # (the device's triangulations for this one frame as well: two host Delaunay calls are 5 ms, the whole
@@ -1043,7 +1081,7 @@ class ScaleEstimator:
             self._store_flat_feature(one["pf"], one["out"], [f3], [f2], one["masks"], 0, status[0])
             self._chunk_free(one)
         finally:
-            self.mutate_inputs = mutate
+            self.mutate_inputs = keep_mutate
 
     def _push(self, raw, status, level, host_errors, single=False, filtered_hint=None):
         """The cross-frame half of scale_calculation for a run of frames (:396-400, :413-422): window
