@@ -406,14 +406,6 @@ def e2e_gpu_leg(args, device, sizes, seed, n_frames, exact=False):
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[1]
     a1 = ctx.alloc_stats()
-    if os.environ.get("MVOSR_BENCH_PROFILE_LEG") == ("exact" if exact else "fixed"):      # (diagnostic: where the host spends one more such call)
-        import cProfile
-        import pstats
-        pr = cProfile.Profile()
-        pr.enable()
-        est.scale_calculation_batch(f3s, f2s)
-        pr.disable()
-        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(25)
     # the triangulation kernel alone on resident point sets of the workload's size
     n = int(max(sizes))
     F = 4096 if n <= 6000 else 256
@@ -910,15 +902,14 @@ def main():
                 ok = gpu_status[i] == j[5] and ((np.isnan(gpu_raw[i]) and np.isnan(j[4])) or gpu_raw[i] == j[4])
                 mism_gpu += 0 if ok else 1
             line["parity_mismatches_vs_oracle"] = mism_gpu
-            cpu_budget = float(os.environ.get("MVOSR_BENCH_CPU_BUDGET", "1.0"))      # (diagnostic: scales the CPU legs' 10 + 10 + 8 s)
-            fps, sample_n, _ = cpu_single_core(cpu_jobs, 10.0 * cpu_budget)
+            fps, sample_n, _ = cpu_single_core(cpu_jobs, 10.0)
             line["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
                                     "sample": "%d runs over %d frames of the same workload, triangulations supplied (vectorised NumPy "
                                               "oracle, one thread; host Delaunay %.1f CPU-ms/frame not included)"
                                               % (sample_n, len(cpu_jobs), delaunay_cpu_s * 1e3)}
             # the secondary legs must not cost the headline line: a failure is reported in its place
             try:
-                fps_l, sample_l, mism_l = cpu_single_core(cpu_jobs, 10.0 * cpu_budget, loops=True)
+                fps_l, sample_l, mism_l = cpu_single_core(cpu_jobs, 10.0, loops=True)
                 line["cpu_baseline_reference_shaped"] = {
                     "value": fps_l, "unit": "frames/s", "cores": 1, "kind": "port",
                     "sample": "%d runs over the same frames; loop-faithful flavour of the oracle (one Python iteration per triangle "
@@ -928,7 +919,7 @@ def main():
             except Exception as exc:                                    # noqa: BLE001
                 line["cpu_baseline_reference_shaped"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             try:
-                allv, alln = cpu_all_cores(cpu_pool, cpu_workers, 8.0 * cpu_budget, fps)
+                allv, alln = cpu_all_cores(cpu_pool, cpu_workers, 8.0, fps)
                 line["cpu_baseline_all_cores"] = {"value": allv, "unit": "frames/s", "cores": cpu_workers, "kind": "port",
                                                   "sample": "%d frames dealt from the same sample to %d processes (the CPUs this process "
                                                             "may use: affinity and cgroup quota), triangulations supplied" % (alln, cpu_workers)}
