@@ -578,3 +578,49 @@ def test_relabellings_keep_every_triangle():
                 if feature_ids:
                     assert np.all(m[t2])                                 # every vertex is a survivor
                 assert pf.n2_expected[f] == int(m.sum())
+
+
+def test_canonical_rows_key_sort_equals_lexsort():
+    """packing.canonical_rows (round 6: one 63-bit key per row) against the plain np.sort + np.lexsort form, including ids beyond the
+    key's 21 bits (the fallback) and an empty triangulation."""
+    from mvoscalerecovery_amd import packing
+    rng = np.random.default_rng(5)
+
+    def plain(t):
+        t = np.sort(np.asarray(t, dtype=np.int32).reshape(-1, 3), axis=1)
+        return t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))] if len(t) else t
+    for hi in (50, 4000, (1 << 21) - 1, 1 << 22):
+        t = rng.integers(0, hi + 1, (3000, 3)).astype(np.int32)
+        got = packing.canonical_rows(t)
+        assert got.dtype == np.int32 and got.flags.c_contiguous and np.array_equal(got, plain(t)), hi
+    assert packing.canonical_rows(np.zeros((0, 3), np.int32)).shape == (0, 3)
+
+
+def test_exact_mask_lazy_last():
+    """engine.exact_mask_of: the chunk's last frame with more than three features below the vanishing row is on the mask, and every
+    frame directly followed by a three-feature frame; lazy_last drops only the former (round 6)."""
+    from mvoscalerecovery_amd.engine import exact_mask_of
+    cnt = np.array([900, 3, 800, 700, 3, 3, 600, 500])
+    assert exact_mask_of(cnt).tolist() == [1, 0, 0, 1, 0, 0, 0, 1]
+    assert exact_mask_of(cnt, lazy_last=True).tolist() == [1, 0, 0, 1, 0, 0, 0, 0]
+    tail = np.array([900, 800, 3])
+    assert exact_mask_of(tail).tolist() == exact_mask_of(tail, lazy_last=True).tolist() == [0, 1, 0]      # (held by the other rule)
+    assert exact_mask_of(np.array([3, 3]), lazy_last=True).sum() == 0 and exact_mask_of(cnt, everything=True).all()
+
+
+def test_delaunay_submit_fast_and_canonical_inline():
+    """packing.delaunay_submit(workers=0, fast=True, canonical=True): the host replay where it accepts a set, SciPy where it declines,
+    rows in canonical form from the job itself (the handle says so, attach_* then skips its own pass)."""
+    from mvoscalerecovery_amd import packing, synth
+    sets = [synth.synth_frame(i, 200 + 150 * i, base_seed=99)[1] for i in range(5)]
+    sets[2] = np.round(sets[2] * 4) / 4                                   # (declined by the replay: SciPy's rows)
+    sets.append(np.stack([np.linspace(0, 100, 20), np.linspace(190, 300, 20)], axis=1))          # collinear: SciPy raises
+    h = packing.delaunay_submit(sets, 0, fast=True, canonical=True)
+    assert h.canonical
+    rows = h.get()
+    for p, r in zip(sets[:5], rows[:5]):
+        assert np.array_equal(r, packing.canonical_rows(packing.delaunay_simplices(p)))
+    assert isinstance(rows[5], Exception)
+    plain = packing.delaunay_submit(sets[:5], 0, fast=True).get()
+    for p, r in zip(sets[:5], plain):
+        assert np.array_equal(r, packing.delaunay_simplices(p))
