@@ -1415,13 +1415,31 @@ __global__ __launch_bounds__(WAVES *kWave, (WAVES == 8 && MODE == MODE_HOT ? MVO
     extern __shared__ __attribute__((aligned(16))) char smem[];
     for_frames<MODE, LIST>(a, [&](const int64_t f) {
     constexpr int B = WAVES * kWave;
+    MVOSR_STAMP_DECL
+    MVOSR_STAMP(11);                               // (before the frame's offsets and counts are asked for)
     const int n = a.b.feat_cnt[f];
     const int64_t off = a.b.feat_off[f];
     const int64_t t1b = a.b.tri1_off[f], t2b = a.b.tri2_off[f];
     const int t1n = tri_rows(a.b.tri1_off, a.b.tri1_cnt, f), t2n = tri_rows(a.b.tri2_off, a.b.tri2_cnt, f);
     const Smem s = carve(smem, n, WAVES);
-    MVOSR_STAMP_DECL
+#ifdef MVOSR_STAGGER
+    // Experiment (round 6, LABNOTES 10.10): the launch's first generation of workgroups starts spread over MVOSR_STAGGER
+    // ticks of s_memtime (100 MHz) instead of all at once, so that equal-length frames do not march through their phases in step.
+    if (MODE == MODE_HOT && !LIST && blockIdx.x < 768u) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = ((blockIdx.x * 2654435761u) >> 12) % (unsigned)(MVOSR_STAGGER);
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+#ifdef MVOSR_STAMPS
+    if (n < 0) return;                             // (never: makes the stamp below wait for the frame's counts)
+#endif
     MVOSR_STAMP(0);
+#ifdef MVOSR_STAMPS
+    if (threadIdx.x == 0) {                        // where the workgroup ran: HW_ID (CU, SE) and XCC_ID
+        stamps[10] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+#endif
 
     RoadResult R;
     R.height = nan(""); R.n_sel = R.n_kept = R.n_modes = 0; R.mode_left = R.mode_right = -1;
@@ -1446,7 +1464,7 @@ __global__ __launch_bounds__(WAVES *kWave, (WAVES == 8 && MODE == MODE_HOT ? MVO
     frame_tail<WAVES, MODE>(a, s, f, off, nvalid, mask_mismatch || too_many_rows, S, R);
     MVOSR_STAMP(9);
 #ifdef MVOSR_STAMPS
-    if (threadIdx.x == 0 && a.o.hist) { unsigned long long *d = reinterpret_cast<unsigned long long *>(a.o.hist + f * 2 * kBins); for (int i = 0; i < 10; ++i) d[i] = stamps[i]; }
+    if (threadIdx.x == 0 && a.o.hist) { unsigned long long *d = reinterpret_cast<unsigned long long *>(a.o.hist + f * 2 * kBins); for (int i = 0; i < 12; ++i) d[i] = stamps[i]; }
 #endif
     });
 }
