@@ -300,6 +300,7 @@ int mvosr_event_create(mvosr_ctx *ctx, void **event);
 int mvosr_event_record(mvosr_ctx *ctx, void *event);          /* on the context's current stream */
 int mvosr_event_elapsed_ms(mvosr_ctx *ctx, void *start, void *stop, float *ms);  /* synchronises on `stop` */
 int mvosr_event_sync(mvosr_ctx *ctx, void *event);             /* host waits for the event (not for later work of the stream) */
+int mvosr_event_query(mvosr_ctx *ctx, void *event, int *done);  /* *done = 1 when the work recorded before the event has finished, else 0; never waits */
 int mvosr_event_destroy(mvosr_ctx *ctx, void *event);
 
 /* ---- host-side packing (no GPU work) ---------------------------------------------------------

@@ -113,6 +113,7 @@ SYMBOLS = {
     "mvosr_event_record": (C.c_int, [_P, _P]),
     "mvosr_event_elapsed_ms": (C.c_int, [_P, _P, _P, C.POINTER(C.c_float)]),
     "mvosr_event_sync": (C.c_int, [_P, _P]),
+    "mvosr_event_query": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
     "mvosr_event_destroy": (C.c_int, [_P, _P]),
     "mvosr_pack_count": (C.c_int, [C.c_int64, _P, _P, C.c_double, _P, C.c_int]),
     "mvosr_pack_fill": (C.c_int, [C.c_int64, _P, _P, _P, C.c_double, _P, _P, _P, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int, _P]),
@@ -447,6 +448,16 @@ class DeviceBlock:
             self._pf_event = ctx.event()
         ctx.record(self._pf_event)
         return self
+
+    def ready(self):
+        """True when a ``read`` would not wait: the block's host copy exists, or the download queued by ``prefetch`` has finished."""
+        if self._mirror is not None:
+            return True
+        if getattr(self, "_pf_stage", None) is None:
+            return False
+        done = C.c_int(0)
+        check(self.ctx.lib.mvosr_event_query(self.ctx.handle, self._pf_event, C.byref(done)), "event_query")
+        return bool(done.value)
 
     def invalidate(self):
         self._mirror = None

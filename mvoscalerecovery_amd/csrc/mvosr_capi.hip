@@ -673,6 +673,15 @@ int mvosr_event_sync(mvosr_ctx *ctx, void *event) {
     return MVOSR_OK;
 }
 
+int mvosr_event_query(mvosr_ctx *ctx, void *event, int *done) {
+    if (!ctx || !event || !done) return set_error(MVOSR_ERR_ARG, "event_query: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const hipError_t e = hipEventQuery(reinterpret_cast<hipEvent_t>(event));
+    if (e != hipSuccess && e != hipErrorNotReady) return set_error(MVOSR_ERR_HIP, "event_query: %s", hipGetErrorString(e));
+    *done = e == hipSuccess ? 1 : 0;
+    return MVOSR_OK;
+}
+
 int mvosr_event_destroy(mvosr_ctx *ctx, void *event) {
     if (!ctx) return set_error(MVOSR_ERR_ARG, "event_destroy: null context");
     if (!event) return MVOSR_OK;

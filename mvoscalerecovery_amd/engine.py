@@ -391,6 +391,10 @@ class DeviceOutputs:
     def get(self, name):
         return self.bufs[name].download()
 
+    def ready(self):
+        """True when ``get`` would not wait (the download queued by ``prefetch`` has finished)."""
+        return self.block is None or self.block.ready()
+
     def free(self):
         if self.block is not None:
             self.block.free()

@@ -361,6 +361,10 @@ class _DelaunayHandle:
         self.n, self._done, self._async, self._rows, self._out_off = n, done, async_result, rows, out_off
         self.canonical = bool(canonical)         # the rows come back in canonical form already (the workers did it)
 
+    def ready(self):
+        """True when ``get()`` would not wait."""
+        return self._done is not None or self._async.ready()
+
     def get(self):
         if self._done is None:
             out, f = [], 0
@@ -372,15 +376,18 @@ class _DelaunayHandle:
         return self._done
 
 
-def delaunay_submit(point_sets, workers=0, slot=0, fast=False, canonical=False):
+def delaunay_submit(point_sets, workers=0, slot=0, fast=False, canonical=False, background=False):
     """Start triangulating many point sets on the process pool and return at once (a handle with ``get()``): the host
     stage that bounds end-to-end throughput (SURVEY.md §7 hard part 1) runs while the caller packs, uploads and
     launches the GPU stages of other chunks.  ``slot`` names the pair of shared-memory segments the call uses — calls
     that are in flight at the same time need different slots.  ``fast``: the C replay of Qhull's run (:func:`qhull_rows_host`) where it
-    accepts a set, SciPy otherwise — the same rows (the default estimator's few-frames path; ``triangulation="scipy"`` never asks)."""
+    accepts a set, SciPy otherwise — the same rows (the default estimator's few-frames path; ``triangulation="scipy"`` never asks).
+    ``background``: a SINGLE set goes to the pool as well (when there is one) instead of being triangulated here — for callers that
+    have other work before they ask for the rows (a declined frame discovered in the middle of a batch call: 2.6 ms of SciPy off the
+    thread that packs and launches the following chunks)."""
     n = len(point_sets)
     workers = resolve_workers(workers)
-    if not (workers and workers > 1 and n > 1):
+    if not (workers and workers > 1 and (n > 1 or (background and n == 1))):
         return _DelaunayHandle(n, done=[_delaunay_job(p, fast, canonical) for p in point_sets], canonical=canonical)
     pool = _get_pool(int(workers))
     counts = np.array([len(p) for p in point_sets], dtype=np.int64)
@@ -554,6 +561,9 @@ class _Tri2Handle:
         self.todo, self.handle, self.n_frames = todo, handle, n_frames
         self.canonical = bool(getattr(handle, "canonical", False))
 
+    def ready(self):
+        return self.handle.ready()
+
     def get(self):
         tri2s = [np.zeros((0, 3), dtype=np.int32)] * self.n_frames
         for f, t in zip(self.todo, self.handle.get()):
@@ -578,7 +588,7 @@ def survivor_points(pf: PackedFrames, valid_masks):
     return pts
 
 
-def submit_tri2(pf: PackedFrames, valid_masks, workers=0, slot=1, fast=False):
+def submit_tri2(pf: PackedFrames, valid_masks, workers=0, slot=1, fast=False, background=False):
     """Start the second triangulation of every frame: SciPy over the features with ``valid_masks[f]`` (the vote result
     that came back from the GPU, in the PACKED order).  For frames that :func:`apply_locality_order` permuted, Delaunay
     still runs on the survivors in their original order — the reference's exact call.  Finish with :func:`attach_tri2`."""
@@ -595,7 +605,8 @@ def submit_tri2(pf: PackedFrames, valid_masks, workers=0, slot=1, fast=False):
         # <= 3 features below the vanishing row: the reference never makes the second call (:263-270)
         pts.append(np.stack([u[m], v[m]], axis=1) if len(m) > 3 else None)
     todo = [f for f, p in enumerate(pts) if p is not None]
-    return _Tri2Handle(todo, delaunay_submit([pts[f] for f in todo], workers, slot, fast, canonical=bool(pf.extra.get("canonical"))), pf.n_frames)
+    return _Tri2Handle(todo, delaunay_submit([pts[f] for f in todo], workers, slot, fast, canonical=bool(pf.extra.get("canonical")),
+                                             background=background), pf.n_frames)
 
 
 def attach_tri2(pf: PackedFrames, tri2s=None, valid_masks=None, workers=0, feature_ids=False):

@@ -445,6 +445,13 @@ class ScaleEstimator:
 
     def _chunk_vote(self, st, tri2s, k):
         """First triangulation in, vote on the GPU (:151-167), start of the second triangulation (:266)."""
+        self._chunk_vote_start(st, tri2s)
+        if tri2s is None:
+            self._chunk_vote_finish(st, 4 + k % 4)
+
+    def _chunk_vote_start(self, st, tri2s=None):
+        """The first half of ``_chunk_vote``: the first triangulation attached, the batch uploaded, the vote LAUNCHED and the download
+        of its counters queued behind it — nothing is waited for."""
         eng = st.get("eng") or self.engine
         ctx, pf = eng.ctx, st["pf"]
         packing.attach_tri1(pf, st["h1"], self.delaunay_workers)
@@ -458,22 +465,33 @@ class ScaleEstimator:
         if tri2s is None:
             vote_out = DeviceOutputs(ctx, st["dbatch"], counts=True, stage=True)
             eng.outlier_vote_batch(st["dbatch"], vote_out)
-            ctx.sync()
-            counters = vote_out.get("vote_counters")
-            st["masks"] = [counters[pf.frame_slice(f)] >= 0 for f in range(st["n"])]             # :166
-            if self.verbose:
-                for m in st["masks"]:
-                    print('feature rejected ', int(np.sum(~m)))
-                    print('feature left     ', int(np.sum(m)))
-            vote_out.free()
-            st["h2"] = packing.submit_tri2(pf, st["masks"], self.delaunay_workers, slot=4 + k % 4, fast=st.get("fast", False))
+            vote_out.prefetch()
+            st["vote_out"] = vote_out
         else:
             if any(p is not None for p in (pf.extra.get("perm") or [])):
                 raise ValueError("precomputed tri2s for dense (re-ordered) frames need the vote mask: pass tri1s only")
             st["h2"] = tri2s
 
+    def _chunk_vote_finish(self, st, slot, background=False):
+        """The second half: the vote's counters (waited for), the keep masks (:166), the start of the second triangulation (:266)."""
+        pf, vote_out = st["pf"], st.pop("vote_out")
+        counters = vote_out.get("vote_counters")
+        st["masks"] = [counters[pf.frame_slice(f)] >= 0 for f in range(st["n"])]             # :166
+        if self.verbose:
+            for m in st["masks"]:
+                print('feature rejected ', int(np.sum(~m)))
+                print('feature left     ', int(np.sum(m)))
+        vote_out.free()
+        st["h2"] = packing.submit_tri2(pf, st["masks"], self.delaunay_workers, slot=slot, fast=st.get("fast", False), background=background)
+
     def _chunk_scale(self, st, tri2s, stage, keep=False):
         """Second triangulation in, the fused GPU stages (:225-248, :324-354, :419), results to the host."""
+        self._chunk_scale_start(st, stage)
+        return self._chunk_scale_finish(st, stage, keep=keep)
+
+    def _chunk_scale_start(self, st, stage):
+        """The first half of ``_chunk_scale``: the second triangulation attached (waited for), its rows uploaded, the fused stages
+        LAUNCHED and the download of their results queued behind them."""
         eng = st.get("eng") or self.engine
         ctx, pf = eng.ctx, st["pf"]
         # dense frames: rows renumbered over the features, so that the kernel need not compact (less HBM traffic)
@@ -482,9 +500,15 @@ class ScaleEstimator:
         st["dbatch"].set_tri2(pf)
         out = DeviceOutputs(ctx, st["dbatch"], counts=True, stage=stage)
         eng.scale_batch(st["dbatch"], out)
+        out.prefetch()
+        st["out"] = out
+
+    def _chunk_scale_finish(self, st, stage, keep=False):
+        """The second half: the results (waited for), the exact levels around the batch's first error."""
+        eng = st.get("eng") or self.engine
+        pf, out = st["pf"], st["out"]
         host_errors = dict(pf.extra["tri2_errors"])                           # QhullError at :266
         host_errors.update(pf.extra["tri1_errors"])                           # ... or already at :257
-        ctx.sync()
         res = (out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts"))
         if not stage:
             res = (res[0], res[1], self._exact_after(eng, st["dbatch"], out, res[1], res[2], host_errors), res[3])
@@ -701,6 +725,8 @@ class ScaleEstimator:
         eng = st.get("engine") or self.engine
         pf = st["pf"]
         stage = st["stage"]
+        if defer:
+            self._advance_deferred(defer)        # (host work for earlier chunks' re-runs, before this chunk's results are waited for)
         if not st["gpu"]:
             sub = self._chunk_begin(f3s, f2s, 0, _remapped=st["remapped"])
             self._chunk_vote(sub, None, 0)
@@ -755,7 +781,7 @@ class ScaleEstimator:
                 f2 = np.asarray(f2s[f], dtype=np.float64)
                 pts.append(np.ascontiguousarray(f2[f2[:, 1] > self.vanish]) if f2.ndim == 2 and f2.size else np.zeros((0, 2)))   # :252-254
             handle = packing.delaunay_submit(pts, self.delaunay_workers, slot=8 + len(defer) % self.GPU_REDO_MAX_DEFERRED,
-                                             fast=self._host_replay, canonical=self.check_triangle == "fixed")
+                                             fast=self._host_replay, canonical=self.check_triangle == "fixed", background=True)
         pend = {"st": st, "redo": redo, "s12": (s1, s2), "f3s": f3s, "f2s": f2s, "res": res, "keep": keep, "h1": handle}
         if handle is not None:
             defer.append(pend)
@@ -766,28 +792,86 @@ class ScaleEstimator:
         self._chunk_gpu_complete(pend)
         return res
 
+    GPU_REDO_EARLY = True           # a deferred re-run's vote and second triangulation START while later chunks run (_advance_deferred) ...
+    GPU_REDO_EARLY_MAX = 16         # ... for chunks with at most so many frames to redo (more: the one merged re-run at the call's end)
+
+    def _advance_deferred(self, pending):
+        """Deferred re-runs, one step further where that step does not WAIT (round 6, LABNOTES 10.11).  A chunk's few declined frames
+        (and, in the reference-exact mode, the few frames of its exact pass) need first triangulation -> vote -> second triangulation ->
+        product kernels, a chain of two host triangulations and two device round trips: at the call's end that chain is 4-8 ms during
+        which nothing else runs — a fifth of a 34 ms call for ONE declined frame.  Here, whenever the call collects a chunk: a record
+        whose first triangulations are back gets its batch uploaded and its vote launched (on the re-runs' own context, download of
+        the counters queued behind it); a record whose counters have arrived gets its second triangulations started on the worker pool.
+        ``_chunk_gpu_complete_all`` then finds only the product kernels left to do for every chunk but the call's last."""
+        if not self.GPU_REDO_EARLY:
+            return
+        for idx, p in enumerate(pending):
+            state = p.get("early", 0)
+            if state == 0 and 0 < len(p["redo"]) <= self.GPU_REDO_EARLY_MAX and p["h1"].ready():
+                rows = p["h1"].get()
+                remapped = p["st"]["remapped"]
+                sub = self._chunk_begin([p["f3s"][f] for f in p["redo"]], [p["f2s"][f] for f in p["redo"]], 0, tri1s=rows, _remapped=remapped,
+                                        _exact_all=True, _fast=self._host_replay,
+                                        _eng=self._redo_engine(remapped) if self.GPU_REDO_CONTEXT else None)
+                sub["pf"].extra["tri1_is_canonical"] = self.check_triangle == "fixed"   # (the workers brought the rows to canonical form)
+                self._chunk_vote_start(sub)
+                p["sub"], p["early"] = sub, 1
+                self.redo_early_started = getattr(self, "redo_early_started", 0) + 1
+            elif state == 1 and p["sub"]["vote_out"].ready():
+                # (slots 16..: a pair of shared-memory segments per record in flight)
+                self._chunk_vote_finish(p["sub"], 16 + idx % self.GPU_REDO_MAX_DEFERRED, background=True)
+                p["early"] = 2
+            elif state == 2 and p["sub"]["h2"].ready():
+                self._chunk_scale_start(p["sub"], False)
+                p["early"] = 3
+                self.redo_early_launched = getattr(self, "redo_early_launched", 0) + 1     # (only its results are left for the call's end)
+
     def _chunk_gpu_complete_all(self, pending):
-        """The declined frames of several chunks in ONE re-run through the host path (their first triangulations were started by
-        ``_chunk_gpu_finish``), results scattered back; then every chunk's own completion."""
+        """The declined frames of several chunks through the host path (their first triangulations were started by
+        ``_chunk_gpu_finish``), results scattered back; then every chunk's own completion.  Chunks whose re-run ``_advance_deferred``
+        has started finish it here, each as its own small batch; the others' frames go through ONE merged re-run."""
         if not pending:
             return
-        f3_all, f2_all, tri1_all, where = [], [], [], []
-        for k, p in enumerate(pending):
-            rows = p["h1"].get()
-            for j, f in enumerate(p["redo"]):
-                f3_all.append(p["f3s"][f]); f2_all.append(p["f2s"][f]); tri1_all.append(rows[j]); where.append((k, int(f)))
-        remapped = pending[0]["st"]["remapped"]
-        sub = self._chunk_begin(f3_all, f2_all, 0, tri1s=tri1_all, _remapped=remapped, _exact_all=True, _fast=self._host_replay,
-                                _eng=self._redo_engine(remapped) if self.GPU_REDO_CONTEXT else None)
-        sub["pf"].extra["tri1_is_canonical"] = self.check_triangle == "fixed"       # (the workers brought the rows to canonical form)
-        self._chunk_vote(sub, None, 0)
-        r_raw, r_status, r_level, r_counts, r_err = self._chunk_scale(sub, None, False)
+        self._advance_deferred(pending)
         errs = [dict() for _ in pending]
-        for i, (k, f) in enumerate(where):
-            res = pending[k]["res"]
-            res[0][f], res[1][f], res[2][f], res[3][f] = r_raw[i], r_status[i], r_level[i], r_counts[i]
-            if i in r_err:
-                errs[k][f] = r_err[i]
+        for k, p in enumerate(pending):        # (every started re-run's remaining launches first, then their results)
+            if p.get("early") == 1:
+                self._chunk_vote_finish(p["sub"], 16 + k % self.GPU_REDO_MAX_DEFERRED)
+                p["early"] = 2
+        for k, p in enumerate(pending):
+            if p.get("early") == 2:
+                self._chunk_scale_start(p["sub"], False)
+                p["early"] = 3
+        for k, p in enumerate(pending):
+            if not p.get("early"):
+                continue
+            sub = p["sub"]
+            r_raw, r_status, r_level, r_counts, r_err = self._chunk_scale_finish(sub, False)
+            res = p["res"]
+            for i, f in enumerate(p["redo"]):
+                res[0][f], res[1][f], res[2][f], res[3][f] = r_raw[i], r_status[i], r_level[i], r_counts[i]
+                if i in r_err:
+                    errs[k][int(f)] = r_err[i]
+            p["sub"] = None
+        rest = [k for k, p in enumerate(pending) if not p.get("early")]
+        if rest:
+            f3_all, f2_all, tri1_all, where = [], [], [], []
+            for k in rest:
+                p = pending[k]
+                rows = p["h1"].get()
+                for j, f in enumerate(p["redo"]):
+                    f3_all.append(p["f3s"][f]); f2_all.append(p["f2s"][f]); tri1_all.append(rows[j]); where.append((k, int(f)))
+            remapped = pending[rest[0]]["st"]["remapped"]
+            sub = self._chunk_begin(f3_all, f2_all, 0, tri1s=tri1_all, _remapped=remapped, _exact_all=True, _fast=self._host_replay,
+                                    _eng=self._redo_engine(remapped) if self.GPU_REDO_CONTEXT else None)
+            sub["pf"].extra["tri1_is_canonical"] = self.check_triangle == "fixed"       # (the workers brought the rows to canonical form)
+            self._chunk_vote(sub, None, 0)
+            r_raw, r_status, r_level, r_counts, r_err = self._chunk_scale(sub, None, False)
+            for i, (k, f) in enumerate(where):
+                res = pending[k]["res"]
+                res[0][f], res[1][f], res[2][f], res[3][f] = r_raw[i], r_status[i], r_level[i], r_counts[i]
+                if i in r_err:
+                    errs[k][f] = r_err[i]
         for k, p in enumerate(pending):
             p["res"][4] = errs[k]
             p["merged"] = True

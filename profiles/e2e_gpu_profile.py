@@ -22,6 +22,10 @@ if SNAP > 0:
     import numpy as np
     pool = [(a, np.ascontiguousarray(np.round(b * 4) / 4)) if ((i * 2654435761) % (1 << 32)) / float(1 << 32) < SNAP else (a, b) for i, (a, b) in enumerate(pool)]
 f3, f2 = [pool[i % P][0] for i in range(F)], [pool[i % P][1] for i in range(F)]
+if os.environ.get("SNAP_ONE"):        # ONE frame of the call (that index) snapped to 1/4 px: what a single declined frame costs (LABNOTES 10.11)
+    import numpy as np
+    for i_ in os.environ["SNAP_ONE"].split(","):
+        f2[int(i_)] = np.ascontiguousarray(np.round(f2[int(i_)] * 4) / 4)
 if WHICH == "rescale":
     from mvoscalerecovery_amd.rescale import ScaleEstimator as RescaleEstimator
     est = RescaleEstimator(1.75, window_size=5, triangulation="gpu", delaunay_workers=0, ransac_seed=2024)

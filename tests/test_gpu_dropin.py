@@ -941,3 +941,35 @@ def test_host_replay_in_the_delaunay_workers(gpu):
     rows = packing.delaunay_submit([f[1][f[1][:, 1] > 185] for f in frames], 3, slot=3, fast=True).get()
     for f, r in zip(frames, rows):
         assert np.array_equal(r, packing.delaunay_simplices(f[1][f[1][:, 1] > 185]))
+
+
+@pytest.mark.parametrize("mode", ["fixed", "reference"])
+def test_deferred_reruns_started_early_equal_the_merged_rerun(gpu, mode):
+    """Round 6: a chunk's declined frames (and, with the reference's vote, the frames of its exact pass) have their re-run STARTED
+    while later chunks run — first triangulations back -> vote launched -> counters back -> second triangulations on the pool -> product
+    kernels launched (``_advance_deferred``) — instead of one merged re-run at the call's end.  Same numbers either way, equal to the
+    oracle's frame-by-frame run; the early route is really taken; a declined frame in the call's LAST chunk goes the merged way."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    so = _oracle()
+    F, chunk = 1500, 128
+    frames = [synth.synth_frame(i, 220 + (i * 37) % 160, base_seed=4242, upper_fraction=0.1) for i in range(F)]
+    declined = [3, 130, 131, 700, 1100, F - 2]
+    for f in declined:                                # quarter-pixel grid and a repeated pixel: both device triangulations decline
+        a3, a2 = frames[f][0].copy(), np.ascontiguousarray(np.round(frames[f][1] * 4) / 4)
+        a2[5], a3[5] = a2[60], a3[60]
+        frames[f] = (a3, a2)
+    f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
+    ref = so.OracleScaleEstimator(1.75, window_size=5, check_triangle=mode)
+    want = [ref.scale_calculation(a.copy(), b.copy()) for a, b in frames]
+    outs = {}
+    for early in (True, False):
+        est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle=mode, delaunay_workers=3 if early else 0)
+        est.GPU_REDO_EARLY = early
+        est.GPU_CHUNK, est.GPU_RAMP, est.GPU_MIN_CHUNK, est.GPU_EXACT_CHUNK, est.GPU_EXACT_TWO_CONTEXTS = chunk, False, 1, chunk, False
+        got = est.scale_calculation_batch(f3s, f2s)
+        assert [w[0] for w in want] == list(got[0]) and [w[1] for w in want] == list(got[1]), (mode, early)
+        assert est.declined_total >= len(declined) - 1, est.declined_total
+        outs[early] = (got, est.height_level, getattr(est, "redo_early_started", 0), getattr(est, "redo_early_launched", 0))
+    assert outs[True][1] == outs[False][1] == ref.height_level
+    assert outs[True][2] >= 3 and outs[True][3] >= 1 and outs[False][2] == 0, outs[True][2:]
