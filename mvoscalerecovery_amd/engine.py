@@ -187,7 +187,29 @@ class DeviceBatch:
             self.set_tri2(pf)
         self._struct = None
 
-    def triangulate(self, engine, standin=False, tri1_rows=None):
+    def _queue_early_status(self):
+        """The first triangulation's status words on their way to the host right behind that kernel — before the vote, the second
+        triangulation and the product kernels of the chunk are even launched (``early_status`` waits for this copy alone)."""
+        ctx, F = self.ctx, max(self.n_frames, 1)
+        self._early_stage = _lib.PinnedBuffer(ctx, 4 * F)
+        _lib.check(ctx.lib.mvosr_memcpy_d2h_async(ctx.handle, self._early_stage.ptr, self.bufs["dt1_status"].ptr, 4 * F), "d2h_async (early status)")
+        self._early_event = ctx.event()
+        ctx.record(self._early_event)
+
+    def early_status(self):
+        """Host copy of the first triangulation's status (non-zero: declined) as soon as THAT kernel has finished; None when not asked for."""
+        stage = getattr(self, "_early_stage", None)
+        if stage is None:
+            return None
+        ctx = self.ctx
+        _lib.check(ctx.lib.mvosr_event_sync(ctx.handle, self._early_event), "event_sync")
+        s = np.array(stage.view(0, (max(self.n_frames, 1),), np.int32), copy=True)[:self.n_frames]
+        stage.free(_lib.MARK_IDLE)
+        ctx.lib.mvosr_event_destroy(ctx.handle, self._early_event)
+        self._early_stage, self._early_event = None, None
+        return s
+
+    def triangulate(self, engine, standin=False, tri1_rows=None, early_status=False):
         """Delaunay #1 -> depth-order vote -> Delaunay #2 over the survivors (/root/reference/src/scale_calculator.py:
         257-267), three launches on the context's stream; rows, counters and counts stay in HBM.  ``standin`` (reference vote
         only; HOT launches without stage outputs, frames that fit the LDS-resident kernels): the second triangulation by the fast
@@ -218,6 +240,8 @@ class DeviceBatch:
                 _lib.check(lib.mvosr_delaunay_qhull_batch(ctx.handle, self.n_frames, b["feat_off"].ptr, b["feat_cnt"].ptr, b["u"].ptr, b["v"].ptr,
                                                           None, int(self.max_feat), b["tri_off"].ptr, b["tri1"].ptr, b["tri1_cnt"].ptr, None,
                                                           b["dt1_status"].ptr, None), "mvosr_delaunay_qhull_batch (first triangulation)")
+                if early_status:
+                    self._queue_early_status()
             o = _lib.Outputs()
             o.vote_counters = b["vote_counters"].ptr
             bs = self.struct()
@@ -242,6 +266,8 @@ class DeviceBatch:
                                                None, int(self.max_feat), b["tri_off"].ptr, b["tri1"].ptr, b["tri1_cnt"].ptr, None,
                                                b["dt1_status"].ptr, None, None, None, None, b["dt_info"].ptr),
                    "mvosr_delaunay_batch_ex (first triangulation)")
+        if early_status:
+            self._queue_early_status()
         o = _lib.Outputs()
         o.vote_counters = b["vote_counters"].ptr
         bs = self.struct()
@@ -326,6 +352,10 @@ class DeviceBatch:
         self.bufs["exact_mask"].upload(np.ascontiguousarray(mask, dtype=np.uint8))
 
     def free(self):
+        if getattr(self, "_early_stage", None) is not None:       # (an early status nobody read)
+            self._early_stage.free()
+            self.ctx.lib.mvosr_event_destroy(self.ctx.handle, self._early_event)
+            self._early_stage, self._early_event = None, None
         for b in self.blocks:
             b.free()
         self.blocks = []

@@ -376,6 +376,24 @@ class _DelaunayHandle:
         return self._done
 
 
+class _JoinedHandle:
+    """Several handles as one: ``parts`` = [(positions, handle)], the positions of a part's sets in the joined list."""
+
+    def __init__(self, n, parts):
+        self.n, self.parts = n, parts
+        self.canonical = all(getattr(h, "canonical", False) for _, h in parts) if parts else False
+
+    def ready(self):
+        return all(h.ready() for _, h in self.parts)
+
+    def get(self):
+        out = [None] * self.n
+        for pos, h in self.parts:
+            for i, r in zip(pos, h.get()):
+                out[int(i)] = r
+        return out
+
+
 def delaunay_submit(point_sets, workers=0, slot=0, fast=False, canonical=False, background=False):
     """Start triangulating many point sets on the process pool and return at once (a handle with ``get()``): the host
     stage that bounds end-to-end throughput (SURVEY.md §7 hard part 1) runs while the caller packs, uploads and

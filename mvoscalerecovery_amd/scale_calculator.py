@@ -613,6 +613,11 @@ class ScaleEstimator:
     GPU_EXACT_CHUNK = 16384     # check_triangle="reference" (the Qhull-rows kernel): frames per chunk, at most ...
     GPU_EXACT_CHUNK_POINTS = 33000000   # ... and features per chunk (~0.75 KB each on the device: 25 GB at the cap)
 
+    def _lower_points(self, f2):
+        """A frame's pixels below the vanishing row (:252-254), contiguous — what the first Delaunay call sees."""
+        f2 = np.asarray(f2, dtype=np.float64)
+        return np.ascontiguousarray(f2[f2[:, 1] > self.vanish]) if f2.ndim == 2 and f2.size else np.zeros((0, 2))
+
     def _second_engine(self):
         """A second context on the same device (its own compute and upload streams, workspace and caches) with the same parameters."""
         if getattr(self, "_engine2", None) is None:
@@ -636,7 +641,8 @@ class ScaleEstimator:
                                                   camera_pitch=0.0 if remapped else self.camera_pitch, check_triangle=self.check_triangle)
         return self._redo_engines[key]
 
-    def _chunk_gpu(self, f3s, f2s, stage, tables=False, eng=None, single_exact=False, hot_only=False, lazy_last=False, host_exact=False):
+    def _chunk_gpu(self, f3s, f2s, stage, tables=False, eng=None, single_exact=False, hot_only=False, lazy_last=False, host_exact=False,
+                   early_status=False):
         """One chunk with both triangulations built on the device: pack (C packer, straight into page-locked memory) ->
         ONE upload -> Delaunay #1, vote, Delaunay #2, scale kernel, road model, the exact re-runs known in advance and
         the download of the results, all queued; nothing is waited for here (``_chunk_gpu_finish`` does)."""
@@ -685,7 +691,8 @@ class ScaleEstimator:
         st["tri1_rows"] = tri1_rows
         db = DeviceBatch(ctx, pf, with_tri2=False, device_triangulation=True, uploaded=blk, lazy_last=lazy_last)
         try:
-            db.triangulate(eng, standin=self.GPU_EXACT_STANDIN and (single_exact or not stage), tri1_rows=tri1_rows)
+            db.triangulate(eng, standin=self.GPU_EXACT_STANDIN and (single_exact or not stage), tri1_rows=tri1_rows,
+                           early_status=early_status and tri1_rows is None)
         except _lib.MvosrAllocError:
             # the triangulation kernels' workspace (frames x largest frame) did not fit next to whatever else lives on the
             # device: nothing was launched — this chunk takes the host's triangulations (MVOSR_ERR_ALLOC)
@@ -736,6 +743,16 @@ class ScaleEstimator:
                 self._chunk_free(st)
             return list(res)
         db, out = st["dbatch"], st["out"]
+        early = None
+        if defer is not None and not stage:
+            # (the call's last chunk: whatever its first triangulation declined is known behind THAT kernel — the frames' SciPy calls
+            # start now, under the chunk's vote, second triangulation and product kernels, instead of after them)
+            s1e = db.early_status()
+            if s1e is not None and s1e.any():
+                ef = np.nonzero(s1e != 0)[0]
+                early = (ef, packing.delaunay_submit([self._lower_points(f2s[f]) for f in ef], self.delaunay_workers, slot=24,
+                                                     fast=self._host_replay, canonical=self.check_triangle == "fixed", background=True))
+                self.redo_early_status_hits = getattr(self, "redo_early_status_hits", 0) + 1
         s1, s2 = db.triangulation_status()
         redo = np.nonzero((s1 != 0) | (s2 != 0))[0]
         res = [out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts"), {}]
@@ -776,19 +793,25 @@ class ScaleEstimator:
             # long for a slot: round 5 ran the re-run in each chunk's epilogue on the chunk's own stream (72 declined frames in
             # 16 384: 53 k -> 30 k frames/s); on its own context but still between the chunks 80 declined frames cost 96 -> 66 k
             # (and 529 -> 93 k in the fixed mode, whose chunks are short).
-            pts = []
-            for f in redo:
-                f2 = np.asarray(f2s[f], dtype=np.float64)
-                pts.append(np.ascontiguousarray(f2[f2[:, 1] > self.vanish]) if f2.ndim == 2 and f2.size else np.zeros((0, 2)))   # :252-254
-            handle = packing.delaunay_submit(pts, self.delaunay_workers, slot=8 + len(defer) % self.GPU_REDO_MAX_DEFERRED,
+            have = set(int(f) for f in early[0]) if early is not None else set()
+            rest = [k for k, f in enumerate(redo) if int(f) not in have]
+            handle = packing.delaunay_submit([self._lower_points(f2s[redo[k]]) for k in rest], self.delaunay_workers,
+                                             slot=8 + len(defer) % self.GPU_REDO_MAX_DEFERRED,
                                              fast=self._host_replay, canonical=self.check_triangle == "fixed", background=True)
+            if early is not None:
+                where = {int(f): k for k, f in enumerate(redo)}
+                handle = packing._JoinedHandle(len(redo), [([where[int(f)] for f in early[0]], early[1]), (rest, handle)])
         pend = {"st": st, "redo": redo, "s12": (s1, s2), "f3s": f3s, "f2s": f2s, "res": res, "keep": keep, "h1": handle}
         if handle is not None:
             defer.append(pend)
             if len(defer) >= self.GPU_REDO_MAX_DEFERRED:       # (bounded: a deferred chunk keeps its device blocks and a pool slot)
                 self._chunk_gpu_complete_all(defer)
                 del defer[:]
+            else:
+                self._advance_deferred(defer)                  # (this chunk's results were waited for: earlier records may have moved on)
             return res
+        if defer:
+            self._advance_deferred(defer)
         self._chunk_gpu_complete(pend)
         return res
 
@@ -1028,7 +1051,8 @@ class ScaleEstimator:
             bounds.append((a, b))
             queue.append((self._chunk_gpu(feature3ds[a:b], feature2ds[a:b], stage, tables=tb, eng=engines[k % len(engines)],
                                           lazy_last=lazy_last and not (eager_final and b == F),
-                                          host_exact=exact and not stage and self.GPU_EXACT_HOST_REDO and self.GPU_EXACT_STANDIN), a, b))
+                                          host_exact=exact and not stage and self.GPU_EXACT_HOST_REDO and self.GPU_EXACT_STANDIN,
+                                          early_status=self.GPU_REDO_EARLY and deferred is not None and b == F and k > 0), a, b))
             # GPU_PIPELINE chunks stay queued behind the one whose results are collected: this process packs and uploads
             # the next chunk meanwhile (the kernel timeline shows the GPU 98 % busy between a call's first and last chunk
             # with one: what a call pays beyond its kernels is its first chunk's pack + upload and the host's epilogue)

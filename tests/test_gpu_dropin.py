@@ -948,7 +948,8 @@ def test_deferred_reruns_started_early_equal_the_merged_rerun(gpu, mode):
     """Round 6: a chunk's declined frames (and, with the reference's vote, the frames of its exact pass) have their re-run STARTED
     while later chunks run — first triangulations back -> vote launched -> counters back -> second triangulations on the pool -> product
     kernels launched (``_advance_deferred``) — instead of one merged re-run at the call's end.  Same numbers either way, equal to the
-    oracle's frame-by-frame run; the early route is really taken; a declined frame in the call's LAST chunk goes the merged way."""
+    oracle's frame-by-frame run; the early route is really taken; a declined frame in the call's LAST chunk is found by the early read of
+    the first triangulation's status."""
     from mvoscalerecovery_amd import synth
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
     so = _oracle()
@@ -970,6 +971,9 @@ def test_deferred_reruns_started_early_equal_the_merged_rerun(gpu, mode):
         got = est.scale_calculation_batch(f3s, f2s)
         assert [w[0] for w in want] == list(got[0]) and [w[1] for w in want] == list(got[1]), (mode, early)
         assert est.declined_total >= len(declined) - 1, est.declined_total
-        outs[early] = (got, est.height_level, getattr(est, "redo_early_started", 0), getattr(est, "redo_early_launched", 0))
+        outs[early] = (got, est.height_level, getattr(est, "redo_early_started", 0), getattr(est, "redo_early_launched", 0),
+                       getattr(est, "redo_early_status_hits", 0))
     assert outs[True][1] == outs[False][1] == ref.height_level
     assert outs[True][2] >= 3 and outs[True][3] >= 1 and outs[False][2] == 0, outs[True][2:]
+    # the LAST chunk's declined frame: found behind the first triangulation's kernel, its SciPy call under the chunk's other kernels
+    assert outs[True][4] == 1 and outs[False][4] == 0, (outs[True][4], outs[False][4])

@@ -624,3 +624,21 @@ def test_delaunay_submit_fast_and_canonical_inline():
     plain = packing.delaunay_submit(sets[:5], 0, fast=True).get()
     for p, r in zip(sets[:5], plain):
         assert np.array_equal(r, packing.delaunay_simplices(p))
+
+
+def test_delaunay_submit_background_single_set():
+    """packing.delaunay_submit(background=True): ONE set goes to the worker pool too (a declined frame found in the middle of a batch call:
+    its SciPy call off the thread that launches the next chunks); the handle says when get() would not wait; same rows as the inline call."""
+    import time
+    from mvoscalerecovery_amd import packing, synth
+    pts = synth.synth_frame(3, 500, base_seed=12)[1]
+    inline = packing.delaunay_submit([pts], 2)
+    assert inline.ready() and inline._async is None                       # (a single set without the flag: triangulated in the call)
+    h = packing.delaunay_submit([pts], 2, slot=9, background=True)
+    assert h._async is not None
+    t0 = time.time()
+    while not h.ready() and time.time() - t0 < 30:
+        time.sleep(0.005)
+    assert h.ready()
+    assert np.array_equal(h.get()[0], inline.get()[0]) and np.array_equal(h.get()[0], packing.delaunay_simplices(pts))
+    assert packing.delaunay_submit([pts], 0, background=True).ready()      # (no pool: inline whatever the flag)
