@@ -549,13 +549,13 @@ def _pack_tris(tris):
     return off, flat
 
 
-def submit_tri1(pf: PackedFrames, workers=0, slot=0, fast=False):
+def submit_tri1(pf: PackedFrames, workers=0, slot=0, fast=False, background=False):
     """Start the first triangulation of every frame (SciPy on the packed (u,v)); finish with :func:`attach_tri1`."""
     pts = []
     for f in range(pf.n_frames):
         s = pf.frame_slice(f)
         pts.append(np.stack([pf.u[s], pf.v[s]], axis=1))
-    return delaunay_submit(pts, workers, slot, fast, canonical=bool(pf.extra.get("canonical")))
+    return delaunay_submit(pts, workers, slot, fast, canonical=bool(pf.extra.get("canonical")), background=background)
 
 
 def attach_tri1(pf: PackedFrames, tri1s=None, workers=0):

@@ -334,9 +334,9 @@ class ScaleEstimator:
         return _lib.RescaleParams(self._good_bits, MIN_VALID_FOR_RETRI, -80.0, -85.0, 0.9, RANSAC_MIN_POINTS, self.N_HYP,
                                   RANSAC_THRESHOLD, RANSAC_GOAL, float(self.absolute_reference), self._seed, int(frame_base))
 
-    def _launch_flat_ransac(self, db, keep_ptr, dt2_ptr, frame_base, frame_ids, id_triples, stage, max_tri):
+    def _launch_flat_ransac(self, db, keep_ptr, dt2_ptr, frame_base, frame_ids, id_triples, stage, max_tri, ctx=None):
         """mvosr_flat_ransac_batch over a DeviceBatch; returns the outputs' block (download queued)."""
-        ctx, F, H = self.ctx, db.n_frames, self.N_HYP
+        ctx, F, H = ctx or self.ctx, db.n_frames, self.N_HYP
         spec = [("raw_scale", F, np.float64), ("height_level", F, np.float64), ("model", (F, 4), np.float64),
                 ("best_ic", F, np.int32), ("used", F, np.int32), ("n_kept", F, np.int32), ("status", F, np.int32)]
         out = ctx.block(spec)
@@ -369,7 +369,7 @@ class ScaleEstimator:
             blk.mark(True)
         return out, flags, side
 
-    def _chunk_dev_gpu(self, f3s, f2s, frame_base, id_triples, stage, tables=False):
+    def _chunk_dev_gpu(self, f3s, f2s, frame_base, id_triples, stage, tables=False, early_status=False):
         """One chunk, both triangulations on the device: pack (C packer into page-locked memory) -> ONE upload -> every
         launch and the download of the results queued; nothing is waited for here."""
         ctx, lib = self.ctx, self.ctx.lib
@@ -397,6 +397,8 @@ class ScaleEstimator:
                                                    bufs["v"].ptr, None, int(db.max_feat), bufs["tri_off"].ptr, bufs["tri1"].ptr,
                                                    bufs["tri1_cnt"].ptr, None, bufs["dt1_status"].ptr, None, None, None, None,
                                                    bufs["dt_info"].ptr), "mvosr_delaunay_batch_ex (first triangulation)")
+            if early_status:                       # (the call's last chunk: what this kernel declined, known right behind it — _chunk_dev_finish)
+                db._queue_early_status()
             bs = db.struct()
             keep = bufs["vote_counters"]                                        # (the block's per-feature int32 plane: here the keep flags)
             _lib.check(lib.mvosr_graph_keep_batch(ctx.handle, C.byref(bs), C.c_uint32(self._good_bits), MIN_VALID_FOR_RETRI,
@@ -462,30 +464,68 @@ class ScaleEstimator:
 
     def _chunk_dev_host(self, f3s, f2s, frame_base, frame_ids, id_triples, stage):
         """The same kernels on the host's triangulations (SciPy's rows in canonical form): triangulation="scipy" with
-        sampling="device", and the frames the device triangulation declined.  Synchronous."""
-        ctx, lib = self.ctx, self.ctx.lib
+        sampling="device", and the frames the device triangulation declined.  Synchronous: the four steps below, one after the other."""
+        rec = self._host_begin(f3s, f2s, frame_base)
+        self._host_keep_start(rec)
+        self._host_tri2_start(rec)
+        self._host_flat_start(rec, frame_base, frame_ids, id_triples, stage)
+        return self._host_collect(rec, stage)
+
+    # The host path in steps none of which waits for more than its own inputs (round 6: a deferred re-run advances through them while
+    # the call's later chunks run, _advance_deferred): packed + first triangulations started -> (those back) uploaded, the vote
+    # launched, its keep words on their way -> (those back) second triangulations started -> (those back) uploaded, flat_selection +
+    # RANSAC launched, results on their way -> collected.
+    def _host_begin(self, f3s, f2s, frame_base, slot=0, background=False, ctx=None):
         pf = packing.pack_features(f3s, f2s, self.vanish)                                   # rescale.py:115-117
         if pf.n_frames and pf.max_feat > self._max_points():
             self._refuse_oversized(pf, frame_base if np.isscalar(frame_base) else self._frame_counter)
         pf.extra["canonical"] = True
-        packing.attach_tri1(pf, None, self.delaunay_workers)                                # :124
+        return {"pf": pf, "h1": packing.submit_tri1(pf, self.delaunay_workers, slot=slot, background=background), "step": 0,   # :124
+                "ctx": ctx or self.ctx}
+
+    def _redo_context(self):
+        """A second context on the device (its own stream, workspace, caches) for the re-runs that advance while later chunks run: on the
+        estimator's own stream their few launches would sit BEHIND the chunks already queued — two chunks, 8 ms each — at every step."""
+        if getattr(self, "_redo_ctx", None) is None:
+            self._redo_ctx = _lib.Context(self.ctx.device)
+        return self._redo_ctx
+
+    def _host_keep_start(self, rec):
+        ctx, lib, pf = rec["ctx"], self.ctx.lib, rec["pf"]
+        packing.attach_tri1(pf, rec.pop("h1"), self.delaunay_workers)
         db = DeviceBatch(ctx, pf, with_tri2=False)
-        F = pf.n_frames
         aux = ctx.block([("keep", max(pf.total_padded, 1), np.int32)])
         bs = db.struct()
         _lib.check(lib.mvosr_graph_keep_batch(ctx.handle, C.byref(bs), C.c_uint32(self._good_bits), MIN_VALID_FOR_RETRI, None,
                                               aux["keep"].ptr, None, None), "mvosr_graph_keep_batch")
-        keep = aux["keep"].download()
-        masks = [keep[pf.frame_slice(f)] >= 0 for f in range(F)]
-        packing.attach_tri2(pf, None, masks, self.delaunay_workers)                         # :134-137
+        aux.prefetch()
+        rec.update(db=db, aux=aux, step=1)
+
+    def _host_tri2_start(self, rec, slot=1, background=False):
+        pf = rec["pf"]
+        keep = rec["aux"]["keep"].download()
+        rec["keep"] = keep
+        rec["masks"] = [keep[pf.frame_slice(f)] >= 0 for f in range(pf.n_frames)]
+        rec["h2"] = packing.submit_tri2(pf, rec["masks"], self.delaunay_workers, slot=slot, background=background)   # :134-137
+        rec["step"] = 2
+
+    def _host_flat_start(self, rec, frame_base, frame_ids, id_triples, stage):
+        pf, db = rec["pf"], rec["db"]
+        packing.attach_tri2(pf, rec.pop("h2"), rec["masks"], self.delaunay_workers)
         db.set_tri2(pf)
         db.n_rows2 = int(pf.tri2_off[-1])
-        max_tri = int(np.max(np.diff(pf.tri2_off))) if F else 0
-        out, flags, side = self._launch_flat_ransac(db, aux["keep"].ptr, None, frame_base, frame_ids, id_triples, stage, max(max_tri, 1))
+        max_tri = int(np.max(np.diff(pf.tri2_off))) if pf.n_frames else 0
+        rec["out"], rec["flags"], side = self._launch_flat_ransac(db, rec["aux"]["keep"].ptr, None, frame_base, frame_ids, id_triples, stage,
+                                                                  max(max_tri, 1), ctx=rec["ctx"])
+        rec["side"] = side + [rec["aux"]]
+        rec["step"] = 3
+
+    def _host_collect(self, rec, stage):
+        pf = rec["pf"]
         host_errors = dict(pf.extra["tri2_errors"])
         host_errors.update(pf.extra["tri1_errors"])
-        res = self._collect(out, F)
-        st = {"pf": pf, "db": db, "out": out, "flags": flags, "side": side + [aux], "host_errors": host_errors, "keep": keep}
+        res = self._collect(rec["out"], pf.n_frames)
+        st = {"pf": pf, "db": rec["db"], "out": rec["out"], "flags": rec["flags"], "side": rec["side"], "host_errors": host_errors, "keep": rec["keep"]}
         if stage:
             res["stage"] = self._stage_outputs(st, host=True)
         self._free_chunk(st)
@@ -533,6 +573,21 @@ class ScaleEstimator:
         if not st["gpu"]:
             return self._chunk_dev_host(f3s, f2s, frame_base, None, id_triples, stage)
         db = st["db"]
+        early = None
+        if defer is not None and not stage and self.GPU_REDO_EARLY:
+            # the call's LAST chunk: the frames its first triangulation declined are known behind that kernel.  This thread has nothing
+            # else to do: it takes them through their first triangulation (waited for — the chunk's other kernels are running), the
+            # vote (on the re-runs' context) and the start of their second triangulation now; the call's end launches the rest
+            s1e = db.early_status()
+            if s1e is not None and s1e.any() and int(np.count_nonzero(s1e)) <= self.GPU_REDO_EARLY_MAX:
+                ef = np.nonzero(s1e != 0)[0]
+                rec = self._host_begin([f3s[f] for f in ef], [f2s[f] for f in ef], 0, slot=24, background=True, ctx=self._redo_context())
+                rec["ids"] = frame_base + ef
+                rec["triples"] = None if id_triples is None else [id_triples[f] for f in ef]
+                self._host_keep_start(rec)
+                self._host_tri2_start(rec, slot=25, background=True)
+                early = (ef, rec)
+                self.redo_early_status_hits = getattr(self, "redo_early_status_hits", 0) + 1
         res = self._collect(st["out"], F)
         s1, s2 = db.triangulation_status()
         redo = np.nonzero((s1 != 0) | (s2 != 0))[0]
@@ -541,9 +596,25 @@ class ScaleEstimator:
             res["stage"] = self._stage_outputs(st)
         self._free_chunk(st)
         res["host_errors"] = {}
+        if early is not None:
+            if defer is not None and len(redo) == len(early[0]) and np.array_equal(redo, early[0]):
+                defer.append((res, redo, frame_base, f3s, f2s, id_triples, early[1]))      # (continues where the early steps left it)
+                return res
+            self._free_chunk({"db": early[1].get("db"), "side": [early[1]["aux"]]})         # (more frames than the early read knew of: the merged way)
         if len(redo) and defer is not None:
-            defer.append((res, redo, frame_base, f3s, f2s, id_triples))
+            rec = None
+            if self.GPU_REDO_EARLY and not stage and len(redo) <= self.GPU_REDO_EARLY_MAX and len(defer) < 8:
+                # (a few frames: their re-run starts now — first triangulations on the pool — and advances while later chunks run)
+                rec = self._host_begin([f3s[f] for f in redo], [f2s[f] for f in redo], 0, slot=8 + len(defer), background=True,
+                                       ctx=self._redo_context())
+                rec["ids"] = frame_base + redo
+                rec["triples"] = None if id_triples is None else [id_triples[f] for f in redo]
+                self.redo_early_started = getattr(self, "redo_early_started", 0) + 1
+            defer.append((res, redo, frame_base, f3s, f2s, id_triples, rec))
+            self._advance_deferred(defer)
             return res
+        if defer:
+            self._advance_deferred(defer)
         if len(redo):
             sub = self._chunk_dev_host([f3s[f] for f in redo], [f2s[f] for f in redo], 0, frame_base + redo,
                                        None if id_triples is None else [id_triples[f] for f in redo], stage)
@@ -556,8 +627,48 @@ class ScaleEstimator:
                         res["stage"][k][f] = sub["stage"][k][j]
         return res
 
+    GPU_REDO_EARLY = True           # a deferred re-run of at most GPU_REDO_EARLY_MAX frames is started at once and advanced while later chunks run
+    GPU_REDO_EARLY_MAX = 16
+
+    def _advance_deferred(self, deferred):
+        """Started re-runs one step further wherever that step would not wait (see the _host_* steps); everything is queued on the
+        estimator's one stream, behind the chunks launched so far — nothing here blocks, the results are simply there later."""
+        for k, item in enumerate(deferred):
+            rec = item[6]
+            if rec is None:
+                continue
+            if rec["step"] == 0 and rec["h1"].ready():
+                self._host_keep_start(rec)
+            elif rec["step"] == 1 and rec["aux"].ready():
+                self._host_tri2_start(rec, slot=16 + k, background=True)
+            elif rec["step"] == 2 and rec["h2"].ready():
+                self._host_flat_start(rec, 0, rec["ids"], rec["triples"], False)
+                self.redo_early_launched = getattr(self, "redo_early_launched", 0) + 1
+
     def _finish_deferred(self, deferred, stage):
-        """The declined frames of every chunk of a call in one batch through the host's triangulations, scattered back."""
+        """The declined frames of every chunk of a call through the host's triangulations, scattered back: the started re-runs each
+        finish their remaining steps (launches first, then the results), the others go in one merged batch."""
+        if not deferred:
+            return
+        self._advance_deferred(deferred)
+        started = [(k, item) for k, item in enumerate(deferred) if item[6] is not None]
+        for k, item in started:
+            if item[6]["step"] == 0:
+                self._host_keep_start(item[6])
+        for k, item in started:
+            if item[6]["step"] == 1:
+                self._host_tri2_start(item[6], slot=16 + k)
+        for k, item in started:
+            if item[6]["step"] == 2:
+                self._host_flat_start(item[6], 0, item[6]["ids"], item[6]["triples"], stage)
+        for k, item in started:
+            res, redo = item[0], item[1]
+            sub = self._host_collect(item[6], stage)
+            for key in ("raw_scale", "height_level", "model", "best_ic", "used", "n_kept", "status"):
+                res[key][redo] = sub[key]
+            for j, e in sub["host_errors"].items():
+                res["host_errors"][int(redo[j])] = e
+        deferred = [item[:6] for item in deferred if item[6] is None]
         if not deferred:
             return
         f3_all, f2_all, ids, trs, where = [], [], [], [], []
@@ -624,7 +735,8 @@ class ScaleEstimator:
                 tr = None if id_triples is None else id_triples[a:b]
                 self._trace("launch", len(bounds), b - a)
                 queue.append((self._chunk_dev_gpu(feature3ds[a:b], feature2ds[a:b], base + a, tr, stage,
-                                                  tables=(tuple(t[:b - a] for t in tb) if tb is not None else None)), a, b))
+                                                  tables=(tuple(t[:b - a] for t in tb) if tb is not None else None),
+                                                  early_status=self.GPU_REDO_EARLY and not stage and b == F and a > 0), a, b))
                 bounds.append((a, b))
                 self._trace("launched", len(bounds) - 1, b - a)
                 while len(queue) > self.GPU_PIPELINE:

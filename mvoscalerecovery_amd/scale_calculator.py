@@ -753,6 +753,17 @@ class ScaleEstimator:
                 early = (ef, packing.delaunay_submit([self._lower_points(f2s[f]) for f in ef], self.delaunay_workers, slot=24,
                                                      fast=self._host_replay, canonical=self.check_triangle == "fixed", background=True))
                 self.redo_early_status_hits = getattr(self, "redo_early_status_hits", 0) + 1
+                if self.GPU_REDO_EARLY and len(ef) <= self.GPU_REDO_EARLY_MAX:
+                    # ... and this thread has nothing else to do for the call's last chunk: it takes those frames through their first
+                    # triangulation (waited for: the chunk's other kernels are running), the vote (on the re-runs' context) and the start
+                    # of their second triangulation NOW, so that the call's end finds only their product kernels left to launch
+                    rows = early[1].get()
+                    sub = self._chunk_begin([f3s[f] for f in ef], [f2s[f] for f in ef], 0, tri1s=rows, _remapped=st["remapped"], _exact_all=True,
+                                            _fast=self._host_replay, _eng=self._redo_engine(st["remapped"]) if self.GPU_REDO_CONTEXT else None)
+                    sub["pf"].extra["tri1_is_canonical"] = self.check_triangle == "fixed"
+                    self._chunk_vote_start(sub)
+                    self._chunk_vote_finish(sub, 25, background=True)
+                    st["early_sub"] = sub
         s1, s2 = db.triangulation_status()
         redo = np.nonzero((s1 != 0) | (s2 != 0))[0]
         res = [out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts"), {}]
@@ -802,6 +813,12 @@ class ScaleEstimator:
                 where = {int(f): k for k, f in enumerate(redo)}
                 handle = packing._JoinedHandle(len(redo), [([where[int(f)] for f in early[0]], early[1]), (rest, handle)])
         pend = {"st": st, "redo": redo, "s12": (s1, s2), "f3s": f3s, "f2s": f2s, "res": res, "keep": keep, "h1": handle}
+        esub = st.pop("early_sub", None)
+        if esub is not None:
+            if handle is not None and early is not None and len(redo) == len(early[0]) and np.array_equal(redo, early[0]):
+                pend["sub"], pend["early"] = esub, 2          # (the record continues where the early steps left it: _advance_deferred)
+            else:                                              # (more frames to redo than the early read knew of: the merged way for all)
+                self._chunk_free(esub)
         if handle is not None:
             defer.append(pend)
             if len(defer) >= self.GPU_REDO_MAX_DEFERRED:       # (bounded: a deferred chunk keeps its device blocks and a pool slot)

@@ -43,12 +43,23 @@ def main():
     places = [("none", []), ("1 first", [17]), ("1 last", [F - 9]), ("2 ends", [17, F - 9]),
               ("4 spread", [int(F * (j + 0.5) / 4) for j in range(4)]), ("16 spread", [int(F * (j + 0.5) / 16) for j in range(16)])]
     places = places[:int(os.environ.get("PLACES", "99"))]
-    for exact in ((True,) if os.environ.get("EXACT_ONLY") else (True, False)):
-        est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", delaunay_workers=W,
-                             check_triangle="reference" if exact else "fixed")
+    legs = [x for x in os.environ.get("LEGS", "exact,fixed,rescale").split(",") if x]
+    if os.environ.get("EXACT_ONLY"):
+        legs = ["exact"]
+    early = os.environ.get("EARLY", "1") != "0"                               # EARLY=0: the merged re-run at the call's end only (before §10.11)
+    for leg in legs:
+        exact = leg == "exact"
+        if leg == "rescale":
+            from mvoscalerecovery_amd.rescale import ScaleEstimator as RescaleEstimator
+            est = RescaleEstimator(1.75, window_size=5, triangulation="gpu", delaunay_workers=W, ransac_seed=2024)
+        else:
+            est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", delaunay_workers=W,
+                                 check_triangle="reference" if exact else "fixed")
+        est.GPU_REDO_EARLY = early
         acc = {}
-        for nm in ("_chunk_gpu_complete_all", "_chunk_begin", "_chunk_vote", "_chunk_scale", "_chunk_gpu", "_chunk_gpu_finish"):
-            timed(est, nm, acc)
+        for nm in ("_chunk_gpu_complete_all", "_chunk_begin", "_chunk_vote", "_chunk_scale", "_chunk_gpu", "_chunk_gpu_finish", "_finish_deferred"):
+            if hasattr(est, nm):
+                timed(est, nm, acc)
         from mvoscalerecovery_amd import engine as _eng
         for cls_, nm in ((_eng.DeviceBatch, "triangulation_status"), (packing, "delaunay_submit")):
             fn = getattr(cls_, nm)
@@ -72,7 +83,7 @@ def main():
             ts, parts = [], []
             for _ in range(calls):
                 acc.clear()
-                ctxs = [est.engine.ctx] + ([est._engine2.ctx] if getattr(est, "_engine2", None) is not None else [])
+                ctxs = [est.engine.ctx if hasattr(est, "engine") else est.ctx] + ([est._engine2.ctx] if getattr(est, "_engine2", None) is not None else [])
                 a0 = [c.alloc_stats() for c in ctxs]
                 t0 = time.perf_counter()
                 est.scale_calculation_batch(f3s, f2s)
@@ -81,14 +92,19 @@ def main():
                 acc["mallocs"] = sum(b["hip_malloc"] - a["hip_malloc"] for a, b in zip(a0, a1))
                 acc["frees"] = sum(b["hip_free"] - a["hip_free"] for a, b in zip(a0, a1))
                 parts.append(dict(acc))
+            if os.environ.get("SHOW_CALLS"):
+                print("   calls (ms): " + " ".join("%.1f" % (t * 1e3) for t in ts))
             k = int(np.argsort(ts)[len(ts) // 2])
             med = ts[k]
             if ref is None:
                 ref = med
             p = parts[k]
+            print("[early started %d launched %d status hits %d] " % (getattr(est, "redo_early_started", 0), getattr(est, "redo_early_launched", 0),
+                                                                         getattr(est, "redo_early_status_hits", 0)), end="")
+            est.redo_early_started = est.redo_early_launched = est.redo_early_status_hits = 0
             print("%-9s %-9s: %7.2f ms per call (%+6.2f), %6.1f k frames/s, declined %3d; re-run %5.2f ms = begin %5.2f + vote %5.2f + scale %5.2f + rest %5.2f; launch side %6.2f, collect side %6.2f ms; hipMalloc %d hipFree %d; status waits %6.2f ms in %d, submits %5.2f ms in %d" % (
-                "exact" if exact else "fixed", label, med * 1e3, (med - ref) * 1e3, F / med / 1e3, est.declined_total,
-                p.get("_chunk_gpu_complete_all", 0.0) * 1e3, p.get("_chunk_begin", 0.0) * 1e3, p.get("_chunk_vote", 0.0) * 1e3, p.get("_chunk_scale", 0.0) * 1e3,
+                leg, label, med * 1e3, (med - ref) * 1e3, F / med / 1e3, getattr(est, "declined_total", getattr(est, "last_declined", 0)),
+                (p.get("_chunk_gpu_complete_all", 0.0) + p.get("_finish_deferred", 0.0)) * 1e3, p.get("_chunk_begin", 0.0) * 1e3, p.get("_chunk_vote", 0.0) * 1e3, p.get("_chunk_scale", 0.0) * 1e3,
                 (p.get("_chunk_gpu_complete_all", 0.0) - p.get("_chunk_begin", 0.0) - p.get("_chunk_vote", 0.0) - p.get("_chunk_scale", 0.0)) * 1e3,
                 p.get("_chunk_gpu", 0.0) * 1e3, p.get("_chunk_gpu_finish", 0.0) * 1e3, p.get("mallocs", 0), p.get("frees", 0),
                 p.get("triangulation_status", 0.0) * 1e3, p.get("triangulation_status_calls", 0), p.get("delaunay_submit", 0.0) * 1e3, p.get("delaunay_submit_calls", 0)), flush=True)

@@ -346,3 +346,32 @@ def test_rescale_default_construction_is_device_resident(gpu, monkeypatch):
     for i in range(8):
         f3, f2 = synth.synth_frame(i, 600 + 150 * i, base_seed=515)
         assert est.scale_calculation(f3, f2) == explicit.scale_calculation(f3, f2), i
+
+
+def test_rescale_deferred_reruns_started_early(gpu):
+    """Round 6: the few frames a chunk's device triangulation declines have their host re-run STARTED when the chunk is collected and
+    advanced while the call's later chunks run (``_advance_deferred``: first triangulations on the pool -> vote launched -> keep words
+    back -> second triangulations -> flat_selection + RANSAC launched), instead of one merged re-run at the call's end.  Same scales,
+    planes and counts as the merged re-run and as triangulation="scipy" with the device's sampler; the early route is really taken."""
+    from mvoscalerecovery_amd.rescale import ScaleEstimator
+    F = 1900
+    frames = _rescale_frames([150 + (i * 29) % 200 for i in range(F)], base_seed=91)
+    declined = [5, 600, 601, 1200, F - 3]
+    for f in declined:                                # quarter-pixel grid and a repeated pixel: the device triangulation declines
+        a3, a2 = frames[f][0].copy(), np.ascontiguousarray(np.round(frames[f][1] * 4) / 4)
+        a2[5], a3[5] = a2[60], a3[60]
+        frames[f] = (a3, a2)
+    f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
+    b = ScaleEstimator(1.75, window_size=5, triangulation="scipy", sampling="device", ransac_seed=99)
+    sb, _ = b.scale_calculation_batch(f3s, f2s)
+    for early in (True, False):
+        a = ScaleEstimator(1.75, window_size=5, triangulation="gpu", ransac_seed=99, delaunay_workers=3 if early else 0)
+        a.GPU_REDO_EARLY = early
+        sa, _ = a.scale_calculation_batch(f3s, f2s)
+        assert np.array_equal(sa, sb), early
+        for k in ("model", "best_ic", "used", "n_kept", "status", "height_level", "raw_scale"):
+            assert np.array_equal(a.last[k], b.last[k], equal_nan=True), (k, early)
+        assert a.last_declined >= len(declined) - 1, a.last_declined
+        assert (getattr(a, "redo_early_started", 0) >= 3) == early, getattr(a, "redo_early_started", 0)
+        # (the LAST chunk's declined frame: found by the early read of the first triangulation's status)
+        assert getattr(a, "redo_early_status_hits", 0) == (1 if early else 0)
