@@ -579,6 +579,8 @@ def main():
     ap.add_argument("--workload", choices=("c2", "kitti", "gridded"), default="c2",
                     help="c2: every frame has --features features (configs[1]); kitti: 300-1500 per frame (configs[2]'s sizes); "
                          "gridded: c2's frames with pixel coordinates rounded to 1/4 px (sites in degenerate position: the decline path)")
+    ap.add_argument("--snap-grid", type=float, default=0.25,
+                    help="--workload gridded: the grid the pixel coordinates are rounded to, in pixels (0.25; 0.0625 = a detector refining to 1/16 px)")
     ap.add_argument("--snap-fraction", type=float, default=1.0,
                     help="--workload gridded: the share of the frames whose coordinates are snapped (1.0: all; 0.005: the decline rate "
                          "ordinary data showed before round 5's restatements — the cost of a FEW declined frames per chunk)")
@@ -604,7 +606,7 @@ def main():
     if args.tile_above > 0:
         TILE_ABOVE[0] = args.tile_above
     if args.workload == "gridded":
-        SNAP[0], SNAP[1] = 0.25, float(args.snap_fraction)
+        SNAP[0], SNAP[1] = float(args.snap_grid), float(args.snap_fraction)
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:

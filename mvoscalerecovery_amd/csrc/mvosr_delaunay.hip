@@ -30,8 +30,10 @@
 // prefix-summed in point order, so the output does not depend on scheduling.
 //
 // Robustness: plain fp64 predicates with guard bands.  A frame in which a decision falls inside a band — two
-// candidates with (nearly) the same cot: four cocircular points; a point (nearly) on the line through an edge;
-// duplicate points — or whose rows fail Euler's relation (2n - 2 - h rows, 3 star triangles per row) is flagged
+// candidates with (nearly) the same cot: four cocircular points; a point (nearly) on the line through an edge where
+// that can decide a triangle (between the edge's ends; beyond them only on a hull edge, and not where the collinearity
+// is exact: dt_step<true>, round 6 — sites on a pixel grid are collinear in threes everywhere without being
+// degenerate); duplicate points — or whose rows fail Euler's relation (2n - 2 - h rows, 3 star triangles per row) is flagged
 // MVOSR_DT_DEGENERATE and left to the host's Qhull (SciPy resolves such inputs by its own rules).
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -95,6 +97,7 @@ constexpr int kDtHardCap = 256;          // points left to the group pass
 constexpr int kDtArenaSlack = 64;
 constexpr double kDtTieTol = 1e-9;       // relative guard band on cot differences
 constexpr double kDtColTol = 1e-12;      // relative guard band on collinearity (|cross| <= tol |a| |b|)
+constexpr double kDtColSeg = (1.0 + 1e-9) / (kDtColTol * kDtColTol);      // a2col * kDtColSeg = |a|^2 (1 + 1e-9): a collinear candidate with a larger dot lies beyond q
 
 // why a frame was declined (status bits 8..)
 enum { DT_WHY_DUP = 1, DT_WHY_TIE = 2, DT_WHY_COLLINEAR = 4, DT_WHY_DEGREE = 8, DT_WHY_ROWS = 16, DT_WHY_EULER = 32,
@@ -297,8 +300,24 @@ struct DtAcc {
 
 constexpr int kDtGroup = 16;            // lanes that share a completion in the group passes: one DPP row
 
-// one candidate of a group pass, branch-free
-__device__ __forceinline__ void dt_step(DtAcc &A, const DtEdge &E, int j, double2 c) {
+// one candidate of a group pass, branch-free.
+// TWO (the pass over the hard points; round 6): the collinearity flag in two kinds.  Bit 0: a candidate (nearly) on the line ahead of p
+// UP TO q — on the segment, or a duplicate of p or q: the edge is no Delaunay edge, or the sign of cr decides a triangle.  Bit 1:
+// BEYOND q: such a candidate sees the edge under a zero angle, it is never the apex where anything else lies on the wanted side,
+// whichever side of the line rounding puts it on — it only matters where nothing does (a hull edge: a sliver triangle or not?), and
+// the completion looks at it only then (dt_col_declines) — and not at all where the collinearity is EXACT (below).  Coordinates
+// quantised to 1/16 px: two frames in three hold such a triple (three sites on a grid line within a cell block), nearly always of the
+// second kind: 65 % of the frames were declined; 5 % with the interior edges let through, 1.8 % with the exactly collinear hull
+// points too (what is left: repeated sites, cocircular quadruples).  The lane pass and the wide searches keep the one flag and hand a
+// flagged point to this pass.
+// d == x - y computed in fp64: was that subtraction exact?  (Knuth's TwoSum error term; -ffp-contract=off keeps it as written)
+__device__ __forceinline__ bool dt_exact_diff(double x, double y, double d) {
+    const double bb = d - x;
+    return (x - (d - bb)) - (y + bb) == 0.0;
+}
+
+template <bool TWO = false>
+__device__ __forceinline__ void dt_step(DtAcc &A, const DtEdge &E, int j, double2 c, double2 q = double2{0.0, 0.0}) {
     const double bx = c.x - E.px, by = c.y - E.py;
     const double cr = E.sgn * __builtin_fma(E.ax, by, -(E.ay * bx));
     const double b2 = __builtin_fma(bx, bx, by * by);
@@ -306,6 +325,22 @@ __device__ __forceinline__ void dt_step(DtAcc &A, const DtEdge &E, int j, double
     const double num = b2 - dot;                                        // (c - p).(c - q)
     const bool skip = (j == E.i) | (j == E.iq);
     const bool col = cr * cr <= E.a2col * b2;                           // (nearly) on the line through the edge ...
+    if constexpr (TWO) {
+        const bool ahead = !skip & col & ((dot > 0.0) | (b2 == 0.0));
+        const bool beyond = dot > E.a2col * kDtColSeg;
+        // EXACTLY collinear (every difference exact, the cross product exactly zero: t = ay bx rounded, ax by - t == 0 and ay bx - t == 0
+        // as FMAs, i.e. without rounding): beyond q of a hull edge that is no sliver in anybody's arithmetic — q is a hull vertex between
+        // p and c, no triangle (Qhull: the facet through the three lifted points is vertical, not a lower one).  Coordinates on a grid.
+        A.flag |= (ahead & !beyond) ? 1 : 0;
+        if (ahead & beyond) {
+            asm volatile("");                      // (a region the wavefront skips — never entered on points in general position —, not a select:
+                                                   // the pass over the hard points runs for a few points of EVERY frame)
+            const double t = E.ay * bx;
+            const bool exact = dt_exact_diff(q.x, E.px, E.ax) & dt_exact_diff(q.y, E.py, E.ay) & dt_exact_diff(c.x, E.px, bx) & dt_exact_diff(c.y, E.py, by) &
+                               (__builtin_fma(E.ax, by, -t) == 0.0) & (__builtin_fma(E.ay, bx, -t) == 0.0);
+            A.flag |= exact ? 0 : 2;
+        }
+    } else
     A.flag |= (!skip & col & ((dot > 0.0) | (b2 == 0.0))) ? 1 : 0;      // ... ahead of p: the sign of cr would decide a triangle
     const bool ok = !skip & !col & (cr > 0.0);
     const double d = __builtin_fma(num, A.c1, -(A.n1 * cr));            // num / cr < n1 / c1  <=>  d < 0
@@ -386,15 +421,19 @@ __device__ __attribute__((noinline)) bool dt_confirm_tie(const double2 *S, const
 }
 
 // a cell box, GL lanes striding over each row
-template <int GL>
-__device__ __forceinline__ void dt_scan_box(DtAcc &A, const double2 *S, const DtGrid &G, const DtBox &B, const DtEdge &E) {
+template <int GL, bool TWO = false>
+__device__ __forceinline__ void dt_scan_box(DtAcc &A, const double2 *S, const DtGrid &G, const DtBox &B, const DtEdge &E, double2 q = double2{0.0, 0.0}) {
     const int gl = lane_id() & (GL - 1);
     for (int y = B.ya; y <= B.yb; ++y) {
         int j0, j1;
         dt_row_range(G, E, y, B.xa, B.xb, j0, j1);
-        for (int j = j0 + gl; j < j1; j += GL) dt_step(A, E, j, S[j]);
+        for (int j = j0 + gl; j < j1; j += GL) dt_step<TWO>(A, E, j, S[j], q);
     }
 }
+
+// Does a collinearity flag of the two-kind form decline the frame?  Bit 0 always; bit 1 only where the search found nothing on the
+// wanted side (id < 0).
+__device__ __forceinline__ bool dt_col_declines(int flag, int id) { return (flag & 1) || ((flag & 2) && id < 0); }
 
 constexpr int kDtRows = 2 * kDtR + 1;
 
@@ -423,7 +462,7 @@ __device__ __forceinline__ DtPick dt_group_pick(const DtAcc &A) {
     const double band = kDtTieTol * (fabs(m) + 1.0);
     const bool close = (A.b1 >= 0 && A.b1 != r.id && t1 - m <= band) || (A.n2 / A.c2 - m <= band);
     r.tie = (r.id >= 0) && dt_group_ballot(close) != 0u;
-    r.flag = dt_group_ballot(A.flag != 0) != 0u;
+    r.flag = (dt_group_ballot((A.flag & 1) != 0) != 0u ? 1 : 0) | (dt_group_ballot((A.flag & 2) != 0) != 0u ? 2 : 0);
     return r;
 }
 
@@ -992,10 +1031,10 @@ __global__ __launch_bounds__(WAVES *kWave, PARTS ? 1 : ((ARENA_OUT && WAVES == 4
                 if (lane == 0) { atomicAdd(&misc[41], my_trips); atomicAdd(&misc[42], 1); atomicAdd(&misc[43], (bb.yb - bb.ya + 1 + kDtServeRows - 1) / kDtServeRows); }
 #endif
                 const DtPick pk = dt_wave_pick(A2);
-                if (pk.flag) degenerate |= DT_WHY_COLLINEAR;
                 if (pk.tie) degenerate |= DT_WHY_TIE;
                 any = true;
-                if (lane == src) { A.reset(); A.b1 = pk.id; y_next = box.yb + 1; j_resume = 0; coop = 0; }
+                // (a collinear candidate ahead of p: the lane's completion hands its point to the group pass, which tells the kinds apart)
+                if (lane == src) { A.reset(); A.b1 = pk.id; A.flag = pk.flag ? 1 : 0; y_next = box.yb + 1; j_resume = 0; coop = 0; }
             }
             }
             return any;
@@ -1119,9 +1158,11 @@ __global__ __launch_bounds__(WAVES *kWave, PARTS ? 1 : ((ARENA_OUT && WAVES == 4
                 }
             } else {
                 DT_MARK(c_m1);
-                if (A.flag) degenerate |= DT_WHY_COLLINEAR;
                 const int ic = A.b1;
-                if (wide) {
+                // a collinear candidate ahead of p was seen: the point goes to the group pass (hard list), whose steps tell a candidate
+                // on the segment from one beyond q (dt_step<true>) — nothing here, in the loop every point of every frame runs through
+                if (A.flag) state = 2;
+                else if (wide) {
                     if (ic >= 0) accept = ic;
                     else {
                         // a hull edge: the star is open.  Counter-clockwise done: clockwise from the first neighbour
@@ -1313,17 +1354,19 @@ __global__ __launch_bounds__(WAVES *kWave, PARTS ? 1 : ((ARENA_OUT && WAVES == 4
                     E.set(p, q, i, iq, sgn);
                     DtAcc A;
                     A.reset();
-                    dt_scan_box<kDtGroup>(A, S, G, blk, E);
+                    dt_scan_box<kDtGroup, true>(A, S, G, blk, E, q);
                     DtPick pk = dt_group_pick(A);
                     if (pk.id < 0 || !dt_inside(dt_circle_box(G, p.x, p.y, q, S[max(pk.id, 0)]), blk)) {
                         // nothing on that side within the block, or a circumcircle that leaves it: search the circle's
                         // cell box, or the whole frame (row by row, each row cut down to the wanted side of the edge)
                         const DtBox B = pk.id < 0 ? all : dt_circle_box(G, p.x, p.y, q, S[pk.id]);
+                        const int seg_seen = pk.flag & 1;           // (a candidate on the segment p..q stays one in whatever box)
                         A.reset();
-                        dt_scan_box<kDtGroup>(A, S, G, B, E);
+                        dt_scan_box<kDtGroup, true>(A, S, G, B, E, q);
                         pk = dt_group_pick(A);
+                        pk.flag |= seg_seen;
                     }
-                    if (pk.flag) degenerate |= DT_WHY_COLLINEAR;
+                    if (dt_col_declines(pk.flag, pk.id)) degenerate |= DT_WHY_COLLINEAR;
                     if (pk.id < 0) { open = 1; break; }                    // a hull edge
                     if (pk.tie) degenerate |= DT_WHY_TIE;
                     if (++deg > kDtWaveDeg) { degenerate |= DT_WHY_DEGREE; bad = 1; break; }

@@ -123,12 +123,25 @@ def render(tag):
                          "the fixed-mode estimator %s (declined %.1f %%); host SciPy for every frame: %s"
                          % (k(ex["value"]), 100 * ex.get("declined_fraction", 0), ex.get("declined_total", 0), ex["frames"], k(fx.get("value", float("nan"))), 100 * fx.get("declined_fraction", 0), k(ho.get("value", float("nan")))),
                          "`profiles/%s_bench_gridded.json`" % tag))
+    g16, g16b = load_line(tag + "_bench_grid16.json"), load_line(tag + "_bench_grid16_before.json")
+    if g16 and "value" in g16.get("e2e_gpu_exact", {}):
+        ex, fx = g16["e2e_gpu_exact"], g16.get("e2e_gpu_triangulation", {})
+        before = ""
+        if g16b and "value" in g16b.get("e2e_gpu_exact", {}):
+            bx, bf = g16b["e2e_gpu_exact"], g16b.get("e2e_gpu_triangulation", {})
+            before = " (the same box with the kernel as it was: %s with %.0f %% declined / %s with %.0f %%)" % (
+                k(bx["value"]), 100 * bx.get("declined_fraction", 0), k(bf.get("value", float("nan"))), 100 * bf.get("declined_fraction", 0))
+        rows.append(("... coordinates on a 1/16 px grid (`--workload gridded --snap-grid 0.0625`: what a detector refining to 1/16 px hands over — exactly collinear triples in two frames of three, few cocircular quadruples)",
+                     "the default estimator end to end **%s frames/s** with %.1f %% of the frames declined (%d of %d), the fixed-mode estimator **%s** (%.1f %% declined)%s: "
+                     "`delaunay_kernel` no longer declines a collinear site beyond q of an interior edge, nor an EXACTLY collinear one on the hull (round 6)"
+                     % (k(ex["value"]), 100 * ex.get("declined_fraction", 0), ex.get("declined_total", 0), ex["frames"], k(fx.get("value", float("nan"))),
+                        100 * fx.get("declined_fraction", 0), before), "`profiles/%s_bench_grid16.json`" % tag))
     g5 = load_line(tag + "_bench_gridded_0005.json")
     if g5 and "value" in g5.get("e2e_gpu_exact", {}):
         ex = g5["e2e_gpu_exact"]
         rows.append(("... a FEW declined frames per chunk (`--workload gridded --snap-fraction 0.005`; round 5: 72 declined frames in 16 384 took the call from 53 k to 30 k frames/s, re-run in the chunk's epilogue on the chunk's own stream)",
-                     "the default estimator end to end **%s frames/s** with %d of %d frames declined (%.2f %%), the fixed-mode estimator **%s** (without declines: the rows above): ONE re-run of the call's declined frames after its last chunk, on a context of its own, "
-                     "their first SciPy calls started on the worker pool at discovery — a per-call cost of 40-80 ms, not a per-chunk stall"
+                     "the default estimator end to end **%s frames/s** with %d of %d frames declined (%.2f %%), the fixed-mode estimator **%s** (without declines: the rows above): the declined frames' re-runs on a context of their own, a chunk's few frames STARTED "
+                     "when the chunk is collected and advanced while later chunks run (first triangulations on the worker pool, vote, second triangulations, product kernels), more than 16 per chunk in one merged re-run after the call's last chunk"
                      % (k(ex["value"]), ex.get("declined_total", 0), ex["frames"], 100 * ex.get("declined_fraction", 0), k(g5.get("e2e_gpu_triangulation", {}).get("value", float("nan")))), "`profiles/%s_bench_gridded_0005.json`" % tag))
     for nm, what in (("share2", "`bench.py --gpus 2 --share-gpu` (two ranks sharing this one GPU over gloo: the N-rank code path as a dry run, not a scaling number)"),
                      ("share2_c4", "`bench.py --gpus 2 --share-gpu --c4 --total-frames 100000` (configs[3]'s split, two ranks on one GPU, dry run)")):

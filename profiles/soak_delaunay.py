@@ -14,6 +14,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 # SOAK_SETS (160) sets per launch of up to SOAK_NMAX (4700) points: 512 sets and more let the launcher pick its small-frame and
 # arena-out instantiations by the largest set (SOAK_SETS=520 SOAK_NMAX=2150 / 3300 / 1100 / 500)
 SETS, NMAX = int(os.environ.get("SOAK_SETS", "160")), int(os.environ.get("SOAK_NMAX", "4700"))
+QUANT = float(os.environ.get("SOAK_QUANT", "0"))
 
 
 def empty_circle_violations(p, tris, verts):
@@ -54,6 +55,8 @@ for rnd in range(rounds):
             p = np.concatenate([rng.uniform(0, 100, (n // 2, 2)), rng.uniform(900, 1000, (n - n // 2, 2)) * [1, 0.1]])
         else:
             p = rng.uniform(0, 1, (n, 2)) ** 3 * [2000.0, 500.0]           # strongly non-uniform density
+        if QUANT:                                   # SOAK_QUANT=16: coordinates on a 1/16 px grid — collinear triples, cocircular quadruples, duplicates
+            p = np.round(p * QUANT) / QUANT
         sets.append(np.ascontiguousarray(p))
     F = len(sets)
     cnt = np.array([len(p) for p in sets], dtype=np.int32)
@@ -119,5 +122,5 @@ for rnd in range(rounds):
             print("MISMATCH second n=%d kept=%d kind=%d; only GPU %d (violating, exactly: %d), only SciPy %d (%d)" % (len(p), len(q), f % 6, len(og), vg, len(orf), vr))
     for b in (d_u, d_v, d_off, d_cnt, d_toff, d_keep, tri1, tri2, c1, c2, s1, s2):
         b.free()
-print("sets %d: first triangulation declined %d, mismatches %d (SciPy's rows violate the empty circle in exact arithmetic, the device's do not: %d; otherwise: %d); "
+print(("coordinates on a 1/%g grid: " % QUANT if QUANT else "") + "sets %d: first triangulation declined %d, mismatches %d (SciPy's rows violate the empty circle in exact arithmetic, the device's do not: %d; otherwise: %d); "
       "seeded second declined %d, mismatches %d (%d; %d)" % (total, declined, bad, qhull_inexact, device_wrong, declined2, bad2, qhull_inexact2, device_wrong2))

@@ -270,3 +270,31 @@ def test_delaunay_small_frame_variants(gpu, n_max):
     assert ok >= 30
     for b in (d_u, d_v, d_off, d_cnt, d_toff, d_keep, tri1, tri2, c1, c2, s1, s2):
         b.free()
+
+
+def test_delaunay_collinear_triples_on_a_pixel_grid(gpu):
+    """Round 6: coordinates quantised to 1/16 px hold exactly collinear triples everywhere (three sites on a grid line within a cell
+    block).  One that lies BEYOND q on the line of an edge p -> q sees the edge under a zero angle: it is never the apex of an interior
+    edge, and on a hull edge it is no sliver where the collinearity is EXACT (every difference and the cross product without rounding).
+    Such frames are triangulated — the triangle set SciPy returns —, not declined (65 % of them were); a hull point that is only NEARLY
+    on the line (inside the guard band, not exact) still declines; repeated sites and cocircular quadruples still decline."""
+    from scipy.spatial import Delaunay
+    from mvoscalerecovery_amd import packing
+    rng = np.random.default_rng(2026)
+    sets = [np.round(rng.uniform(0, 1, (int(n), 2)) * [1241.0, 376.0] * 16) / 16 for n in rng.integers(300, 2100, 96)]
+    got = packing.delaunay_gpu(gpu, sets)
+    declined = sum(t is None for t in got)
+    for k, (pts, tri) in enumerate(zip(sets, got)):
+        if tri is not None:
+            assert np.array_equal(tri, packing.canonical_rows(Delaunay(pts).simplices)), k
+    assert declined <= 12, declined                                          # (measured: 2-5 %; before the change two in three)
+    # exactly collinear points on the hull (a row of sites along the lower border), and exactly collinear triples inside
+    base = np.round(rng.uniform(0, 1, (800, 2)) * [1000.0, 300.0] * 16) / 16 + [0.0, 10.0]
+    border = np.stack([np.arange(0.0, 1000.0, 62.5), np.zeros(16)], axis=1)
+    inner = np.stack([100.0 + 8.0 * np.arange(6), 150.0 + 4.0 * np.arange(6)], axis=1)
+    exact = np.concatenate([base, border, inner])
+    near = exact.copy()
+    near[800 + 5, 1] += 1e-11                                                # one border site a hair off the line: inside the guard band, not exact
+    got = packing.delaunay_gpu(gpu, [exact, near])
+    assert got[0] is not None and np.array_equal(got[0], packing.canonical_rows(Delaunay(exact).simplices))
+    assert got[1] is None and (int(packing.delaunay_gpu.last_status[1]) >> 8) & 4
