@@ -19,9 +19,17 @@ ap.add_argument("--ragged", default="", help="lo:hi — sets of lo..hi points (u
 ap.add_argument("--seeded", action="store_true", help="time the SECOND triangulation: 85 %% of the points kept, seeded with the first one's rows")
 ap.add_argument("--keep", type=float, default=0.85, help="share of the points the second triangulation keeps (the vote keeps ~0.95)")
 ap.add_argument("--no-carry", action="store_true", help="seeded without the untouched stars carried over (mvosr_delaunay_batch_seeded)")
+ap.add_argument("--grid", type=float, default=0.0, help="round the coordinates to this grid (pixels), e.g. 0.0625: collinear triples in most sets (the hard-point pass takes their stars)")
 args = ap.parse_args()
 n, F = args.points, args.sets
 ctx = _lib.default_context(0)
+_frame = synth.synth_frame
+if args.grid > 0:
+    class synth:                                   # noqa: N801  (the pool's frames on the grid)
+        @staticmethod
+        def synth_frame(i, n_, base_seed=99):
+            f3, f2 = _frame(i, n_, base_seed=base_seed)
+            return f3, np.ascontiguousarray(np.round(f2 / args.grid) * args.grid)
 pool = [synth.synth_frame(i, n, base_seed=99)[1] for i in range(64)]
 if args.ragged:
     lo_, hi_ = (int(x) for x in args.ragged.split(":"))
