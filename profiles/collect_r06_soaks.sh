@@ -17,4 +17,4 @@ if [ -f profiles/ab/libmvosr_dtold.so ]; then
   for q in 64 16 4; do MVOSR_LIB_PATH=profiles/ab/libmvosr_dtold.so SOAK_QUANT=$q SOAK_NMAX=2600 timeout 600 python profiles/soak_delaunay.py 12 2>&1 | tail -1 >> $OUT/r06_soak_delaunay_quantised.txt; done
 fi
 timeout 900 python profiles/dt_decline_rate.py 16384 2000 > $OUT/r06_dt_decline_rate.txt 2>&1
-tail -2 $OUT/r06_soak_fixed.txt $OUT/r06_soak_rescale_device.txt $OUT/r06_soak_qhull.txt $OUT/r06_soak_exact.txt
+for f in r06_soak_fixed r06_soak_rescale_device r06_soak_qhull r06_soak_exact r06_soak_delaunay_quantised; do tail -n 2 $OUT/$f.txt; done

@@ -32,6 +32,9 @@ def make(kind, seed, rng):
         return p[rng.random(len(p)) < 0.93]
     if kind == "quarter-pixel grid":
         return np.unique(np.round(synth.synth_frame(seed, n, base_seed=20263333)[1] * 4) / 4, axis=0)
+    if kind.endswith("-pixel grid") and kind.startswith("1/"):          # "1/16-pixel grid", "1/64-pixel grid" (SOAK_KINDS)
+        q = float(kind[2:kind.index("-")])
+        return np.unique(np.round(synth.synth_frame(seed, n, base_seed=20263333)[1] * q) / q, axis=0)
     raise ValueError(kind)
 
 
@@ -39,6 +42,8 @@ def main():
     total = int(sys.argv[1]) if len(sys.argv) > 1 else 12000
     ctx = _lib.Context(0)
     kinds = ["synthetic frame", "float32 positions", "uniform image", "clusters", "survivors (keep mask)", "quarter-pixel grid"]
+    if os.environ.get("SOAK_KINDS"):
+        kinds = [k.strip() for k in os.environ["SOAK_KINDS"].split(",")]
     rng = np.random.default_rng(7)
     t0 = time.time()
     print("mvosr_delaunay_qhull_batch against scipy.spatial.Delaunay (SciPy %s), %d point sets of 40-2300 points" % (__import__("scipy").__version__, total))

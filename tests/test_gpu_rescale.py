@@ -359,7 +359,8 @@ def test_rescale_deferred_reruns_started_early(gpu):
     declined = [5, 600, 601, 1200, F - 3]
     for f in declined:                                # quarter-pixel grid and a repeated pixel: the device triangulation declines
         a3, a2 = frames[f][0].copy(), np.ascontiguousarray(np.round(frames[f][1] * 4) / 4)
-        a2[5], a3[5] = a2[60], a3[60]
+        low = np.nonzero(a2[:, 1] > 200.0)[0]                 # (two sites well below the vanishing row: the repeated site is among the triangulated ones)
+        a2[low[1]], a3[low[1]] = a2[low[0]], a3[low[0]]
         frames[f] = (a3, a2)
     f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
     b = ScaleEstimator(1.75, window_size=5, triangulation="scipy", sampling="device", ransac_seed=99)
