@@ -588,6 +588,12 @@ class ScaleEstimator:
                 self._host_tri2_start(rec, slot=25, background=True)
                 early = (ef, rec)
                 self.redo_early_status_hits = getattr(self, "redo_early_status_hits", 0) + 1
+        if defer and self.GPU_REDO_EARLY and not stage:
+            # (re-runs of earlier chunks are under way: the thread looks in on them every 0.2 ms instead of sleeping until this chunk's
+            # results arrive — each step of a record is taken the moment its inputs are there)
+            while any(item[6] is not None and item[6]["step"] < 3 for item in defer) and not (st["out"].ready() and db.info.ready()):
+                self._advance_deferred(defer)
+                time.sleep(2e-4)
         res = self._collect(st["out"], F)
         s1, s2 = db.triangulation_status()
         redo = np.nonzero((s1 != 0) | (s2 != 0))[0]

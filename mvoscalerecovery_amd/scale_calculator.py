@@ -24,6 +24,8 @@ from __future__ import annotations
 import os
 from collections import deque
 
+import time
+
 import numpy as np
 
 from . import _lib
@@ -764,6 +766,12 @@ class ScaleEstimator:
                     self._chunk_vote_start(sub)
                     self._chunk_vote_finish(sub, 25, background=True)
                     st["early_sub"] = sub
+        if defer and self.GPU_REDO_EARLY:
+            # re-runs of earlier chunks are under way: instead of sleeping until this chunk's results arrive (tens of ms with the
+            # reference's vote), the thread looks in on them every 0.2 ms — each step of a record is taken the moment its inputs are there
+            while any(p.get("early", 0) < 3 and 0 < len(p["redo"]) <= self.GPU_REDO_EARLY_MAX for p in defer) and not (db.info.ready() and out.ready()):
+                self._advance_deferred(defer)
+                time.sleep(2e-4)
         s1, s2 = db.triangulation_status()
         redo = np.nonzero((s1 != 0) | (s2 != 0))[0]
         res = [out.get("raw_scale"), out.get("status"), out.get("height_level"), out.get("counts"), {}]

@@ -77,16 +77,22 @@ def main():
         ref = None
         for label, where in places:
             f2s = list(base2)
+            f3c = list(f3s)
             for w in where:
-                f2s[w] = np.ascontiguousarray(np.round(base2[w] * 4.0) / 4.0)
-            est.scale_calculation_batch(f3s, f2s)                            # (the re-run's context and buffers of this size exist)
+                # declined by construction by BOTH device triangulations: a quarter-pixel grid and a repeated site (below the vanishing
+                # row, i.e. among the triangulated ones) — since round 6's collinearity change the grid alone no longer is, for the fast kernel
+                a3, a2 = f3s[w].copy(), np.ascontiguousarray(np.round(base2[w] * 4.0) / 4.0)
+                low = np.nonzero(a2[:, 1] > 200.0)[0]
+                a2[low[1]], a3[low[1]] = a2[low[0]], a3[low[0]]
+                f2s[w], f3c[w] = a2, a3
+            est.scale_calculation_batch(f3c, f2s)                            # (the re-run's context and buffers of this size exist)
             ts, parts = [], []
             for _ in range(calls):
                 acc.clear()
                 ctxs = [est.engine.ctx if hasattr(est, "engine") else est.ctx] + ([est._engine2.ctx] if getattr(est, "_engine2", None) is not None else [])
                 a0 = [c.alloc_stats() for c in ctxs]
                 t0 = time.perf_counter()
-                est.scale_calculation_batch(f3s, f2s)
+                est.scale_calculation_batch(f3c, f2s)
                 ts.append(time.perf_counter() - t0)
                 a1 = [c.alloc_stats() for c in ctxs]
                 acc["mallocs"] = sum(b["hip_malloc"] - a["hip_malloc"] for a, b in zip(a0, a1))
