@@ -86,6 +86,22 @@ def main():
                 a2[low[1]], a3[low[1]] = a2[low[0]], a3[low[0]]
                 f2s[w], f3c[w] = a2, a3
             est.scale_calculation_batch(f3c, f2s)                            # (the re-run's context and buffers of this size exist)
+            if os.environ.get("AB"):
+                # AB=1: the same estimator with GPU_REDO_EARLY on and off in alternating calls — one process, one box, one pool of frames
+                t_on, t_off = [], []
+                for rep in range(2 * calls):
+                    est.GPU_REDO_EARLY = rep % 2 == 0
+                    t0 = time.perf_counter()
+                    est.scale_calculation_batch(f3c, f2s)
+                    (t_on if rep % 2 == 0 else t_off).append(time.perf_counter() - t0)
+                est.GPU_REDO_EARLY = early
+                m_on, m_off = sorted(t_on)[len(t_on) // 2], sorted(t_off)[len(t_off) // 2]
+                if ref is None:
+                    ref = (m_on, m_off)
+                print("%-8s %-9s: started early %7.2f ms (%+6.2f), merged at the end %7.2f ms (%+6.2f); declined %3d" % (
+                    leg, label, m_on * 1e3, (m_on - ref[0]) * 1e3, m_off * 1e3, (m_off - ref[1]) * 1e3,
+                    getattr(est, "declined_total", getattr(est, "last_declined", 0))), flush=True)
+                continue
             ts, parts = [], []
             for _ in range(calls):
                 acc.clear()
