@@ -295,6 +295,10 @@ int mvosr_memcpy_d2h(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes); 
 int mvosr_memcpy_h2d_async(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);
 int mvosr_upload_fence(mvosr_ctx *ctx);
 int mvosr_memcpy_d2h_async(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* Device -> host on a stream of the context's own that carries nothing else, waited for: for results whose producing work the caller has
+ * already waited for (an event recorded behind it).  A copy queued on the compute stream behind long kernels parks a copy engine until
+ * they finish, and an upload of ANOTHER stream that lands on that engine waits with it. */
+int mvosr_memcpy_d2h_side(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);
 int mvosr_memset(mvosr_ctx *ctx, void *dst, int value, size_t bytes);
 int mvosr_event_create(mvosr_ctx *ctx, void **event);
 int mvosr_event_record(mvosr_ctx *ctx, void *event);          /* on the context's current stream */

@@ -406,6 +406,7 @@ int mvosr_ctx_create(int device, mvosr_ctx **out) {
     ctx->ws_ysel = nullptr; ctx->ws_ysel_len = 0; ctx->ws_nsel = nullptr; ctx->ws_nsel_len = 0;
     ctx->n_hip_malloc = ctx->n_hip_free = ctx->n_host_malloc = ctx->n_host_free = ctx->n_cache_hits = 0;
     ctx->upload_stream = nullptr;
+    ctx->download_stream = nullptr;
     e = hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return set_hip_error("upload stream / event", e); }
     ctx->n_cu = prop.multiProcessorCount;
@@ -431,6 +432,7 @@ int mvosr_ctx_destroy(mvosr_ctx *ctx) {
     for (auto &kv : ctx->host_cache.live) { (void)hipEventDestroy(kv.second.ev); (void)hipHostFree(kv.first); }
     (void)hipEventDestroy(ctx->upload_ev);
     if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
+    if (ctx->download_stream) (void)hipStreamDestroy(ctx->download_stream);
     for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) if (ctx->prof_ev[i][j]) (void)hipEventDestroy(ctx->prof_ev[i][j]);
     for (int i = 0; i < 2; ++i) if (ctx->ws_dense[i]) (void)hipFree(ctx->ws_dense[i]);
     if (ctx->ws_ysel) (void)hipFree(ctx->ws_ysel);
@@ -596,6 +598,17 @@ int mvosr_memcpy_h2d_async(mvosr_ctx *ctx, void *dst, const void *src, size_t by
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(ensure_upload_stream(ctx));
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->upload_stream));
+    return MVOSR_OK;
+}
+
+int mvosr_memcpy_d2h_side(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return set_error(MVOSR_ERR_ARG, "memcpy_d2h_side: null argument");
+    if (!bytes) return MVOSR_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // (a stream of its own: on the upload stream the copy would wait behind the NEXT chunk's upload, 6 ms of PCIe, whenever that was queued first)
+    if (!ctx->download_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->download_stream, hipStreamNonBlocking));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->download_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->download_stream));
     return MVOSR_OK;
 }
 

@@ -192,8 +192,7 @@ class DeviceBatch:
         triangulation and the product kernels of the chunk are even launched (``early_status`` waits for this copy alone)."""
         ctx, F = self.ctx, max(self.n_frames, 1)
         self._early_stage = _lib.PinnedBuffer(ctx, 4 * F)
-        _lib.check(ctx.lib.mvosr_memcpy_d2h_async(ctx.handle, self._early_stage.ptr, self.bufs["dt1_status"].ptr, 4 * F), "d2h_async (early status)")
-        self._early_event = ctx.event()
+        self._early_event = ctx.event()                # (an event only: the copy is made when the status is asked for, on the upload stream)
         ctx.record(self._early_event)
 
     def early_status(self):
@@ -203,6 +202,7 @@ class DeviceBatch:
             return None
         ctx = self.ctx
         _lib.check(ctx.lib.mvosr_event_sync(ctx.handle, self._early_event), "event_sync")
+        _lib.check(ctx.lib.mvosr_memcpy_d2h_side(ctx.handle, stage.ptr, self.bufs["dt1_status"].ptr, 4 * max(self.n_frames, 1)), "d2h_side (early status)")
         s = np.array(stage.view(0, (max(self.n_frames, 1),), np.int32), copy=True)[:self.n_frames]
         stage.free(_lib.MARK_IDLE)
         ctx.lib.mvosr_event_destroy(ctx.handle, self._early_event)
@@ -285,6 +285,10 @@ class DeviceBatch:
 
     def prefetch_info(self):
         self.info.prefetch()
+
+    def mark_info_done(self):
+        """See DeviceBlock.mark_done: the statuses are fetched when they are read, behind an event, not by a copy parked on the stream."""
+        self.info.mark_done()
 
     def mark(self, marked=True):
         """See DeviceBlock.mark: call after the last launch of a chunk; engine launches on the batch withdraw it."""
@@ -408,6 +412,12 @@ class DeviceOutputs:
         """Queue the download of the per-frame results behind the launches so far (see DeviceBlock.prefetch)."""
         if self.block is not None:
             self.block.prefetch()
+            self.block.mark(True)
+
+    def mark_done(self):
+        """See DeviceBlock.mark_done (instead of ``prefetch`` for chunks of a streamed batch)."""
+        if self.block is not None:
+            self.block.mark_done()
             self.block.mark(True)
 
     def invalidate(self):

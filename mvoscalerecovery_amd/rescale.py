@@ -328,6 +328,7 @@ class ScaleEstimator:
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk
     GPU_RAMP_FRACTIONS = (1 / 6, 1 / 3, 1 / 2, 2 / 3, 5 / 6)   # the short first chunks, as fractions of a full one (scale_calculator.py)
     GPU_PIPELINE = 2            # chunks queued on the device behind the one being collected
+    GPU_SIDE_DOWNLOADS = True   # streamed batches: results copied when read, behind an event, on the upload stream (scale_calculator.ScaleEstimator.GPU_SIDE_DOWNLOADS)
     N_HYP = RANSAC_ITERATIONS
 
     def _rescale_params(self, frame_base):
@@ -363,7 +364,13 @@ class ScaleEstimator:
                                                    d_tr["id_triples"].ptr if d_tr is not None else None,
                                                    d_ids["frame_ids"].ptr if d_ids is not None else None, dt2_ptr,
                                                    C.byref(o), int(max_tri)), "mvosr_flat_ransac_batch")
-        out.prefetch()
+        # (the results are copied when they are read, behind an event, on the upload stream: a download queued here would park a copy engine
+        # behind this chunk's kernels, and an upload of the next chunk that lands on that engine waits with it — DeviceBlock.mark_done; the
+        # per-frame call with stage outputs keeps the queued download)
+        if stage or not self.GPU_SIDE_DOWNLOADS:
+            out.prefetch()
+        else:
+            out.mark_done()
         out.mark(True)
         for blk in side:
             blk.mark(True)
@@ -416,7 +423,10 @@ class ScaleEstimator:
         db.n_rows2 = 2 * pf.total_padded
         out, flags, side = self._launch_flat_ransac(db, keep.ptr, bufs["dt2_status"].ptr, frame_base, None, id_triples, stage,
                                                     2 * int(db.max_feat))
-        db.prefetch_info()
+        if stage or not self.GPU_SIDE_DOWNLOADS:
+            db.prefetch_info()
+        else:
+            db.mark_info_done()
         db.mark()
         return {"gpu": True, "pf": pf, "db": db, "out": out, "flags": flags, "side": side}
 
@@ -498,7 +508,7 @@ class ScaleEstimator:
         bs = db.struct()
         _lib.check(lib.mvosr_graph_keep_batch(ctx.handle, C.byref(bs), C.c_uint32(self._good_bits), MIN_VALID_FOR_RETRI, None,
                                               aux["keep"].ptr, None, None), "mvosr_graph_keep_batch")
-        aux.prefetch()
+        aux.mark_done()
         rec.update(db=db, aux=aux, step=1)
 
     def _host_tri2_start(self, rec, slot=1, background=False):

@@ -467,7 +467,7 @@ class ScaleEstimator:
         if tri2s is None:
             vote_out = DeviceOutputs(ctx, st["dbatch"], counts=True, stage=True)
             eng.outlier_vote_batch(st["dbatch"], vote_out)
-            vote_out.prefetch()
+            vote_out.mark_done()
             st["vote_out"] = vote_out
         else:
             if any(p is not None for p in (pf.extra.get("perm") or [])):
@@ -502,7 +502,7 @@ class ScaleEstimator:
         st["dbatch"].set_tri2(pf)
         out = DeviceOutputs(ctx, st["dbatch"], counts=True, stage=stage)
         eng.scale_batch(st["dbatch"], out)
-        out.prefetch()
+        out.mark_done()
         st["out"] = out
 
     def _chunk_scale_finish(self, st, stage, keep=False):
@@ -719,8 +719,13 @@ class ScaleEstimator:
             # (64 us per call).  Used when the frame turns out to be an ordinary one (_push decides).
             eng.window_median(out.bufs["raw_scale"].ptr, 1, self.window_size, list(self.scale_queue), out.bufs["filtered"].ptr)
             st["filtered_queue"] = list(self.scale_queue)
-        out.prefetch()
-        db.prefetch_info()
+        if stage or not self.GPU_SIDE_DOWNLOADS:
+            out.prefetch()
+            db.prefetch_info()
+        else:
+            # (streamed batches: no download parked on the stream behind the chunk's kernels — an event, and the copy when it is read)
+            out.mark_done()
+            db.mark_info_done()
         db.mark()                     # the chunk's last launch is queued: its blocks' next users need not wait for later chunks
         st["dbatch"], st["out"] = db, out
         return st
@@ -840,6 +845,8 @@ class ScaleEstimator:
         self._chunk_gpu_complete(pend)
         return res
 
+    GPU_SIDE_DOWNLOADS = True       # streamed batches: a chunk's results are copied when they are read, behind an event, on the upload stream — not by
+                                    # a copy parked on the compute stream behind the chunk's kernels (False: as before round 6's second half; LABNOTES 10.14)
     GPU_REDO_EARLY = True           # a deferred re-run's vote and second triangulation START while later chunks run (_advance_deferred) ...
     GPU_REDO_EARLY_MAX = 16         # ... for chunks with at most so many frames to redo (more: the one merged re-run at the call's end)
 
