@@ -978,3 +978,27 @@ def test_deferred_reruns_started_early_equal_the_merged_rerun(gpu, mode):
     assert outs[True][2] >= 3 and outs[True][3] >= 1 and outs[False][2] == 0, outs[True][2:]
     # the LAST chunk's declined frame: found behind the first triangulation's kernel, its SciPy call under the chunk's other kernels
     assert outs[True][4] == 1 and outs[False][4] == 0, (outs[True][4], outs[False][4])
+
+
+@pytest.mark.parametrize("mode", ["fixed", "reference"])
+def test_side_downloads_equal_queued_downloads(gpu, mode):
+    """Round 6: a streamed chunk's results are copied when they are read — behind an event, on a stream of their own
+    (``DeviceBlock.mark_done``, ``mvosr_memcpy_d2h_side``) — instead of by a download queued on the compute stream behind the chunk's
+    kernels (which parks a copy engine, LABNOTES 10.14).  Same numbers either way, several chunks, a declined frame among them."""
+    from mvoscalerecovery_amd import synth
+    from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
+    frames = [synth.synth_frame(i, 200 + (i * 31) % 150, base_seed=777, upper_fraction=0.1) for i in range(700)]
+    a3, a2 = frames[300][0].copy(), frames[300][1].copy()
+    low = np.nonzero(a2[:, 1] > 200.0)[0]
+    a2[low[1]], a3[low[1]] = a2[low[0]], a3[low[0]]                      # a repeated site: declined, redone on the host
+    frames[300] = (a3, a2)
+    f3s, f2s = [f[0] for f in frames], [f[1] for f in frames]
+    got = {}
+    for side in (True, False):
+        est = ScaleEstimator(1.75, window_size=5, mutate_inputs=False, triangulation="gpu", check_triangle=mode, delaunay_workers=0)
+        est.GPU_SIDE_DOWNLOADS = side
+        est.GPU_CHUNK, est.GPU_RAMP, est.GPU_MIN_CHUNK, est.GPU_EXACT_CHUNK, est.GPU_EXACT_TWO_CONTEXTS = 128, False, 1, 128, False
+        s, d = est.scale_calculation_batch(f3s, f2s)
+        got[side] = (np.asarray(s), np.asarray(d), est.height_level, est.declined_total)
+    assert np.array_equal(got[True][0], got[False][0]) and np.array_equal(got[True][1], got[False][1])
+    assert got[True][2] == got[False][2] and got[True][3] == got[False][3] >= 1
