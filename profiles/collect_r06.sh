@@ -71,4 +71,7 @@ for F in 16384 32768; do
   grep "frames/s" $OUT/r06_e2e_exact_$F.log >> $OUT/r06_e2e_exact_busy_$F.txt
   rm -f $OUT/r06_e2e_exact_$F/e2e_kernel_trace.csv
 done
+# the same-process A/B of the side downloads (LABNOTES 10.14): every e2e path, two shapes
+: > $OUT/r06_side_downloads_ab.txt
+for a in "exact 16384 2000" "exact 16384 300:1500" "fixed 32768 2000" "fixed 32768 300:1500" "rescale 32768 2000" "rescale 32768 300:1500"; do timeout 300 python profiles/side_downloads_ab.py $a 5 >> $OUT/r06_side_downloads_ab.txt 2>&1; done
 ls $OUT | grep r06_

@@ -3,7 +3,7 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd $R
 for f in r06_bench.json r06_bench_kitti.json r06_bench_dense.json r06_bench_gridded.json r06_bench_gridded_0005.json r06_bench_grid16.json r06_bench_grid16_before.json r06_bench_share2.json r06_bench_share2_c4.json r06_delaunay_bench.jsonl \
-         r06_qhull_check.txt r06_latency_probe.txt r06_soak_single_exact.txt r06_gputest_count.txt r06_e2e_exact_busy_16384.txt r06_e2e_exact_busy_32768.txt; do
+         r06_qhull_check.txt r06_latency_probe.txt r06_soak_single_exact.txt r06_gputest_count.txt r06_e2e_exact_busy_16384.txt r06_e2e_exact_busy_32768.txt r06_side_downloads_ab.txt; do
   [ -f gpurun_out/$f ] && cp gpurun_out/$f profiles/$f
 done
 cp gpurun_out/r06_e2e_exact_16384/e2e_kernel_stats.csv profiles/r06_e2e_exact_kernel_stats.csv 2>/dev/null
