@@ -295,10 +295,12 @@ int mvosr_memcpy_d2h(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes); 
 int mvosr_memcpy_h2d_async(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);
 int mvosr_upload_fence(mvosr_ctx *ctx);
 int mvosr_memcpy_d2h_async(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);
-/* Device -> host on a stream of the context's own that carries nothing else, waited for: for results whose producing work the caller has
- * already waited for (an event recorded behind it).  A copy queued on the compute stream behind long kernels parks a copy engine until
- * they finish, and an upload of ANOTHER stream that lands on that engine waits with it. */
-int mvosr_memcpy_d2h_side(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* Device -> PAGE-LOCKED host memory (mvosr_host_alloc) by a KERNEL on the context's compute stream, asynchronous: no copy engine is
+ * involved.  For the results of a streamed chunk: a hipMemcpyAsync queued on the compute stream behind long kernels parks the SDMA engine
+ * HIP assigns it until those kernels end, and an upload of ANOTHER stream that lands on that engine waits with it (whether it does is
+ * decided per process); a copy issued after the kernels, on any stream, waits the other way round behind an upload in flight.  Record
+ * an event behind this call and wait for it (mvosr_event_sync / _query) before reading `dst`. */
+int mvosr_memcpy_d2h_kernel(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes);
 int mvosr_memset(mvosr_ctx *ctx, void *dst, int value, size_t bytes);
 int mvosr_event_create(mvosr_ctx *ctx, void **event);
 int mvosr_event_record(mvosr_ctx *ctx, void *event);          /* on the context's current stream */

@@ -108,7 +108,7 @@ SYMBOLS = {
     "mvosr_memcpy_d2h_async": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "mvosr_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "mvosr_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
-    "mvosr_memcpy_d2h_side": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "mvosr_memcpy_d2h_kernel": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "mvosr_memset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),
     "mvosr_event_create": (C.c_int, [_P, C.POINTER(_P)]),
     "mvosr_event_record": (C.c_int, [_P, _P]),
@@ -184,7 +184,7 @@ def load():
         raise MvosrLibraryError(
             "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C mvoscalerecovery_amd/csrc`). There is no CPU fallback." % LIB_PATH)
-    # A context owns a compute, an upload and (streamed batches) a download stream, the exact device path runs two contexts and a third for re-runs, a host application (torch) has streams of
+    # A context owns a compute and an upload stream, the exact device path runs two contexts and a third for re-runs, a host application (torch) has streams of
     # its own: beyond ROCm's default of four hardware queues per process streams SHARE a queue and stop overlapping (measured: the
     # exact path's two contexts 78 k instead of 94 k frames/s inside bench.py).  The variable that lifts the limit is the HOST
     # APPLICATION's (it is read when the HIP runtime initialises and is inherited by child processes): this binding sets it only when
@@ -451,26 +451,27 @@ class DeviceBlock:
         return self
 
     def mark_done(self):
-        """Instead of ``prefetch``: only an EVENT behind the work launched so far.  The first ``read`` waits for it and then copies the
-        block on a stream of its own (mvosr_memcpy_d2h_side).  A download queued on the compute stream behind long kernels
-        parks a copy engine until they finish — and an upload of another stream that HIP puts on the same engine waits with it: the
-        reference-exact batch call ran at 98 k or 118 k frames/s by box for exactly that (LABNOTES 10.14)."""
+        """Like ``prefetch`` — the block on its way to a page-locked image behind the work launched so far, an event behind the copy —
+        but the copy is made by a KERNEL (mvosr_memcpy_d2h_kernel), not by a copy engine.  For the chunks of a streamed batch: a
+        ``hipMemcpyAsync`` queued behind long kernels parks the SDMA engine HIP assigns it until they finish, and an upload of another
+        stream that lands on the same engine waits with it — the reference-exact batch call ran at 95 or 118 k frames/s by process for
+        exactly that (LABNOTES 10.14); a copy issued AFTER the kernels waits the other way round, behind an upload in flight."""
         ctx = self.ctx
         if self.nbytes > self.STAGE_LIMIT:
             return self
         self.invalidate()
+        self._pf_stage = PinnedBuffer(ctx, self.nbytes)
+        check(ctx.lib.mvosr_memcpy_d2h_kernel(ctx.handle, self._pf_stage.ptr, self.ptr, self.nbytes), "d2h_kernel")
         if getattr(self, "_pf_event", None) is None:
             self._pf_event = ctx.event()
         ctx.record(self._pf_event)
-        self._done_marked = True
         return self
 
     def ready(self):
-        """True when a ``read`` would not wait (long): the block's host copy exists, the download queued by ``prefetch`` has finished, or
-        the work ``mark_done`` put its event behind has."""
+        """True when a ``read`` would not wait: the block's host copy exists, or the download queued by ``prefetch`` / ``mark_done`` has finished."""
         if self._mirror is not None:
             return True
-        if getattr(self, "_pf_stage", None) is None and not getattr(self, "_done_marked", False):
+        if getattr(self, "_pf_stage", None) is None:
             return False
         done = C.c_int(0)
         check(self.ctx.lib.mvosr_event_query(self.ctx.handle, self._pf_event, C.byref(done)), "event_query")
@@ -478,7 +479,6 @@ class DeviceBlock:
 
     def invalidate(self):
         self._mirror = None
-        self._done_marked = False
         if getattr(self, "_pf_stage", None) is not None:
             self._pf_stage.free()
             self._pf_stage = None
@@ -491,13 +491,6 @@ class DeviceBlock:
             out = np.empty(view.shape, dtype=view.dtype)
             check(ctx.lib.mvosr_memcpy_d2h(ctx.handle, addr(out), view.ptr, view.nbytes), "d2h")
             return out
-        if self._mirror is None and getattr(self, "_done_marked", False):
-            check(ctx.lib.mvosr_event_sync(ctx.handle, self._pf_event), "event_sync")
-            stage = PinnedBuffer(ctx, self.nbytes)
-            check(ctx.lib.mvosr_memcpy_d2h_side(ctx.handle, stage.ptr, self.ptr, self.nbytes), "d2h_side")
-            self._mirror = np.array(stage.view(0, (self.nbytes,), np.uint8), copy=True)
-            stage.free(MARK_IDLE)
-            self._done_marked = False
         if self._mirror is None and getattr(self, "_pf_stage", None) is not None:
             check(ctx.lib.mvosr_event_sync(ctx.handle, self._pf_event), "event_sync")
             self._mirror = np.array(self._pf_stage.view(0, (self.nbytes,), np.uint8), copy=True)

@@ -406,7 +406,6 @@ int mvosr_ctx_create(int device, mvosr_ctx **out) {
     ctx->ws_ysel = nullptr; ctx->ws_ysel_len = 0; ctx->ws_nsel = nullptr; ctx->ws_nsel_len = 0;
     ctx->n_hip_malloc = ctx->n_hip_free = ctx->n_host_malloc = ctx->n_host_free = ctx->n_cache_hits = 0;
     ctx->upload_stream = nullptr;
-    ctx->download_stream = nullptr;
     e = hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return set_hip_error("upload stream / event", e); }
     ctx->n_cu = prop.multiProcessorCount;
@@ -432,7 +431,6 @@ int mvosr_ctx_destroy(mvosr_ctx *ctx) {
     for (auto &kv : ctx->host_cache.live) { (void)hipEventDestroy(kv.second.ev); (void)hipHostFree(kv.first); }
     (void)hipEventDestroy(ctx->upload_ev);
     if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
-    if (ctx->download_stream) (void)hipStreamDestroy(ctx->download_stream);
     for (int i = 0; i < kProfRing; ++i) for (int j = 0; j < 3; ++j) if (ctx->prof_ev[i][j]) (void)hipEventDestroy(ctx->prof_ev[i][j]);
     for (int i = 0; i < 2; ++i) if (ctx->ws_dense[i]) (void)hipFree(ctx->ws_dense[i]);
     if (ctx->ws_ysel) (void)hipFree(ctx->ws_ysel);
@@ -601,14 +599,27 @@ int mvosr_memcpy_h2d_async(mvosr_ctx *ctx, void *dst, const void *src, size_t by
     return MVOSR_OK;
 }
 
-int mvosr_memcpy_d2h_side(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes) {
-    if (!ctx || (bytes && (!dst || !src))) return set_error(MVOSR_ERR_ARG, "memcpy_d2h_side: null argument");
+// device memory -> page-locked host memory by the shader cores (no SDMA engine): 16 bytes per thread and trip where both ends allow it
+__global__ void copy_to_host_kernel(unsigned char *dst, const unsigned char *src, size_t bytes) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0) {
+        const size_t n16 = bytes >> 4;
+        for (size_t i = tid; i < n16; i += nthr) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+        for (size_t i = (n16 << 4) + tid; i < bytes; i += nthr) dst[i] = src[i];
+    } else {
+        for (size_t i = tid; i < bytes; i += nthr) dst[i] = src[i];
+    }
+}
+
+int mvosr_memcpy_d2h_kernel(mvosr_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return set_error(MVOSR_ERR_ARG, "memcpy_d2h_kernel: null argument");
     if (!bytes) return MVOSR_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    // (a stream of its own: on the upload stream the copy would wait behind the NEXT chunk's upload, 6 ms of PCIe, whenever that was queued first)
-    if (!ctx->download_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->download_stream, hipStreamNonBlocking));
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->download_stream));
-    HIP_TRY(hipStreamSynchronize(ctx->download_stream));
+    const size_t per_block = 256 * 16;
+    const unsigned blocks = (unsigned)std::min<size_t>(256, (bytes + per_block - 1) / per_block);
+    hipLaunchKernelGGL(copy_to_host_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<unsigned char *>(dst),
+                       reinterpret_cast<const unsigned char *>(src), bytes);
+    HIP_TRY(hipGetLastError());
     return MVOSR_OK;
 }
 

@@ -55,7 +55,6 @@ struct mvosr_ctx {
     // host <-> device plumbing: a second stream for uploads (so that the next chunk's inputs travel under the current
     // chunk's kernels), the caching allocators, and their counters (mvosr_ctx_alloc_stats)
     hipStream_t upload_stream;
-    hipStream_t download_stream;    // device -> host copies of results the host has waited for (mvosr_memcpy_d2h_side): created on first use
     hipEvent_t upload_ev;
     mvosr_block_cache dev_cache, host_cache;
     int64_t n_hip_malloc, n_hip_free, n_host_malloc, n_host_free, n_cache_hits;

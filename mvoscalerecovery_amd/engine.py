@@ -192,7 +192,8 @@ class DeviceBatch:
         triangulation and the product kernels of the chunk are even launched (``early_status`` waits for this copy alone)."""
         ctx, F = self.ctx, max(self.n_frames, 1)
         self._early_stage = _lib.PinnedBuffer(ctx, 4 * F)
-        self._early_event = ctx.event()                # (an event only: the copy is made when the status is asked for, on the upload stream)
+        _lib.check(ctx.lib.mvosr_memcpy_d2h_kernel(ctx.handle, self._early_stage.ptr, self.bufs["dt1_status"].ptr, 4 * F), "d2h_kernel (early status)")
+        self._early_event = ctx.event()                # (a copy by a kernel, not by a copy engine: DeviceBlock.mark_done)
         ctx.record(self._early_event)
 
     def early_status(self):
@@ -202,7 +203,6 @@ class DeviceBatch:
             return None
         ctx = self.ctx
         _lib.check(ctx.lib.mvosr_event_sync(ctx.handle, self._early_event), "event_sync")
-        _lib.check(ctx.lib.mvosr_memcpy_d2h_side(ctx.handle, stage.ptr, self.bufs["dt1_status"].ptr, 4 * max(self.n_frames, 1)), "d2h_side (early status)")
         s = np.array(stage.view(0, (max(self.n_frames, 1),), np.int32), copy=True)[:self.n_frames]
         stage.free(_lib.MARK_IDLE)
         ctx.lib.mvosr_event_destroy(ctx.handle, self._early_event)

@@ -328,7 +328,7 @@ class ScaleEstimator:
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk
     GPU_RAMP_FRACTIONS = (1 / 6, 1 / 3, 1 / 2, 2 / 3, 5 / 6)   # the short first chunks, as fractions of a full one (scale_calculator.py)
     GPU_PIPELINE = 2            # chunks queued on the device behind the one being collected
-    GPU_SIDE_DOWNLOADS = True   # streamed batches: results copied when read, behind an event, on the upload stream (scale_calculator.ScaleEstimator.GPU_SIDE_DOWNLOADS)
+    GPU_SIDE_DOWNLOADS = os.environ.get("MVOSR_SIDE_DOWNLOADS", "1") != "0"   # streamed batches: results copied when read, behind an event, on the upload stream (scale_calculator.ScaleEstimator.GPU_SIDE_DOWNLOADS)
     N_HYP = RANSAC_ITERATIONS
 
     def _rescale_params(self, frame_base):

@@ -845,7 +845,7 @@ class ScaleEstimator:
         self._chunk_gpu_complete(pend)
         return res
 
-    GPU_SIDE_DOWNLOADS = True       # streamed batches: a chunk's results are copied when they are read, behind an event, on the upload stream — not by
+    GPU_SIDE_DOWNLOADS = os.environ.get("MVOSR_SIDE_DOWNLOADS", "1") != "0"       # streamed batches: a chunk's results are copied when they are read, behind an event, on the upload stream — not by
                                     # a copy parked on the compute stream behind the chunk's kernels (False: as before round 6's second half; LABNOTES 10.14)
     GPU_REDO_EARLY = True           # a deferred re-run's vote and second triangulation START while later chunks run (_advance_deferred) ...
     GPU_REDO_EARLY_MAX = 16         # ... for chunks with at most so many frames to redo (more: the one merged re-run at the call's end)

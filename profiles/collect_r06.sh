@@ -73,5 +73,5 @@ for F in 16384 32768; do
 done
 # the same-process A/B of the side downloads (LABNOTES 10.14): every e2e path, two shapes
 : > $OUT/r06_side_downloads_ab.txt
-for a in "exact 16384 2000" "exact 16384 300:1500" "fixed 32768 2000" "fixed 32768 300:1500" "rescale 32768 2000" "rescale 32768 300:1500"; do timeout 300 python profiles/side_downloads_ab.py $a 5 >> $OUT/r06_side_downloads_ab.txt 2>&1; done
+for a in "exact 16384 2000" "exact 16384 300:1500" "fixed 32768 2000" "fixed 32768 300:1500" "rescale 32768 2000" "rescale 32768 300:1500"; do timeout 300 python $R/profiles/side_downloads_ab.py $a 5 >> $OUT/r06_side_downloads_ab.txt 2>&1; done
 ls $OUT | grep r06_

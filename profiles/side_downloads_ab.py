@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Same-process A/B of GPU_SIDE_DOWNLOADS (results copied when read, behind an event, on the upload stream) against downloads queued on the
+"""Same-process A/B of GPU_SIDE_DOWNLOADS (results copied to page-locked memory by a kernel) against downloads queued by hipMemcpyAsync on the
 compute stream behind each chunk's kernels: one estimator per path, the knob flipped between calls.  LABNOTES 10.14.
     python profiles/side_downloads_ab.py [exact|fixed|rescale] [frames] [features | lo:hi] [pairs]"""
 import os, sys, time

@@ -982,9 +982,9 @@ def test_deferred_reruns_started_early_equal_the_merged_rerun(gpu, mode):
 
 @pytest.mark.parametrize("mode", ["fixed", "reference"])
 def test_side_downloads_equal_queued_downloads(gpu, mode):
-    """Round 6: a streamed chunk's results are copied when they are read — behind an event, on a stream of their own
-    (``DeviceBlock.mark_done``, ``mvosr_memcpy_d2h_side``) — instead of by a download queued on the compute stream behind the chunk's
-    kernels (which parks a copy engine, LABNOTES 10.14).  Same numbers either way, several chunks, a declined frame among them."""
+    """Round 6: a streamed chunk's results reach the host through a copy KERNEL into page-locked memory (``DeviceBlock.mark_done``,
+    ``mvosr_memcpy_d2h_kernel``) instead of a download queued on the compute stream behind the chunk's kernels (which parks a copy
+    engine, LABNOTES 10.14).  Same numbers either way, several chunks, a declined frame among them."""
     from mvoscalerecovery_amd import synth
     from mvoscalerecovery_amd.scale_calculator import ScaleEstimator
     frames = [synth.synth_frame(i, 200 + (i * 31) % 150, base_seed=777, upper_fraction=0.1) for i in range(700)]
