@@ -1088,7 +1088,10 @@ class ScaleEstimator:
             # GPU_PIPELINE chunks stay queued behind the one whose results are collected: this process packs and uploads
             # the next chunk meanwhile (the kernel timeline shows the GPU 98 % busy between a call's first and last chunk
             # with one: what a call pays beyond its kernels is its first chunk's pack + upload and the host's epilogue)
-            while len(queue) > self.GPU_PIPELINE:
+            while len(queue) > self.GPU_PIPELINE + (1 if len(engines) == 2 else 0):
+                # (two contexts taking the chunks in turn: one more chunk in flight — each context then has its next chunk queued behind
+                # the one it is working on: 65 536 frames 116.3-117.0 -> 119.7-120.3 k frames/s, 16 384 frames unchanged:
+                # profiles/r06_exact_shape_sweep.txt)
                 ps, pa, pb = queue.pop(0)
                 self._chunk_states.append((ps, pa, pb))
                 results.append(self._chunk_gpu_finish(ps, feature3ds[pa:pb], feature2ds[pa:pb], defer=deferred))
