@@ -328,7 +328,7 @@ class ScaleEstimator:
     GPU_CHUNK_POINTS = 10000000 # ... and features per chunk
     GPU_RAMP_FRACTIONS = (1 / 6, 1 / 3, 1 / 2, 2 / 3, 5 / 6)   # the short first chunks, as fractions of a full one (scale_calculator.py)
     GPU_PIPELINE = 2            # chunks queued on the device behind the one being collected
-    GPU_SIDE_DOWNLOADS = os.environ.get("MVOSR_SIDE_DOWNLOADS", "1") != "0"   # streamed batches: results copied when read, behind an event, on the upload stream (scale_calculator.ScaleEstimator.GPU_SIDE_DOWNLOADS)
+    GPU_SIDE_DOWNLOADS = os.environ.get("MVOSR_SIDE_DOWNLOADS", "1") != "0"   # streamed batches: results to page-locked memory by a copy kernel, no copy engine (scale_calculator.ScaleEstimator.GPU_SIDE_DOWNLOADS)
     N_HYP = RANSAC_ITERATIONS
 
     def _rescale_params(self, frame_base):
@@ -364,8 +364,8 @@ class ScaleEstimator:
                                                    d_tr["id_triples"].ptr if d_tr is not None else None,
                                                    d_ids["frame_ids"].ptr if d_ids is not None else None, dt2_ptr,
                                                    C.byref(o), int(max_tri)), "mvosr_flat_ransac_batch")
-        # (the results are copied when they are read, behind an event, on the upload stream: a download queued here would park a copy engine
-        # behind this chunk's kernels, and an upload of the next chunk that lands on that engine waits with it — DeviceBlock.mark_done; the
+        # (the results reach their page-locked image through a copy KERNEL: a hipMemcpyAsync queued here would park a copy engine behind
+        # this chunk's kernels, and an upload of the next chunk that lands on that engine waits with it — DeviceBlock.mark_done; the
         # per-frame call with stage outputs keeps the queued download)
         if stage or not self.GPU_SIDE_DOWNLOADS:
             out.prefetch()
@@ -647,8 +647,8 @@ class ScaleEstimator:
     GPU_REDO_EARLY_MAX = 16
 
     def _advance_deferred(self, deferred):
-        """Started re-runs one step further wherever that step would not wait (see the _host_* steps); everything is queued on the
-        estimator's one stream, behind the chunks launched so far — nothing here blocks, the results are simply there later."""
+        """Started re-runs one step further wherever that step would not wait (see the _host_* steps); their launches go to a context of
+        their own (_redo_context) — nothing here blocks."""
         for k, item in enumerate(deferred):
             rec = item[6]
             if rec is None:

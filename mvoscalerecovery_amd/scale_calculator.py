@@ -723,7 +723,7 @@ class ScaleEstimator:
             out.prefetch()
             db.prefetch_info()
         else:
-            # (streamed batches: no download parked on the stream behind the chunk's kernels — an event, and the copy when it is read)
+            # (streamed batches: no download parked on a copy engine behind the chunk's kernels — a copy kernel into page-locked memory)
             out.mark_done()
             db.mark_info_done()
         db.mark()                     # the chunk's last launch is queued: its blocks' next users need not wait for later chunks
@@ -845,8 +845,8 @@ class ScaleEstimator:
         self._chunk_gpu_complete(pend)
         return res
 
-    GPU_SIDE_DOWNLOADS = os.environ.get("MVOSR_SIDE_DOWNLOADS", "1") != "0"       # streamed batches: a chunk's results are copied when they are read, behind an event, on the upload stream — not by
-                                    # a copy parked on the compute stream behind the chunk's kernels (False: as before round 6's second half; LABNOTES 10.14)
+    GPU_SIDE_DOWNLOADS = os.environ.get("MVOSR_SIDE_DOWNLOADS", "1") != "0"       # streamed batches: a chunk's results reach page-locked memory through a copy KERNEL — not through a
+                                    # hipMemcpyAsync parked on a copy engine behind the chunk's kernels (False / MVOSR_SIDE_DOWNLOADS=0: as before round 6's second half; LABNOTES 10.14)
     GPU_REDO_EARLY = True           # a deferred re-run's vote and second triangulation START while later chunks run (_advance_deferred) ...
     GPU_REDO_EARLY_MAX = 16         # ... for chunks with at most so many frames to redo (more: the one merged re-run at the call's end)
 
