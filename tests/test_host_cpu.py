@@ -642,3 +642,19 @@ def test_delaunay_submit_background_single_set():
     assert h.ready()
     assert np.array_equal(h.get()[0], inline.get()[0]) and np.array_equal(h.get()[0], packing.delaunay_simplices(pts))
     assert packing.delaunay_submit([pts], 0, background=True).ready()      # (no pool: inline whatever the flag)
+
+
+def test_joined_delaunay_handle():
+    """packing._JoinedHandle: two submissions seen as one list in the caller's order (the last chunk's early-found declined frames and the
+    rest of its frames to redo: scale_calculator._chunk_gpu_finish)."""
+    from mvoscalerecovery_amd import packing, synth
+    sets = [synth.synth_frame(i, 120 + 40 * i, base_seed=5)[1] for i in range(5)]
+    a = packing.delaunay_submit([sets[3], sets[0]], 0)
+    b = packing.delaunay_submit([sets[1], sets[2], sets[4]], 0, canonical=False)
+    j = packing._JoinedHandle(5, [([3, 0], a), ([1, 2, 4], b)])
+    assert j.ready() and not j.canonical
+    rows = j.get()
+    for p, r in zip(sets, rows):
+        assert np.array_equal(r, packing.delaunay_simplices(p))
+    assert packing._JoinedHandle(2, [([0], packing.delaunay_submit([sets[0]], 0, canonical=True)),
+                                     ([1], packing.delaunay_submit([sets[1]], 0, canonical=True))]).canonical
