@@ -15,7 +15,8 @@ timeout 900 python bench.py --workload gridded --no-cpu-baseline > $OUT/r06_benc
 timeout 900 python bench.py --workload gridded --snap-fraction 0.005 --no-cpu-baseline > $OUT/r06_bench_gridded_0005.json 2> $OUT/r06_bench_gridded_0005.err
 # coordinates on a 1/16 px grid: collinear triples everywhere, few cocircular quadruples (the fast kernel declined two frames in three of these; r06_bench_grid16_before.json is that kernel on the same box, profiles/ab/libmvosr_dtold.so, when it is there)
 timeout 900 python bench.py --workload gridded --snap-grid 0.0625 --no-cpu-baseline > $OUT/r06_bench_grid16.json 2> $OUT/r06_bench_grid16.err
-[ -f profiles/ab/libmvosr_dtold.so ] && MVOSR_LIB_PATH=profiles/ab/libmvosr_dtold.so timeout 900 python bench.py --workload gridded --snap-grid 0.0625 --no-cpu-baseline > $OUT/r06_bench_grid16_before.json 2> /dev/null
+# (only while that library still has every symbol of the current ABI — it does not since mvosr_memcpy_d2h_kernel: the committed r06_bench_grid16_before.json is the run of the round's third collection)
+[ -f profiles/ab/libmvosr_dtold.so ] && MVOSR_LIB_PATH=profiles/ab/libmvosr_dtold.so timeout 900 python bench.py --workload gridded --snap-grid 0.0625 --no-cpu-baseline > $OUT/r06_bench_grid16_before.tmp 2> /dev/null && [ -s $OUT/r06_bench_grid16_before.tmp ] && mv $OUT/r06_bench_grid16_before.tmp $OUT/r06_bench_grid16_before.json
 # the N-rank paths as dry runs on this one GPU (gloo, the ranks share the device): a driver-side 8-GPU run then fails for hardware reasons only
 timeout 900 python bench.py --gpus 2 --share-gpu --frames 16384 --steps 5 --warmup 1 > $OUT/r06_bench_share2.json 2> $OUT/r06_bench_share2.err
 timeout 900 python bench.py --gpus 2 --share-gpu --c4 --total-frames 100000 --steps 5 --warmup 1 > $OUT/r06_bench_share2_c4.json 2> $OUT/r06_bench_share2_c4.err

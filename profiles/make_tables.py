@@ -23,7 +23,8 @@ def load_line(name):
     p = os.path.join(HERE, name)
     if not os.path.isfile(p):
         return None
-    return json.loads([ln for ln in open(p).read().splitlines() if ln.startswith("{")][-1])
+    lines = [ln for ln in open(p).read().splitlines() if ln.startswith("{")]
+    return json.loads(lines[-1]) if lines else None        # (an empty file: a run that produced no line)
 
 
 def k(x):
