@@ -4,8 +4,8 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; OUT=$R/gpurun_out
 export TMPDIR=/tmp MVOSR_DELAUNAY_WORKERS=0 GPU_MAX_HW_QUEUES=${HWQ:-8}
 cd /tmp
-python3 $R/profiles/exact_host_trace.py 16384 2000 2>&1
-python3 $R/profiles/exact_host_trace.py 16384 2000 2>&1
+SIDE=${SIDE:-1} python3 $R/profiles/exact_host_trace.py 16384 2000 2>&1
+SIDE=${SIDE:-1} python3 $R/profiles/exact_host_trace.py 16384 2000 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/boxprobe -o e2e -- python3 $R/profiles/e2e_gpu_profile.py 16384 2000 exact > $OUT/boxprobe.log 2>&1
 grep "frames/s" $OUT/boxprobe.log
 python3 $R/profiles/e2e_gpu_busy.py $OUT/boxprobe/e2e_kernel_trace.csv | head -16
